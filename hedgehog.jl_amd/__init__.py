@@ -1,0 +1,40 @@
+"""MI355X-native Monte Carlo engine behind Hedgehog.jl's `solve(problem, MonteCarlo(...))` API.
+
+Host mirror (Python) of the reference's operator interface for this path; the arithmetic runs in
+hand-written HIP kernels behind the C-ABI of include/hedgehog_mc.h (lib/libhedgehog_mc.so).
+Import as `hedgehog_jl_amd` (shim at the repository root; the directory name carries a dot).
+"""
+from . import _ffi
+from ._ffi import Context, HedgehogMCError, get_context, load_library
+from .dates import Date, DateTime, add_years, to_ticks, yearfrac
+from .dual import Dual
+from .greeks import (BatchGreekProblem, FDBackward, FDCentral, FDForward, FiniteDifference,
+                     ForwardAD, GreekProblem, GreekResult, PropertyLens, SpotLens, VolLens,
+                     ZeroRateSpineLens, optic, set)
+from .montecarlo import (AbstractPricingMethod, Antithetic, BlackScholesExact, EulerMaruyama,
+                         HestonBroadieKaya, HestonDynamics, LognormalDynamics, MethodError,
+                         MonteCarlo, NoVarianceReduction, SimulationConfig, solve_montecarlo)
+from .domain import (American, BlackScholesInputs, Call, European, FlatRateCurve, FlatVolSurface,
+                    Forward, HestonInputs, MonteCarloSolution, PricingProblem, Put, Spot,
+                    VanillaOption, df, get_vol, zero_rate)
+
+
+def solve(*args, **kw):
+    """The reference's single verb (src/Hedgehog.jl:59-98), for the methods on the hot path:
+
+        solve(prob::PricingProblem, method::MonteCarlo)                      montecarlo.jl:478
+        solve(gprob::GreekProblem, ::ForwardAD, method)                      greeks_problem.jl:249
+        solve(gprob::GreekProblem, ::FiniteDifference, method)               greeks_problem.jl:318
+        solve(gprob::BatchGreekProblem, ::GreekMethod, method)               greeks_problem.jl:559
+    """
+    from . import greeks as _g
+    if len(args) == 2 and isinstance(args[0], PricingProblem) and isinstance(args[1], MonteCarlo):
+        return solve_montecarlo(args[0], args[1], **kw)
+    if len(args) == 3 and isinstance(args[0], GreekProblem):
+        if isinstance(args[1], ForwardAD):
+            return _g.solve_greek_ad(args[0], args[2], solve)
+        if isinstance(args[1], FiniteDifference):
+            return _g.solve_greek_fd(args[0], args[1], args[2], solve)
+    if len(args) == 3 and isinstance(args[0], BatchGreekProblem):
+        return _g.solve_batch(args[0], args[1], args[2], solve)
+    raise MethodError("no method matching solve(" + ", ".join(type(a).__name__ for a in args) + ")")

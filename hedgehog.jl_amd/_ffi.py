@@ -1,0 +1,168 @@
+"""ctypes binding of libhedgehog_mc.so (include/hedgehog_mc.h).
+
+The product path has no CPU fallback: if the HIP library is missing or no HIP device is present,
+every compute call raises `HedgehogMCError`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HH_MAX_PARTIALS = 8
+HH_TILE_PATHS = 256
+HH_ACC_LEN = 16
+HH_ACC_SUM, HH_ACC_SUMSQ, HH_ACC_DSUM, HH_ACC_NPATHS = 0, 1, 2, 10
+
+HH_LOGNORMAL, HH_HESTON = 0, 1
+HH_EULER_MARUYAMA, HH_EXACT_LAW, HH_BROADIE_KAYA = 0, 1, 2
+HH_NOISE_GENERATE, HH_NOISE_REPLAY = 0, 1
+HH_REPLAY_TILE_MAJOR, HH_REPLAY_PATH_MAJOR = 0, 1
+
+HH_OK, HH_ERR_INVALID, HH_ERR_UNSUPPORTED, HH_ERR_HIP, HH_ERR_NOMEM = 0, -1, -2, -3, -4
+
+_dp = C.POINTER(C.c_double)
+
+
+class hh_model(C.Structure):
+    _fields_ = [(n, C.c_double) for n in
+                ("S0", "V0", "kappa", "theta", "sigma", "rho", "r_drift", "discount", "T", "strike",
+                 "cp")] + \
+               [(n, _dp) for n in
+                ("dS0", "dV0", "dkappa", "dtheta", "dsigma", "dr_drift", "ddiscount", "dstrike")]
+
+
+class hh_config(C.Structure):
+    _fields_ = [
+        ("dynamics", C.c_int32), ("strategy", C.c_int32), ("antithetic", C.c_int32),
+        ("em_split", C.c_int32), ("compat_sqrt_alpha", C.c_int32), ("noise_mode", C.c_int32),
+        ("replay_layout", C.c_int32), ("seeds_on_device", C.c_int32),
+        ("replay_on_device", C.c_int32), ("terminal_on_device", C.c_int32),
+        ("n_steps", C.c_uint32), ("n_partials", C.c_uint32),
+        ("n_paths", C.c_uint64), ("path_offset", C.c_uint64),
+        ("seeds", C.c_void_p), ("replay", C.c_void_p),
+        ("bk_n_sigma", C.c_double), ("bk_cf_tol", C.c_double), ("bk_atol", C.c_double),
+        ("bk_moment_h", C.c_double),
+        ("bk_newton_maxiter", C.c_int32), ("bk_bisect_maxiter", C.c_int32),
+    ]
+
+
+class hh_result(C.Structure):
+    _fields_ = [
+        ("price", C.c_double), ("std_error", C.c_double),
+        ("sum_payoff", C.c_double), ("sumsq_payoff", C.c_double),
+        ("dprice", C.c_double * HH_MAX_PARTIALS),
+        ("n_paths_done", C.c_uint64),
+        ("bk_newton_fail", C.c_uint64), ("bk_bisect_fallback", C.c_uint64),
+        ("bk_maxguess_fallback", C.c_uint64), ("bk_cf_terms", C.c_uint64),
+        ("kernel_ms", C.c_double), ("total_ms", C.c_double),
+    ]
+
+
+class HedgehogMCError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"hedgehog_mc error {code}: {msg}")
+        self.code = code
+
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libhedgehog_mc.so")
+
+# every symbol include/hedgehog_mc.h declares: (name, restype, argtypes)
+_vp = C.c_void_p
+SYMBOLS = [
+    ("hh_abi_version", C.c_int, []),
+    ("hh_ctx_create", C.c_int, [C.POINTER(_vp), C.c_int]),
+    ("hh_ctx_destroy", None, [_vp]),
+    ("hh_ctx_set_stream", C.c_int, [_vp, _vp]),
+    ("hh_last_error", C.c_char_p, [_vp]),
+    ("hh_mc_solve", C.c_int, [_vp, C.POINTER(hh_model), C.POINTER(hh_config), C.POINTER(hh_result), _vp]),
+    ("hh_mc_accumulate", C.c_int, [_vp, C.POINTER(hh_model), C.POINTER(hh_config), _vp, _vp]),
+    ("hh_mc_finalize", C.c_int, [C.POINTER(hh_model), C.POINTER(hh_config), _vp, C.POINTER(hh_result)]),
+    ("hh_replay_elems", C.c_size_t, [C.c_uint64, C.c_uint32, C.c_int32]),
+    ("hh_replay_pack", C.c_int, [_vp, C.c_int32, C.c_uint64, C.c_uint32, _vp, C.c_int32, _vp]),
+    ("hh_wiener_fill", C.c_int, [_vp, C.c_int32, C.c_double, C.c_double, C.c_uint32, C.c_uint64, _vp, C.c_int32, _vp]),
+    ("hh_device_malloc", C.c_int, [_vp, C.c_size_t, C.POINTER(_vp)]),
+    ("hh_device_free", C.c_int, [_vp, _vp]),
+    ("hh_memcpy_h2d", C.c_int, [_vp, _vp, _vp, C.c_size_t]),
+    ("hh_memcpy_d2h", C.c_int, [_vp, _vp, _vp, C.c_size_t]),
+    ("hh_ctx_synchronize", C.c_int, [_vp]),
+]
+
+_lib = None
+
+
+def load_library(path: str | None = None):
+    """Load the C-ABI library (once). Raises HedgehogMCError when it has not been built."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise HedgehogMCError(HH_ERR_HIP, f"{path} not found — build it with "
+                              "`python -c 'import __graft_entry__ as g; g.build()'`; "
+                              "there is no CPU fallback")
+    try:  # share PyTorch's HIP runtime (same libamdhip64 soname) when torch is the allocator
+        import torch  # noqa: F401
+    except Exception:  # pragma: no cover - torch is optional for the C-ABI itself
+        pass
+    lib = C.CDLL(path, mode=C.RTLD_GLOBAL)
+    for name, res, args in SYMBOLS:
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+class Context:
+    """Owns one hh_ctx (one device, one stream)."""
+
+    def __init__(self, device: int = 0, stream: int | None = None):
+        self.lib = load_library()
+        h = _vp()
+        rc = self.lib.hh_ctx_create(C.byref(h), int(device))
+        if rc != HH_OK:
+            raise HedgehogMCError(rc, f"hh_ctx_create(device={device}) failed — no HIP device? "
+                                  "(the product path has no CPU fallback)")
+        self.handle = h
+        self.device = int(device)
+        if stream is not None:
+            self.set_stream(stream)
+
+    def check(self, rc: int):
+        if rc != HH_OK:
+            raise HedgehogMCError(rc, self.lib.hh_last_error(self.handle).decode(errors="replace"))
+
+    def set_stream(self, stream: int | None):
+        self.check(self.lib.hh_ctx_set_stream(self.handle, _vp(stream or 0)))
+
+    def synchronize(self):
+        self.check(self.lib.hh_ctx_synchronize(self.handle))
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.hh_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_contexts: dict[int, Context] = {}
+
+
+def get_context(device: int = 0) -> Context:
+    ctx = _contexts.get(device)
+    if ctx is None:
+        ctx = _contexts[device] = Context(device)
+    return ctx
+
+
+def seed_array(values, n: int):
+    """P-long seed vector -> ctypes double array (or NULL when all zero)."""
+    if values is None or not any(values):
+        return None
+    arr = (C.c_double * n)(*[float(v) for v in values])
+    return arr

@@ -1,0 +1,388 @@
+// C-ABI of libhedgehog_mc.so (include/hedgehog_mc.h): context, argument checking, staging of
+// caller buffers, kernel sequencing.  No arithmetic of the pricing path happens on the host except
+// hh_mc_finalize's discount·mean (montecarlo.jl:489-490) on the reduced accumulator vector.
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "hh_kernels.h"
+
+struct hh_ctx {
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  double* records = nullptr;
+  size_t records_cap = 0;  // in records
+  uint64_t* seeds = nullptr;
+  size_t seeds_cap = 0;  // in elements
+  double* replay = nullptr;  // tile-major staging
+  size_t replay_cap = 0;
+  double* replay_src = nullptr;  // path-major staging
+  size_t replay_src_cap = 0;
+  double* terminal = nullptr;
+  size_t terminal_cap = 0;
+  double* accum = nullptr;       // device, HH_ACC_LEN
+  double* accum_host = nullptr;  // pinned, HH_ACC_LEN
+  char err[512] = {0};
+};
+
+namespace {
+
+const char* kNoCtx = "hedgehog_mc: no context";
+
+int fail(hh_ctx* ctx, int code, const char* fmt, ...) {
+  if (ctx) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(ctx->err, sizeof(ctx->err), fmt, ap);
+    va_end(ap);
+  }
+  return code;
+}
+
+#define HH_HIP(ctx, expr)                                                                   \
+  do {                                                                                      \
+    hipError_t e__ = (hipError_t)(expr);                                                    \
+    if (e__ != hipSuccess)                                                                  \
+      return fail(ctx, HH_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__),  \
+                  __FILE__, __LINE__);                                                      \
+  } while (0)
+
+template <class T>
+int ensure(hh_ctx* ctx, T*& buf, size_t& cap, size_t need) {
+  if (need <= cap) return HH_OK;
+  if (buf) HH_HIP(ctx, hipFree(buf));
+  buf = nullptr;
+  cap = 0;
+  hipError_t e = hipMalloc((void**)&buf, need * sizeof(T));
+  if (e != hipSuccess)
+    return fail(ctx, HH_ERR_NOMEM, "hipMalloc(%zu bytes) failed: %s", need * sizeof(T),
+                hipGetErrorString(e));
+  cap = need;
+  return HH_OK;
+}
+
+int ncomp_of(int dynamics) { return dynamics == HH_HESTON ? 2 : 1; }
+
+int validate(hh_ctx* ctx, const hh_model* m, const hh_config* c) {
+  if (!m || !c) return fail(ctx, HH_ERR_INVALID, "model/config is NULL");
+  if (c->n_paths == 0) return fail(ctx, HH_ERR_INVALID, "n_paths must be >= 1");
+  if (c->n_paths > (1ull << 40)) return fail(ctx, HH_ERR_INVALID, "n_paths too large");
+  if (c->n_partials > HH_MAX_PARTIALS)
+    return fail(ctx, HH_ERR_INVALID, "n_partials %u > HH_MAX_PARTIALS", c->n_partials);
+  const bool logn = c->dynamics == HH_LOGNORMAL, hest = c->dynamics == HH_HESTON;
+  if (!logn && !hest) return fail(ctx, HH_ERR_INVALID, "unknown dynamics %d", c->dynamics);
+  // the (dynamics, strategy) pairs that have a sde_problem / marginal_law method in the reference
+  // (montecarlo.jl:140-231, 293-320); anything else is a MethodError there
+  const bool ok = (logn && (c->strategy == HH_EULER_MARUYAMA || c->strategy == HH_EXACT_LAW)) ||
+                  (hest && (c->strategy == HH_EULER_MARUYAMA || c->strategy == HH_BROADIE_KAYA));
+  if (!ok)
+    return fail(ctx, HH_ERR_UNSUPPORTED, "no simulation method for dynamics %d with strategy %d",
+                c->dynamics, c->strategy);
+  if (!(m->S0 > 0.0) || !std::isfinite(m->S0)) return fail(ctx, HH_ERR_INVALID, "S0 must be > 0");
+  if (!(m->T > 0.0) || !std::isfinite(m->T)) return fail(ctx, HH_ERR_INVALID, "T must be > 0");
+  if (m->cp != 1.0 && m->cp != -1.0) return fail(ctx, HH_ERR_INVALID, "cp must be +1 or -1");
+  if (hest && !(std::fabs(m->rho) <= 1.0)) return fail(ctx, HH_ERR_INVALID, "|rho| must be <= 1");
+  if (c->strategy == HH_EULER_MARUYAMA && c->n_steps == 0)
+    return fail(ctx, HH_ERR_INVALID, "n_steps must be >= 1 for EulerMaruyama");
+  if (c->strategy == HH_BROADIE_KAYA) {
+    // final_sample(law, sample, ::Antithetic) needs mean(law), which LogHestonDistribution does
+    // not define (montecarlo.jl:387); dual numbers do not pass rand! (heston.jl:261-276)
+    if (c->antithetic)
+      return fail(ctx, HH_ERR_UNSUPPORTED, "HestonBroadieKaya has no antithetic form");
+    if (c->n_partials)
+      return fail(ctx, HH_ERR_UNSUPPORTED, "HestonBroadieKaya does not carry dual partials");
+    if (c->noise_mode != HH_NOISE_GENERATE)
+      return fail(ctx, HH_ERR_UNSUPPORTED, "HestonBroadieKaya has no REPLAY mode");
+    if (m->sigma == 0.0 || m->kappa == 0.0 || !(m->V0 > 0.0))
+      return fail(ctx, HH_ERR_INVALID, "HestonBroadieKaya needs sigma != 0, kappa != 0, V0 > 0");
+  }
+  if (c->noise_mode == HH_NOISE_REPLAY) {
+    if (!c->replay) return fail(ctx, HH_ERR_INVALID, "REPLAY needs a replay buffer");
+    if (((uintptr_t)c->replay & 15u) != 0)
+      return fail(ctx, HH_ERR_INVALID, "replay buffer must be 16-byte aligned");
+  } else if (c->noise_mode == HH_NOISE_GENERATE) {
+    if (!c->seeds) return fail(ctx, HH_ERR_INVALID, "GENERATE needs seeds");
+  } else {
+    return fail(ctx, HH_ERR_INVALID, "unknown noise_mode %d", c->noise_mode);
+  }
+  return HH_OK;
+}
+
+size_t replay_elems(uint64_t n_paths, uint32_t n_steps, int dynamics) {
+  return (size_t)hh::tiles_for(n_paths) * n_steps * ncomp_of(dynamics) * hh::kTile;
+}
+
+}  // namespace
+
+extern "C" {
+
+int hh_abi_version(void) { return HH_ABI_VERSION; }
+
+int hh_ctx_create(hh_ctx** out, int device_id) {
+  if (!out) return HH_ERR_INVALID;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return HH_ERR_HIP;  // no CPU fallback
+  if (device_id < 0 || device_id >= n) return HH_ERR_INVALID;
+  hh_ctx* ctx = new (std::nothrow) hh_ctx();
+  if (!ctx) return HH_ERR_NOMEM;
+  ctx->device = device_id;
+  if (hipSetDevice(device_id) != hipSuccess ||
+      hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
+      hipMalloc((void**)&ctx->accum, HH_ACC_LEN * sizeof(double)) != hipSuccess ||
+      hipHostMalloc((void**)&ctx->accum_host, HH_ACC_LEN * sizeof(double), hipHostMallocDefault) !=
+          hipSuccess) {
+    hh_ctx_destroy(ctx);
+    return HH_ERR_HIP;
+  }
+  ctx->stream = ctx->own_stream;
+  *out = ctx;
+  return HH_OK;
+}
+
+void hh_ctx_destroy(hh_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->records) (void)hipFree(ctx->records);
+  if (ctx->seeds) (void)hipFree(ctx->seeds);
+  if (ctx->replay) (void)hipFree(ctx->replay);
+  if (ctx->replay_src) (void)hipFree(ctx->replay_src);
+  if (ctx->terminal) (void)hipFree(ctx->terminal);
+  if (ctx->accum) (void)hipFree(ctx->accum);
+  if (ctx->accum_host) (void)hipHostFree(ctx->accum_host);
+  if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+  if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+  if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+  delete ctx;
+}
+
+int hh_ctx_set_stream(hh_ctx* ctx, void* hip_stream) {
+  if (!ctx) return HH_ERR_INVALID;
+  ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+  return HH_OK;
+}
+
+const char* hh_last_error(const hh_ctx* ctx) { return ctx ? ctx->err : kNoCtx; }
+
+int hh_ctx_synchronize(hh_ctx* ctx) {
+  if (!ctx) return HH_ERR_INVALID;
+  HH_HIP(ctx, hipSetDevice(ctx->device));
+  HH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return HH_OK;
+}
+
+size_t hh_replay_elems(uint64_t n_paths, uint32_t n_steps, int32_t dynamics) {
+  return replay_elems(n_paths, n_steps, dynamics);
+}
+
+int hh_replay_pack(hh_ctx* ctx, int32_t dynamics, uint64_t n_paths, uint32_t n_steps,
+                   const double* src, int32_t src_on_device, double* dst) {
+  if (!ctx) return HH_ERR_INVALID;
+  if (!src || !dst || n_paths == 0 || n_steps == 0)
+    return fail(ctx, HH_ERR_INVALID, "hh_replay_pack: bad arguments");
+  HH_HIP(ctx, hipSetDevice(ctx->device));
+  const int nc = ncomp_of(dynamics);
+  const double* src_dev = src;
+  if (!src_on_device) {
+    const size_t n = (size_t)n_paths * n_steps * nc;
+    int rc = ensure(ctx, ctx->replay_src, ctx->replay_src_cap, n);
+    if (rc) return rc;
+    HH_HIP(ctx, hipMemcpyAsync(ctx->replay_src, src, n * sizeof(double), hipMemcpyHostToDevice,
+                               ctx->stream));
+    src_dev = ctx->replay_src;
+  }
+  HH_HIP(ctx, hh::launch_replay_pack(nc, n_paths, n_steps, src_dev, dst, ctx->stream));
+  return HH_OK;
+}
+
+int hh_wiener_fill(hh_ctx* ctx, int32_t dynamics, double rho, double T, uint32_t n_steps,
+                   uint64_t n_paths, const uint64_t* seeds, int32_t seeds_on_device, double* dst) {
+  if (!ctx) return HH_ERR_INVALID;
+  if (!seeds || !dst || n_paths == 0 || n_steps == 0 || !(T > 0.0) || !(std::fabs(rho) <= 1.0))
+    return fail(ctx, HH_ERR_INVALID, "hh_wiener_fill: bad arguments");
+  HH_HIP(ctx, hipSetDevice(ctx->device));
+  const uint64_t* seeds_dev = seeds;
+  if (!seeds_on_device) {
+    int rc = ensure(ctx, ctx->seeds, ctx->seeds_cap, (size_t)n_paths);
+    if (rc) return rc;
+    HH_HIP(ctx, hipMemcpyAsync(ctx->seeds, seeds, n_paths * sizeof(uint64_t),
+                               hipMemcpyHostToDevice, ctx->stream));
+    seeds_dev = ctx->seeds;
+  }
+  const double dt = T / (double)n_steps;
+  HH_HIP(ctx, hh::launch_wiener_fill(dynamics, rho, std::sqrt(dt), n_steps, n_paths, seeds_dev, dst,
+                                     ctx->stream));
+  return HH_OK;
+}
+
+int hh_mc_accumulate(hh_ctx* ctx, const hh_model* m, const hh_config* c, double* accum_dev,
+                     double* terminal) {
+  if (!ctx) return HH_ERR_INVALID;
+  int rc = validate(ctx, m, c);
+  if (rc) return rc;
+  if (!accum_dev) return fail(ctx, HH_ERR_INVALID, "accum_dev is NULL");
+  HH_HIP(ctx, hipSetDevice(ctx->device));
+
+  const uint32_t n_tiles = hh::tiles_for(c->n_paths);
+  rc = ensure(ctx, ctx->records, ctx->records_cap, (size_t)n_tiles * hh::kRecStride);
+  if (rc) return rc;
+
+  hh::DevicePtrs p{};
+  p.records = ctx->records;
+
+  // seeds: per-trajectory for Euler (montecarlo.jl:331), seeds[1] only for the exact laws (:456)
+  if (c->noise_mode == HH_NOISE_GENERATE) {
+    const size_t need = (c->strategy == HH_EULER_MARUYAMA) ? (size_t)c->n_paths : 1;
+    if (c->seeds_on_device) {
+      p.seeds = c->seeds;
+    } else {
+      rc = ensure(ctx, ctx->seeds, ctx->seeds_cap, need);
+      if (rc) return rc;
+      HH_HIP(ctx, hipMemcpyAsync(ctx->seeds, c->seeds, need * sizeof(uint64_t),
+                                 hipMemcpyHostToDevice, ctx->stream));
+      p.seeds = ctx->seeds;
+    }
+  } else {
+    const uint32_t steps = (c->strategy == HH_EULER_MARUYAMA) ? c->n_steps : 1;
+    const int dyn = (c->strategy == HH_EULER_MARUYAMA) ? c->dynamics : HH_LOGNORMAL;
+    const int nc = ncomp_of(dyn);
+    const size_t tile_elems = replay_elems(c->n_paths, steps, dyn);
+    if (c->replay_layout == HH_REPLAY_PATH_MAJOR) {
+      rc = ensure(ctx, ctx->replay, ctx->replay_cap, tile_elems);
+      if (rc) return rc;
+      rc = hh_replay_pack(ctx, dyn, c->n_paths, steps, c->replay, c->replay_on_device, ctx->replay);
+      if (rc) return rc;
+      p.replay = ctx->replay;
+    } else if (c->replay_layout == HH_REPLAY_TILE_MAJOR) {
+      if (c->replay_on_device) {
+        p.replay = c->replay;
+      } else {
+        rc = ensure(ctx, ctx->replay, ctx->replay_cap, tile_elems);
+        if (rc) return rc;
+        HH_HIP(ctx, hipMemcpyAsync(ctx->replay, c->replay, tile_elems * sizeof(double),
+                                   hipMemcpyHostToDevice, ctx->stream));
+        p.replay = ctx->replay;
+      }
+    } else {
+      return fail(ctx, HH_ERR_INVALID, "unknown replay_layout %d", c->replay_layout);
+    }
+    (void)nc;
+  }
+
+  const size_t n_term = (size_t)c->n_paths * (c->antithetic ? 2 : 1);
+  if (terminal) {
+    if (c->terminal_on_device) {
+      p.terminal = terminal;
+    } else {
+      rc = ensure(ctx, ctx->terminal, ctx->terminal_cap, n_term);
+      if (rc) return rc;
+      p.terminal = ctx->terminal;
+    }
+  }
+
+  if (c->strategy == HH_BROADIE_KAYA)
+    HH_HIP(ctx, hh::launch_bk(*m, *c, p, ctx->stream));
+  else
+    HH_HIP(ctx, hh::launch_simulation(*m, *c, p, ctx->stream));
+  HH_HIP(ctx, hh::launch_reduce_records(ctx->records, n_tiles, (double)c->n_paths, accum_dev,
+                                        ctx->stream));
+
+  if (terminal && !c->terminal_on_device) {
+    HH_HIP(ctx, hipMemcpyAsync(terminal, ctx->terminal, n_term * sizeof(double),
+                               hipMemcpyDeviceToHost, ctx->stream));
+    HH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  return HH_OK;
+}
+
+int hh_mc_finalize(const hh_model* m, const hh_config* c, const double* acc, hh_result* out) {
+  if (!m || !c || !acc || !out) return HH_ERR_INVALID;
+  const double n = acc[HH_ACC_NPATHS];
+  if (!(n >= 1.0)) return HH_ERR_INVALID;
+  const double mean = acc[HH_ACC_SUM] / n;
+  out->sum_payoff = acc[HH_ACC_SUM];
+  out->sumsq_payoff = acc[HH_ACC_SUMSQ];
+  out->price = m->discount * mean;  // montecarlo.jl:489-490
+  double var = 0.0;
+  if (n > 1.0) var = (acc[HH_ACC_SUMSQ] - n * mean * mean) / (n - 1.0);
+  if (!(var > 0.0)) var = 0.0;
+  out->std_error = m->discount * std::sqrt(var / n);
+  for (uint32_t k = 0; k < HH_MAX_PARTIALS; ++k) {
+    double d = 0.0;
+    if (k < c->n_partials) {
+      const double dD = m->ddiscount ? m->ddiscount[k] : 0.0;
+      d = dD * mean + m->discount * (acc[HH_ACC_DSUM + k] / n);
+    }
+    out->dprice[k] = d;
+  }
+  out->n_paths_done = (uint64_t)n;
+  out->bk_newton_fail = (uint64_t)acc[HH_ACC_BK_NEWTON_FAIL];
+  out->bk_bisect_fallback = (uint64_t)acc[HH_ACC_BK_BISECT];
+  out->bk_maxguess_fallback = (uint64_t)acc[HH_ACC_BK_MAXGUESS];
+  out->bk_cf_terms = (uint64_t)acc[HH_ACC_BK_CF_TERMS];
+  return HH_OK;
+}
+
+int hh_mc_solve(hh_ctx* ctx, const hh_model* m, const hh_config* c, hh_result* out,
+                double* terminal) {
+  if (!ctx) return HH_ERR_INVALID;
+  if (!out) return fail(ctx, HH_ERR_INVALID, "result is NULL");
+  const auto t0 = std::chrono::steady_clock::now();
+  std::memset(out, 0, sizeof(*out));
+  HH_HIP(ctx, hipSetDevice(ctx->device));
+  HH_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  int rc = hh_mc_accumulate(ctx, m, c, ctx->accum, terminal);
+  if (rc) return rc;
+  HH_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  HH_HIP(ctx, hipMemcpyAsync(ctx->accum_host, ctx->accum, HH_ACC_LEN * sizeof(double),
+                             hipMemcpyDeviceToHost, ctx->stream));
+  HH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  rc = hh_mc_finalize(m, c, ctx->accum_host, out);
+  if (rc) return fail(ctx, rc, "finalize failed");
+  float ms = 0.f;
+  HH_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+  out->kernel_ms = ms;
+  out->total_ms =
+      std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  return HH_OK;
+}
+
+int hh_device_malloc(hh_ctx* ctx, size_t bytes, void** out_dev) {
+  if (!ctx || !out_dev) return HH_ERR_INVALID;
+  HH_HIP(ctx, hipSetDevice(ctx->device));
+  hipError_t e = hipMalloc(out_dev, bytes);
+  if (e != hipSuccess)
+    return fail(ctx, HH_ERR_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+  return HH_OK;
+}
+
+int hh_device_free(hh_ctx* ctx, void* dev) {
+  if (!ctx) return HH_ERR_INVALID;
+  HH_HIP(ctx, hipSetDevice(ctx->device));
+  HH_HIP(ctx, hipFree(dev));
+  return HH_OK;
+}
+
+int hh_memcpy_h2d(hh_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes) {
+  if (!ctx) return HH_ERR_INVALID;
+  HH_HIP(ctx, hipSetDevice(ctx->device));
+  HH_HIP(ctx, hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+  HH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return HH_OK;
+}
+
+int hh_memcpy_d2h(hh_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes) {
+  if (!ctx) return HH_ERR_INVALID;
+  HH_HIP(ctx, hipSetDevice(ctx->device));
+  HH_HIP(ctx, hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  HH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return HH_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,65 @@
+// Kernel argument blocks and launchers shared between the C-ABI translation unit (hh_api.hip) and
+// the kernel translation units.  Everything here is internal; the public surface is
+// include/hedgehog_mc.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/hedgehog_mc.h"
+
+namespace hh {
+
+constexpr int kTile = HH_TILE_PATHS;  // paths per tile == paths per workgroup
+constexpr int kRecStride = HH_ACC_LEN;
+
+// value + P partials (forward-mode dual number; ForwardDiff.Dual{Tag,Float64,P} on the reference
+// side, greeks_problem.jl:260).  P = 0 keeps a 1-element dummy that is never touched.
+template <int P>
+struct DualT {
+  double v;
+  double d[P > 0 ? P : 1];
+};
+
+// Model/problem block passed BY VALUE as the kernel argument (every field is wave-uniform, so it
+// is read through scalar loads).
+template <int P>
+struct SimArgs {
+  DualT<P> x0;      // log S0                     (montecarlo.jl:182,201)
+  DualT<P> v0;      // V0
+  DualT<P> kappa, theta, sigma;
+  DualT<P> r;       // drift rate
+  DualT<P> gdrift;  // lognormal: r - sigma^2/2   (heston.jl:35)
+  DualT<P> strike;
+  DualT<P> law_mu, law_sd;  // exact lognormal law x = mu + sd·z (montecarlo.jl:302)
+  double dt, sqrt_dt, rho, rho_c, cp;
+  uint64_t n_paths;
+  uint64_t path_offset;
+  uint32_t n_steps;
+  uint32_t n_tiles;
+  const uint64_t* seeds;  // device
+  const double* replay;   // device, tile-major
+  double* terminal;       // device or nullptr
+  double* records;        // device, [n_tiles][kRecStride]
+};
+
+struct DevicePtrs {
+  const uint64_t* seeds;
+  const double* replay;
+  double* terminal;
+  double* records;
+};
+
+inline uint32_t tiles_for(uint64_t n_paths) { return (uint32_t)((n_paths + kTile - 1) / kTile); }
+inline int pad_partials(uint32_t p) { return p == 0 ? 0 : p == 1 ? 1 : p <= 3 ? 3 : 8; }
+
+// All launchers return a hipError_t as int (0 = success) and only enqueue work on `s`.
+int launch_simulation(const hh_model& m, const hh_config& c, const DevicePtrs& p, hipStream_t s);
+int launch_bk(const hh_model& m, const hh_config& c, const DevicePtrs& p, hipStream_t s);
+int launch_reduce_records(const double* records, uint32_t n_records, double n_paths, double* accum,
+                          hipStream_t s);
+int launch_wiener_fill(int dynamics, double rho, double sqrt_dt, uint32_t n_steps, uint64_t n_paths,
+                       const uint64_t* seeds_dev, double* dst, hipStream_t s);
+int launch_replay_pack(int ncomp, uint64_t n_paths, uint32_t n_steps, const double* src_dev,
+                       double* dst_dev, hipStream_t s);
+
+}  // namespace hh

@@ -1,0 +1,557 @@
+// Path-simulation kernels for gfx950 (wave64, fp64 VALU; no MFMA — the path has no contraction).
+//
+// What they replace, per trajectory, is the body of StochasticDiffEq.solve(EnsembleProblem, EM();
+// dt, trajectories) as driven by montecarlo.jl:342-375, with the drift/diffusion closures of
+// heston.jl:7-52, followed by final_sample (montecarlo.jl:398), the payoff functor
+// (payoffs.jl:154-156), the antithetic pair average (montecarlo.jl:430-432) and the Σ that feeds
+// mean() at montecarlo.jl:490 — fused into one pass that keeps the whole state in registers.
+//
+// Work decomposition: one workgroup = one tile of 256 trajectories; the time axis is a serial
+// recurrence inside a thread.  REPLAY streams the tile's increments dW[tile][step][comp][256]
+// from HBM as one contiguous run per workgroup with 16-byte loads per lane and a two-chunk
+// register pipeline; GENERATE draws them in registers from Philox keyed by the trajectory seed.
+// Every workgroup leaves one record of partial sums; a second tiny kernel adds the records in a
+// fixed order, so results are bit-reproducible for a given (n_paths, sharding).
+#include "hh_kernels.h"
+#include "hh_rng.h"
+
+namespace hh {
+
+// ------------------------------------------------------------------------------------------
+// model policies: one explicit Euler–Maruyama step on the log-state
+// ------------------------------------------------------------------------------------------
+
+// heston.jl:7-31.  u = [log S, v];  f = [mu - v+/2, kappa(theta - v+)],  g = [sqrt(v+), sigma sqrt(v+)]
+// with v+ = max(v, 0).  K = u + dt f(u);  u' = K + g(.) dW, g taken at K (SPLIT, the integrator's
+// split-step form) or at u.
+template <int P, bool SPLIT>
+struct HestonModel {
+  static constexpr int NCOMP = 2;
+  struct State {
+    DualT<P> x, v;
+  };
+  __device__ static __forceinline__ void init(State& s, const SimArgs<P>& a) {
+    s.x = a.x0;
+    s.v = a.v0;
+  }
+  __device__ static __forceinline__ void step(State& s, const SimArgs<P>& a, double dW1,
+                                              double dW2) {
+    const bool pos = s.v.v > 0.0;
+    const double vp = pos ? s.v.v : 0.0;
+    const double th_m_v = a.theta.v - vp;
+    const double Kx = fma(a.dt, a.r.v - 0.5 * vp, s.x.v);
+    const double Kv = fma(a.dt, a.kappa.v * th_m_v, s.v.v);
+    const bool wpos = SPLIT ? (Kv > 0.0) : pos;
+    const double w = SPLIT ? (wpos ? Kv : 0.0) : vp;
+    const double sq = sqrt(w);
+    if constexpr (P > 0) {
+      // d sqrt(w+) = dw / (2 sqrt(w)) for w > 0, and 0 at the clip ("dual rules")
+      const double inv2s = wpos ? 0.5 / sq : 0.0;
+#pragma unroll
+      for (int k = 0; k < P; ++k) {
+        const double vpd = pos ? s.v.d[k] : 0.0;
+        const double Kxd = fma(a.dt, a.r.d[k] - 0.5 * vpd, s.x.d[k]);
+        const double fvd = fma(a.kappa.d[k], th_m_v, a.kappa.v * (a.theta.d[k] - vpd));
+        const double Kvd = fma(a.dt, fvd, s.v.d[k]);
+        const double wd = SPLIT ? (wpos ? Kvd : 0.0) : vpd;
+        const double sd = wd * inv2s;
+        const double gvd = fma(a.sigma.d[k], sq, a.sigma.v * sd);
+        s.x.d[k] = fma(sd, dW1, Kxd);
+        s.v.d[k] = fma(gvd, dW2, Kvd);
+      }
+    }
+    s.x.v = fma(sq, dW1, Kx);
+    s.v.v = fma(a.sigma.v * sq, dW2, Kv);
+  }
+};
+
+// heston.jl:33-52.  x' = x + dt (mu - sigma^2/2) + sigma dW  (g constant, so split is irrelevant)
+template <int P>
+struct GbmModel {
+  static constexpr int NCOMP = 1;
+  struct State {
+    DualT<P> x;
+  };
+  __device__ static __forceinline__ void init(State& s, const SimArgs<P>& a) { s.x = a.x0; }
+  __device__ static __forceinline__ void step(State& s, const SimArgs<P>& a, double dW, double) {
+    if constexpr (P > 0) {
+#pragma unroll
+      for (int k = 0; k < P; ++k)
+        s.x.d[k] = fma(a.sigma.d[k], dW, fma(a.dt, a.gdrift.d[k], s.x.d[k]));
+    }
+    s.x.v = fma(a.sigma.v, dW, fma(a.dt, a.gdrift.v, s.x.v));
+  }
+};
+
+// ------------------------------------------------------------------------------------------
+// payoff + reduction
+// ------------------------------------------------------------------------------------------
+
+// S = exp(x) (montecarlo.jl:398); payoff max(cp (S-K), 0) (payoffs.jl:154-156)
+template <int P>
+__device__ __forceinline__ void payoff_of(const DualT<P>& x, const SimArgs<P>& a, double& S,
+                                          double& p, double (&pd)[P > 0 ? P : 1]) {
+  S = exp(x.v);
+  const double m = a.cp * (S - a.strike.v);
+  const bool itm = m > 0.0;
+  p = itm ? m : 0.0;
+  if constexpr (P > 0) {
+#pragma unroll
+    for (int k = 0; k < P; ++k) pd[k] = itm ? a.cp * fma(S, x.d[k], -a.strike.d[k]) : 0.0;
+  }
+}
+
+// wave64 shuffle tree, then across the workgroup's waves through LDS; lane 0 writes the record.
+template <int N, int NWAVES>
+__device__ __forceinline__ void block_reduce_store(double (&acc)[N], double* __restrict__ rec) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc[i] += __shfl_down(acc[i], off, 64);
+  }
+  __shared__ double sm[NWAVES][N];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) sm[wave][i] = acc[i];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      double t = sm[0][i];
+#pragma unroll
+      for (int w = 1; w < NWAVES; ++w) t += sm[w][i];
+      rec[i] = t;
+    }
+#pragma unroll
+    for (int i = N; i < kRecStride; ++i) rec[i] = 0.0;
+  }
+}
+
+template <int P, bool ANTI, class State>
+__device__ __forceinline__ void finish_path(const State& st, const State& sa, const SimArgs<P>& a,
+                                            uint64_t path, double (&acc)[2 + P]) {
+  if (path >= a.n_paths) return;
+  double S, p, pd[P > 0 ? P : 1];
+  payoff_of<P>(st.x, a, S, p, pd);
+  if (a.terminal) a.terminal[path] = S;
+  if constexpr (ANTI) {
+    double Sa, pa, pda[P > 0 ? P : 1];
+    payoff_of<P>(sa.x, a, Sa, pa, pda);
+    if (a.terminal) a.terminal[a.n_paths + path] = Sa;
+    p = (p + pa) / 2;  // montecarlo.jl:431
+    if constexpr (P > 0) {
+#pragma unroll
+      for (int k = 0; k < P; ++k) pd[k] = (pd[k] + pda[k]) / 2;
+    }
+  }
+  acc[0] += p;
+  acc[1] = fma(p, p, acc[1]);
+  if constexpr (P > 0) {
+#pragma unroll
+    for (int k = 0; k < P; ++k) acc[2 + k] += pd[k];
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Euler–Maruyama kernel
+// ------------------------------------------------------------------------------------------
+
+template <int PPT>
+struct VecOf;
+template <>
+struct VecOf<1> {
+  using type = double;
+  __device__ static __forceinline__ double get(const type& v, int) { return v; }
+};
+template <>
+struct VecOf<2> {
+  using type = double __attribute__((ext_vector_type(2)));
+  __device__ static __forceinline__ double get(const type& v, int j) { return j ? v.y : v.x; }
+};
+
+constexpr int kChunk = 4;  // steps per register chunk of the REPLAY pipeline
+
+template <class M, int P, bool REPLAY, bool ANTI, int PPT>
+__global__ __launch_bounds__(kTile / PPT) void euler_kernel(const SimArgs<P> a) {
+  constexpr int NC = M::NCOMP;
+  using State = typename M::State;
+  using Vec = typename VecOf<PPT>::type;
+
+  const uint32_t tile = blockIdx.x;
+  const uint32_t tid = threadIdx.x;
+  const uint64_t path0 = (uint64_t)tile * kTile + (uint64_t)tid * PPT;
+  const uint32_t n_steps = a.n_steps;
+
+  State st[PPT];
+  State sa[ANTI ? PPT : 1];
+#pragma unroll
+  for (int j = 0; j < PPT; ++j) {
+    M::init(st[j], a);
+    if constexpr (ANTI) M::init(sa[j], a);
+  }
+
+  if constexpr (REPLAY) {
+    // the tile's increments: element (step, comp, lane) at ((step*NC + comp)*256 + lane)
+    const double* __restrict__ base =
+        a.replay + (size_t)tile * n_steps * NC * kTile + (size_t)tid * PPT;
+    Vec A[kChunk][NC], B[kChunk][NC];
+
+    auto load = [&](Vec(&buf)[kChunk][NC], uint32_t s0) {
+#pragma unroll
+      for (int u = 0; u < kChunk; ++u) {
+        if (s0 + u < n_steps) {
+#pragma unroll
+          for (int c = 0; c < NC; ++c)
+            buf[u][c] = *reinterpret_cast<const Vec*>(base + ((size_t)(s0 + u) * NC + c) * kTile);
+        }
+      }
+    };
+    auto compute = [&](const Vec(&buf)[kChunk][NC], uint32_t s0) {
+#pragma unroll
+      for (int u = 0; u < kChunk; ++u) {
+        if (s0 + u < n_steps) {
+#pragma unroll
+          for (int j = 0; j < PPT; ++j) {
+            const double d1 = VecOf<PPT>::get(buf[u][0], j);
+            const double d2 = NC > 1 ? VecOf<PPT>::get(buf[u][NC - 1], j) : 0.0;
+            M::step(st[j], a, d1, d2);
+            if constexpr (ANTI) M::step(sa[j], a, -d1, -d2);  // montecarlo.jl:258: -W
+          }
+        }
+      }
+    };
+
+    uint32_t s = 0;
+    load(A, 0);
+    while (s < n_steps) {
+      load(B, s + kChunk);
+      compute(A, s);
+      s += kChunk;
+      if (s >= n_steps) break;
+      load(A, s + kChunk);
+      compute(B, s);
+      s += kChunk;
+    }
+  } else {
+    uint64_t key[PPT];
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) key[j] = (path0 + j < a.n_paths) ? a.seeds[path0 + j] : 0ull;
+
+    if constexpr (NC == 2) {
+      for (uint32_t s = 0; s < n_steps; ++s) {
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) {
+          double z1, z2;
+          normal_pair(key[j], s, 0u, 0u, kDomEuler, z1, z2);
+          const double d1 = a.sqrt_dt * z1;
+          const double d2 = a.sqrt_dt * fma(a.rho, z1, a.rho_c * z2);
+          M::step(st[j], a, d1, d2);
+          if constexpr (ANTI) M::step(sa[j], a, -d1, -d2);
+        }
+      }
+    } else {
+      // scalar noise: one Philox block feeds two consecutive steps
+      for (uint32_t s = 0; s < n_steps; s += 2) {
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) {
+          double z1, z2;
+          normal_pair(key[j], s >> 1, 0u, 0u, kDomEuler, z1, z2);
+          const double d1 = a.sqrt_dt * z1;
+          M::step(st[j], a, d1, 0.0);
+          if constexpr (ANTI) M::step(sa[j], a, -d1, 0.0);
+          if (s + 1 < n_steps) {
+            const double d2 = a.sqrt_dt * z2;
+            M::step(st[j], a, d2, 0.0);
+            if constexpr (ANTI) M::step(sa[j], a, -d2, 0.0);
+          }
+        }
+      }
+    }
+  }
+
+  double acc[2 + P];
+#pragma unroll
+  for (int i = 0; i < 2 + P; ++i) acc[i] = 0.0;
+#pragma unroll
+  for (int j = 0; j < PPT; ++j) finish_path<P, ANTI>(st[j], sa[ANTI ? j : 0], a, path0 + j, acc);
+  block_reduce_store<2 + P, kTile / PPT / 64>(acc, a.records + (size_t)tile * kRecStride);
+}
+
+// ------------------------------------------------------------------------------------------
+// exact lognormal law (montecarlo.jl:293-303, 384-390, 412-414, 454-459)
+// ------------------------------------------------------------------------------------------
+
+template <int P>
+struct ExactState {
+  DualT<P> x;
+};
+
+template <int P, bool REPLAY, bool ANTI>
+__global__ __launch_bounds__(kTile / 2) void exact_gbm_kernel(const SimArgs<P> a) {
+  const uint32_t tile = blockIdx.x;
+  const uint32_t tid = threadIdx.x;
+  const uint64_t path0 = (uint64_t)tile * kTile + (uint64_t)tid * 2;
+
+  double acc[2 + P];
+#pragma unroll
+  for (int i = 0; i < 2 + P; ++i) acc[i] = 0.0;
+
+  // trajectory G (global index) takes component G&1 of Philox block G>>1
+  const uint64_t g0 = a.path_offset + path0;
+  double z[2];
+  if constexpr (REPLAY) {
+    // standard normals supplied by the caller, one per trajectory (tile-major with 1 step, 1 comp)
+    z[0] = path0 < a.n_paths ? a.replay[path0] : 0.0;
+    z[1] = path0 + 1 < a.n_paths ? a.replay[path0 + 1] : 0.0;
+  } else {
+    const uint64_t key = a.seeds[0];  // ONE key for the whole sample (montecarlo.jl:456)
+    double z1, z2;
+    normal_pair(key, (uint32_t)(g0 >> 1), (uint32_t)(g0 >> 33), 0u, kDomExactGbm, z1, z2);
+    if ((g0 & 1ull) == 0) {
+      z[0] = z1;
+      z[1] = z2;
+    } else {
+      z[0] = z2;
+      const uint64_t g1 = g0 + 1;
+      normal_pair(key, (uint32_t)(g1 >> 1), (uint32_t)(g1 >> 33), 0u, kDomExactGbm, z1, z2);
+      z[1] = z1;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    ExactState<P> st, sa;
+    st.x.v = fma(a.law_sd.v, z[j], a.law_mu.v);
+    if constexpr (ANTI) sa.x.v = 2 * a.law_mu.v - st.x.v;  // montecarlo.jl:387
+    if constexpr (P > 0) {
+#pragma unroll
+      for (int k = 0; k < P; ++k) {
+        st.x.d[k] = fma(a.law_sd.d[k], z[j], a.law_mu.d[k]);
+        if constexpr (ANTI) sa.x.d[k] = 2 * a.law_mu.d[k] - st.x.d[k];
+      }
+    }
+    finish_path<P, ANTI>(st, sa, a, path0 + j, acc);
+  }
+  block_reduce_store<2 + P, kTile / 2 / 64>(acc, a.records + (size_t)tile * kRecStride);
+}
+
+// ------------------------------------------------------------------------------------------
+// record reduction: one workgroup per accumulator slot, fixed summation order
+// ------------------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void reduce_records_kernel(const double* __restrict__ rec,
+                                                              uint32_t n, double n_paths,
+                                                              double* __restrict__ accum) {
+  __shared__ double sm[256];
+  const int slot = blockIdx.x;
+  const int tid = threadIdx.x;
+  double t = 0.0;
+  for (uint32_t b = tid; b < n; b += 256) t += rec[(size_t)b * kRecStride + slot];
+  sm[tid] = t;
+  __syncthreads();
+#pragma unroll
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s) sm[tid] += sm[tid + s];
+    __syncthreads();
+  }
+  if (tid == 0) accum[slot] = (slot == HH_ACC_NPATHS) ? n_paths : sm[0];
+}
+
+// ------------------------------------------------------------------------------------------
+// REPLAY buffer helpers
+// ------------------------------------------------------------------------------------------
+
+constexpr int kFillSteps = 16;  // steps per workgroup of the fill kernel
+
+template <int NC>
+__global__ __launch_bounds__(kTile) void wiener_fill_kernel(double rho, double rho_c,
+                                                            double sqrt_dt, uint32_t n_steps,
+                                                            uint64_t n_paths,
+                                                            const uint64_t* __restrict__ seeds,
+                                                            double* __restrict__ dst) {
+  const uint32_t tile = blockIdx.x;
+  const uint32_t s0 = blockIdx.y * kFillSteps;
+  const uint64_t path = (uint64_t)tile * kTile + threadIdx.x;
+  const bool live = path < n_paths;
+  const uint64_t key = live ? seeds[path] : 0ull;
+  double* out = dst + (size_t)tile * n_steps * NC * kTile + threadIdx.x;
+  for (uint32_t s = s0; s < s0 + kFillSteps && s < n_steps; ++s) {
+    double z1, z2;
+    if constexpr (NC == 2) {
+      normal_pair(key, s, 0u, 0u, kDomEuler, z1, z2);
+      const double d1 = sqrt_dt * z1;
+      const double d2 = sqrt_dt * fma(rho, z1, rho_c * z2);
+      out[((size_t)s * 2 + 0) * kTile] = live ? d1 : 0.0;
+      out[((size_t)s * 2 + 1) * kTile] = live ? d2 : 0.0;
+    } else {
+      normal_pair(key, s >> 1, 0u, 0u, kDomEuler, z1, z2);
+      const double d = sqrt_dt * ((s & 1u) ? z2 : z1);
+      out[(size_t)s * kTile] = live ? d : 0.0;
+    }
+  }
+}
+
+constexpr int kPackSteps = 8;
+
+// src[path][step][comp] -> dst[tile][step][comp][256], transposed through LDS so that both the
+// reads (along step·comp) and the writes (along path) are contiguous per wave.
+template <int NC>
+__global__ __launch_bounds__(256) void replay_pack_kernel(uint64_t n_paths, uint32_t n_steps,
+                                                          const double* __restrict__ src,
+                                                          double* __restrict__ dst) {
+  constexpr int COLS = kPackSteps * NC;
+  __shared__ double sm[kTile][COLS + 1];
+  const uint32_t tile = blockIdx.x;
+  const uint32_t s0 = blockIdx.y * kPackSteps;
+  const int tid = threadIdx.x;
+  const int col = tid % COLS, row0 = tid / COLS;
+  constexpr int ROWS_PER_IT = 256 / COLS;
+  for (int row = row0; row < kTile; row += ROWS_PER_IT) {
+    const uint64_t path = (uint64_t)tile * kTile + row;
+    const uint32_t s = s0 + col / NC;
+    double v = 0.0;
+    if (path < n_paths && s < n_steps) v = src[((size_t)path * n_steps + s0) * NC + col];
+    sm[row][col] = v;
+  }
+  __syncthreads();
+  double* out = dst + (size_t)tile * n_steps * NC * kTile + tid;
+  for (int c = 0; c < COLS; ++c) {
+    const uint32_t s = s0 + c / NC;
+    if (s < n_steps) out[((size_t)s * NC + (c % NC)) * kTile] = sm[tid][c];
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// host-side launchers
+// ------------------------------------------------------------------------------------------
+
+static inline double seed_of(const double* p, uint32_t k, uint32_t n) {
+  return (p && k < n) ? p[k] : 0.0;
+}
+
+template <int P>
+static SimArgs<P> make_args(const hh_model& m, const hh_config& c, const DevicePtrs& p) {
+  SimArgs<P> a{};
+  const uint32_t np = c.n_partials;
+  const double sig2h = 0.5 * m.sigma * m.sigma;
+  a.x0.v = log(m.S0);
+  a.v0.v = m.V0;
+  a.kappa.v = m.kappa;
+  a.theta.v = m.theta;
+  a.sigma.v = m.sigma;
+  a.r.v = m.r_drift;
+  a.gdrift.v = m.r_drift - sig2h;
+  a.strike.v = m.strike;
+  // exact law (montecarlo.jl:302): Normal(log S0 + (r - σ²/2)·√α, σ·√α); compat flag keeps the √α
+  const double sqT = sqrt(m.T);
+  const double tmul = c.compat_sqrt_alpha ? sqT : m.T;
+  a.law_mu.v = a.x0.v + a.gdrift.v * tmul;
+  a.law_sd.v = m.sigma * sqT;
+  for (int k = 0; k < P; ++k) {
+    const double dS0 = seed_of(m.dS0, k, np), dsig = seed_of(m.dsigma, k, np),
+                 dr = seed_of(m.dr_drift, k, np);
+    a.x0.d[k] = dS0 / m.S0;
+    a.v0.d[k] = seed_of(m.dV0, k, np);
+    a.kappa.d[k] = seed_of(m.dkappa, k, np);
+    a.theta.d[k] = seed_of(m.dtheta, k, np);
+    a.sigma.d[k] = dsig;
+    a.r.d[k] = dr;
+    a.gdrift.d[k] = dr - m.sigma * dsig;
+    a.strike.d[k] = seed_of(m.dstrike, k, np);
+    a.law_mu.d[k] = a.x0.d[k] + a.gdrift.d[k] * tmul;
+    a.law_sd.d[k] = dsig * sqT;
+  }
+  a.dt = m.T / (double)(c.n_steps ? c.n_steps : 1);  // montecarlo.jl:349
+  a.sqrt_dt = sqrt(a.dt);
+  a.rho = m.rho;
+  a.rho_c = sqrt(1.0 - m.rho * m.rho);
+  a.cp = m.cp;
+  a.n_paths = c.n_paths;
+  a.path_offset = c.path_offset;
+  a.n_steps = c.n_steps;
+  a.n_tiles = tiles_for(c.n_paths);
+  a.seeds = p.seeds;
+  a.replay = p.replay;
+  a.terminal = p.terminal;
+  a.records = p.records;
+  return a;
+}
+
+template <class M, int P, bool REPLAY, bool ANTI>
+static int launch_euler_t(const SimArgs<P>& a, hipStream_t s) {
+  constexpr int PPT = REPLAY ? 2 : 1;
+  hipLaunchKernelGGL((euler_kernel<M, P, REPLAY, ANTI, PPT>), dim3(a.n_tiles), dim3(kTile / PPT), 0,
+                     s, a);
+  return (int)hipGetLastError();
+}
+
+template <class M, int P>
+static int launch_euler_m(const SimArgs<P>& a, bool replay, bool anti, hipStream_t s) {
+  if (replay) return anti ? launch_euler_t<M, P, true, true>(a, s) : launch_euler_t<M, P, true, false>(a, s);
+  return anti ? launch_euler_t<M, P, false, true>(a, s) : launch_euler_t<M, P, false, false>(a, s);
+}
+
+template <int P>
+static int launch_sim_p(const hh_model& m, const hh_config& c, const DevicePtrs& p, hipStream_t s) {
+  const SimArgs<P> a = make_args<P>(m, c, p);
+  const bool anti = c.antithetic != 0;
+  const bool replay = c.noise_mode == HH_NOISE_REPLAY;
+  if (c.strategy == HH_EXACT_LAW) {
+    const dim3 g(a.n_tiles), b(kTile / 2);
+    if (replay) {
+      if (anti) hipLaunchKernelGGL((exact_gbm_kernel<P, true, true>), g, b, 0, s, a);
+      else hipLaunchKernelGGL((exact_gbm_kernel<P, true, false>), g, b, 0, s, a);
+    } else {
+      if (anti) hipLaunchKernelGGL((exact_gbm_kernel<P, false, true>), g, b, 0, s, a);
+      else hipLaunchKernelGGL((exact_gbm_kernel<P, false, false>), g, b, 0, s, a);
+    }
+    return (int)hipGetLastError();
+  }
+  if (c.dynamics == HH_LOGNORMAL) return launch_euler_m<GbmModel<P>, P>(a, replay, anti, s);
+  if (c.em_split) return launch_euler_m<HestonModel<P, true>, P>(a, replay, anti, s);
+  return launch_euler_m<HestonModel<P, false>, P>(a, replay, anti, s);
+}
+
+int launch_simulation(const hh_model& m, const hh_config& c, const DevicePtrs& p, hipStream_t s) {
+  switch (pad_partials(c.n_partials)) {
+    case 0: return launch_sim_p<0>(m, c, p, s);
+    case 1: return launch_sim_p<1>(m, c, p, s);
+    case 3: return launch_sim_p<3>(m, c, p, s);
+    default: return launch_sim_p<8>(m, c, p, s);
+  }
+}
+
+int launch_reduce_records(const double* records, uint32_t n_records, double n_paths, double* accum,
+                          hipStream_t s) {
+  hipLaunchKernelGGL(reduce_records_kernel, dim3(kRecStride), dim3(256), 0, s, records, n_records,
+                     n_paths, accum);
+  return (int)hipGetLastError();
+}
+
+int launch_wiener_fill(int dynamics, double rho, double sqrt_dt, uint32_t n_steps, uint64_t n_paths,
+                       const uint64_t* seeds_dev, double* dst, hipStream_t s) {
+  const dim3 grid(tiles_for(n_paths), (n_steps + kFillSteps - 1) / kFillSteps);
+  const double rho_c = sqrt(1.0 - rho * rho);
+  if (dynamics == HH_HESTON)
+    hipLaunchKernelGGL(wiener_fill_kernel<2>, grid, dim3(kTile), 0, s, rho, rho_c, sqrt_dt, n_steps,
+                       n_paths, seeds_dev, dst);
+  else
+    hipLaunchKernelGGL(wiener_fill_kernel<1>, grid, dim3(kTile), 0, s, rho, rho_c, sqrt_dt, n_steps,
+                       n_paths, seeds_dev, dst);
+  return (int)hipGetLastError();
+}
+
+int launch_replay_pack(int ncomp, uint64_t n_paths, uint32_t n_steps, const double* src_dev,
+                       double* dst_dev, hipStream_t s) {
+  const dim3 grid(tiles_for(n_paths), (n_steps + kPackSteps - 1) / kPackSteps);
+  if (ncomp == 2)
+    hipLaunchKernelGGL(replay_pack_kernel<2>, grid, dim3(256), 0, s, n_paths, n_steps, src_dev,
+                       dst_dev);
+  else
+    hipLaunchKernelGGL(replay_pack_kernel<1>, grid, dim3(256), 0, s, n_paths, n_steps, src_dev,
+                       dst_dev);
+  return (int)hipGetLastError();
+}
+
+}  // namespace hh

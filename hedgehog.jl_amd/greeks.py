@@ -1,0 +1,177 @@
+"""Host mirror of /root/reference/src/greeks/greeks_problem.jl (hot-path part):
+lenses (:18-130), ForwardAD (:193, :249-262), FiniteDifference (:204-220, :279-329),
+BatchGreekProblem (:541-568) and ZeroRateSpineLens (pricing_methods.jl:26-60).
+
+ForwardAD pushes a host `Dual` through `set(prob, lens, ·)`; solve() hands its partials to the
+kernels as dual seeds and returns a Dual price — exactly the contract ForwardDiff.derivative needs
+at greeks_problem.jl:258-260.  BatchGreekProblem + ForwardAD + MonteCarlo seeds one partial per
+lens and makes ONE fused pass (the reference re-simulates the same noise once per lens,
+greeks_problem.jl:567, so the results coincide).
+"""
+from __future__ import annotations
+
+import copy
+from dataclasses import dataclass
+from typing import Any
+
+from .dual import Dual
+from .domain import BlackScholesInputs, FlatRateCurve, FlatVolSurface, HestonInputs
+
+
+def _replace(obj, name, val):
+    new = copy.copy(obj)
+    object.__setattr__(new, name, val)
+    return new
+
+
+def _set_path(obj, path, val):
+    if len(path) == 1:
+        return _replace(obj, path[0], val)
+    return _replace(obj, path[0], _set_path(getattr(obj, path[0]), path[1:], val))
+
+
+class GreekLens: pass
+
+
+@dataclass(frozen=True)
+class PropertyLens(GreekLens):
+    """Accessors' `@optic _.market_inputs.spot`: optic("market_inputs.spot")."""
+    path: tuple
+
+    def __call__(self, prob):
+        for p in self.path:
+            prob = getattr(prob, p)
+        return prob
+
+
+def optic(path: str) -> PropertyLens:
+    return PropertyLens(tuple(path.lstrip("_.").split(".")))
+
+
+@dataclass(frozen=True)
+class SpotLens(GreekLens):
+    """greeks_problem.jl:18-49."""
+    def __call__(self, p): return p.market_inputs.spot
+
+
+@dataclass(frozen=True)
+class VolLens(GreekLens):
+    """greeks_problem.jl:56-80; flat surface only (:119-130)."""
+    strike: Any
+    expiry: Any
+
+    def __call__(self, prob):
+        sigma = getattr(prob.market_inputs, "sigma", None)
+        if not isinstance(sigma, FlatVolSurface):
+            raise TypeError("VolLens needs market_inputs.sigma::FlatVolSurface")
+        return sigma.σ
+
+
+@dataclass(frozen=True)
+class ZeroRateSpineLens(GreekLens):
+    """pricing_methods.jl:26-60; getter defined for BlackScholesInputs with a flat curve (:30-32)."""
+    i: int
+
+    def __call__(self, prob):
+        m = prob.market_inputs
+        if not (isinstance(m, BlackScholesInputs) and isinstance(m.rate, FlatRateCurve)):
+            raise TypeError("ZeroRateSpineLens getter: BlackScholesInputs{FlatRateCurve} only")
+        return m.rate.rate
+
+
+def set(prob, lens, val):  # noqa: A001 - the reference's name (Accessors.set)
+    if isinstance(lens, PropertyLens):
+        return _set_path(prob, lens.path, val)
+    if isinstance(lens, SpotLens):
+        return _set_path(prob, ("market_inputs", "spot"), val)
+    if isinstance(lens, VolLens):
+        sigma = prob.market_inputs.sigma
+        return _set_path(prob, ("market_inputs", "sigma"), FlatVolSurface(sigma.reference_date, val))
+    if isinstance(lens, ZeroRateSpineLens):
+        curve = prob.market_inputs.rate
+        return _set_path(prob, ("market_inputs", "rate"), FlatRateCurve(curve.reference_date, val))
+    raise TypeError(f"unknown lens {lens!r}")
+
+
+# ---- methods ----
+class GreekMethod: pass
+class ForwardAD(GreekMethod): pass
+class FDScheme: pass
+class FDForward(FDScheme): pass
+class FDBackward(FDScheme): pass
+class FDCentral(FDScheme): pass
+
+
+@dataclass(frozen=True)
+class FiniteDifference(GreekMethod):
+    """greeks_problem.jl:204-220: relative bump, central by default."""
+    bump: float
+    scheme: Any = None
+
+    def __post_init__(self):
+        if self.scheme is None:
+            object.__setattr__(self, "scheme", FDCentral())
+
+
+@dataclass(frozen=True)
+class GreekProblem:
+    pricing_problem: Any
+    wrt: Any
+
+
+@dataclass(frozen=True)
+class BatchGreekProblem:
+    pricing_problem: Any
+    lenses: Any
+
+
+@dataclass(frozen=True)
+class GreekResult:
+    greek: Any
+
+
+def _seed(x0, k, n):
+    return Dual(float(x0), tuple(1.0 if j == k else 0.0 for j in range(n)))
+
+
+def solve_greek_ad(gprob: GreekProblem, pricing_method, solve):
+    """greeks_problem.jl:249-262."""
+    prob, lens = gprob.pricing_problem, gprob.wrt
+    x0 = lens(prob)
+    price = solve(set(prob, lens, _seed(x0, 0, 1)), pricing_method).price
+    return GreekResult(price.partials[0] if isinstance(price, Dual) else 0.0)
+
+
+def solve_greek_fd(gprob: GreekProblem, method: FiniteDifference, pricing_method, solve):
+    """greeks_problem.jl:279-329 (common random numbers come from the fixed seeds)."""
+    prob, lens, eps = gprob.pricing_problem, gprob.wrt, method.bump
+    x0 = lens(prob)
+    price = lambda x: solve(set(prob, lens, x), pricing_method).price
+    if isinstance(method.scheme, FDForward):
+        d = (price(x0 * (1 + eps)) - price(x0)) / (x0 * eps)
+    elif isinstance(method.scheme, FDBackward):
+        d = (price(x0) - price(x0 * (1 - eps))) / (x0 * eps)
+    else:
+        d = (price(x0 * (1 + eps)) - price(x0 * (1 - eps))) / (2 * eps * x0)
+    return GreekResult(d)
+
+
+def solve_batch(gprob: BatchGreekProblem, method, pricing_method, solve):
+    """greeks_problem.jl:559-568 -> {lens: greek}; ForwardAD through MonteCarlo is one fused pass."""
+    from .montecarlo import MonteCarlo
+    lenses, prob = tuple(gprob.lenses), gprob.pricing_problem
+    if isinstance(method, ForwardAD) and isinstance(pricing_method, MonteCarlo) and \
+            0 < len(lenses) <= 8:
+        n = len(lenses)
+        p = prob
+        for k, lens in enumerate(lenses):
+            x0 = lens(p)
+            if isinstance(x0, Dual):  # two lenses on the same input
+                x0 = Dual(x0.value, tuple(a + (1.0 if j == k else 0.0)
+                                          for j, a in enumerate(x0.partials)))
+            else:
+                x0 = _seed(x0, k, n)
+            p = set(p, lens, x0)
+        price = solve(p, pricing_method).price
+        return {lens: price.partials[k] for k, lens in enumerate(lenses)}
+    return {lens: solve(GreekProblem(prob, lens), method, pricing_method).greek for lens in lenses}

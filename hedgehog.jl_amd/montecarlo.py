@@ -1,0 +1,192 @@
+"""Host mirror of /root/reference/src/pricing_methods/montecarlo.jl — types and `solve`.
+
+Same names, argument meaning and error behaviour as the reference; the body of `solve` is one
+call through the C-ABI (include/hedgehog_mc.h) into the HIP kernels.  There is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Any
+
+import numpy as np
+
+from . import _ffi
+from .dates import yearfrac
+from .dual import Dual, n_partials, partials_of, value_of
+from .domain import (BlackScholesInputs, European, HestonInputs, MonteCarloSolution, PricingProblem,
+                    Spot, VanillaOption, df, get_vol, zero_rate)
+
+
+# ---- montecarlo.jl:8-43 ----
+class PriceDynamics: pass
+class LognormalDynamics(PriceDynamics): pass
+class HestonDynamics(PriceDynamics): pass
+class VarianceReductionStrategy: pass
+class NoVarianceReduction(VarianceReductionStrategy): pass
+class Antithetic(VarianceReductionStrategy): pass
+# ---- montecarlo.jl:86-115 ----
+class SimulationStrategy: pass
+class EulerMaruyama(SimulationStrategy): pass
+class ExactSimulation(SimulationStrategy): pass
+class HestonBroadieKaya(ExactSimulation): pass
+class BlackScholesExact(ExactSimulation): pass
+
+for _c in (LognormalDynamics, HestonDynamics, NoVarianceReduction, Antithetic, EulerMaruyama,
+           HestonBroadieKaya, BlackScholesExact):
+    _c.__eq__ = lambda a, b: type(a) is type(b)
+    _c.__hash__ = lambda a: hash(type(a).__name__)
+    _c.__repr__ = lambda a: type(a).__name__ + "()"
+
+
+class AbstractPricingMethod: pass
+
+
+class SimulationConfig:
+    """montecarlo.jl:58-79.  `SimulationConfig(trajectories; steps=1, seeds=nothing,
+    variance_reduction=NoVarianceReduction())`; too few seeds -> ValueError (ArgumentError there)."""
+
+    def __init__(self, trajectories, steps=1, seeds=None, variance_reduction=None):
+        if variance_reduction is None:
+            variance_reduction = NoVarianceReduction()
+        if seeds is None:  # montecarlo.jl:77: rand(UInt64, trajectories)
+            seeds = np.random.default_rng().integers(0, 2**64, size=int(trajectories),
+                                                     dtype=np.uint64)
+        seeds = np.ascontiguousarray(np.asarray(seeds).astype(np.uint64, copy=False))
+        if len(seeds) < trajectories:  # montecarlo.jl:65-66
+            raise ValueError(f"Number of seeds ({len(seeds)}) must be ≥ number of trajectories "
+                             f"({trajectories}).")
+        self.trajectories = int(trajectories)
+        self.steps = int(steps)
+        self.variance_reduction = variance_reduction
+        self.seeds = seeds
+
+    def replace(self, **kw):
+        """Accessors' `@set config.seeds = …` (test/agreement/montecarlo_heston.jl:87)."""
+        d = dict(trajectories=self.trajectories, steps=self.steps, seeds=self.seeds,
+                 variance_reduction=self.variance_reduction)
+        d.update(kw)
+        return SimulationConfig(**d)
+
+
+@dataclass(frozen=True)
+class MonteCarlo(AbstractPricingMethod):
+    """montecarlo.jl:127-131.  `em_split` / `compat_sqrt_alpha` / `device` are build options with
+    the reference's behaviour as default (quirks Q1, EM split form)."""
+    dynamics: Any
+    strategy: Any
+    config: SimulationConfig
+    em_split: bool = True
+    compat_sqrt_alpha: bool = False
+    device: int = 0
+
+
+class MethodError(TypeError):
+    """Julia's MethodError: no `solve` / `sde_problem` method for this combination."""
+
+
+# ------------------------------------------------------------------------------------------------
+
+def _model_and_config(prob: PricingProblem, method: MonteCarlo, n_paths=None, path_offset=0):
+    """Resolve dates/curves exactly as sde_problem / marginal_law / solve do and pack the C structs.
+
+    Returns (hh_model, hh_config, keepalive, P, discount)."""
+    payoff, m = prob.payoff, prob.market_inputs
+    # solve's signature: VanillaOption{…, European, C, Spot}  (montecarlo.jl:479)
+    if not (isinstance(payoff, VanillaOption) and isinstance(payoff.exercise_style, European)
+            and isinstance(payoff.underlying, Spot)):
+        raise MethodError("solve(::PricingProblem, ::MonteCarlo) needs a European VanillaOption on Spot")
+    dyn, strat, cfg = method.dynamics, method.strategy, method.config
+    euler = isinstance(strat, EulerMaruyama)
+
+    if isinstance(dyn, LognormalDynamics) and isinstance(m, BlackScholesInputs) and \
+            isinstance(strat, (EulerMaruyama, BlackScholesExact)):
+        dynamics = _ffi.HH_LOGNORMAL
+        strategy = _ffi.HH_EULER_MARUYAMA if euler else _ffi.HH_EXACT_LAW
+        sigma, V0, kappa, theta, rho = get_vol(m.sigma, None, None), 0.0, 0.0, 0.0, 0.0
+    elif isinstance(dyn, HestonDynamics) and isinstance(m, HestonInputs) and \
+            isinstance(strat, (EulerMaruyama, HestonBroadieKaya)):
+        dynamics = _ffi.HH_HESTON
+        strategy = _ffi.HH_EULER_MARUYAMA if euler else _ffi.HH_BROADIE_KAYA
+        sigma, V0, kappa, theta, rho = m.σ, m.V0, m.κ, m.θ, m.ρ
+    else:
+        raise MethodError(f"no sde_problem / marginal_law for {type(dyn).__name__} + "
+                          f"{type(strat).__name__} on {type(m).__name__}")
+
+    if euler:
+        T = yearfrac(m.referenceDate, payoff.expiry)          # montecarlo.jl:173,197
+        r_drift = zero_rate(m.rate, 0.0)                      # montecarlo.jl:176,200
+    else:
+        T = yearfrac(m.rate.reference_date, payoff.expiry)    # montecarlo.jl:301,317
+        r_drift = zero_rate(m.rate, payoff.expiry)            # montecarlo.jl:299,318
+    discount = df(m.rate, payoff.expiry)                      # montecarlo.jl:489
+
+    scal = dict(S0=m.spot, V0=V0, kappa=kappa, theta=theta, sigma=sigma, r_drift=r_drift,
+                discount=discount, strike=payoff.strike)
+    if isinstance(rho, Dual):
+        raise MethodError("differentiation with respect to ρ is not supported "
+                          "(the reference cannot push a Dual through svd(Γ), heston.jl:18-20)")
+    P = n_partials(*scal.values())
+    if P > _ffi.HH_MAX_PARTIALS:
+        raise ValueError(f"at most {_ffi.HH_MAX_PARTIALS} partials per solve")
+    keep = []
+    model = _ffi.hh_model()
+    for k, v in scal.items():
+        setattr(model, k, value_of(v))
+        arr = _ffi.seed_array(partials_of(v, P), P) if P else None
+        if arr is not None:
+            keep.append(arr)
+            setattr(model, "d" + k, C.cast(arr, C.POINTER(C.c_double)))
+    model.rho = float(rho)
+    model.T = float(T)
+    model.cp = payoff.call_put()
+
+    c = _ffi.hh_config()
+    c.dynamics, c.strategy = dynamics, strategy
+    c.antithetic = int(isinstance(cfg.variance_reduction, Antithetic))
+    c.em_split = int(method.em_split)
+    c.compat_sqrt_alpha = int(method.compat_sqrt_alpha)
+    c.noise_mode = _ffi.HH_NOISE_GENERATE
+    c.n_steps = cfg.steps
+    c.n_partials = P
+    c.n_paths = cfg.trajectories if n_paths is None else n_paths
+    c.path_offset = path_offset
+    return model, c, keep, P, discount
+
+
+def _price_from(res, discount, P):
+    if P == 0:
+        return res.price
+    return Dual(res.price, tuple(res.dprice[k] for k in range(P)))
+
+
+def solve_montecarlo(prob: PricingProblem, method: MonteCarlo, ensemble: bool = True,
+                     replay=None, replay_layout=_ffi.HH_REPLAY_PATH_MAJOR) -> MonteCarloSolution:
+    """solve(prob, method::MonteCarlo) — montecarlo.jl:478-493.
+
+    `replay` (optional, build extension): Wiener increments to consume instead of drawing them —
+    numpy array [path][step][comp] (or tile-major), the noise-replay parity mode of DESIGN.md."""
+    model, c, keep, P, discount = _model_and_config(prob, method)
+    cfg = method.config
+    ctx = _ffi.get_context(method.device)
+    seeds = cfg.seeds
+    c.seeds = seeds.ctypes.data
+    if replay is not None:
+        replay = np.ascontiguousarray(replay, dtype=np.float64)
+        c.noise_mode = _ffi.HH_NOISE_REPLAY
+        c.replay_layout = replay_layout
+        c.replay = replay.ctypes.data
+    anti = bool(c.antithetic)
+    term = None
+    term_ptr = None
+    if ensemble:
+        term = np.empty(c.n_paths * (2 if anti else 1), dtype=np.float64)
+        term_ptr = term.ctypes.data
+    res = _ffi.hh_result()
+    ctx.check(ctx.lib.hh_mc_solve(ctx.handle, C.byref(model), C.byref(c), C.byref(res), term_ptr))
+    del keep
+    ens = None
+    if term is not None:  # montecarlo.jl:398-402: vector, or tuple of two for antithetic
+        ens = (term[:c.n_paths], term[c.n_paths:]) if anti else term
+    return MonteCarloSolution(prob, method, _price_from(res, discount, P), ens,
+                              std_error=res.std_error, result=res)

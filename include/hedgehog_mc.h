@@ -1,0 +1,184 @@
+/*
+ * hedgehog_mc.h — C-ABI of libhedgehog_mc.so, the MI355X (gfx950) Monte Carlo engine that stands in
+ * for the hot path of Hedgehog.jl's
+ *
+ *     solve(prob::PricingProblem{VanillaOption{…,European,C,Spot},I}, method::MonteCarlo)
+ *                                             (reference: src/pricing_methods/montecarlo.jl:478-493)
+ *
+ * and for the ForwardDiff-dual Greeks that run through it (src/greeks/greeks_problem.jl:249-262,
+ * 559-568).  The reference has no FFI seam of its own: its extension point is Julia multiple
+ * dispatch on `solve`.  The entry points below are what a Julia `ccall` — or the
+ * Python host mirror in this repository — binds to replace that method body.
+ *
+ * Conventions
+ *   - plain C types only; every function returns an int status (0 = HH_OK, negative = error) and
+ *     never throws or aborts across the boundary; text via hh_last_error().
+ *   - all arithmetic is IEEE fp64 (the reference computes in Float64 throughout).
+ *   - the caller owns every buffer it passes, for the duration of the call only; the library owns
+ *     whatever it allocates inside hh_ctx and releases it in hh_ctx_destroy().
+ *   - a hh_ctx is bound to ONE device and ONE HIP stream and is single-owner (not thread-safe);
+ *     use one ctx per host thread / per GPU.  Multi-GPU = one process (or thread) per GPU, each
+ *     with its own ctx, exchanging only the HH_ACC_LEN-double accumulator vector (one all-reduce).
+ *   - there is NO CPU fallback in this library: without a HIP device every compute entry point
+ *     fails with HH_ERR_HIP.
+ */
+#ifndef HEDGEHOG_MC_H
+#define HEDGEHOG_MC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HH_ABI_VERSION 1
+#define HH_MAX_PARTIALS 8   /* max. number of dual-number partials carried through one solve    */
+#define HH_TILE_PATHS 256   /* paths per tile of the tile-major REPLAY layout (see below)        */
+#define HH_ACC_LEN 16       /* doubles in the accumulator vector exchanged between GPUs          */
+
+/* accumulator vector slots (all are plain sums, so one SUM all-reduce combines shards) */
+#define HH_ACC_SUM 0        /* Σ payoff (undiscounted; antithetic: Σ of pair averages)           */
+#define HH_ACC_SUMSQ 1      /* Σ payoff²                                                         */
+#define HH_ACC_DSUM 2       /* [2, 2+HH_MAX_PARTIALS): Σ ∂payoff/∂θ_k                             */
+#define HH_ACC_NPATHS 10    /* number of trajectories accumulated                                */
+#define HH_ACC_BK_NEWTON_FAIL 11
+#define HH_ACC_BK_BISECT 12
+#define HH_ACC_BK_MAXGUESS 13
+#define HH_ACC_BK_CF_TERMS 14 /* Σ characteristic-function series terms evaluated (Broadie–Kaya) */
+
+enum hh_status {
+  HH_OK = 0,
+  HH_ERR_INVALID = -1,     /* bad argument (NULL, sizes, ranges)                                  */
+  HH_ERR_UNSUPPORTED = -2, /* combination the reference itself cannot run (e.g. BK + antithetic)  */
+  HH_ERR_HIP = -3,         /* HIP runtime error, or no HIP device                                 */
+  HH_ERR_NOMEM = -4
+};
+
+/* montecarlo.jl:8-22 */
+enum hh_dynamics { HH_LOGNORMAL = 0, HH_HESTON = 1 };
+/* montecarlo.jl:86-115: EulerMaruyama / BlackScholesExact / HestonBroadieKaya */
+enum hh_strategy { HH_EULER_MARUYAMA = 0, HH_EXACT_LAW = 1, HH_BROADIE_KAYA = 2 };
+enum hh_noise_mode { HH_NOISE_GENERATE = 0, HH_NOISE_REPLAY = 1 };
+enum hh_replay_layout { HH_REPLAY_TILE_MAJOR = 0, HH_REPLAY_PATH_MAJOR = 1 };
+
+typedef struct hh_ctx hh_ctx; /* opaque: device, stream, scratch */
+
+/*
+ * Model scalars after the host has resolved dates and curves exactly as the reference does:
+ *   T        = yearfrac(referenceDate, expiry)                      (montecarlo.jl:173,197)
+ *   r_drift  = zero_rate(rate, 0.0) for Euler (montecarlo.jl:176,200),
+ *              zero_rate(rate, expiry) for the exact laws (montecarlo.jl:299,318)
+ *   discount = df(rate, expiry)                                     (montecarlo.jl:489)
+ *   cp       = +1 call / -1 put                                     (payoffs.jl:76-87)
+ * Lognormal: sigma is the flat vol; V0, kappa, theta, rho are ignored.
+ * d* are the dual-number seeds: each is NULL or points to n_partials doubles, direction k of
+ * parameter θ being dθ[k].  (Spot enters as x0 = log S0, the library applies dx0 = dS0/S0.)
+ */
+typedef struct hh_model {
+  double S0, V0, kappa, theta, sigma, rho;
+  double r_drift, discount, T, strike, cp;
+  const double *dS0, *dV0, *dkappa, *dtheta, *dsigma, *dr_drift, *ddiscount, *dstrike;
+} hh_model;
+
+typedef struct hh_config {
+  int32_t dynamics;          /* enum hh_dynamics                                                  */
+  int32_t strategy;          /* enum hh_strategy                                                  */
+  int32_t antithetic;        /* 0 NoVarianceReduction, 1 Antithetic (montecarlo.jl:29-43)         */
+  int32_t em_split;          /* Euler diffusion evaluated at K=u+dt·f(u) (1) or at u (0)          */
+  int32_t compat_sqrt_alpha; /* exact lognormal mean uses (r-σ²/2)·√T as montecarlo.jl:302 (1)
+                                or the correct ·T (0); identical at T = 1                         */
+  int32_t noise_mode;        /* enum hh_noise_mode                                                */
+  int32_t replay_layout;     /* enum hh_replay_layout (REPLAY only)                               */
+  int32_t seeds_on_device;   /* seeds / replay / terminal point to device memory of ctx's device  */
+  int32_t replay_on_device;
+  int32_t terminal_on_device;
+  uint32_t n_steps;          /* SimulationConfig.steps (montecarlo.jl:60); exact laws ignore it   */
+  uint32_t n_partials;       /* 0..HH_MAX_PARTIALS                                                */
+  uint64_t n_paths;          /* SimulationConfig.trajectories of THIS shard                       */
+  uint64_t path_offset;      /* global index of this shard's first trajectory (exact laws draw by
+                                global index from ONE key, montecarlo.jl:456, so results do not
+                                depend on the sharding)                                           */
+  const uint64_t* seeds;     /* Euler: ≥ n_paths per-trajectory seeds (montecarlo.jl:331);
+                                exact laws: seeds[0] only (montecarlo.jl:456)                     */
+  const double* replay;      /* REPLAY: Wiener increments, see hh_replay_elems()                  */
+  /* Broadie–Kaya controls, defaults of sample_from_cf.jl:27,50,75,105-113 when 0 */
+  double bk_n_sigma;         /* n = 5                                                             */
+  double bk_cf_tol;          /* cf_tol = 1e-3                                                     */
+  double bk_atol;            /* atol = 1e-4                                                       */
+  double bk_moment_h;        /* h = 1e-2                                                          */
+  int32_t bk_newton_maxiter; /* 10                                                                */
+  int32_t bk_bisect_maxiter; /* 100                                                               */
+} hh_config;
+
+typedef struct hh_result {
+  double price;               /* discount · mean(payoff)            (montecarlo.jl:489-490)       */
+  double std_error;           /* build extension; the reference computes none                     */
+  double sum_payoff, sumsq_payoff;
+  double dprice[HH_MAX_PARTIALS]; /* partials of price, direction k                              */
+  uint64_t n_paths_done;
+  uint64_t bk_newton_fail, bk_bisect_fallback, bk_maxguess_fallback, bk_cf_terms;
+  double kernel_ms;           /* HIP-event time of the simulation + reduction kernels             */
+  double total_ms;            /* host wall time of the call                                       */
+} hh_result;
+
+int hh_abi_version(void);
+
+/* Context. device_id is a HIP device ordinal of this process. */
+int hh_ctx_create(hh_ctx** out, int device_id);
+void hh_ctx_destroy(hh_ctx* ctx);
+/* Borrow an external hipStream_t (e.g. PyTorch's current stream); NULL restores the ctx's own. */
+int hh_ctx_set_stream(hh_ctx* ctx, void* hip_stream);
+const char* hh_last_error(const hh_ctx* ctx); /* NUL-terminated, owned by ctx (or static if NULL) */
+
+/*
+ * Replaces the body of solve(prob, ::MonteCarlo) (montecarlo.jl:478-493): simulate, payoff,
+ * discount·mean.  Synchronous.  `terminal` (nullable) receives the samples at expiry that the
+ * reference keeps in MonteCarloSolution.ensemble (pricing_solutions.jl:22-27): n_paths doubles,
+ * followed by n_paths mirrored samples when antithetic.
+ */
+int hh_mc_solve(hh_ctx* ctx, const hh_model* model, const hh_config* cfg, hh_result* out,
+                double* terminal);
+
+/*
+ * Split form for path-sharded multi-GPU runs: enqueue simulation + reduction on the ctx stream and
+ * leave the HH_ACC_LEN accumulator doubles in DEVICE memory `accum_dev` (no host sync), so the
+ * caller can all-reduce them (RCCL) and then finalize on the host.
+ */
+int hh_mc_accumulate(hh_ctx* ctx, const hh_model* model, const hh_config* cfg, double* accum_dev,
+                     double* terminal);
+/* Pure host arithmetic: accumulator vector (HOST memory) -> price, std_error, dprice. */
+int hh_mc_finalize(const hh_model* model, const hh_config* cfg, const double* accum_host,
+                   hh_result* out);
+
+/*
+ * REPLAY increments.  Tile-major layout (what the step kernels stream):
+ *     dW[tile][step][comp][HH_TILE_PATHS],  tile = path / 256, comp < ncomp (1 lognormal, 2 Heston),
+ * the last tile zero-padded.  hh_replay_elems() = ceil(n_paths/256)·n_steps·ncomp·256 doubles.
+ * Path-major layout (what the reference's saved noise gives per trajectory, montecarlo.jl:258,370):
+ *     dW[path][step][comp]  (n_paths·n_steps·ncomp doubles); repacked on the device by
+ * hh_replay_pack() (hh_mc_solve does this itself when replay_layout = HH_REPLAY_PATH_MAJOR).
+ * For Heston the increments are the CORRELATED ones, cov = dt·[1 ρ; ρ 1] (heston.jl:18-20).
+ */
+size_t hh_replay_elems(uint64_t n_paths, uint32_t n_steps, int32_t dynamics);
+int hh_replay_pack(hh_ctx* ctx, int32_t dynamics, uint64_t n_paths, uint32_t n_steps,
+                   const double* src_path_major, int32_t src_on_device, double* dst_tile_major_dev);
+/*
+ * Fill a tile-major REPLAY buffer on the device with exactly the increments GENERATE mode would
+ * draw (Philox4x32-10 keyed by seeds[i], counter = step; Box–Muller; lower-triangular correlation).
+ */
+int hh_wiener_fill(hh_ctx* ctx, int32_t dynamics, double rho, double T, uint32_t n_steps,
+                   uint64_t n_paths, const uint64_t* seeds, int32_t seeds_on_device,
+                   double* dst_tile_major_dev);
+
+/* Device memory helpers for hosts without another allocator (the Julia wrapper). */
+int hh_device_malloc(hh_ctx* ctx, size_t bytes, void** out_dev);
+int hh_device_free(hh_ctx* ctx, void* dev);
+int hh_memcpy_h2d(hh_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
+int hh_memcpy_d2h(hh_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
+int hh_ctx_synchronize(hh_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HEDGEHOG_MC_H */
