@@ -85,6 +85,8 @@ SYMBOLS = [
     ("hh_memcpy_h2d", C.c_int, [_vp, _vp, _vp, C.c_size_t]),
     ("hh_memcpy_d2h", C.c_int, [_vp, _vp, _vp, C.c_size_t]),
     ("hh_ctx_synchronize", C.c_int, [_vp]),
+    ("hh_ctx_enable_timing", C.c_int, [_vp, C.c_int32]),
+    ("hh_ctx_read_timings", C.c_int, [_vp, _vp, C.c_int32, C.POINTER(C.c_int32)]),
 ]
 
 _lib = None
@@ -137,6 +139,16 @@ class Context:
 
     def synchronize(self):
         self.check(self.lib.hh_ctx_synchronize(self.handle))
+
+    def enable_timing(self, on: bool = True):
+        self.check(self.lib.hh_ctx_enable_timing(self.handle, int(on)))
+
+    def read_timings(self):
+        """ms of each simulation-kernel launch since the last read (syncs the stream)."""
+        buf = (C.c_double * 256)()
+        n = C.c_int32(0)
+        self.check(self.lib.hh_ctx_read_timings(self.handle, buf, 256, C.byref(n)))
+        return [buf[i] for i in range(n.value)]
 
     def close(self):
         if getattr(self, "handle", None):

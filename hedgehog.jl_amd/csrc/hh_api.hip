@@ -26,6 +26,11 @@ struct hh_ctx {
   size_t terminal_cap = 0;
   double* accum = nullptr;       // device, HH_ACC_LEN
   double* accum_host = nullptr;  // pinned, HH_ACC_LEN
+  // optional per-launch timing of the simulation kernel (hh_ctx_enable_timing)
+  static constexpr int kTimingSlots = 256;
+  bool timing = false;
+  hipEvent_t tev[kTimingSlots][2] = {};
+  int t_count = 0;  // pairs recorded since the last read (capped at kTimingSlots)
   char err[512] = {0};
 };
 
@@ -156,6 +161,9 @@ void hh_ctx_destroy(hh_ctx* ctx) {
   if (ctx->terminal) (void)hipFree(ctx->terminal);
   if (ctx->accum) (void)hipFree(ctx->accum);
   if (ctx->accum_host) (void)hipHostFree(ctx->accum_host);
+  for (auto& pr : ctx->tev)
+    for (auto& e : pr)
+      if (e) (void)hipEventDestroy(e);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -286,10 +294,16 @@ int hh_mc_accumulate(hh_ctx* ctx, const hh_model* m, const hh_config* c, double*
     }
   }
 
+  const int slot = ctx->t_count % hh_ctx::kTimingSlots;
+  if (ctx->timing) HH_HIP(ctx, hipEventRecord(ctx->tev[slot][0], ctx->stream));
   if (c->strategy == HH_BROADIE_KAYA)
     HH_HIP(ctx, hh::launch_bk(*m, *c, p, ctx->stream));
   else
     HH_HIP(ctx, hh::launch_simulation(*m, *c, p, ctx->stream));
+  if (ctx->timing) {
+    HH_HIP(ctx, hipEventRecord(ctx->tev[slot][1], ctx->stream));
+    ++ctx->t_count;
+  }
   HH_HIP(ctx, hh::launch_reduce_records(ctx->records, n_tiles, (double)c->n_paths, accum_dev,
                                         ctx->stream));
 
@@ -350,6 +364,34 @@ int hh_mc_solve(hh_ctx* ctx, const hh_model* m, const hh_config* c, hh_result* o
   out->kernel_ms = ms;
   out->total_ms =
       std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  return HH_OK;
+}
+
+int hh_ctx_enable_timing(hh_ctx* ctx, int32_t on) {
+  if (!ctx) return HH_ERR_INVALID;
+  HH_HIP(ctx, hipSetDevice(ctx->device));
+  if (on && !ctx->tev[0][0]) {
+    for (auto& pr : ctx->tev)
+      for (auto& e : pr) HH_HIP(ctx, hipEventCreate(&e));
+  }
+  ctx->timing = on != 0;
+  ctx->t_count = 0;
+  return HH_OK;
+}
+
+int hh_ctx_read_timings(hh_ctx* ctx, double* ms, int32_t cap, int32_t* n_out) {
+  if (!ctx || !ms || !n_out || cap < 0) return HH_ERR_INVALID;
+  HH_HIP(ctx, hipSetDevice(ctx->device));
+  HH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  int n = ctx->t_count < hh_ctx::kTimingSlots ? ctx->t_count : hh_ctx::kTimingSlots;
+  if (n > cap) n = cap;
+  for (int i = 0; i < n; ++i) {
+    float t = 0.f;
+    HH_HIP(ctx, hipEventElapsedTime(&t, ctx->tev[i][0], ctx->tev[i][1]));
+    ms[i] = t;
+  }
+  *n_out = n;
+  ctx->t_count = 0;
   return HH_OK;
 }
 

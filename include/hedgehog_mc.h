@@ -171,6 +171,16 @@ int hh_wiener_fill(hh_ctx* ctx, int32_t dynamics, double rho, double T, uint32_t
                    uint64_t n_paths, const uint64_t* seeds, int32_t seeds_on_device,
                    double* dst_tile_major_dev);
 
+/*
+ * Measurement hooks (the reference has no tracing; the build supplies its own).  When
+ * enabled, every hh_mc_accumulate / hh_mc_solve brackets its SIMULATION kernel (not the staging
+ * copies, not the record reduction) with HIP events on the ctx stream; hh_ctx_read_timings
+ * synchronizes the stream and returns the elapsed ms of the launches recorded since the last read
+ * (at most 256 are kept).
+ */
+int hh_ctx_enable_timing(hh_ctx* ctx, int32_t on);
+int hh_ctx_read_timings(hh_ctx* ctx, double* ms, int32_t cap, int32_t* n_out);
+
 /* Device memory helpers for hosts without another allocator (the Julia wrapper). */
 int hh_device_malloc(hh_ctx* ctx, size_t bytes, void** out_dev);
 int hh_device_free(hh_ctx* ctx, void* dev);

@@ -1,0 +1,234 @@
+"""Parity of the HIP path (through the C-ABI) with the CPU oracle on identical inputs.
+
+Tolerances (fp64; the BASELINE bar is 1e-4 relative on the price):
+  * REPLAY (identical Wiener increments): per-path samples 1e-12 rel, price 1e-12 rel
+  * GENERATE (same Philox stream, different libm for log/sincospi): per-path 1e-11 rel
+  * dual partials: 1e-10 rel on the accumulated Greeks
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from hedgehog_jl_amd import _ffi
+from tests import oracle_ffi as o
+
+pytestmark = pytest.mark.gpu
+
+GBM, HES = _ffi.HH_LOGNORMAL, _ffi.HH_HESTON
+EM, EXACT = _ffi.HH_EULER_MARUYAMA, _ffi.HH_EXACT_LAW
+GEN, REP = _ffi.HH_NOISE_GENERATE, _ffi.HH_NOISE_REPLAY
+
+
+def gpu_solve(ctx, model, cfg, want_terminal=True):
+    res = _ffi.hh_result()
+    n = cfg.n_paths * (2 if cfg.antithetic else 1)
+    term = np.zeros(n) if want_terminal else None
+    ctx.check(ctx.lib.hh_mc_solve(ctx.handle, C.byref(model), C.byref(cfg), C.byref(res),
+                                  term.ctypes.data if term is not None else None))
+    return res, term
+
+
+def seeds_for(n, salt=0):
+    return (np.arange(1, n + 1, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)
+            + np.uint64(salt))
+
+
+def check(res_g, term_g, res_o, term_o, P, rtol_path, rtol_price, rtol_d=1e-10):
+    np.testing.assert_allclose(term_g, term_o, rtol=rtol_path, atol=0)
+    assert res_g.n_paths_done == res_o.n_paths_done
+    assert res_g.price == pytest.approx(res_o.price, rel=rtol_price, abs=1e-300)
+    assert res_g.std_error == pytest.approx(res_o.std_error, rel=1e-8, abs=1e-14)
+    for k in range(P):
+        assert res_g.dprice[k] == pytest.approx(res_o.dprice[k], rel=rtol_d, abs=1e-12)
+
+
+HESTON_SEEDS = {"S0": [1, 0, 0], "V0": [0, 1, 0], "r_drift": [0, 0, 1],
+                "discount": [0, 0, -float(np.exp(-0.03))]}
+
+
+@pytest.mark.parametrize("n_paths", [1, 255, 256, 257, 1000, 4099])
+@pytest.mark.parametrize("n_steps", [1, 3, 4, 5, 8, 9, 100])
+def test_heston_euler_replay_ragged(hhlib, oracle, n_paths, n_steps):
+    seeds = seeds_for(n_paths)
+    dW = oracle.wiener_fill(HES, -0.7, 1.0, n_steps, seeds)
+    m = o.make_model()
+    c = o.make_config(HES, EM, n_paths, n_steps, noise_mode=REP, replay=dW)
+    rg, tg = gpu_solve(hhlib, m, c)
+    ro, to, _ = oracle.mc_solve(m, c)
+    check(rg, tg, ro, to, 0, 1e-12, 1e-12)
+
+
+@pytest.mark.parametrize("dyn", [GBM, HES])
+@pytest.mark.parametrize("anti", [0, 1])
+@pytest.mark.parametrize("noise", [GEN, REP])
+@pytest.mark.parametrize("P", [0, 1, 3, 5])
+@pytest.mark.parametrize("split", [1, 0])
+def test_euler_matrix(hhlib, oracle, dyn, anti, noise, P, split):
+    if dyn == GBM and split == 0:
+        pytest.skip("split is irrelevant for constant diffusion")
+    n_paths, n_steps = 3000, 50
+    seeds = seeds_for(n_paths, 7)
+    names = ["S0", "sigma", "r_drift", "strike", "V0"] if dyn == GBM else \
+        ["S0", "V0", "r_drift", "kappa", "sigma"]
+    sd = {}
+    for k in range(P):
+        v = [0.0] * P
+        v[k] = 1.0
+        sd[names[k]] = v
+    if P >= 3:  # the rate also moves the discount factor
+        sd["discount"] = [0.0, 0.0, -float(np.exp(-0.03))] + [0.0] * (P - 3)
+    m = o.make_model(sigma=0.2 if dyn == GBM else 0.3, seeds=sd, n_partials=P)
+    rep = oracle.wiener_fill(dyn, m.rho, m.T, n_steps, seeds) if noise == REP else None
+    c = o.make_config(dyn, EM, n_paths, n_steps, antithetic=anti, em_split=split, noise_mode=noise,
+                      seeds=seeds, replay=rep, n_partials=P)
+    rg, tg = gpu_solve(hhlib, m, c)
+    ro, to, _ = oracle.mc_solve(m, c)
+    check(rg, tg, ro, to, P, 1e-12 if noise == REP else 1e-11, 1e-12 if noise == REP else 1e-11)
+
+
+@pytest.mark.parametrize("cp", [1.0, -1.0])
+def test_put_and_call_q2_parameters(hhlib, oracle, cp):
+    """The parameter set the reference's own test actually runs: V0=1.5, κ=0.04, θ=0.3,
+    σ=-0.6 (negative vol-of-vol), ρ=0.04, r=0.05, T=364/365."""
+    n_paths, n_steps = 2000, 200
+    seeds = seeds_for(n_paths, 3)
+    m = o.make_model(S0=100, V0=1.5, kappa=0.04, theta=0.3, sigma=-0.6, rho=0.04, r=0.05,
+                     T=364 / 365, strike=100, cp=cp)
+    c = o.make_config(HES, EM, n_paths, n_steps, antithetic=1, seeds=seeds)
+    rg, tg = gpu_solve(hhlib, m, c)
+    ro, to, _ = oracle.mc_solve(m, c)
+    check(rg, tg, ro, to, 0, 1e-10, 1e-11)
+
+
+@pytest.mark.parametrize("anti", [0, 1])
+@pytest.mark.parametrize("P", [0, 3])
+@pytest.mark.parametrize("offset", [0, 1, 12345])
+@pytest.mark.parametrize("compat", [0, 1])
+def test_exact_lognormal(hhlib, oracle, anti, P, offset, compat):
+    n_paths = 5001
+    sd = {"S0": [1, 0, 0], "sigma": [0, 1, 0], "r_drift": [0, 0, 1],
+          "discount": [0, 0, -float(366 / 365 * np.exp(-0.03 * 366 / 365))]} if P else {}
+    m = o.make_model(S0=1.0, sigma=1.0, r=0.03, T=366 / 365, strike=1.0, seeds=sd, n_partials=P)
+    c = o.make_config(GBM, EXACT, n_paths, antithetic=anti, seeds=[42], n_partials=P,
+                      path_offset=offset, compat_sqrt_alpha=compat)
+    rg, tg = gpu_solve(hhlib, m, c)
+    ro, to, _ = oracle.mc_solve(m, c)
+    check(rg, tg, ro, to, P, 1e-12, 1e-12)
+
+
+def test_exact_lognormal_replay_normals(hhlib, oracle):
+    n = 777
+    z = np.random.default_rng(5).standard_normal(n)
+    m = o.make_model(S0=100, sigma=0.2, r=0.05, T=1.0, strike=90)
+    c = o.make_config(GBM, EXACT, n, antithetic=1, noise_mode=REP, replay=z)
+    rg, tg = gpu_solve(hhlib, m, c)
+    ro, to, _ = oracle.mc_solve(m, c)
+    check(rg, tg, ro, to, 0, 1e-13, 1e-13)
+
+
+def test_exact_sharding_is_invisible(hhlib):
+    """Exact laws draw by GLOBAL trajectory index from one key (montecarlo.jl:456), so two shards
+    reproduce the single-shard samples exactly."""
+    n = 6000
+    m = o.make_model(S0=100, sigma=0.2, r=0.05, T=1.0, strike=100)
+    full = gpu_solve(hhlib, m, o.make_config(GBM, EXACT, n, seeds=[9]))[1]
+    a = gpu_solve(hhlib, m, o.make_config(GBM, EXACT, 2501, seeds=[9]))[1]
+    b = gpu_solve(hhlib, m, o.make_config(GBM, EXACT, n - 2501, seeds=[9], path_offset=2501))[1]
+    np.testing.assert_array_equal(full, np.concatenate([a, b]))
+
+
+@pytest.mark.parametrize("dyn", [GBM, HES])
+@pytest.mark.parametrize("n_paths,n_steps", [(1, 1), (300, 7), (1025, 33)])
+def test_wiener_fill_matches_oracle(hhlib, oracle, dyn, n_paths, n_steps):
+    import torch
+    seeds = seeds_for(n_paths, 11)
+    want = oracle.wiener_fill(dyn, -0.7, 1.5, n_steps, seeds)
+    n = hhlib.lib.hh_replay_elems(n_paths, n_steps, dyn)
+    assert n == want.size
+    buf = torch.full((n,), float("nan"), dtype=torch.float64, device="cuda")
+    hhlib.check(hhlib.lib.hh_wiener_fill(hhlib.handle, dyn, -0.7, 1.5, n_steps, n_paths,
+                                         seeds.ctypes.data, 0, buf.data_ptr()))
+    hhlib.synchronize()
+    np.testing.assert_allclose(buf.cpu().numpy(), want, rtol=0, atol=2e-15)
+
+
+@pytest.mark.parametrize("dyn", [GBM, HES])
+@pytest.mark.parametrize("n_paths,n_steps", [(1, 1), (300, 7), (1025, 33)])
+def test_replay_pack_bit_exact(hhlib, oracle, dyn, n_paths, n_steps):
+    import torch
+    nc = 2 if dyn == HES else 1
+    src = np.random.default_rng(1).standard_normal((n_paths, n_steps, nc))
+    want = oracle.replay_pack(dyn, n_paths, n_steps, src)
+    buf = torch.full((want.size,), float("nan"), dtype=torch.float64, device="cuda")
+    hhlib.check(hhlib.lib.hh_replay_pack(hhlib.handle, dyn, n_paths, n_steps, src.ctypes.data, 0,
+                                         buf.data_ptr()))
+    hhlib.synchronize()
+    np.testing.assert_array_equal(buf.cpu().numpy(), want)
+
+
+def test_path_major_replay_equals_tile_major(hhlib, oracle):
+    n_paths, n_steps = 700, 12
+    src = np.random.default_rng(2).standard_normal((n_paths, n_steps, 2)) * 0.05
+    m = o.make_model()
+    c1 = o.make_config(HES, EM, n_paths, n_steps, noise_mode=REP, replay=src,
+                       replay_layout=_ffi.HH_REPLAY_PATH_MAJOR)
+    c2 = o.make_config(HES, EM, n_paths, n_steps, noise_mode=REP,
+                       replay=oracle.replay_pack(HES, n_paths, n_steps, src))
+    r1, t1 = gpu_solve(hhlib, m, c1)
+    r2, t2 = gpu_solve(hhlib, m, c2)
+    np.testing.assert_array_equal(t1, t2)
+    assert r1.price == r2.price
+    ro, to, _ = oracle.mc_solve(m, c1)
+    np.testing.assert_allclose(t1, to, rtol=1e-12)
+
+
+def test_device_resident_inputs(hhlib, oracle):
+    """seeds / replay / terminal living in HBM (the bench configuration)."""
+    import torch
+    n_paths, n_steps = 2048 + 17, 20
+    seeds = seeds_for(n_paths, 5)
+    m = o.make_model()
+    c = o.make_config(HES, EM, n_paths, n_steps, seeds=seeds)
+    ro, to, _ = oracle.mc_solve(m, c)
+    d_seeds = torch.from_numpy(seeds.view(np.int64)).cuda()
+    d_term = torch.zeros(n_paths, dtype=torch.float64, device="cuda")
+    c.seeds = d_seeds.data_ptr()
+    c.seeds_on_device = 1
+    c.terminal_on_device = 1
+    res = _ffi.hh_result()
+    hhlib.check(hhlib.lib.hh_mc_solve(hhlib.handle, C.byref(m), C.byref(c), C.byref(res),
+                                      d_term.data_ptr()))
+    np.testing.assert_allclose(d_term.cpu().numpy(), to, rtol=1e-11)
+    # same draws through a device-resident REPLAY buffer
+    n = hhlib.lib.hh_replay_elems(n_paths, n_steps, HES)
+    d_rep = torch.empty(n, dtype=torch.float64, device="cuda")
+    hhlib.check(hhlib.lib.hh_wiener_fill(hhlib.handle, HES, m.rho, m.T, n_steps, n_paths,
+                                         d_seeds.data_ptr(), 1, d_rep.data_ptr()))
+    c.noise_mode, c.replay, c.replay_on_device = REP, d_rep.data_ptr(), 1
+    res2 = _ffi.hh_result()
+    hhlib.check(hhlib.lib.hh_mc_solve(hhlib.handle, C.byref(m), C.byref(c), C.byref(res2),
+                                      d_term.data_ptr()))
+    assert res2.price == pytest.approx(res.price, rel=1e-13)
+    assert res.price == pytest.approx(ro.price, rel=1e-11)
+
+
+def test_error_codes(hhlib):
+    m = o.make_model()
+    res = _ffi.hh_result()
+    lib, h = hhlib.lib, hhlib.handle
+
+    def rc(cfg, model=m):
+        return lib.hh_mc_solve(h, C.byref(model), C.byref(cfg), C.byref(res), None)
+
+    assert rc(o.make_config(HES, EM, 0, 10, seeds=[1])) == _ffi.HH_ERR_INVALID
+    assert rc(o.make_config(HES, EM, 10, 0, seeds=np.arange(10))) == _ffi.HH_ERR_INVALID
+    assert rc(o.make_config(HES, EXACT, 10, seeds=[1])) == _ffi.HH_ERR_UNSUPPORTED
+    assert rc(o.make_config(GBM, _ffi.HH_BROADIE_KAYA, 10, seeds=[1])) == _ffi.HH_ERR_UNSUPPORTED
+    assert rc(o.make_config(HES, _ffi.HH_BROADIE_KAYA, 10, antithetic=1, seeds=[1])) == \
+        _ffi.HH_ERR_UNSUPPORTED
+    assert rc(o.make_config(HES, EM, 10, 5)) == _ffi.HH_ERR_INVALID          # no seeds
+    assert rc(o.make_config(HES, EM, 10, 5, noise_mode=REP)) == _ffi.HH_ERR_INVALID  # no replay
+    assert b"replay" in lib.hh_last_error(h)
+    bad = o.make_model(S0=-1.0)
+    assert rc(o.make_config(HES, EM, 10, 5, seeds=np.arange(10)), bad) == _ffi.HH_ERR_INVALID
