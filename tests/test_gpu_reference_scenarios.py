@@ -1,0 +1,186 @@
+"""The reference's own Monte Carlo agreement tests, re-run through the host mirror of its API on
+the HIP path (test/agreement/montecarlo_black_scholes.jl, montecarlo_heston.jl,
+greeks_agreement.jl:170-241), plus full-size property checks of BASELINE.json's configurations."""
+import numpy as np
+import pytest
+
+import hedgehog_jl_amd as hh
+from oracle import analytic
+
+pytestmark = pytest.mark.gpu
+
+
+def bs_problem(S=100.0, K=100.0, r=0.05, sigma=0.2, ref=hh.Date(2020, 1, 1), expiry=None,
+               cp=None):
+    expiry = expiry or hh.add_years(ref, 1)
+    payoff = hh.VanillaOption(K, expiry, hh.European(), cp or hh.Call(), hh.Spot())
+    return hh.PricingProblem(payoff, hh.BlackScholesInputs(ref, r, S, sigma))
+
+
+def heston_problem(ref=hh.Date(2020, 1, 1), expiry=None, params=(0.04, 2.0, 0.04, 0.3, -0.7),
+                   r=0.03):
+    expiry = expiry or hh.add_years(ref, 1)
+    payoff = hh.VanillaOption(100.0, expiry, hh.European(), hh.Call(), hh.Spot())
+    return hh.PricingProblem(payoff, hh.HestonInputs(ref, r, 100.0, *params))
+
+
+@pytest.mark.parametrize("strategy", [hh.BlackScholesExact(), hh.EulerMaruyama()])
+def test_black_scholes_mc_vs_analytic(strategy):
+    """montecarlo_black_scholes.jl:52-151."""
+    prob = bs_problem()
+    ref = analytic.bs_price(100, 100, 0.05, 0.2, 366 / 365)
+    var = {}
+    for vr in (hh.NoVarianceReduction(), hh.Antithetic()):
+        prices = []
+        for trial in range(1, 6):
+            seeds = np.random.default_rng(42 + trial).integers(1, 10**9, 10_000)
+            cfg = hh.SimulationConfig(10_000, seeds=seeds, variance_reduction=vr)
+            sol = hh.solve(prob, hh.MonteCarlo(hh.LognormalDynamics(), strategy, cfg))
+            prices.append(sol.price)
+            ens = sol.ensemble
+            if isinstance(vr, hh.Antithetic):
+                assert isinstance(ens, tuple) and len(ens[0]) == len(ens[1]) == 10_000
+            else:
+                assert ens.shape == (10_000,)
+        assert np.mean(prices) == pytest.approx(ref, rel=0.02)
+        var[type(vr).__name__] = np.var(prices)
+    assert var["NoVarianceReduction"] / var["Antithetic"] > 1.0
+
+
+def test_solution_is_consistent_with_its_ensemble():
+    """price == df · mean(payoff.(ensemble))  (montecarlo.jl:488-490)."""
+    prob = heston_problem()
+    for vr in (hh.NoVarianceReduction(), hh.Antithetic()):
+        cfg = hh.SimulationConfig(5000, steps=30, seeds=np.arange(1, 5001), variance_reduction=vr)
+        sol = hh.solve(prob, hh.MonteCarlo(hh.HestonDynamics(), hh.EulerMaruyama(), cfg))
+        D = hh.df(prob.market_inputs.rate, prob.payoff.expiry)
+        if isinstance(sol.ensemble, tuple):
+            pay = (prob.payoff(sol.ensemble[0]) + prob.payoff(sol.ensemble[1])) / 2
+        else:
+            pay = prob.payoff(sol.ensemble)
+        assert sol.price == pytest.approx(D * pay.mean(), rel=1e-12)
+        assert sol.problem is prob and sol.method.config is cfg
+
+
+def test_heston_euler_vs_carr_madan():
+    """montecarlo_heston.jl:8-126."""
+    prob = heston_problem()
+    ref = analytic.carr_madan_heston(100, 100, 0.03, 0.04, 2.0, 0.04, 0.3, -0.7, 366 / 365)
+    var = {}
+    for n, vr in ((5000, hh.NoVarianceReduction()), (2500, hh.Antithetic())):
+        prices = []
+        for trial in range(1, 6):
+            seeds = np.random.default_rng(42 + trial).integers(1, 10**9, 5000)
+            cfg = hh.SimulationConfig(n, steps=100, seeds=seeds, variance_reduction=vr)
+            prices.append(hh.solve(prob, hh.MonteCarlo(hh.HestonDynamics(), hh.EulerMaruyama(),
+                                                       cfg)).price)
+        assert np.mean(prices) == pytest.approx(ref, rel=0.05)
+        var[n] = np.var(prices)
+    assert var[5000] / var[2500] > 1.0
+
+
+def test_mc_greeks_vs_analytic():
+    """greeks_agreement.jl:170-241."""
+    prob = bs_problem(S=1.0, K=1.0, r=0.03, sigma=1.0, expiry=hh.Date(2021, 1, 1))
+    seeds = np.random.default_rng(42).integers(1, 10**9, 100_000)
+    mc = hh.MonteCarlo(hh.LognormalDynamics(), hh.BlackScholesExact(),
+                       hh.SimulationConfig(100_000, seeds=seeds))
+    T = 366 / 365
+    g = analytic.bs_greeks(1.0, 1.0, 0.03, 1.0, T)
+    assert hh.solve(prob, mc).price == pytest.approx(analytic.bs_price(1, 1, 0.03, 1.0, T), rel=3e-2)
+    spot_lens, vol_lens, rate_lens = hh.optic("market_inputs.spot"), hh.VolLens(1, 1), \
+        hh.ZeroRateSpineLens(1)
+    delta = hh.solve(hh.GreekProblem(prob, spot_lens), hh.ForwardAD(), mc).greek
+    vega = hh.solve(hh.GreekProblem(prob, vol_lens), hh.ForwardAD(), mc).greek
+    rho = hh.solve(hh.GreekProblem(prob, rate_lens), hh.ForwardAD(), mc).greek
+    assert delta == pytest.approx(g["delta"], rel=3e-2)
+    assert vega == pytest.approx(g["vega"], rel=1e-1)
+    assert rho == pytest.approx(g["rho"], rel=1e-2)
+    # one fused pass gives the same three numbers (greeks_problem.jl:559-568)
+    batch = hh.solve(hh.BatchGreekProblem(prob, (spot_lens, vol_lens, rate_lens)), hh.ForwardAD(), mc)
+    assert batch[spot_lens] == pytest.approx(delta, rel=1e-12)
+    assert batch[vol_lens] == pytest.approx(vega, rel=1e-12)
+    assert batch[rate_lens] == pytest.approx(rho, rel=1e-12)
+    # finite differences on top of solve, common random numbers (greeks_problem.jl:279-329)
+    for scheme in (hh.FDCentral(), hh.FDForward(), hh.FDBackward()):
+        fd = hh.solve(hh.GreekProblem(prob, spot_lens), hh.FiniteDifference(1e-4, scheme), mc).greek
+        assert fd == pytest.approx(delta, rel=2e-3)
+
+
+def test_config5_batch_greeks_heston_euler_full_size():
+    """BASELINE config 5: (Δ, ν≡∂V0, ρ) through Heston Euler, 10^6 paths x 252 steps, one fused
+    pass; checked against the Fourier derivatives within MC error + Euler bias, and
+    against central finite differences on the same seeds."""
+    prob = heston_problem(ref=hh.Date(2021, 1, 1), expiry=hh.Date(2022, 1, 1))  # T = 1 exactly
+    n = 1_000_000
+    mc = hh.MonteCarlo(hh.HestonDynamics(), hh.EulerMaruyama(),
+                       hh.SimulationConfig(n, steps=252, seeds=np.arange(1, n + 1)))
+    lenses = (hh.optic("market_inputs.spot"), hh.optic("market_inputs.V0"),
+              hh.optic("market_inputs.rate.rate"))
+    g = hh.solve(hh.BatchGreekProblem(prob, lenses), hh.ForwardAD(), mc)
+    sol = hh.solve(prob, mc, ensemble=False)
+    assert sol.price == pytest.approx(9.242521073959068, abs=4 * sol.std_error + 0.02)
+    assert g[lenses[0]] == pytest.approx(0.65565115, rel=1e-2)
+    assert g[lenses[1]] == pytest.approx(40.7248418, rel=3e-2)
+    assert g[lenses[2]] == pytest.approx(56.3225943, rel=1e-2)
+    for lens in lenses:
+        fd = hh.solve(hh.GreekProblem(prob, lens), hh.FiniteDifference(1e-5), mc).greek
+        assert g[lens] == pytest.approx(fd, rel=5e-4)
+
+
+def test_config2_exact_lognormal_full_size():
+    """BASELINE config 2: 10^6 exact lognormal samples vs BlackScholesAnalytic within 3 std errors."""
+    prob = bs_problem(ref=hh.Date(2021, 1, 1), expiry=hh.Date(2022, 1, 1))
+    n = 1_000_000
+    for vr in (hh.NoVarianceReduction(), hh.Antithetic()):
+        mc = hh.MonteCarlo(hh.LognormalDynamics(), hh.BlackScholesExact(),
+                           hh.SimulationConfig(n, seeds=[20240101] * n, variance_reduction=vr))
+        sol = hh.solve(prob, mc)
+        assert sol.price == pytest.approx(10.450583572185565, abs=3 * sol.std_error)
+        S = sol.ensemble[0] if isinstance(sol.ensemble, tuple) else sol.ensemble
+        # martingale: E[S_T] = S0 e^{rT}
+        assert S.mean() == pytest.approx(100 * np.exp(0.05), rel=2e-3)
+
+
+def test_config3_full_size_properties():
+    """BASELINE config 3 at full size (10^6 x 252): size-independent properties.
+      * GENERATE and REPLAY-of-the-same-draws agree to rounding;
+      * two path shards' accumulators add up to the single-shard ones (what the all-reduce does);
+      * put-call parity of the MC estimators: C - P = D (E[S_T] - K) on the same paths."""
+    import ctypes as C
+
+    import torch
+
+    from hedgehog_jl_amd import _ffi
+    from tests import oracle_ffi as o
+    ctx = hh.get_context(0)
+    lib, h = ctx.lib, ctx.handle
+    n, steps = 1_000_000, 252
+    seeds = torch.arange(1, n + 1, dtype=torch.int64, device="cuda")
+    m = o.make_model()
+    dW = torch.empty(lib.hh_replay_elems(n, steps, 1), dtype=torch.float64, device="cuda")
+    ctx.check(lib.hh_wiener_fill(h, 1, m.rho, m.T, steps, n, seeds.data_ptr(), 1, dW.data_ptr()))
+    term = torch.empty(n, dtype=torch.float64, device="cuda")
+
+    def run(noise, n_paths=n, seed_off=0, cp=1.0, want_term=False):
+        mm = o.make_model(cp=cp)
+        c = o.make_config(1, 0, n_paths, steps, noise_mode=noise)
+        c.seeds, c.seeds_on_device = seeds.data_ptr() + 8 * seed_off, 1
+        c.replay, c.replay_on_device, c.terminal_on_device = dW.data_ptr(), 1, 1
+        r = _ffi.hh_result()
+        ctx.check(lib.hh_mc_solve(h, C.byref(mm), C.byref(c), C.byref(r),
+                                  term.data_ptr() if want_term else None))
+        return r
+
+    gen, rep = run(0, want_term=True), run(1)
+    assert rep.price == pytest.approx(gen.price, rel=1e-13)
+    assert gen.price == pytest.approx(9.242521073959068, abs=4 * gen.std_error + 0.02)
+    half = 499_968  # a multiple of the 256-path tile, so shard tiles coincide with the full run's
+    a, b = run(0, half), run(0, n - half, seed_off=half)
+    assert a.sum_payoff + b.sum_payoff == pytest.approx(gen.sum_payoff, rel=1e-13)
+    assert a.sumsq_payoff + b.sumsq_payoff == pytest.approx(gen.sumsq_payoff, rel=1e-13)
+    put = run(0, cp=-1.0)
+    D = float(np.exp(-0.03))
+    ES = float(term.mean().item())
+    assert gen.price - put.price == pytest.approx(D * (ES - 100.0), rel=1e-10)
+    assert ES == pytest.approx(100 * np.exp(0.03), rel=1e-3)  # martingale check

@@ -1,0 +1,168 @@
+"""Host mirror of the reference's operator interface — everything that needs no GPU."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import hedgehog_jl_amd as hh
+from hedgehog_jl_amd import _ffi
+from hedgehog_jl_amd.montecarlo import _model_and_config
+from tests.conftest import HAS_GPU, ROOT
+
+
+def heston_problem(cp=hh.Call()):
+    ref = hh.Date(2020, 1, 1)
+    payoff = hh.VanillaOption(100.0, hh.add_years(ref, 1), hh.European(), cp, hh.Spot())
+    return hh.PricingProblem(payoff, hh.HestonInputs(ref, 0.03, 100.0, 0.04, 2.0, 0.04, 0.3, -0.7))
+
+
+def bs_problem():
+    ref = hh.Date(2020, 1, 1)
+    payoff = hh.VanillaOption(1.0, hh.Date(2021, 1, 1), hh.European(), hh.Call(), hh.Spot())
+    return hh.PricingProblem(payoff, hh.BlackScholesInputs(ref, 0.03, 1.0, 1.0))
+
+
+def test_yearfrac_act365():
+    assert hh.yearfrac(hh.Date(2020, 1, 1), hh.Date(2021, 1, 1)) == 366 / 365
+    assert hh.yearfrac(hh.Date(2021, 1, 1), hh.Date(2022, 1, 1)) == 1.0
+    assert hh.to_ticks(hh.Date(1, 1, 1)) == 366 * 86400000  # Julia: date2epochdays(Date(1)) == 366
+    assert hh.to_ticks(12345) == 12345
+
+
+def test_simulation_config_contract():
+    cfg = hh.SimulationConfig(10)
+    assert cfg.steps == 1 and isinstance(cfg.variance_reduction, hh.NoVarianceReduction)
+    assert cfg.seeds.dtype == np.uint64 and len(cfg.seeds) == 10
+    with pytest.raises(ValueError, match="must be ≥ number of trajectories"):  # montecarlo.jl:65-66
+        hh.SimulationConfig(10, seeds=[1, 2, 3])
+    c2 = cfg.replace(seeds=np.arange(20), variance_reduction=hh.Antithetic())
+    assert c2.trajectories == 10 and isinstance(c2.variance_reduction, hh.Antithetic)
+
+
+def test_model_packing_heston_euler():
+    prob = heston_problem()
+    method = hh.MonteCarlo(hh.HestonDynamics(), hh.EulerMaruyama(),
+                           hh.SimulationConfig(100, steps=50, variance_reduction=hh.Antithetic()))
+    m, c, _, P, D = _model_and_config(prob, method)
+    assert (c.dynamics, c.strategy, c.antithetic, c.n_steps, c.n_paths) == (1, 0, 1, 50, 100)
+    assert m.T == 366 / 365 and m.r_drift == 0.03 and m.cp == 1.0 and P == 0
+    assert m.discount == pytest.approx(np.exp(-0.03 * 366 / 365), rel=1e-15)
+    assert (m.V0, m.kappa, m.theta, m.sigma, m.rho) == (0.04, 2.0, 0.04, 0.3, -0.7)
+
+
+def test_model_packing_duals():
+    prob = bs_problem()
+    method = hh.MonteCarlo(hh.LognormalDynamics(), hh.BlackScholesExact(), hh.SimulationConfig(10))
+    p2 = hh.set(prob, hh.ZeroRateSpineLens(1), hh.Dual(0.03, (1.0,)))
+    m, c, keep, P, D = _model_and_config(p2, method)
+    assert P == 1 and c.n_partials == 1 and c.strategy == _ffi.HH_EXACT_LAW
+    assert m.dr_drift[0] == 1.0
+    T = 366 / 365
+    assert m.ddiscount[0] == pytest.approx(-T * np.exp(-0.03 * T), rel=1e-14)  # rate_curve.jl:149
+    assert not m.dS0 and not m.dsigma
+    p3 = hh.set(prob, hh.VolLens(1, 1), hh.Dual(1.0, (1.0,)))
+    m, *_ = _model_and_config(p3, method)
+    assert m.dsigma[0] == 1.0 and not m.dr_drift
+
+
+def test_unsupported_combinations_raise_method_error():
+    prob = heston_problem()
+    cfg = hh.SimulationConfig(10)
+    with pytest.raises(hh.MethodError):  # Heston inputs + lognormal dynamics: no sde_problem method
+        _model_and_config(prob, hh.MonteCarlo(hh.LognormalDynamics(), hh.EulerMaruyama(), cfg))
+    with pytest.raises(hh.MethodError):
+        _model_and_config(prob, hh.MonteCarlo(hh.HestonDynamics(), hh.BlackScholesExact(), cfg))
+    amer = hh.PricingProblem(hh.VanillaOption(100.0, hh.Date(2021, 1, 1), hh.American(), hh.Call(),
+                                              hh.Spot()), prob.market_inputs)
+    with pytest.raises(hh.MethodError):  # montecarlo.jl:479: European + Spot only
+        _model_and_config(amer, hh.MonteCarlo(hh.HestonDynamics(), hh.EulerMaruyama(), cfg))
+    with pytest.raises(hh.MethodError):
+        hh.solve(prob, "not a method")
+    with pytest.raises(TypeError):  # pricing_methods.jl:30-36: no ZeroRateSpineLens getter for Heston
+        hh.ZeroRateSpineLens(1)(prob)
+    with pytest.raises(TypeError):  # greeks_problem.jl:66-69: HestonInputs has no sigma surface
+        hh.VolLens(1, 1)(prob)
+
+
+def test_lenses_get_set():
+    prob = heston_problem()
+    for lens, val in ((hh.SpotLens(), 100.0), (hh.optic("market_inputs.spot"), 100.0),
+                      (hh.optic("_.market_inputs.V0"), 0.04),
+                      (hh.optic("market_inputs.rate.rate"), 0.03)):
+        assert lens(prob) == val
+        p2 = hh.set(prob, lens, val * 2)
+        assert lens(p2) == val * 2 and lens(prob) == val  # functional update
+    bs = bs_problem()
+    assert hh.VolLens(1, 1)(bs) == 1.0 and hh.ZeroRateSpineLens(1)(bs) == 0.03
+    assert hh.ZeroRateSpineLens(1)(hh.set(bs, hh.ZeroRateSpineLens(1), 0.05)) == 0.05
+    assert hh.VolLens(1, 1)(hh.set(bs, hh.VolLens(1, 1), 0.5)) == 0.5
+    assert len({hh.SpotLens(): 1, hh.optic("market_inputs.spot"): 2, hh.VolLens(1, 1): 3}) == 3
+
+
+def test_dual_arithmetic():
+    from hedgehog_jl_amd.dual import dexp, dlog
+    x = hh.Dual(2.0, (1.0, 0.0))
+    y = hh.Dual(3.0, (0.0, 1.0))
+    z = dexp(-x * y) + dlog(x) / y - 2 * x ** 2
+    assert z.value == pytest.approx(np.exp(-6) + np.log(2) / 3 - 8)
+    assert z.partials[0] == pytest.approx(-3 * np.exp(-6) + 1 / 6 - 8)
+    assert z.partials[1] == pytest.approx(-2 * np.exp(-6) - np.log(2) / 9)
+    assert (1 - x).partials == (-1.0, 0.0) and (1 / x).partials[0] == -0.25
+    assert x > 1 and x < y
+
+
+def test_cabi_header_and_library_agree():
+    """Every function include/hedgehog_mc.h declares is bound in _ffi.SYMBOLS and exported by the
+    built library (no compute call is made here)."""
+    hdr = open(os.path.join(ROOT, "include", "hedgehog_mc.h")).read()
+    declared = set(re.findall(r"^\s*(?:int|void|size_t|const char\*)\s+(hh_\w+)\s*\(", hdr, re.M))
+    bound = {s[0] for s in _ffi.SYMBOLS}
+    assert declared == bound, declared ^ bound
+    lib = hh.load_library()
+    for name in declared:
+        assert hasattr(lib, name)
+    assert lib.hh_abi_version() == 1
+    assert lib.hh_replay_elems(257, 3, 1) == 2 * 3 * 2 * 256
+    assert lib.hh_replay_elems(256, 5, 0) == 5 * 256
+    # struct layouts seen by ctypes == what the compiler laid out (sizes are part of the ABI)
+    assert C.sizeof(_ffi.hh_model) == 11 * 8 + 8 * 8
+    assert C.sizeof(_ffi.hh_result) == 4 * 8 + 8 * 8 + 5 * 8 + 2 * 8
+    assert C.sizeof(_ffi.hh_config) == 10 * 4 + 2 * 4 + 2 * 8 + 2 * 8 + 4 * 8 + 2 * 4
+
+
+def test_finalize_is_pure_host_arithmetic():
+    lib = hh.load_library()
+    from tests import oracle_ffi as o
+    T = 1.0
+    m = o.make_model(seeds={"discount": [-T * np.exp(-0.03)]}, n_partials=1)
+    c = o.make_config(1, 0, 4, 1, n_partials=1)
+    acc = np.zeros(16)
+    acc[0], acc[1], acc[2], acc[10] = 10.0, 30.0, 2.0, 4.0
+    r = _ffi.hh_result()
+    assert lib.hh_mc_finalize(C.byref(m), C.byref(c), acc.ctypes.data, C.byref(r)) == 0
+    D = np.exp(-0.03)
+    assert r.price == pytest.approx(D * 2.5)
+    assert r.std_error == pytest.approx(D * np.sqrt(((30 - 4 * 2.5**2) / 3) / 4))
+    assert r.dprice[0] == pytest.approx(-T * D * 2.5 + D * 0.5)
+
+
+@pytest.mark.skipif(HAS_GPU, reason="checks the no-GPU failure mode")
+def test_product_fails_loudly_without_gpu():
+    """No CPU fallback: without a HIP device the product path raises, it does not compute."""
+    with pytest.raises(hh.HedgehogMCError):
+        hh.Context(0)
+    prob = heston_problem()
+    with pytest.raises(hh.HedgehogMCError):
+        hh.solve(prob, hh.MonteCarlo(hh.HestonDynamics(), hh.EulerMaruyama(),
+                                     hh.SimulationConfig(16, steps=4)))
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "hedgehog.jl_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "oracle" not in src.lower(), (dirpath, f)
