@@ -95,6 +95,15 @@ void hho_normal_pair(uint64_t key, uint32_t c0, uint32_t c1, uint32_t c2, uint32
   *z2 = r * s;
 }
 
+/* two U(0,1) from the Philox block of (key, c0, c1, c2, domain) — used by oracle/bk_oracle.py */
+void hho_uniform_pair(uint64_t key, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t dom, double* u1,
+                      double* u2) {
+  uint32_t ctr[4] = {c0, c1, c2, dom}, k[2] = {(uint32_t)key, (uint32_t)(key >> 32)}, o[4];
+  hho_philox4x32_10(ctr, k, o);
+  *u1 = u01(o[0], o[1]);
+  *u2 = u01(o[2], o[3]);
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* REPLAY buffers                                                                              */
 /* ------------------------------------------------------------------------------------------ */
