@@ -14,6 +14,7 @@ from .greeks import (BatchGreekProblem, FDBackward, FDCentral, FDForward, Finite
 from .montecarlo import (AbstractPricingMethod, Antithetic, BlackScholesExact, EulerMaruyama,
                          HestonBroadieKaya, HestonDynamics, LognormalDynamics, MethodError,
                          MonteCarlo, NoVarianceReduction, SimulationConfig, solve_montecarlo)
+from .distributed import shard_range, solve_sharded
 from .domain import (American, BlackScholesInputs, Call, European, FlatRateCurve, FlatVolSurface,
                     Forward, HestonInputs, MonteCarloSolution, PricingProblem, Put, Spot,
                     VanillaOption, df, get_vol, zero_rate)

@@ -184,3 +184,20 @@ def test_config3_full_size_properties():
     ES = float(term.mean().item())
     assert gen.price - put.price == pytest.approx(D * (ES - 100.0), rel=1e-10)
     assert ES == pytest.approx(100 * np.exp(0.03), rel=1e-3)  # martingale check
+
+
+def test_solve_sharded_hip_path_world1():
+    """The sharded driver on the HIP path (device-resident accumulators, no process group) agrees
+    with plain solve()."""
+    prob = heston_problem()
+    n = 50_001
+    mc = hh.MonteCarlo(hh.HestonDynamics(), hh.EulerMaruyama(),
+                       hh.SimulationConfig(n, steps=50, seeds=np.arange(1, n + 1),
+                                           variance_reduction=hh.Antithetic()))
+    a = hh.solve(prob, mc, ensemble=False)
+    b = hh.solve_sharded(prob, mc)
+    assert b.price == pytest.approx(a.price, rel=1e-14)
+    assert b.std_error == pytest.approx(a.std_error, rel=1e-12)
+    p2 = hh.set(prob, hh.optic("market_inputs.V0"), hh.Dual(0.04, (1.0,)))
+    ga, gb = hh.solve(p2, mc, ensemble=False).price, hh.solve_sharded(p2, mc).price
+    assert gb.partials[0] == pytest.approx(ga.partials[0], rel=1e-13)
