@@ -1,0 +1,154 @@
+# HedgehogMC.jl — thin Julia host layer over libhedgehog_mc.so (include/hedgehog_mc.h).
+#
+# WRITTEN WITHOUT A JULIA TOOLCHAIN: neither the build image nor the GPU box has `julia`, so this
+# file has never been executed.  It is the reference-side binding a Hedgehog.jl maintainer would
+# add (INTEGRATION.md); the same C-ABI is exercised for real by the Python mirror and the tests.
+#
+# Usage (on a host with Julia, Hedgehog.jl, ForwardDiff and a built libhedgehog_mc.so):
+#     include("julia/HedgehogMC.jl"); using .HedgehogMC
+#     HedgehogMC.install!()          # route Hedgehog.solve(::PricingProblem, ::MonteCarlo) to the GPU
+#     sol = Hedgehog.solve(prob, MonteCarlo(HestonDynamics(), EulerMaruyama(), cfg))
+module HedgehogMC
+
+using Hedgehog
+using ForwardDiff
+import Hedgehog: PricingProblem, VanillaOption, European, Spot, MonteCarlo, MonteCarloSolution,
+                 LognormalDynamics, HestonDynamics, EulerMaruyama, BlackScholesExact,
+                 HestonBroadieKaya, Antithetic, BlackScholesInputs, HestonInputs,
+                 yearfrac, zero_rate, df, get_vol
+
+const LIB = Ref{String}(get(ENV, "HEDGEHOG_MC_LIB",
+                            joinpath(@__DIR__, "..", "hedgehog.jl_amd", "lib", "libhedgehog_mc.so")))
+
+const HH_MAX_PARTIALS = 8
+
+# ---- C structs (layout of include/hedgehog_mc.h) ---------------------------------------------
+struct HHModel
+    S0::Cdouble; V0::Cdouble; kappa::Cdouble; theta::Cdouble; sigma::Cdouble; rho::Cdouble
+    r_drift::Cdouble; discount::Cdouble; T::Cdouble; strike::Cdouble; cp::Cdouble
+    dS0::Ptr{Cdouble}; dV0::Ptr{Cdouble}; dkappa::Ptr{Cdouble}; dtheta::Ptr{Cdouble}
+    dsigma::Ptr{Cdouble}; dr_drift::Ptr{Cdouble}; ddiscount::Ptr{Cdouble}; dstrike::Ptr{Cdouble}
+end
+
+struct HHConfig
+    dynamics::Int32; strategy::Int32; antithetic::Int32; em_split::Int32
+    compat_sqrt_alpha::Int32; noise_mode::Int32; replay_layout::Int32
+    seeds_on_device::Int32; replay_on_device::Int32; terminal_on_device::Int32
+    n_steps::UInt32; n_partials::UInt32
+    n_paths::UInt64; path_offset::UInt64
+    seeds::Ptr{UInt64}; replay::Ptr{Cdouble}
+    bk_n_sigma::Cdouble; bk_cf_tol::Cdouble; bk_atol::Cdouble; bk_moment_h::Cdouble
+    bk_newton_maxiter::Int32; bk_bisect_maxiter::Int32
+end
+
+struct HHResult
+    price::Cdouble; std_error::Cdouble; sum_payoff::Cdouble; sumsq_payoff::Cdouble
+    dprice::NTuple{8,Cdouble}
+    n_paths_done::UInt64
+    bk_newton_fail::UInt64; bk_bisect_fallback::UInt64; bk_maxguess_fallback::UInt64
+    bk_cf_terms::UInt64
+    kernel_ms::Cdouble; total_ms::Cdouble
+end
+
+# ---- context ----------------------------------------------------------------------------------
+mutable struct Context
+    handle::Ptr{Cvoid}
+end
+
+function Context(device::Integer = 0)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    rc = ccall((:hh_ctx_create, LIB[]), Cint, (Ref{Ptr{Cvoid}}, Cint), h, device)
+    rc == 0 || error("hh_ctx_create failed ($rc): no HIP device? There is no CPU fallback.")
+    ctx = Context(h[])
+    finalizer(c -> ccall((:hh_ctx_destroy, LIB[]), Cvoid, (Ptr{Cvoid},), c.handle), ctx)
+    return ctx
+end
+
+const CTX = Ref{Union{Nothing,Context}}(nothing)
+context() = (CTX[] === nothing && (CTX[] = Context(0)); CTX[]::Context)
+
+last_error(ctx) = unsafe_string(ccall((:hh_last_error, LIB[]), Cstring, (Ptr{Cvoid},), ctx.handle))
+
+# ---- dual-number plumbing (greeks_problem.jl:258-260) ------------------------------------------
+_val(x) = ForwardDiff.value(x)
+_npartials(x) = x isa ForwardDiff.Dual ? ForwardDiff.npartials(x) : 0
+_partials(x, P) = x isa ForwardDiff.Dual ? collect(Float64, ForwardDiff.partials(x)) : zeros(P)
+_dualtype(xs...) = (i = findfirst(x -> x isa ForwardDiff.Dual, xs); i === nothing ? nothing : typeof(xs[i]))
+
+# ---- solve(prob, ::MonteCarlo) on the GPU (montecarlo.jl:478-493) -------------------------------
+function solve_hip(prob::PricingProblem{VanillaOption{TS,TE,European,C,Spot},I},
+                   method::MonteCarlo; ensemble::Bool = true,
+                   em_split::Bool = true, compat_sqrt_alpha::Bool = false) where {TS,TE,C,I}
+    m, payoff, cfg = prob.market_inputs, prob.payoff, method.config
+    dyn, strat = method.dynamics, method.strategy
+    euler = strat isa EulerMaruyama
+    if dyn isa LognormalDynamics && m isa BlackScholesInputs && (euler || strat isa BlackScholesExact)
+        dynamics, strategy = 0, euler ? 0 : 1
+        sigma, V0, kappa, theta, rho = get_vol(m.sigma, nothing, nothing), 0.0, 0.0, 0.0, 0.0
+    elseif dyn isa HestonDynamics && m isa HestonInputs && (euler || strat isa HestonBroadieKaya)
+        dynamics, strategy = 1, euler ? 0 : 2
+        sigma, V0, kappa, theta, rho = m.σ, m.V0, m.κ, m.θ, m.ρ
+    else
+        throw(MethodError(Hedgehog.solve, (prob, method)))
+    end
+    if euler
+        T = yearfrac(m.referenceDate, payoff.expiry)           # montecarlo.jl:173,197
+        r_drift = zero_rate(m.rate, 0.0)                       # montecarlo.jl:176,200
+    else
+        T = yearfrac(m.rate.reference_date, payoff.expiry)     # montecarlo.jl:301,317
+        r_drift = zero_rate(m.rate, payoff.expiry)             # montecarlo.jl:299,318
+    end
+    discount = df(m.rate, payoff.expiry)                        # montecarlo.jl:489
+
+    scal = (m.spot, V0, kappa, theta, sigma, r_drift, discount, payoff.strike)
+    P = maximum(_npartials, scal)
+    P <= HH_MAX_PARTIALS || error("at most $HH_MAX_PARTIALS partials per solve")
+    seedvecs = [_partials(x, P) for x in scal]
+    ptr(i) = (P == 0 || all(iszero, seedvecs[i])) ? Ptr{Cdouble}(C_NULL) : pointer(seedvecs[i])
+
+    seeds = convert(Vector{UInt64}, cfg.seeds .% UInt64)
+    anti = cfg.variance_reduction isa Antithetic
+    n = Int(cfg.trajectories)
+    terminal = ensemble ? Vector{Float64}(undef, anti ? 2n : n) : Float64[]
+    res = Ref{HHResult}()
+    ctx = context()
+    GC.@preserve seedvecs seeds terminal begin
+        model = HHModel(_val(m.spot), _val(V0), _val(kappa), _val(theta), _val(sigma), Float64(rho),
+                        _val(r_drift), _val(discount), Float64(T), _val(payoff.strike),
+                        payoff.call_put(),
+                        ptr(1), ptr(2), ptr(3), ptr(4), ptr(5), ptr(6), ptr(7), ptr(8))
+        config = HHConfig(dynamics, strategy, anti, em_split, compat_sqrt_alpha,
+                          0, 0, 0, 0, 0, UInt32(cfg.steps), UInt32(P), UInt64(n), UInt64(0),
+                          pointer(seeds), Ptr{Cdouble}(C_NULL), 0.0, 0.0, 0.0, 0.0, 0, 0)
+        rc = ccall((:hh_mc_solve, LIB[]), Cint,
+                   (Ptr{Cvoid}, Ref{HHModel}, Ref{HHConfig}, Ref{HHResult}, Ptr{Cdouble}),
+                   ctx.handle, model, config, res,
+                   ensemble ? pointer(terminal) : Ptr{Cdouble}(C_NULL))
+        rc == -2 && throw(MethodError(Hedgehog.solve, (prob, method)))
+        rc == 0 || error("hh_mc_solve failed ($rc): $(last_error(ctx))")
+    end
+    r = res[]
+    DT = _dualtype(scal...)
+    price = DT === nothing ? r.price :
+        DT(r.price, ForwardDiff.Partials(ntuple(k -> r.dprice[k], P)))   # same tag as the input Dual
+    ens = !ensemble ? nothing : anti ? (terminal[1:n], terminal[n+1:2n]) : terminal
+    return MonteCarloSolution(prob, method, price, ens)                  # pricing_solutions.jl:22-27
+end
+
+"""
+    install!()
+
+Overwrite `Hedgehog.solve(::PricingProblem{<:VanillaOption{…,European,…,Spot}}, ::MonteCarlo)`
+(montecarlo.jl:478-481) with the GPU implementation.  `GreekProblem`/`BatchGreekProblem`/
+`FiniteDifference` solvers (greeks_problem.jl:249-329, 559-568) then run through it unchanged.
+"""
+function install!()
+    @eval Hedgehog function solve(
+        prob::PricingProblem{VanillaOption{TS,TE,European,C,Spot},I}, method::MonteCarlo,
+    ) where {TS,TE,C,I<:AbstractMarketInputs}
+        return $(solve_hip)(prob, method)
+    end
+    return nothing
+end
+
+end # module

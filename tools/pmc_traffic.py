@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Turns two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE — collected in SEPARATE runs, with
+--kernel-trace only) into profiles/pmc_traffic.json, which bench.py reports as roofline.traffic.
+
+gfx950 corrections (MI355X_MICROARCH.md §HBM): the counters are in KiB; FETCH_SIZE reports exactly
+half of the bytes of a wide coalesced streaming read (16 B per lane, which is what the REPLAY
+kernel issues), so the read side is doubled; WRITE_SIZE is exact for streaming stores (checked here
+against wiener_fill_kernel, whose store volume is known exactly).
+
+usage: tools/pmc_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> [tag]
+"""
+import collections
+import csv
+import json
+import os
+import sys
+
+KERNEL = "euler_kernel<hh::HestonModel<0, true>, 0, true, false, 2>"
+
+
+def per_kernel(path, counter):
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] == counter:
+            agg[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    return {k: (sum(v) / len(v), len(v)) for k, v in agg.items()}
+
+
+def main():
+    fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
+    write = per_kernel(sys.argv[2], "WRITE_SIZE")
+    tag = sys.argv[3] if len(sys.argv) > 3 else "r01"
+    fk = next(k for k in fetch if KERNEL in k)
+    f_kib, n = fetch[fk]
+    w_kib, _ = write[fk]
+    fill = next((k for k in write if "wiener_fill_kernel" in k), None)
+    out = {
+        "kernel": fk,
+        "launches": n,
+        "FETCH_SIZE_KiB_raw": f_kib,
+        "WRITE_SIZE_KiB_raw": w_kib,
+        "read_bytes_corrected": 2.0 * f_kib * 1024.0,
+        "write_bytes": w_kib * 1024.0,
+        "hbm_bytes_per_launch": 2.0 * f_kib * 1024.0 + w_kib * 1024.0,
+        "correction": "FETCH_SIZE x2 (gfx950, 16 B/lane coalesced streaming reads), KiB -> bytes",
+        "calibration": {"wiener_fill_kernel_WRITE_SIZE_bytes": write[fill][0] * 1024.0 if fill else None,
+                        "expected_bytes": 3907 * 252 * 2 * 256 * 8},
+        "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py "
+                  "--steps 3 --warmup 1 --no-cpu-baseline; round " + tag,
+    }
+    dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles",
+                       "pmc_traffic.json")
+    json.dump(out, open(dst, "w"), indent=1)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
