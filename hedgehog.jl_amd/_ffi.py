@@ -73,6 +73,7 @@ SYMBOLS = [
     ("hh_ctx_create", C.c_int, [C.POINTER(_vp), C.c_int]),
     ("hh_ctx_destroy", None, [_vp]),
     ("hh_ctx_set_stream", C.c_int, [_vp, _vp]),
+    ("hh_ctx_reset_stream", C.c_int, [_vp]),
     ("hh_last_error", C.c_char_p, [_vp]),
     ("hh_mc_solve", C.c_int, [_vp, C.POINTER(hh_model), C.POINTER(hh_config), C.POINTER(hh_result), _vp]),
     ("hh_mc_accumulate", C.c_int, [_vp, C.POINTER(hh_model), C.POINTER(hh_config), _vp, _vp]),
@@ -135,7 +136,11 @@ class Context:
             raise HedgehogMCError(rc, self.lib.hh_last_error(self.handle).decode(errors="replace"))
 
     def set_stream(self, stream: int | None):
-        self.check(self.lib.hh_ctx_set_stream(self.handle, _vp(stream or 0)))
+        """Launch on an external hipStream_t handle (0 = the default stream); None = own stream."""
+        if stream is None:
+            self.check(self.lib.hh_ctx_reset_stream(self.handle))
+        else:
+            self.check(self.lib.hh_ctx_set_stream(self.handle, _vp(stream)))
 
     def synchronize(self):
         self.check(self.lib.hh_ctx_synchronize(self.handle))

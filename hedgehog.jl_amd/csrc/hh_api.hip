@@ -153,7 +153,7 @@ int hh_ctx_create(hh_ctx** out, int device_id) {
 void hh_ctx_destroy(hh_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
-  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  (void)hipStreamSynchronize(ctx->stream);
   if (ctx->records) (void)hipFree(ctx->records);
   if (ctx->seeds) (void)hipFree(ctx->seeds);
   if (ctx->replay) (void)hipFree(ctx->replay);
@@ -172,7 +172,13 @@ void hh_ctx_destroy(hh_ctx* ctx) {
 
 int hh_ctx_set_stream(hh_ctx* ctx, void* hip_stream) {
   if (!ctx) return HH_ERR_INVALID;
-  ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+  ctx->stream = (hipStream_t)hip_stream;  // NULL is the device's default (null) stream
+  return HH_OK;
+}
+
+int hh_ctx_reset_stream(hh_ctx* ctx) {
+  if (!ctx) return HH_ERR_INVALID;
+  ctx->stream = ctx->own_stream;
   return HH_OK;
 }
 

@@ -171,10 +171,30 @@ struct VecOf<2> {
   __device__ static __forceinline__ double get(const type& v, int j) { return j ? v.y : v.x; }
 };
 
-constexpr int kChunk = 4;  // steps per register chunk of the REPLAY pipeline
+// tuning knobs of the REPLAY pipeline (tools/tune_replay.py builds variants with -D)
+#ifndef HH_REPLAY_CHUNK
+#define HH_REPLAY_CHUNK 2
+#endif
+#ifndef HH_REPLAY_NT
+#define HH_REPLAY_NT 1
+#endif
+#ifndef HH_REPLAY_MINW
+#define HH_REPLAY_MINW 1
+#endif
+constexpr int kChunk = HH_REPLAY_CHUNK;  // steps per register chunk of the REPLAY pipeline
+
+template <class Vec>
+__device__ __forceinline__ Vec stream_load(const double* p) {
+#if HH_REPLAY_NT
+  return __builtin_nontemporal_load(reinterpret_cast<const Vec*>(p));  // read-once stream
+#else
+  return *reinterpret_cast<const Vec*>(p);
+#endif
+}
 
 template <class M, int P, bool REPLAY, bool ANTI, int PPT>
-__global__ __launch_bounds__(kTile / PPT) void euler_kernel(const SimArgs<P> a) {
+__global__ __launch_bounds__(kTile / PPT, REPLAY ? HH_REPLAY_MINW : 1) void euler_kernel(
+    const SimArgs<P> a) {
   constexpr int NC = M::NCOMP;
   using State = typename M::State;
   using Vec = typename VecOf<PPT>::type;
@@ -204,7 +224,7 @@ __global__ __launch_bounds__(kTile / PPT) void euler_kernel(const SimArgs<P> a) 
         if (s0 + u < n_steps) {
 #pragma unroll
           for (int c = 0; c < NC; ++c)
-            buf[u][c] = *reinterpret_cast<const Vec*>(base + ((size_t)(s0 + u) * NC + c) * kTile);
+            buf[u][c] = stream_load<Vec>(base + ((size_t)(s0 + u) * NC + c) * kTile);
         }
       }
     };

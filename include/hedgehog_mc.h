@@ -127,8 +127,11 @@ int hh_abi_version(void);
 /* Context. device_id is a HIP device ordinal of this process. */
 int hh_ctx_create(hh_ctx** out, int device_id);
 void hh_ctx_destroy(hh_ctx* ctx);
-/* Borrow an external hipStream_t (e.g. PyTorch's current stream); NULL restores the ctx's own. */
+/* Borrow an external hipStream_t (e.g. PyTorch's current stream).  NULL is a valid handle: the
+ * device's default (null) stream — which is what PyTorch uses unless told otherwise.
+ * hh_ctx_reset_stream goes back to the ctx's own non-blocking stream. */
 int hh_ctx_set_stream(hh_ctx* ctx, void* hip_stream);
+int hh_ctx_reset_stream(hh_ctx* ctx);
 const char* hh_last_error(const hh_ctx* ctx); /* NUL-terminated, owned by ctx (or static if NULL) */
 
 /*

@@ -1,0 +1,109 @@
+#!/usr/bin/env python3
+"""Interleaved A/B timing of REPLAY-kernel build variants in ONE process (guide rule 24).
+Builds hedgehog.jl_amd/lib/variants/libhh_<tag>.so with -D knobs, then on the GPU box times each
+variant round-robin on the H252 10^6 x 252 workload and prints median / min kernel ms.
+
+    python tools/tune_replay.py build            # here (cross-compile)
+    python tools/tune_replay.py run [rounds]     # on the GPU box
+"""
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+VDIR = os.path.join(ROOT, "hedgehog.jl_amd", "lib", "variants")
+CSRC = os.path.join(ROOT, "hedgehog.jl_amd", "csrc")
+
+VARIANTS = {
+    "c4_w1": ["-DHH_REPLAY_CHUNK=4", "-DHH_REPLAY_MINW=1"],
+    "c4_w4": ["-DHH_REPLAY_CHUNK=4", "-DHH_REPLAY_MINW=4"],
+    "c2_w4": ["-DHH_REPLAY_CHUNK=2", "-DHH_REPLAY_MINW=4"],
+    "c8_w2": ["-DHH_REPLAY_CHUNK=8", "-DHH_REPLAY_MINW=2"],
+    "c4_w4_nt": ["-DHH_REPLAY_CHUNK=4", "-DHH_REPLAY_MINW=4", "-DHH_REPLAY_NT=1"],
+    "c4_w1_nt": ["-DHH_REPLAY_CHUNK=4", "-DHH_REPLAY_MINW=1", "-DHH_REPLAY_NT=1"],
+    "c2_w4_nt": ["-DHH_REPLAY_CHUNK=2", "-DHH_REPLAY_MINW=4", "-DHH_REPLAY_NT=1"],
+    "c4_w8": ["-DHH_REPLAY_CHUNK=4", "-DHH_REPLAY_MINW=8"],
+    "c4_w8_nt": ["-DHH_REPLAY_CHUNK=4", "-DHH_REPLAY_MINW=8", "-DHH_REPLAY_NT=1"],
+    "c3_w8": ["-DHH_REPLAY_CHUNK=3", "-DHH_REPLAY_MINW=8"],
+}
+if os.environ.get("HH_VARIANTS"):
+    VARIANTS = json.loads(os.environ["HH_VARIANTS"])
+
+
+def build():
+    os.makedirs(VDIR, exist_ok=True)
+    procs = []
+    for tag, flags in VARIANTS.items():
+        out = os.path.join(VDIR, f"libhh_{tag}.so")
+        cmd = ["hipcc", "-shared", "-fPIC", "-O3", "-std=c++17", "--offload-arch=gfx950",
+               "-ffp-contract=off", *flags, *[os.path.join(CSRC, f) for f in
+                                             ("hh_api.hip", "hh_kernels.hip", "hh_bk.hip")],
+               "-o", out, "-Rpass-analysis=kernel-resource-usage"]
+        procs.append((tag, subprocess.Popen(cmd, stderr=subprocess.PIPE, text=True)))
+    for tag, p in procs:
+        err = p.communicate()[1]
+        if p.returncode:
+            print(err)
+            raise SystemExit(f"{tag} failed")
+        lines = err.splitlines()
+        for i, ln in enumerate(lines):
+            if "HestonModelILi0ELb1EEELi0ELb1ELb0ELi2" in ln and "Function Name" in ln:
+                vg = [x for x in lines[i:i + 8] if "VGPRs:" in x or "Occupancy" in x]
+                print(tag, " ".join(x.split("remark:")[1].strip().split("[")[0] for x in vg))
+
+
+def run(rounds=7):
+    import numpy as np
+    import torch
+    from hedgehog_jl_amd import _ffi
+    from tests import oracle_ffi as o
+    n_paths, n_steps = 1_000_000, 252
+    dev = torch.device("cuda", 0)
+    seeds = torch.arange(1, n_paths + 1, dtype=torch.int64, device=dev)
+    libs = {}
+    for tag in VARIANTS:
+        lib = C.CDLL(os.path.join(VDIR, f"libhh_{tag}.so"))
+        for name, res, args in _ffi.SYMBOLS:
+            f = getattr(lib, name)
+            f.restype, f.argtypes = res, args
+        h = C.c_void_p()
+        assert lib.hh_ctx_create(C.byref(h), 0) == 0
+        lib.hh_ctx_enable_timing(h, 1)
+        libs[tag] = (lib, h)
+    lib0, h0 = next(iter(libs.values()))
+    m = o.make_model()
+    dW = torch.empty(lib0.hh_replay_elems(n_paths, n_steps, 1), dtype=torch.float64, device=dev)
+    assert lib0.hh_wiener_fill(h0, 1, m.rho, m.T, n_steps, n_paths, seeds.data_ptr(), 1,
+                               dW.data_ptr()) == 0
+    lib0.hh_ctx_synchronize(h0)
+    acc = torch.zeros(16, dtype=torch.float64, device=dev)
+    c = o.make_config(1, 0, n_paths, n_steps, noise_mode=1)
+    c.replay, c.replay_on_device = dW.data_ptr(), 1
+    times = {t: [] for t in libs}
+    prices = {}
+    for r in range(rounds + 1):
+        for tag, (lib, h) in libs.items():
+            for _ in range(5):
+                assert lib.hh_mc_accumulate(h, C.byref(m), C.byref(c), acc.data_ptr(), None) == 0
+            buf = (C.c_double * 256)()
+            n = C.c_int32()
+            lib.hh_ctx_read_timings(h, buf, 256, C.byref(n))
+            if r > 0:
+                times[tag] += [buf[i] for i in range(n.value)]
+            prices[tag] = float(acc[0].item())
+    ref = next(iter(prices.values()))
+    for tag, t in times.items():
+        t = np.array(t)
+        gbs = 16.0 * n_paths * n_steps / (np.median(t) * 1e-3) / 1e9
+        print(f"{tag:12s} median {np.median(t):.4f} ms  min {t.min():.4f}  max {t.max():.4f}  "
+              f"-> {gbs:7.1f} GB/s ({gbs / 80:.1f}% of 8 TB/s)  same_sum={prices[tag] == ref}")
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "build":
+        build()
+    else:
+        run(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
