@@ -232,3 +232,37 @@ def test_error_codes(hhlib):
     assert b"replay" in lib.hh_last_error(h)
     bad = o.make_model(S0=-1.0)
     assert rc(o.make_config(HES, EM, 10, 5, seeds=np.arange(10)), bad) == _ffi.HH_ERR_INVALID
+
+
+def test_timing_hooks(hhlib):
+    m = o.make_model()
+    c = o.make_config(HES, EM, 4096, 16, seeds=seeds_for(4096))
+    hhlib.enable_timing(True)
+    for _ in range(3):
+        gpu_solve(hhlib, m, c, want_terminal=False)
+    t = hhlib.read_timings()
+    hhlib.enable_timing(False)
+    assert len(t) == 3 and all(0 < x < 50 for x in t)
+    assert hhlib.read_timings() == []
+
+
+def test_ten_million_paths_shards_add_up(hhlib):
+    """Largest BASELINE size (10^7 trajectories, the 1->8 GPU scaling size) in GENERATE mode:
+    eight path shards' accumulators add up to the single launch (what the all-reduce computes)."""
+    import torch
+    n, steps, G = 10_000_000, 252, 8
+    seeds = torch.arange(1, n + 1, dtype=torch.int64, device="cuda")
+    m = o.make_model()
+
+    def run(n_paths, off):
+        c = o.make_config(HES, EM, n_paths, steps)
+        c.seeds, c.seeds_on_device = seeds.data_ptr() + 8 * off, 1
+        return gpu_solve(hhlib, m, c, want_terminal=False)[0]
+
+    full = run(n, 0)
+    per = n // G  # 1_250_000: not a multiple of 256, so shard tiles differ from the full run's
+    parts = [run(per, g * per) for g in range(G)]
+    assert sum(p.sum_payoff for p in parts) == pytest.approx(full.sum_payoff, rel=1e-12)
+    assert sum(p.sumsq_payoff for p in parts) == pytest.approx(full.sumsq_payoff, rel=1e-12)
+    assert sum(p.n_paths_done for p in parts) == full.n_paths_done == n
+    assert full.price == pytest.approx(9.242521073959068, abs=4 * full.std_error + 0.02)
