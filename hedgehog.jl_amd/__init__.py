@@ -6,6 +6,7 @@ Import as `hedgehog_jl_amd` (shim at the repository root; the directory name car
 """
 from . import _ffi
 from ._ffi import Context, HedgehogMCError, get_context, load_library
+from .basket import BasketPricingProblem, BasketPricingSolution, solve_basket
 from .dates import Date, DateTime, add_years, to_ticks, yearfrac
 from .dual import Dual
 from .greeks import (BatchGreekProblem, FDBackward, FDCentral, FDForward, FiniteDifference,
@@ -27,10 +28,13 @@ def solve(*args, **kw):
         solve(gprob::GreekProblem, ::ForwardAD, method)                      greeks_problem.jl:249
         solve(gprob::GreekProblem, ::FiniteDifference, method)               greeks_problem.jl:318
         solve(gprob::BatchGreekProblem, ::GreekMethod, method)               greeks_problem.jl:559
+        solve(prob::BasketPricingProblem, method::MonteCarlo)                basket.jl:35
     """
     from . import greeks as _g
     if len(args) == 2 and isinstance(args[0], PricingProblem) and isinstance(args[1], MonteCarlo):
         return solve_montecarlo(args[0], args[1], **kw)
+    if len(args) == 2 and isinstance(args[0], BasketPricingProblem) and isinstance(args[1], MonteCarlo):
+        return solve_basket(args[0], args[1], **kw)
     if len(args) == 3 and isinstance(args[0], GreekProblem):
         if isinstance(args[1], ForwardAD):
             return _g.solve_greek_ad(args[0], args[2], solve)

@@ -1,0 +1,71 @@
+"""Host mirror of /root/reference/src/calibration/basket.jl: `BasketPricingProblem`,
+`BasketPricingSolution` and `solve(::BasketPricingProblem, ::MonteCarlo)`.
+
+The reference prices a basket as independent solves (basket.jl:35-38).  With the fixed seeds of
+`SimulationConfig`, payoffs that share an expiry see the same trajectories, so here every expiry
+group is ONE simulation whose terminal samples are reduced against all of the group's strikes
+(`hh_mc_solve_basket`).  Results equal the per-payoff solves (tests/test_gpu_basket.py).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Any
+
+import numpy as np
+
+from . import _ffi
+from .domain import MonteCarloSolution, PricingProblem
+from .dual import Dual
+from .montecarlo import MonteCarlo, _model_and_config, _price_from, solve_montecarlo
+
+
+@dataclass(frozen=True)
+class BasketPricingProblem:
+    """basket.jl:10-13."""
+    payoffs: Any
+    market_inputs: Any
+
+
+@dataclass(frozen=True)
+class BasketPricingSolution:
+    """basket.jl:24-27."""
+    problem: BasketPricingProblem
+    solutions: Any
+
+
+def solve_basket(prob: BasketPricingProblem, method: MonteCarlo, ensemble: bool = False):
+    """basket.jl:35-38 for a MonteCarlo method."""
+    payoffs = list(prob.payoffs)
+    sols: list = [None] * len(payoffs)
+    groups: dict = {}
+    for i, p in enumerate(payoffs):
+        if isinstance(getattr(p, "strike", None), Dual):  # strike partials: plain per-payoff solve
+            sols[i] = solve_montecarlo(PricingProblem(p, prob.market_inputs), method, ensemble)
+        else:
+            groups.setdefault(getattr(p, "expiry", None), []).append(i)
+    ctx = _ffi.get_context(method.device)
+    cfg = method.config
+    for idx in groups.values():
+        first = PricingProblem(payoffs[idx[0]], prob.market_inputs)
+        model, c, keep, P, discount = _model_and_config(first, method)  # raises MethodError as solve
+        for i in idx[1:]:
+            _model_and_config(PricingProblem(payoffs[i], prob.market_inputs), method)
+        K = len(idx)
+        strikes = (C.c_double * K)(*[float(payoffs[i].strike) for i in idx])
+        cps = (C.c_double * K)(*[payoffs[i].call_put() for i in idx])
+        c.seeds = cfg.seeds.ctypes.data
+        anti = bool(c.antithetic)
+        term = np.empty(c.n_paths * (2 if anti else 1)) if ensemble else None
+        res = (_ffi.hh_result * K)()
+        ctx.check(ctx.lib.hh_mc_solve_basket(ctx.handle, C.byref(model), C.byref(c), strikes, cps, K,
+                                             res, term.ctypes.data if ensemble else None))
+        ens = None
+        if ensemble:
+            ens = (term[:c.n_paths], term[c.n_paths:]) if anti else term
+        for k, i in enumerate(idx):
+            sols[i] = MonteCarloSolution(PricingProblem(payoffs[i], prob.market_inputs), method,
+                                         _price_from(res[k], discount, P), ens,
+                                         std_error=res[k].std_error, result=res[k])
+        del keep
+    return BasketPricingSolution(prob, sols)

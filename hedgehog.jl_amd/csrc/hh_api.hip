@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <vector>
 
 #include "hh_kernels.h"
 
@@ -24,6 +25,14 @@ struct hh_ctx {
   size_t replay_src_cap = 0;
   double* terminal = nullptr;
   size_t terminal_cap = 0;
+  double* terminal_d = nullptr;  // [P][n_total] terminal partials (basket Greeks)
+  size_t terminal_d_cap = 0;
+  double* payoffs = nullptr;  // [2][n_payoffs]: strikes, cps
+  size_t payoffs_cap = 0;
+  double* basket_records = nullptr;
+  size_t basket_records_cap = 0;
+  double* basket_accum = nullptr;
+  size_t basket_accum_cap = 0;
   double* accum = nullptr;       // device, HH_ACC_LEN
   double* accum_host = nullptr;  // pinned, HH_ACC_LEN
   // optional per-launch timing of the simulation kernel (hh_ctx_enable_timing)
@@ -159,6 +168,10 @@ void hh_ctx_destroy(hh_ctx* ctx) {
   if (ctx->replay) (void)hipFree(ctx->replay);
   if (ctx->replay_src) (void)hipFree(ctx->replay_src);
   if (ctx->terminal) (void)hipFree(ctx->terminal);
+  if (ctx->terminal_d) (void)hipFree(ctx->terminal_d);
+  if (ctx->payoffs) (void)hipFree(ctx->payoffs);
+  if (ctx->basket_records) (void)hipFree(ctx->basket_records);
+  if (ctx->basket_accum) (void)hipFree(ctx->basket_accum);
   if (ctx->accum) (void)hipFree(ctx->accum);
   if (ctx->accum_host) (void)hipHostFree(ctx->accum_host);
   for (auto& pr : ctx->tev)
@@ -235,14 +248,12 @@ int hh_wiener_fill(hh_ctx* ctx, int32_t dynamics, double rho, double T, uint32_t
   return HH_OK;
 }
 
-int hh_mc_accumulate(hh_ctx* ctx, const hh_model* m, const hh_config* c, double* accum_dev,
-                     double* terminal) {
-  if (!ctx) return HH_ERR_INVALID;
-  int rc = validate(ctx, m, c);
-  if (rc) return rc;
-  if (!accum_dev) return fail(ctx, HH_ERR_INVALID, "accum_dev is NULL");
-  HH_HIP(ctx, hipSetDevice(ctx->device));
-
+// Shared body of hh_mc_accumulate / hh_mc_accumulate_basket: stage caller buffers, run the
+// simulation kernel (which also reduces the payoff of m->strike / m->cp into ctx->records) and
+// leave the terminal samples in device memory when asked.
+static int run_simulation(hh_ctx* ctx, const hh_model* m, const hh_config* c, double* terminal,
+                          bool need_terminal_dev, double** terminal_dev_out) {
+  int rc = HH_OK;
   const uint32_t n_tiles = hh::tiles_for(c->n_paths);
   rc = ensure(ctx, ctx->records, ctx->records_cap, (size_t)n_tiles * hh::kRecStride);
   if (rc) return rc;
@@ -265,7 +276,6 @@ int hh_mc_accumulate(hh_ctx* ctx, const hh_model* m, const hh_config* c, double*
   } else {
     const uint32_t steps = (c->strategy == HH_EULER_MARUYAMA) ? c->n_steps : 1;
     const int dyn = (c->strategy == HH_EULER_MARUYAMA) ? c->dynamics : HH_LOGNORMAL;
-    const int nc = ncomp_of(dyn);
     const size_t tile_elems = replay_elems(c->n_paths, steps, dyn);
     if (c->replay_layout == HH_REPLAY_PATH_MAJOR) {
       rc = ensure(ctx, ctx->replay, ctx->replay_cap, tile_elems);
@@ -286,19 +296,23 @@ int hh_mc_accumulate(hh_ctx* ctx, const hh_model* m, const hh_config* c, double*
     } else {
       return fail(ctx, HH_ERR_INVALID, "unknown replay_layout %d", c->replay_layout);
     }
-    (void)nc;
   }
 
   const size_t n_term = (size_t)c->n_paths * (c->antithetic ? 2 : 1);
-  if (terminal) {
-    if (c->terminal_on_device) {
-      p.terminal = terminal;
-    } else {
-      rc = ensure(ctx, ctx->terminal, ctx->terminal_cap, n_term);
-      if (rc) return rc;
-      p.terminal = ctx->terminal;
-    }
+  if (terminal && c->terminal_on_device) {
+    p.terminal = terminal;
+  } else if (terminal || need_terminal_dev) {
+    rc = ensure(ctx, ctx->terminal, ctx->terminal_cap, n_term);
+    if (rc) return rc;
+    p.terminal = ctx->terminal;
   }
+  if (need_terminal_dev && c->n_partials) {
+    rc = ensure(ctx, ctx->terminal_d, ctx->terminal_d_cap,
+                n_term * (size_t)hh::pad_partials(c->n_partials));
+    if (rc) return rc;
+    p.terminal_d = ctx->terminal_d;
+  }
+  if (terminal_dev_out) *terminal_dev_out = p.terminal;
 
   const int slot = ctx->t_count % hh_ctx::kTimingSlots;
   if (ctx->timing) HH_HIP(ctx, hipEventRecord(ctx->tev[slot][0], ctx->stream));
@@ -310,13 +324,101 @@ int hh_mc_accumulate(hh_ctx* ctx, const hh_model* m, const hh_config* c, double*
     HH_HIP(ctx, hipEventRecord(ctx->tev[slot][1], ctx->stream));
     ++ctx->t_count;
   }
-  HH_HIP(ctx, hh::launch_reduce_records(ctx->records, n_tiles, (double)c->n_paths, accum_dev,
-                                        ctx->stream));
+  return HH_OK;
+}
 
+static int copy_back_terminal(hh_ctx* ctx, const hh_config* c, double* terminal) {
   if (terminal && !c->terminal_on_device) {
+    const size_t n_term = (size_t)c->n_paths * (c->antithetic ? 2 : 1);
     HH_HIP(ctx, hipMemcpyAsync(terminal, ctx->terminal, n_term * sizeof(double),
                                hipMemcpyDeviceToHost, ctx->stream));
     HH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  return HH_OK;
+}
+
+int hh_mc_accumulate(hh_ctx* ctx, const hh_model* m, const hh_config* c, double* accum_dev,
+                     double* terminal) {
+  if (!ctx) return HH_ERR_INVALID;
+  int rc = validate(ctx, m, c);
+  if (rc) return rc;
+  if (!accum_dev) return fail(ctx, HH_ERR_INVALID, "accum_dev is NULL");
+  HH_HIP(ctx, hipSetDevice(ctx->device));
+  rc = run_simulation(ctx, m, c, terminal, false, nullptr);
+  if (rc) return rc;
+  HH_HIP(ctx, hh::launch_reduce_records(ctx->records, hh::tiles_for(c->n_paths),
+                                        (double)c->n_paths, accum_dev, ctx->stream));
+  return copy_back_terminal(ctx, c, terminal);
+}
+
+int hh_mc_accumulate_basket(hh_ctx* ctx, const hh_model* m, const hh_config* c,
+                            const double* strikes, const double* cps, uint32_t n_payoffs,
+                            double* accum_dev, double* terminal) {
+  if (!ctx) return HH_ERR_INVALID;
+  int rc = validate(ctx, m, c);
+  if (rc) return rc;
+  if (!accum_dev || !strikes || !cps || n_payoffs == 0 || n_payoffs > 65535)
+    return fail(ctx, HH_ERR_INVALID, "hh_mc_accumulate_basket: bad arguments");
+  for (uint32_t k = 0; k < n_payoffs; ++k)
+    if (cps[k] != 1.0 && cps[k] != -1.0) return fail(ctx, HH_ERR_INVALID, "cp must be +1 or -1");
+  if (m->dstrike)
+    return fail(ctx, HH_ERR_UNSUPPORTED, "strike partials are not carried through a basket");
+  HH_HIP(ctx, hipSetDevice(ctx->device));
+  double* term_dev = nullptr;
+  rc = run_simulation(ctx, m, c, terminal, true, &term_dev);
+  if (rc) return rc;
+
+  hh::BasketArgs b{};
+  b.n_paths = c->n_paths;
+  b.n_chunks = hh::basket_chunks(c->n_paths);
+  b.antithetic = c->antithetic;
+  rc = ensure(ctx, ctx->payoffs, ctx->payoffs_cap, (size_t)2 * n_payoffs);
+  if (rc) return rc;
+  HH_HIP(ctx, hipMemcpyAsync(ctx->payoffs, strikes, n_payoffs * sizeof(double),
+                             hipMemcpyHostToDevice, ctx->stream));
+  HH_HIP(ctx, hipMemcpyAsync(ctx->payoffs + n_payoffs, cps, n_payoffs * sizeof(double),
+                             hipMemcpyHostToDevice, ctx->stream));
+  rc = ensure(ctx, ctx->basket_records, ctx->basket_records_cap,
+              (size_t)n_payoffs * b.n_chunks * hh::kRecStride);
+  if (rc) return rc;
+  b.terminal = term_dev;
+  b.terminal_d = c->n_partials ? ctx->terminal_d : nullptr;
+  b.strikes = ctx->payoffs;
+  b.cps = ctx->payoffs + n_payoffs;
+  b.records = ctx->basket_records;
+  HH_HIP(ctx, hh::launch_basket_payoffs(b, n_payoffs, c->n_partials, ctx->stream));
+  HH_HIP(ctx, hh::launch_reduce_records(ctx->basket_records, b.n_chunks, (double)c->n_paths,
+                                        accum_dev, ctx->stream, n_payoffs));
+  return copy_back_terminal(ctx, c, terminal);
+}
+
+int hh_mc_solve_basket(hh_ctx* ctx, const hh_model* m, const hh_config* c, const double* strikes,
+                       const double* cps, uint32_t n_payoffs, hh_result* out, double* terminal) {
+  if (!ctx) return HH_ERR_INVALID;
+  if (!out) return fail(ctx, HH_ERR_INVALID, "result is NULL");
+  const auto t0 = std::chrono::steady_clock::now();
+  HH_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t n_acc = (size_t)n_payoffs * HH_ACC_LEN;
+  int rc = ensure(ctx, ctx->basket_accum, ctx->basket_accum_cap, n_acc);
+  if (rc) return rc;
+  HH_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  rc = hh_mc_accumulate_basket(ctx, m, c, strikes, cps, n_payoffs, ctx->basket_accum, terminal);
+  if (rc) return rc;
+  HH_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  std::vector<double> host(n_acc);
+  HH_HIP(ctx, hipMemcpyAsync(host.data(), ctx->basket_accum, n_acc * sizeof(double),
+                             hipMemcpyDeviceToHost, ctx->stream));
+  HH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  float ms = 0.f;
+  HH_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+  const double total =
+      std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  for (uint32_t k = 0; k < n_payoffs; ++k) {
+    std::memset(&out[k], 0, sizeof(hh_result));
+    rc = hh_mc_finalize(m, c, host.data() + (size_t)k * HH_ACC_LEN, &out[k]);
+    if (rc) return fail(ctx, rc, "finalize failed");
+    out[k].kernel_ms = ms;
+    out[k].total_ms = total;
   }
   return HH_OK;
 }

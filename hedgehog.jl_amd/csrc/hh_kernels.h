@@ -39,6 +39,7 @@ struct SimArgs {
   const uint64_t* seeds;  // device
   const double* replay;   // device, tile-major
   double* terminal;       // device or nullptr
+  double* terminal_d;     // device or nullptr: dS_T/dθ_k at [k * n_total + index]
   double* records;        // device, [n_tiles][kRecStride]
 };
 
@@ -46,8 +47,25 @@ struct DevicePtrs {
   const uint64_t* seeds;
   const double* replay;
   double* terminal;
+  double* terminal_d;
   double* records;
 };
+
+// several payoffs on ONE set of terminal samples (basket.jl:35-38, same-expiry payoffs)
+constexpr int kBasketChunk = 4096;  // trajectories per workgroup of basket_payoff_kernel
+struct BasketArgs {
+  const double* terminal;    // [n_paths] (+ [n_paths] mirrored)
+  const double* terminal_d;  // [P][n_total] or nullptr
+  const double* strikes;     // [n_payoffs]
+  const double* cps;         // [n_payoffs]
+  uint64_t n_paths;
+  uint32_t n_chunks;
+  int antithetic;
+  double* records;           // [n_payoffs][n_chunks][kRecStride]
+};
+inline uint32_t basket_chunks(uint64_t n_paths) {
+  return (uint32_t)((n_paths + kBasketChunk - 1) / kBasketChunk);
+}
 
 inline uint32_t tiles_for(uint64_t n_paths) { return (uint32_t)((n_paths + kTile - 1) / kTile); }
 inline int pad_partials(uint32_t p) { return p == 0 ? 0 : p == 1 ? 1 : p <= 3 ? 3 : 8; }
@@ -56,6 +74,8 @@ inline int pad_partials(uint32_t p) { return p == 0 ? 0 : p == 1 ? 1 : p <= 3 ? 
 int launch_simulation(const hh_model& m, const hh_config& c, const DevicePtrs& p, hipStream_t s);
 int launch_bk(const hh_model& m, const hh_config& c, const DevicePtrs& p, hipStream_t s);
 int launch_reduce_records(const double* records, uint32_t n_records, double n_paths, double* accum,
+                          hipStream_t s, uint32_t n_groups = 1);
+int launch_basket_payoffs(const BasketArgs& b, uint32_t n_payoffs, uint32_t n_partials,
                           hipStream_t s);
 int launch_wiener_fill(int dynamics, double rho, double sqrt_dt, uint32_t n_steps, uint64_t n_paths,
                        const uint64_t* seeds_dev, double* dst, hipStream_t s);

@@ -136,10 +136,24 @@ __device__ __forceinline__ void finish_path(const State& st, const State& sa, co
   double S, p, pd[P > 0 ? P : 1];
   payoff_of<P>(st.x, a, S, p, pd);
   if (a.terminal) a.terminal[path] = S;
+  const uint64_t n_total = ANTI ? 2 * a.n_paths : a.n_paths;
+  if constexpr (P > 0) {
+    if (a.terminal_d) {
+#pragma unroll
+      for (int k = 0; k < P; ++k) a.terminal_d[(uint64_t)k * n_total + path] = S * st.x.d[k];
+    }
+  }
   if constexpr (ANTI) {
     double Sa, pa, pda[P > 0 ? P : 1];
     payoff_of<P>(sa.x, a, Sa, pa, pda);
     if (a.terminal) a.terminal[a.n_paths + path] = Sa;
+    if constexpr (P > 0) {
+      if (a.terminal_d) {
+#pragma unroll
+        for (int k = 0; k < P; ++k)
+          a.terminal_d[(uint64_t)k * n_total + a.n_paths + path] = Sa * sa.x.d[k];
+      }
+    }
     p = (p + pa) / 2;  // montecarlo.jl:431
     if constexpr (P > 0) {
 #pragma unroll
@@ -366,6 +380,8 @@ __global__ __launch_bounds__(256) void reduce_records_kernel(const double* __res
   __shared__ double sm[256];
   const int slot = blockIdx.x;
   const int tid = threadIdx.x;
+  rec += (size_t)blockIdx.y * n * kRecStride;  // group = one payoff of a basket
+  accum += (size_t)blockIdx.y * kRecStride;
   double t = 0.0;
   for (uint32_t b = tid; b < n; b += 256) t += rec[(size_t)b * kRecStride + slot];
   sm[tid] = t;
@@ -494,6 +510,7 @@ static SimArgs<P> make_args(const hh_model& m, const hh_config& c, const DeviceP
   a.seeds = p.seeds;
   a.replay = p.replay;
   a.terminal = p.terminal;
+  a.terminal_d = p.terminal_d;
   a.records = p.records;
   return a;
 }
@@ -543,9 +560,69 @@ int launch_simulation(const hh_model& m, const hh_config& c, const DevicePtrs& p
 }
 
 int launch_reduce_records(const double* records, uint32_t n_records, double n_paths, double* accum,
+                          hipStream_t s, uint32_t n_groups) {
+  hipLaunchKernelGGL(reduce_records_kernel, dim3(kRecStride, n_groups), dim3(256), 0, s, records,
+                     n_records, n_paths, accum);
+  return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// basket: K payoffs reduced over one set of terminal samples.  The reference prices a basket as K
+// independent solves (basket.jl:35-38); with fixed seeds, payoffs sharing an expiry see the SAME
+// trajectories, so one simulation + this kernel is result-equivalent.
+// ------------------------------------------------------------------------------------------
+
+template <int P>
+__global__ __launch_bounds__(256) void basket_payoff_kernel(const BasketArgs b) {
+  const uint32_t chunk = blockIdx.x, k = blockIdx.y;
+  const double strike = b.strikes[k], cp = b.cps[k];
+  const uint64_t n_total = b.antithetic ? 2 * b.n_paths : b.n_paths;
+  double acc[2 + P];
+#pragma unroll
+  for (int i = 0; i < 2 + P; ++i) acc[i] = 0.0;
+  const uint64_t i0 = (uint64_t)chunk * kBasketChunk;
+  for (uint32_t j = threadIdx.x; j < (uint32_t)kBasketChunk; j += 256) {
+    const uint64_t i = i0 + j;
+    if (i >= b.n_paths) break;
+    const double S = b.terminal[i];
+    const double m = cp * (S - strike);
+    const bool itm = m > 0.0;
+    double p = itm ? m : 0.0;
+    double pd[P > 0 ? P : 1];
+    if constexpr (P > 0) {
+#pragma unroll
+      for (int q = 0; q < P; ++q) pd[q] = itm ? cp * b.terminal_d[(uint64_t)q * n_total + i] : 0.0;
+    }
+    if (b.antithetic) {
+      const double Sa = b.terminal[b.n_paths + i];
+      const double ma = cp * (Sa - strike);
+      const bool itma = ma > 0.0;
+      p = (p + (itma ? ma : 0.0)) / 2;
+      if constexpr (P > 0) {
+#pragma unroll
+        for (int q = 0; q < P; ++q)
+          pd[q] = (pd[q] + (itma ? cp * b.terminal_d[(uint64_t)q * n_total + b.n_paths + i] : 0.0)) / 2;
+      }
+    }
+    acc[0] += p;
+    acc[1] = fma(p, p, acc[1]);
+    if constexpr (P > 0) {
+#pragma unroll
+      for (int q = 0; q < P; ++q) acc[2 + q] += pd[q];
+    }
+  }
+  block_reduce_store<2 + P, 4>(acc, b.records + ((size_t)k * b.n_chunks + chunk) * kRecStride);
+}
+
+int launch_basket_payoffs(const BasketArgs& b, uint32_t n_payoffs, uint32_t n_partials,
                           hipStream_t s) {
-  hipLaunchKernelGGL(reduce_records_kernel, dim3(kRecStride), dim3(256), 0, s, records, n_records,
-                     n_paths, accum);
+  const dim3 grid(b.n_chunks, n_payoffs), block(256);
+  switch (pad_partials(n_partials)) {
+    case 0: hipLaunchKernelGGL(basket_payoff_kernel<0>, grid, block, 0, s, b); break;
+    case 1: hipLaunchKernelGGL(basket_payoff_kernel<1>, grid, block, 0, s, b); break;
+    case 3: hipLaunchKernelGGL(basket_payoff_kernel<3>, grid, block, 0, s, b); break;
+    default: hipLaunchKernelGGL(basket_payoff_kernel<8>, grid, block, 0, s, b); break;
+  }
   return (int)hipGetLastError();
 }
 

@@ -155,6 +155,21 @@ int hh_mc_finalize(const hh_model* model, const hh_config* cfg, const double* ac
                    hh_result* out);
 
 /*
+ * Several payoffs on ONE simulation — solve(::BasketPricingProblem, method) for payoffs that share
+ * an expiry (src/calibration/basket.jl:35-38 prices them as independent solves; with the fixed
+ * seeds of SimulationConfig they see the same trajectories, so the results coincide).  Payoff k is
+ * max(cps[k]·(S_T − strikes[k]), 0); model->strike / model->cp are ignored.  The accumulator block
+ * is n_payoffs × HH_ACC_LEN doubles, payoff-major (all-reducible as one vector); dual partials of
+ * the model parameters are carried for every payoff (strike partials are not).
+ */
+int hh_mc_accumulate_basket(hh_ctx* ctx, const hh_model* model, const hh_config* cfg,
+                            const double* strikes, const double* cps, uint32_t n_payoffs,
+                            double* accum_dev, double* terminal);
+int hh_mc_solve_basket(hh_ctx* ctx, const hh_model* model, const hh_config* cfg,
+                       const double* strikes, const double* cps, uint32_t n_payoffs,
+                       hh_result* out /* n_payoffs */, double* terminal);
+
+/*
  * REPLAY increments.  Tile-major layout (what the step kernels stream):
  *     dW[tile][step][comp][HH_TILE_PATHS],  tile = path / 256, comp < ncomp (1 lognormal, 2 Heston),
  * the last tile zero-padded.  hh_replay_elems() = ceil(n_paths/256)·n_steps·ncomp·256 doubles.
