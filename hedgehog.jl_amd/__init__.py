@@ -12,6 +12,7 @@ from .dual import Dual
 from .greeks import (BatchGreekProblem, FDBackward, FDCentral, FDForward, FiniteDifference,
                      ForwardAD, GreekProblem, GreekResult, PropertyLens, SpotLens, VolLens,
                      ZeroRateSpineLens, optic, set)
+from .lsm import LSM, LSMSolution, solve_lsm
 from .montecarlo import (AbstractPricingMethod, Antithetic, BlackScholesExact, EulerMaruyama,
                          HestonBroadieKaya, HestonDynamics, LognormalDynamics, MethodError,
                          MonteCarlo, NoVarianceReduction, SimulationConfig, solve_montecarlo)
@@ -29,10 +30,13 @@ def solve(*args, **kw):
         solve(gprob::GreekProblem, ::FiniteDifference, method)               greeks_problem.jl:318
         solve(gprob::BatchGreekProblem, ::GreekMethod, method)               greeks_problem.jl:559
         solve(prob::BasketPricingProblem, method::MonteCarlo)                basket.jl:35
+        solve(prob::PricingProblem{<:VanillaOption{…,American,…}}, ::LSM)     least_squares_montecarlo.jl:99
     """
     from . import greeks as _g
     if len(args) == 2 and isinstance(args[0], PricingProblem) and isinstance(args[1], MonteCarlo):
         return solve_montecarlo(args[0], args[1], **kw)
+    if len(args) == 2 and isinstance(args[0], PricingProblem) and isinstance(args[1], LSM):
+        return solve_lsm(args[0], args[1], **kw)
     if len(args) == 2 and isinstance(args[0], BasketPricingProblem) and isinstance(args[1], MonteCarlo):
         return solve_basket(args[0], args[1], **kw)
     if len(args) == 3 and isinstance(args[0], GreekProblem):

@@ -58,6 +58,12 @@ class hh_result(C.Structure):
     ]
 
 
+class hh_lsm_result(C.Structure):
+    _fields_ = [("price", C.c_double), ("std_error", C.c_double), ("n_paths_total", C.c_uint64),
+                ("rows_regressed", C.c_uint32), ("rows_skipped", C.c_uint32),
+                ("kernel_ms", C.c_double), ("total_ms", C.c_double)]
+
+
 class HedgehogMCError(RuntimeError):
     def __init__(self, code: int, msg: str):
         super().__init__(f"hedgehog_mc error {code}: {msg}")
@@ -80,6 +86,8 @@ SYMBOLS = [
     ("hh_mc_finalize", C.c_int, [C.POINTER(hh_model), C.POINTER(hh_config), _vp, C.POINTER(hh_result)]),
     ("hh_mc_accumulate_basket", C.c_int, [_vp, C.POINTER(hh_model), C.POINTER(hh_config), _vp, _vp, C.c_uint32, _vp, _vp]),
     ("hh_mc_solve_basket", C.c_int, [_vp, C.POINTER(hh_model), C.POINTER(hh_config), _vp, _vp, C.c_uint32, _vp, _vp]),
+    ("hh_lsm_grid_elems", C.c_size_t, [C.c_uint64, C.c_uint32, C.c_int32]),
+    ("hh_lsm_solve", C.c_int, [_vp, C.POINTER(hh_model), C.POINTER(hh_config), C.c_int32, C.c_double, C.POINTER(hh_lsm_result), _vp, _vp, _vp]),
     ("hh_replay_elems", C.c_size_t, [C.c_uint64, C.c_uint32, C.c_int32]),
     ("hh_replay_pack", C.c_int, [_vp, C.c_int32, C.c_uint64, C.c_uint32, _vp, C.c_int32, _vp]),
     ("hh_wiener_fill", C.c_int, [_vp, C.c_int32, C.c_double, C.c_double, C.c_uint32, C.c_uint64, _vp, C.c_int32, _vp]),

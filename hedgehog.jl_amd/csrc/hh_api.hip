@@ -33,6 +33,14 @@ struct hh_ctx {
   size_t basket_records_cap = 0;
   double* basket_accum = nullptr;
   size_t basket_accum_cap = 0;
+  double* lsm_grid = nullptr;  // [n_steps+1][ntot]
+  size_t lsm_grid_cap = 0;
+  double* lsm_val = nullptr;
+  size_t lsm_val_cap = 0;
+  int32_t* lsm_tau = nullptr;
+  size_t lsm_tau_cap = 0;
+  double* lsm_scratch = nullptr;
+  size_t lsm_scratch_cap = 0;
   double* accum = nullptr;       // device, HH_ACC_LEN
   double* accum_host = nullptr;  // pinned, HH_ACC_LEN
   // optional per-launch timing of the simulation kernel (hh_ctx_enable_timing)
@@ -172,6 +180,10 @@ void hh_ctx_destroy(hh_ctx* ctx) {
   if (ctx->payoffs) (void)hipFree(ctx->payoffs);
   if (ctx->basket_records) (void)hipFree(ctx->basket_records);
   if (ctx->basket_accum) (void)hipFree(ctx->basket_accum);
+  if (ctx->lsm_grid) (void)hipFree(ctx->lsm_grid);
+  if (ctx->lsm_val) (void)hipFree(ctx->lsm_val);
+  if (ctx->lsm_tau) (void)hipFree(ctx->lsm_tau);
+  if (ctx->lsm_scratch) (void)hipFree(ctx->lsm_scratch);
   if (ctx->accum) (void)hipFree(ctx->accum);
   if (ctx->accum_host) (void)hipHostFree(ctx->accum_host);
   for (auto& pr : ctx->tev)
@@ -467,6 +479,86 @@ int hh_mc_solve(hh_ctx* ctx, const hh_model* m, const hh_config* c, hh_result* o
   HH_HIP(ctx, hipStreamSynchronize(ctx->stream));
   rc = hh_mc_finalize(m, c, ctx->accum_host, out);
   if (rc) return fail(ctx, rc, "finalize failed");
+  float ms = 0.f;
+  HH_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+  out->kernel_ms = ms;
+  out->total_ms =
+      std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  return HH_OK;
+}
+
+size_t hh_lsm_grid_elems(uint64_t n_paths, uint32_t n_steps, int32_t antithetic) {
+  return (size_t)(n_steps + 1) * n_paths * (antithetic ? 2 : 1);
+}
+
+int hh_lsm_solve(hh_ctx* ctx, const hh_model* m, const hh_config* c, int32_t degree,
+                 double step_discount, hh_lsm_result* out, int32_t* stop_time, double* stop_value,
+                 double* spot_grid) {
+  if (!ctx) return HH_ERR_INVALID;
+  if (!m || !c || !out) return fail(ctx, HH_ERR_INVALID, "hh_lsm_solve: NULL argument");
+  const auto t0 = std::chrono::steady_clock::now();
+  // The reference's LSM regresses on the first state component of simulate_paths' solution, which
+  // is the SPOT only for the GBM noise process of (LognormalDynamics, BlackScholesExact)
+  // (least_squares_montecarlo.jl:53,76; montecarlo.jl:140-159) — that is the supported pair.
+  if (c->dynamics != HH_LOGNORMAL || c->strategy != HH_EXACT_LAW)
+    return fail(ctx, HH_ERR_UNSUPPORTED, "LSM needs LognormalDynamics + BlackScholesExact paths");
+  if (c->noise_mode != HH_NOISE_GENERATE || c->n_partials != 0)
+    return fail(ctx, HH_ERR_UNSUPPORTED, "LSM: GENERATE noise, no dual partials");
+  if (c->n_paths == 0 || c->n_steps == 0 || !c->seeds || degree < 1 || degree > 8)
+    return fail(ctx, HH_ERR_INVALID, "LSM: n_paths, n_steps >= 1, seeds, 1 <= degree <= 8");
+  if (!(m->S0 > 0.0) || !(m->T > 0.0) || (m->cp != 1.0 && m->cp != -1.0) ||
+      !(step_discount > 0.0) || !std::isfinite(step_discount))
+    return fail(ctx, HH_ERR_INVALID, "LSM: bad model scalars");
+  HH_HIP(ctx, hipSetDevice(ctx->device));
+  const uint64_t ntot = c->n_paths * (c->antithetic ? 2 : 1);
+  const size_t grid_elems = hh_lsm_grid_elems(c->n_paths, c->n_steps, c->antithetic);
+  const uint32_t ch = hh::lsm_chunks(ntot);
+  int rc;
+  if ((rc = ensure(ctx, ctx->lsm_grid, ctx->lsm_grid_cap, grid_elems))) return rc;
+  if ((rc = ensure(ctx, ctx->lsm_val, ctx->lsm_val_cap, (size_t)ntot))) return rc;
+  if ((rc = ensure(ctx, ctx->lsm_tau, ctx->lsm_tau_cap, (size_t)ntot))) return rc;
+  const size_t nscr = hh::lsm_scratch_doubles(ntot, c->n_steps, degree);
+  if ((rc = ensure(ctx, ctx->lsm_scratch, ctx->lsm_scratch_cap, nscr))) return rc;
+  if ((rc = ensure(ctx, ctx->records, ctx->records_cap, (size_t)ch * hh::kRecStride))) return rc;
+  const uint64_t* seeds_dev = c->seeds;
+  if (!c->seeds_on_device) {
+    if ((rc = ensure(ctx, ctx->seeds, ctx->seeds_cap, (size_t)c->n_paths))) return rc;
+    HH_HIP(ctx, hipMemcpyAsync(ctx->seeds, c->seeds, c->n_paths * sizeof(uint64_t),
+                               hipMemcpyHostToDevice, ctx->stream));
+    seeds_dev = ctx->seeds;
+  }
+  HH_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  HH_HIP(ctx, hh::launch_gbm_grid(seeds_dev, c->n_paths, c->n_steps, m->S0, m->r_drift, m->sigma,
+                                  m->T, c->antithetic, ctx->lsm_grid, ctx->stream));
+  HH_HIP(ctx, hh::launch_lsm(ctx->lsm_grid, ntot, c->n_steps, m->strike, m->cp, step_discount,
+                             degree, ctx->lsm_tau, ctx->lsm_val, ctx->lsm_scratch, ctx->records,
+                             ctx->stream));
+  HH_HIP(ctx, hh::launch_reduce_records(ctx->records, ch, (double)ntot, ctx->accum, ctx->stream));
+  HH_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  double counters[2] = {0, 0};
+  HH_HIP(ctx, hipMemcpyAsync(ctx->accum_host, ctx->accum, HH_ACC_LEN * sizeof(double),
+                             hipMemcpyDeviceToHost, ctx->stream));
+  HH_HIP(ctx, hipMemcpyAsync(counters, ctx->lsm_scratch + nscr - 2, 2 * sizeof(double),
+                             hipMemcpyDeviceToHost, ctx->stream));
+  if (stop_time)
+    HH_HIP(ctx, hipMemcpyAsync(stop_time, ctx->lsm_tau, ntot * sizeof(int32_t),
+                               hipMemcpyDeviceToHost, ctx->stream));
+  if (stop_value)
+    HH_HIP(ctx, hipMemcpyAsync(stop_value, ctx->lsm_val, ntot * sizeof(double),
+                               hipMemcpyDeviceToHost, ctx->stream));
+  if (spot_grid)
+    HH_HIP(ctx, hipMemcpyAsync(spot_grid, ctx->lsm_grid, grid_elems * sizeof(double),
+                               hipMemcpyDeviceToHost, ctx->stream));
+  HH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  const double n = (double)ntot, mean = ctx->accum_host[HH_ACC_SUM] / n;
+  double var = n > 1.0 ? (ctx->accum_host[HH_ACC_SUMSQ] - n * mean * mean) / (n - 1.0) : 0.0;
+  if (!(var > 0.0)) var = 0.0;
+  std::memset(out, 0, sizeof(*out));
+  out->price = mean;  // price = mean(discount^t * val) (least_squares_montecarlo.jl:133-134)
+  out->std_error = std::sqrt(var / n);
+  out->n_paths_total = ntot;
+  out->rows_regressed = (uint32_t)counters[0];
+  out->rows_skipped = (uint32_t)counters[1];
   float ms = 0.f;
   HH_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
   out->kernel_ms = ms;

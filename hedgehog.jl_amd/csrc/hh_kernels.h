@@ -77,6 +77,14 @@ int launch_reduce_records(const double* records, uint32_t n_records, double n_pa
                           hipStream_t s, uint32_t n_groups = 1);
 int launch_basket_payoffs(const BasketArgs& b, uint32_t n_payoffs, uint32_t n_partials,
                           hipStream_t s);
+// LSM (hh_lsm.hip)
+uint32_t lsm_chunks(uint64_t ntot);
+size_t lsm_scratch_doubles(uint64_t ntot, uint32_t n_steps, int degree);
+int launch_gbm_grid(const uint64_t* seeds_dev, uint64_t n_paths, uint32_t n_steps, double S0,
+                    double r, double sigma, double T, int anti, double* grid, hipStream_t s);
+int launch_lsm(const double* grid, uint64_t ntot, uint32_t n_steps, double strike, double cp,
+               double step_discount, int degree, int32_t* tau, double* val, double* scratch,
+               double* records, hipStream_t s);
 int launch_wiener_fill(int dynamics, double rho, double sqrt_dt, uint32_t n_steps, uint64_t n_paths,
                        const uint64_t* seeds_dev, double* dst, hipStream_t s);
 int launch_replay_pack(int ncomp, uint64_t n_paths, uint32_t n_steps, const double* src_dev,

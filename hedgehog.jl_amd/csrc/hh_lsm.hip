@@ -1,0 +1,483 @@
+// Longstaff–Schwartz American pricing on the full path grid — the consumer of simulate_paths that
+// needs every time step.  Reference: solve(::PricingProblem{VanillaOption{…,
+// American,…}}, ::LSM), src/pricing_methods/least_squares_montecarlo.jl:99-165, on the paths of
+// sde_problem(::LognormalDynamics, ::BlackScholesExact) (montecarlo.jl:140-159, antithetic :270-284).
+//
+// Layout: spot grid S[step][path] (step-major: every backward step streams two contiguous rows),
+// per-path stopping state tau[path] (int32), val[path] (fp64).
+//
+// The backward induction is serial in time but data-parallel over paths; each step is ONE launch:
+//   reduce last launch's partial moment sums Σ z^k y  ->  solve the (d+1)x(d+1) normal equations
+//   (every workgroup redundantly, same order => same coefficients)  ->  exercise decision for its
+//   own paths  ->  its partial moment sums for the NEXT (earlier) row.
+// Everything that depends on the spots only (in-the-money count, mean, std, power sums Σ z^k of every
+// row) is precomputed for all rows in three launches.  The regression is done in the standardised
+// variable z = (x - mean)/std: same polynomial space as Polynomials.fit(x, y, degree) (:126), so the
+// fitted function is the same; its Gram matrix is well conditioned in fp64.
+#include <cmath>
+
+#include "hh_kernels.h"
+#include "hh_rng.h"
+
+namespace hh {
+
+namespace {
+
+constexpr int kLsmChunk = 1024;  // paths per workgroup (256 threads x 4)
+constexpr int kLsmMaxDeg = 8;
+
+// ---- full path grid -----------------------------------------------------------------------
+
+template <bool ANTI>
+__global__ __launch_bounds__(256) void gbm_grid_kernel(const uint64_t* __restrict__ seeds,
+                                                       uint64_t n_paths, uint32_t n_steps,
+                                                       double S0, double a, double b,
+                                                       double* __restrict__ grid) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_paths) return;
+  const uint64_t ntot = ANTI ? 2 * n_paths : n_paths;
+  const uint64_t key = seeds[i];  // montecarlo.jl:331
+  double S = S0, Sa = S0;
+  grid[i] = S0;
+  if (ANTI) grid[n_paths + i] = S0;
+  for (uint32_t s = 0; s < n_steps; s += 2) {
+    double z[2];
+    normal_pair(key, s >> 1, 0u, 0u, kDomEuler, z[0], z[1]);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      if (s + h < n_steps) {
+        // GBM process increment dW = W (exp((μ-σ²/2) dt + σ √dt z) - 1)
+        S = S + S * (exp(fma(b, z[h], a)) - 1.0);
+        grid[(size_t)(s + h + 1) * ntot + i] = S;
+        if (ANTI) {  // flipped σ, same draws (montecarlo.jl:276)
+          Sa = Sa + Sa * (exp(fma(-b, z[h], a)) - 1.0);
+          grid[(size_t)(s + h + 1) * ntot + n_paths + i] = Sa;
+        }
+      }
+    }
+  }
+}
+
+// ---- helpers --------------------------------------------------------------------------------
+
+template <int N>
+__device__ __forceinline__ void block_sum(double (&v)[N], double (&out)[N]) {
+  // all threads receive the workgroup sums (fixed order: wave tree, then waves 0..3)
+  __shared__ double sm[4][N];
+  __syncthreads();  // protect sm from a previous use
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v[i] += __shfl_down(v[i], off, 64);
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) sm[wave][i] = v[i];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < N; ++i) out[i] = ((sm[0][i] + sm[1][i]) + sm[2][i]) + sm[3][i];
+}
+
+// sum NV-vectors written by `n_rec` workgroups (rec[r*NV + i]) — every workgroup does this in the
+// same order, so all of them obtain bit-identical totals
+template <int NV>
+__device__ __forceinline__ void reduce_records(const double* __restrict__ rec, uint32_t n_rec,
+                                               double (&tot)[NV]) {
+  double v[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) v[i] = 0.0;
+  for (uint32_t r = threadIdx.x; r < n_rec; r += 256) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] += rec[(size_t)r * NV + i];
+  }
+  block_sum<NV>(v, tot);
+}
+
+struct RowStat {
+  double n, mu, sd;
+};
+
+// ---- precompute: per-row in-the-money statistics and power sums --------------------------------
+
+__global__ __launch_bounds__(256) void lsm_stats_kernel(const double* __restrict__ grid,
+                                                        uint64_t ntot, double strike, double cp,
+                                                        uint32_t n_chunks,
+                                                        double* __restrict__ rec /*[row][chunk][3]*/) {
+  const uint32_t chunk = blockIdx.x, row = blockIdx.y;
+  const double* S = grid + (size_t)row * ntot;
+  double v[3] = {0, 0, 0};
+  for (int j = 0; j < kLsmChunk / 256; ++j) {
+    const uint64_t p = (uint64_t)chunk * kLsmChunk + j * 256 + threadIdx.x;
+    if (p < ntot) {
+      const double x = S[p];
+      if (cp * (x - strike) > 0.0) {
+        v[0] += 1.0;
+        v[1] += x;
+        v[2] = fma(x, x, v[2]);
+      }
+    }
+  }
+  double t[3];
+  block_sum<3>(v, t);
+  if (threadIdx.x == 0) {
+    double* o = rec + ((size_t)row * n_chunks + chunk) * 3;
+    o[0] = t[0]; o[1] = t[1]; o[2] = t[2];
+  }
+}
+
+__global__ __launch_bounds__(256) void lsm_rowstat_kernel(const double* __restrict__ rec,
+                                                          uint32_t n_chunks,
+                                                          RowStat* __restrict__ rs) {
+  const uint32_t row = blockIdx.x;
+  double t[3];
+  reduce_records<3>(rec + (size_t)row * n_chunks * 3, n_chunks, t);
+  if (threadIdx.x == 0) {
+    RowStat r{t[0], 0.0, 1.0};
+    if (t[0] > 0.0) {
+      r.mu = t[1] / t[0];
+      const double var = t[2] / t[0] - r.mu * r.mu;
+      r.sd = var > 0.0 ? sqrt(var) : 1.0;
+    }
+    rs[row] = r;
+  }
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void lsm_pow_kernel(const double* __restrict__ grid, uint64_t ntot,
+                                                      double strike, double cp, uint32_t n_chunks,
+                                                      const RowStat* __restrict__ rs,
+                                                      double* __restrict__ rec /*[row][chunk][2D+1]*/) {
+  constexpr int NV = 2 * D + 1;
+  const uint32_t chunk = blockIdx.x, row = blockIdx.y;
+  const double* S = grid + (size_t)row * ntot;
+  const RowStat r = rs[row];
+  double v[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) v[i] = 0.0;
+  for (int j = 0; j < kLsmChunk / 256; ++j) {
+    const uint64_t p = (uint64_t)chunk * kLsmChunk + j * 256 + threadIdx.x;
+    if (p < ntot) {
+      const double x = S[p];
+      if (cp * (x - strike) > 0.0) {
+        const double z = (x - r.mu) / r.sd;
+        double pw = 1.0;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+          v[i] += pw;
+          pw *= z;
+        }
+      }
+    }
+  }
+  double t[NV];
+  block_sum<NV>(v, t);
+  if (threadIdx.x == 0) {
+    double* o = rec + ((size_t)row * n_chunks + chunk) * NV;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) o[i] = t[i];
+  }
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void lsm_powsum_kernel(const double* __restrict__ rec,
+                                                         uint32_t n_chunks,
+                                                         double* __restrict__ P /*[row][2D+1]*/) {
+  constexpr int NV = 2 * D + 1;
+  const uint32_t row = blockIdx.x;
+  double t[NV];
+  reduce_records<NV>(rec + (size_t)row * n_chunks * NV, n_chunks, t);
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) P[(size_t)row * NV + i] = t[i];
+  }
+}
+
+// ---- backward induction -----------------------------------------------------------------------
+
+struct LsmStepArgs {
+  const double* grid;
+  uint64_t ntot;
+  double strike, cp, ln_disc;  // ln of the per-step discount factor
+  uint32_t n_steps, n_chunks;
+  int32_t* tau;
+  double* val;
+  const RowStat* rs;
+  const double* P;   // [row][2D+1]
+  double* recB;      // [row][chunk][D+1]: partial Σ z^k y of the row
+  double* counters;  // [0] rows regressed, [1] rows skipped (no in-the-money path)
+};
+
+// contribution of this workgroup's paths to Σ z^k y of `row`, y = D^(tau - row) val
+// (least_squares_montecarlo.jl:115-116), written to recB[row][chunk]
+template <int D>
+__device__ __forceinline__ void emit_moments(const LsmStepArgs& a, uint32_t row, const int (&tau)[4],
+                                             const double (&val)[4]) {
+  const double* S = a.grid + (size_t)row * a.ntot;
+  const RowStat r = a.rs[row];
+  double v[D + 1];
+#pragma unroll
+  for (int i = 0; i <= D; ++i) v[i] = 0.0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const uint64_t p = (uint64_t)blockIdx.x * kLsmChunk + j * 256 + threadIdx.x;
+    if (p < a.ntot) {
+      const double x = S[p];
+      if (a.cp * (x - a.strike) > 0.0) {
+        const double z = (x - r.mu) / r.sd;
+        const double y = exp(a.ln_disc * (double)(tau[j] - (int)row)) * val[j];
+        double pw = y;
+#pragma unroll
+        for (int i = 0; i <= D; ++i) {
+          v[i] += pw;
+          pw *= z;
+        }
+      }
+    }
+  }
+  double t[D + 1];
+  block_sum<D + 1>(v, t);
+  if (threadIdx.x == 0) {
+    double* o = a.recB + ((size_t)row * a.n_chunks + blockIdx.x) * (D + 1);
+#pragma unroll
+    for (int i = 0; i <= D; ++i) o[i] = t[i];
+  }
+}
+
+// stopping_info = [(nsteps, payoff(S_T))] (:109), and the moment sums of row nsteps-1
+template <int D>
+__global__ __launch_bounds__(256) void lsm_init_kernel(const LsmStepArgs a) {
+  const double* S = a.grid + (size_t)a.n_steps * a.ntot;
+  int tau[4];
+  double val[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const uint64_t p = (uint64_t)blockIdx.x * kLsmChunk + j * 256 + threadIdx.x;
+    tau[j] = (int)a.n_steps;
+    val[j] = 0.0;
+    if (p < a.ntot) {
+      const double m = a.cp * (S[p] - a.strike);
+      val[j] = m > 0.0 ? m : 0.0;
+      a.tau[p] = tau[j];
+      a.val[p] = val[j];
+    }
+  }
+  if (a.n_steps >= 2) emit_moments<D>(a, a.n_steps - 1, tau, val);
+}
+
+// one backward step at time index t (the reference's loop body for i = t+1, :112-131)
+template <int D>
+__global__ __launch_bounds__(256) void lsm_step_kernel(const LsmStepArgs a, uint32_t t) {
+  constexpr int N = D + 1;
+  const RowStat r = a.rs[t];
+  __shared__ double coef[N];
+  __shared__ int have_fit;
+  double B[N];
+  reduce_records<N>(a.recB + (size_t)t * a.n_chunks * N, a.n_chunks, B);
+  if (threadIdx.x == 0) {
+    have_fit = 0;
+    if (r.n > 0.0) {  // isempty(in_the_money) && continue (:120)
+      // normal equations G c = B, G_jk = Σ z^(j+k); Gaussian elimination with partial pivoting
+      const double* P = a.P + (size_t)t * (2 * D + 1);
+      double M[N][N + 1];
+#pragma unroll
+      for (int j = 0; j < N; ++j) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) M[j][k] = P[j + k];
+        M[j][N] = B[j];
+      }
+      double scale = 0.0;
+#pragma unroll
+      for (int j = 0; j < N; ++j) scale = fmax(scale, fabs(M[j][j]));
+      bool dead[N];
+#pragma unroll
+      for (int c = 0; c < N; ++c) {
+        int piv = c;
+        double best = fabs(M[c][c]);
+#pragma unroll
+        for (int j = 0; j < N; ++j)
+          if (j > c && fabs(M[j][c]) > best) {
+            best = fabs(M[j][c]);
+            piv = j;
+          }
+#pragma unroll
+        for (int j = 0; j < N; ++j)
+          if (j == piv && piv != c) {
+#pragma unroll
+            for (int k = 0; k <= N; ++k) {
+              const double tmp = M[c][k];
+              M[c][k] = M[j][k];
+              M[j][k] = tmp;
+            }
+          }
+        // rank deficiency (fewer distinct in-the-money spots than coefficients): drop the column
+        dead[c] = !(best > 1e-13 * scale);
+        if (!dead[c]) {
+          const double inv = 1.0 / M[c][c];
+#pragma unroll
+          for (int j = 0; j < N; ++j)
+            if (j > c) {
+              const double f = M[j][c] * inv;
+#pragma unroll
+              for (int k = 0; k <= N; ++k)
+                if (k >= c) M[j][k] = fma(-f, M[c][k], M[j][k]);
+            }
+        }
+      }
+      double cf[N];
+#pragma unroll
+      for (int c = N - 1; c >= 0; --c) {
+        double s = M[c][N];
+#pragma unroll
+        for (int k = 0; k < N; ++k)
+          if (k > c) s = fma(-M[c][k], cf[k], s);
+        cf[c] = dead[c] ? 0.0 : s / M[c][c];
+      }
+#pragma unroll
+      for (int c = 0; c < N; ++c) coef[c] = cf[c];
+      have_fit = 1;
+    }
+    if (blockIdx.x == 0) a.counters[r.n > 0.0 ? 0 : 1] += 1.0;
+  }
+  __syncthreads();
+
+  const double* S = a.grid + (size_t)t * a.ntot;
+  int tau[4];
+  double val[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const uint64_t p = (uint64_t)blockIdx.x * kLsmChunk + j * 256 + threadIdx.x;
+    tau[j] = 0;
+    val[j] = 0.0;
+    if (p < a.ntot) {
+      tau[j] = a.tau[p];
+      val[j] = a.val[p];
+      const double x = S[p];
+      const double pay = a.cp * (x - a.strike);
+      if (have_fit && pay > 0.0) {
+        const double z = (x - r.mu) / r.sd;
+        double cont = coef[D];  // cont_value = poly(x) (:127), Horner in z
+#pragma unroll
+        for (int c = D - 1; c >= 0; --c) cont = fma(cont, z, coef[c]);
+        if (pay > cont) {  // update_stopping_info! (:163-164)
+          tau[j] = (int)t;
+          val[j] = pay;
+          a.tau[p] = tau[j];
+          a.val[p] = pay;
+        }
+      }
+    }
+  }
+  if (t >= 2) emit_moments<D>(a, t - 1, tau, val);
+}
+
+// discounted_values = discount^t * val (:133): per-workgroup Σ and Σ² into 16-double records
+__global__ __launch_bounds__(256) void lsm_final_kernel(const int32_t* __restrict__ tau,
+                                                        const double* __restrict__ val,
+                                                        uint64_t ntot, double ln_disc,
+                                                        double* __restrict__ records) {
+  double v[2] = {0, 0};
+  for (int j = 0; j < 4; ++j) {
+    const uint64_t p = (uint64_t)blockIdx.x * kLsmChunk + j * 256 + threadIdx.x;
+    if (p < ntot) {
+      const double d = exp(ln_disc * (double)tau[p]) * val[p];
+      v[0] += d;
+      v[1] = fma(d, d, v[1]);
+    }
+  }
+  double t[2];
+  block_sum<2>(v, t);
+  if (threadIdx.x == 0) {
+    double* rec = records + (size_t)blockIdx.x * kRecStride;
+    for (int i = 0; i < kRecStride; ++i) rec[i] = 0.0;
+    rec[HH_ACC_SUM] = t[0];
+    rec[HH_ACC_SUMSQ] = t[1];
+  }
+}
+
+template <int D>
+int run_lsm(const LsmStepArgs& a, double* rec_pow, hipStream_t s) {
+  const dim3 b(256);
+  const uint32_t rows = a.n_steps + 1;
+  hipLaunchKernelGGL(lsm_pow_kernel<D>, dim3(a.n_chunks, rows), b, 0, s, a.grid, a.ntot, a.strike,
+                     a.cp, a.n_chunks, a.rs, rec_pow);
+  hipLaunchKernelGGL(lsm_powsum_kernel<D>, dim3(rows), b, 0, s, rec_pow, a.n_chunks,
+                     const_cast<double*>(a.P));
+  hipLaunchKernelGGL(lsm_init_kernel<D>, dim3(a.n_chunks), b, 0, s, a);
+  for (uint32_t t = a.n_steps - 1; t >= 1; --t)  // for i = nsteps:-1:2, t = i-1 (:112-113)
+    hipLaunchKernelGGL(lsm_step_kernel<D>, dim3(a.n_chunks), b, 0, s, a, t);
+  return (int)hipGetLastError();
+}
+
+}  // namespace
+
+uint32_t lsm_chunks(uint64_t ntot) { return (uint32_t)((ntot + kLsmChunk - 1) / kLsmChunk); }
+
+// scratch sizes in doubles, for the caller (hh_api.hip) to allocate
+size_t lsm_scratch_doubles(uint64_t ntot, uint32_t n_steps, int degree) {
+  const size_t rows = (size_t)n_steps + 1, ch = lsm_chunks(ntot);
+  const size_t nv = 2 * (size_t)degree + 1;
+  // rec_stats [rows][ch][3] | rowstat [rows][3] | rec_pow [rows][ch][nv] | P [rows][nv] |
+  // recB [rows][ch][degree+1] | counters [2]
+  return rows * ch * 3 + rows * 3 + rows * ch * nv + rows * nv + rows * ch * (degree + 1) + 2;
+}
+
+int launch_gbm_grid(const uint64_t* seeds_dev, uint64_t n_paths, uint32_t n_steps, double S0,
+                    double r, double sigma, double T, int anti, double* grid, hipStream_t s) {
+  const double dt = T / (double)n_steps;
+  const double a = (r - 0.5 * sigma * sigma) * dt, b = sigma * sqrt(dt);
+  const dim3 g((unsigned)((n_paths + 255) / 256)), blk(256);
+  if (anti)
+    hipLaunchKernelGGL(gbm_grid_kernel<true>, g, blk, 0, s, seeds_dev, n_paths, n_steps, S0, a, b,
+                       grid);
+  else
+    hipLaunchKernelGGL(gbm_grid_kernel<false>, g, blk, 0, s, seeds_dev, n_paths, n_steps, S0, a, b,
+                       grid);
+  return (int)hipGetLastError();
+}
+
+// Backward induction on a device-resident grid.  `scratch` has lsm_scratch_doubles() doubles,
+// `records` lsm_chunks() x kRecStride; on return `records` holds the per-workgroup Σ, Σ² of the
+// discounted stopped values and scratch's last two doubles the regressed / skipped row counts.
+int launch_lsm(const double* grid, uint64_t ntot, uint32_t n_steps, double strike, double cp,
+               double step_discount, int degree, int32_t* tau, double* val, double* scratch,
+               double* records, hipStream_t s) {
+  if (degree < 1 || degree > kLsmMaxDeg) return (int)hipErrorInvalidValue;
+  const size_t rows = (size_t)n_steps + 1, ch = lsm_chunks(ntot), nv = 2 * (size_t)degree + 1;
+  double* rec_stats = scratch;
+  RowStat* rs = reinterpret_cast<RowStat*>(rec_stats + rows * ch * 3);
+  double* rec_pow = reinterpret_cast<double*>(rs) + rows * 3;
+  double* P = rec_pow + rows * ch * nv;
+  double* recB = P + rows * nv;
+  double* counters = recB + rows * ch * (degree + 1);
+
+  hipError_t e = hipMemsetAsync(counters, 0, 2 * sizeof(double), s);
+  if (e != hipSuccess) return (int)e;
+  const dim3 b(256);
+  hipLaunchKernelGGL(lsm_stats_kernel, dim3((unsigned)ch, (unsigned)rows), b, 0, s, grid, ntot,
+                     strike, cp, (uint32_t)ch, rec_stats);
+  hipLaunchKernelGGL(lsm_rowstat_kernel, dim3((unsigned)rows), b, 0, s, rec_stats, (uint32_t)ch, rs);
+
+  LsmStepArgs a{};
+  a.grid = grid; a.ntot = ntot; a.strike = strike; a.cp = cp; a.ln_disc = log(step_discount);
+  a.n_steps = n_steps; a.n_chunks = (uint32_t)ch; a.tau = tau; a.val = val; a.rs = rs; a.P = P;
+  a.recB = recB; a.counters = counters;
+  int rc = 0;
+  switch (degree) {
+    case 1: rc = run_lsm<1>(a, rec_pow, s); break;
+    case 2: rc = run_lsm<2>(a, rec_pow, s); break;
+    case 3: rc = run_lsm<3>(a, rec_pow, s); break;
+    case 4: rc = run_lsm<4>(a, rec_pow, s); break;
+    case 5: rc = run_lsm<5>(a, rec_pow, s); break;
+    case 6: rc = run_lsm<6>(a, rec_pow, s); break;
+    case 7: rc = run_lsm<7>(a, rec_pow, s); break;
+    default: rc = run_lsm<8>(a, rec_pow, s); break;
+  }
+  if (rc) return rc;
+  hipLaunchKernelGGL(lsm_final_kernel, dim3((unsigned)ch), b, 0, s, tau, val, ntot, a.ln_disc,
+                     records);
+  return (int)hipGetLastError();
+}
+
+}  // namespace hh

@@ -1,0 +1,91 @@
+"""Host mirror of /root/reference/src/pricing_methods/least_squares_montecarlo.jl:
+`LSM` (:12-34), `LSMSolution` (src/solutions/pricing_solutions.jl) and
+`solve(::PricingProblem{VanillaOption{…,American,…}}, ::LSM)` (:99-136), running on the HIP path
+(`hh_lsm_solve`).  Supported paths: LognormalDynamics + BlackScholesExact, the pair the reference's
+LSM is used with (test/agreement/american_options.jl) — for the log-state Euler problems
+extract_spot_grid (:47-85) would hand the regression log-prices, so those combinations raise
+MethodError here."""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import Any
+
+import numpy as np
+
+from . import _ffi
+from .dates import MILLISECONDS_IN_YEAR_365, yearfrac
+from .domain import American, BlackScholesInputs, PricingProblem, VanillaOption, df, get_vol, zero_rate
+from .montecarlo import (AbstractPricingMethod, Antithetic, BlackScholesExact, LognormalDynamics,
+                         MethodError, MonteCarlo)
+
+
+@dataclass(frozen=True)
+class LSM(AbstractPricingMethod):
+    """least_squares_montecarlo.jl:12-34: LSM(mc_method, degree) or
+    LSM(dynamics, strategy, config, degree)."""
+    mc_method: MonteCarlo
+    degree: int
+
+    def __init__(self, *args):
+        if len(args) == 2:
+            mc, degree = args
+        elif len(args) == 4:
+            mc, degree = MonteCarlo(args[0], args[1], args[2]), args[3]
+        else:
+            raise TypeError("LSM(mc_method, degree) or LSM(dynamics, strategy, config, degree)")
+        object.__setattr__(self, "mc_method", mc)
+        object.__setattr__(self, "degree", int(degree))
+
+
+@dataclass(frozen=True)
+class LSMSolution:
+    """pricing_solutions.jl LSMSolution: stopping_info = (times, values) arrays, spot_paths the
+    (nsteps+1, npaths) matrix (None unless requested)."""
+    problem: Any
+    method: Any
+    price: float
+    stopping_info: Any
+    spot_paths: Any
+    std_error: float = field(default=float("nan"), compare=False)
+    result: Any = field(default=None, compare=False, repr=False)
+
+
+def solve_lsm(prob: PricingProblem, method: LSM, spot_paths: bool = False,
+              stopping_info: bool = True) -> LSMSolution:
+    payoff, m = prob.payoff, prob.market_inputs
+    if not (isinstance(payoff, VanillaOption) and isinstance(payoff.exercise_style, American)):
+        raise MethodError("solve(::PricingProblem, ::LSM) needs an American VanillaOption")
+    mc = method.mc_method
+    if not (isinstance(mc.dynamics, LognormalDynamics) and isinstance(mc.strategy, BlackScholesExact)
+            and isinstance(m, BlackScholesInputs)):
+        raise MethodError("LSM on the HIP path: LognormalDynamics + BlackScholesExact on "
+                          "BlackScholesInputs")
+    cfg = mc.config
+    T = yearfrac(m.referenceDate, payoff.expiry)                       # :104
+    nsteps = cfg.steps
+    # discount = df(rate, add_yearfrac(referenceDate, T / nsteps))      # :107
+    step_discount = float(df(m.rate, m.referenceDate + (T / nsteps) * MILLISECONDS_IN_YEAR_365))
+    model = _ffi.hh_model()
+    model.S0, model.sigma = float(m.spot), float(get_vol(m.sigma, None, None))
+    model.r_drift = float(zero_rate(m.rate, 0.0))                      # montecarlo.jl:150
+    model.T, model.strike, model.cp = float(T), float(payoff.strike), payoff.call_put()
+    model.discount = 1.0
+    c = _ffi.hh_config()
+    c.dynamics, c.strategy = _ffi.HH_LOGNORMAL, _ffi.HH_EXACT_LAW
+    c.antithetic = int(isinstance(cfg.variance_reduction, Antithetic))
+    c.n_steps, c.n_paths = nsteps, cfg.trajectories
+    c.seeds = cfg.seeds.ctypes.data
+    ntot = cfg.trajectories * (2 if c.antithetic else 1)
+    tau = np.empty(ntot, dtype=np.int32) if stopping_info else None
+    val = np.empty(ntot) if stopping_info else None
+    grid = np.empty((nsteps + 1, ntot)) if spot_paths else None
+    res = _ffi.hh_lsm_result()
+    ctx = _ffi.get_context(mc.device)
+    ctx.check(ctx.lib.hh_lsm_solve(ctx.handle, C.byref(model), C.byref(c), method.degree,
+                                   step_discount, C.byref(res),
+                                   tau.ctypes.data if stopping_info else None,
+                                   val.ctypes.data if stopping_info else None,
+                                   grid.ctypes.data if spot_paths else None))
+    return LSMSolution(prob, method, res.price, (tau, val) if stopping_info else None, grid,
+                       std_error=res.std_error, result=res)

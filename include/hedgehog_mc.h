@@ -170,6 +170,29 @@ int hh_mc_solve_basket(hh_ctx* ctx, const hh_model* model, const hh_config* cfg,
                        hh_result* out /* n_payoffs */, double* terminal);
 
 /*
+ * Longstaff–Schwartz American pricing on the full path grid:
+ *   solve(::PricingProblem{VanillaOption{…,American,…}}, ::LSM)
+ *                              (src/pricing_methods/least_squares_montecarlo.jl:99-165)
+ * cfg: dynamics = HH_LOGNORMAL, strategy = HH_EXACT_LAW (the BlackScholesExact GBM-process paths the
+ * reference's LSM is used with, montecarlo.jl:140-159; trajectory i keyed by seeds[i],
+ * montecarlo.jl:331; antithetic = flipped σ, :270-284), n_steps, n_paths, antithetic, seeds.
+ * step_discount = df(rate, referenceDate + T/nsteps) (:107); degree = LSM.degree (1..8).
+ * Optional host outputs (nullable): stop_time / stop_value = the reference's stopping_info
+ * ((n_paths·(1+antithetic)) entries), spot_grid = the (n_steps+1) x n_total path matrix in
+ * step-major order (the transpose of extract_spot_grid's matrix, :47-85).
+ */
+typedef struct hh_lsm_result {
+  double price, std_error;
+  uint64_t n_paths_total;
+  uint32_t rows_regressed, rows_skipped; /* time rows with / without an in-the-money path */
+  double kernel_ms, total_ms;
+} hh_lsm_result;
+size_t hh_lsm_grid_elems(uint64_t n_paths, uint32_t n_steps, int32_t antithetic);
+int hh_lsm_solve(hh_ctx* ctx, const hh_model* model, const hh_config* cfg, int32_t degree,
+                 double step_discount, hh_lsm_result* out, int32_t* stop_time, double* stop_value,
+                 double* spot_grid);
+
+/*
  * REPLAY increments.  Tile-major layout (what the step kernels stream):
  *     dW[tile][step][comp][HH_TILE_PATHS],  tile = path / 256, comp < ncomp (1 lognormal, 2 Heston),
  * the last tile zero-padded.  hh_replay_elems() = ceil(n_paths/256)·n_steps·ncomp·256 doubles.

@@ -78,3 +78,30 @@ def carr_madan_heston(S0, K, r, V0, kappa, theta, sigma, rho, T, cp=1.0, alpha=1
     if cp > 0:
         return call
     return call - S0 + K * D  # put-call parity (payoffs.jl:172-193)
+
+
+def crr_price(S0, K, r, sigma, T, steps, cp=1.0, american=True, on_forward=False) -> float:
+    """Cox–Ross–Rubinstein tree exactly as /root/reference/src/pricing_methods/
+    cox_ross_rubinstein.jl:99-141 builds it (tree on the FORWARD, u = e^{σ√ΔT}, p = 1/(1+u);
+    spot node = e^{-r (steps-i) ΔT} · forward node, :75-81).  The reference's LSM tests compare
+    against it (test/agreement/american_options.jl)."""
+    import numpy as np
+    dT = T / steps
+    fwd = S0 / math.exp(-r * T)
+    u = math.exp(sigma * math.sqrt(dT))
+    p = 1.0 / (1.0 + u)
+    disc = math.exp(-r * dT)
+
+    def forward_at(i):
+        return fwd * u ** np.arange(-i, i + 1, 2, dtype=np.float64)
+
+    def underlying_at(i):
+        f = forward_at(i)
+        return f if on_forward else math.exp(-r * (steps - i) * dT) * f
+
+    payoff = lambda s: np.maximum(cp * (s - K), 0.0)
+    value = payoff(forward_at(steps))
+    for step in range(steps - 1, -1, -1):
+        cont = disc * (p * value[1:] + (1 - p) * value[:-1])
+        value = np.maximum(cont, payoff(underlying_at(step))) if american else cont
+    return float(value[0])

@@ -401,3 +401,40 @@ int hho_num_threads(void) {
   return 1;
 #endif
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* full spot grid for the LSM consumer (least_squares_montecarlo.jl:105-106)                    */
+/* ------------------------------------------------------------------------------------------ */
+
+/*
+ * simulate_paths on the NoiseProblem of sde_problem(::LognormalDynamics, ::BlackScholesExact)
+ * (montecarlo.jl:140-159): a GeometricBrownianMotionProcess stepped with dt = T/steps, each step an
+ * exact lognormal increment dW = W (exp((μ-σ²/2) dt + σ √dt z) - 1) [DiffEqNoiseProcess, third party],
+ * trajectory i seeded with seeds[i] (montecarlo.jl:331); the antithetic ensemble flips σ
+ * (montecarlo.jl:270-284).  out[(s)*ntot + p], s = 0..n_steps, ntot = n_paths·(1+anti): the
+ * transpose of extract_spot_grid's (nsteps+1) x npaths matrix (least_squares_montecarlo.jl:47-85).
+ */
+void hho_gbm_grid(const uint64_t* seeds, uint64_t n_paths, uint32_t n_steps, double S0, double r,
+                  double sigma, double T, int anti, double* out) {
+  const uint64_t ntot = n_paths * (anti ? 2u : 1u);
+  const double dt = T / (double)n_steps;
+  const double a = (r - 0.5 * sigma * sigma) * dt, b = sigma * sqrt(dt);
+#pragma omp parallel for schedule(static)
+  for (int64_t ii = 0; ii < (int64_t)n_paths; ++ii) {
+    const uint64_t i = (uint64_t)ii;
+    double S = S0, Sa = S0;
+    out[i] = S0;
+    if (anti) out[n_paths + i] = S0;
+    for (uint32_t s = 0; s < n_steps; ++s) {
+      double z1, z2;
+      hho_normal_pair(seeds[i], s >> 1, 0u, 0u, 0u, &z1, &z2);
+      const double z = (s & 1u) ? z2 : z1;
+      S = S + S * (exp(fma(b, z, a)) - 1.0);
+      out[(size_t)(s + 1) * ntot + i] = S;
+      if (anti) {
+        Sa = Sa + Sa * (exp(fma(-b, z, a)) - 1.0);
+        out[(size_t)(s + 1) * ntot + n_paths + i] = Sa;
+      }
+    }
+  }
+}
