@@ -198,3 +198,28 @@ def test_edge_cases(oracle):
     r, t, _ = oracle.mc_solve(mm, o.make_config(GBM, EXACT, 50, antithetic=1, seeds=[1]))
     mu = math.log(100) + (0.05 - 0.02) * 1.0
     assert np.log(t[:50]) + np.log(t[50:]) == pytest.approx(2 * mu, rel=1e-13)
+
+
+def test_crr_regression_values_of_the_reference():
+    """test/unit/binomial_tree.jl:18,26 — the tree the reference's LSM tests compare against."""
+    assert analytic.crr_price(1.0, 1.0, 0.2, 0.4, 1.0, 80, cp=1.0) == \
+        pytest.approx(0.25225758542934945, abs=1e-8)
+    assert analytic.crr_price(1.0, 1.0, 0.2, 0.4, 1.0, 80, cp=-1.0, on_forward=True) == \
+        pytest.approx(0.07409148128021317, abs=1e-8)
+
+
+def test_lsm_oracle_like_reference():
+    """test/agreement/american_options.jl:8-50 (scaled down): American put, antithetic GBM-process
+    paths, degree 5, vs the CRR tree at the reference's rtol 0.02."""
+    from oracle import lsm_oracle
+    T = 366 / 365
+    seeds = np.random.default_rng(12345).integers(0, 2**63, 20_000).astype(np.uint64)
+    grid = lsm_oracle.gbm_grid(seeds, 50, 100.0, 0.05, 0.2, T, True)
+    assert grid.shape == (51, 40_000) and np.all(grid[0] == 100.0)
+    # antithetic pair: log-returns mirror around the drift
+    lr = np.log(grid[1] / grid[0])
+    assert lr[:20_000] + lr[20_000:] == pytest.approx(2 * (0.05 - 0.02) * T / 50, abs=1e-12)
+    r = lsm_oracle.lsm_solve(grid, 100.0, -1.0, math.exp(-0.05 * T / 50), 5)
+    assert r["price"] == pytest.approx(analytic.crr_price(100, 100, 0.05, 0.2, T, 1000, cp=-1.0),
+                                       rel=0.02)
+    assert r["stop_time"].min() >= 1 and r["stop_time"].max() == 50
