@@ -162,12 +162,12 @@ struct CfIter {
 // evaluate_chf (heston.jl:184-212).  theta_prev = NaN starts a new unwrapping sequence.
 __device__ cx evaluate_chf(const BkArgs& p, const CfIter& it, double a, double& theta_prev) {
   const cx g = csqrt({p.kappa * p.kappa, -2.0 * p.sigma2 * a});
-  const cx e = cexp({-g.re * p.T, -g.im * p.T});
+  const cx eh = cexp({-0.5 * g.re * p.T, -0.5 * g.im * p.T});  // exp(-γT/2)
+  const cx e = eh * eh;                                          // exp(-γT)
   const cx ome = {1.0 - e.re, -e.im};
   const cx ope = {1.0 + e.re, e.im};
   const cx zeta_g = cdiv(ome, g);
   const cx eta_g = cdiv(g * ope, ome);
-  const cx eh = cexp({-0.5 * g.re * p.T, -0.5 * g.im * p.T});
   cx nu_g = cdiv((it.sqrtV0VT * 4.0) * (g * eh), ome);
   nu_g = {nu_g.re / p.sigma2, nu_g.im / p.sigma2};
   // continuous unwrapping of arg(ν_γ) (heston.jl:198-205)

@@ -1,0 +1,104 @@
+/*
+ * Plain-C client of libhedgehog_mc.so: exercises the boundary exactly as a foreign host (Julia's
+ * ccall, cgo, …) would — no Python, no torch, only include/hedgehog_mc.h.  Built with gcc and run on
+ * the GPU box by tests/test_gpu_cabi_c.py.  Prints "OK <price> <std_error>" on success.
+ *
+ * Checks, with library-owned device memory only (hh_device_malloc / hh_memcpy_*):
+ *   - GENERATE solve == REPLAY solve of hh_wiener_fill's buffer (same draws)
+ *   - accumulate + finalize split == hh_mc_solve
+ *   - a fused 3-partial Greek pass returns the same price
+ *   - error codes and hh_last_error for bad arguments
+ */
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/hedgehog_mc.h"
+
+#define CHECK(cond, msg)                                   \
+  do {                                                     \
+    if (!(cond)) {                                         \
+      fprintf(stderr, "FAIL %s (%s:%d)\n", msg, __FILE__, __LINE__); \
+      return 1;                                            \
+    }                                                      \
+  } while (0)
+
+int main(void) {
+  hh_ctx* ctx = NULL;
+  int rc = hh_ctx_create(&ctx, 0);
+  if (rc != HH_OK) {
+    fprintf(stderr, "hh_ctx_create failed (%d): no HIP device — there is no CPU fallback\n", rc);
+    return 2;
+  }
+  CHECK(hh_abi_version() == HH_ABI_VERSION, "abi version");
+
+  const uint64_t N = 200000;
+  const uint32_t M = 64;
+  uint64_t* seeds = (uint64_t*)malloc(N * sizeof(uint64_t));
+  for (uint64_t i = 0; i < N; ++i) seeds[i] = i + 1;
+
+  hh_model m;
+  memset(&m, 0, sizeof(m));
+  m.S0 = 100; m.V0 = 0.04; m.kappa = 2; m.theta = 0.04; m.sigma = 0.3; m.rho = -0.7;
+  m.r_drift = 0.03; m.T = 1.0; m.discount = exp(-0.03); m.strike = 100; m.cp = 1;
+  hh_config c;
+  memset(&c, 0, sizeof(c));
+  c.dynamics = HH_HESTON; c.strategy = HH_EULER_MARUYAMA; c.em_split = 1;
+  c.n_paths = N; c.n_steps = M; c.seeds = seeds;
+
+  hh_result gen, rep, split, greeks;
+  CHECK(hh_mc_solve(ctx, &m, &c, &gen, NULL) == HH_OK, hh_last_error(ctx));
+  CHECK(gen.n_paths_done == N && gen.price > 8.5 && gen.price < 10.0, "price band");
+
+  /* same draws through a device-resident REPLAY buffer owned by the library's allocator */
+  void *d_seeds = NULL, *d_dw = NULL, *d_acc = NULL;
+  const size_t n_el = hh_replay_elems(N, M, HH_HESTON);
+  CHECK(hh_device_malloc(ctx, N * sizeof(uint64_t), &d_seeds) == HH_OK, hh_last_error(ctx));
+  CHECK(hh_device_malloc(ctx, n_el * sizeof(double), &d_dw) == HH_OK, hh_last_error(ctx));
+  CHECK(hh_device_malloc(ctx, HH_ACC_LEN * sizeof(double), &d_acc) == HH_OK, hh_last_error(ctx));
+  CHECK(hh_memcpy_h2d(ctx, d_seeds, seeds, N * sizeof(uint64_t)) == HH_OK, hh_last_error(ctx));
+  CHECK(hh_wiener_fill(ctx, HH_HESTON, m.rho, m.T, M, N, (const uint64_t*)d_seeds, 1,
+                       (double*)d_dw) == HH_OK, hh_last_error(ctx));
+  hh_config cr = c;
+  cr.noise_mode = HH_NOISE_REPLAY; cr.replay = (const double*)d_dw; cr.replay_on_device = 1;
+  CHECK(hh_mc_solve(ctx, &m, &cr, &rep, NULL) == HH_OK, hh_last_error(ctx));
+  CHECK(fabs(rep.price - gen.price) <= 1e-13 * gen.price, "REPLAY == GENERATE");
+
+  /* accumulate (device accumulators, no sync) + finalize on the host */
+  double acc[HH_ACC_LEN];
+  CHECK(hh_mc_accumulate(ctx, &m, &cr, (double*)d_acc, NULL) == HH_OK, hh_last_error(ctx));
+  CHECK(hh_memcpy_d2h(ctx, acc, d_acc, sizeof(acc)) == HH_OK, hh_last_error(ctx));
+  CHECK(hh_mc_finalize(&m, &cr, acc, &split) == HH_OK, "finalize");
+  CHECK(split.price == rep.price && split.std_error == rep.std_error, "split == solve");
+
+  /* three dual partials in one pass: dS0, dV0, dr (drift and discount) */
+  const double dS0[3] = {1, 0, 0}, dV0[3] = {0, 1, 0}, dr[3] = {0, 0, 1};
+  const double dD[3] = {0, 0, -m.T * m.discount};
+  hh_model mg = m;
+  mg.dS0 = dS0; mg.dV0 = dV0; mg.dr_drift = dr; mg.ddiscount = dD;
+  hh_config cg = c;
+  cg.n_partials = 3;
+  CHECK(hh_mc_solve(ctx, &mg, &cg, &greeks, NULL) == HH_OK, hh_last_error(ctx));
+  CHECK(fabs(greeks.price - gen.price) <= 1e-13 * gen.price, "greeks pass price");
+  CHECK(greeks.dprice[0] > 0.5 && greeks.dprice[0] < 0.8, "delta band");
+  CHECK(greeks.dprice[1] > 30 && greeks.dprice[1] < 50, "dV0 band");
+  CHECK(greeks.dprice[2] > 45 && greeks.dprice[2] < 65, "rho band");
+
+  /* error behaviour */
+  hh_config bad = c;
+  bad.n_paths = 0;
+  CHECK(hh_mc_solve(ctx, &m, &bad, &gen, NULL) == HH_ERR_INVALID, "n_paths = 0");
+  bad = c;
+  bad.strategy = HH_EXACT_LAW; /* Heston has no closed-form marginal law in the reference */
+  CHECK(hh_mc_solve(ctx, &m, &bad, &gen, NULL) == HH_ERR_UNSUPPORTED, "unsupported pair");
+  CHECK(strlen(hh_last_error(ctx)) > 0, "error text");
+  CHECK(hh_mc_solve(NULL, &m, &c, &gen, NULL) == HH_ERR_INVALID, "NULL ctx");
+
+  CHECK(hh_device_free(ctx, d_seeds) == HH_OK && hh_device_free(ctx, d_dw) == HH_OK &&
+        hh_device_free(ctx, d_acc) == HH_OK, "free");
+  hh_ctx_destroy(ctx);
+  free(seeds);
+  printf("OK %.10f %.6f\n", rep.price, rep.std_error);
+  return 0;
+}
