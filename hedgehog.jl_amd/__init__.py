@@ -10,7 +10,8 @@ from .basket import BasketPricingProblem, BasketPricingSolution, solve_basket
 from .dates import Date, DateTime, add_years, to_ticks, yearfrac
 from .dual import Dual
 from .greeks import (BatchGreekProblem, FDBackward, FDCentral, FDForward, FiniteDifference,
-                     ForwardAD, GreekProblem, GreekResult, PropertyLens, SpotLens, VolLens,
+                     ForwardAD, GreekProblem, GreekResult, PropertyLens, SecondOrderGreekProblem, SpotLens,
+                     VolLens,
                      ZeroRateSpineLens, optic, set)
 from .lsm import LSM, LSMSolution, solve_lsm
 from .montecarlo import (AbstractPricingMethod, Antithetic, BlackScholesExact, EulerMaruyama,
@@ -28,6 +29,7 @@ def solve(*args, **kw):
         solve(prob::PricingProblem, method::MonteCarlo)                      montecarlo.jl:478
         solve(gprob::GreekProblem, ::ForwardAD, method)                      greeks_problem.jl:249
         solve(gprob::GreekProblem, ::FiniteDifference, method)               greeks_problem.jl:318
+        solve(gprob::SecondOrderGreekProblem, ::FiniteDifference, method)    greeks_problem.jl:396
         solve(gprob::BatchGreekProblem, ::GreekMethod, method)               greeks_problem.jl:559
         solve(prob::BasketPricingProblem, method::MonteCarlo)                basket.jl:35
         solve(prob::PricingProblem{<:VanillaOption{…,American,…}}, ::LSM)     least_squares_montecarlo.jl:99
@@ -44,6 +46,9 @@ def solve(*args, **kw):
             return _g.solve_greek_ad(args[0], args[2], solve)
         if isinstance(args[1], FiniteDifference):
             return _g.solve_greek_fd(args[0], args[1], args[2], solve)
+    if len(args) == 3 and isinstance(args[0], SecondOrderGreekProblem) and \
+            isinstance(args[1], FiniteDifference):
+        return _g.solve_second_order_fd(args[0], args[1], args[2], solve)
     if len(args) == 3 and isinstance(args[0], BatchGreekProblem):
         return _g.solve_batch(args[0], args[1], args[2], solve)
     raise MethodError("no method matching solve(" + ", ".join(type(a).__name__ for a in args) + ")")

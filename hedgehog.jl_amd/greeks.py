@@ -156,6 +156,31 @@ def solve_greek_fd(gprob: GreekProblem, method: FiniteDifference, pricing_method
     return GreekResult(d)
 
 
+@dataclass(frozen=True)
+class SecondOrderGreekProblem:
+    """greeks_problem.jl:341-345."""
+    pricing_problem: Any
+    wrt1: Any
+    wrt2: Any
+
+
+def solve_second_order_fd(gprob: SecondOrderGreekProblem, method: FiniteDifference,
+                          pricing_method, solve):
+    """greeks_problem.jl:396-422: ABSOLUTE bump ε, 3-point (same lens) or 4-point cross stencil on
+    top of plain solves (common random numbers through the fixed seeds) — what the reference's own
+    test uses for the MC gamma (greeks_agreement.jl:221-224).  Second-order ForwardAD through the
+    Monte Carlo path is not offered (the reference flags it as unstable there)."""
+    prob, l1, l2, eps = gprob.pricing_problem, gprob.wrt1, gprob.wrt2, method.bump
+    x0, y0 = l1(prob), l2(prob)
+    f = lambda x, y: solve(set(set(prob, l1, x), l2, y), pricing_method).price
+    if l1 == l2:
+        d = (f(x0 + eps, y0 + eps) - 2 * f(x0, y0) + f(x0 - eps, y0 - eps)) / eps**2
+    else:
+        d = (f(x0 + eps, y0 + eps) - f(x0 + eps, y0 - eps) - f(x0 - eps, y0 + eps)
+             + f(x0 - eps, y0 - eps)) / (4 * eps**2)
+    return GreekResult(d)
+
+
 def solve_batch(gprob: BatchGreekProblem, method, pricing_method, solve):
     """greeks_problem.jl:559-568 -> {lens: greek}; ForwardAD through MonteCarlo is one fused pass."""
     from .montecarlo import MonteCarlo

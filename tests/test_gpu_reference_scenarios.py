@@ -96,6 +96,12 @@ def test_mc_greeks_vs_analytic():
     assert delta == pytest.approx(g["delta"], rel=3e-2)
     assert vega == pytest.approx(g["vega"], rel=1e-1)
     assert rho == pytest.approx(g["rho"], rel=1e-2)
+    # gamma by second-order finite differences on the MC price (greeks_agreement.jl:221-224)
+    gamma = hh.solve(hh.SecondOrderGreekProblem(prob, spot_lens, spot_lens),
+                     hh.FiniteDifference(1e-1), mc).greek
+    d1 = (np.log(1.0) + (0.03 + 0.5) * T) / np.sqrt(T)
+    gamma_an = np.exp(-0.5 * d1 * d1) / np.sqrt(2 * np.pi) / (1.0 * 1.0 * np.sqrt(T))
+    assert gamma == pytest.approx(gamma_an, rel=2e-1)
     # one fused pass gives the same three numbers (greeks_problem.jl:559-568)
     batch = hh.solve(hh.BatchGreekProblem(prob, (spot_lens, vol_lens, rate_lens)), hh.ForwardAD(), mc)
     assert batch[spot_lens] == pytest.approx(delta, rel=1e-12)
