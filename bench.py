@@ -102,21 +102,41 @@ def main():
 
     cfg_rep, cfg_gen = config(_ffi.HH_NOISE_REPLAY), config(_ffi.HH_NOISE_GENERATE)
 
-    def step(cfg):
-        ctx.check(lib.hh_mc_accumulate(h, C.byref(model), C.byref(cfg), accum.data_ptr(), None))
-        if dist is not None:
-            dist.all_reduce(accum)  # the path's one exchange: 16 doubles, SUM
+    # Steps are independent pricing jobs: the (latency-bound, 128-byte) all-reduce of step k is
+    # issued asynchronously on RCCL's stream and overlaps the simulation kernel of step k+1; two
+    # accumulator buffers alternate, and every all-reduce has completed before the clock stops.
+    accums = [accum, torch.zeros_like(accum)]
+    pending = [None, None]
+
+    def step(cfg, i):
+        b = i & 1
+        if pending[b] is not None:
+            pending[b].wait()
+            pending[b] = None
+        ctx.check(lib.hh_mc_accumulate(h, C.byref(model), C.byref(cfg), accums[b].data_ptr(), None))
+        if dist is not None:  # the path's one exchange: 16 doubles, SUM
+            pending[b] = dist.all_reduce(accums[b], async_op=True)
+        return b
+
+    def drain():
+        for b in (0, 1):
+            if pending[b] is not None:
+                pending[b].wait()
+                pending[b] = None
 
     def timed(cfg, k, w):
-        for _ in range(w):
-            step(cfg)
+        last = 0
+        for i in range(w):
+            step(cfg, i)
+        drain()
         ctx.enable_timing(True)
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
-        for _ in range(k):
-            step(cfg)
+        for i in range(k):
+            last = step(cfg, i)
+        drain()
         torch.cuda.synchronize(dev)
         if dist is not None:
             dist.barrier()
@@ -127,6 +147,7 @@ def main():
             t = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
+        accum.copy_(accums[last])
         return dt, kern_ms
 
     dt_rep, kern_rep = timed(cfg_rep, args.steps, args.warmup)
