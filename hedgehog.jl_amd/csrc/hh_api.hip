@@ -299,9 +299,13 @@ static int run_simulation(hh_ctx* ctx, const hh_model* m, const hh_config* c, do
       if (c->replay_on_device) {
         p.replay = c->replay;
       } else {
+        // exact law: one standard normal per trajectory, n_paths doubles (no tile padding needed:
+        // the kernel guards the tail); Euler: the padded tile-major buffer of hh_replay_elems()
+        const size_t host_elems =
+            (c->strategy == HH_EULER_MARUYAMA) ? tile_elems : (size_t)c->n_paths;
         rc = ensure(ctx, ctx->replay, ctx->replay_cap, tile_elems);
         if (rc) return rc;
-        HH_HIP(ctx, hipMemcpyAsync(ctx->replay, c->replay, tile_elems * sizeof(double),
+        HH_HIP(ctx, hipMemcpyAsync(ctx->replay, c->replay, host_elems * sizeof(double),
                                    hipMemcpyHostToDevice, ctx->stream));
         p.replay = ctx->replay;
       }

@@ -200,6 +200,9 @@ int hh_lsm_solve(hh_ctx* ctx, const hh_model* model, const hh_config* cfg, int32
  *     dW[path][step][comp]  (n_paths·n_steps·ncomp doubles); repacked on the device by
  * hh_replay_pack() (hh_mc_solve does this itself when replay_layout = HH_REPLAY_PATH_MAJOR).
  * For Heston the increments are the CORRELATED ones, cov = dt·[1 ρ; ρ 1] (heston.jl:18-20).
+ * Exact lognormal law (HH_EXACT_LAW) in REPLAY mode: `replay` holds ONE standard normal per
+ * trajectory, n_paths doubles (x = μ + σ̃·z, montecarlo.jl:302,413); no padding required.
+ * Broadie–Kaya has no REPLAY mode.
  */
 size_t hh_replay_elems(uint64_t n_paths, uint32_t n_steps, int32_t dynamics);
 int hh_replay_pack(hh_ctx* ctx, int32_t dynamics, uint64_t n_paths, uint32_t n_steps,
