@@ -322,9 +322,10 @@ static int run_simulation(hh_ctx* ctx, const hh_model* m, const hh_config* c, do
     if (rc) return rc;
     p.terminal = ctx->terminal;
   }
-  if (need_terminal_dev && c->n_partials) {
+  const int n_active = c->n_partials ? hh::count_active_partials(*m, *c) : 0;
+  if (need_terminal_dev && n_active) {
     rc = ensure(ctx, ctx->terminal_d, ctx->terminal_d_cap,
-                n_term * (size_t)hh::pad_partials(c->n_partials));
+                n_term * (size_t)hh::pad_partials((uint32_t)n_active));
     if (rc) return rc;
     p.terminal_d = ctx->terminal_d;
   }
@@ -363,7 +364,7 @@ int hh_mc_accumulate(hh_ctx* ctx, const hh_model* m, const hh_config* c, double*
   rc = run_simulation(ctx, m, c, terminal, false, nullptr);
   if (rc) return rc;
   HH_HIP(ctx, hh::launch_reduce_records(ctx->records, hh::tiles_for(c->n_paths),
-                                        (double)c->n_paths, accum_dev, ctx->stream));
+                                        (double)c->n_paths, accum_dev, ctx->stream, 1, m, c));
   return copy_back_terminal(ctx, c, terminal);
 }
 
@@ -398,13 +399,14 @@ int hh_mc_accumulate_basket(hh_ctx* ctx, const hh_model* m, const hh_config* c,
               (size_t)n_payoffs * b.n_chunks * hh::kRecStride);
   if (rc) return rc;
   b.terminal = term_dev;
-  b.terminal_d = c->n_partials ? ctx->terminal_d : nullptr;
+  const int n_active = c->n_partials ? hh::count_active_partials(*m, *c) : 0;
+  b.terminal_d = n_active ? ctx->terminal_d : nullptr;
   b.strikes = ctx->payoffs;
   b.cps = ctx->payoffs + n_payoffs;
   b.records = ctx->basket_records;
-  HH_HIP(ctx, hh::launch_basket_payoffs(b, n_payoffs, c->n_partials, ctx->stream));
+  HH_HIP(ctx, hh::launch_basket_payoffs(b, n_payoffs, (uint32_t)n_active, ctx->stream));
   HH_HIP(ctx, hh::launch_reduce_records(ctx->basket_records, b.n_chunks, (double)c->n_paths,
-                                        accum_dev, ctx->stream, n_payoffs));
+                                        accum_dev, ctx->stream, n_payoffs, m, c));
   return copy_back_terminal(ctx, c, terminal);
 }
 

@@ -11,6 +11,8 @@ namespace hh {
 
 constexpr int kTile = HH_TILE_PATHS;  // paths per tile == paths per workgroup
 constexpr int kRecStride = HH_ACC_LEN;
+// internal record slots of the simulation / basket kernels (never part of the public vector)
+constexpr int kRecItmS = 11;  // Σ 1[itm]·cp·S   (kRecItmS + 1: Σ 1[itm]·cp)
 
 // value + P partials (forward-mode dual number; ForwardDiff.Dual{Tag,Float64,P} on the reference
 // side, greeks_problem.jl:260).  P = 0 keeps a 1-element dummy that is never touched.
@@ -73,9 +75,12 @@ inline int pad_partials(uint32_t p) { return p == 0 ? 0 : p == 1 ? 1 : p <= 3 ? 
 // All launchers return a hipError_t as int (0 = success) and only enqueue work on `s`.
 int launch_simulation(const hh_model& m, const hh_config& c, const DevicePtrs& p, hipStream_t s);
 int launch_bk(const hh_model& m, const hh_config& c, const DevicePtrs& p, hipStream_t s);
+// m, c given: finish the dual partials (active slots re-ordered, passive ones in closed form)
 int launch_reduce_records(const double* records, uint32_t n_records, double n_paths, double* accum,
-                          hipStream_t s, uint32_t n_groups = 1);
-int launch_basket_payoffs(const BasketArgs& b, uint32_t n_payoffs, uint32_t n_partials,
+                          hipStream_t s, uint32_t n_groups = 1, const hh_model* m = nullptr,
+                          const hh_config* c = nullptr);
+int count_active_partials(const hh_model& m, const hh_config& c);
+int launch_basket_payoffs(const BasketArgs& b, uint32_t n_payoffs, uint32_t n_active_partials,
                           hipStream_t s);
 // LSM (hh_lsm.hip)
 uint32_t lsm_chunks(uint64_t ntot);

@@ -46,7 +46,13 @@ struct HestonModel {
     const double sq = sqrt(w);
     if constexpr (P > 0) {
       // d sqrt(w+) = dw / (2 sqrt(w)) for w > 0, and 0 at the clip ("dual rules")
-      const double inv2s = wpos ? 0.5 / sq : 0.0;
+      // 1/(2 sqrt(w)): hardware reciprocal + one Newton step (relative error ~1e-16; an IEEE
+      // division would cost ~14 instructions per path-step and the partials do not need it)
+      double inv2s = 0.0;
+      if (wpos) {
+        const double r0 = __builtin_amdgcn_rcp(sq);
+        inv2s = 0.5 * fma(r0, fma(-sq, r0, 1.0), r0);
+      }
 #pragma unroll
       for (int k = 0; k < P; ++k) {
         const double vpd = pos ? s.v.d[k] : 0.0;
@@ -88,21 +94,29 @@ struct GbmModel {
 // ------------------------------------------------------------------------------------------
 
 // S = exp(x) (montecarlo.jl:398); payoff max(cp (S-K), 0) (payoffs.jl:154-156)
+// Partials: only the directions that reach the variance/diffusion ("active", see PartialMap) are
+// carried per path; pd[k] = 1[itm]·cp·S·∂x_k.  wS = 1[itm]·cp·S and wN = 1[itm]·cp feed the two sums
+// from which every PASSIVE direction (spot, drift rate, strike: ∂x_T is the same constant on every
+// path) is finished in closed form by the record reduction.
 template <int P>
 __device__ __forceinline__ void payoff_of(const DualT<P>& x, const SimArgs<P>& a, double& S,
-                                          double& p, double (&pd)[P > 0 ? P : 1]) {
+                                          double& p, double (&pd)[P > 0 ? P : 1], double& wS,
+                                          double& wN) {
   S = exp(x.v);
   const double m = a.cp * (S - a.strike.v);
   const bool itm = m > 0.0;
   p = itm ? m : 0.0;
+  wS = itm ? a.cp * S : 0.0;
+  wN = itm ? a.cp : 0.0;
   if constexpr (P > 0) {
 #pragma unroll
-    for (int k = 0; k < P; ++k) pd[k] = itm ? a.cp * fma(S, x.d[k], -a.strike.d[k]) : 0.0;
+    for (int k = 0; k < P; ++k) pd[k] = wS * x.d[k];
   }
 }
 
 // wave64 shuffle tree, then across the workgroup's waves through LDS; lane 0 writes the record.
-template <int N, int NWAVES>
+// The last TAIL entries of acc go to record slots kRecItmS, kRecItmS+1 (the in-the-money sums).
+template <int N, int NWAVES, int TAIL = 0>
 __device__ __forceinline__ void block_reduce_store(double (&acc)[N], double* __restrict__ rec) {
 #pragma unroll
   for (int i = 0; i < N; ++i) {
@@ -118,23 +132,23 @@ __device__ __forceinline__ void block_reduce_store(double (&acc)[N], double* __r
   __syncthreads();
   if (threadIdx.x == 0) {
 #pragma unroll
+    for (int i = 0; i < kRecStride; ++i) rec[i] = 0.0;
+#pragma unroll
     for (int i = 0; i < N; ++i) {
       double t = sm[0][i];
 #pragma unroll
       for (int w = 1; w < NWAVES; ++w) t += sm[w][i];
-      rec[i] = t;
+      rec[i < N - TAIL ? i : kRecItmS + (i - (N - TAIL))] = t;
     }
-#pragma unroll
-    for (int i = N; i < kRecStride; ++i) rec[i] = 0.0;
   }
 }
 
 template <int P, bool ANTI, class State>
 __device__ __forceinline__ void finish_path(const State& st, const State& sa, const SimArgs<P>& a,
-                                            uint64_t path, double (&acc)[2 + P]) {
+                                            uint64_t path, double (&acc)[4 + P]) {
   if (path >= a.n_paths) return;
-  double S, p, pd[P > 0 ? P : 1];
-  payoff_of<P>(st.x, a, S, p, pd);
+  double S, p, pd[P > 0 ? P : 1], wS, wN;
+  payoff_of<P>(st.x, a, S, p, pd, wS, wN);
   if (a.terminal) a.terminal[path] = S;
   const uint64_t n_total = ANTI ? 2 * a.n_paths : a.n_paths;
   if constexpr (P > 0) {
@@ -144,8 +158,8 @@ __device__ __forceinline__ void finish_path(const State& st, const State& sa, co
     }
   }
   if constexpr (ANTI) {
-    double Sa, pa, pda[P > 0 ? P : 1];
-    payoff_of<P>(sa.x, a, Sa, pa, pda);
+    double Sa, pa, pda[P > 0 ? P : 1], wSa, wNa;
+    payoff_of<P>(sa.x, a, Sa, pa, pda, wSa, wNa);
     if (a.terminal) a.terminal[a.n_paths + path] = Sa;
     if constexpr (P > 0) {
       if (a.terminal_d) {
@@ -155,6 +169,8 @@ __device__ __forceinline__ void finish_path(const State& st, const State& sa, co
       }
     }
     p = (p + pa) / 2;  // montecarlo.jl:431
+    wS = (wS + wSa) / 2;
+    wN = (wN + wNa) / 2;
     if constexpr (P > 0) {
 #pragma unroll
       for (int k = 0; k < P; ++k) pd[k] = (pd[k] + pda[k]) / 2;
@@ -166,6 +182,8 @@ __device__ __forceinline__ void finish_path(const State& st, const State& sa, co
 #pragma unroll
     for (int k = 0; k < P; ++k) acc[2 + k] += pd[k];
   }
+  acc[2 + P] += wS;
+  acc[3 + P] += wN;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -305,12 +323,12 @@ __global__ __launch_bounds__(kTile / PPT, REPLAY ? HH_REPLAY_MINW : 1) void eule
     }
   }
 
-  double acc[2 + P];
+  double acc[4 + P];
 #pragma unroll
-  for (int i = 0; i < 2 + P; ++i) acc[i] = 0.0;
+  for (int i = 0; i < 4 + P; ++i) acc[i] = 0.0;
 #pragma unroll
   for (int j = 0; j < PPT; ++j) finish_path<P, ANTI>(st[j], sa[ANTI ? j : 0], a, path0 + j, acc);
-  block_reduce_store<2 + P, kTile / PPT / 64>(acc, a.records + (size_t)tile * kRecStride);
+  block_reduce_store<4 + P, kTile / PPT / 64, 2>(acc, a.records + (size_t)tile * kRecStride);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -328,9 +346,9 @@ __global__ __launch_bounds__(kTile / 2) void exact_gbm_kernel(const SimArgs<P> a
   const uint32_t tid = threadIdx.x;
   const uint64_t path0 = (uint64_t)tile * kTile + (uint64_t)tid * 2;
 
-  double acc[2 + P];
+  double acc[4 + P];
 #pragma unroll
-  for (int i = 0; i < 2 + P; ++i) acc[i] = 0.0;
+  for (int i = 0; i < 4 + P; ++i) acc[i] = 0.0;
 
   // trajectory G (global index) takes component G&1 of Philox block G>>1
   const uint64_t g0 = a.path_offset + path0;
@@ -367,23 +385,32 @@ __global__ __launch_bounds__(kTile / 2) void exact_gbm_kernel(const SimArgs<P> a
     }
     finish_path<P, ANTI>(st, sa, a, path0 + j, acc);
   }
-  block_reduce_store<2 + P, kTile / 2 / 64>(acc, a.records + (size_t)tile * kRecStride);
+  block_reduce_store<4 + P, kTile / 2 / 64, 2>(acc, a.records + (size_t)tile * kRecStride);
 }
 
 // ------------------------------------------------------------------------------------------
 // record reduction: one workgroup per accumulator slot, fixed summation order
 // ------------------------------------------------------------------------------------------
 
-__global__ __launch_bounds__(256) void reduce_records_kernel(const double* __restrict__ rec,
-                                                              uint32_t n, double n_paths,
-                                                              double* __restrict__ accum) {
-  __shared__ double sm[256];
-  const int slot = blockIdx.x;
+// Which dual directions are carried per path ("active": they reach the variance / diffusion) and
+// how the others ("passive": spot, drift rate, strike — ∂x_T is one constant for all paths) are
+// finished in closed form:  Σ∂p_k = xdT_k · Σ 1[itm]·cp·S  −  dK_k · Σ 1[itm]·cp.
+struct PartialMap {
+  int sim;          // 1: records of a simulation/basket kernel (slots kRecItmS.. are internal)
+  int n;            // n_partials of the call
+  int n_active;
+  int active[HH_MAX_PARTIALS];  // compact j -> original direction k
+  int src[HH_MAX_PARTIALS];     // original k -> compact j, or -1 when passive
+  double xdT[HH_MAX_PARTIALS];  // passive: ∂ log S_T / ∂θ_k
+  double dK[HH_MAX_PARTIALS];   // strike seed of direction k
+};
+
+__device__ __forceinline__ double sum_slot(const double* __restrict__ rec, uint32_t n, int slot,
+                                           double* sm) {
   const int tid = threadIdx.x;
-  rec += (size_t)blockIdx.y * n * kRecStride;  // group = one payoff of a basket
-  accum += (size_t)blockIdx.y * kRecStride;
   double t = 0.0;
   for (uint32_t b = tid; b < n; b += 256) t += rec[(size_t)b * kRecStride + slot];
+  __syncthreads();
   sm[tid] = t;
   __syncthreads();
 #pragma unroll
@@ -391,7 +418,32 @@ __global__ __launch_bounds__(256) void reduce_records_kernel(const double* __res
     if (tid < s) sm[tid] += sm[tid + s];
     __syncthreads();
   }
-  if (tid == 0) accum[slot] = (slot == HH_ACC_NPATHS) ? n_paths : sm[0];
+  return sm[0];
+}
+
+__global__ __launch_bounds__(256) void reduce_records_kernel(const double* __restrict__ rec,
+                                                              uint32_t n, double n_paths,
+                                                              double* __restrict__ accum,
+                                                              const PartialMap map) {
+  __shared__ double sm[256];
+  const int slot = blockIdx.x;
+  rec += (size_t)blockIdx.y * n * kRecStride;  // group = one payoff of a basket
+  accum += (size_t)blockIdx.y * kRecStride;
+  double out;
+  const int k = slot - HH_ACC_DSUM;
+  if (map.n > 0 && k >= 0 && k < HH_MAX_PARTIALS) {
+    out = 0.0;
+    if (k < map.n) {
+      if (map.src[k] >= 0) out = sum_slot(rec, n, HH_ACC_DSUM + map.src[k], sm);
+      else if (map.xdT[k] != 0.0) out = map.xdT[k] * sum_slot(rec, n, kRecItmS, sm);
+      if (map.dK[k] != 0.0) out -= map.dK[k] * sum_slot(rec, n, kRecItmS + 1, sm);
+    }
+  } else if (map.sim && (slot == kRecItmS || slot == kRecItmS + 1)) {
+    out = 0.0;  // internal sums do not leave the device
+  } else {
+    out = sum_slot(rec, n, slot, sm);
+  }
+  if (threadIdx.x == 0) accum[slot] = (slot == HH_ACC_NPATHS) ? n_paths : out;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -466,8 +518,47 @@ static inline double seed_of(const double* p, uint32_t k, uint32_t n) {
   return (p && k < n) ? p[k] : 0.0;
 }
 
+static PartialMap classify_partials(const hh_model& m, const hh_config& c) {
+  PartialMap pm{};
+  const uint32_t np = c.n_partials;
+  pm.n = (int)np;
+  const bool euler = c.strategy == HH_EULER_MARUYAMA;
+  const bool heston = c.dynamics == HH_HESTON;
+  const double dt = m.T / (double)(c.n_steps ? c.n_steps : 1);
+  const double sqT = sqrt(m.T), tmul = c.compat_sqrt_alpha ? sqT : m.T;
+  for (uint32_t k = 0; k < np && k < HH_MAX_PARTIALS; ++k) {
+    const double dsig = seed_of(m.dsigma, k, np);
+    bool act = dsig != 0.0;
+    if (heston && euler)
+      act = act || seed_of(m.dV0, k, np) != 0.0 || seed_of(m.dkappa, k, np) != 0.0 ||
+            seed_of(m.dtheta, k, np) != 0.0;
+    pm.dK[k] = seed_of(m.dstrike, k, np);
+    if (act) {
+      pm.src[k] = pm.n_active;
+      pm.active[pm.n_active++] = (int)k;
+    } else {
+      pm.src[k] = -1;
+      // ∂x_T: x0' = dS0/S0, then M drift updates fma(dt, dr, ·) (Euler) or dr·tmul (exact law);
+      // the diffusion carries nothing in a passive direction
+      const double dr = seed_of(m.dr_drift, k, np);
+      double xd = seed_of(m.dS0, k, np) / m.S0;
+      if (euler)
+        for (uint32_t s = 0; s < c.n_steps; ++s) xd = fma(dt, dr, xd);
+      else
+        xd = xd + dr * tmul;
+      pm.xdT[k] = xd;
+    }
+  }
+  return pm;
+}
+
+int count_active_partials(const hh_model& m, const hh_config& c) {
+  return classify_partials(m, c).n_active;
+}
+
 template <int P>
-static SimArgs<P> make_args(const hh_model& m, const hh_config& c, const DevicePtrs& p) {
+static SimArgs<P> make_args(const hh_model& m, const hh_config& c, const DevicePtrs& p,
+                            const PartialMap& pm) {
   SimArgs<P> a{};
   const uint32_t np = c.n_partials;
   const double sig2h = 0.5 * m.sigma * m.sigma;
@@ -484,19 +575,19 @@ static SimArgs<P> make_args(const hh_model& m, const hh_config& c, const DeviceP
   const double tmul = c.compat_sqrt_alpha ? sqT : m.T;
   a.law_mu.v = a.x0.v + a.gdrift.v * tmul;
   a.law_sd.v = m.sigma * sqT;
-  for (int k = 0; k < P; ++k) {
+  for (int j = 0; j < P && j < pm.n_active; ++j) {  // active directions only, compacted
+    const uint32_t k = (uint32_t)pm.active[j];
     const double dS0 = seed_of(m.dS0, k, np), dsig = seed_of(m.dsigma, k, np),
                  dr = seed_of(m.dr_drift, k, np);
-    a.x0.d[k] = dS0 / m.S0;
-    a.v0.d[k] = seed_of(m.dV0, k, np);
-    a.kappa.d[k] = seed_of(m.dkappa, k, np);
-    a.theta.d[k] = seed_of(m.dtheta, k, np);
-    a.sigma.d[k] = dsig;
-    a.r.d[k] = dr;
-    a.gdrift.d[k] = dr - m.sigma * dsig;
-    a.strike.d[k] = seed_of(m.dstrike, k, np);
-    a.law_mu.d[k] = a.x0.d[k] + a.gdrift.d[k] * tmul;
-    a.law_sd.d[k] = dsig * sqT;
+    a.x0.d[j] = dS0 / m.S0;
+    a.v0.d[j] = seed_of(m.dV0, k, np);
+    a.kappa.d[j] = seed_of(m.dkappa, k, np);
+    a.theta.d[j] = seed_of(m.dtheta, k, np);
+    a.sigma.d[j] = dsig;
+    a.r.d[j] = dr;
+    a.gdrift.d[j] = dr - m.sigma * dsig;
+    a.law_mu.d[j] = a.x0.d[j] + a.gdrift.d[j] * tmul;
+    a.law_sd.d[j] = dsig * sqT;
   }
   a.dt = m.T / (double)(c.n_steps ? c.n_steps : 1);  // montecarlo.jl:349
   a.sqrt_dt = sqrt(a.dt);
@@ -530,8 +621,9 @@ static int launch_euler_m(const SimArgs<P>& a, bool replay, bool anti, hipStream
 }
 
 template <int P>
-static int launch_sim_p(const hh_model& m, const hh_config& c, const DevicePtrs& p, hipStream_t s) {
-  const SimArgs<P> a = make_args<P>(m, c, p);
+static int launch_sim_p(const hh_model& m, const hh_config& c, const DevicePtrs& p,
+                        const PartialMap& pm, hipStream_t s) {
+  const SimArgs<P> a = make_args<P>(m, c, p, pm);
   const bool anti = c.antithetic != 0;
   const bool replay = c.noise_mode == HH_NOISE_REPLAY;
   if (c.strategy == HH_EXACT_LAW) {
@@ -551,18 +643,26 @@ static int launch_sim_p(const hh_model& m, const hh_config& c, const DevicePtrs&
 }
 
 int launch_simulation(const hh_model& m, const hh_config& c, const DevicePtrs& p, hipStream_t s) {
-  switch (pad_partials(c.n_partials)) {
-    case 0: return launch_sim_p<0>(m, c, p, s);
-    case 1: return launch_sim_p<1>(m, c, p, s);
-    case 3: return launch_sim_p<3>(m, c, p, s);
-    default: return launch_sim_p<8>(m, c, p, s);
+  const PartialMap pm = classify_partials(m, c);
+  switch (pad_partials((uint32_t)pm.n_active)) {
+    case 0: return launch_sim_p<0>(m, c, p, pm, s);
+    case 1: return launch_sim_p<1>(m, c, p, pm, s);
+    case 3: return launch_sim_p<3>(m, c, p, pm, s);
+    default: return launch_sim_p<8>(m, c, p, pm, s);
   }
 }
 
 int launch_reduce_records(const double* records, uint32_t n_records, double n_paths, double* accum,
-                          hipStream_t s, uint32_t n_groups) {
+                          hipStream_t s, uint32_t n_groups, const hh_model* m, const hh_config* c) {
+  PartialMap pm{};
+  if (m && c && c->strategy != HH_BROADIE_KAYA) {
+    if (c->n_partials) pm = classify_partials(*m, *c);
+    pm.sim = 1;
+    if (n_groups > 1)  // basket: strike partials are not carried
+      for (double& d : pm.dK) d = 0.0;
+  }
   hipLaunchKernelGGL(reduce_records_kernel, dim3(kRecStride, n_groups), dim3(256), 0, s, records,
-                     n_records, n_paths, accum);
+                     n_records, n_paths, accum, pm);
   return (int)hipGetLastError();
 }
 
@@ -577,9 +677,9 @@ __global__ __launch_bounds__(256) void basket_payoff_kernel(const BasketArgs b) 
   const uint32_t chunk = blockIdx.x, k = blockIdx.y;
   const double strike = b.strikes[k], cp = b.cps[k];
   const uint64_t n_total = b.antithetic ? 2 * b.n_paths : b.n_paths;
-  double acc[2 + P];
+  double acc[4 + P];
 #pragma unroll
-  for (int i = 0; i < 2 + P; ++i) acc[i] = 0.0;
+  for (int i = 0; i < 4 + P; ++i) acc[i] = 0.0;
   const uint64_t i0 = (uint64_t)chunk * kBasketChunk;
   for (uint32_t j = threadIdx.x; j < (uint32_t)kBasketChunk; j += 256) {
     const uint64_t i = i0 + j;
@@ -588,8 +688,9 @@ __global__ __launch_bounds__(256) void basket_payoff_kernel(const BasketArgs b) 
     const double m = cp * (S - strike);
     const bool itm = m > 0.0;
     double p = itm ? m : 0.0;
+    double wS = itm ? cp * S : 0.0, wN = itm ? cp : 0.0;
     double pd[P > 0 ? P : 1];
-    if constexpr (P > 0) {
+    if constexpr (P > 0) {  // terminal_d holds dS_T = S·∂x of the ACTIVE directions
 #pragma unroll
       for (int q = 0; q < P; ++q) pd[q] = itm ? cp * b.terminal_d[(uint64_t)q * n_total + i] : 0.0;
     }
@@ -598,6 +699,8 @@ __global__ __launch_bounds__(256) void basket_payoff_kernel(const BasketArgs b) 
       const double ma = cp * (Sa - strike);
       const bool itma = ma > 0.0;
       p = (p + (itma ? ma : 0.0)) / 2;
+      wS = (wS + (itma ? cp * Sa : 0.0)) / 2;
+      wN = (wN + (itma ? cp : 0.0)) / 2;
       if constexpr (P > 0) {
 #pragma unroll
         for (int q = 0; q < P; ++q)
@@ -610,14 +713,16 @@ __global__ __launch_bounds__(256) void basket_payoff_kernel(const BasketArgs b) 
 #pragma unroll
       for (int q = 0; q < P; ++q) acc[2 + q] += pd[q];
     }
+    acc[2 + P] += wS;
+    acc[3 + P] += wN;
   }
-  block_reduce_store<2 + P, 4>(acc, b.records + ((size_t)k * b.n_chunks + chunk) * kRecStride);
+  block_reduce_store<4 + P, 4, 2>(acc, b.records + ((size_t)k * b.n_chunks + chunk) * kRecStride);
 }
 
-int launch_basket_payoffs(const BasketArgs& b, uint32_t n_payoffs, uint32_t n_partials,
+int launch_basket_payoffs(const BasketArgs& b, uint32_t n_payoffs, uint32_t n_active_partials,
                           hipStream_t s) {
   const dim3 grid(b.n_chunks, n_payoffs), block(256);
-  switch (pad_partials(n_partials)) {
+  switch (pad_partials(n_active_partials)) {
     case 0: hipLaunchKernelGGL(basket_payoff_kernel<0>, grid, block, 0, s, b); break;
     case 1: hipLaunchKernelGGL(basket_payoff_kernel<1>, grid, block, 0, s, b); break;
     case 3: hipLaunchKernelGGL(basket_payoff_kernel<3>, grid, block, 0, s, b); break;

@@ -266,3 +266,29 @@ def test_ten_million_paths_shards_add_up(hhlib):
     assert sum(p.sumsq_payoff for p in parts) == pytest.approx(full.sumsq_payoff, rel=1e-12)
     assert sum(p.n_paths_done for p in parts) == full.n_paths_done == n
     assert full.price == pytest.approx(9.242521073959068, abs=4 * full.std_error + 0.02)
+
+
+@pytest.mark.parametrize("dyn,strategy", [(HES, EM), (GBM, EM), (GBM, EXACT)])
+@pytest.mark.parametrize("anti", [0, 1])
+def test_mixed_active_and_passive_directions(hhlib, oracle, dyn, strategy, anti):
+    """Directions that never reach the diffusion (spot, rate, strike) are finished in closed form
+    by the record reduction; directions that do (V0, κ, θ, σ) are carried per path; a direction
+    may mix both kinds of seed.  All must equal the oracle's step-by-step dual propagation."""
+    n, steps, P = 4000 + 11, 33, 7
+    D = float(np.exp(-0.03))
+    sd = {
+        "S0": [1, 0, 0, 0, 0.5, 0, 0],
+        "V0": [0, 1, 0, 0, 0.25, 0, 0],
+        "r_drift": [0, 0, 1, 0, 0, 0.1, 0],
+        "discount": [0, 0, -D, 0, 0, -0.1 * D, 0],
+        "strike": [0, 0, 0, 1, 0, 0.3, 0],
+        "sigma": [0, 0, 0, 0, 0, 0, 1],
+        "kappa": [0, 0, 0, 0, 0.1, 0, 0],
+    }
+    m = o.make_model(sigma=0.2 if dyn == GBM else 0.3, seeds=sd, n_partials=P)
+    c = o.make_config(dyn, strategy, n, steps, antithetic=anti, seeds=seeds_for(n, 3) if
+                      strategy == EM else [77], n_partials=P)
+    rg, tg = gpu_solve(hhlib, m, c)
+    ro, to, _ = oracle.mc_solve(m, c)
+    check(rg, tg, ro, to, P, 1e-11, 1e-11, rtol_d=1e-9)
+    assert rg.bk_newton_fail == 0 and rg.bk_bisect_fallback == 0  # internal slots stay internal
