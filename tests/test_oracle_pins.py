@@ -223,3 +223,37 @@ def test_lsm_oracle_like_reference():
     assert r["price"] == pytest.approx(analytic.crr_price(100, 100, 0.05, 0.2, T, 1000, cp=-1.0),
                                        rel=0.02)
     assert r["stop_time"].min() >= 1 and r["stop_time"].max() == 50
+
+
+@pytest.mark.parametrize("d,lam", [(3.5556, 0.5547), (0.1333, 16.5), (0.5, 0.3), (32.0, 35.0),
+                                   (1.5, 400.0)])
+def test_noncentral_chisq_sampler_has_the_right_law(d, lam):
+    """The NCχ² draw of Broadie–Kaya (heston.jl:131) is third-party in the reference
+    (Distributions.NoncentralChisq); the restated sampler shared by oracle and kernel (normal shift
+    for d > 1, Poisson mixture otherwise, Marsaglia–Tsang gamma, PTRS Poisson) must have exactly
+    that law: Kolmogorov–Smirnov against scipy.stats.ncx2 and the first two moments."""
+    from scipy import stats
+
+    from oracle import bk_oracle as bk
+    n = 20_000
+    x = np.array([bk.noncentral_chisq(d, lam, bk.Draws(987654321, i)) for i in range(n)])
+    assert stats.kstest(x, stats.ncx2(d, lam).cdf).pvalue > 1e-3
+    assert x.mean() == pytest.approx(d + lam, abs=5 * math.sqrt(2 * (d + 2 * lam) / n))
+    assert x.var() == pytest.approx(2 * (d + 2 * lam), rel=0.08)
+
+
+def test_bk_oracle_like_reference():
+    """test/agreement/montecarlo_heston.jl:208-253 on the oracle (scaled down): Broadie–Kaya vs
+    Carr–Madan at the reference's rtol 2e-2, with the parameters that test ACTUALLY runs (Q2) and
+    with the intended ones."""
+    from oracle import bk_oracle as bk
+    for prm, bound in ((dict(S0=100.0, V0=1.5, kappa=0.04, theta=0.3, sigma=-0.6, rho=0.04, r=0.05,
+                             T=364 / 365), 32.0),
+                       (dict(S0=100.0, V0=0.04, kappa=1.5, theta=0.04, sigma=0.3, rho=-0.6, r=0.05,
+                             T=364 / 365), 200.0)):
+        D = math.exp(-prm["r"] * prm["T"])
+        r = bk.mc_solve(**prm, strike=100.0, cp=1.0, discount=D, n_paths=1500, seed0=42)
+        cm = analytic.carr_madan_heston(prm["S0"], 100.0, prm["r"], prm["V0"], prm["kappa"],
+                                        prm["theta"], prm["sigma"], prm["rho"], prm["T"], bound=bound)
+        assert abs(r["price"] - cm) < 4 * r["std_error"] + 0.02 * cm
+        assert np.all(np.isfinite(r["terminal"])) and r["stats"]["maxguess"] <= 15
