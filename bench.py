@@ -50,6 +50,7 @@ def parse():
     ap.add_argument("--paths", type=int, default=1_000_000, help="trajectories per GPU")
     ap.add_argument("--nsteps", type=int, default=252, help="Euler steps per trajectory")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the other BASELINE configs")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
 
@@ -212,6 +213,47 @@ def main():
             "price": res_gen.price,
             "rel_diff_vs_replay": abs(res_gen.price - res.price) / abs(res.price)},
     }
+
+    # ---- the other BASELINE.json configurations, a few launches each (rank 0, N = 1 only) -----
+    if world == 1 and not args.no_extra:
+        def kernel_ms(mdl, cfg, reps=5):
+            ctx.check(lib.hh_mc_accumulate(h, C.byref(mdl), C.byref(cfg), accum.data_ptr(), None))
+            ctx.enable_timing(True)
+            for _ in range(reps):
+                ctx.check(lib.hh_mc_accumulate(h, C.byref(mdl), C.byref(cfg), accum.data_ptr(), None))
+            t = float(np.median(ctx.read_timings()))
+            ctx.enable_timing(False)
+            r = _ffi.hh_result()
+            a = accum.cpu().numpy().copy()
+            lib.hh_mc_finalize(C.byref(mdl), C.byref(cfg), a.ctypes.data, C.byref(r))
+            return t, r
+
+        sd = {"S0": [1, 0, 0], "V0": [0, 1, 0], "r_drift": [0, 0, 1],
+              "discount": [0, 0, -float(np.exp(-H252["r"] * H252["T"]))]}
+        m5 = o.make_model(**H252, seeds=sd, n_partials=3)
+        c5 = config(_ffi.HH_NOISE_REPLAY)
+        c5.n_partials = 3
+        t5, r5 = kernel_ms(m5, c5)
+        c4 = o.make_config(_ffi.HH_HESTON, _ffi.HH_BROADIE_KAYA, n_paths)
+        c4.seeds, c4.seeds_on_device = seeds.data_ptr(), 1
+        t4, r4 = kernel_ms(model, c4, reps=3)
+        m2 = o.make_model(S0=100.0, sigma=0.2, r=0.05, T=1.0, strike=100.0)
+        c2 = o.make_config(_ffi.HH_LOGNORMAL, _ffi.HH_EXACT_LAW, n_paths)
+        c2.seeds, c2.seeds_on_device = seeds.data_ptr(), 1
+        t2, r2 = kernel_ms(m2, c2)
+        out["other_configs"] = {
+            "config2_lognormal_exact": {"paths_per_s": n_paths / (t2 * 1e-3), "kernel_ms": t2,
+                                        "price": r2.price, "analytic": 10.450583572185565},
+            "config4_broadie_kaya": {"paths_per_s": n_paths / (t4 * 1e-3), "kernel_ms": t4,
+                                     "price": r4.price, "std_error": r4.std_error,
+                                     "cf_terms_per_path": r4.bk_cf_terms / n_paths,
+                                     "bisect_fallbacks": int(r4.bk_bisect_fallback)},
+            "config5_greeks_delta_dV0_rho_replay": {
+                "path_steps_per_s": n_paths * n_steps / (t5 * 1e-3), "kernel_ms": t5,
+                "hbm_GBs": BYTES_PER_PATH_STEP * n_paths * n_steps / (t5 * 1e-3) / 1e9,
+                "greeks": [r5.dprice[k] for k in range(3)],
+                "fourier": [0.65565115, 40.7248418, 56.3225943]},
+        }
 
     # ---- bounded-sample checks against the CPU oracle (rank 0, N = 1 only) ------------------
     if world == 1 and not args.no_cpu_baseline:
