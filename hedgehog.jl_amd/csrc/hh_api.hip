@@ -33,6 +33,8 @@ struct hh_ctx {
   size_t basket_records_cap = 0;
   double* basket_accum = nullptr;
   size_t basket_accum_cap = 0;
+  unsigned char* bk_scratch = nullptr;
+  size_t bk_scratch_cap = 0;
   double* lsm_grid = nullptr;  // [n_steps+1][ntot]
   size_t lsm_grid_cap = 0;
   double* lsm_val = nullptr;
@@ -180,6 +182,7 @@ void hh_ctx_destroy(hh_ctx* ctx) {
   if (ctx->payoffs) (void)hipFree(ctx->payoffs);
   if (ctx->basket_records) (void)hipFree(ctx->basket_records);
   if (ctx->basket_accum) (void)hipFree(ctx->basket_accum);
+  if (ctx->bk_scratch) (void)hipFree(ctx->bk_scratch);
   if (ctx->lsm_grid) (void)hipFree(ctx->lsm_grid);
   if (ctx->lsm_val) (void)hipFree(ctx->lsm_val);
   if (ctx->lsm_tau) (void)hipFree(ctx->lsm_tau);
@@ -267,11 +270,17 @@ static int run_simulation(hh_ctx* ctx, const hh_model* m, const hh_config* c, do
                           bool need_terminal_dev, double** terminal_dev_out) {
   int rc = HH_OK;
   const uint32_t n_tiles = hh::tiles_for(c->n_paths);
-  rc = ensure(ctx, ctx->records, ctx->records_cap, (size_t)n_tiles * hh::kRecStride);
+  const bool bk = c->strategy == HH_BROADIE_KAYA;
+  rc = ensure(ctx, ctx->records, ctx->records_cap, (size_t)n_tiles * hh::kRecStride * (bk ? 2 : 1));
   if (rc) return rc;
 
   hh::DevicePtrs p{};
   p.records = ctx->records;
+  if (bk) {
+    rc = ensure(ctx, ctx->bk_scratch, ctx->bk_scratch_cap, hh::bk_scratch_bytes(c->n_paths));
+    if (rc) return rc;
+    p.bk_scratch = ctx->bk_scratch;
+  }
 
   // seeds: per-trajectory for Euler (montecarlo.jl:331), seeds[1] only for the exact laws (:456)
   if (c->noise_mode == HH_NOISE_GENERATE) {
@@ -363,8 +372,9 @@ int hh_mc_accumulate(hh_ctx* ctx, const hh_model* m, const hh_config* c, double*
   HH_HIP(ctx, hipSetDevice(ctx->device));
   rc = run_simulation(ctx, m, c, terminal, false, nullptr);
   if (rc) return rc;
-  HH_HIP(ctx, hh::launch_reduce_records(ctx->records, hh::tiles_for(c->n_paths),
-                                        (double)c->n_paths, accum_dev, ctx->stream, 1, m, c));
+  const uint32_t n_rec = hh::tiles_for(c->n_paths) * (c->strategy == HH_BROADIE_KAYA ? 2u : 1u);
+  HH_HIP(ctx, hh::launch_reduce_records(ctx->records, n_rec, (double)c->n_paths, accum_dev,
+                                        ctx->stream, 1, m, c));
   return copy_back_terminal(ctx, c, terminal);
 }
 

@@ -45,7 +45,8 @@ struct BkArgs {
   uint64_t n_paths, path_offset;
   const uint64_t* seeds;
   double* terminal;
-  double* records;
+  double* records;                 // [2·n_tiles][kRecStride]: phase 1, then phase 2
+  unsigned long long* fail_mask;   // [n_tiles][4] ballots of the trajectories left to phase 2
 };
 
 struct cx {
@@ -279,64 +280,117 @@ __device__ int poisson(double mu, const PathDraws& dr, int& it) {
   }
 }
 
+// everything a trajectory needs before the CDF inversion: draws, V_T, CF iterator, moments
+struct PathSetup {
+  double Z, u, VT;
+  CfIter cf;
+  double initial_guess, max_guess, h;
+};
+
+__device__ void bk_setup(const BkArgs& p, uint64_t path, PathSetup& s) {
+  const uint64_t key = p.seeds[0];  // montecarlo.jl:456
+  const uint64_t G = p.path_offset + path;
+  const PathDraws dr{(uint32_t)key, (uint32_t)(key >> 32), (uint32_t)G, (uint32_t)(G >> 32)};
+  double zshift, u_boost;
+  dr.normals(0u, s.Z, zshift);
+  dr.uniforms(1u, s.u, u_boost);
+
+  // 1. V_T (heston.jl:131)
+  int it = 0;
+  double chi;
+  if (p.d > 1.0) {
+    const double g = gamma_any(0.5 * (p.d - 1.0), dr, it, u_boost);
+    const double sh = zshift + sqrt(p.lam);
+    chi = sh * sh + 2.0 * g;
+  } else {
+    const int n = poisson(0.5 * p.lam, dr, it);
+    chi = 2.0 * gamma_any(0.5 * p.d + (double)n, dr, it, u_boost);
+  }
+  s.VT = p.cscale * chi;
+
+  // 2. HestonCFIterator (heston.jl:165-176) and the moment heuristics (sample_from_cf.jl:31-37)
+  s.cf.VT = s.VT;
+  s.cf.sqrtV0VT = sqrt(p.V0 * s.VT);
+  s.cf.sumV = (p.V0 + s.VT) / p.sigma2;
+  s.cf.logI_k = log_besseli(p, {p.nuk_factor * s.cf.sqrtV0VT, 0.0}).re;
+  double th = __builtin_nan("");
+  const double hm = p.moment_h;
+  const cx pp = evaluate_chf(p, s.cf, hm, th);
+  const cx p0 = evaluate_chf(p, s.cf, 0.0, th);
+  const cx pm = evaluate_chf(p, s.cf, -hm, th);
+  // mean = Re(-i ϕ'), variance = Re(-ϕ'' - mean²)   (sample_from_cf.jl:57-61)
+  const double mean = (pp.im - pm.im) / (2.0 * hm);
+  const double var = -((pp.re - 2.0 * p0.re + pm.re) / (hm * hm)) - mean * mean;
+  const double sd = sqrt(fmax(var, 1e-12));
+  const double normal_sample = mean + sd * normcdfinv(s.u);
+  s.initial_guess = normal_sample > 0.0 ? normal_sample : mean * 0.01;
+  s.max_guess = mean + 11.0 * sd;
+  s.h = kPi / (mean + p.n_sigma * sd);
+}
+
+// 3. log S_T (heston.jl:288-297), S_T = exp(.) (montecarlo.jl:384), payoff
+__device__ __forceinline__ double bk_finish(const BkArgs& p, const PathSetup& s, double IV,
+                                            uint64_t path) {
+  const double mu = p.logS0 + p.r * p.T - 0.5 * IV +
+                    (p.rho / p.sigma) * (s.VT - p.V0 - p.kappa * p.theta * p.T + p.kappa * IV);
+  const double sigma2 = (1.0 - p.rho * p.rho) * IV;
+  const double S = exp(mu + sqrt(sigma2) * s.Z);
+  if (p.terminal) p.terminal[path] = S;
+  const double m = p.cp * (S - p.strike);
+  return m > 0.0 ? m : 0.0;
+}
+
+__device__ __forceinline__ void bk_store_record(double (&acc)[6], double* rec) {
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc[i] += __shfl_down(acc[i], off, 64);
+  }
+  __shared__ double sm[kTile / 64][6];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) sm[wave][i] = acc[i];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      t[i] = sm[0][i];
+      for (int w = 1; w < kTile / 64; ++w) t[i] += sm[w][i];
+    }
+    for (int i = 0; i < kRecStride; ++i) rec[i] = 0.0;
+    rec[HH_ACC_SUM] = t[0];
+    rec[HH_ACC_SUMSQ] = t[1];
+    rec[HH_ACC_BK_NEWTON_FAIL] = t[2];
+    rec[HH_ACC_BK_BISECT] = t[3];
+    rec[HH_ACC_BK_MAXGUESS] = t[4];
+    rec[HH_ACC_BK_CF_TERMS] = t[5];
+  }
+}
+
+// Phase 1: every trajectory up to and including the secant iteration of inverse_cdf
+// (sample_from_cf.jl:116-122).  A trajectory whose secant fails is NOT finished here: one such lane
+// would keep its whole wave in the ~15-evaluation bisection ladder (2 % of the paths fail, so 3 out
+// of 4 waves would).  It is flagged in a per-wave ballot instead and finished, densely packed, by
+// bk_fallback_kernel.  Flags are ballots in trajectory order, so the result is bit-reproducible.
 __global__ __launch_bounds__(kTile) void bk_kernel(const BkArgs p) {
   const uint32_t tile = blockIdx.x, tid = threadIdx.x;
   const uint64_t path = (uint64_t)tile * kTile + tid;
   double acc[6] = {0, 0, 0, 0, 0, 0};  // Σp, Σp², newton_fail, bisect, maxguess, cf_terms
+  bool failed = false;
 
   if (path < p.n_paths) {
-    const uint64_t key = p.seeds[0];  // montecarlo.jl:456
-    const uint64_t G = p.path_offset + path;
-    const PathDraws dr{(uint32_t)key, (uint32_t)(key >> 32), (uint32_t)G, (uint32_t)(G >> 32)};
-    double Z, zshift, u, u_boost;
-    dr.normals(0u, Z, zshift);
-    dr.uniforms(1u, u, u_boost);
-
-    // 1. V_T (heston.jl:131)
-    int it = 0;
-    double chi;
-    if (p.d > 1.0) {
-      const double g = gamma_any(0.5 * (p.d - 1.0), dr, it, u_boost);
-      const double s = zshift + sqrt(p.lam);
-      chi = s * s + 2.0 * g;
-    } else {
-      const int n = poisson(0.5 * p.lam, dr, it);
-      chi = 2.0 * gamma_any(0.5 * p.d + (double)n, dr, it, u_boost);
-    }
-    const double VT = p.cscale * chi;
-
-    // 2. ∫V (heston.jl:165-176, sample_from_cf.jl:27-41)
-    CfIter cf;
-    cf.VT = VT;
-    cf.sqrtV0VT = sqrt(p.V0 * VT);
-    cf.sumV = (p.V0 + VT) / p.sigma2;
-    cf.logI_k = log_besseli(p, {p.nuk_factor * cf.sqrtV0VT, 0.0}).re;
-
+    PathSetup s;
+    bk_setup(p, path, s);
     double n_terms = 0.0;
-    double mean, var;
-    {
-      double th = __builtin_nan("");
-      const double h = p.moment_h;
-      const cx pp = evaluate_chf(p, cf, h, th);
-      const cx p0 = evaluate_chf(p, cf, 0.0, th);
-      const cx pm = evaluate_chf(p, cf, -h, th);
-      // mean = Re(-i ϕ'), variance = Re(-ϕ'' - mean²)   (sample_from_cf.jl:57-61)
-      mean = (pp.im - pm.im) / (2.0 * h);
-      var = -((pp.re - 2.0 * p0.re + pm.re) / (h * h)) - mean * mean;
-    }
-    const double s2 = fmax(var, 1e-12);
-    const double sd = sqrt(s2);
-    const double normal_sample = mean + sd * normcdfinv(u);
-    const double initial_guess = normal_sample > 0.0 ? normal_sample : mean * 0.01;
-    const double max_guess = mean + 11.0 * sd;
-    const double h = kPi / (mean + p.n_sigma * sd);
-
-    // inverse_cdf (sample_from_cf.jl:105-135): secant from (x0 + dx, x0)
-    const double hs = 6.0554544523933395e-06;  // eps^(1/3)
-    double x1 = initial_guess;
+    // secant from (x0 + dx, x0), dx = h + |x0| h², h = eps^(1/3)
+    const double hs = 6.0554544523933395e-06;
+    double x1 = s.initial_guess;
     double x0 = x1 + hs + fabs(x1) * hs * hs;
-    double f0 = cdf_from_cf(p, cf, x0, h, n_terms) - u;
-    double f1 = cdf_from_cf(p, cf, x1, h, n_terms) - u;
+    double f0 = cdf_from_cf(p, s.cf, x0, s.h, n_terms) - s.u;
+    double f1 = cdf_from_cf(p, s.cf, x1, s.h, n_terms) - s.u;
     int evals = 2;
     bool ok = false;
     while (true) {
@@ -350,88 +404,124 @@ __global__ __launch_bounds__(kTile) void bk_kernel(const BkArgs p) {
       x0 = x1;
       f0 = f1;
       x1 = x2;
-      f1 = cdf_from_cf(p, cf, x2, h, n_terms) - u;
+      f1 = cdf_from_cf(p, s.cf, x2, s.h, n_terms) - s.u;
       ++evals;
     }
-    double IV;
+    acc[5] = n_terms;
     if (ok && !(x1 < 0.0)) {
-      IV = x1;
+      const double pay = bk_finish(p, s, x1, path);
+      acc[0] = pay;
+      acc[1] = pay * pay;
     } else {
+      failed = true;
       acc[2] = 1.0;
-      double fa = cdf_from_cf(p, cf, 0.0, h, n_terms) - u;
-      const double fb = cdf_from_cf(p, cf, max_guess, h, n_terms) - u;
-      if (fa * fb > 0.0) {
-        acc[4] = 1.0;
-        IV = max_guess;  // sample_from_cf.jl:124-126
-      } else {
-        acc[3] = 1.0;
-        double lo = 0.0, hi = max_guess;
-        bool exact = false;
-        for (int i = 0; i < p.bisect_maxiter; ++i) {
-          const double mid = 0.5 * (lo + hi);
-          const double fm = cdf_from_cf(p, cf, mid, h, n_terms) - u;
-          if (fm == 0.0) {
-            lo = hi = mid;
-            exact = true;
-            break;
-          }
-          if ((fm < 0.0) == (fa < 0.0)) {
-            lo = mid;
-            fa = fm;
-          } else {
-            hi = mid;
-          }
-          if (hi - lo <= p.atol) break;
-        }
-        (void)exact;
-        IV = 0.5 * (lo + hi);
+    }
+  }
+  const unsigned long long mask = __ballot(failed);
+  if ((tid & 63) == 0) p.fail_mask[(size_t)tile * (kTile / 64) + (tid >> 6)] = mask;
+  bk_store_record(acc, p.records + (size_t)tile * kRecStride);
+}
+
+// exclusive prefix sum of the per-tile failure counts (single workgroup; n_tiles is small)
+__global__ __launch_bounds__(256) void bk_scan_kernel(const unsigned long long* __restrict__ mask,
+                                                      uint32_t n_tiles,
+                                                      uint32_t* __restrict__ prefix) {
+  __shared__ uint32_t sm[256];
+  __shared__ uint32_t carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (uint32_t base = 0; base < n_tiles; base += 256) {
+    const uint32_t t = base + threadIdx.x;
+    uint32_t c = 0;
+    if (t < n_tiles) {
+#pragma unroll
+      for (int w = 0; w < kTile / 64; ++w) c += (uint32_t)__popcll(mask[(size_t)t * (kTile / 64) + w]);
+    }
+    sm[threadIdx.x] = c;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {  // Hillis–Steele inclusive scan
+      const uint32_t v = threadIdx.x >= (unsigned)off ? sm[threadIdx.x - off] : 0;
+      __syncthreads();
+      sm[threadIdx.x] += v;
+      __syncthreads();
+    }
+    if (t < n_tiles) prefix[t] = carry + sm[threadIdx.x] - c;
+    __syncthreads();
+    if (threadIdx.x == 255) carry += sm[255];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) prefix[n_tiles] = carry;
+}
+
+// Phase 2: the fall-back ladder (sample_from_cf.jl:123-133) for the flagged trajectories, one per
+// lane, in trajectory order.
+__global__ __launch_bounds__(kTile) void bk_fallback_kernel(const BkArgs p, uint32_t n_tiles,
+                                                            const uint32_t* __restrict__ prefix) {
+  const uint32_t total = prefix[n_tiles];
+  const uint32_t g = blockIdx.x * kTile + threadIdx.x;
+  double* rec = p.records + (size_t)(n_tiles + blockIdx.x) * kRecStride;
+  if (blockIdx.x * (uint32_t)kTile >= total) {  // nothing for this workgroup (uniform branch)
+    if (threadIdx.x == 0)
+      for (int i = 0; i < kRecStride; ++i) rec[i] = 0.0;
+    return;
+  }
+  double acc[6] = {0, 0, 0, 0, 0, 0};
+  if (g < total) {
+    // tile = last t with prefix[t] <= g, then the (g - prefix[t])-th set bit of its 4 ballots
+    uint32_t lo = 0, hi = n_tiles;  // invariant: prefix[lo] <= g < prefix[hi]
+    while (hi - lo > 1) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (prefix[mid] <= g) lo = mid; else hi = mid;
+    }
+    uint32_t r = g - prefix[lo];
+    uint32_t bit = 0;
+    for (int w = 0; w < kTile / 64; ++w) {
+      unsigned long long mk = p.fail_mask[(size_t)lo * (kTile / 64) + w];
+      const uint32_t c = (uint32_t)__popcll(mk);
+      if (r < c) {
+        for (uint32_t i = 0; i < r; ++i) mk &= mk - 1;  // drop the r lowest set bits
+        bit = (uint32_t)w * 64u + (uint32_t)(__ffsll((long long)mk) - 1);
+        break;
       }
+      r -= c;
+    }
+    const uint64_t path = (uint64_t)lo * kTile + bit;
+
+    PathSetup s;
+    bk_setup(p, path, s);
+    double n_terms = 0.0;
+    double IV;
+    double fa = cdf_from_cf(p, s.cf, 0.0, s.h, n_terms) - s.u;
+    const double fb = cdf_from_cf(p, s.cf, s.max_guess, s.h, n_terms) - s.u;
+    if (fa * fb > 0.0) {
+      acc[4] = 1.0;
+      IV = s.max_guess;  // sample_from_cf.jl:124-126
+    } else {
+      acc[3] = 1.0;
+      double lo_x = 0.0, hi_x = s.max_guess;
+      for (int i = 0; i < p.bisect_maxiter; ++i) {
+        const double mid = 0.5 * (lo_x + hi_x);
+        const double fm = cdf_from_cf(p, s.cf, mid, s.h, n_terms) - s.u;
+        if (fm == 0.0) {
+          lo_x = hi_x = mid;
+          break;
+        }
+        if ((fm < 0.0) == (fa < 0.0)) {
+          lo_x = mid;
+          fa = fm;
+        } else {
+          hi_x = mid;
+        }
+        if (hi_x - lo_x <= p.atol) break;
+      }
+      IV = 0.5 * (lo_x + hi_x);
     }
     acc[5] = n_terms;
-
-    // 3. log S_T (heston.jl:288-297)
-    const double mu = p.logS0 + p.r * p.T - 0.5 * IV +
-                      (p.rho / p.sigma) * (VT - p.V0 - p.kappa * p.theta * p.T + p.kappa * IV);
-    const double sigma2 = (1.0 - p.rho * p.rho) * IV;
-    const double logS = mu + sqrt(sigma2) * Z;
-
-    const double S = exp(logS);  // montecarlo.jl:384
-    if (p.terminal) p.terminal[path] = S;
-    const double m = p.cp * (S - p.strike);
-    const double pay = m > 0.0 ? m : 0.0;
+    const double pay = bk_finish(p, s, IV, path);
     acc[0] = pay;
     acc[1] = pay * pay;
   }
-
-  // workgroup reduction into the tile's record
-#pragma unroll
-  for (int i = 0; i < 6; ++i) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) acc[i] += __shfl_down(acc[i], off, 64);
-  }
-  __shared__ double sm[kTile / 64][6];
-  const int lane = tid & 63, wave = tid >> 6;
-  if (lane == 0) {
-#pragma unroll
-    for (int i = 0; i < 6; ++i) sm[wave][i] = acc[i];
-  }
-  __syncthreads();
-  if (tid == 0) {
-    double t[6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      t[i] = sm[0][i];
-      for (int w = 1; w < kTile / 64; ++w) t[i] += sm[w][i];
-    }
-    double* rec = p.records + (size_t)tile * kRecStride;
-    for (int i = 0; i < kRecStride; ++i) rec[i] = 0.0;
-    rec[HH_ACC_SUM] = t[0];
-    rec[HH_ACC_SUMSQ] = t[1];
-    rec[HH_ACC_BK_NEWTON_FAIL] = t[2];
-    rec[HH_ACC_BK_BISECT] = t[3];
-    rec[HH_ACC_BK_MAXGUESS] = t[4];
-    rec[HH_ACC_BK_CF_TERMS] = t[5];
-  }
+  bk_store_record(acc, rec);
 }
 
 void hankel_coefficients(double nu, double* coef) {
@@ -445,6 +535,11 @@ void hankel_coefficients(double nu, double* coef) {
 }
 
 }  // namespace
+
+size_t bk_scratch_bytes(uint64_t n_paths) {
+  const size_t n_tiles = tiles_for(n_paths);
+  return n_tiles * (kTile / 64) * sizeof(unsigned long long) + (n_tiles + 1) * sizeof(uint32_t);
+}
 
 int launch_bk(const hh_model& m, const hh_config& c, const DevicePtrs& ptr, hipStream_t s) {
   BkArgs a{};
@@ -476,7 +571,12 @@ int launch_bk(const hh_model& m, const hh_config& c, const DevicePtrs& ptr, hipS
   a.seeds = ptr.seeds;
   a.terminal = ptr.terminal;
   a.records = ptr.records;
-  hipLaunchKernelGGL(bk_kernel, dim3(tiles_for(c.n_paths)), dim3(kTile), 0, s, a);
+  const uint32_t n_tiles = tiles_for(c.n_paths);
+  a.fail_mask = reinterpret_cast<unsigned long long*>(ptr.bk_scratch);
+  uint32_t* prefix = reinterpret_cast<uint32_t*>(a.fail_mask + (size_t)n_tiles * (kTile / 64));
+  hipLaunchKernelGGL(bk_kernel, dim3(n_tiles), dim3(kTile), 0, s, a);
+  hipLaunchKernelGGL(bk_scan_kernel, dim3(1), dim3(256), 0, s, a.fail_mask, n_tiles, prefix);
+  hipLaunchKernelGGL(bk_fallback_kernel, dim3(n_tiles), dim3(kTile), 0, s, a, n_tiles, prefix);
   return (int)hipGetLastError();
 }
 

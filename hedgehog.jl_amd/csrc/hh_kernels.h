@@ -51,6 +51,7 @@ struct DevicePtrs {
   double* terminal;
   double* terminal_d;
   double* records;
+  void* bk_scratch;  // Broadie–Kaya: bk_scratch_bytes() of device memory
 };
 
 // several payoffs on ONE set of terminal samples (basket.jl:35-38, same-expiry payoffs)
@@ -75,6 +76,7 @@ inline int pad_partials(uint32_t p) { return p == 0 ? 0 : p == 1 ? 1 : p <= 3 ? 
 // All launchers return a hipError_t as int (0 = success) and only enqueue work on `s`.
 int launch_simulation(const hh_model& m, const hh_config& c, const DevicePtrs& p, hipStream_t s);
 int launch_bk(const hh_model& m, const hh_config& c, const DevicePtrs& p, hipStream_t s);
+size_t bk_scratch_bytes(uint64_t n_paths);  // BK writes 2·tiles_for(n_paths) records
 // m, c given: finish the dual partials (active slots re-ordered, passive ones in closed form)
 int launch_reduce_records(const double* records, uint32_t n_records, double n_paths, double* accum,
                           hipStream_t s, uint32_t n_groups = 1, const hh_model* m = nullptr,
