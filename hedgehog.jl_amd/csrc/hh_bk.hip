@@ -47,6 +47,9 @@ struct BkArgs {
   double* terminal;
   double* records;                 // [2·n_tiles][kRecStride]: phase 1, then phase 2
   unsigned long long* fail_mask;   // [n_tiles][4] ballots of the trajectories left to phase 2
+  double* phi_cache;               // [cache_cap][cache_stride] cached Re ϕ(h·j), one column per lane
+  size_t cache_stride;
+  int cache_cap;
 };
 
 struct cx {
@@ -190,19 +193,51 @@ __device__ cx evaluate_chf(const BkArgs& p, const CfIter& it, double a, double& 
   return cexp(ex) * cdiv({p.zeta_k, 0.0}, zeta_g);
 }
 
+// The series terms ϕ(h·j) of cdf_from_cf do not depend on x: the reference re-evaluates them in
+// every one of the ~5-15 CDF evaluations of a trajectory's root search; here they are evaluated ONCE
+// (in the reference's order, with its continuous phase unwrapping) and Re ϕ_j is kept in a
+// per-lane column of a device scratch array, [term][lane] so a wave's accesses are contiguous.  The
+// stopping index does not depend on x either.  Same values, same summation order, bit-identical
+// results; a later evaluation costs one load + one sin per term instead of one complex-Bessel CF.
+struct PhiCache {
+  double* col;     // this lane's column: term j at col[(j-1)*stride]
+  size_t stride;
+  int cap;         // terms the column can hold
+  int filled;      // terms evaluated so far (≥ j_stop once known)
+  int j_stop;      // index of the last term (0 = not known yet)
+  double theta_run;  // unwrapped angle after term `filled`
+  double theta_cap;  // unwrapped angle after term `cap` (restart point when j_stop > cap)
+};
+
 // cdf_from_cf (sample_from_cf.jl:75-96)
-__device__ double cdf_from_cf(const BkArgs& p, const CfIter& it, double x, double h,
+__device__ double cdf_from_cf(const BkArgs& p, const CfIter& it, double x, double h, PhiCache& c,
                               double& n_terms) {
   if (x < 0.0) return 0.0;
   double result = h * x / kPi;
   const double pref = 2.0 / kPi, stop = kPi * p.cf_tol / 2.0;
-  double theta_prev = __builtin_nan("");
+  double theta_tail = c.theta_cap;  // for terms beyond the cached ones
   for (int j = 1; j < 1000000; ++j) {
     const double aj = h * (double)j;
-    const cx phi = evaluate_chf(p, it, aj, theta_prev);
-    result += pref * sin(aj * x) / (double)j * phi.re;
+    double re;
+    bool last;
+    if (j <= c.filled && j <= c.cap) {
+      re = c.col[(size_t)(j - 1) * c.stride];
+      last = j == c.j_stop;
+    } else {
+      double& th = (j <= c.cap || c.filled < c.cap) ? c.theta_run : theta_tail;
+      const cx phi = evaluate_chf(p, it, aj, th);
+      re = phi.re;
+      last = !(cabs(phi) / (double)j >= stop);  // also leaves on NaN
+      if (j > c.filled) {  // first time this term is seen
+        c.filled = j;
+        if (j <= c.cap) c.col[(size_t)(j - 1) * c.stride] = re;
+        if (j == c.cap) c.theta_cap = c.theta_run;
+        if (last) c.j_stop = j;
+      }
+    }
+    result += pref * sin(aj * x) / (double)j * re;
     n_terms += 1.0;
-    if (!(cabs(phi) / (double)j >= stop)) break;  // also leaves on NaN
+    if (last) break;
   }
   return result;
 }
@@ -284,10 +319,18 @@ __device__ int poisson(double mu, const PathDraws& dr, int& it) {
 struct PathSetup {
   double Z, u, VT;
   CfIter cf;
+  PhiCache cache;
   double initial_guess, max_guess, h;
 };
 
 __device__ void bk_setup(const BkArgs& p, uint64_t path, PathSetup& s) {
+  s.cache.col = p.phi_cache + ((size_t)blockIdx.x * kTile + threadIdx.x);
+  s.cache.stride = p.cache_stride;
+  s.cache.cap = p.cache_cap;
+  s.cache.filled = 0;
+  s.cache.j_stop = 0;
+  s.cache.theta_run = __builtin_nan("");
+  s.cache.theta_cap = __builtin_nan("");
   const uint64_t key = p.seeds[0];  // montecarlo.jl:456
   const uint64_t G = p.path_offset + path;
   const PathDraws dr{(uint32_t)key, (uint32_t)(key >> 32), (uint32_t)G, (uint32_t)(G >> 32)};
@@ -389,8 +432,8 @@ __global__ __launch_bounds__(kTile) void bk_kernel(const BkArgs p) {
     const double hs = 6.0554544523933395e-06;
     double x1 = s.initial_guess;
     double x0 = x1 + hs + fabs(x1) * hs * hs;
-    double f0 = cdf_from_cf(p, s.cf, x0, s.h, n_terms) - s.u;
-    double f1 = cdf_from_cf(p, s.cf, x1, s.h, n_terms) - s.u;
+    double f0 = cdf_from_cf(p, s.cf, x0, s.h, s.cache, n_terms) - s.u;
+    double f1 = cdf_from_cf(p, s.cf, x1, s.h, s.cache, n_terms) - s.u;
     int evals = 2;
     bool ok = false;
     while (true) {
@@ -404,7 +447,7 @@ __global__ __launch_bounds__(kTile) void bk_kernel(const BkArgs p) {
       x0 = x1;
       f0 = f1;
       x1 = x2;
-      f1 = cdf_from_cf(p, s.cf, x2, s.h, n_terms) - s.u;
+      f1 = cdf_from_cf(p, s.cf, x2, s.h, s.cache, n_terms) - s.u;
       ++evals;
     }
     acc[5] = n_terms;
@@ -491,8 +534,8 @@ __global__ __launch_bounds__(kTile) void bk_fallback_kernel(const BkArgs p, uint
     bk_setup(p, path, s);
     double n_terms = 0.0;
     double IV;
-    double fa = cdf_from_cf(p, s.cf, 0.0, s.h, n_terms) - s.u;
-    const double fb = cdf_from_cf(p, s.cf, s.max_guess, s.h, n_terms) - s.u;
+    double fa = cdf_from_cf(p, s.cf, 0.0, s.h, s.cache, n_terms) - s.u;
+    const double fb = cdf_from_cf(p, s.cf, s.max_guess, s.h, s.cache, n_terms) - s.u;
     if (fa * fb > 0.0) {
       acc[4] = 1.0;
       IV = s.max_guess;  // sample_from_cf.jl:124-126
@@ -501,7 +544,7 @@ __global__ __launch_bounds__(kTile) void bk_fallback_kernel(const BkArgs p, uint
       double lo_x = 0.0, hi_x = s.max_guess;
       for (int i = 0; i < p.bisect_maxiter; ++i) {
         const double mid = 0.5 * (lo_x + hi_x);
-        const double fm = cdf_from_cf(p, s.cf, mid, s.h, n_terms) - s.u;
+        const double fm = cdf_from_cf(p, s.cf, mid, s.h, s.cache, n_terms) - s.u;
         if (fm == 0.0) {
           lo_x = hi_x = mid;
           break;
@@ -536,9 +579,25 @@ void hankel_coefficients(double nu, double* coef) {
 
 }  // namespace
 
+constexpr int kPhiCapMax = 64;                   // series terms cached per trajectory
+constexpr size_t kPhiBudget = (size_t)4 << 30;   // at most 4 GiB of device scratch for the cache
+
+static int phi_cache_cap(size_t n_tiles) {
+  const size_t lanes = n_tiles * kTile;
+  size_t cap = kPhiBudget / (lanes * sizeof(double));
+  if (cap > (size_t)kPhiCapMax) cap = kPhiCapMax;
+  if (cap < 8) cap = 8;
+  return (int)cap;
+}
+
+static size_t bk_flags_bytes(size_t n_tiles) {
+  size_t b = n_tiles * (kTile / 64) * sizeof(unsigned long long) + (n_tiles + 1) * sizeof(uint32_t);
+  return (b + 255) & ~(size_t)255;
+}
+
 size_t bk_scratch_bytes(uint64_t n_paths) {
   const size_t n_tiles = tiles_for(n_paths);
-  return n_tiles * (kTile / 64) * sizeof(unsigned long long) + (n_tiles + 1) * sizeof(uint32_t);
+  return bk_flags_bytes(n_tiles) + n_tiles * kTile * sizeof(double) * (size_t)phi_cache_cap(n_tiles);
 }
 
 int launch_bk(const hh_model& m, const hh_config& c, const DevicePtrs& ptr, hipStream_t s) {
@@ -574,6 +633,10 @@ int launch_bk(const hh_model& m, const hh_config& c, const DevicePtrs& ptr, hipS
   const uint32_t n_tiles = tiles_for(c.n_paths);
   a.fail_mask = reinterpret_cast<unsigned long long*>(ptr.bk_scratch);
   uint32_t* prefix = reinterpret_cast<uint32_t*>(a.fail_mask + (size_t)n_tiles * (kTile / 64));
+  a.phi_cache = reinterpret_cast<double*>(reinterpret_cast<unsigned char*>(ptr.bk_scratch) +
+                                          bk_flags_bytes(n_tiles));
+  a.cache_stride = (size_t)n_tiles * kTile;
+  a.cache_cap = phi_cache_cap(n_tiles);
   hipLaunchKernelGGL(bk_kernel, dim3(n_tiles), dim3(kTile), 0, s, a);
   hipLaunchKernelGGL(bk_scan_kernel, dim3(1), dim3(256), 0, s, a.fail_mask, n_tiles, prefix);
   hipLaunchKernelGGL(bk_fallback_kernel, dim3(n_tiles), dim3(kTile), 0, s, a, n_tiles, prefix);

@@ -94,3 +94,25 @@ def test_bk_full_size_vs_carr_madan(hhlib, name, cm_bound):
     se_S = term.std() / math.sqrt(n)
     assert abs(term.mean() - prm["S0"] * math.exp(prm["r"] * prm["T"])) < 4 * se_S + 1e-3 * prm["S0"]
     assert res.n_paths_done == n and res.bk_maxguess_fallback < 0.01 * n
+
+
+def test_bk_long_series_beyond_the_term_cache(hhlib):
+    """cf_tol = 1e-6 makes the CDF series ~170 terms long, beyond the 64 cached Re ϕ_j per
+    trajectory: the tail is recomputed from the stored unwrapped angle and must still reproduce the
+    oracle, which re-evaluates every term in every CDF call as the reference does."""
+    prm = PARAMS["h252"]
+    n = 300
+    m = o.make_model(**prm)
+    c = o.make_config(_ffi.HH_HESTON, _ffi.HH_BROADIE_KAYA, n, seeds=[31337])
+    c.bk_cf_tol, c.bk_atol, c.bk_newton_maxiter = 1e-6, 1e-6, 20
+    res = _ffi.hh_result()
+    term = np.zeros(n)
+    hhlib.check(hhlib.lib.hh_mc_solve(hhlib.handle, C.byref(m), C.byref(c), C.byref(res),
+                                      term.ctypes.data))
+    ref = bk_oracle.mc_solve(**prm, discount=m.discount, n_paths=n, seed0=31337, cf_tol=1e-6,
+                             atol=1e-6, maxiter_newton=20)
+    assert res.bk_cf_terms / n > 100
+    rel = np.abs(term - ref["terminal"]) / ref["terminal"]
+    assert np.mean(rel > 1e-7) <= 0.02, np.sort(rel)[-5:]
+    assert res.bk_cf_terms == pytest.approx(ref["cf_terms"], rel=0.02)
+    assert res.price == pytest.approx(ref["price"], rel=1e-5)
