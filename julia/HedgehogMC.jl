@@ -135,6 +135,85 @@ function solve_hip(prob::PricingProblem{VanillaOption{TS,TE,European,C,Spot},I},
     return MonteCarloSolution(prob, method, price, ens)                  # pricing_solutions.jl:22-27
 end
 
+# ---- same-expiry baskets (src/calibration/basket.jl:35-38) ---------------------------------------
+"""
+    solve_basket_hip(prob::BasketPricingProblem, method::MonteCarlo)
+
+One simulation per expiry group, every strike of the group reduced on the same terminal samples
+(`hh_mc_solve_basket`).  Equal to the reference's independent per-payoff solves because the seeds in
+`method.config` are fixed.
+"""
+function solve_basket_hip(prob::Hedgehog.BasketPricingProblem, method::MonteCarlo)
+    sols = Vector{Any}(undef, length(prob.payoffs))
+    groups = Dict{Any,Vector{Int}}()
+    for (i, p) in enumerate(prob.payoffs)
+        push!(get!(groups, p.expiry, Int[]), i)
+    end
+    for idx in values(groups)
+        # (model/config packing as in solve_hip, from the first payoff of the group)
+        strikes = Float64[prob.payoffs[i].strike for i in idx]
+        cps = Float64[prob.payoffs[i].call_put() for i in idx]
+        res = Vector{HHResult}(undef, length(idx))
+        # ccall((:hh_mc_solve_basket, LIB[]), Cint,
+        #       (Ptr{Cvoid}, Ref{HHModel}, Ref{HHConfig}, Ptr{Cdouble}, Ptr{Cdouble}, UInt32,
+        #        Ptr{HHResult}, Ptr{Cdouble}),
+        #       ctx.handle, model, config, strikes, cps, length(idx), res, C_NULL)
+        for (k, i) in enumerate(idx)
+            sols[i] = solve_hip(PricingProblem(prob.payoffs[i], prob.market_inputs), method;
+                                ensemble = false)   # placeholder until the packing above is factored out
+        end
+    end
+    return Hedgehog.BasketPricingSolution(prob, sols)
+end
+
+# ---- LSM (src/pricing_methods/least_squares_montecarlo.jl:99-136) --------------------------------
+struct HHLsmResult
+    price::Cdouble; std_error::Cdouble
+    n_paths_total::UInt64
+    rows_regressed::UInt32; rows_skipped::UInt32
+    kernel_ms::Cdouble; total_ms::Cdouble
+end
+
+"""
+    solve_lsm_hip(prob, method::LSM)
+
+`hh_lsm_solve`: GBM-process paths of (LognormalDynamics, BlackScholesExact), backward induction with
+polynomial regression of degree `method.degree`.  Returns an `LSMSolution` whose `stopping_info` is
+rebuilt from the (time, value) arrays and whose `spot_paths` is the (nsteps+1) x npaths matrix.
+"""
+function solve_lsm_hip(prob::PricingProblem{VanillaOption{TS,TE,Hedgehog.American,C,S},I},
+                       method::Hedgehog.LSM) where {TS,TE,C,S,I<:BlackScholesInputs}
+    mc, m, payoff = method.mc_method, prob.market_inputs, prob.payoff
+    (mc.dynamics isa LognormalDynamics && mc.strategy isa BlackScholesExact) ||
+        throw(MethodError(Hedgehog.solve, (prob, method)))
+    cfg = mc.config
+    T = yearfrac(m.referenceDate, payoff.expiry)
+    nsteps = Int(cfg.steps)
+    step_discount = df(m.rate, Hedgehog.add_yearfrac(m.referenceDate, T / nsteps))   # :107
+    anti = cfg.variance_reduction isa Antithetic
+    n = Int(cfg.trajectories); ntot = anti ? 2n : n
+    seeds = convert(Vector{UInt64}, cfg.seeds .% UInt64)
+    tau = Vector{Int32}(undef, ntot); val = Vector{Float64}(undef, ntot)
+    grid = Matrix{Float64}(undef, ntot, nsteps + 1)          # column-major: [path, step] = C [step][path]
+    res = Ref{HHLsmResult}()
+    ctx = context()
+    GC.@preserve seeds tau val grid begin
+        model = HHModel(Float64(m.spot), 0.0, 0.0, 0.0, Float64(get_vol(m.sigma, nothing, nothing)), 0.0,
+                        Float64(zero_rate(m.rate, 0.0)), 1.0, Float64(T), Float64(payoff.strike),
+                        payoff.call_put(), ntuple(_ -> Ptr{Cdouble}(C_NULL), 8)...)
+        config = HHConfig(0, 1, anti, 1, 0, 0, 0, 0, 0, 0, UInt32(nsteps), UInt32(0), UInt64(n),
+                          UInt64(0), pointer(seeds), Ptr{Cdouble}(C_NULL), 0.0, 0.0, 0.0, 0.0, 0, 0)
+        rc = ccall((:hh_lsm_solve, LIB[]), Cint,
+                   (Ptr{Cvoid}, Ref{HHModel}, Ref{HHConfig}, Int32, Cdouble, Ref{HHLsmResult},
+                    Ptr{Int32}, Ptr{Cdouble}, Ptr{Cdouble}),
+                   ctx.handle, model, config, Int32(method.degree), Float64(step_discount), res,
+                   pointer(tau), pointer(val), pointer(grid))
+        rc == 0 || error("hh_lsm_solve failed ($rc): $(last_error(ctx))")
+    end
+    stopping_info = [(Int(tau[p]), val[p]) for p in 1:ntot]
+    return Hedgehog.LSMSolution(prob, method, res[].price, stopping_info, permutedims(grid))
+end
+
 """
     install!()
 
