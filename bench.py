@@ -74,7 +74,6 @@ def main():
 
     import hedgehog_jl_amd as hh
     from hedgehog_jl_amd import _ffi
-    from tests import oracle_ffi as o  # struct builders; the oracle itself only in cpu_baseline
 
     ctx = hh.Context(dev.index)  # raises without a HIP device — there is no CPU fallback
     lib, h = ctx.lib, ctx.handle
@@ -85,7 +84,7 @@ def main():
     # seeds[i] = global 1-based trajectory index; shard = contiguous range
     g0 = rank * n_paths
     seeds = torch.arange(g0 + 1, g0 + n_paths + 1, dtype=torch.int64, device=dev)
-    model = o.make_model(**H252)
+    model = _ffi.make_model(**H252)
 
     # synthetic input, generated on the device BEFORE the timed region: correlated increments
     n_el = lib.hh_replay_elems(n_paths, n_steps, _ffi.HH_HESTON)
@@ -95,8 +94,8 @@ def main():
     accum = torch.zeros(_ffi.HH_ACC_LEN, dtype=torch.float64, device=dev)
 
     def config(noise):
-        c = o.make_config(_ffi.HH_HESTON, _ffi.HH_EULER_MARUYAMA, n_paths, n_steps,
-                          noise_mode=noise)
+        c = _ffi.make_config(_ffi.HH_HESTON, _ffi.HH_EULER_MARUYAMA, n_paths, n_steps,
+                             noise_mode=noise)
         c.seeds, c.seeds_on_device = seeds.data_ptr(), 1
         c.replay, c.replay_on_device = dW.data_ptr(), 1
         return c
@@ -230,15 +229,15 @@ def main():
 
         sd = {"S0": [1, 0, 0], "V0": [0, 1, 0], "r_drift": [0, 0, 1],
               "discount": [0, 0, -float(np.exp(-H252["r"] * H252["T"]))]}
-        m5 = o.make_model(**H252, seeds=sd, n_partials=3)
+        m5 = _ffi.make_model(**H252, seeds=sd, n_partials=3)
         c5 = config(_ffi.HH_NOISE_REPLAY)
         c5.n_partials = 3
         t5, r5 = kernel_ms(m5, c5)
-        c4 = o.make_config(_ffi.HH_HESTON, _ffi.HH_BROADIE_KAYA, n_paths)
+        c4 = _ffi.make_config(_ffi.HH_HESTON, _ffi.HH_BROADIE_KAYA, n_paths)
         c4.seeds, c4.seeds_on_device = seeds.data_ptr(), 1
         t4, r4 = kernel_ms(model, c4, reps=3)
-        m2 = o.make_model(S0=100.0, sigma=0.2, r=0.05, T=1.0, strike=100.0)
-        c2 = o.make_config(_ffi.HH_LOGNORMAL, _ffi.HH_EXACT_LAW, n_paths)
+        m2 = _ffi.make_model(S0=100.0, sigma=0.2, r=0.05, T=1.0, strike=100.0)
+        c2 = _ffi.make_config(_ffi.HH_LOGNORMAL, _ffi.HH_EXACT_LAW, n_paths)
         c2.seeds, c2.seeds_on_device = seeds.data_ptr(), 1
         t2, r2 = kernel_ms(m2, c2)
         out["other_configs"] = {
@@ -257,12 +256,13 @@ def main():
 
     # ---- bounded-sample checks against the CPU oracle (rank 0, N = 1 only) ------------------
     if world == 1 and not args.no_cpu_baseline:
-        orc = o.load()
+        from tests import oracle_ffi  # the ONLY use of the oracle here: checker + timed CPU baseline
+        orc = oracle_ffi.load()
         tiles = 200                                   # 51,200 trajectories of the SAME buffer
         ns = min(n_paths, tiles * _ffi.HH_TILE_PATHS)
         n_s_el = lib.hh_replay_elems(ns, n_steps, _ffi.HH_HESTON)
         dW_s = dW[:n_s_el].cpu().numpy()
-        c_s = o.make_config(_ffi.HH_HESTON, _ffi.HH_EULER_MARUYAMA, ns, n_steps,
+        c_s = _ffi.make_config(_ffi.HH_HESTON, _ffi.HH_EULER_MARUYAMA, ns, n_steps,
                             noise_mode=_ffi.HH_NOISE_REPLAY, replay=dW_s)
         r_gpu = _ffi.hh_result()
         ctx.check(lib.hh_mc_solve(h, C.byref(model), C.byref(c_s), C.byref(r_gpu), None))

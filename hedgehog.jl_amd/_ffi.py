@@ -193,3 +193,48 @@ def seed_array(values, n: int):
         return None
     arr = (C.c_double * n)(*[float(v) for v in values])
     return arr
+
+
+# ---- plain-number builders of the C structs (bench, tools, tests drive the C-ABI directly) ----------
+
+def make_model(S0=100.0, V0=0.04, kappa=2.0, theta=0.04, sigma=0.3, rho=-0.7, r=0.03, T=1.0,
+               strike=100.0, cp=1.0, discount=None, seeds=None, n_partials=0):
+    """hh_model from plain numbers; defaults = benchmark problem H252.
+    seeds: dict name -> list of n_partials dual seeds (names: S0, V0, kappa, theta, sigma, r_drift,
+    discount, strike)."""
+    import math
+    m = hh_model()
+    m.S0, m.V0, m.kappa, m.theta, m.sigma, m.rho = S0, V0, kappa, theta, sigma, rho
+    m.r_drift, m.T, m.strike, m.cp = r, T, strike, cp
+    m.discount = math.exp(-r * T) if discount is None else discount
+    keep = []
+    for name, vals in (seeds or {}).items():
+        arr = (C.c_double * n_partials)(*vals)
+        keep.append(arr)
+        setattr(m, "d" + name, C.cast(arr, C.POINTER(C.c_double)))
+    m._keep = keep
+    return m
+
+
+def make_config(dynamics, strategy, n_paths, n_steps=1, antithetic=0, em_split=1, noise_mode=0,
+                seeds=None, replay=None, replay_layout=0, n_partials=0, path_offset=0,
+                compat_sqrt_alpha=0):
+    """hh_config from plain numbers; `seeds` / `replay` are HOST numpy arrays (kept alive on the
+    returned struct) — set the pointer fields and the *_on_device flags yourself for device memory."""
+    import numpy as np
+    c = hh_config()
+    c.dynamics, c.strategy, c.antithetic, c.em_split = dynamics, strategy, antithetic, em_split
+    c.compat_sqrt_alpha = compat_sqrt_alpha
+    c.noise_mode, c.replay_layout = noise_mode, replay_layout
+    c.n_steps, c.n_partials, c.n_paths, c.path_offset = n_steps, n_partials, n_paths, path_offset
+    keep = []
+    if seeds is not None:
+        seeds = np.ascontiguousarray(seeds, dtype=np.uint64)
+        keep.append(seeds)
+        c.seeds = seeds.ctypes.data
+    if replay is not None:
+        replay = np.ascontiguousarray(replay, dtype=np.float64)
+        keep.append(replay)
+        c.replay = replay.ctypes.data
+    c._keep = keep
+    return c

@@ -17,7 +17,6 @@ import torch  # noqa: E402
 
 import hedgehog_jl_amd as hh  # noqa: E402
 from hedgehog_jl_amd import _ffi  # noqa: E402
-from tests import oracle_ffi as o  # noqa: E402  (struct builders only)
 
 
 def main():
@@ -55,24 +54,24 @@ def main():
 
     # config 1: BS Euler 10^4 x 100 (examples/montecarlo_black_scholes.jl: put, S=K=1, r=.03, σ=.04)
     T366 = 366 / 365
-    m1 = o.make_model(S0=1.0, sigma=0.04, r=0.03, T=T366, strike=1.0, cp=-1.0)
-    run("config1_bs_euler_1e4x100", m1, dev_cfg(o.make_config(0, 0, 10_000, 100)), 1e4 * 100,
+    m1 = _ffi.make_model(S0=1.0, sigma=0.04, r=0.03, T=T366, strike=1.0, cp=-1.0)
+    run("config1_bs_euler_1e4x100", m1, dev_cfg(_ffi.make_config(0, 0, 10_000, 100)), 1e4 * 100,
         "path-steps/s")
     # config 2: lognormal exact 10^6 vs BlackScholesAnalytic
-    m2 = o.make_model(S0=100.0, sigma=0.2, r=0.05, T=1.0, strike=100.0)
-    run("config2_lognormal_exact_1e6", m2, dev_cfg(o.make_config(0, 1, N)), N, "paths/s")
+    m2 = _ffi.make_model(S0=100.0, sigma=0.2, r=0.05, T=1.0, strike=100.0)
+    run("config2_lognormal_exact_1e6", m2, dev_cfg(_ffi.make_config(0, 1, N)), N, "paths/s")
     out["config2_lognormal_exact_1e6"]["analytic"] = 10.450583572185565
     # config 3: Heston Euler 10^6 x 252, GENERATE and REPLAY (+ antithetic REPLAY)
-    m3 = o.make_model()
+    m3 = _ffi.make_model()
     dW = torch.empty(lib.hh_replay_elems(N, M, 1), dtype=torch.float64, device=dev)
     ctx.check(lib.hh_wiener_fill(h, 1, m3.rho, m3.T, M, N, seeds.data_ptr(), 1, dW.data_ptr()))
 
     def rep_cfg(**kw):
-        c = dev_cfg(o.make_config(1, 0, N, M, noise_mode=1, **kw))
+        c = dev_cfg(_ffi.make_config(1, 0, N, M, noise_mode=1, **kw))
         c.replay, c.replay_on_device = dW.data_ptr(), 1
         return c
 
-    run("config3_heston_euler_generate", m3, dev_cfg(o.make_config(1, 0, N, M)), N * M,
+    run("config3_heston_euler_generate", m3, dev_cfg(_ffi.make_config(1, 0, N, M)), N * M,
         "path-steps/s")
     run("config3_heston_euler_replay", m3, rep_cfg(), N * M, "path-steps/s")
     out["config3_heston_euler_replay"]["hbm_GBs"] = 16e-9 * out["config3_heston_euler_replay"]["throughput"]
@@ -81,15 +80,15 @@ def main():
     # config 5: (Δ, ∂V0, ρ) fused, 10^6 x 252
     sd = {"S0": [1, 0, 0], "V0": [0, 1, 0], "r_drift": [0, 0, 1],
           "discount": [0, 0, -float(np.exp(-0.03))]}
-    m5 = o.make_model(seeds=sd, n_partials=3)
-    run("config5_greeks3_generate", m5, dev_cfg(o.make_config(1, 0, N, M, n_partials=3)), N * M,
+    m5 = _ffi.make_model(seeds=sd, n_partials=3)
+    run("config5_greeks3_generate", m5, dev_cfg(_ffi.make_config(1, 0, N, M, n_partials=3)), N * M,
         "path-steps/s")
     run("config5_greeks3_replay", m5, rep_cfg(n_partials=3), N * M, "path-steps/s")
     out["config5_greeks3_replay"]["hbm_GBs"] = 16e-9 * out["config5_greeks3_replay"]["throughput"]
     out["config5_greeks3_replay"]["fourier_targets"] = [0.65565115, 40.7248418, 56.3225943]
     del dW
     # config 4: Broadie–Kaya 10^6
-    c4 = o.make_config(1, 2, N)
+    c4 = _ffi.make_config(1, 2, N)
     seed0 = torch.tensor([99], dtype=torch.int64, device=dev)
     c4.seeds, c4.seeds_on_device = seed0.data_ptr(), 1
     run("config4_broadie_kaya_1e6", m3, c4, N, "paths/s", reps=5, warm=1,

@@ -2,12 +2,11 @@ import sys, ctypes as C, numpy as np
 sys.path.insert(0, '.')
 import hedgehog_jl_amd as hh
 from hedgehog_jl_amd import _ffi
-from tests import oracle_ffi as o
 ctx = hh.get_context(0)
-m = o.make_model()
+m = _ffi.make_model()
 cm = 9.242521073959068
 def run(seed, n=1_000_000, **kw):
-    c = o.make_config(1, 2, n, seeds=[seed])
+    c = _ffi.make_config(1, 2, n, seeds=[seed])
     for k, v in kw.items(): setattr(c, k, v)
     r = _ffi.hh_result()
     ctx.check(ctx.lib.hh_mc_solve(ctx.handle, C.byref(m), C.byref(c), C.byref(r), None))

@@ -12,13 +12,12 @@ import torch  # noqa: E402
 
 import hedgehog_jl_amd as hh  # noqa: E402
 from hedgehog_jl_amd import _ffi  # noqa: E402
-from tests import oracle_ffi as o  # noqa: E402
 
 ctx = hh.Context(0)
 lib, h = ctx.lib, ctx.handle
 N, M = 1_000_000, 252
 seeds = torch.arange(1, N + 1, dtype=torch.int64, device="cuda")
-m = o.make_model()
+m = _ffi.make_model()
 n_el = lib.hh_replay_elems(N, M, 1)
 dW = torch.empty(n_el, dtype=torch.float64, device="cuda")
 ctx.check(lib.hh_wiener_fill(h, 1, m.rho, m.T, M, N, seeds.data_ptr(), 1, dW.data_ptr()))
@@ -27,7 +26,7 @@ host_pageable = dW.cpu().numpy()
 host_pinned = torch.empty(n_el, dtype=torch.float64, pin_memory=True)
 host_pinned.copy_(dW.cpu())
 for label, ptr in (("pageable", host_pageable.ctypes.data), ("pinned", host_pinned.data_ptr())):
-    c = o.make_config(1, 0, N, M, noise_mode=1)
+    c = _ffi.make_config(1, 0, N, M, noise_mode=1)
     c.replay = ptr
     r = _ffi.hh_result()
     ts = []

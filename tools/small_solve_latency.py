@@ -11,17 +11,16 @@ import torch  # noqa: E402
 
 import hedgehog_jl_amd as hh  # noqa: E402
 from hedgehog_jl_amd import _ffi  # noqa: E402
-from tests import oracle_ffi as o  # noqa: E402
 
 ctx = hh.Context(0)
 lib, h = ctx.lib, ctx.handle
 for label, n, steps, dyn in (("BS Euler 1e4x100", 10_000, 100, 0), ("Heston Euler 1e4x100", 10_000, 100, 1),
                              ("Heston Euler 1e5x252", 100_000, 252, 1)):
-    m = o.make_model(sigma=0.2 if dyn == 0 else 0.3)
+    m = _ffi.make_model(sigma=0.2 if dyn == 0 else 0.3)
     seeds_h = np.arange(1, n + 1, dtype=np.uint64)
     seeds_d = torch.from_numpy(seeds_h.view(np.int64)).cuda()
     for where in ("host seeds", "device seeds"):
-        c = o.make_config(dyn, 0, n, steps, seeds=seeds_h)
+        c = _ffi.make_config(dyn, 0, n, steps, seeds=seeds_h)
         if where == "device seeds":
             c.seeds, c.seeds_on_device = seeds_d.data_ptr(), 1
         r = _ffi.hh_result()

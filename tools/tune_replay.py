@@ -59,7 +59,6 @@ def run(rounds=7):
     import numpy as np
     import torch
     from hedgehog_jl_amd import _ffi
-    from tests import oracle_ffi as o
     n_paths, n_steps = 1_000_000, 252
     dev = torch.device("cuda", 0)
     seeds = torch.arange(1, n_paths + 1, dtype=torch.int64, device=dev)
@@ -74,13 +73,13 @@ def run(rounds=7):
         lib.hh_ctx_enable_timing(h, 1)
         libs[tag] = (lib, h)
     lib0, h0 = next(iter(libs.values()))
-    m = o.make_model()
+    m = _ffi.make_model()
     dW = torch.empty(lib0.hh_replay_elems(n_paths, n_steps, 1), dtype=torch.float64, device=dev)
     assert lib0.hh_wiener_fill(h0, 1, m.rho, m.T, n_steps, n_paths, seeds.data_ptr(), 1,
                                dW.data_ptr()) == 0
     lib0.hh_ctx_synchronize(h0)
     acc = torch.zeros(16, dtype=torch.float64, device=dev)
-    c = o.make_config(1, 0, n_paths, n_steps, noise_mode=1)
+    c = _ffi.make_config(1, 0, n_paths, n_steps, noise_mode=1)
     c.replay, c.replay_on_device = dW.data_ptr(), 1
     times = {t: [] for t in libs}
     prices = {}
