@@ -1,34 +1,47 @@
-# parity_replay.jl — per-draw parity of the HIP path against the REFERENCE itself.
+# parity_replay.jl — exports the REFERENCE's own Wiener draws and results so that the HIP path can be
+# checked per trajectory against Hedgehog.jl itself (closes the "parity unpinned" gap of DESIGN.md §2).
 #
-# NOT RUN in this build (no Julia on the build image or GPU box).  On a host with Julia +
-# Hedgehog.jl + libhedgehog_mc.so it closes the "parity unpinned" gap of DESIGN.md §2: simulate with
-# the reference, saving the noise (the mechanism the reference itself uses for antithetic replay,
-# montecarlo.jl:370), export per-trajectory increments diff(W.W), feed them to the kernels in
-# HH_NOISE_REPLAY / HH_REPLAY_PATH_MAJOR mode, and compare terminal samples and price.
-# It also settles em_split empirically (run both, one matches to ~1e-13).
+# NOT RUN in this build: there is no Julia on the build image or on the GPU box.  On a host with
+# Julia + Hedgehog.jl:
+#
+#     julia --project julia/parity_replay.jl out_dir            # writes dW.bin, ST.bin, meta.json
+#     python tools/check_reference_replay.py out_dir/meta.json  # on the MI355X box
+#
+# Mechanism: simulate with the reference, saving the noise — exactly what the reference itself does
+# for antithetic replay (montecarlo.jl:370) — and export per-trajectory increments diff(W.W); the
+# kernels consume them through HH_NOISE_REPLAY / HH_REPLAY_PATH_MAJOR.  Comparing both em_split
+# settings also settles which step form StochasticDiffEq's EM() uses.
 using Hedgehog, StochasticDiffEq, Dates
-include(joinpath(@__DIR__, "HedgehogMC.jl"))
-using .HedgehogMC
+
+outdir = length(ARGS) >= 1 ? ARGS[1] : "replay_out"
+mkpath(outdir)
 
 ref = Date(2021, 1, 1); expiry = Date(2022, 1, 1)
-prob = PricingProblem(VanillaOption(100.0, expiry, European(), Call(), Spot()),
-                      HestonInputs(ref, 0.03, 100.0, 0.04, 2.0, 0.04, 0.3, -0.7))
-N, M = 10_000, 252
+S0, K, r, V0, κ, θ, σ, ρ = 100.0, 100.0, 0.03, 0.04, 2.0, 0.04, 0.3, -0.7
+prob = PricingProblem(VanillaOption(K, expiry, European(), Call(), Spot()),
+                      HestonInputs(ref, r, S0, V0, κ, θ, σ, ρ))
+N, M = 20_000, 252
 cfg = SimulationConfig(N; steps = M, seeds = collect(UInt64, 1:N))
 method = MonteCarlo(HestonDynamics(), EulerMaruyama(), cfg)
 
 sde = Hedgehog.sde_problem(prob, method)
 ens = StochasticDiffEq.solve(Hedgehog.get_ensemble_problem(sde, cfg), EM();
                              dt = sde.tspan[2] / M, trajectories = N, save_noise = true)
-dW = Array{Float64}(undef, 2, M, N)                     # [comp][step][path] = path-major in C order
+
+# [comp, step, path] in Julia's column-major order == [path][step][comp] in C order
+dW = Array{Float64}(undef, 2, M, N)
 for i in 1:N, s in 1:M
     dW[:, s, i] .= ens.u[i].W.W[s + 1] .- ens.u[i].W.W[s]
 end
-S_ref = Hedgehog.final_sample(ens)
-price_ref = Hedgehog.solve(prob, method).price
+S_ref = Hedgehog.final_sample(ens)                       # montecarlo.jl:398
+payoffs = Hedgehog.reduce_payoffs(S_ref, prob.payoff, cfg.variance_reduction)
+price_ref = df(prob.market_inputs.rate, prob.payoff.expiry) * sum(payoffs) / N
 
-for split in (true, false)
-    # (solve_hip with a `replay` keyword mirrors the Python mirror's solve_montecarlo(replay=…))
-    println("em_split=$split: see hedgehog_jl_amd.solve_montecarlo(replay=dW) for the call; ",
-            "compare maximum(abs.(S_gpu .- S_ref) ./ S_ref) and abs(price_gpu - price_ref)/price_ref")
+write(joinpath(outdir, "dW.bin"), dW)
+write(joinpath(outdir, "ST.bin"), S_ref)
+open(joinpath(outdir, "meta.json"), "w") do io
+    print(io, """{"n_paths": $N, "n_steps": $M, "S0": $S0, "strike": $K, "r": $r, "V0": $V0,
+ "kappa": $κ, "theta": $θ, "sigma": $σ, "rho": $ρ, "T": $(sde.tspan[2]), "cp": 1.0,
+ "price": $price_ref, "dW": "dW.bin", "ST": "ST.bin", "layout": "path-major [path][step][comp] float64 LE"}""")
 end
+println("wrote $outdir: price_ref = $price_ref")

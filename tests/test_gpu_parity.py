@@ -292,3 +292,23 @@ def test_mixed_active_and_passive_directions(hhlib, oracle, dyn, strategy, anti)
     ro, to, _ = oracle.mc_solve(m, c)
     check(rg, tg, ro, to, P, 1e-11, 1e-11, rtol_d=1e-9)
     assert rg.bk_newton_fail == 0 and rg.bk_bisect_fallback == 0  # internal slots stay internal
+
+
+def test_reference_replay_exchange_format(capsys):
+    """tools/check_reference_replay.py on the committed format self-test (oracle-generated with
+    em_split=1): the matching step form agrees to rounding, the other one does not."""
+    import os
+    import runpy
+    import sys
+
+    from tests.conftest import ROOT
+    meta = os.path.join(ROOT, "tests", "golden", "replay_selftest", "meta.json")
+    argv = sys.argv
+    sys.argv = ["check_reference_replay.py", meta]
+    try:
+        runpy.run_path(os.path.join(ROOT, "tools", "check_reference_replay.py"), run_name="__main__")
+    finally:
+        sys.argv = argv
+    lines = [ln for ln in capsys.readouterr().out.splitlines() if ln.startswith("em_split")]
+    err = {ln.split(":")[0]: float(ln.split("= ")[1].split(",")[0]) for ln in lines}
+    assert err["em_split=1"] < 1e-12 and err["em_split=0"] > 1e-6
