@@ -257,3 +257,23 @@ def test_bk_oracle_like_reference():
                                         prm["theta"], prm["sigma"], prm["rho"], prm["T"], bound=bound)
         assert abs(r["price"] - cm) < 4 * r["std_error"] + 0.02 * cm
         assert np.all(np.isfinite(r["terminal"])) and r["stats"]["maxguess"] <= 15
+
+
+def test_oracle_reproduces_committed_replay_fixture(oracle):
+    """tests/golden/replay_selftest (made by tests/golden/make_replay_selftest.py): the oracle must
+    reproduce the stored terminal samples and price from the stored increments bit for bit — guards
+    the oracle, the path-major layout and the exchange format of julia/parity_replay.jl."""
+    base = os.path.join(os.path.dirname(__file__), "golden", "replay_selftest")
+    meta = json.load(open(os.path.join(base, "meta.json")))
+    n, steps = meta["n_paths"], meta["n_steps"]
+    dW = np.fromfile(os.path.join(base, meta["dW"]), dtype="<f8")
+    ST = np.fromfile(os.path.join(base, meta["ST"]), dtype="<f8")
+    m = o.make_model(S0=meta["S0"], V0=meta["V0"], kappa=meta["kappa"], theta=meta["theta"],
+                     sigma=meta["sigma"], rho=meta["rho"], r=meta["r"], T=meta["T"],
+                     strike=meta["strike"], cp=meta["cp"])
+    c = o.make_config(HES, EM, n, steps, em_split=1, noise_mode=1, replay=dW, replay_layout=1)
+    r, t, _ = oracle.mc_solve(m, c)
+    np.testing.assert_array_equal(t, ST)
+    assert r.price == meta["price"]
+    c0 = o.make_config(HES, EM, n, steps, em_split=0, noise_mode=1, replay=dW, replay_layout=1)
+    assert np.max(np.abs(oracle.mc_solve(m, c0)[1] - ST) / ST) > 1e-6  # the other step form differs
