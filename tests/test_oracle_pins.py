@@ -261,7 +261,7 @@ def test_bk_oracle_like_reference():
 
 def test_oracle_reproduces_committed_replay_fixture(oracle):
     """tests/golden/replay_selftest (made by tests/golden/make_replay_selftest.py): the oracle must
-    reproduce the stored terminal samples and price from the stored increments bit for bit — guards
+    reproduce the stored terminal samples and price from the stored increments — guards
     the oracle, the path-major layout and the exchange format of julia/parity_replay.jl."""
     base = os.path.join(os.path.dirname(__file__), "golden", "replay_selftest")
     meta = json.load(open(os.path.join(base, "meta.json")))
@@ -273,7 +273,7 @@ def test_oracle_reproduces_committed_replay_fixture(oracle):
                      strike=meta["strike"], cp=meta["cp"])
     c = o.make_config(HES, EM, n, steps, em_split=1, noise_mode=1, replay=dW, replay_layout=1)
     r, t, _ = oracle.mc_solve(m, c)
-    np.testing.assert_array_equal(t, ST)
-    assert r.price == meta["price"]
+    np.testing.assert_allclose(t, ST, rtol=1e-14)  # identical up to the host libm's exp()
+    assert r.price == pytest.approx(meta["price"], rel=1e-14)
     c0 = o.make_config(HES, EM, n, steps, em_split=0, noise_mode=1, replay=dW, replay_layout=1)
     assert np.max(np.abs(oracle.mc_solve(m, c0)[1] - ST) / ST) > 1e-6  # the other step form differs
