@@ -416,7 +416,7 @@ int hh_mc_accumulate_basket(hh_ctx* ctx, const hh_model* m, const hh_config* c,
   b.records = ctx->basket_records;
   HH_HIP(ctx, hh::launch_basket_payoffs(b, n_payoffs, (uint32_t)n_active, ctx->stream));
   HH_HIP(ctx, hh::launch_reduce_records(ctx->basket_records, b.n_chunks, (double)c->n_paths,
-                                        accum_dev, ctx->stream, n_payoffs, m, c));
+                                        accum_dev, ctx->stream, n_payoffs, m, c, true));
   return copy_back_terminal(ctx, c, terminal);
 }
 

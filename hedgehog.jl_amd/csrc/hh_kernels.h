@@ -80,7 +80,7 @@ size_t bk_scratch_bytes(uint64_t n_paths);  // BK writes 2·tiles_for(n_paths) r
 // m, c given: finish the dual partials (active slots re-ordered, passive ones in closed form)
 int launch_reduce_records(const double* records, uint32_t n_records, double n_paths, double* accum,
                           hipStream_t s, uint32_t n_groups = 1, const hh_model* m = nullptr,
-                          const hh_config* c = nullptr);
+                          const hh_config* c = nullptr, bool basket = false);
 int count_active_partials(const hh_model& m, const hh_config& c);
 int launch_basket_payoffs(const BasketArgs& b, uint32_t n_payoffs, uint32_t n_active_partials,
                           hipStream_t s);

@@ -653,12 +653,13 @@ int launch_simulation(const hh_model& m, const hh_config& c, const DevicePtrs& p
 }
 
 int launch_reduce_records(const double* records, uint32_t n_records, double n_paths, double* accum,
-                          hipStream_t s, uint32_t n_groups, const hh_model* m, const hh_config* c) {
+                          hipStream_t s, uint32_t n_groups, const hh_model* m, const hh_config* c,
+                          bool basket) {
   PartialMap pm{};
-  if (m && c && c->strategy != HH_BROADIE_KAYA) {
+  if (m && c && (basket || c->strategy != HH_BROADIE_KAYA)) {
     if (c->n_partials) pm = classify_partials(*m, *c);
     pm.sim = 1;
-    if (n_groups > 1)  // basket: strike partials are not carried
+    if (basket)  // strike partials are not carried through a basket
       for (double& d : pm.dK) d = 0.0;
   }
   hipLaunchKernelGGL(reduce_records_kernel, dim3(kRecStride, n_groups), dim3(256), 0, s, records,

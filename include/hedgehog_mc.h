@@ -160,7 +160,9 @@ int hh_mc_finalize(const hh_model* model, const hh_config* cfg, const double* ac
  * seeds of SimulationConfig they see the same trajectories, so the results coincide).  Payoff k is
  * max(cps[k]·(S_T − strikes[k]), 0); model->strike / model->cp are ignored.  The accumulator block
  * is n_payoffs × HH_ACC_LEN doubles, payoff-major (all-reducible as one vector); dual partials of
- * the model parameters are carried for every payoff (strike partials are not).
+ * the model parameters are carried for every payoff (strike partials are not).  Works for every
+ * simulation strategy, Broadie–Kaya included.  Host arrays passed to an *_accumulate entry point
+ * must stay valid until the ctx stream has been synchronized.
  */
 int hh_mc_accumulate_basket(hh_ctx* ctx, const hh_model* model, const hh_config* cfg,
                             const double* strikes, const double* cps, uint32_t n_payoffs,

@@ -93,3 +93,23 @@ def test_basket_full_size_strike_ladder():
     ctx.check(ctx.lib.hh_mc_solve(ctx.handle, C.byref(m), C.byref(c), C.byref(single), None))
     assert res[20].price == pytest.approx(single.price, rel=1e-12)  # K = 100 call
     assert res[0].kernel_ms < 3 * single.kernel_ms + 1.0
+
+
+def test_basket_on_broadie_kaya_samples(hhlib):
+    """A strike ladder on exact Heston samples: one Broadie–Kaya simulation, all strikes reduced on
+    it; each equals the single-payoff solve on the same key."""
+    n = 20_000
+    strikes = np.array([90.0, 100.0, 110.0, 100.0])
+    cps = np.array([1.0, 1.0, 1.0, -1.0])
+    m = o.make_model()
+    c = o.make_config(1, 2, n, seeds=[2718])
+    res = (_ffi.hh_result * 4)()
+    hhlib.check(hhlib.lib.hh_mc_solve_basket(hhlib.handle, C.byref(m), C.byref(c),
+                                             strikes.ctypes.data, cps.ctypes.data, 4, res, None))
+    for k in range(4):
+        mk = o.make_model(strike=float(strikes[k]), cp=float(cps[k]))
+        single = _ffi.hh_result()
+        hhlib.check(hhlib.lib.hh_mc_solve(hhlib.handle, C.byref(mk), C.byref(c), C.byref(single),
+                                          None))
+        assert res[k].price == pytest.approx(single.price, rel=1e-12)
+        assert res[k].bk_newton_fail == 0  # counters belong to the simulation, not to a payoff
