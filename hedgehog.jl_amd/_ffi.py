@@ -43,6 +43,7 @@ class hh_config(C.Structure):
         ("bk_n_sigma", C.c_double), ("bk_cf_tol", C.c_double), ("bk_atol", C.c_double),
         ("bk_moment_h", C.c_double),
         ("bk_newton_maxiter", C.c_int32), ("bk_bisect_maxiter", C.c_int32),
+        ("seeds_len", C.c_uint64), ("replay_len", C.c_uint64),
     ]
 
 
@@ -232,9 +233,11 @@ def make_config(dynamics, strategy, n_paths, n_steps=1, antithetic=0, em_split=1
         seeds = np.ascontiguousarray(seeds, dtype=np.uint64)
         keep.append(seeds)
         c.seeds = seeds.ctypes.data
+        c.seeds_len = seeds.size
     if replay is not None:
         replay = np.ascontiguousarray(replay, dtype=np.float64)
         keep.append(replay)
         c.replay = replay.ctypes.data
+        c.replay_len = replay.size
     c._keep = keep
     return c

@@ -124,12 +124,28 @@ int validate(hh_ctx* ctx, const hh_model* m, const hh_config* c) {
     if (m->sigma == 0.0 || m->kappa == 0.0 || !(m->V0 > 0.0))
       return fail(ctx, HH_ERR_INVALID, "HestonBroadieKaya needs sigma != 0, kappa != 0, V0 > 0");
   }
+  const bool euler = c->strategy == HH_EULER_MARUYAMA;
   if (c->noise_mode == HH_NOISE_REPLAY) {
     if (!c->replay) return fail(ctx, HH_ERR_INVALID, "REPLAY needs a replay buffer");
     if (((uintptr_t)c->replay & 15u) != 0)
       return fail(ctx, HH_ERR_INVALID, "replay buffer must be 16-byte aligned");
+    if (c->replay_len) {  // operand shape: what the kernels (or the packer) will index
+      uint64_t need = c->n_paths;  // exact law: one normal per trajectory
+      if (euler)
+        need = c->replay_layout == HH_REPLAY_PATH_MAJOR
+                   ? c->n_paths * (uint64_t)c->n_steps * (uint64_t)ncomp_of(c->dynamics)
+                   : (uint64_t)hh::tiles_for(c->n_paths) * c->n_steps * ncomp_of(c->dynamics) *
+                         hh::kTile;
+      if (c->replay_len < need)
+        return fail(ctx, HH_ERR_INVALID, "replay buffer holds %llu elements, %llu needed",
+                    (unsigned long long)c->replay_len, (unsigned long long)need);
+    }
   } else if (c->noise_mode == HH_NOISE_GENERATE) {
     if (!c->seeds) return fail(ctx, HH_ERR_INVALID, "GENERATE needs seeds");
+    const uint64_t need = euler ? c->n_paths : 1;  // montecarlo.jl:65-66, 331, 456
+    if (c->seeds_len && c->seeds_len < need)
+      return fail(ctx, HH_ERR_INVALID, "Number of seeds (%llu) must be >= number of trajectories (%llu)",
+                  (unsigned long long)c->seeds_len, (unsigned long long)need);
   } else {
     return fail(ctx, HH_ERR_INVALID, "unknown noise_mode %d", c->noise_mode);
   }

@@ -171,11 +171,13 @@ def solve_montecarlo(prob: PricingProblem, method: MonteCarlo, ensemble: bool = 
     ctx = _ffi.get_context(method.device)
     seeds = cfg.seeds
     c.seeds = seeds.ctypes.data
+    c.seeds_len = seeds.size
     if replay is not None:
         replay = np.ascontiguousarray(replay, dtype=np.float64)
         c.noise_mode = _ffi.HH_NOISE_REPLAY
         c.replay_layout = replay_layout
         c.replay = replay.ctypes.data
+        c.replay_len = replay.size
     anti = bool(c.antithetic)
     term = None
     term_ptr = None

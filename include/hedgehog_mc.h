@@ -109,6 +109,11 @@ typedef struct hh_config {
   double bk_moment_h;        /* h = 1e-2                                                          */
   int32_t bk_newton_maxiter; /* 10                                                                */
   int32_t bk_bisect_maxiter; /* 100                                                               */
+  /* Optional operand-shape checks (0 = not checked): the number of ELEMENTS behind `seeds` and
+     `replay`.  When given, a buffer shorter than what the kernels will index is rejected with
+     HH_ERR_INVALID on the host instead of faulting on the device.                               */
+  uint64_t seeds_len;
+  uint64_t replay_len;
 } hh_config;
 
 typedef struct hh_result {

@@ -39,6 +39,7 @@ struct HHConfig
     seeds::Ptr{UInt64}; replay::Ptr{Cdouble}
     bk_n_sigma::Cdouble; bk_cf_tol::Cdouble; bk_atol::Cdouble; bk_moment_h::Cdouble
     bk_newton_maxiter::Int32; bk_bisect_maxiter::Int32
+    seeds_len::UInt64; replay_len::UInt64
 end
 
 struct HHResult
@@ -119,7 +120,8 @@ function solve_hip(prob::PricingProblem{VanillaOption{TS,TE,European,C,Spot},I},
                         ptr(1), ptr(2), ptr(3), ptr(4), ptr(5), ptr(6), ptr(7), ptr(8))
         config = HHConfig(dynamics, strategy, anti, em_split, compat_sqrt_alpha,
                           0, 0, 0, 0, 0, UInt32(cfg.steps), UInt32(P), UInt64(n), UInt64(0),
-                          pointer(seeds), Ptr{Cdouble}(C_NULL), 0.0, 0.0, 0.0, 0.0, 0, 0)
+                          pointer(seeds), Ptr{Cdouble}(C_NULL), 0.0, 0.0, 0.0, 0.0, 0, 0,
+                          UInt64(length(seeds)), UInt64(0))
         rc = ccall((:hh_mc_solve, LIB[]), Cint,
                    (Ptr{Cvoid}, Ref{HHModel}, Ref{HHConfig}, Ref{HHResult}, Ptr{Cdouble}),
                    ctx.handle, model, config, res,
@@ -202,7 +204,8 @@ function solve_lsm_hip(prob::PricingProblem{VanillaOption{TS,TE,Hedgehog.America
                         Float64(zero_rate(m.rate, 0.0)), 1.0, Float64(T), Float64(payoff.strike),
                         payoff.call_put(), ntuple(_ -> Ptr{Cdouble}(C_NULL), 8)...)
         config = HHConfig(0, 1, anti, 1, 0, 0, 0, 0, 0, 0, UInt32(nsteps), UInt32(0), UInt64(n),
-                          UInt64(0), pointer(seeds), Ptr{Cdouble}(C_NULL), 0.0, 0.0, 0.0, 0.0, 0, 0)
+                          UInt64(0), pointer(seeds), Ptr{Cdouble}(C_NULL), 0.0, 0.0, 0.0, 0.0, 0, 0,
+                          UInt64(length(seeds)), UInt64(0))
         rc = ccall((:hh_lsm_solve, LIB[]), Cint,
                    (Ptr{Cvoid}, Ref{HHModel}, Ref{HHConfig}, Int32, Cdouble, Ref{HHLsmResult},
                     Ptr{Int32}, Ptr{Cdouble}, Ptr{Cdouble}),

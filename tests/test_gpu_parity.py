@@ -232,6 +232,15 @@ def test_error_codes(hhlib):
     assert b"replay" in lib.hh_last_error(h)
     bad = o.make_model(S0=-1.0)
     assert rc(o.make_config(HES, EM, 10, 5, seeds=np.arange(10)), bad) == _ffi.HH_ERR_INVALID
+    # operand-shape checks: short buffers are rejected on the host, never indexed on the device
+    assert rc(o.make_config(HES, EM, 300, 5, seeds=np.arange(299))) == _ffi.HH_ERR_INVALID
+    assert b"seeds" in lib.hh_last_error(h)
+    short = np.zeros(2 * 5 * 2 * 256 - 1)
+    assert rc(o.make_config(HES, EM, 300, 5, noise_mode=REP, replay=short)) == _ffi.HH_ERR_INVALID
+    assert rc(o.make_config(HES, EM, 300, 5, noise_mode=REP, replay=np.zeros(300 * 5 * 2 - 1),
+                            replay_layout=_ffi.HH_REPLAY_PATH_MAJOR)) == _ffi.HH_ERR_INVALID
+    assert rc(o.make_config(GBM, EXACT, 300, noise_mode=REP, replay=np.zeros(299))) == \
+        _ffi.HH_ERR_INVALID
 
 
 def test_timing_hooks(hhlib):

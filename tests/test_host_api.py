@@ -129,7 +129,7 @@ def test_cabi_header_and_library_agree():
     # struct layouts seen by ctypes == what the compiler laid out (sizes are part of the ABI)
     assert C.sizeof(_ffi.hh_model) == 11 * 8 + 8 * 8
     assert C.sizeof(_ffi.hh_result) == 4 * 8 + 8 * 8 + 5 * 8 + 2 * 8
-    assert C.sizeof(_ffi.hh_config) == 10 * 4 + 2 * 4 + 2 * 8 + 2 * 8 + 4 * 8 + 2 * 4
+    assert C.sizeof(_ffi.hh_config) == 10 * 4 + 2 * 4 + 2 * 8 + 2 * 8 + 4 * 8 + 2 * 4 + 2 * 8
 
 
 def test_finalize_is_pure_host_arithmetic():
