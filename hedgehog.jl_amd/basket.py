@@ -55,6 +55,7 @@ def solve_basket(prob: BasketPricingProblem, method: MonteCarlo, ensemble: bool 
         strikes = (C.c_double * K)(*[float(payoffs[i].strike) for i in idx])
         cps = (C.c_double * K)(*[payoffs[i].call_put() for i in idx])
         c.seeds = cfg.seeds.ctypes.data
+        c.seeds_len = cfg.seeds.size
         anti = bool(c.antithetic)
         term = np.empty(c.n_paths * (2 if anti else 1)) if ensemble else None
         res = (_ffi.hh_result * K)()

@@ -538,6 +538,9 @@ int hh_lsm_solve(hh_ctx* ctx, const hh_model* m, const hh_config* c, int32_t deg
     return fail(ctx, HH_ERR_UNSUPPORTED, "LSM: GENERATE noise, no dual partials");
   if (c->n_paths == 0 || c->n_steps == 0 || !c->seeds || degree < 1 || degree > 8)
     return fail(ctx, HH_ERR_INVALID, "LSM: n_paths, n_steps >= 1, seeds, 1 <= degree <= 8");
+  if (c->seeds_len && c->seeds_len < c->n_paths)
+    return fail(ctx, HH_ERR_INVALID, "Number of seeds (%llu) must be >= number of trajectories (%llu)",
+                (unsigned long long)c->seeds_len, (unsigned long long)c->n_paths);
   if (!(m->S0 > 0.0) || !(m->T > 0.0) || (m->cp != 1.0 && m->cp != -1.0) ||
       !(step_discount > 0.0) || !std::isfinite(step_discount))
     return fail(ctx, HH_ERR_INVALID, "LSM: bad model scalars");

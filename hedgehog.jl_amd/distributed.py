@@ -54,6 +54,7 @@ def solve_sharded(prob, method: MonteCarlo, group=None, accumulate=None) -> Mont
     if c.strategy == _ffi.HH_EULER_MARUYAMA:
         seeds = np.ascontiguousarray(seeds[start:stop] if stop > start else seeds[:1])
     c.seeds = seeds.ctypes.data
+    c.seeds_len = seeds.size
     acc = (accumulate or _hip_accumulate)(model, c, method.device)
     if not isinstance(acc, torch.Tensor):
         acc = torch.as_tensor(np.asarray(acc, dtype=np.float64))

@@ -76,6 +76,7 @@ def solve_lsm(prob: PricingProblem, method: LSM, spot_paths: bool = False,
     c.antithetic = int(isinstance(cfg.variance_reduction, Antithetic))
     c.n_steps, c.n_paths = nsteps, cfg.trajectories
     c.seeds = cfg.seeds.ctypes.data
+    c.seeds_len = cfg.seeds.size
     ntot = cfg.trajectories * (2 if c.antithetic else 1)
     tau = np.empty(ntot, dtype=np.int32) if stopping_info else None
     val = np.empty(ntot) if stopping_info else None
