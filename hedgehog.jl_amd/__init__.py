@@ -19,8 +19,8 @@ from .montecarlo import (AbstractPricingMethod, Antithetic, BlackScholesExact, E
                          MonteCarlo, NoVarianceReduction, SimulationConfig, solve_montecarlo)
 from .distributed import shard_range, solve_sharded
 from .domain import (American, BlackScholesInputs, Call, European, FlatRateCurve, FlatVolSurface,
-                    Forward, HestonInputs, MonteCarloSolution, PricingProblem, Put, Spot,
-                    VanillaOption, df, get_vol, zero_rate)
+                    Forward, HestonInputs, MonteCarloSolution, PricingProblem, Put, RateCurve, Spot,
+                    VanillaOption, df, get_vol, spine_zeros, zero_rate)
 
 
 def solve(*args, **kw):

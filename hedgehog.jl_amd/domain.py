@@ -84,12 +84,60 @@ class FlatRateCurve:
         object.__setattr__(self, "rate", rate)
 
 
-def zero_rate(curve: FlatRateCurve, ticks):
-    """rate_curve.jl:185-186."""
-    return curve.rate
+@dataclass(frozen=True)
+class RateCurve:
+    """rate_curve.jl:20-24, 60-91: zero rates on a tenor spine, built from discount factors
+    (z = -log(df)/t), interpolated LINEARLY in the zero rate with CONSTANT extrapolation (the
+    reference's default `interp`).  Host-side scalar lookups only; the kernels see r_drift and
+    discount.  Zero rates may be `Dual` (ZeroRateSpineLens, pricing_methods.jl:34-50)."""
+    reference_date: int
+    tenors: tuple
+    zeros: tuple
+
+    def __init__(self, reference_date, tenors, dfs=None, zeros=None):
+        tenors = tuple(float(t) for t in tenors)
+        if not tenors:
+            raise ValueError("Input 'tenors' cannot be empty.")
+        if any(b < a for a, b in zip(tenors, tenors[1:])):
+            raise ValueError("'tenors' must be sorted.")
+        if tenors[0] < 0:
+            raise ValueError("First tenor must be non-negative.")
+        if zeros is None:
+            if len(dfs) != len(tenors):
+                raise ValueError("Mismatched lengths for 'tenors' and 'dfs'.")
+            if not all(d > 0 for d in dfs):
+                raise ValueError("All discount factors must be positive.")
+            import math
+            zeros = tuple(-math.log(d) / t for d, t in zip(dfs, tenors))
+        object.__setattr__(self, "reference_date", to_ticks(reference_date))
+        object.__setattr__(self, "tenors", tenors)
+        object.__setattr__(self, "zeros", tuple(zeros))
+
+    def interpolate(self, t):
+        ts, zs = self.tenors, self.zeros
+        if t <= ts[0]:
+            return zs[0]
+        if t >= ts[-1]:
+            return zs[-1]
+        import bisect
+        i = bisect.bisect_right(ts, t) - 1
+        w = (t - ts[i]) / (ts[i + 1] - ts[i])
+        return zs[i] + (zs[i + 1] - zs[i]) * w
 
 
-def df(curve: FlatRateCurve, t):
+def spine_zeros(curve):
+    """pricing_methods.jl:59, rate_curve.jl spine accessors."""
+    return [curve.rate] if isinstance(curve, FlatRateCurve) else list(curve.zeros)
+
+
+def zero_rate(curve, ticks):
+    """rate_curve.jl:182-186: flat -> the rate; RateCurve -> interpolator(yearfrac(ref, ticks))."""
+    if isinstance(curve, FlatRateCurve):
+        return curve.rate
+    return curve.interpolate(yearfrac(curve.reference_date, to_ticks(ticks)))
+
+
+def df(curve, t):
     """rate_curve.jl:149-150."""
     ticks = to_ticks(t)
     return dexp(-zero_rate(curve, ticks) * yearfrac(curve.reference_date, ticks))
@@ -131,7 +179,7 @@ class BlackScholesInputs:
 
     def __init__(self, reference_date, rate, spot, sigma):
         ref = to_ticks(reference_date)
-        if not isinstance(rate, FlatRateCurve):
+        if not isinstance(rate, (FlatRateCurve, RateCurve)):
             rate = FlatRateCurve(ref, rate)
         if not isinstance(sigma, FlatVolSurface):
             sigma = FlatVolSurface(ref, sigma)
@@ -155,7 +203,7 @@ class HestonInputs:
 
     def __init__(self, reference_date, rate, spot, V0, κ, θ, σ, ρ):
         ref = to_ticks(reference_date)
-        if not isinstance(rate, FlatRateCurve):
+        if not isinstance(rate, (FlatRateCurve, RateCurve)):
             rate = FlatRateCurve(ref, rate)
         for k, v in (("referenceDate", ref), ("rate", rate), ("spot", spot), ("V0", V0), ("κ", κ),
                      ("θ", θ), ("σ", σ), ("ρ", ρ)):

@@ -15,7 +15,7 @@ from dataclasses import dataclass
 from typing import Any
 
 from .dual import Dual
-from .domain import BlackScholesInputs, FlatRateCurve, FlatVolSurface, HestonInputs
+from .domain import BlackScholesInputs, FlatRateCurve, FlatVolSurface, HestonInputs, RateCurve
 
 
 def _replace(obj, name, val):
@@ -69,13 +69,16 @@ class VolLens(GreekLens):
 
 @dataclass(frozen=True)
 class ZeroRateSpineLens(GreekLens):
-    """pricing_methods.jl:26-60; getter defined for BlackScholesInputs with a flat curve (:30-32)."""
+    """pricing_methods.jl:26-60; getter defined for BlackScholesInputs with a flat curve (:30-32)
+    or an interpolated RateCurve (:34-36, 1-based spine index)."""
     i: int
 
     def __call__(self, prob):
         m = prob.market_inputs
-        if not (isinstance(m, BlackScholesInputs) and isinstance(m.rate, FlatRateCurve)):
-            raise TypeError("ZeroRateSpineLens getter: BlackScholesInputs{FlatRateCurve} only")
+        if not isinstance(m, BlackScholesInputs):
+            raise TypeError("ZeroRateSpineLens getter: BlackScholesInputs only")
+        if isinstance(m.rate, RateCurve):
+            return m.rate.zeros[self.i - 1]
         return m.rate.rate
 
 
@@ -87,9 +90,15 @@ def set(prob, lens, val):  # noqa: A001 - the reference's name (Accessors.set)
     if isinstance(lens, VolLens):
         sigma = prob.market_inputs.sigma
         return _set_path(prob, ("market_inputs", "sigma"), FlatVolSurface(sigma.reference_date, val))
-    if isinstance(lens, ZeroRateSpineLens):
+    if isinstance(lens, ZeroRateSpineLens):  # pricing_methods.jl:39-57
         curve = prob.market_inputs.rate
-        return _set_path(prob, ("market_inputs", "rate"), FlatRateCurve(curve.reference_date, val))
+        if isinstance(curve, RateCurve):
+            z = list(curve.zeros)
+            z[lens.i - 1] = val
+            new = RateCurve(curve.reference_date, curve.tenors, zeros=z)
+        else:
+            new = FlatRateCurve(curve.reference_date, val)
+        return _set_path(prob, ("market_inputs", "rate"), new)
     raise TypeError(f"unknown lens {lens!r}")
 
 

@@ -166,3 +166,42 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 src = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "oracle" not in src.lower(), (dirpath, f)
+
+
+def test_interpolated_rate_curve_scalars_and_spine_lens():
+    """rate_curve.jl:60-91,182-186 (linear in the zero rate, constant extrapolation) and
+    pricing_methods.jl:34-50.  The kernels only ever see the scalars the host resolves — including
+    the reference's quirk Q4: the Euler drift uses zero_rate(curve, 0.0), i.e. the FIRST spine zero,
+    while the exact law and the discount use the rate at expiry."""
+    import math
+    ref = hh.Date(2020, 1, 1)
+    tenors = [0.25, 0.5, 1.0, 2.0, 5.0]
+    zs = [0.02, 0.025, 0.03, 0.035, 0.04]
+    curve = hh.RateCurve(ref, tenors, [math.exp(-z * t) for z, t in zip(zs, tenors)])
+    assert curve.zeros == pytest.approx(zs, rel=1e-12) and hh.spine_zeros(curve) == list(curve.zeros)
+    assert hh.zero_rate(curve, 0.0) == curve.zeros[0]                       # constant extrapolation
+    assert hh.zero_rate(curve, hh.Date(2030, 1, 1)) == curve.zeros[-1]
+    T = 366 / 365
+    zT = zs[2] + (zs[3] - zs[2]) * (T - 1.0)
+    assert hh.zero_rate(curve, hh.Date(2021, 1, 1)) == pytest.approx(zT, rel=1e-12)
+    assert hh.df(curve, hh.Date(2021, 1, 1)) == pytest.approx(math.exp(-zT * T), rel=1e-13)
+    with pytest.raises(ValueError):
+        hh.RateCurve(ref, [1.0, 0.5], [0.9, 0.95])
+    with pytest.raises(ValueError):
+        hh.RateCurve(ref, [], [])
+
+    payoff = hh.VanillaOption(100.0, hh.Date(2021, 1, 1), hh.European(), hh.Call(), hh.Spot())
+    prob = hh.PricingProblem(payoff, hh.BlackScholesInputs(ref, curve, 100.0, 0.2))
+    lens = hh.ZeroRateSpineLens(3)
+    assert lens(prob) == curve.zeros[2]
+    p2 = hh.set(prob, lens, hh.Dual(lens(prob), (1.0,)))
+    cfg = hh.SimulationConfig(10, steps=5)
+    m, c, _, P, _ = _model_and_config(p2, hh.MonteCarlo(hh.LognormalDynamics(),
+                                                        hh.BlackScholesExact(), cfg))
+    w3 = 1.0 - (T - 1.0)  # weight of spine node 3 at t = T
+    assert m.r_drift == pytest.approx(zT) and m.dr_drift[0] == pytest.approx(w3)
+    assert m.ddiscount[0] == pytest.approx(-T * w3 * math.exp(-zT * T))
+    m, c, _, P, _ = _model_and_config(p2, hh.MonteCarlo(hh.LognormalDynamics(), hh.EulerMaruyama(),
+                                                        cfg))
+    assert m.r_drift == curve.zeros[0] and not m.dr_drift          # Q4: drift from the first node
+    assert m.ddiscount[0] == pytest.approx(-T * w3 * math.exp(-zT * T))
