@@ -15,7 +15,7 @@ from dataclasses import dataclass
 from typing import Any
 
 from .dual import Dual
-from .domain import BlackScholesInputs, FlatRateCurve, FlatVolSurface, HestonInputs, RateCurve
+from .domain import BlackScholesInputs, FlatRateCurve, FlatVolSurface, RateCurve
 
 
 def _replace(obj, name, val):

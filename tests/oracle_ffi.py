@@ -8,7 +8,6 @@ import subprocess
 
 import numpy as np
 
-import hedgehog_jl_amd as hh
 from hedgehog_jl_amd import _ffi
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -7,7 +7,6 @@ import sys
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 import hedgehog_jl_amd as hh  # noqa: E402
