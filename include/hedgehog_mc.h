@@ -123,7 +123,8 @@ typedef struct hh_result {
   double dprice[HH_MAX_PARTIALS]; /* partials of price, direction k                              */
   uint64_t n_paths_done;
   uint64_t bk_newton_fail, bk_bisect_fallback, bk_maxguess_fallback, bk_cf_terms;
-  double kernel_ms;           /* HIP-event time of the simulation + reduction kernels             */
+  double kernel_ms;           /* HIP-event time of everything the call enqueued: staging copies
+                                 of host seeds / increments, simulation, record reduction         */
   double total_ms;            /* host wall time of the call                                       */
 } hh_result;
 
