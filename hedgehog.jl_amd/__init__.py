@@ -6,6 +6,8 @@ Import as `hedgehog_jl_amd` (shim at the repository root; the directory name car
 """
 from . import _ffi
 from ._ffi import Context, HedgehogMCError, get_context, load_library
+from .analytic import (AnalyticSolution, BlackScholesAnalytic, CarrMadan, solve_black_scholes,
+                       solve_carr_madan)
 from .basket import BasketPricingProblem, BasketPricingSolution, solve_basket
 from .dates import Date, DateTime, add_years, to_ticks, yearfrac
 from .dual import Dual
@@ -32,11 +34,17 @@ def solve(*args, **kw):
         solve(gprob::SecondOrderGreekProblem, ::FiniteDifference, method)    greeks_problem.jl:396
         solve(gprob::BatchGreekProblem, ::GreekMethod, method)               greeks_problem.jl:559
         solve(prob::BasketPricingProblem, method::MonteCarlo)                basket.jl:35
+        solve(prob, ::CarrMadan) / solve(prob, ::BlackScholesAnalytic)       carr_madan.jl:47, black_scholes.jl:38
         solve(prob::PricingProblem{<:VanillaOption{…,American,…}}, ::LSM)     least_squares_montecarlo.jl:99
     """
     from . import greeks as _g
     if len(args) == 2 and isinstance(args[0], PricingProblem) and isinstance(args[1], MonteCarlo):
         return solve_montecarlo(args[0], args[1], **kw)
+    if len(args) == 2 and isinstance(args[0], PricingProblem) and isinstance(args[1], CarrMadan):
+        return solve_carr_madan(args[0], args[1])
+    if len(args) == 2 and isinstance(args[0], PricingProblem) and \
+            isinstance(args[1], BlackScholesAnalytic):
+        return solve_black_scholes(args[0], args[1])
     if len(args) == 2 and isinstance(args[0], PricingProblem) and isinstance(args[1], LSM):
         return solve_lsm(args[0], args[1], **kw)
     if len(args) == 2 and isinstance(args[0], BasketPricingProblem) and isinstance(args[1], MonteCarlo):

@@ -8,7 +8,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib", "libhedgehog_mc.so")
-SOURCES = ["hh_api.hip", "hh_kernels.hip", "hh_bk.hip", "hh_lsm.hip"]
+SOURCES = ["hh_api.hip", "hh_kernels.hip", "hh_bk.hip", "hh_lsm.hip", "hh_fourier.hip"]
 FLAGS = ["-shared", "-fPIC", "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off",
          "-Wall", "-Wno-unused-function"]
 

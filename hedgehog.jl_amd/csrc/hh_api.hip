@@ -519,6 +519,27 @@ int hh_mc_solve(hh_ctx* ctx, const hh_model* m, const hh_config* c, hh_result* o
   return HH_OK;
 }
 
+int hh_carr_madan(hh_ctx* ctx, const hh_model* m, int32_t dynamics, int32_t compat_sqrt_alpha,
+                  double alpha, double bound, double* price_out) {
+  if (!ctx) return HH_ERR_INVALID;
+  if (!m || !price_out) return fail(ctx, HH_ERR_INVALID, "hh_carr_madan: NULL argument");
+  if (dynamics != HH_LOGNORMAL && dynamics != HH_HESTON)
+    return fail(ctx, HH_ERR_INVALID, "unknown dynamics %d", dynamics);
+  if (!(m->S0 > 0.0) || !(m->strike > 0.0) || !(m->T > 0.0) || !(alpha > 0.0) || !(bound > 0.0) ||
+      (m->cp != 1.0 && m->cp != -1.0) || (dynamics == HH_HESTON && m->sigma == 0.0))
+    return fail(ctx, HH_ERR_INVALID, "hh_carr_madan: bad scalars");
+  HH_HIP(ctx, hipSetDevice(ctx->device));
+  HH_HIP(ctx, hh::launch_carr_madan(*m, dynamics, compat_sqrt_alpha, alpha, bound, ctx->accum,
+                                    ctx->stream));
+  HH_HIP(ctx, hipMemcpyAsync(ctx->accum_host, ctx->accum, sizeof(double), hipMemcpyDeviceToHost,
+                             ctx->stream));
+  HH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  const double call = ctx->accum_host[0];
+  // parity_transform (payoffs.jl:172-193): put = call − S + K·D
+  *price_out = m->cp > 0.0 ? call : call - m->S0 + m->strike * m->discount;
+  return HH_OK;
+}
+
 size_t hh_lsm_grid_elems(uint64_t n_paths, uint32_t n_steps, int32_t antithetic) {
   return (size_t)(n_steps + 1) * n_paths * (antithetic ? 2 : 1);
 }

@@ -84,6 +84,9 @@ int launch_reduce_records(const double* records, uint32_t n_records, double n_pa
 int count_active_partials(const hh_model& m, const hh_config& c);
 int launch_basket_payoffs(const BasketArgs& b, uint32_t n_payoffs, uint32_t n_active_partials,
                           hipStream_t s);
+// Carr–Madan on the device (hh_fourier.hip)
+int launch_carr_madan(const hh_model& m, int dynamics, int compat_sqrt_alpha, double alpha,
+                      double bound, double* out_dev, hipStream_t s);
 // LSM (hh_lsm.hip)
 uint32_t lsm_chunks(uint64_t ntot);
 size_t lsm_scratch_doubles(uint64_t ntot, uint32_t n_steps, int degree);

@@ -178,6 +178,17 @@ int hh_mc_solve_basket(hh_ctx* ctx, const hh_model* model, const hh_config* cfg,
                        hh_result* out /* n_payoffs */, double* terminal);
 
 /*
+ * Carr–Madan Fourier price of a European vanilla on the device — solve(prob, ::CarrMadan)
+ * (src/pricing_methods/carr_madan.jl:47-92) with the Heston marginal law (heston.jl:307-319) or the
+ * lognormal one (sample_from_cf.jl:14-16; compat_sqrt_alpha as in hh_config).  It is the analytic
+ * value the reference's MC tests compare against; model->r_drift = zero_rate(rate, expiry),
+ * model->T = yearfrac(rate.reference_date, expiry), model->discount = df(rate, expiry).
+ * alpha = damping factor, bound = integration bound (CarrMadan(α, bound, dynamics)).
+ */
+int hh_carr_madan(hh_ctx* ctx, const hh_model* model, int32_t dynamics, int32_t compat_sqrt_alpha,
+                  double alpha, double bound, double* price_out);
+
+/*
  * Longstaff–Schwartz American pricing on the full path grid:
  *   solve(::PricingProblem{VanillaOption{…,American,…}}, ::LSM)
  *                              (src/pricing_methods/least_squares_montecarlo.jl:99-165)

@@ -1,0 +1,61 @@
+"""Device Carr–Madan against the scipy restatement (oracle/analytic.py) and the
+values the reference's MC tests use as their targets."""
+import numpy as np
+import pytest
+
+import hedgehog_jl_amd as hh
+from oracle import analytic
+
+pytestmark = pytest.mark.gpu
+
+
+def heston_prob(params, r, ref, expiry, K=100.0, cp=None):
+    payoff = hh.VanillaOption(K, expiry, hh.European(), cp or hh.Call(), hh.Spot())
+    return hh.PricingProblem(payoff, hh.HestonInputs(ref, r, 100.0, *params))
+
+
+@pytest.mark.parametrize("params,r,ref,expiry,bound,target", [
+    ((0.04, 2.0, 0.04, 0.3, -0.7), 0.03, hh.Date(2020, 1, 1), hh.Date(2021, 1, 1), 32.0,
+     9.257069529912402),                                   # montecarlo_heston.jl:13-49
+    ((0.04, 2.0, 0.04, 0.3, -0.7), 0.03, hh.Date(2021, 1, 1), hh.Date(2022, 1, 1), 400.0,
+     9.242521073959068),                                   # H252
+    ((1.5, 0.04, 0.3, -0.6, 0.04), 0.05, hh.Date(2025, 1, 1), hh.Date(2025, 12, 31), 32.0,
+     46.31412390823014),                                   # montecarlo_heston.jl:161-170 as run (Q2)
+])
+def test_carr_madan_heston_targets(params, r, ref, expiry, bound, target):
+    prob = heston_prob(params, r, ref, expiry)
+    price = hh.solve(prob, hh.CarrMadan(1.0, bound, hh.HestonDynamics())).price
+    assert price == pytest.approx(target, rel=1e-9)
+    T = hh.yearfrac(ref, expiry)
+    V0, k, th, s, rho = params
+    assert price == pytest.approx(
+        analytic.carr_madan_heston(100.0, 100.0, r, V0, k, th, s, rho, T, bound=bound), rel=1e-9)
+    put = hh.solve(heston_prob(params, r, ref, expiry, cp=hh.Put()),
+                   hh.CarrMadan(1.0, bound, hh.HestonDynamics())).price
+    assert put == pytest.approx(price - 100.0 + 100.0 * np.exp(-r * T), rel=1e-12)
+
+
+def test_carr_madan_lognormal_equals_black_scholes():
+    """test/agreement/price_agreement.jl: Carr–Madan with the lognormal law vs BlackScholesAnalytic,
+    atol 1e-6 (365-day expiry, so the √α quirk of montecarlo.jl:302 is invisible)."""
+    ref = hh.Date(2021, 1, 1)
+    for K in (80.0, 100.0, 125.0):
+        for cp in (hh.Call(), hh.Put()):
+            payoff = hh.VanillaOption(K, hh.Date(2022, 1, 1), hh.European(), cp, hh.Spot())
+            prob = hh.PricingProblem(payoff, hh.BlackScholesInputs(ref, 0.05, 100.0, 0.2))
+            cm = hh.solve(prob, hh.CarrMadan(1.0, 32.0, hh.LognormalDynamics())).price
+            bs = hh.solve(prob, hh.BlackScholesAnalytic()).price
+            assert cm == pytest.approx(bs, abs=1e-6)
+            assert bs == pytest.approx(analytic.bs_price(100.0, K, 0.05, 0.2, 1.0, cp()), rel=1e-13)
+
+
+def test_monte_carlo_against_the_device_fourier_price():
+    """The reference's Heston agreement test, entirely on the GPU box: Euler MC vs device Carr–Madan."""
+    prob = heston_prob((0.04, 2.0, 0.04, 0.3, -0.7), 0.03, hh.Date(2020, 1, 1), hh.Date(2021, 1, 1))
+    cm = hh.solve(prob, hh.CarrMadan(1.0, 32.0, hh.HestonDynamics())).price
+    n = 400_000
+    mc = hh.solve(prob, hh.MonteCarlo(hh.HestonDynamics(), hh.EulerMaruyama(),
+                                      hh.SimulationConfig(n, steps=200, seeds=np.arange(1, n + 1),
+                                                          variance_reduction=hh.Antithetic())),
+                  ensemble=False)
+    assert abs(mc.price - cm) < 4 * mc.std_error + 0.02

@@ -40,7 +40,7 @@ def build():
         out = os.path.join(VDIR, f"libhh_{tag}.so")
         cmd = ["hipcc", "-shared", "-fPIC", "-O3", "-std=c++17", "--offload-arch=gfx950",
                "-ffp-contract=off", *flags, *[os.path.join(CSRC, f) for f in
-                                             ("hh_api.hip", "hh_kernels.hip", "hh_bk.hip", "hh_lsm.hip")],
+                                             ("hh_api.hip", "hh_kernels.hip", "hh_bk.hip", "hh_lsm.hip", "hh_fourier.hip")],
                "-o", out, "-Rpass-analysis=kernel-resource-usage"]
         procs.append((tag, subprocess.Popen(cmd, stderr=subprocess.PIPE, text=True)))
     for tag, p in procs:
