@@ -56,7 +56,6 @@ struct cx {
   double re, im;
 };
 __device__ __forceinline__ cx operator+(cx a, cx b) { return {a.re + b.re, a.im + b.im}; }
-__device__ __forceinline__ cx operator-(cx a, cx b) { return {a.re - b.re, a.im - b.im}; }
 __device__ __forceinline__ cx operator*(cx a, cx b) {
   return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re};
 }
