@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 #include "hh_kernels.h"
@@ -51,6 +52,7 @@ struct hh_ctx {
   hipEvent_t tev[kTimingSlots][2] = {};
   int t_count = 0;  // pairs recorded since the last read (capped at kTimingSlots)
   char err[512] = {0};
+  std::recursive_mutex mu;  // entry points serialise on it: a ctx may be shared between threads
 };
 
 namespace {
@@ -216,12 +218,14 @@ void hh_ctx_destroy(hh_ctx* ctx) {
 
 int hh_ctx_set_stream(hh_ctx* ctx, void* hip_stream) {
   if (!ctx) return HH_ERR_INVALID;
+  std::lock_guard<std::recursive_mutex> lock__(ctx->mu);
   ctx->stream = (hipStream_t)hip_stream;  // NULL is the device's default (null) stream
   return HH_OK;
 }
 
 int hh_ctx_reset_stream(hh_ctx* ctx) {
   if (!ctx) return HH_ERR_INVALID;
+  std::lock_guard<std::recursive_mutex> lock__(ctx->mu);
   ctx->stream = ctx->own_stream;
   return HH_OK;
 }
@@ -230,6 +234,7 @@ const char* hh_last_error(const hh_ctx* ctx) { return ctx ? ctx->err : kNoCtx; }
 
 int hh_ctx_synchronize(hh_ctx* ctx) {
   if (!ctx) return HH_ERR_INVALID;
+  std::lock_guard<std::recursive_mutex> lock__(ctx->mu);
   HH_HIP(ctx, hipSetDevice(ctx->device));
   HH_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return HH_OK;
@@ -242,6 +247,7 @@ size_t hh_replay_elems(uint64_t n_paths, uint32_t n_steps, int32_t dynamics) {
 int hh_replay_pack(hh_ctx* ctx, int32_t dynamics, uint64_t n_paths, uint32_t n_steps,
                    const double* src, int32_t src_on_device, double* dst) {
   if (!ctx) return HH_ERR_INVALID;
+  std::lock_guard<std::recursive_mutex> lock__(ctx->mu);
   if (!src || !dst || n_paths == 0 || n_steps == 0)
     return fail(ctx, HH_ERR_INVALID, "hh_replay_pack: bad arguments");
   HH_HIP(ctx, hipSetDevice(ctx->device));
@@ -262,6 +268,7 @@ int hh_replay_pack(hh_ctx* ctx, int32_t dynamics, uint64_t n_paths, uint32_t n_s
 int hh_wiener_fill(hh_ctx* ctx, int32_t dynamics, double rho, double T, uint32_t n_steps,
                    uint64_t n_paths, const uint64_t* seeds, int32_t seeds_on_device, double* dst) {
   if (!ctx) return HH_ERR_INVALID;
+  std::lock_guard<std::recursive_mutex> lock__(ctx->mu);
   if (!seeds || !dst || n_paths == 0 || n_steps == 0 || !(T > 0.0) || !(std::fabs(rho) <= 1.0))
     return fail(ctx, HH_ERR_INVALID, "hh_wiener_fill: bad arguments");
   HH_HIP(ctx, hipSetDevice(ctx->device));
@@ -382,6 +389,7 @@ static int copy_back_terminal(hh_ctx* ctx, const hh_config* c, double* terminal)
 int hh_mc_accumulate(hh_ctx* ctx, const hh_model* m, const hh_config* c, double* accum_dev,
                      double* terminal) {
   if (!ctx) return HH_ERR_INVALID;
+  std::lock_guard<std::recursive_mutex> lock__(ctx->mu);
   int rc = validate(ctx, m, c);
   if (rc) return rc;
   if (!accum_dev) return fail(ctx, HH_ERR_INVALID, "accum_dev is NULL");
@@ -398,6 +406,7 @@ int hh_mc_accumulate_basket(hh_ctx* ctx, const hh_model* m, const hh_config* c,
                             const double* strikes, const double* cps, uint32_t n_payoffs,
                             double* accum_dev, double* terminal) {
   if (!ctx) return HH_ERR_INVALID;
+  std::lock_guard<std::recursive_mutex> lock__(ctx->mu);
   int rc = validate(ctx, m, c);
   if (rc) return rc;
   if (!accum_dev || !strikes || !cps || n_payoffs == 0 || n_payoffs > 65535)
@@ -439,6 +448,7 @@ int hh_mc_accumulate_basket(hh_ctx* ctx, const hh_model* m, const hh_config* c,
 int hh_mc_solve_basket(hh_ctx* ctx, const hh_model* m, const hh_config* c, const double* strikes,
                        const double* cps, uint32_t n_payoffs, hh_result* out, double* terminal) {
   if (!ctx) return HH_ERR_INVALID;
+  std::lock_guard<std::recursive_mutex> lock__(ctx->mu);
   if (!out) return fail(ctx, HH_ERR_INVALID, "result is NULL");
   const auto t0 = std::chrono::steady_clock::now();
   HH_HIP(ctx, hipSetDevice(ctx->device));
@@ -498,6 +508,7 @@ int hh_mc_finalize(const hh_model* m, const hh_config* c, const double* acc, hh_
 int hh_mc_solve(hh_ctx* ctx, const hh_model* m, const hh_config* c, hh_result* out,
                 double* terminal) {
   if (!ctx) return HH_ERR_INVALID;
+  std::lock_guard<std::recursive_mutex> lock__(ctx->mu);
   if (!out) return fail(ctx, HH_ERR_INVALID, "result is NULL");
   const auto t0 = std::chrono::steady_clock::now();
   std::memset(out, 0, sizeof(*out));
@@ -522,6 +533,7 @@ int hh_mc_solve(hh_ctx* ctx, const hh_model* m, const hh_config* c, hh_result* o
 int hh_carr_madan(hh_ctx* ctx, const hh_model* m, int32_t dynamics, int32_t compat_sqrt_alpha,
                   double alpha, double bound, double* price_out) {
   if (!ctx) return HH_ERR_INVALID;
+  std::lock_guard<std::recursive_mutex> lock__(ctx->mu);
   if (!m || !price_out) return fail(ctx, HH_ERR_INVALID, "hh_carr_madan: NULL argument");
   if (dynamics != HH_LOGNORMAL && dynamics != HH_HESTON)
     return fail(ctx, HH_ERR_INVALID, "unknown dynamics %d", dynamics);
@@ -548,6 +560,7 @@ int hh_lsm_solve(hh_ctx* ctx, const hh_model* m, const hh_config* c, int32_t deg
                  double step_discount, hh_lsm_result* out, int32_t* stop_time, double* stop_value,
                  double* spot_grid) {
   if (!ctx) return HH_ERR_INVALID;
+  std::lock_guard<std::recursive_mutex> lock__(ctx->mu);
   if (!m || !c || !out) return fail(ctx, HH_ERR_INVALID, "hh_lsm_solve: NULL argument");
   const auto t0 = std::chrono::steady_clock::now();
   // The reference's LSM regresses on the first state component of simulate_paths' solution, which
@@ -625,6 +638,7 @@ int hh_lsm_solve(hh_ctx* ctx, const hh_model* m, const hh_config* c, int32_t deg
 
 int hh_ctx_enable_timing(hh_ctx* ctx, int32_t on) {
   if (!ctx) return HH_ERR_INVALID;
+  std::lock_guard<std::recursive_mutex> lock__(ctx->mu);
   HH_HIP(ctx, hipSetDevice(ctx->device));
   if (on && !ctx->tev[0][0]) {
     for (auto& pr : ctx->tev)
@@ -637,6 +651,7 @@ int hh_ctx_enable_timing(hh_ctx* ctx, int32_t on) {
 
 int hh_ctx_read_timings(hh_ctx* ctx, double* ms, int32_t cap, int32_t* n_out) {
   if (!ctx || !ms || !n_out || cap < 0) return HH_ERR_INVALID;
+  std::lock_guard<std::recursive_mutex> lock__(ctx->mu);
   HH_HIP(ctx, hipSetDevice(ctx->device));
   HH_HIP(ctx, hipStreamSynchronize(ctx->stream));
   int n = ctx->t_count < hh_ctx::kTimingSlots ? ctx->t_count : hh_ctx::kTimingSlots;
@@ -653,6 +668,7 @@ int hh_ctx_read_timings(hh_ctx* ctx, double* ms, int32_t cap, int32_t* n_out) {
 
 int hh_device_malloc(hh_ctx* ctx, size_t bytes, void** out_dev) {
   if (!ctx || !out_dev) return HH_ERR_INVALID;
+  std::lock_guard<std::recursive_mutex> lock__(ctx->mu);
   HH_HIP(ctx, hipSetDevice(ctx->device));
   hipError_t e = hipMalloc(out_dev, bytes);
   if (e != hipSuccess)
@@ -662,6 +678,7 @@ int hh_device_malloc(hh_ctx* ctx, size_t bytes, void** out_dev) {
 
 int hh_device_free(hh_ctx* ctx, void* dev) {
   if (!ctx) return HH_ERR_INVALID;
+  std::lock_guard<std::recursive_mutex> lock__(ctx->mu);
   HH_HIP(ctx, hipSetDevice(ctx->device));
   HH_HIP(ctx, hipFree(dev));
   return HH_OK;
@@ -669,6 +686,7 @@ int hh_device_free(hh_ctx* ctx, void* dev) {
 
 int hh_memcpy_h2d(hh_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes) {
   if (!ctx) return HH_ERR_INVALID;
+  std::lock_guard<std::recursive_mutex> lock__(ctx->mu);
   HH_HIP(ctx, hipSetDevice(ctx->device));
   HH_HIP(ctx, hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
   HH_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -677,6 +695,7 @@ int hh_memcpy_h2d(hh_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes
 
 int hh_memcpy_d2h(hh_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes) {
   if (!ctx) return HH_ERR_INVALID;
+  std::lock_guard<std::recursive_mutex> lock__(ctx->mu);
   HH_HIP(ctx, hipSetDevice(ctx->device));
   HH_HIP(ctx, hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
   HH_HIP(ctx, hipStreamSynchronize(ctx->stream));

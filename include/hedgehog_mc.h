@@ -16,8 +16,9 @@
  *   - all arithmetic is IEEE fp64 (the reference computes in Float64 throughout).
  *   - the caller owns every buffer it passes, for the duration of the call only; the library owns
  *     whatever it allocates inside hh_ctx and releases it in hh_ctx_destroy().
- *   - a hh_ctx is bound to ONE device and ONE HIP stream and is single-owner (not thread-safe);
- *     use one ctx per host thread / per GPU.  Multi-GPU = one process (or thread) per GPU, each
+ *   - a hh_ctx is bound to ONE device and ONE HIP stream; its entry points serialise on an
+ *     internal mutex, so sharing one between threads is safe but gains nothing — use one ctx per
+ *     host thread / per GPU.  Multi-GPU = one process (or thread) per GPU, each
  *     with its own ctx, exchanging only the HH_ACC_LEN-double accumulator vector (one all-reduce).
  *   - there is NO CPU fallback in this library: without a HIP device every compute entry point
  *     fails with HH_ERR_HIP.

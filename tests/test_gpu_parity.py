@@ -321,3 +321,29 @@ def test_reference_replay_exchange_format(capsys):
     lines = [ln for ln in capsys.readouterr().out.splitlines() if ln.startswith("em_split")]
     err = {ln.split(":")[0]: float(ln.split("= ")[1].split(",")[0]) for ln in lines}
     assert err["em_split=1"] < 1e-12 and err["em_split=0"] > 1e-6
+
+
+def test_context_shared_between_threads(hhlib, oracle):
+    """Entry points serialise on the ctx mutex: concurrent solves from several host threads on ONE
+    ctx each get their own correct result (ctypes releases the GIL during the call)."""
+    import threading
+    m = o.make_model()
+    want = {}
+    cfgs = {}
+    for t in range(4):
+        n = 3000 + 517 * t
+        cfgs[t] = o.make_config(HES, EM, n, 20 + t, antithetic=t & 1, seeds=seeds_for(n, t))
+        want[t] = oracle.mc_solve(m, cfgs[t], want_terminal=False)[0].price
+    got = {}
+
+    def work(t):
+        for _ in range(10):
+            got[t] = gpu_solve(hhlib, m, cfgs[t], want_terminal=False)[0].price
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    for t in range(4):
+        assert got[t] == pytest.approx(want[t], rel=1e-11)
