@@ -42,13 +42,99 @@ __host__ __device__ __forceinline__ double u01_from_bits(uint32_t lo, uint32_t h
   return ((double)(w >> 12) + 0.5) * 0x1p-52;
 }
 
+// The same value built without integer->double conversions: 1.mantissa in [1, 2), then one exact
+// subtraction of (1 - 2^-53):  (1 + k 2^-52) - (1 - 2^-53) = (k + 1/2) 2^-52.
+__device__ __forceinline__ double u01_fast(uint32_t lo, uint32_t hi) {
+  const uint64_t w = ((uint64_t)hi << 32) | lo;
+  return __longlong_as_double((long long)(0x3FF0000000000000ull | (w >> 12))) -
+         0x1.fffffffffffffp-1;
+}
+
+// ---- transcendentals of the Box–Muller transform, specialised to its argument ranges ------------
+// The generic library routines cost 98 (log) + 71 (sincospi) + 22 (sqrt) VALU instructions per pair
+// of normals — more than everything else in a GENERATE path-step together; their generality (full
+// range, special values, denormals) is not needed here.  Accuracy of each: <= 2 ulp.
+
+// -2 ln(u), u in (0, 1):  u = 2^e m, m in [sqrt(1/2), sqrt(2));  ln m = 2 atanh(s), s = (m-1)/(m+1)
+__device__ __forceinline__ double neg2_log_unit(double u) {
+  double m = __builtin_amdgcn_frexp_mant(u);  // [1/2, 1)
+  int e = __builtin_amdgcn_frexp_exp(u);
+  const bool lowm = m < 0x1.6a09e667f3bcdp-1;  // sqrt(1/2)
+  m = lowm ? 2.0 * m : m;
+  e = lowm ? e - 1 : e;
+  const double f = m - 1.0, d = m + 1.0;  // f exact
+  double r = __builtin_amdgcn_rcp(d);     // hardware reciprocal + two Newton steps
+  r = fma(fma(-d, r, 1.0), r, r);
+  r = fma(fma(-d, r, 1.0), r, r);
+  double s = f * r;
+  s = fma(fma(-s, d, f), r, s);           // residual correction: s = f/d to < 1 ulp
+  const double z = s * s;
+  double p = 0x1.af286bca1af28p-4;        // 2/19
+  p = fma(p, z, 0x1.e1e1e1e1e1e1ep-4);    // 2/17
+  p = fma(p, z, 0x1.1111111111111p-3);    // 2/15
+  p = fma(p, z, 0x1.3b13b13b13b14p-3);    // 2/13
+  p = fma(p, z, 0x1.745d1745d1746p-3);    // 2/11
+  p = fma(p, z, 0x1.c71c71c71c71cp-3);    // 2/9
+  p = fma(p, z, 0x1.2492492492492p-2);    // 2/7
+  p = fma(p, z, 0x1.999999999999ap-2);    // 2/5
+  p = fma(p, z, 0x1.5555555555555p-1);    // 2/3
+  const double de = (double)e;
+  // ln u = e ln2_hi + (2 s + (s z p + e ln2_lo)); ln2_hi has 21 trailing zero bits (exact product)
+  const double t = fma(s * z, p, de * 1.90821492927058770002e-10);
+  const double lg = fma(de, 6.93147180369123816490e-01, fma(2.0, s, t));
+  return -2.0 * lg;
+}
+
+// sqrt(a) for a normal, positive a: reciprocal-square-root seed + two coupled Newton steps
+__device__ __forceinline__ double sqrt_pos(double a) {
+  const double y = __builtin_amdgcn_rsq(a);
+  double g = a * y, h = 0.5 * y;
+  double rr = fma(-h, g, 0.5);
+  g = fma(g, rr, g);
+  h = fma(h, rr, h);
+  rr = fma(-h, g, 0.5);
+  g = fma(g, rr, g);
+  h = fma(h, rr, h);
+  return fma(fma(-g, g, a), h, g);
+}
+
+// sin(pi t), cos(pi t) for t in (0, 2): t = q/2 + r exactly, |r| <= 1/4; Taylor in r^2
+__device__ __forceinline__ void sincospi_02(double t, double& sn, double& cs) {
+  const double q = __builtin_rint(2.0 * t);
+  const double r = fma(q, -0.5, t);
+  const double z = r * r;
+  double ps = -0x1.6fadb9f155744p-16;
+  ps = fma(ps, z, 0x1.e8f434d018d63p-12);
+  ps = fma(ps, z, -0x1.e3074fde8871fp-8);
+  ps = fma(ps, z, 0x1.50783487ee782p-4);
+  ps = fma(ps, z, -0x1.32d2cce62bd86p-1);
+  ps = fma(ps, z, 0x1.466bc6775aae2p+1);
+  ps = fma(ps, z, -0x1.4abbce625be53p+2);
+  ps = fma(ps, z, 0x1.921fb54442d18p+1);
+  const double sr = r * ps;
+  double pc = 0x1.20c62c2f2d7f5p-18;
+  pc = fma(pc, z, -0x1.b6e24f44b128fp-14);
+  pc = fma(pc, z, 0x1.f9d38a3763cc3p-10);
+  pc = fma(pc, z, -0x1.a6d1f2a204a8cp-6);
+  pc = fma(pc, z, 0x1.e1f506891babbp-3);
+  pc = fma(pc, z, -0x1.55d3c7e3cbffap+0);
+  pc = fma(pc, z, 0x1.03c1f081b5ac4p+2);
+  pc = fma(pc, z, -0x1.3bd3cc9be45dep+2);
+  const double cr = fma(pc, z, 1.0);
+  const int qi = (int)q;
+  const bool swap = qi & 1;
+  const double s0 = swap ? cr : sr, c0 = swap ? sr : cr;
+  sn = (qi & 2) ? -s0 : s0;            // quadrants 2, 3
+  cs = ((qi + 1) & 2) ? -c0 : c0;      // quadrants 1, 2
+}
+
 // Two independent N(0,1) from one Philox block (Box–Muller).
 __device__ __forceinline__ void normal_pair(const Philox4& b, double& z1, double& z2) {
-  const double u1 = u01_from_bits(b.c0, b.c1);
-  const double t = 2.0 * u01_from_bits(b.c2, b.c3);  // angle / pi, in (0, 2)
-  const double r = sqrt(-2.0 * log(u1));
+  const double u1 = u01_fast(b.c0, b.c1);
+  const double t = 2.0 * u01_fast(b.c2, b.c3);  // angle / pi, in (0, 2)
+  const double r = sqrt_pos(neg2_log_unit(u1));
   double s, c;
-  sincospi(t, &s, &c);
+  sincospi_02(t, s, c);
   z1 = r * c;
   z2 = r * s;
 }
