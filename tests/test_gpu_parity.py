@@ -347,3 +347,26 @@ def test_context_shared_between_threads(hhlib, oracle):
         th.join()
     for t in range(4):
         assert got[t] == pytest.approx(want[t], rel=1e-11)
+
+
+def test_device_normals_against_libm_box_muller(hhlib, oracle):
+    """The kernels' Box–Muller uses range-specialised -2ln(u), sqrt and sincospi (csrc/hh_rng.h);
+    the oracle uses glibc's log/sqrt/sin/cos on the same Philox bits.  2 million normals, dt = 1 and
+    rho = 0 so that the filled increments ARE the normals: absolute agreement to a few ulp of 1,
+    tails included."""
+    import torch
+    n, steps = 200_000, 5
+    seeds = seeds_for(n, 99)
+    want = oracle.wiener_fill(HES, 0.0, float(steps), steps, seeds)
+    buf = torch.empty(want.size, dtype=torch.float64, device="cuda")
+    hhlib.check(hhlib.lib.hh_wiener_fill(hhlib.handle, HES, 0.0, float(steps), steps, n,
+                                         seeds.ctypes.data, 0, buf.data_ptr()))
+    hhlib.synchronize()
+    got = buf.cpu().numpy()
+    err = np.abs(got - want)
+    assert err.max() < 4e-15, err.max()
+    live = want != 0
+    assert np.max(err[live] / np.maximum(np.abs(want[live]), 1e-3)) < 4e-15
+    assert np.abs(want).max() > 5.0  # the sample does reach the tails
+    z = got[live]
+    assert abs(z.mean()) < 5 / np.sqrt(z.size) and abs(z.var() - 1) < 5 * np.sqrt(2 / z.size)
