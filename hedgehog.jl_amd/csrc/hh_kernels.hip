@@ -213,6 +213,9 @@ struct VecOf<2> {
 #ifndef HH_REPLAY_MINW
 #define HH_REPLAY_MINW 1
 #endif
+#ifndef HH_REPLAY_LDS
+#define HH_REPLAY_LDS 4  // chunks in each wave's LDS ring; 0 = two-chunk register pipeline instead
+#endif
 constexpr int kChunk = HH_REPLAY_CHUNK;  // steps per register chunk of the REPLAY pipeline
 
 template <class Vec>
@@ -275,6 +278,71 @@ __global__ __launch_bounds__(kTile / PPT, REPLAY ? HH_REPLAY_MINW : 1) void eule
       }
     };
 
+    // Which REPLAY pipeline: the LDS ring wins where the kernel is purely HBM-bound (no partials, no
+    // mirrored path: 6.75-6.9 vs 6.45 TB/s); with more VALU work per step its 32 KiB of LDS per
+    // workgroup (10 waves per CU) hides less latency than the register pipeline's 16-20 waves, and
+    // it measured slower (antithetic 0.81 vs 0.72 ms, one carried partial 0.76 vs 0.70 ms).
+    constexpr bool kUseLds = HH_REPLAY_LDS > 0 && P == 0 && !ANTI && PPT == 2;
+    if constexpr (kUseLds) {
+    // LDS-staged streaming.  Each wave moves its half-tile (128 trajectories =
+    // 1 KiB per step and component) through a PRIVATE ring in LDS with LDS-DMA
+    // (global_load_lds_dwordx4: 16 B per lane straight into LDS, no VGPR staging).  A wave reads back
+    // only what it wrote itself, so there is no barrier in the loop: a counted s_waitcnt vmcnt lets
+    // the R-1 younger chunks stay in flight while chunk k is consumed.  R = HH_REPLAY_LDS chunks of
+    // kChunk steps; 4 x 2 was the fastest of the sweep in tools/tune_replay.py.
+    constexpr int R = HH_REPLAY_LDS > 0 ? HH_REPLAY_LDS : 1;
+    constexpr int PER_CHUNK = kChunk * NC;  // LDS-DMA instructions per chunk and wave
+    static_assert((R - 1) * PER_CHUNK <= 63, "vmcnt is a 6-bit counter");
+    __shared__ __attribute__((aligned(16))) double ring[kTile / PPT / 64][R][kChunk][NC][128];
+    const int wave = tid >> 6, lane = tid & 63;
+    const double* gbase = a.replay + (size_t)tile * n_steps * NC * kTile + wave * 128 + lane * 2;
+    const uint32_t n_chunks = n_steps / kChunk;
+    auto issue = [&](uint32_t k) {
+#pragma unroll
+      for (int u = 0; u < kChunk; ++u)
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+          __builtin_amdgcn_global_load_lds(
+              (const __attribute__((address_space(1))) void*)(gbase +
+                                                              ((size_t)(k * kChunk + u) * NC + c) * kTile),
+              (__attribute__((address_space(3))) void*)&ring[wave][k % R][u][c][0], 16, 0,
+              HH_REPLAY_NT ? 2 : 0);
+    };
+    for (uint32_t k = 0; k + 1 < (uint32_t)R && k < n_chunks; ++k) issue(k);
+    for (uint32_t k = 0; k < n_chunks; ++k) {
+      if (k + R - 1 < n_chunks) issue(k + R - 1);
+      // chunk k has landed once at most `after` younger chunks are still in flight
+      const uint32_t after = n_chunks - 1 - k < (uint32_t)(R - 1) ? n_chunks - 1 - k : (uint32_t)(R - 1);
+#define HH_WAIT_CHUNKS(n) \
+  case n: asm volatile("s_waitcnt vmcnt(%0)" ::"n"((n) * PER_CHUNK < 63 ? (n) * PER_CHUNK : 63) : "memory"); break;
+      switch (after) {
+        HH_WAIT_CHUNKS(0) HH_WAIT_CHUNKS(1) HH_WAIT_CHUNKS(2) HH_WAIT_CHUNKS(3) HH_WAIT_CHUNKS(4)
+        HH_WAIT_CHUNKS(5) HH_WAIT_CHUNKS(6) HH_WAIT_CHUNKS(7)
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+      }
+#undef HH_WAIT_CHUNKS
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < kChunk; ++u) {
+        Vec v[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+          v[c] = *reinterpret_cast<const Vec*>(&ring[wave][k % R][u][c][lane * 2]);
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) {
+          const double d1 = VecOf<PPT>::get(v[0], j);
+          const double d2 = NC > 1 ? VecOf<PPT>::get(v[NC - 1], j) : 0.0;
+          M::step(st[j], a, d1, d2);
+          if constexpr (ANTI) M::step(sa[j], a, -d1, -d2);  // montecarlo.jl:258: -W
+        }
+      }
+    }
+    // the n_steps % kChunk last steps: plain register loads
+    if (n_chunks * kChunk < n_steps) {
+      load(A, n_chunks * kChunk);
+      compute(A, n_chunks * kChunk);
+    }
+    } else {
     uint32_t s = 0;
     load(A, 0);
     while (s < n_steps) {
@@ -285,6 +353,7 @@ __global__ __launch_bounds__(kTile / PPT, REPLAY ? HH_REPLAY_MINW : 1) void eule
       load(A, s + kChunk);
       compute(B, s);
       s += kChunk;
+    }
     }
   } else {
     uint64_t key[PPT];
