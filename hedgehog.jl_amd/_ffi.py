@@ -71,7 +71,8 @@ class HedgehogMCError(RuntimeError):
         self.code = code
 
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libhedgehog_mc.so")
+LIB_PATH = os.environ.get("HEDGEHOG_MC_LIB") or os.path.join(
+    os.path.dirname(os.path.abspath(__file__)), "lib", "libhedgehog_mc.so")  # env: A/B builds
 
 # every symbol include/hedgehog_mc.h declares: (name, restype, argtypes)
 _vp = C.c_void_p
