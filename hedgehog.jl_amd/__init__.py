@@ -15,7 +15,7 @@ from .greeks import (BatchGreekProblem, FDBackward, FDCentral, FDForward, Finite
                      ForwardAD, GreekProblem, GreekResult, PropertyLens, SecondOrderGreekProblem, SpotLens,
                      VolLens,
                      ZeroRateSpineLens, optic, set)
-from .lsm import LSM, LSMSolution, solve_lsm
+from .lsm import LSM, HestonExactPaths, LSMSolution, simulate_heston_exact_paths, solve_lsm
 from .montecarlo import (AbstractPricingMethod, Antithetic, BlackScholesExact, EulerMaruyama,
                          HestonBroadieKaya, HestonDynamics, LognormalDynamics, MethodError,
                          MonteCarlo, NoVarianceReduction, SimulationConfig, solve_montecarlo)

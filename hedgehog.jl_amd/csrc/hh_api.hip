@@ -38,6 +38,8 @@ struct hh_ctx {
   size_t bk_scratch_cap = 0;
   double* lsm_grid = nullptr;  // [n_steps+1][ntot]
   size_t lsm_grid_cap = 0;
+  double* heston_var = nullptr;  // [n_steps+1][n_paths] variance rows of the exact Heston grid
+  size_t heston_var_cap = 0;
   double* lsm_val = nullptr;
   size_t lsm_val_cap = 0;
   int32_t* lsm_tau = nullptr;
@@ -202,6 +204,7 @@ void hh_ctx_destroy(hh_ctx* ctx) {
   if (ctx->basket_accum) (void)hipFree(ctx->basket_accum);
   if (ctx->bk_scratch) (void)hipFree(ctx->bk_scratch);
   if (ctx->lsm_grid) (void)hipFree(ctx->lsm_grid);
+  if (ctx->heston_var) (void)hipFree(ctx->heston_var);
   if (ctx->lsm_val) (void)hipFree(ctx->lsm_val);
   if (ctx->lsm_tau) (void)hipFree(ctx->lsm_tau);
   if (ctx->lsm_scratch) (void)hipFree(ctx->lsm_scratch);
@@ -556,51 +559,21 @@ size_t hh_lsm_grid_elems(uint64_t n_paths, uint32_t n_steps, int32_t antithetic)
   return (size_t)(n_steps + 1) * n_paths * (antithetic ? 2 : 1);
 }
 
-int hh_lsm_solve(hh_ctx* ctx, const hh_model* m, const hh_config* c, int32_t degree,
-                 double step_discount, hh_lsm_result* out, int32_t* stop_time, double* stop_value,
-                 double* spot_grid) {
-  if (!ctx) return HH_ERR_INVALID;
-  std::lock_guard<std::recursive_mutex> lock__(ctx->mu);
-  if (!m || !c || !out) return fail(ctx, HH_ERR_INVALID, "hh_lsm_solve: NULL argument");
-  const auto t0 = std::chrono::steady_clock::now();
-  // The reference's LSM regresses on the first state component of simulate_paths' solution, which
-  // is the SPOT only for the GBM noise process of (LognormalDynamics, BlackScholesExact)
-  // (least_squares_montecarlo.jl:53,76; montecarlo.jl:140-159) — that is the supported pair.
-  if (c->dynamics != HH_LOGNORMAL || c->strategy != HH_EXACT_LAW)
-    return fail(ctx, HH_ERR_UNSUPPORTED, "LSM needs LognormalDynamics + BlackScholesExact paths");
-  if (c->noise_mode != HH_NOISE_GENERATE || c->n_partials != 0)
-    return fail(ctx, HH_ERR_UNSUPPORTED, "LSM: GENERATE noise, no dual partials");
-  if (c->n_paths == 0 || c->n_steps == 0 || !c->seeds || degree < 1 || degree > 8)
-    return fail(ctx, HH_ERR_INVALID, "LSM: n_paths, n_steps >= 1, seeds, 1 <= degree <= 8");
-  if (c->seeds_len && c->seeds_len < c->n_paths)
-    return fail(ctx, HH_ERR_INVALID, "Number of seeds (%llu) must be >= number of trajectories (%llu)",
-                (unsigned long long)c->seeds_len, (unsigned long long)c->n_paths);
-  if (!(m->S0 > 0.0) || !(m->T > 0.0) || (m->cp != 1.0 && m->cp != -1.0) ||
-      !(step_discount > 0.0) || !std::isfinite(step_discount))
-    return fail(ctx, HH_ERR_INVALID, "LSM: bad model scalars");
-  HH_HIP(ctx, hipSetDevice(ctx->device));
-  const uint64_t ntot = c->n_paths * (c->antithetic ? 2 : 1);
-  const size_t grid_elems = hh_lsm_grid_elems(c->n_paths, c->n_steps, c->antithetic);
+// Backward induction on a spot grid already in device memory (rows = dates, ntot trajectories):
+// launches, reduction and the copies back.  The caller recorded ctx->ev0 before producing the grid.
+static int lsm_on_grid(hh_ctx* ctx, const double* grid_dev, uint64_t ntot, uint32_t n_steps,
+                       const hh_model* m, int32_t degree, double step_discount, hh_lsm_result* out,
+                       int32_t* stop_time, double* stop_value,
+                       std::chrono::steady_clock::time_point t0) {
   const uint32_t ch = hh::lsm_chunks(ntot);
   int rc;
-  if ((rc = ensure(ctx, ctx->lsm_grid, ctx->lsm_grid_cap, grid_elems))) return rc;
   if ((rc = ensure(ctx, ctx->lsm_val, ctx->lsm_val_cap, (size_t)ntot))) return rc;
   if ((rc = ensure(ctx, ctx->lsm_tau, ctx->lsm_tau_cap, (size_t)ntot))) return rc;
-  const size_t nscr = hh::lsm_scratch_doubles(ntot, c->n_steps, degree);
+  const size_t nscr = hh::lsm_scratch_doubles(ntot, n_steps, degree);
   if ((rc = ensure(ctx, ctx->lsm_scratch, ctx->lsm_scratch_cap, nscr))) return rc;
   if ((rc = ensure(ctx, ctx->records, ctx->records_cap, (size_t)ch * hh::kRecStride))) return rc;
-  const uint64_t* seeds_dev = c->seeds;
-  if (!c->seeds_on_device) {
-    if ((rc = ensure(ctx, ctx->seeds, ctx->seeds_cap, (size_t)c->n_paths))) return rc;
-    HH_HIP(ctx, hipMemcpyAsync(ctx->seeds, c->seeds, c->n_paths * sizeof(uint64_t),
-                               hipMemcpyHostToDevice, ctx->stream));
-    seeds_dev = ctx->seeds;
-  }
-  HH_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-  HH_HIP(ctx, hh::launch_gbm_grid(seeds_dev, c->n_paths, c->n_steps, m->S0, m->r_drift, m->sigma,
-                                  m->T, c->antithetic, ctx->lsm_grid, ctx->stream));
-  HH_HIP(ctx, hh::launch_lsm(ctx->lsm_grid, ntot, c->n_steps, m->strike, m->cp, step_discount,
-                             degree, ctx->lsm_tau, ctx->lsm_val, ctx->lsm_scratch, ctx->records,
+  HH_HIP(ctx, hh::launch_lsm(grid_dev, ntot, n_steps, m->strike, m->cp, step_discount, degree,
+                             ctx->lsm_tau, ctx->lsm_val, ctx->lsm_scratch, ctx->records,
                              ctx->stream));
   HH_HIP(ctx, hh::launch_reduce_records(ctx->records, ch, (double)ntot, ctx->accum, ctx->stream));
   HH_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
@@ -614,9 +587,6 @@ int hh_lsm_solve(hh_ctx* ctx, const hh_model* m, const hh_config* c, int32_t deg
                                hipMemcpyDeviceToHost, ctx->stream));
   if (stop_value)
     HH_HIP(ctx, hipMemcpyAsync(stop_value, ctx->lsm_val, ntot * sizeof(double),
-                               hipMemcpyDeviceToHost, ctx->stream));
-  if (spot_grid)
-    HH_HIP(ctx, hipMemcpyAsync(spot_grid, ctx->lsm_grid, grid_elems * sizeof(double),
                                hipMemcpyDeviceToHost, ctx->stream));
   HH_HIP(ctx, hipStreamSynchronize(ctx->stream));
   const double n = (double)ntot, mean = ctx->accum_host[HH_ACC_SUM] / n;
@@ -634,6 +604,195 @@ int hh_lsm_solve(hh_ctx* ctx, const hh_model* m, const hh_config* c, int32_t deg
   out->total_ms =
       std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   return HH_OK;
+}
+
+static int lsm_check_scalars(hh_ctx* ctx, const hh_model* m, const hh_config* c, int32_t degree,
+                             double step_discount) {
+  if (c->n_paths == 0 || c->n_steps == 0 || degree < 1 || degree > 8)
+    return fail(ctx, HH_ERR_INVALID, "LSM: n_paths, n_steps >= 1, 1 <= degree <= 8");
+  if (c->n_paths > (1ull << 40)) return fail(ctx, HH_ERR_INVALID, "n_paths too large");
+  if (!(m->S0 > 0.0) || !(m->T > 0.0) || (m->cp != 1.0 && m->cp != -1.0) ||
+      !(step_discount > 0.0) || !std::isfinite(step_discount))
+    return fail(ctx, HH_ERR_INVALID, "LSM: bad model scalars");
+  return HH_OK;
+}
+
+// seeds of the trajectories in device memory (staged if the caller's are on the host)
+static int stage_path_seeds(hh_ctx* ctx, const hh_config* c, const uint64_t** out) {
+  if (!c->seeds) return fail(ctx, HH_ERR_INVALID, "GENERATE needs seeds");
+  if (c->seeds_len && c->seeds_len < c->n_paths)
+    return fail(ctx, HH_ERR_INVALID, "Number of seeds (%llu) must be >= number of trajectories (%llu)",
+                (unsigned long long)c->seeds_len, (unsigned long long)c->n_paths);
+  *out = c->seeds;
+  if (!c->seeds_on_device) {
+    int rc = ensure(ctx, ctx->seeds, ctx->seeds_cap, (size_t)c->n_paths);
+    if (rc) return rc;
+    HH_HIP(ctx, hipMemcpyAsync(ctx->seeds, c->seeds, c->n_paths * sizeof(uint64_t),
+                               hipMemcpyHostToDevice, ctx->stream));
+    *out = ctx->seeds;
+  }
+  return HH_OK;
+}
+
+// The n_steps Broadie–Kaya transitions of length T/n_steps into ctx->lsm_grid (spot rows) and
+// ctx->heston_var (variance rows); per-transition accumulator vectors (BK counters) into
+// ctx->basket_accum[n_steps][HH_ACC_LEN].
+static int run_heston_grid(hh_ctx* ctx, const hh_model* m, const hh_config* c) {
+  if (c->dynamics != HH_HESTON || c->strategy != HH_BROADIE_KAYA)
+    return fail(ctx, HH_ERR_UNSUPPORTED, "exact Heston grid needs HestonDynamics + HestonBroadieKaya");
+  if (c->noise_mode != HH_NOISE_GENERATE || c->n_partials != 0 || c->antithetic)
+    return fail(ctx, HH_ERR_UNSUPPORTED,
+                "exact Heston grid: GENERATE noise, no dual partials, no antithetic form");
+  if (c->n_paths == 0 || c->n_steps == 0 || c->n_paths > (1ull << 40))
+    return fail(ctx, HH_ERR_INVALID, "exact Heston grid: n_paths, n_steps >= 1");
+  if (!(m->S0 > 0.0) || !(m->T > 0.0) || !std::isfinite(m->S0) || !std::isfinite(m->T) ||
+      !(std::fabs(m->rho) <= 1.0) || m->sigma == 0.0 || m->kappa == 0.0 || !(m->V0 > 0.0))
+    return fail(ctx, HH_ERR_INVALID,
+                "exact Heston grid: S0, T, V0 > 0, |rho| <= 1, sigma != 0, kappa != 0");
+  const uint64_t n = c->n_paths;
+  const size_t grid_elems = (size_t)(c->n_steps + 1) * n;
+  const uint32_t n_tiles = hh::tiles_for(n);
+  int rc;
+  if ((rc = ensure(ctx, ctx->lsm_grid, ctx->lsm_grid_cap, grid_elems))) return rc;
+  if ((rc = ensure(ctx, ctx->heston_var, ctx->heston_var_cap, grid_elems))) return rc;
+  if ((rc = ensure(ctx, ctx->records, ctx->records_cap, (size_t)n_tiles * hh::kRecStride * 2)))
+    return rc;
+  if ((rc = ensure(ctx, ctx->bk_scratch, ctx->bk_scratch_cap, hh::bk_scratch_bytes(n)))) return rc;
+  if ((rc = ensure(ctx, ctx->basket_accum, ctx->basket_accum_cap, (size_t)c->n_steps * HH_ACC_LEN)))
+    return rc;
+  hh::DevicePtrs p{};
+  p.records = ctx->records;
+  p.bk_scratch = ctx->bk_scratch;
+  if ((rc = stage_path_seeds(ctx, c, &p.seeds))) return rc;
+  HH_HIP(ctx, hh::launch_fill_rows(ctx->lsm_grid, ctx->heston_var, n, m->S0, m->V0, ctx->stream));
+  hh_model step_model = *m;
+  step_model.T = m->T / (double)c->n_steps;  // dt of solve(NoiseProblem; dt = T / steps)
+  step_model.cp = 1.0;
+  hh_config step_cfg = *c;
+  step_cfg.path_offset = 0;
+  for (uint32_t k = 0; k < c->n_steps; ++k) {
+    const hh::BkTransition tr{ctx->lsm_grid + (size_t)k * n, ctx->heston_var + (size_t)k * n,
+                              ctx->lsm_grid + (size_t)(k + 1) * n,
+                              ctx->heston_var + (size_t)(k + 1) * n, k};
+    HH_HIP(ctx, hh::launch_bk(step_model, step_cfg, p, ctx->stream, &tr));
+    HH_HIP(ctx, hh::launch_reduce_records(ctx->records, 2 * n_tiles, (double)n,
+                                          ctx->basket_accum + (size_t)k * HH_ACC_LEN, ctx->stream,
+                                          1, &step_model, &step_cfg));
+  }
+  return HH_OK;
+}
+
+// BK counters of all transitions, summed
+static int heston_grid_counters(hh_ctx* ctx, uint32_t n_steps, uint64_t* newton_fail,
+                                uint64_t* bisect, uint64_t* maxguess, uint64_t* cf_terms) {
+  std::vector<double> acc((size_t)n_steps * HH_ACC_LEN);
+  HH_HIP(ctx, hipMemcpyAsync(acc.data(), ctx->basket_accum, acc.size() * sizeof(double),
+                             hipMemcpyDeviceToHost, ctx->stream));
+  HH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  double f = 0, b = 0, g = 0, t = 0;
+  for (uint32_t k = 0; k < n_steps; ++k) {
+    const double* a = acc.data() + (size_t)k * HH_ACC_LEN;
+    f += a[HH_ACC_BK_NEWTON_FAIL]; b += a[HH_ACC_BK_BISECT];
+    g += a[HH_ACC_BK_MAXGUESS]; t += a[HH_ACC_BK_CF_TERMS];
+  }
+  *newton_fail = (uint64_t)f; *bisect = (uint64_t)b; *maxguess = (uint64_t)g; *cf_terms = (uint64_t)t;
+  return HH_OK;
+}
+
+int hh_heston_exact_grid(hh_ctx* ctx, const hh_model* m, const hh_config* c, double* spot_grid,
+                         double* var_grid, int32_t grids_on_device, hh_result* out) {
+  if (!ctx) return HH_ERR_INVALID;
+  std::lock_guard<std::recursive_mutex> lock__(ctx->mu);
+  if (!m || !c) return fail(ctx, HH_ERR_INVALID, "hh_heston_exact_grid: NULL argument");
+  const auto t0 = std::chrono::steady_clock::now();
+  HH_HIP(ctx, hipSetDevice(ctx->device));
+  HH_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  int rc = run_heston_grid(ctx, m, c);
+  if (rc) return rc;
+  HH_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  const size_t bytes = (size_t)(c->n_steps + 1) * c->n_paths * sizeof(double);
+  const hipMemcpyKind kind = grids_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+  if (spot_grid) HH_HIP(ctx, hipMemcpyAsync(spot_grid, ctx->lsm_grid, bytes, kind, ctx->stream));
+  if (var_grid) HH_HIP(ctx, hipMemcpyAsync(var_grid, ctx->heston_var, bytes, kind, ctx->stream));
+  HH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (out) {
+    std::memset(out, 0, sizeof(*out));
+    if ((rc = heston_grid_counters(ctx, c->n_steps, &out->bk_newton_fail, &out->bk_bisect_fallback,
+                                   &out->bk_maxguess_fallback, &out->bk_cf_terms)))
+      return rc;
+    out->n_paths_done = c->n_paths;
+    float ms = 0.f;
+    HH_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    out->kernel_ms = ms;
+    out->total_ms =
+        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  }
+  return HH_OK;
+}
+
+int hh_lsm_solve(hh_ctx* ctx, const hh_model* m, const hh_config* c, int32_t degree,
+                 double step_discount, hh_lsm_result* out, int32_t* stop_time, double* stop_value,
+                 double* spot_grid) {
+  if (!ctx) return HH_ERR_INVALID;
+  std::lock_guard<std::recursive_mutex> lock__(ctx->mu);
+  if (!m || !c || !out) return fail(ctx, HH_ERR_INVALID, "hh_lsm_solve: NULL argument");
+  const auto t0 = std::chrono::steady_clock::now();
+  // The reference's LSM regresses on the first state component of simulate_paths' solution
+  // (least_squares_montecarlo.jl:53,76).  Path sources: the GBM noise process of (LognormalDynamics,
+  // BlackScholesExact) (montecarlo.jl:140-159), whose state IS the spot, and the per-date exact
+  // Heston transitions of (HestonDynamics, HestonBroadieKaya) (montecarlo.jl:209-231), whose spot
+  // rows exp(log S) are used here (the reference hands its regression the log-state).
+  const bool gbm = c->dynamics == HH_LOGNORMAL && c->strategy == HH_EXACT_LAW;
+  const bool heston = c->dynamics == HH_HESTON && c->strategy == HH_BROADIE_KAYA;
+  if (!gbm && !heston)
+    return fail(ctx, HH_ERR_UNSUPPORTED,
+                "LSM needs LognormalDynamics + BlackScholesExact or HestonDynamics + "
+                "HestonBroadieKaya paths");
+  if (c->noise_mode != HH_NOISE_GENERATE || c->n_partials != 0)
+    return fail(ctx, HH_ERR_UNSUPPORTED, "LSM: GENERATE noise, no dual partials");
+  int rc = lsm_check_scalars(ctx, m, c, degree, step_discount);
+  if (rc) return rc;
+  HH_HIP(ctx, hipSetDevice(ctx->device));
+  const uint64_t ntot = c->n_paths * (c->antithetic ? 2 : 1);
+  const size_t grid_elems = hh_lsm_grid_elems(c->n_paths, c->n_steps, c->antithetic);
+  HH_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  if (gbm) {
+    if ((rc = ensure(ctx, ctx->lsm_grid, ctx->lsm_grid_cap, grid_elems))) return rc;
+    const uint64_t* seeds_dev = nullptr;
+    if ((rc = stage_path_seeds(ctx, c, &seeds_dev))) return rc;
+    HH_HIP(ctx, hh::launch_gbm_grid(seeds_dev, c->n_paths, c->n_steps, m->S0, m->r_drift, m->sigma,
+                                    m->T, c->antithetic, ctx->lsm_grid, ctx->stream));
+  } else {
+    if ((rc = run_heston_grid(ctx, m, c))) return rc;
+  }
+  rc = lsm_on_grid(ctx, ctx->lsm_grid, ntot, c->n_steps, m, degree, step_discount, out, stop_time,
+                   stop_value, t0);
+  if (rc) return rc;
+  if (spot_grid) {
+    HH_HIP(ctx, hipMemcpyAsync(spot_grid, ctx->lsm_grid, grid_elems * sizeof(double),
+                               hipMemcpyDeviceToHost, ctx->stream));
+    HH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  return HH_OK;
+}
+
+int hh_lsm_solve_grid(hh_ctx* ctx, const hh_model* m, const double* spot_grid_dev, uint64_t n_paths,
+                      uint32_t n_steps, int32_t degree, double step_discount, hh_lsm_result* out,
+                      int32_t* stop_time, double* stop_value) {
+  if (!ctx) return HH_ERR_INVALID;
+  std::lock_guard<std::recursive_mutex> lock__(ctx->mu);
+  if (!m || !spot_grid_dev || !out)
+    return fail(ctx, HH_ERR_INVALID, "hh_lsm_solve_grid: NULL argument");
+  const auto t0 = std::chrono::steady_clock::now();
+  hh_config c{};
+  c.n_paths = n_paths;
+  c.n_steps = n_steps;
+  int rc = lsm_check_scalars(ctx, m, &c, degree, step_discount);
+  if (rc) return rc;
+  HH_HIP(ctx, hipSetDevice(ctx->device));
+  HH_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  return lsm_on_grid(ctx, spot_grid_dev, n_paths, n_steps, m, degree, step_discount, out, stop_time,
+                     stop_value, t0);
 }
 
 int hh_ctx_enable_timing(hh_ctx* ctx, int32_t on) {

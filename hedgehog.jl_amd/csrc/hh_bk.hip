@@ -30,8 +30,8 @@ constexpr double kSeriesR = 13.0;  // |z| below which the power series is used f
 struct BkArgs {
   // model
   double kappa, theta, sigma, sigma2, rho, V0, T, logS0, r, strike, cp;
-  // sample_V_T constants (heston.jl:128-130)
-  double d, lam, cscale;
+  // sample_V_T constants (heston.jl:128-130); λ = lam_num·V0 / lam_den
+  double d, lam_num, lam_den, cscale;
   // HestonCFIterator constants (heston.jl:167-172)
   double nu, zeta_k, eta_k, nuk_factor;  // ν_κ = nuk_factor·sqrt(V0·VT)
   // Bessel helpers (host-precomputed: they depend on ν only)
@@ -45,6 +45,13 @@ struct BkArgs {
   uint64_t n_paths, path_offset;
   const uint64_t* seeds;
   double* terminal;
+  // one transition of a multi-date grid (HestonNoise, heston.jl:82-91): per-trajectory start state
+  // read from row `step`, end state written to row `step + 1`; NULL = the one-shot terminal law
+  const double* in_spot;
+  const double* in_var;
+  double* out_spot;
+  double* out_var;
+  uint32_t step;
   double* records;                 // [2·n_tiles][kRecStride]: phase 1, then phase 2
   unsigned long long* fail_mask;   // [n_tiles][4] ballots of the trajectories left to phase 2
   double* phi_cache;               // [cache_cap][cache_stride] cached Re ϕ(h·j), one column per lane
@@ -316,7 +323,7 @@ __device__ int poisson(double mu, const PathDraws& dr, int& it) {
 
 // everything a trajectory needs before the CDF inversion: draws, V_T, CF iterator, moments
 struct PathSetup {
-  double Z, u, VT;
+  double Z, u, VT, V0, logS0;
   CfIter cf;
   PhiCache cache;
   double initial_guess, max_guess, h;
@@ -330,8 +337,14 @@ __device__ void bk_setup(const BkArgs& p, uint64_t path, PathSetup& s) {
   s.cache.j_stop = 0;
   s.cache.theta_run = __builtin_nan("");
   s.cache.theta_cap = __builtin_nan("");
-  const uint64_t key = p.seeds[0];  // montecarlo.jl:456
-  const uint64_t G = p.path_offset + path;
+  // terminal law: ONE stream, seeds[1], indexed by trajectory (montecarlo.jl:456); grid: the
+  // trajectory's own seed (montecarlo.jl:331), indexed by the transition
+  const bool grid = p.in_var != nullptr;
+  const uint64_t key = grid ? p.seeds[path] : p.seeds[0];
+  const uint64_t G = grid ? (uint64_t)p.step : p.path_offset + path;
+  s.V0 = grid ? p.in_var[path] : p.V0;
+  s.logS0 = grid ? log(p.in_spot[path]) : p.logS0;  // heston.jl:84: S = exp(W[1]), then log(S0) :289
+  const double lam = p.lam_num * s.V0 / p.lam_den;  // heston.jl:129
   const PathDraws dr{(uint32_t)key, (uint32_t)(key >> 32), (uint32_t)G, (uint32_t)(G >> 32)};
   double zshift, u_boost;
   dr.normals(0u, s.Z, zshift);
@@ -342,18 +355,18 @@ __device__ void bk_setup(const BkArgs& p, uint64_t path, PathSetup& s) {
   double chi;
   if (p.d > 1.0) {
     const double g = gamma_any(0.5 * (p.d - 1.0), dr, it, u_boost);
-    const double sh = zshift + sqrt(p.lam);
+    const double sh = zshift + sqrt(lam);
     chi = sh * sh + 2.0 * g;
   } else {
-    const int n = poisson(0.5 * p.lam, dr, it);
+    const int n = poisson(0.5 * lam, dr, it);
     chi = 2.0 * gamma_any(0.5 * p.d + (double)n, dr, it, u_boost);
   }
   s.VT = p.cscale * chi;
 
   // 2. HestonCFIterator (heston.jl:165-176) and the moment heuristics (sample_from_cf.jl:31-37)
   s.cf.VT = s.VT;
-  s.cf.sqrtV0VT = sqrt(p.V0 * s.VT);
-  s.cf.sumV = (p.V0 + s.VT) / p.sigma2;
+  s.cf.sqrtV0VT = sqrt(s.V0 * s.VT);
+  s.cf.sumV = (s.V0 + s.VT) / p.sigma2;
   s.cf.logI_k = log_besseli(p, {p.nuk_factor * s.cf.sqrtV0VT, 0.0}).re;
   double th = __builtin_nan("");
   const double hm = p.moment_h;
@@ -373,11 +386,15 @@ __device__ void bk_setup(const BkArgs& p, uint64_t path, PathSetup& s) {
 // 3. log S_T (heston.jl:288-297), S_T = exp(.) (montecarlo.jl:384), payoff
 __device__ __forceinline__ double bk_finish(const BkArgs& p, const PathSetup& s, double IV,
                                             uint64_t path) {
-  const double mu = p.logS0 + p.r * p.T - 0.5 * IV +
-                    (p.rho / p.sigma) * (s.VT - p.V0 - p.kappa * p.theta * p.T + p.kappa * IV);
+  const double mu = s.logS0 + p.r * p.T - 0.5 * IV +
+                    (p.rho / p.sigma) * (s.VT - s.V0 - p.kappa * p.theta * p.T + p.kappa * IV);
   const double sigma2 = (1.0 - p.rho * p.rho) * IV;
   const double S = exp(mu + sqrt(sigma2) * s.Z);
   if (p.terminal) p.terminal[path] = S;
+  if (p.out_spot) {
+    p.out_spot[path] = S;
+    p.out_var[path] = s.VT;
+  }
   const double m = p.cp * (S - p.strike);
   return m > 0.0 ? m : 0.0;
 }
@@ -566,6 +583,16 @@ __global__ __launch_bounds__(kTile) void bk_fallback_kernel(const BkArgs p, uint
   bk_store_record(acc, rec);
 }
 
+__global__ __launch_bounds__(256) void fill_rows_kernel(double* __restrict__ spot0,
+                                                        double* __restrict__ var0, uint64_t n,
+                                                        double S0, double V0) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) {
+    spot0[i] = S0;
+    var0[i] = V0;
+  }
+}
+
 void hankel_coefficients(double nu, double* coef) {
   // a_0 = 1, a_k = a_{k-1} (4ν² − (2k−1)²) / (8k)   (DLMF 10.17.1)
   const double mu = 4.0 * nu * nu;
@@ -594,25 +621,39 @@ static size_t bk_flags_bytes(size_t n_tiles) {
   return (b + 255) & ~(size_t)255;
 }
 
+int launch_fill_rows(double* spot0, double* var0, uint64_t n, double S0, double V0, hipStream_t s) {
+  hipLaunchKernelGGL(fill_rows_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, spot0,
+                     var0, n, S0, V0);
+  return (int)hipGetLastError();
+}
+
 size_t bk_scratch_bytes(uint64_t n_paths) {
   const size_t n_tiles = tiles_for(n_paths);
   return bk_flags_bytes(n_tiles) + n_tiles * kTile * sizeof(double) * (size_t)phi_cache_cap(n_tiles);
 }
 
-int launch_bk(const hh_model& m, const hh_config& c, const DevicePtrs& ptr, hipStream_t s) {
+int launch_bk(const hh_model& m, const hh_config& c, const DevicePtrs& ptr, hipStream_t s,
+              const BkTransition* tr) {
   BkArgs a{};
+  if (tr) {
+    a.in_spot = tr->in_spot; a.in_var = tr->in_var;
+    a.out_spot = tr->out_spot; a.out_var = tr->out_var;
+    a.step = tr->step;
+  }
   a.kappa = m.kappa; a.theta = m.theta; a.sigma = m.sigma; a.sigma2 = m.sigma * m.sigma;
   a.rho = m.rho; a.V0 = m.V0; a.T = m.T; a.logS0 = log(m.S0); a.r = m.r_drift;
   a.strike = m.strike; a.cp = m.cp;
   const double em1 = -expm1(-m.kappa * m.T);  // 1 − e^{−κT}
   a.d = 4.0 * m.kappa * m.theta / a.sigma2;                                   // heston.jl:128
-  a.lam = 4.0 * m.kappa * exp(-m.kappa * m.T) * m.V0 / (a.sigma2 * em1);     // heston.jl:129
+  a.lam_num = 4.0 * m.kappa * exp(-m.kappa * m.T);                            // heston.jl:129
+  a.lam_den = a.sigma2 * em1;
   a.cscale = a.sigma2 * em1 / (4.0 * m.kappa);                               // heston.jl:130
   a.nu = 0.5 * a.d - 1.0;                                                    // heston.jl:168
   a.zeta_k = em1 / m.kappa;                                                  // heston.jl:170
   a.eta_k = m.kappa * (1.0 + exp(-m.kappa * m.T)) / em1;                     // heston.jl:171
   a.nuk_factor = 4.0 * m.kappa * exp(-0.5 * m.kappa * m.T) / a.sigma2 / em1;  // heston.jl:172
-  if (!(a.d > 0.0) || !std::isfinite(a.d) || !(a.lam >= 0.0)) return (int)hipErrorInvalidValue;
+  if (!(a.d > 0.0) || !std::isfinite(a.d) || !(a.lam_num * m.V0 / a.lam_den >= 0.0))
+    return (int)hipErrorInvalidValue;
   a.n_int = a.nu >= 1.0 ? (int)floor(a.nu) : 0;
   a.nu0 = a.nu - a.n_int;
   a.lgam_nu0p1 = lgamma(a.nu0 + 1.0);

@@ -75,8 +75,21 @@ inline int pad_partials(uint32_t p) { return p == 0 ? 0 : p == 1 ? 1 : p <= 3 ? 
 
 // All launchers return a hipError_t as int (0 = success) and only enqueue work on `s`.
 int launch_simulation(const hh_model& m, const hh_config& c, const DevicePtrs& p, hipStream_t s);
-int launch_bk(const hh_model& m, const hh_config& c, const DevicePtrs& p, hipStream_t s);
+// One transition of the per-date exact Heston grid (HestonNoise, heston.jl:82-91): start state of
+// every trajectory read from in_*, end state written to out_* (n_paths doubles each, device);
+// m.T is the length of the transition.  NULL = the one-shot terminal law of launch_bk.
+struct BkTransition {
+  const double* in_spot;
+  const double* in_var;
+  double* out_spot;
+  double* out_var;
+  uint32_t step;
+};
+int launch_bk(const hh_model& m, const hh_config& c, const DevicePtrs& p, hipStream_t s,
+              const BkTransition* tr = nullptr);
 size_t bk_scratch_bytes(uint64_t n_paths);  // BK writes 2·tiles_for(n_paths) records
+// row 0 of the exact Heston grid: spot0[i] = S0, var0[i] = V0
+int launch_fill_rows(double* spot0, double* var0, uint64_t n, double S0, double V0, hipStream_t s);
 // m, c given: finish the dual partials (active slots re-ordered, passive ones in closed form)
 int launch_reduce_records(const double* records, uint32_t n_records, double n_paths, double* accum,
                           hipStream_t s, uint32_t n_groups = 1, const hh_model* m = nullptr,

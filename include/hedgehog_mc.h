@@ -211,6 +211,32 @@ size_t hh_lsm_grid_elems(uint64_t n_paths, uint32_t n_steps, int32_t antithetic)
 int hh_lsm_solve(hh_ctx* ctx, const hh_model* model, const hh_config* cfg, int32_t degree,
                  double step_discount, hh_lsm_result* out, int32_t* stop_time, double* stop_value,
                  double* spot_grid);
+/*
+ * The same backward induction on a spot grid the caller already holds in DEVICE memory
+ * (grid[(n_steps+1)][n_paths], row k = date k·T/n_steps): the regression / stopping part of
+ * least_squares_montecarlo.jl:107-134 alone, for any path source.  Uses model->strike, cp only.
+ */
+int hh_lsm_solve_grid(hh_ctx* ctx, const hh_model* model, const double* spot_grid_dev,
+                      uint64_t n_paths, uint32_t n_steps, int32_t degree, double step_discount,
+                      hh_lsm_result* out, int32_t* stop_time, double* stop_value);
+
+/*
+ * Per-date EXACT Heston paths: the NoiseProblem that sde_problem(::PricingProblem, ::HestonDynamics,
+ * ::HestonBroadieKaya) builds (src/pricing_methods/montecarlo.jl:209-231) on the HestonNoise process
+ * (src/distributions/heston.jl:82-91), stepped with dt = T/n_steps by simulate_paths (:342-353):
+ * every step draws (log S, V) at t+dt from LogHestonDistribution(S_t, V_t, κ, θ, σ, ρ, r, dt) —
+ * one Broadie–Kaya transition per date and trajectory.
+ * cfg: dynamics = HH_HESTON, strategy = HH_BROADIE_KAYA, noise_mode = HH_NOISE_GENERATE, n_steps,
+ * n_paths, seeds (ONE PER TRAJECTORY here, montecarlo.jl:331 — unlike the one-shot terminal law,
+ * which reads seeds[0] only), bk_* controls; no antithetic form, no dual partials.
+ * Outputs (nullable; host, or device when grids_on_device): spot_grid[(n_steps+1)][n_paths] =
+ * exp(log S) rows (row 0 = S0) and var_grid of the same shape (row 0 = V0);
+ * hh_lsm_grid_elems(n_paths, n_steps, 0) doubles each.  out (nullable): the bk_* counters summed
+ * over all transitions, n_paths_done, kernel_ms, total_ms; price fields are zero.
+ * hh_lsm_solve accepts the same (dynamics, strategy) pair and regresses on the spot rows.
+ */
+int hh_heston_exact_grid(hh_ctx* ctx, const hh_model* model, const hh_config* cfg, double* spot_grid,
+                         double* var_grid, int32_t grids_on_device, hh_result* out);
 
 /*
  * REPLAY increments.  Tile-major layout (what the step kernels stream):

@@ -391,3 +391,24 @@ def mc_solve(S0, V0, kappa, theta, sigma, rho, r, T, strike, cp, discount, n_pat
     se = discount * pay.std(ddof=1) / math.sqrt(n_paths) if n_paths > 1 else 0.0
     return dict(price=price, std_error=se, terminal=S, V_T=VT, integral_V=IV, stats=stats,
                 cf_terms=counter.terms)
+
+
+def exact_grid(S0, V0, kappa, theta, sigma, rho, r, T, n_steps, seeds, stats=None, counter=None,
+               **kw):
+    """Per-date exact Heston paths: the NoiseProblem of sde_problem(::HestonDynamics,
+    ::HestonBroadieKaya) (montecarlo.jl:209-231) on HestonNoise (heston.jl:82-91), stepped with
+    dt = T / n_steps.  Each step: S, V = exp(W[1]), W[2]; (log S', V') ~ LogHestonDistribution(S, V,
+    κ, θ, σ, ρ, r, dt) (heston.jl:84-86), where sample_log_S_T takes log(S) again (:289).
+    Trajectory i draws from Philox keyed by seeds[i] (montecarlo.jl:331), counter = transition index.
+    Returns (spot[(n_steps+1), n], var[(n_steps+1), n]); spot rows are exp(log S)."""
+    n = len(seeds)
+    dt = T / n_steps
+    spot = np.empty((n_steps + 1, n))
+    var = np.empty((n_steps + 1, n))
+    spot[0], var[0] = S0, V0
+    for i in range(n):
+        for k in range(n_steps):
+            dist = LogHestonDistribution(spot[k, i], var[k, i], kappa, theta, sigma, rho, r, dt)
+            logS, VT, _ = rand_path(dist, int(seeds[i]), k, stats, counter, **kw)
+            spot[k + 1, i], var[k + 1, i] = math.exp(logS), VT
+    return spot, var
