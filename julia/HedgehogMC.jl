@@ -218,6 +218,39 @@ function solve_lsm_hip(prob::PricingProblem{VanillaOption{TS,TE,Hedgehog.America
 end
 
 """
+    heston_exact_paths_hip(prob, method::MonteCarlo) -> (spot, variance)
+
+`hh_heston_exact_grid`: what `simulate_paths(sde_problem(prob, HestonDynamics(), HestonBroadieKaya()),
+method, NoVarianceReduction())` (montecarlo.jl:209-231, 342-353 on `HestonNoise`, heston.jl:82-91)
+holds per trajectory, as two (nsteps+1) x npaths matrices; `log.(spot)` is the first state component
+of the reference's solution objects.  One seed per trajectory (montecarlo.jl:331).
+"""
+function heston_exact_paths_hip(prob::PricingProblem{P,I}, method::MonteCarlo) where {P,I<:HestonInputs}
+    (method.dynamics isa HestonDynamics && method.strategy isa HestonBroadieKaya) ||
+        throw(MethodError(heston_exact_paths_hip, (prob, method)))
+    m, payoff, cfg = prob.market_inputs, prob.payoff, method.config
+    T = yearfrac(m.referenceDate, payoff.expiry)                                   # montecarlo.jl:219
+    nsteps = Int(cfg.steps); n = Int(cfg.trajectories)
+    seeds = convert(Vector{UInt64}, cfg.seeds .% UInt64)
+    spot = Matrix{Float64}(undef, n, nsteps + 1)             # column-major: [path, step] = C [step][path]
+    var = Matrix{Float64}(undef, n, nsteps + 1)
+    ctx = context()
+    GC.@preserve seeds spot var begin
+        model = HHModel(Float64(m.spot), Float64(m.V0), Float64(m.κ), Float64(m.θ), Float64(m.σ),
+                        Float64(m.ρ), Float64(zero_rate(m.rate, 0.0)), 1.0, Float64(T),
+                        Float64(payoff.strike), 1.0, ntuple(_ -> Ptr{Cdouble}(C_NULL), 8)...)
+        config = HHConfig(1, 2, false, 1, 0, 0, 0, 0, 0, 0, UInt32(nsteps), UInt32(0), UInt64(n),
+                          UInt64(0), pointer(seeds), Ptr{Cdouble}(C_NULL), 0.0, 0.0, 0.0, 0.0, 0, 0,
+                          UInt64(length(seeds)), UInt64(0))
+        rc = ccall((:hh_heston_exact_grid, LIB[]), Cint,
+                   (Ptr{Cvoid}, Ref{HHModel}, Ref{HHConfig}, Ptr{Cdouble}, Ptr{Cdouble}, Int32, Ptr{Cvoid}),
+                   ctx.handle, model, config, pointer(spot), pointer(var), Int32(0), C_NULL)
+        rc == 0 || error("hh_heston_exact_grid failed ($rc): $(last_error(ctx))")
+    end
+    return permutedims(spot), permutedims(var)
+end
+
+"""
     install!()
 
 Overwrite `Hedgehog.solve(::PricingProblem{<:VanillaOption{…,European,…,Spot}}, ::MonteCarlo)`
