@@ -98,7 +98,8 @@ int ncomp_of(int dynamics) { return dynamics == HH_HESTON ? 2 : 1; }
 int validate(hh_ctx* ctx, const hh_model* m, const hh_config* c) {
   if (!m || !c) return fail(ctx, HH_ERR_INVALID, "model/config is NULL");
   if (c->n_paths == 0) return fail(ctx, HH_ERR_INVALID, "n_paths must be >= 1");
-  if (c->n_paths > (1ull << 40)) return fail(ctx, HH_ERR_INVALID, "n_paths too large");
+  // one workgroup per 256 trajectories: the tile count must fit a grid dimension (< 2^31)
+  if (c->n_paths > (1ull << 38)) return fail(ctx, HH_ERR_INVALID, "n_paths too large (max 2^38)");
   if (c->n_partials > HH_MAX_PARTIALS)
     return fail(ctx, HH_ERR_INVALID, "n_partials %u > HH_MAX_PARTIALS", c->n_partials);
   const bool logn = c->dynamics == HH_LOGNORMAL, hest = c->dynamics == HH_HESTON;
@@ -610,7 +611,8 @@ static int lsm_check_scalars(hh_ctx* ctx, const hh_model* m, const hh_config* c,
                              double step_discount) {
   if (c->n_paths == 0 || c->n_steps == 0 || degree < 1 || degree > 8)
     return fail(ctx, HH_ERR_INVALID, "LSM: n_paths, n_steps >= 1, 1 <= degree <= 8");
-  if (c->n_paths > (1ull << 40)) return fail(ctx, HH_ERR_INVALID, "n_paths too large");
+  // one workgroup per 256 trajectories: the tile count must fit a grid dimension (< 2^31)
+  if (c->n_paths > (1ull << 38)) return fail(ctx, HH_ERR_INVALID, "n_paths too large (max 2^38)");
   if (!(m->S0 > 0.0) || !(m->T > 0.0) || (m->cp != 1.0 && m->cp != -1.0) ||
       !(step_discount > 0.0) || !std::isfinite(step_discount))
     return fail(ctx, HH_ERR_INVALID, "LSM: bad model scalars");
@@ -643,7 +645,7 @@ static int run_heston_grid(hh_ctx* ctx, const hh_model* m, const hh_config* c) {
   if (c->noise_mode != HH_NOISE_GENERATE || c->n_partials != 0 || c->antithetic)
     return fail(ctx, HH_ERR_UNSUPPORTED,
                 "exact Heston grid: GENERATE noise, no dual partials, no antithetic form");
-  if (c->n_paths == 0 || c->n_steps == 0 || c->n_paths > (1ull << 40))
+  if (c->n_paths == 0 || c->n_steps == 0 || c->n_paths > (1ull << 38))
     return fail(ctx, HH_ERR_INVALID, "exact Heston grid: n_paths, n_steps >= 1");
   if (!(m->S0 > 0.0) || !(m->T > 0.0) || !std::isfinite(m->S0) || !std::isfinite(m->T) ||
       !(std::fabs(m->rho) <= 1.0) || m->sigma == 0.0 || m->kappa == 0.0 || !(m->V0 > 0.0))

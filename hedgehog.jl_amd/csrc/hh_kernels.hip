@@ -216,6 +216,18 @@ struct VecOf<2> {
 #ifndef HH_REPLAY_LDS
 #define HH_REPLAY_LDS 4  // chunks in each wave's LDS ring; 0 = two-chunk register pipeline instead
 #endif
+#ifndef HH_REPLAY_PIPE
+#define HH_REPLAY_PIPE 0  // standard ring: 0 = drain all LDS-DMA before each chunk is read
+#endif
+#ifndef HH_REPLAY_LDS_DEEP
+#define HH_REPLAY_LDS_DEEP 8  // ring depth when the grid cannot fill the chip (<= kDeepRingTiles)
+#endif
+#ifndef HH_REPLAY_LDS_ANTI
+#define HH_REPLAY_LDS_ANTI 0  // the same for the antithetic kernels
+#endif
+#ifndef HH_REPLAY_LDS_DUAL
+#define HH_REPLAY_LDS_DUAL 0  // ... and for the kernels carrying dual partials
+#endif
 constexpr int kChunk = HH_REPLAY_CHUNK;  // steps per register chunk of the REPLAY pipeline
 
 template <class Vec>
@@ -227,7 +239,8 @@ __device__ __forceinline__ Vec stream_load(const double* p) {
 #endif
 }
 
-template <class M, int P, bool REPLAY, bool ANTI, int PPT>
+// RING: chunks in each wave's LDS ring of the REPLAY stream (0 = register pipeline), see below
+template <class M, int P, bool REPLAY, bool ANTI, int PPT, int RING, bool PIPE>
 __global__ __launch_bounds__(kTile / PPT, REPLAY ? HH_REPLAY_MINW : 1) void euler_kernel(
     const SimArgs<P> a) {
   constexpr int NC = M::NCOMP;
@@ -278,25 +291,37 @@ __global__ __launch_bounds__(kTile / PPT, REPLAY ? HH_REPLAY_MINW : 1) void eule
       }
     };
 
-    // Which REPLAY pipeline: the LDS ring wins where the kernel is purely HBM-bound (no partials, no
-    // mirrored path: 6.75-6.9 vs 6.45 TB/s); with more VALU work per step its 32 KiB of LDS per
-    // workgroup (10 waves per CU) hides less latency than the register pipeline's 16-20 waves, and
-    // it measured slower (antithetic 0.81 vs 0.72 ms, one carried partial 0.76 vs 0.70 ms).
-    constexpr bool kUseLds = HH_REPLAY_LDS > 0 && P == 0 && !ANTI && PPT == 2;
+    // Which REPLAY pipeline (measurements: DESIGN.md §5, tools/tune_replay.py, tools/replay_sizes.py).
+    // RING > 0: each wave moves its half-tile (128 trajectories = 1 KiB per step and component)
+    // through a PRIVATE ring of RING chunks in LDS, filled by LDS-DMA (global_load_lds_dwordx4: 16 B
+    // per lane straight into LDS, no VGPR staging).  A wave reads back only what it wrote itself, so
+    // there is no workgroup barrier in the loop, only s_waitcnt.
+    //  * PIPE = false, the form used when the grid fills the chip: the wave DRAINS its LDS-DMA
+    //    (vmcnt(0)) before reading a chunk, so its own loads never overlap its own arithmetic;
+    //    overlap comes from the other waves of the CU, whose number the ring's LDS footprint caps
+    //    (4 x 2 steps x 2 components x 1 KiB x 2 waves = 32 KiB per workgroup -> 8 waves per CU,
+    //    32 KiB in flight per CU).  That is the fastest point found at 10^6 trajectories (6.9 TB/s):
+    //    more waves, more bytes per wave or a pipelined ring all put more requests in flight and
+    //    LOWER the achieved bandwidth (6.4-6.7 TB/s).
+    //  * PIPE = true, for grids that cannot fill the chip: counted waits keep the RING-1 younger
+    //    chunks in flight while chunk k is consumed (28 KiB per wave at RING = 8): 1.6x the drain
+    //    form's bandwidth at 10^5 trajectories.  The read-back then has to be invisible to the
+    //    compiler (inline ds_read_b128): it treats any LDS read it knows about as aliasing ALL
+    //    outstanding LDS-DMA and puts s_waitcnt vmcnt(0) in front of it.
+    // RING = 0 (dual partials, antithetic pairs): two register chunks, load(B) || compute(A) — with
+    // more arithmetic per step the LDS forms measured slower (0.81 vs 0.72 ms, 0.76 vs 0.70 ms).
+    constexpr int R = RING;
+    constexpr bool kUseLds = R > 0 && PPT == 2;
     if constexpr (kUseLds) {
-    // LDS-staged streaming.  Each wave moves its half-tile (128 trajectories =
-    // 1 KiB per step and component) through a PRIVATE ring in LDS with LDS-DMA
-    // (global_load_lds_dwordx4: 16 B per lane straight into LDS, no VGPR staging).  A wave reads back
-    // only what it wrote itself, so there is no barrier in the loop: a counted s_waitcnt vmcnt lets
-    // the R-1 younger chunks stay in flight while chunk k is consumed.  R = HH_REPLAY_LDS chunks of
-    // kChunk steps; 4 x 2 was the fastest of the sweep in tools/tune_replay.py.
-    constexpr int R = HH_REPLAY_LDS > 0 ? HH_REPLAY_LDS : 1;
     constexpr int PER_CHUNK = kChunk * NC;  // LDS-DMA instructions per chunk and wave
     static_assert((R - 1) * PER_CHUNK <= 63, "vmcnt is a 6-bit counter");
     __shared__ __attribute__((aligned(16))) double ring[kTile / PPT / 64][R][kChunk][NC][128];
     const int wave = tid >> 6, lane = tid & 63;
     const double* gbase = a.replay + (size_t)tile * n_steps * NC * kTile + wave * 128 + lane * 2;
     const uint32_t n_chunks = n_steps / kChunk;
+    // LDS byte address of this lane's 16 B in slot 0, step 0, component 0 of the wave's ring
+    const uint32_t ring_lds =
+        (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)&ring[wave][0][0][0][lane * 2];
     auto issue = [&](uint32_t k) {
 #pragma unroll
       for (int u = 0; u < kChunk; ++u)
@@ -311,27 +336,50 @@ __global__ __launch_bounds__(kTile / PPT, REPLAY ? HH_REPLAY_MINW : 1) void eule
     for (uint32_t k = 0; k + 1 < (uint32_t)R && k < n_chunks; ++k) issue(k);
     for (uint32_t k = 0; k < n_chunks; ++k) {
       if (k + R - 1 < n_chunks) issue(k + R - 1);
-      // chunk k has landed once at most `after` younger chunks are still in flight
-      const uint32_t after = n_chunks - 1 - k < (uint32_t)(R - 1) ? n_chunks - 1 - k : (uint32_t)(R - 1);
+      Vec v[kChunk][NC];
+      if constexpr (PIPE) {
+        // chunk k has landed once at most `after` younger chunks are still in flight
+        const uint32_t after =
+            n_chunks - 1 - k < (uint32_t)(R - 1) ? n_chunks - 1 - k : (uint32_t)(R - 1);
 #define HH_WAIT_CHUNKS(n) \
   case n: asm volatile("s_waitcnt vmcnt(%0)" ::"n"((n) * PER_CHUNK < 63 ? (n) * PER_CHUNK : 63) : "memory"); break;
-      switch (after) {
-        HH_WAIT_CHUNKS(0) HH_WAIT_CHUNKS(1) HH_WAIT_CHUNKS(2) HH_WAIT_CHUNKS(3) HH_WAIT_CHUNKS(4)
-        HH_WAIT_CHUNKS(5) HH_WAIT_CHUNKS(6) HH_WAIT_CHUNKS(7)
-        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-      }
+        switch (after) {
+          HH_WAIT_CHUNKS(0) HH_WAIT_CHUNKS(1) HH_WAIT_CHUNKS(2) HH_WAIT_CHUNKS(3) HH_WAIT_CHUNKS(4)
+          HH_WAIT_CHUNKS(5) HH_WAIT_CHUNKS(6) HH_WAIT_CHUNKS(7)
+          default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        }
 #undef HH_WAIT_CHUNKS
-      __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_sched_barrier(0);
+        const uint32_t slot = ring_lds + (k % R) * (uint32_t)(kChunk * NC * 1024);
+#pragma unroll
+        for (int u = 0; u < kChunk; ++u)
+#pragma unroll
+          for (int c = 0; c < NC; ++c)
+            asm volatile("ds_read_b128 %0, %1 offset:%2"
+                         : "=v"(v[u][c])
+                         : "v"(slot), "n"((u * NC + c) * 1024)
+                         : "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+      }
 #pragma unroll
       for (int u = 0; u < kChunk; ++u) {
-        Vec v[NC];
+        if constexpr (PIPE) {
+          // LDS returns in order: step u is there once (kChunk-1-u)·NC reads are still pending.  The
+          // "+v" operands are a data dependence: no use of v[u][] may be scheduled above its wait.
 #pragma unroll
-        for (int c = 0; c < NC; ++c)
-          v[c] = *reinterpret_cast<const Vec*>(&ring[wave][k % R][u][c][lane * 2]);
+          for (int c = 0; c < NC; ++c)
+            asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(v[u][c]) : "n"((kChunk - 1 - u) * NC) : "memory");
+        } else {  // read step by step: the next step's LDS reads overlap this step's flops
+#pragma unroll
+          for (int c = 0; c < NC; ++c)
+            v[u][c] = *reinterpret_cast<const Vec*>(&ring[wave][k % R][u][c][lane * 2]);
+        }
 #pragma unroll
         for (int j = 0; j < PPT; ++j) {
-          const double d1 = VecOf<PPT>::get(v[0], j);
-          const double d2 = NC > 1 ? VecOf<PPT>::get(v[NC - 1], j) : 0.0;
+          const double d1 = VecOf<PPT>::get(v[u][0], j);
+          const double d2 = NC > 1 ? VecOf<PPT>::get(v[u][NC - 1], j) : 0.0;
           M::step(st[j], a, d1, d2);
           if constexpr (ANTI) M::step(sa[j], a, -d1, -d2);  // montecarlo.jl:258: -W
         }
@@ -675,11 +723,25 @@ static SimArgs<P> make_args(const hh_model& m, const hh_config& c, const DeviceP
   return a;
 }
 
+// With the standard ring (32 KiB of LDS per Heston workgroup) a CU holds 4 workgroups, the chip
+// 1024; a grid of at most half that cannot fill it, so each wave gets a deeper, pipelined ring
+// (more bytes in flight per wave) instead: 2 workgroups per CU still hold the whole grid.
+constexpr uint32_t kDeepRingTiles = 512;
+
 template <class M, int P, bool REPLAY, bool ANTI>
 static int launch_euler_t(const SimArgs<P>& a, hipStream_t s) {
   constexpr int PPT = REPLAY ? 2 : 1;
-  hipLaunchKernelGGL((euler_kernel<M, P, REPLAY, ANTI, PPT>), dim3(a.n_tiles), dim3(kTile / PPT), 0,
-                     s, a);
+  constexpr int RING = !REPLAY ? 0 : ANTI ? HH_REPLAY_LDS_ANTI : P > 0 ? HH_REPLAY_LDS_DUAL
+                                                                     : HH_REPLAY_LDS;
+  const dim3 g(a.n_tiles), b(kTile / PPT);
+  if constexpr (RING > 0 && HH_REPLAY_LDS_DEEP > 0) {
+    if (a.n_tiles <= kDeepRingTiles) {
+      hipLaunchKernelGGL((euler_kernel<M, P, REPLAY, ANTI, PPT, HH_REPLAY_LDS_DEEP, true>), g, b, 0,
+                         s, a);
+      return (int)hipGetLastError();
+    }
+  }
+  hipLaunchKernelGGL((euler_kernel<M, P, REPLAY, ANTI, PPT, RING, HH_REPLAY_PIPE != 0>), g, b, 0, s, a);
   return (int)hipGetLastError();
 }
 

@@ -50,8 +50,9 @@ def build():
             raise SystemExit(f"{tag} failed")
         lines = err.splitlines()
         for i, ln in enumerate(lines):
-            if "HestonModelILi0ELb1EEELi0ELb1ELb0ELi2" in ln and "Function Name" in ln:
-                vg = [x for x in lines[i:i + 8] if "VGPRs:" in x or "Occupancy" in x]
+            if os.environ.get("HH_TUNE_KERNEL", "HestonModelILi0ELb1EEELi0ELb1ELb0ELi2") in ln \
+                    and "Function Name" in ln:
+                vg = [x for x in lines[i:i + 12] if "VGPRs:" in x or "Occupancy" in x or "LDS Size" in x]
                 print(tag, " ".join(x.split("remark:")[1].strip().split("[")[0] for x in vg))
 
 
@@ -73,13 +74,19 @@ def run(rounds=7):
         lib.hh_ctx_enable_timing(h, 1)
         libs[tag] = (lib, h)
     lib0, h0 = next(iter(libs.values()))
-    m = _ffi.make_model()
+    mode = os.environ.get("HH_TUNE_MODE", "price")   # price | anti | greeks3
+    if mode == "greeks3":
+        m = _ffi.make_model(seeds={"S0": [1, 0, 0], "V0": [0, 1, 0], "r_drift": [0, 0, 1],
+                                   "discount": [0, 0, -float(np.exp(-0.03))]}, n_partials=3)
+    else:
+        m = _ffi.make_model()
     dW = torch.empty(lib0.hh_replay_elems(n_paths, n_steps, 1), dtype=torch.float64, device=dev)
     assert lib0.hh_wiener_fill(h0, 1, m.rho, m.T, n_steps, n_paths, seeds.data_ptr(), 1,
                                dW.data_ptr()) == 0
     lib0.hh_ctx_synchronize(h0)
     acc = torch.zeros(16, dtype=torch.float64, device=dev)
-    c = _ffi.make_config(1, 0, n_paths, n_steps, noise_mode=1)
+    c = _ffi.make_config(1, 0, n_paths, n_steps, noise_mode=1, antithetic=int(mode == "anti"),
+                         n_partials=3 if mode == "greeks3" else 0)
     c.replay, c.replay_on_device = dW.data_ptr(), 1
     times = {t: [] for t in libs}
     prices = {}
