@@ -60,6 +60,22 @@ def test_heston_euler_replay_ragged(hhlib, oracle, n_paths, n_steps):
 
 
 @pytest.mark.parametrize("dyn", [GBM, HES])
+@pytest.mark.parametrize("n_steps", [1, 2, 5, 9])
+def test_replay_ragged_above_the_small_grid_threshold(hhlib, oracle, dyn, n_steps):
+    """More than 512 workgroups: the launch takes the drain form of the LDS ring (ragged last
+    tile, odd step counts, fewer chunks than ring slots); below that the pipelined deep ring runs
+    (test_heston_euler_replay_ragged)."""
+    n_paths = 512 * 256 + 4099
+    seeds = seeds_for(n_paths, 9)
+    m = o.make_model(sigma=0.2 if dyn == GBM else 0.3)
+    dW = oracle.wiener_fill(dyn, m.rho, m.T, n_steps, seeds)
+    c = o.make_config(dyn, EM, n_paths, n_steps, noise_mode=REP, replay=dW)
+    rg, tg = gpu_solve(hhlib, m, c)
+    ro, to, _ = oracle.mc_solve(m, c)
+    check(rg, tg, ro, to, 0, 1e-12, 1e-12)
+
+
+@pytest.mark.parametrize("dyn", [GBM, HES])
 @pytest.mark.parametrize("anti", [0, 1])
 @pytest.mark.parametrize("noise", [GEN, REP])
 @pytest.mark.parametrize("P", [0, 1, 3, 5])
