@@ -24,6 +24,29 @@ namespace hh {
 // heston.jl:7-31.  u = [log S, v];  f = [mu - v+/2, kappa(theta - v+)],  g = [sqrt(v+), sigma sqrt(v+)]
 // with v+ = max(v, 0).  K = u + dt f(u);  u' = K + g(.) dW, g taken at K (SPLIT, the integrator's
 // split-step form) or at u.
+#ifndef HH_LEAN_SQRT
+#define HH_LEAN_SQRT 1
+#endif
+// sqrt of the clipped variance w >= 0.  The library routine is v_rsq_f64 + one coupled Newton step
+// + two residual corrections, wrapped in a 2^±256 range scaling for arguments below 2^-767 and a
+// class test for 0/inf: 18 instructions, more than half of a Heston path-step.  This is the same
+// core sequence (so the same, correctly rounded, result for every w >= 2^-767) with the zero
+// handled by one select; a clipped variance between 0 and 2^-767 cannot change any later state.
+__device__ __forceinline__ double sqrt_clipped(double w) {
+#if HH_LEAN_SQRT
+  const double y = __builtin_amdgcn_rsq(w);
+  double g = w * y, h = 0.5 * y;
+  const double r = fma(-h, g, 0.5);
+  g = fma(g, r, g);
+  h = fma(h, r, h);
+  g = fma(fma(-g, g, w), h, g);
+  g = fma(fma(-g, g, w), h, g);
+  return w > 0.0 ? g : 0.0;
+#else
+  return sqrt(w);
+#endif
+}
+
 template <int P, bool SPLIT>
 struct HestonModel {
   static constexpr int NCOMP = 2;
@@ -39,11 +62,11 @@ struct HestonModel {
     const bool pos = s.v.v > 0.0;
     const double vp = pos ? s.v.v : 0.0;
     const double th_m_v = a.theta.v - vp;
-    const double Kx = fma(a.dt, a.r.v - 0.5 * vp, s.x.v);
+    const double Kx = fma(a.dt, fma(-0.5, vp, a.r.v), s.x.v);  // r - vp/2: the product is exact
     const double Kv = fma(a.dt, a.kappa.v * th_m_v, s.v.v);
     const bool wpos = SPLIT ? (Kv > 0.0) : pos;
     const double w = SPLIT ? (wpos ? Kv : 0.0) : vp;
-    const double sq = sqrt(w);
+    const double sq = sqrt_clipped(w);
     if constexpr (P > 0) {
       // d sqrt(w+) = dw / (2 sqrt(w)) for w > 0, and 0 at the clip ("dual rules")
       // 1/(2 sqrt(w)): hardware reciprocal + one Newton step (relative error ~1e-16; an IEEE
