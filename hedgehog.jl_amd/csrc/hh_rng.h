@@ -55,6 +55,17 @@ __device__ __forceinline__ double u01_fast(uint32_t lo, uint32_t hi) {
 // of normals — more than everything else in a GENERATE path-step together; their generality (full
 // range, special values, denormals) is not needed here.  Accuracy of each: <= 2 ulp.
 
+// One Horner step p·z + c as a three-operand v_fma_f64.  Written as asm because the compiler turns
+// fma(p, z, CONSTANT) in a loop into "v_mov_b64 tmp, c ; v_fmac_f64 tmp, p, z" — it selects the
+// two-address v_fmac form against the materialised constant, and after the constant is hoisted out
+// of the loop a 64-bit copy per step remains: 17 extra VALU instructions per pair of normals (9 %
+// of a GENERATE path-step).  Same operation, same rounding.
+__device__ __forceinline__ double horner(double p, double z, double c) {
+  double d;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(p), "v"(z), "v"(c));
+  return d;
+}
+
 // -2 ln(u), u in (0, 1):  u = 2^e m, m in [sqrt(1/2), sqrt(2));  ln m = 2 atanh(s), s = (m-1)/(m+1)
 __device__ __forceinline__ double neg2_log_unit(double u) {
   double m = __builtin_amdgcn_frexp_mant(u);  // [1/2, 1)
@@ -70,14 +81,14 @@ __device__ __forceinline__ double neg2_log_unit(double u) {
   s = fma(fma(-s, d, f), r, s);           // residual correction: s = f/d to < 1 ulp
   const double z = s * s;
   double p = 0x1.af286bca1af28p-4;        // 2/19
-  p = fma(p, z, 0x1.e1e1e1e1e1e1ep-4);    // 2/17
-  p = fma(p, z, 0x1.1111111111111p-3);    // 2/15
-  p = fma(p, z, 0x1.3b13b13b13b14p-3);    // 2/13
-  p = fma(p, z, 0x1.745d1745d1746p-3);    // 2/11
-  p = fma(p, z, 0x1.c71c71c71c71cp-3);    // 2/9
-  p = fma(p, z, 0x1.2492492492492p-2);    // 2/7
-  p = fma(p, z, 0x1.999999999999ap-2);    // 2/5
-  p = fma(p, z, 0x1.5555555555555p-1);    // 2/3
+  p = horner(p, z, 0x1.e1e1e1e1e1e1ep-4);    // 2/17
+  p = horner(p, z, 0x1.1111111111111p-3);    // 2/15
+  p = horner(p, z, 0x1.3b13b13b13b14p-3);    // 2/13
+  p = horner(p, z, 0x1.745d1745d1746p-3);    // 2/11
+  p = horner(p, z, 0x1.c71c71c71c71cp-3);    // 2/9
+  p = horner(p, z, 0x1.2492492492492p-2);    // 2/7
+  p = horner(p, z, 0x1.999999999999ap-2);    // 2/5
+  p = horner(p, z, 0x1.5555555555555p-1);    // 2/3
   const double de = (double)e;
   // ln u = e ln2_hi + (2 s + (s z p + e ln2_lo)); ln2_hi has 21 trailing zero bits (exact product)
   const double t = fma(s * z, p, de * 1.90821492927058770002e-10);
@@ -104,22 +115,22 @@ __device__ __forceinline__ void sincospi_02(double t, double& sn, double& cs) {
   const double r = fma(q, -0.5, t);
   const double z = r * r;
   double ps = -0x1.6fadb9f155744p-16;
-  ps = fma(ps, z, 0x1.e8f434d018d63p-12);
-  ps = fma(ps, z, -0x1.e3074fde8871fp-8);
-  ps = fma(ps, z, 0x1.50783487ee782p-4);
-  ps = fma(ps, z, -0x1.32d2cce62bd86p-1);
-  ps = fma(ps, z, 0x1.466bc6775aae2p+1);
-  ps = fma(ps, z, -0x1.4abbce625be53p+2);
-  ps = fma(ps, z, 0x1.921fb54442d18p+1);
+  ps = horner(ps, z, 0x1.e8f434d018d63p-12);
+  ps = horner(ps, z, -0x1.e3074fde8871fp-8);
+  ps = horner(ps, z, 0x1.50783487ee782p-4);
+  ps = horner(ps, z, -0x1.32d2cce62bd86p-1);
+  ps = horner(ps, z, 0x1.466bc6775aae2p+1);
+  ps = horner(ps, z, -0x1.4abbce625be53p+2);
+  ps = horner(ps, z, 0x1.921fb54442d18p+1);
   const double sr = r * ps;
   double pc = 0x1.20c62c2f2d7f5p-18;
-  pc = fma(pc, z, -0x1.b6e24f44b128fp-14);
-  pc = fma(pc, z, 0x1.f9d38a3763cc3p-10);
-  pc = fma(pc, z, -0x1.a6d1f2a204a8cp-6);
-  pc = fma(pc, z, 0x1.e1f506891babbp-3);
-  pc = fma(pc, z, -0x1.55d3c7e3cbffap+0);
-  pc = fma(pc, z, 0x1.03c1f081b5ac4p+2);
-  pc = fma(pc, z, -0x1.3bd3cc9be45dep+2);
+  pc = horner(pc, z, -0x1.b6e24f44b128fp-14);
+  pc = horner(pc, z, 0x1.f9d38a3763cc3p-10);
+  pc = horner(pc, z, -0x1.a6d1f2a204a8cp-6);
+  pc = horner(pc, z, 0x1.e1f506891babbp-3);
+  pc = horner(pc, z, -0x1.55d3c7e3cbffap+0);
+  pc = horner(pc, z, 0x1.03c1f081b5ac4p+2);
+  pc = horner(pc, z, -0x1.3bd3cc9be45dep+2);
   const double cr = fma(pc, z, 1.0);
   const int qi = (int)q;
   const bool swap = qi & 1;
