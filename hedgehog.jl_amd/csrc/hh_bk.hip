@@ -67,20 +67,29 @@ __device__ __forceinline__ cx operator*(cx a, cx b) {
   return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re};
 }
 __device__ __forceinline__ cx operator*(double s, cx a) { return {s * a.re, s * a.im}; }
+// 1/x to <= 1 ulp: hardware reciprocal + two Newton steps (5 instructions; the IEEE division
+// sequence is 12).  The quantities divided here are moderate in size: no scaling needed.
+__device__ __forceinline__ double rcp_nr(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  return fma(fma(-x, r, 1.0), r, r);
+}
 __device__ __forceinline__ cx cdiv(cx a, cx b) {
-  const double inv = 1.0 / (b.re * b.re + b.im * b.im);
+  const double inv = rcp_nr(fma(b.re, b.re, b.im * b.im));
   return {(a.re * b.re + a.im * b.im) * inv, (a.im * b.re - a.re * b.im) * inv};
 }
-__device__ __forceinline__ double cabs(cx a) { return hypot(a.re, a.im); }
+// |a| without hypot's range scaling (31 instructions): the moduli taken here (γ, ν_γ, ϕ, series
+// sums) are far from the overflow / underflow thresholds of a² + b²
+__device__ __forceinline__ double cabs(cx a) { return sqrt(fma(a.re, a.re, a.im * a.im)); }
 __device__ __forceinline__ cx csqrt(cx z) {
-  const double r = hypot(z.re, z.im);
+  const double r = cabs(z);
   if (r == 0.0) return {0.0, 0.0};
   if (z.re >= 0.0) {
     const double t = sqrt(0.5 * (r + z.re));
-    return {t, z.im / (2.0 * t)};
+    return {t, z.im * rcp_nr(2.0 * t)};
   }
   const double t = sqrt(0.5 * (r - z.re));
-  return {fabs(z.im) / (2.0 * t), copysign(t, z.im)};
+  return {fabs(z.im) * rcp_nr(2.0 * t), copysign(t, z.im)};
 }
 __device__ __forceinline__ cx cexp(cx z) {
   const double e = exp(z.re);
@@ -88,24 +97,29 @@ __device__ __forceinline__ cx cexp(cx z) {
   sincos(z.im, &s, &c);
   return {e * c, e * s};
 }
-__device__ __forceinline__ cx clog(cx z) { return {log(hypot(z.re, z.im)), atan2(z.im, z.re)}; }
+__device__ __forceinline__ cx clog(cx z) { return {log(cabs(z)), atan2(z.im, z.re)}; }
 
-// log I_ν(z) by the ascending series (DLMF 10.25.2), order ν0 in (-1, 1), Re z >= 0, |z| < kSeriesR
-__device__ cx log_besseli_series(double nu0, double lgam, cx z) {
+// I_ν(z) = exp(lg) · mul: the part that can be huge or tiny stays a logarithm, the O(1) series sum
+// stays a factor — the CF needs exp(log I) only, so log(sum) followed by exp would be wasted work
+struct LogMul {
+  cx lg, mul;
+};
+
+// I_ν(z) by the ascending series (DLMF 10.25.2), order ν0 in (-1, 1), Re z >= 0, |z| = r < kSeriesR,
+// arg z = phi:  I = (z/2)^ν0 / Γ(ν0+1) · Σ (z²/4)^k / (k! (ν0+1)_k)
+__device__ LogMul besseli_series(double nu0, double lgam, cx z, double r, double phi) {
   const cx q = 0.25 * (z * z);
   cx t = {1.0, 0.0}, S = {1.0, 0.0};
   for (int k = 1; k < 200; ++k) {
-    t = (1.0 / ((double)k * ((double)k + nu0))) * (t * q);
+    t = rcp_nr((double)k * ((double)k + nu0)) * (t * q);
     S = S + t;
     if (fabs(t.re) + fabs(t.im) < 1e-17 * (fabs(S.re) + fabs(S.im))) break;
   }
-  const cx lz = clog(0.5 * z);
-  const cx ls = clog(S);
-  return {nu0 * lz.re - lgam + ls.re, nu0 * lz.im + ls.im};
+  return {{nu0 * log(0.5 * r) - lgam, nu0 * phi}, S};
 }
 
-// log I_ν(z) by the Hankel expansion (DLMF 10.40.5), Re z >= 0, |z| large; coef[k] = a_k(ν)
-__device__ cx log_besseli_asym(double nu, const double* coef, cx z) {
+// I_ν(z) by the Hankel expansion (DLMF 10.40.5), Re z >= 0, |z| = r large; coef[k] = a_k(ν)
+__device__ LogMul besseli_asym(double nu, const double* coef, cx z, double r, double phi) {
   const cx w = cdiv({1.0, 0.0}, z);
   cx p = {1.0, 0.0}, S1 = {1.0, 0.0}, S2 = {1.0, 0.0};
   double last = 1e300, sgn = -1.0;
@@ -122,30 +136,34 @@ __device__ cx log_besseli_asym(double nu, const double* coef, cx z) {
   }
   // I = e^z/sqrt(2πz) [S1 + e^{-2z ± iπ(ν+1/2)} S2], upper sign for Im z >= 0
   const double ph = (z.im >= 0.0 ? kPi : -kPi) * (nu + 0.5);
-  const cx e2 = cexp({-2.0 * z.re, -2.0 * z.im + ph});
-  const cx lg = clog(S1 + e2 * S2);
-  const cx l2 = clog({kTwoPi * z.re, kTwoPi * z.im});
-  return {z.re - 0.5 * l2.re + lg.re, z.im - 0.5 * l2.im + lg.im};
+  cx m = S1;
+  if (z.re < 18.5) {  // e^{-2 Re z} < 1e-16: the second sum is below rounding
+    const cx e2 = cexp({-2.0 * z.re, -2.0 * z.im + ph});
+    m = m + e2 * S2;
+  }
+  return {{z.re - 0.5 * log(kTwoPi * r), z.im - 0.5 * phi}, m};
 }
 
-// log I_ν(z), real ν > -1, any complex z != 0 (principal branch of I_ν; the imaginary part is
-// defined modulo 2π — callers exponentiate)
-__device__ cx log_besseli(const BkArgs& a, cx z) {
+// I_ν(z) = exp(lg)·mul for real ν > -1 and complex z != 0 with arg z = phi given by the caller
+// (principal branch; Im lg is defined modulo 2π — callers exponentiate)
+__device__ LogMul besseli_logmul(const BkArgs& a, cx z, double phi) {
   double refl = 0.0;
   if (z.re < 0.0) {  // I_ν(w e^{±iπ}) = e^{±iπν} I_ν(w)  (DLMF 10.34.1)
-    refl = (z.im >= 0.0 ? kPi : -kPi) * a.nu;
+    const double pi_s = z.im >= 0.0 ? kPi : -kPi;
+    refl = pi_s * a.nu;
+    phi -= pi_s;
     z = {-z.re, -z.im};
   }
   const double r = cabs(z);
-  cx res;
+  LogMul res;
   if (a.n_int == 0 || (r >= kSeriesR && r >= 2.0 * a.nu * a.nu + 10.0)) {
-    res = (r < kSeriesR) ? log_besseli_series(a.nu0, a.lgam_nu0p1, z)
-                         : log_besseli_asym(a.nu, a.coef_nu, z);
+    res = (r < kSeriesR) ? besseli_series(a.nu0, a.lgam_nu0p1, z, r, phi)
+                         : besseli_asym(a.nu, a.coef_nu, z, r, phi);
   } else {
     // base order ν0 = ν - n, then I_ν = I_ν0 · Π_{k<n} I_{ν0+k+1}/I_{ν0+k}; the ratios come from
     // the backward recurrence r_k = 1 / (2(ν0+k+1)/z + r_{k+1}), the minimal solution for Re z >= 0
-    res = (r < kSeriesR) ? log_besseli_series(a.nu0, a.lgam_nu0p1, z)
-                         : log_besseli_asym(a.nu0, a.coef_nu0, z);
+    res = (r < kSeriesR) ? besseli_series(a.nu0, a.lgam_nu0p1, z, r, phi)
+                         : besseli_asym(a.nu0, a.coef_nu0, z, r, phi);
     const cx w = cdiv({2.0, 0.0}, z);
     const int n = a.n_int;
     int N = n + (int)r + 30;
@@ -155,12 +173,15 @@ __device__ cx log_besseli(const BkArgs& a, cx z) {
       const double o = a.nu0 + (double)k + 1.0;
       rk = cdiv({1.0, 0.0}, {o * w.re + rk.re, o * w.im + rk.im});
       if (k < n) {
-        const cx l = clog(rk);
-        res = res + l;
+        if (n <= 16) {  // |r_k| < 1: a short product cannot leave the fp64 range
+          res.mul = res.mul * rk;
+        } else {
+          res.lg = res.lg + clog(rk);
+        }
       }
     }
   }
-  res.im += refl;
+  res.lg.im += refl;
   return res;
 }
 
@@ -191,12 +212,12 @@ __device__ cx evaluate_chf(const BkArgs& p, const CfIter& it, double a, double& 
     thu = theta_prev + dl;
   }
   theta_prev = thu;
-  cx lI = log_besseli(p, nu_g);  // principal branch at |ν_γ| cis(θ_unwrapped)
-  lI.im += p.nu * (thu - th);    // + i ν (θ_unwrapped − θ)  (heston.jl:207)
-  // ϕ = e^{-(γ-κ)T/2} (ζκ/ζγ) · exp((V0+VT)/σ² (ηκ-ηγ)) · exp(logIγ − logIκ)
-  const cx ex = {-0.5 * (g.re - p.kappa) * p.T + it.sumV * (p.eta_k - eta_g.re) + lI.re - it.logI_k,
-                 -0.5 * g.im * p.T - it.sumV * eta_g.im + lI.im};
-  return cexp(ex) * cdiv({p.zeta_k, 0.0}, zeta_g);
+  LogMul I = besseli_logmul(p, nu_g, th);  // principal branch at |ν_γ| cis(θ_unwrapped)
+  I.lg.im += p.nu * (thu - th);            // + i ν (θ_unwrapped − θ)  (heston.jl:207)
+  // ϕ = e^{-(γ-κ)T/2} (ζκ/ζγ) · exp((V0+VT)/σ² (ηκ-ηγ)) · Iγ / Iκ
+  const cx ex = {-0.5 * (g.re - p.kappa) * p.T + it.sumV * (p.eta_k - eta_g.re) + I.lg.re - it.logI_k,
+                 -0.5 * g.im * p.T - it.sumV * eta_g.im + I.lg.im};
+  return (cexp(ex) * I.mul) * cdiv({p.zeta_k, 0.0}, zeta_g);
 }
 
 // The series terms ϕ(h·j) of cdf_from_cf do not depend on x: the reference re-evaluates them in
@@ -222,6 +243,11 @@ __device__ double cdf_from_cf(const BkArgs& p, const CfIter& it, double x, doubl
   double result = h * x / kPi;
   const double pref = 2.0 / kPi, stop = kPi * p.cf_tol / 2.0;
   double theta_tail = c.theta_cap;  // for terms beyond the cached ones
+  // sin(h j x), j = 1, 2, …, by rotation (4 flops per term; error grows like j·eps) instead of one
+  // sin() call per term
+  double s1, c1;
+  sincos(h * x, &s1, &c1);
+  double sj = s1, cj = c1;
   for (int j = 1; j < 1000000; ++j) {
     const double aj = h * (double)j;
     double re;
@@ -233,7 +259,7 @@ __device__ double cdf_from_cf(const BkArgs& p, const CfIter& it, double x, doubl
       double& th = (j <= c.cap || c.filled < c.cap) ? c.theta_run : theta_tail;
       const cx phi = evaluate_chf(p, it, aj, th);
       re = phi.re;
-      last = !(cabs(phi) / (double)j >= stop);  // also leaves on NaN
+      last = !(cabs(phi) >= stop * (double)j);  // |ϕ|/j < π·tol/2 (sample_from_cf.jl:88); also leaves on NaN
       if (j > c.filled) {  // first time this term is seen
         c.filled = j;
         if (j <= c.cap) c.col[(size_t)(j - 1) * c.stride] = re;
@@ -241,9 +267,13 @@ __device__ double cdf_from_cf(const BkArgs& p, const CfIter& it, double x, doubl
         if (last) c.j_stop = j;
       }
     }
-    result += pref * sin(aj * x) / (double)j * re;
+    result += pref * sj * rcp_nr((double)j) * re;
     n_terms += 1.0;
     if (last) break;
+    const double sn = fma(sj, c1, cj * s1);
+    cj = fma(cj, c1, -(sj * s1));
+    sj = sn;
+    if ((j & 31) == 0) sincos(h * x * (double)(j + 1), &sj, &cj);  // re-anchor long series
   }
   return result;
 }
@@ -367,7 +397,8 @@ __device__ void bk_setup(const BkArgs& p, uint64_t path, PathSetup& s) {
   s.cf.VT = s.VT;
   s.cf.sqrtV0VT = sqrt(s.V0 * s.VT);
   s.cf.sumV = (s.V0 + s.VT) / p.sigma2;
-  s.cf.logI_k = log_besseli(p, {p.nuk_factor * s.cf.sqrtV0VT, 0.0}).re;
+  const LogMul Ik = besseli_logmul(p, {p.nuk_factor * s.cf.sqrtV0VT, 0.0}, 0.0);
+  s.cf.logI_k = Ik.lg.re + log(Ik.mul.re);  // real, positive argument: I_ν > 0
   double th = __builtin_nan("");
   const double hm = p.moment_h;
   const cx pp = evaluate_chf(p, s.cf, hm, th);
