@@ -399,14 +399,18 @@ __device__ void bk_setup(const BkArgs& p, uint64_t path, PathSetup& s) {
   s.cf.sumV = (s.V0 + s.VT) / p.sigma2;
   const LogMul Ik = besseli_logmul(p, {p.nuk_factor * s.cf.sqrtV0VT, 0.0}, 0.0);
   s.cf.logI_k = Ik.lg.re + log(Ik.mul.re);  // real, positive argument: I_ν > 0
+  // moments_from_cf (sample_from_cf.jl:50-61): mean = Re(-i ϕ'(0)), variance = Re(-ϕ''(0)) - mean²
+  // by central differences of step hm over ϕ(hm), ϕ(0), ϕ(-hm).  The law is real, so ϕ(-a) is the
+  // conjugate of ϕ(a) — operation by operation, also in floating point — and is not evaluated.
+  // ϕ(0) IS evaluated although it equals 1: its rounding error (1e-13 when the Bessel logarithms
+  // are ~10³, short steps) is common to ϕ(±hm) and cancels in the second difference, which is
+  // formed from numbers 1e-10 apart.
   double th = __builtin_nan("");
   const double hm = p.moment_h;
   const cx pp = evaluate_chf(p, s.cf, hm, th);
   const cx p0 = evaluate_chf(p, s.cf, 0.0, th);
-  const cx pm = evaluate_chf(p, s.cf, -hm, th);
-  // mean = Re(-i ϕ'), variance = Re(-ϕ'' - mean²)   (sample_from_cf.jl:57-61)
-  const double mean = (pp.im - pm.im) / (2.0 * hm);
-  const double var = -((pp.re - 2.0 * p0.re + pm.re) / (hm * hm)) - mean * mean;
+  const double mean = pp.im / hm;                                          // (ϕ₊ - ϕ₋)/(2h)
+  const double var = -(2.0 * (pp.re - p0.re) / (hm * hm)) - mean * mean;  // (ϕ₊ - 2ϕ₀ + ϕ₋)/h²
   const double sd = sqrt(fmax(var, 1e-12));
   const double normal_sample = mean + sd * normcdfinv(s.u);
   s.initial_guess = normal_sample > 0.0 ? normal_sample : mean * 0.01;
