@@ -71,7 +71,8 @@ inline uint32_t basket_chunks(uint64_t n_paths) {
 }
 
 inline uint32_t tiles_for(uint64_t n_paths) { return (uint32_t)((n_paths + kTile - 1) / kTile); }
-inline int pad_partials(uint32_t p) { return p == 0 ? 0 : p == 1 ? 1 : p <= 3 ? 3 : 8; }
+// carried basis derivatives (at most 4: V0, κ, θ, σ) -> instantiated kernel width
+inline int pad_partials(uint32_t p) { return p <= 4 ? (int)p : 4; }
 
 // All launchers return a hipError_t as int (0 = success) and only enqueue work on `s`.
 int launch_simulation(const hh_model& m, const hh_config& c, const DevicePtrs& p, hipStream_t s);

@@ -532,17 +532,23 @@ __global__ __launch_bounds__(kTile / 2) void exact_gbm_kernel(const SimArgs<P> a
 // record reduction: one workgroup per accumulator slot, fixed summation order
 // ------------------------------------------------------------------------------------------
 
-// Which dual directions are carried per path ("active": they reach the variance / diffusion) and
-// how the others ("passive": spot, drift rate, strike — ∂x_T is one constant for all paths) are
-// finished in closed form:  Σ∂p_k = xdT_k · Σ 1[itm]·cp·S  −  dK_k · Σ 1[itm]·cp.
+// What is carried per path and how the requested directions are assembled from it.  Derivative
+// propagation is linear in the seeds, so a requested direction k splits into
+//  * its components along the parameters that reach the variance / diffusion — V0, κ, θ, σ for the
+//    Heston Euler scheme, σ alone otherwise.  Only these BASIS derivatives are carried per path
+//    (unit seed each, at most 4 slots whatever n_partials is): Σ∂p_k += w[k][j] · Σ(∂p/∂basis_j);
+//  * its passive part (spot, drift rate, strike): ∂x_T is one constant for all paths, finished in
+//    closed form:  Σ∂p_k += xdT_k · Σ 1[itm]·cp·S  −  dK_k · Σ 1[itm]·cp.
+constexpr int kMaxBasis = 4;
+enum { kBasisV0 = 0, kBasisKappa = 1, kBasisTheta = 2, kBasisSigma = 3 };
 struct PartialMap {
   int sim;          // 1: records of a simulation/basket kernel (slots kRecItmS.. are internal)
   int n;            // n_partials of the call
-  int n_active;
-  int active[HH_MAX_PARTIALS];  // compact j -> original direction k
-  int src[HH_MAX_PARTIALS];     // original k -> compact j, or -1 when passive
-  double xdT[HH_MAX_PARTIALS];  // passive: ∂ log S_T / ∂θ_k
-  double dK[HH_MAX_PARTIALS];   // strike seed of direction k
+  int n_active;     // carried basis derivatives
+  int basis[kMaxBasis];                  // carried slot j -> parameter
+  double w[HH_MAX_PARTIALS][kMaxBasis];  // seed of direction k on the parameter of slot j
+  double xdT[HH_MAX_PARTIALS];           // passive part: ∂ log S_T / ∂θ_k from the spot and rate seeds
+  double dK[HH_MAX_PARTIALS];            // strike seed of direction k
 };
 
 __device__ __forceinline__ double sum_slot(const double* __restrict__ rec, uint32_t n, int slot,
@@ -574,8 +580,9 @@ __global__ __launch_bounds__(256) void reduce_records_kernel(const double* __res
   if (map.n > 0 && k >= 0 && k < HH_MAX_PARTIALS) {
     out = 0.0;
     if (k < map.n) {
-      if (map.src[k] >= 0) out = sum_slot(rec, n, HH_ACC_DSUM + map.src[k], sm);
-      else if (map.xdT[k] != 0.0) out = map.xdT[k] * sum_slot(rec, n, kRecItmS, sm);
+      for (int j = 0; j < map.n_active; ++j)
+        if (map.w[k][j] != 0.0) out = fma(map.w[k][j], sum_slot(rec, n, HH_ACC_DSUM + j, sm), out);
+      if (map.xdT[k] != 0.0) out = fma(map.xdT[k], sum_slot(rec, n, kRecItmS, sm), out);
       if (map.dK[k] != 0.0) out -= map.dK[k] * sum_slot(rec, n, kRecItmS + 1, sm);
     }
   } else if (map.sim && (slot == kRecItmS || slot == kRecItmS + 1)) {
@@ -658,36 +665,39 @@ static inline double seed_of(const double* p, uint32_t k, uint32_t n) {
   return (p && k < n) ? p[k] : 0.0;
 }
 
+static const double* basis_seeds(const hh_model& m, int b) {
+  return b == kBasisV0 ? m.dV0 : b == kBasisKappa ? m.dkappa : b == kBasisTheta ? m.dtheta : m.dsigma;
+}
+
 static PartialMap classify_partials(const hh_model& m, const hh_config& c) {
   PartialMap pm{};
-  const uint32_t np = c.n_partials;
+  const uint32_t np = c.n_partials < HH_MAX_PARTIALS ? c.n_partials : HH_MAX_PARTIALS;
   pm.n = (int)np;
   const bool euler = c.strategy == HH_EULER_MARUYAMA;
   const bool heston = c.dynamics == HH_HESTON;
   const double dt = m.T / (double)(c.n_steps ? c.n_steps : 1);
   const double sqT = sqrt(m.T), tmul = c.compat_sqrt_alpha ? sqT : m.T;
-  for (uint32_t k = 0; k < np && k < HH_MAX_PARTIALS; ++k) {
-    const double dsig = seed_of(m.dsigma, k, np);
-    bool act = dsig != 0.0;
-    if (heston && euler)
-      act = act || seed_of(m.dV0, k, np) != 0.0 || seed_of(m.dkappa, k, np) != 0.0 ||
-            seed_of(m.dtheta, k, np) != 0.0;
+  // parameters some requested direction differentiates along, among those the model reads
+  for (int b = 0; b < kMaxBasis; ++b) {
+    if (b != kBasisSigma && !(heston && euler)) continue;
+    bool used = false;
+    for (uint32_t k = 0; k < np; ++k) used = used || seed_of(basis_seeds(m, b), k, np) != 0.0;
+    if (used) pm.basis[pm.n_active++] = b;
+  }
+  for (uint32_t k = 0; k < np; ++k) {
+    for (int j = 0; j < pm.n_active; ++j) pm.w[k][j] = seed_of(basis_seeds(m, pm.basis[j]), k, np);
     pm.dK[k] = seed_of(m.dstrike, k, np);
-    if (act) {
-      pm.src[k] = pm.n_active;
-      pm.active[pm.n_active++] = (int)k;
-    } else {
-      pm.src[k] = -1;
-      // ∂x_T: x0' = dS0/S0, then M drift updates fma(dt, dr, ·) (Euler) or dr·tmul (exact law);
-      // the diffusion carries nothing in a passive direction
-      const double dr = seed_of(m.dr_drift, k, np);
-      double xd = seed_of(m.dS0, k, np) / m.S0;
-      if (euler)
+    // ∂x_T from the spot and rate seeds: x0' = dS0/S0, then M drift updates fma(dt, dr, ·) (Euler)
+    // or dr·tmul (exact law); the diffusion carries nothing along these
+    const double dr = seed_of(m.dr_drift, k, np);
+    double xd = seed_of(m.dS0, k, np) / m.S0;
+    if (euler) {
+      if (dr != 0.0)
         for (uint32_t s = 0; s < c.n_steps; ++s) xd = fma(dt, dr, xd);
-      else
-        xd = xd + dr * tmul;
-      pm.xdT[k] = xd;
+    } else {
+      xd = xd + dr * tmul;
     }
+    pm.xdT[k] = xd;
   }
   return pm;
 }
@@ -700,7 +710,6 @@ template <int P>
 static SimArgs<P> make_args(const hh_model& m, const hh_config& c, const DevicePtrs& p,
                             const PartialMap& pm) {
   SimArgs<P> a{};
-  const uint32_t np = c.n_partials;
   const double sig2h = 0.5 * m.sigma * m.sigma;
   a.x0.v = log(m.S0);
   a.v0.v = m.V0;
@@ -715,18 +724,15 @@ static SimArgs<P> make_args(const hh_model& m, const hh_config& c, const DeviceP
   const double tmul = c.compat_sqrt_alpha ? sqT : m.T;
   a.law_mu.v = a.x0.v + a.gdrift.v * tmul;
   a.law_sd.v = m.sigma * sqT;
-  for (int j = 0; j < P && j < pm.n_active; ++j) {  // active directions only, compacted
-    const uint32_t k = (uint32_t)pm.active[j];
-    const double dS0 = seed_of(m.dS0, k, np), dsig = seed_of(m.dsigma, k, np),
-                 dr = seed_of(m.dr_drift, k, np);
-    a.x0.d[j] = dS0 / m.S0;
-    a.v0.d[j] = seed_of(m.dV0, k, np);
-    a.kappa.d[j] = seed_of(m.dkappa, k, np);
-    a.theta.d[j] = seed_of(m.dtheta, k, np);
+  for (int j = 0; j < P && j < pm.n_active; ++j) {  // carried slot j: unit seed on its parameter
+    const int b = pm.basis[j];
+    const double dsig = b == kBasisSigma ? 1.0 : 0.0;
+    a.v0.d[j] = b == kBasisV0 ? 1.0 : 0.0;
+    a.kappa.d[j] = b == kBasisKappa ? 1.0 : 0.0;
+    a.theta.d[j] = b == kBasisTheta ? 1.0 : 0.0;
     a.sigma.d[j] = dsig;
-    a.r.d[j] = dr;
-    a.gdrift.d[j] = dr - m.sigma * dsig;
-    a.law_mu.d[j] = a.x0.d[j] + a.gdrift.d[j] * tmul;
+    a.gdrift.d[j] = -m.sigma * dsig;
+    a.law_mu.d[j] = a.gdrift.d[j] * tmul;
     a.law_sd.d[j] = dsig * sqT;
   }
   a.dt = m.T / (double)(c.n_steps ? c.n_steps : 1);  // montecarlo.jl:349
@@ -801,8 +807,9 @@ int launch_simulation(const hh_model& m, const hh_config& c, const DevicePtrs& p
   switch (pad_partials((uint32_t)pm.n_active)) {
     case 0: return launch_sim_p<0>(m, c, p, pm, s);
     case 1: return launch_sim_p<1>(m, c, p, pm, s);
+    case 2: return launch_sim_p<2>(m, c, p, pm, s);
     case 3: return launch_sim_p<3>(m, c, p, pm, s);
-    default: return launch_sim_p<8>(m, c, p, pm, s);
+    default: return launch_sim_p<4>(m, c, p, pm, s);
   }
 }
 
@@ -880,8 +887,9 @@ int launch_basket_payoffs(const BasketArgs& b, uint32_t n_payoffs, uint32_t n_ac
   switch (pad_partials(n_active_partials)) {
     case 0: hipLaunchKernelGGL(basket_payoff_kernel<0>, grid, block, 0, s, b); break;
     case 1: hipLaunchKernelGGL(basket_payoff_kernel<1>, grid, block, 0, s, b); break;
+    case 2: hipLaunchKernelGGL(basket_payoff_kernel<2>, grid, block, 0, s, b); break;
     case 3: hipLaunchKernelGGL(basket_payoff_kernel<3>, grid, block, 0, s, b); break;
-    default: hipLaunchKernelGGL(basket_payoff_kernel<8>, grid, block, 0, s, b); break;
+    default: hipLaunchKernelGGL(basket_payoff_kernel<4>, grid, block, 0, s, b); break;
   }
   return (int)hipGetLastError();
 }
