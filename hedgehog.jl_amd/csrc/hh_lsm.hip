@@ -23,7 +23,17 @@ namespace hh {
 
 namespace {
 
-constexpr int kLsmChunk = 1024;  // paths per workgroup (256 threads x 4)
+constexpr int kLsmChunk = 1024;  // paths per workgroup (256 threads x 4) of the one-off kernels
+// The backward-step kernels take Q paths per thread: 4, or 16 for large ensembles — every workgroup
+// re-reduces all workgroups' partial moment sums at the start of a step, n_chunks²·(D+1) reads per
+// exercise date, which at 2·10⁶ paths and 1024-path chunks is more traffic than the paths themselves
+#ifndef HH_LSM_WIDE_Q
+#define HH_LSM_WIDE_Q 8
+#endif
+constexpr uint64_t kLsmWideFrom = 1ull << 19;  // ensembles from this size on use Q = HH_LSM_WIDE_Q
+// paths per workgroup of the one-off row-statistics kernels (grid = chunks x rows): with 1024 the
+// workgroup reductions of the 3 / 2D+1 sums cost more than reading the paths
+inline uint32_t lsm_one_off_paths(uint64_t ntot) { return ntot >= kLsmWideFrom ? 8192u : 1024u; }
 constexpr int kLsmMaxDeg = 8;
 
 // ---- full path grid -----------------------------------------------------------------------
@@ -103,13 +113,13 @@ struct RowStat {
 
 __global__ __launch_bounds__(256) void lsm_stats_kernel(const double* __restrict__ grid,
                                                         uint64_t ntot, double strike, double cp,
-                                                        uint32_t n_chunks,
+                                                        uint32_t n_chunks, uint32_t per_wg,
                                                         double* __restrict__ rec /*[row][chunk][3]*/) {
   const uint32_t chunk = blockIdx.x, row = blockIdx.y;
   const double* S = grid + (size_t)row * ntot;
   double v[3] = {0, 0, 0};
-  for (int j = 0; j < kLsmChunk / 256; ++j) {
-    const uint64_t p = (uint64_t)chunk * kLsmChunk + j * 256 + threadIdx.x;
+  for (uint32_t j = 0; j < per_wg / 256; ++j) {
+    const uint64_t p = (uint64_t)chunk * per_wg + j * 256 + threadIdx.x;
     if (p < ntot) {
       const double x = S[p];
       if (cp * (x - strike) > 0.0) {
@@ -147,6 +157,7 @@ __global__ __launch_bounds__(256) void lsm_rowstat_kernel(const double* __restri
 template <int D>
 __global__ __launch_bounds__(256) void lsm_pow_kernel(const double* __restrict__ grid, uint64_t ntot,
                                                       double strike, double cp, uint32_t n_chunks,
+                                                      uint32_t per_wg,
                                                       const RowStat* __restrict__ rs,
                                                       double* __restrict__ rec /*[row][chunk][2D+1]*/) {
   constexpr int NV = 2 * D + 1;
@@ -156,8 +167,8 @@ __global__ __launch_bounds__(256) void lsm_pow_kernel(const double* __restrict__
   double v[NV];
 #pragma unroll
   for (int i = 0; i < NV; ++i) v[i] = 0.0;
-  for (int j = 0; j < kLsmChunk / 256; ++j) {
-    const uint64_t p = (uint64_t)chunk * kLsmChunk + j * 256 + threadIdx.x;
+  for (uint32_t j = 0; j < per_wg / 256; ++j) {
+    const uint64_t p = (uint64_t)chunk * per_wg + j * 256 + threadIdx.x;
     if (p < ntot) {
       const double x = S[p];
       if (cp * (x - strike) > 0.0) {
@@ -200,33 +211,39 @@ struct LsmStepArgs {
   const double* grid;
   uint64_t ntot;
   double strike, cp, ln_disc;  // ln of the per-step discount factor
-  uint32_t n_steps, n_chunks;
+  uint32_t n_steps, n_chunks;  // n_chunks: workgroups of the step kernels (256·Q paths each)
   int32_t* tau;
   double* val;
   const RowStat* rs;
   const double* P;   // [row][2D+1]
   double* recB;      // [row][chunk][D+1]: partial Σ z^k y of the row
+  const double* disc_pow;  // [k] = exp(ln_disc·k), k = 0..n_steps: discount over k exercise dates
   double* counters;  // [0] rows regressed, [1] rows skipped (no in-the-money path)
 };
 
+// discount^k for every k the induction can ask for: one table instead of an exp() per path and date
+__global__ __launch_bounds__(256) void lsm_disc_kernel(double ln_disc, uint32_t n, double* out) {
+  const uint32_t k = blockIdx.x * 256 + threadIdx.x;
+  if (k <= n) out[k] = exp(ln_disc * (double)k);
+}
+
 // contribution of this workgroup's paths to Σ z^k y of `row`, y = D^(tau - row) val
 // (least_squares_montecarlo.jl:115-116), written to recB[row][chunk]
-template <int D>
-__device__ __forceinline__ void emit_moments(const LsmStepArgs& a, uint32_t row, const int (&tau)[4],
-                                             const double (&val)[4]) {
-  const double* S = a.grid + (size_t)row * a.ntot;
+template <int D, int Q>
+__device__ __forceinline__ void emit_moments(const LsmStepArgs& a, uint32_t row, const int (&tau)[Q],
+                                             const double (&val)[Q], const double (&xrow)[Q]) {
   const RowStat r = a.rs[row];
   double v[D + 1];
 #pragma unroll
   for (int i = 0; i <= D; ++i) v[i] = 0.0;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const uint64_t p = (uint64_t)blockIdx.x * kLsmChunk + j * 256 + threadIdx.x;
+  for (int j = 0; j < Q; ++j) {
+    const uint64_t p = (uint64_t)blockIdx.x * (256 * Q) + j * 256 + threadIdx.x;
     if (p < a.ntot) {
-      const double x = S[p];
+      const double x = xrow[j];  // S[row][p], loaded by the caller
       if (a.cp * (x - a.strike) > 0.0) {
         const double z = (x - r.mu) / r.sd;
-        const double y = exp(a.ln_disc * (double)(tau[j] - (int)row)) * val[j];
+        const double y = a.disc_pow[tau[j] - (int)row] * val[j];  // tau >= row + 1
         double pw = y;
 #pragma unroll
         for (int i = 0; i <= D; ++i) {
@@ -246,33 +263,53 @@ __device__ __forceinline__ void emit_moments(const LsmStepArgs& a, uint32_t row,
 }
 
 // stopping_info = [(nsteps, payoff(S_T))] (:109), and the moment sums of row nsteps-1
-template <int D>
+template <int D, int Q>
 __global__ __launch_bounds__(256) void lsm_init_kernel(const LsmStepArgs a) {
   const double* S = a.grid + (size_t)a.n_steps * a.ntot;
-  int tau[4];
-  double val[4];
+  const double* Sn = a.grid + (size_t)(a.n_steps >= 2 ? a.n_steps - 1 : a.n_steps) * a.ntot;
+  int tau[Q];
+  double val[Q], xn[Q];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const uint64_t p = (uint64_t)blockIdx.x * kLsmChunk + j * 256 + threadIdx.x;
+  for (int j = 0; j < Q; ++j) {
+    const uint64_t p = (uint64_t)blockIdx.x * (256 * Q) + j * 256 + threadIdx.x;
     tau[j] = (int)a.n_steps;
-    val[j] = 0.0;
+    val[j] = xn[j] = 0.0;
     if (p < a.ntot) {
+      xn[j] = Sn[p];
       const double m = a.cp * (S[p] - a.strike);
       val[j] = m > 0.0 ? m : 0.0;
       a.tau[p] = tau[j];
       a.val[p] = val[j];
     }
   }
-  if (a.n_steps >= 2) emit_moments<D>(a, a.n_steps - 1, tau, val);
+  if (a.n_steps >= 2) emit_moments<D, Q>(a, a.n_steps - 1, tau, val, xn);
 }
 
 // one backward step at time index t (the reference's loop body for i = t+1, :112-131)
-template <int D>
+template <int D, int Q>
 __global__ __launch_bounds__(256) void lsm_step_kernel(const LsmStepArgs a, uint32_t t) {
   constexpr int N = D + 1;
   const RowStat r = a.rs[t];
   __shared__ double coef[N];
   __shared__ int have_fit;
+  // this workgroup's paths first: the loads are in flight while the moment sums are reduced and the
+  // normal equations solved (a serial prologue of several microseconds in every workgroup)
+  const double* S = a.grid + (size_t)t * a.ntot;
+  const double* Sn = a.grid + (size_t)(t >= 2 ? t - 1 : t) * a.ntot;  // row of the next step
+  int tau[Q];
+  double val[Q], xs[Q], xn[Q];
+#pragma unroll
+  for (int j = 0; j < Q; ++j) {
+    const uint64_t p = (uint64_t)blockIdx.x * (256 * Q) + j * 256 + threadIdx.x;
+    tau[j] = 0;
+    val[j] = xs[j] = xn[j] = 0.0;
+    if (p < a.ntot) {
+      tau[j] = a.tau[p];
+      val[j] = a.val[p];
+      xs[j] = S[p];
+      xn[j] = Sn[p];
+    }
+  }
   double B[N];
   reduce_records<N>(a.recB + (size_t)t * a.n_chunks * N, a.n_chunks, B);
   if (threadIdx.x == 0) {
@@ -342,18 +379,11 @@ __global__ __launch_bounds__(256) void lsm_step_kernel(const LsmStepArgs a, uint
   }
   __syncthreads();
 
-  const double* S = a.grid + (size_t)t * a.ntot;
-  int tau[4];
-  double val[4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const uint64_t p = (uint64_t)blockIdx.x * kLsmChunk + j * 256 + threadIdx.x;
-    tau[j] = 0;
-    val[j] = 0.0;
+  for (int j = 0; j < Q; ++j) {
+    const uint64_t p = (uint64_t)blockIdx.x * (256 * Q) + j * 256 + threadIdx.x;
     if (p < a.ntot) {
-      tau[j] = a.tau[p];
-      val[j] = a.val[p];
-      const double x = S[p];
+      const double x = xs[j];
       const double pay = a.cp * (x - a.strike);
       if (have_fit && pay > 0.0) {
         const double z = (x - r.mu) / r.sd;
@@ -369,7 +399,7 @@ __global__ __launch_bounds__(256) void lsm_step_kernel(const LsmStepArgs a, uint
       }
     }
   }
-  if (t >= 2) emit_moments<D>(a, t - 1, tau, val);
+  if (t >= 2) emit_moments<D, Q>(a, t - 1, tau, val, xn);
 }
 
 // discounted_values = discount^t * val (:133): per-workgroup Σ and Σ² into 16-double records
@@ -396,17 +426,30 @@ __global__ __launch_bounds__(256) void lsm_final_kernel(const int32_t* __restric
   }
 }
 
-template <int D>
-int run_lsm(const LsmStepArgs& a, double* rec_pow, hipStream_t s) {
+template <int D, int Q>
+void run_lsm_steps(const LsmStepArgs& a, hipStream_t s) {
   const dim3 b(256);
-  const uint32_t rows = a.n_steps + 1;
-  hipLaunchKernelGGL(lsm_pow_kernel<D>, dim3(a.n_chunks, rows), b, 0, s, a.grid, a.ntot, a.strike,
-                     a.cp, a.n_chunks, a.rs, rec_pow);
-  hipLaunchKernelGGL(lsm_powsum_kernel<D>, dim3(rows), b, 0, s, rec_pow, a.n_chunks,
-                     const_cast<double*>(a.P));
-  hipLaunchKernelGGL(lsm_init_kernel<D>, dim3(a.n_chunks), b, 0, s, a);
+  hipLaunchKernelGGL((lsm_init_kernel<D, Q>), dim3(a.n_chunks), b, 0, s, a);
   for (uint32_t t = a.n_steps - 1; t >= 1; --t)  // for i = nsteps:-1:2, t = i-1 (:112-113)
-    hipLaunchKernelGGL(lsm_step_kernel<D>, dim3(a.n_chunks), b, 0, s, a, t);
+    hipLaunchKernelGGL((lsm_step_kernel<D, Q>), dim3(a.n_chunks), b, 0, s, a, t);
+}
+
+template <int D>
+int run_lsm(LsmStepArgs a, double* rec_pow, hipStream_t s) {
+  const dim3 b(256);
+  const uint32_t rows = a.n_steps + 1, per_wg = lsm_one_off_paths(a.ntot);
+  const uint32_t ch = (uint32_t)((a.ntot + per_wg - 1) / per_wg);
+  hipLaunchKernelGGL(lsm_pow_kernel<D>, dim3(ch, rows), b, 0, s, a.grid, a.ntot, a.strike, a.cp, ch,
+                     per_wg, a.rs, rec_pow);
+  hipLaunchKernelGGL(lsm_powsum_kernel<D>, dim3(rows), b, 0, s, rec_pow, ch,
+                     const_cast<double*>(a.P));
+  if (a.ntot >= kLsmWideFrom) {
+    a.n_chunks = (uint32_t)((a.ntot + 256 * HH_LSM_WIDE_Q - 1) / (256 * HH_LSM_WIDE_Q));
+    run_lsm_steps<D, HH_LSM_WIDE_Q>(a, s);
+  } else {
+    a.n_chunks = lsm_chunks(a.ntot);
+    run_lsm_steps<D, 4>(a, s);
+  }
   return (int)hipGetLastError();
 }
 
@@ -419,8 +462,8 @@ size_t lsm_scratch_doubles(uint64_t ntot, uint32_t n_steps, int degree) {
   const size_t rows = (size_t)n_steps + 1, ch = lsm_chunks(ntot);
   const size_t nv = 2 * (size_t)degree + 1;
   // rec_stats [rows][ch][3] | rowstat [rows][3] | rec_pow [rows][ch][nv] | P [rows][nv] |
-  // recB [rows][ch][degree+1] | counters [2]
-  return rows * ch * 3 + rows * 3 + rows * ch * nv + rows * nv + rows * ch * (degree + 1) + 2;
+  // recB [rows][ch][degree+1] | disc_pow [rows] | counters [2]
+  return rows * ch * 3 + rows * 3 + rows * ch * nv + rows * nv + rows * ch * (degree + 1) + rows + 2;
 }
 
 int launch_gbm_grid(const uint64_t* seeds_dev, uint64_t n_paths, uint32_t n_steps, double S0,
@@ -450,19 +493,24 @@ int launch_lsm(const double* grid, uint64_t ntot, uint32_t n_steps, double strik
   double* rec_pow = reinterpret_cast<double*>(rs) + rows * 3;
   double* P = rec_pow + rows * ch * nv;
   double* recB = P + rows * nv;
-  double* counters = recB + rows * ch * (degree + 1);
+  double* disc_pow = recB + rows * ch * (degree + 1);
+  double* counters = disc_pow + rows;
 
   hipError_t e = hipMemsetAsync(counters, 0, 2 * sizeof(double), s);
   if (e != hipSuccess) return (int)e;
   const dim3 b(256);
-  hipLaunchKernelGGL(lsm_stats_kernel, dim3((unsigned)ch, (unsigned)rows), b, 0, s, grid, ntot,
-                     strike, cp, (uint32_t)ch, rec_stats);
-  hipLaunchKernelGGL(lsm_rowstat_kernel, dim3((unsigned)rows), b, 0, s, rec_stats, (uint32_t)ch, rs);
+  const uint32_t per_wg = lsm_one_off_paths(ntot);
+  const uint32_t ch1 = (uint32_t)((ntot + per_wg - 1) / per_wg);
+  hipLaunchKernelGGL(lsm_stats_kernel, dim3(ch1, (unsigned)rows), b, 0, s, grid, ntot, strike, cp, ch1,
+                     per_wg, rec_stats);
+  hipLaunchKernelGGL(lsm_rowstat_kernel, dim3((unsigned)rows), b, 0, s, rec_stats, ch1, rs);
 
   LsmStepArgs a{};
   a.grid = grid; a.ntot = ntot; a.strike = strike; a.cp = cp; a.ln_disc = log(step_discount);
   a.n_steps = n_steps; a.n_chunks = (uint32_t)ch; a.tau = tau; a.val = val; a.rs = rs; a.P = P;
-  a.recB = recB; a.counters = counters;
+  a.recB = recB; a.disc_pow = disc_pow; a.counters = counters;
+  hipLaunchKernelGGL(lsm_disc_kernel, dim3((unsigned)((rows + 255) / 256)), b, 0, s, a.ln_disc, n_steps,
+                     disc_pow);
   int rc = 0;
   switch (degree) {
     case 1: rc = run_lsm<1>(a, rec_pow, s); break;
