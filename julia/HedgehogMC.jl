@@ -76,11 +76,14 @@ _npartials(x) = x isa ForwardDiff.Dual ? ForwardDiff.npartials(x) : 0
 _partials(x, P) = x isa ForwardDiff.Dual ? collect(Float64, ForwardDiff.partials(x)) : zeros(P)
 _dualtype(xs...) = (i = findfirst(x -> x isa ForwardDiff.Dual, xs); i === nothing ? nothing : typeof(xs[i]))
 
-# ---- solve(prob, ::MonteCarlo) on the GPU (montecarlo.jl:478-493) -------------------------------
-function solve_hip(prob::PricingProblem{VanillaOption{TS,TE,European,C,Spot},I},
-                   method::MonteCarlo; ensemble::Bool = true,
-                   em_split::Bool = true, compat_sqrt_alpha::Bool = false) where {TS,TE,C,I}
-    m, payoff, cfg = prob.market_inputs, prob.payoff, method.config
+# ---- packing shared by the single-payoff and the basket solve --------------------------------------
+"""
+Resolve dates / curves exactly as the reference does (montecarlo.jl:173-201, 299-318, 489) and return
+everything `hh_model` / `hh_config` need: plain values, the dual seed vectors (kept alive by the
+caller) and the Dual type to rebuild prices with.
+"""
+function _resolve(payoff, m, method::MonteCarlo)
+    cfg = method.config
     dyn, strat = method.dynamics, method.strategy
     euler = strat isa EulerMaruyama
     if dyn isa LognormalDynamics && m isa BlackScholesInputs && (euler || strat isa BlackScholesExact)
@@ -90,7 +93,7 @@ function solve_hip(prob::PricingProblem{VanillaOption{TS,TE,European,C,Spot},I},
         dynamics, strategy = 1, euler ? 0 : 2
         sigma, V0, kappa, theta, rho = m.σ, m.V0, m.κ, m.θ, m.ρ
     else
-        throw(MethodError(Hedgehog.solve, (prob, method)))
+        return nothing                                           # no method: MethodError at the caller
     end
     if euler
         T = yearfrac(m.referenceDate, payoff.expiry)           # montecarlo.jl:173,197
@@ -100,28 +103,45 @@ function solve_hip(prob::PricingProblem{VanillaOption{TS,TE,European,C,Spot},I},
         r_drift = zero_rate(m.rate, payoff.expiry)             # montecarlo.jl:299,318
     end
     discount = df(m.rate, payoff.expiry)                        # montecarlo.jl:489
-
     scal = (m.spot, V0, kappa, theta, sigma, r_drift, discount, payoff.strike)
     P = maximum(_npartials, scal)
     P <= HH_MAX_PARTIALS || error("at most $HH_MAX_PARTIALS partials per solve")
     seedvecs = [_partials(x, P) for x in scal]
-    ptr(i) = (P == 0 || all(iszero, seedvecs[i])) ? Ptr{Cdouble}(C_NULL) : pointer(seedvecs[i])
-
     seeds = convert(Vector{UInt64}, cfg.seeds .% UInt64)
     anti = cfg.variance_reduction isa Antithetic
-    n = Int(cfg.trajectories)
-    terminal = ensemble ? Vector{Float64}(undef, anti ? 2n : n) : Float64[]
+    return (; dynamics, strategy, scal, rho = Float64(rho), T = Float64(T), P, seedvecs, seeds, anti,
+            n = Int(cfg.trajectories), steps = Int(cfg.steps), cp = payoff.call_put(),
+            DT = _dualtype(scal...))
+end
+
+# hh_model / hh_config from a resolved problem; the caller holds r.seedvecs and r.seeds in GC.@preserve
+function _structs(r; em_split::Bool = true, compat_sqrt_alpha::Bool = false)
+    ptr(i) = (r.P == 0 || all(iszero, r.seedvecs[i])) ? Ptr{Cdouble}(C_NULL) : pointer(r.seedvecs[i])
+    v = map(_val, r.scal)
+    model = HHModel(v[1], v[2], v[3], v[4], v[5], r.rho, v[6], v[7], r.T, v[8], r.cp,
+                    ptr(1), ptr(2), ptr(3), ptr(4), ptr(5), ptr(6), ptr(7), ptr(8))
+    config = HHConfig(r.dynamics, r.strategy, r.anti, em_split, compat_sqrt_alpha,
+                      0, 0, 0, 0, 0, UInt32(r.steps), UInt32(r.P), UInt64(r.n), UInt64(0),
+                      pointer(r.seeds), Ptr{Cdouble}(C_NULL), 0.0, 0.0, 0.0, 0.0, 0, 0,
+                      UInt64(length(r.seeds)), UInt64(0))
+    return model, config
+end
+
+_price(r, res::HHResult) = r.DT === nothing ? res.price :
+    r.DT(res.price, ForwardDiff.Partials(ntuple(k -> res.dprice[k], r.P)))   # same tag as the input Dual
+
+# ---- solve(prob, ::MonteCarlo) on the GPU (montecarlo.jl:478-493) -------------------------------
+function solve_hip(prob::PricingProblem{VanillaOption{TS,TE,European,C,Spot},I},
+                   method::MonteCarlo; ensemble::Bool = true,
+                   em_split::Bool = true, compat_sqrt_alpha::Bool = false) where {TS,TE,C,I}
+    r = _resolve(prob.payoff, prob.market_inputs, method)
+    r === nothing && throw(MethodError(Hedgehog.solve, (prob, method)))
+    terminal = ensemble ? Vector{Float64}(undef, r.anti ? 2r.n : r.n) : Float64[]
     res = Ref{HHResult}()
     ctx = context()
+    seedvecs, seeds = r.seedvecs, r.seeds
     GC.@preserve seedvecs seeds terminal begin
-        model = HHModel(_val(m.spot), _val(V0), _val(kappa), _val(theta), _val(sigma), Float64(rho),
-                        _val(r_drift), _val(discount), Float64(T), _val(payoff.strike),
-                        payoff.call_put(),
-                        ptr(1), ptr(2), ptr(3), ptr(4), ptr(5), ptr(6), ptr(7), ptr(8))
-        config = HHConfig(dynamics, strategy, anti, em_split, compat_sqrt_alpha,
-                          0, 0, 0, 0, 0, UInt32(cfg.steps), UInt32(P), UInt64(n), UInt64(0),
-                          pointer(seeds), Ptr{Cdouble}(C_NULL), 0.0, 0.0, 0.0, 0.0, 0, 0,
-                          UInt64(length(seeds)), UInt64(0))
+        model, config = _structs(r; em_split, compat_sqrt_alpha)
         rc = ccall((:hh_mc_solve, LIB[]), Cint,
                    (Ptr{Cvoid}, Ref{HHModel}, Ref{HHConfig}, Ref{HHResult}, Ptr{Cdouble}),
                    ctx.handle, model, config, res,
@@ -129,21 +149,17 @@ function solve_hip(prob::PricingProblem{VanillaOption{TS,TE,European,C,Spot},I},
         rc == -2 && throw(MethodError(Hedgehog.solve, (prob, method)))
         rc == 0 || error("hh_mc_solve failed ($rc): $(last_error(ctx))")
     end
-    r = res[]
-    DT = _dualtype(scal...)
-    price = DT === nothing ? r.price :
-        DT(r.price, ForwardDiff.Partials(ntuple(k -> r.dprice[k], P)))   # same tag as the input Dual
-    ens = !ensemble ? nothing : anti ? (terminal[1:n], terminal[n+1:2n]) : terminal
-    return MonteCarloSolution(prob, method, price, ens)                  # pricing_solutions.jl:22-27
+    ens = !ensemble ? nothing : r.anti ? (terminal[1:r.n], terminal[r.n+1:2r.n]) : terminal
+    return MonteCarloSolution(prob, method, _price(r, res[]), ens)       # pricing_solutions.jl:22-27
 end
 
 # ---- same-expiry baskets (src/calibration/basket.jl:35-38) ---------------------------------------
 """
     solve_basket_hip(prob::BasketPricingProblem, method::MonteCarlo)
 
-One simulation per expiry group, every strike of the group reduced on the same terminal samples
-(`hh_mc_solve_basket`).  Equal to the reference's independent per-payoff solves because the seeds in
-`method.config` are fixed.
+One simulation per expiry group, every (strike, call/put) of the group reduced on the same terminal
+samples (`hh_mc_solve_basket`).  Equal to the reference's independent per-payoff solves because the
+seeds in `method.config` are fixed.  Strike partials are not carried through a basket.
 """
 function solve_basket_hip(prob::Hedgehog.BasketPricingProblem, method::MonteCarlo)
     sols = Vector{Any}(undef, length(prob.payoffs))
@@ -151,18 +167,27 @@ function solve_basket_hip(prob::Hedgehog.BasketPricingProblem, method::MonteCarl
     for (i, p) in enumerate(prob.payoffs)
         push!(get!(groups, p.expiry, Int[]), i)
     end
+    ctx = context()
     for idx in values(groups)
-        # (model/config packing as in solve_hip, from the first payoff of the group)
-        strikes = Float64[prob.payoffs[i].strike for i in idx]
+        first_payoff = prob.payoffs[idx[1]]
+        r = _resolve(first_payoff, prob.market_inputs, method)
+        r === nothing && throw(MethodError(Hedgehog.solve, (prob, method)))
+        strikes = Float64[_val(prob.payoffs[i].strike) for i in idx]
         cps = Float64[prob.payoffs[i].call_put() for i in idx]
         res = Vector{HHResult}(undef, length(idx))
-        # ccall((:hh_mc_solve_basket, LIB[]), Cint,
-        #       (Ptr{Cvoid}, Ref{HHModel}, Ref{HHConfig}, Ptr{Cdouble}, Ptr{Cdouble}, UInt32,
-        #        Ptr{HHResult}, Ptr{Cdouble}),
-        #       ctx.handle, model, config, strikes, cps, length(idx), res, C_NULL)
+        seedvecs, seeds = r.seedvecs, r.seeds
+        GC.@preserve seedvecs seeds strikes cps res begin
+            model, config = _structs(r)
+            rc = ccall((:hh_mc_solve_basket, LIB[]), Cint,
+                       (Ptr{Cvoid}, Ref{HHModel}, Ref{HHConfig}, Ptr{Cdouble}, Ptr{Cdouble}, UInt32,
+                        Ptr{HHResult}, Ptr{Cdouble}),
+                       ctx.handle, model, config, pointer(strikes), pointer(cps), UInt32(length(idx)),
+                       pointer(res), Ptr{Cdouble}(C_NULL))
+            rc == 0 || error("hh_mc_solve_basket failed ($rc): $(last_error(ctx))")
+        end
         for (k, i) in enumerate(idx)
-            sols[i] = solve_hip(PricingProblem(prob.payoffs[i], prob.market_inputs), method;
-                                ensemble = false)   # placeholder until the packing above is factored out
+            sols[i] = MonteCarloSolution(PricingProblem(prob.payoffs[i], prob.market_inputs), method,
+                                         _price(r, res[k]), nothing)
         end
     end
     return Hedgehog.BasketPricingSolution(prob, sols)
