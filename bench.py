@@ -157,9 +157,13 @@ def main():
     dt_gen, kern_gen = timed(cfg_gen, args.steps, args.warmup)
     acc_gen = accum.cpu().numpy().copy()
 
+    # every collective of the run is behind us: all ranks leave the process group together, here;
+    # rank 0 then measures the single-GPU extras (other configs, CPU baseline) on its own
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+        dist = None
     if rank != 0:
-        if dist is not None:
-            dist.destroy_process_group()
         return
 
     total_path_steps = float(world) * n_paths * n_steps
@@ -286,9 +290,7 @@ def main():
             "kind": "port",
             "sample": "%d x (%d paths x %d steps, REPLAY of the same increments), %.1f s, "
                       "oracle/hh_oracle.c with OpenMP over paths" % (reps, ns, n_steps, el)}
-    print(json.dumps(out))
-    if dist is not None:
-        dist.destroy_process_group()
+    print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
