@@ -30,7 +30,7 @@ constexpr double kSeriesR = 13.0;  // |z| below which the power series is used f
 
 struct BkArgs {
   // model
-  double kappa, theta, sigma, sigma2, rho, V0, T, logS0, r, strike, cp;
+  double kappa, theta, sigma, sigma2, inv_sigma2, rho, V0, T, logS0, r, strike, cp;
   // sample_V_T constants (heston.jl:128-130); λ = lam_num·V0 / lam_den
   double d, lam_num, lam_den, cscale;
   // HestonCFIterator constants (heston.jl:167-172)
@@ -207,10 +207,11 @@ __device__ cx evaluate_chf(const BkArgs& p, const CfIter& it, double a, double& 
   const cx e = eh * eh;                                          // exp(-γT)
   const cx ome = {1.0 - e.re, -e.im};
   const cx ope = {1.0 + e.re, e.im};
-  const cx zeta_g = cdiv(ome, g);
-  const cx eta_g = cdiv(g * ope, ome);
-  cx nu_g = cdiv((it.sqrtV0VT * 4.0) * (g * eh), ome);
-  nu_g = {nu_g.re / p.sigma2, nu_g.im / p.sigma2};
+  // ζ_γ = (1−e)/γ, η_γ = γ(1+e)/(1−e), ν_γ = 4√(V0 VT) γ e^{−γT/2} / (σ²(1−e))  (heston.jl:188-196):
+  // all three divide by 1−e, and ζ_γ only enters as ζ_κ/ζ_γ = ζ_κ γ/(1−e) — one complex reciprocal
+  const cx g_over_ome = g * cdiv({1.0, 0.0}, ome);
+  const cx eta_g = g_over_ome * ope;
+  const cx nu_g = (it.sqrtV0VT * 4.0 * p.inv_sigma2) * (g_over_ome * eh);
   // continuous unwrapping of arg(ν_γ) (heston.jl:198-205)
   const double th = fm::atan2(nu_g.im, nu_g.re);
   double thu;
@@ -227,7 +228,7 @@ __device__ cx evaluate_chf(const BkArgs& p, const CfIter& it, double a, double& 
   // ϕ = e^{-(γ-κ)T/2} (ζκ/ζγ) · exp((V0+VT)/σ² (ηκ-ηγ)) · Iγ / Iκ
   const cx ex = {-0.5 * (g.re - p.kappa) * p.T + it.sumV * (p.eta_k - eta_g.re) + I.lg.re - it.logI_k,
                  -0.5 * g.im * p.T - it.sumV * eta_g.im + I.lg.im};
-  return (cexp(ex) * I.mul) * cdiv({p.zeta_k, 0.0}, zeta_g);
+  return (cexp(ex) * I.mul) * (p.zeta_k * g_over_ome);
 }
 
 // The series terms ϕ(h·j) of cdf_from_cf do not depend on x: the reference re-evaluates them in
@@ -685,7 +686,7 @@ int launch_bk(const hh_model& m, const hh_config& c, const DevicePtrs& ptr, hipS
     a.out_spot = tr->out_spot; a.out_var = tr->out_var;
     a.step = tr->step;
   }
-  a.kappa = m.kappa; a.theta = m.theta; a.sigma = m.sigma; a.sigma2 = m.sigma * m.sigma;
+  a.kappa = m.kappa; a.theta = m.theta; a.sigma = m.sigma; a.sigma2 = m.sigma * m.sigma; a.inv_sigma2 = 1.0 / a.sigma2;
   a.rho = m.rho; a.V0 = m.V0; a.T = m.T; a.logS0 = log(m.S0); a.r = m.r_drift;
   a.strike = m.strike; a.cp = m.cp;
   const double em1 = -expm1(-m.kappa * m.T);  // 1 − e^{−κT}
