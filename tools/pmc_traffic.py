@@ -15,7 +15,7 @@ import json
 import os
 import sys
 
-KERNEL = "euler_kernel<hh::HestonModel<0, true>, 0, true, false, 2>"
+KERNEL = "euler_kernel<hh::HestonModel<0, true>, 0, true, false, 2, 4, false>"  # price-only REPLAY, drain ring
 
 
 def per_kernel(path, counter):
