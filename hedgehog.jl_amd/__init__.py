@@ -22,7 +22,7 @@ from .montecarlo import (AbstractPricingMethod, Antithetic, BlackScholesExact, E
 from .distributed import shard_range, solve_sharded
 from .domain import (American, BlackScholesInputs, Call, European, FlatRateCurve, FlatVolSurface,
                     Forward, HestonInputs, MonteCarloSolution, PricingProblem, Put, RateCurve, Spot,
-                    VanillaOption, df, get_vol, spine_zeros, zero_rate)
+                    VanillaOption, df, df_yf, get_vol, spine_zeros, zero_rate, zero_rate_yf)
 
 
 def solve(*args, **kw):

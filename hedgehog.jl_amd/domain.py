@@ -143,6 +143,16 @@ def df(curve, t):
     return dexp(-zero_rate(curve, ticks) * yearfrac(curve.reference_date, ticks))
 
 
+def zero_rate_yf(curve, yf):
+    """rate_curve.jl:207-208: zero rate at a year fraction."""
+    return curve.rate if isinstance(curve, FlatRateCurve) else curve.interpolate(yf)
+
+
+def df_yf(curve, yf):
+    """rate_curve.jl:171-172."""
+    return dexp(-zero_rate_yf(curve, yf) * yf)
+
+
 @dataclass(frozen=True)
 class FlatVolSurface:
     """vol_surface.jl:73-81."""

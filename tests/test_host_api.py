@@ -1,5 +1,6 @@
 """Host mirror of the reference's operator interface — everything that needs no GPU."""
 import ctypes as C
+import math
 import os
 import re
 
@@ -205,3 +206,32 @@ def test_interpolated_rate_curve_scalars_and_spine_lens():
                                                         cfg))
     assert m.r_drift == curve.zeros[0] and not m.dr_drift          # Q4: drift from the first node
     assert m.ddiscount[0] == pytest.approx(-T * w3 * math.exp(-zT * T))
+
+
+def test_rate_curve_against_the_reference_test_vectors():
+    """test/unit/rate_curve.jl: the spine (tenors, discount factors) and the flat-curve checks of
+    the reference's own test, held as data in tests/golden/reference_known_answers.json — the host
+    mirror resolves `discount` and `r_drift` from these curves before every solve."""
+    import json
+    import os
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden",
+                                    "reference_known_answers.json")))["rate_curve"]
+    ref = hh.Date(*g["reference_date"])
+    curve = hh.RateCurve(ref, g["tenors"], g["dfs"])
+    for t, d in zip(g["tenors"], g["dfs"]):
+        assert hh.df_yf(curve, t) == pytest.approx(d, abs=g["atol"])                       # :26-28
+        assert hh.zero_rate_yf(curve, t) == pytest.approx(-math.log(d) / t, abs=g["atol"])  # :31-33
+    # constant extrapolation and linear interpolation in the zero rate (the interp of the test)
+    zs = [-math.log(d) / t for d, t in zip(g["dfs"], g["tenors"])]
+    assert hh.zero_rate_yf(curve, 0.01) == zs[0] and hh.zero_rate_yf(curve, 30.0) == zs[-1]
+    assert hh.zero_rate_yf(curve, 0.75) == pytest.approx(0.5 * (zs[1] + zs[2]), abs=1e-15)
+    r = g["flat_rate"]
+    flat = hh.FlatRateCurve(r)
+    for t in g["flat_yearfracs"] + g["flat_vector_yearfracs"]:
+        assert hh.zero_rate_yf(flat, t) == r                                               # :41-42, 51
+        assert hh.df_yf(flat, t) == pytest.approx(math.exp(-r * t), abs=g["atol"])
+    t0, t1 = hh.Date(*g["flat_date_from"]), hh.Date(*g["flat_date_to"])
+    flat = hh.FlatRateCurve(r, reference_date=t0)
+    tau = 365 / 365
+    assert hh.zero_rate(flat, t1) == pytest.approx(r, abs=g["atol"])                       # :61
+    assert hh.df(flat, t1) == pytest.approx(math.exp(-r * tau), abs=g["atol"])              # :62
