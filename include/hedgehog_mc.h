@@ -75,6 +75,9 @@ typedef struct hh_ctx hh_ctx; /* opaque: device, stream, scratch */
  * Lognormal: sigma is the flat vol; V0, kappa, theta, rho are ignored.
  * d* are the dual-number seeds: each is NULL or points to n_partials doubles, direction k of
  * parameter θ being dθ[k].  (Spot enters as x0 = log S0, the library applies dx0 = dS0/S0.)
+ * Cost: the library carries per trajectory one derivative per PARAMETER with a non-zero seed among
+ * V0, kappa, theta, sigma (at most 4, whatever n_partials is) and assembles the n_partials
+ * directions from them; seeds on S0, r_drift, discount and strike cost nothing per trajectory.
  */
 typedef struct hh_model {
   double S0, V0, kappa, theta, sigma, rho;
@@ -96,7 +99,7 @@ typedef struct hh_config {
   int32_t terminal_on_device;
   uint32_t n_steps;          /* SimulationConfig.steps (montecarlo.jl:60); exact laws ignore it   */
   uint32_t n_partials;       /* 0..HH_MAX_PARTIALS                                                */
-  uint64_t n_paths;          /* SimulationConfig.trajectories of THIS shard                       */
+  uint64_t n_paths;          /* SimulationConfig.trajectories of THIS shard (1 .. 2^38)           */
   uint64_t path_offset;      /* global index of this shard's first trajectory (exact laws draw by
                                 global index from ONE key, montecarlo.jl:456, so results do not
                                 depend on the sharding)                                           */
