@@ -9,6 +9,7 @@ import ctypes as C
 import os
 
 HH_MAX_PARTIALS = 8
+HH_LSM_PHASE_POW, HH_LSM_PHASE_INIT, HH_LSM_PHASE_STEP = 1, 2, 3
 HH_TILE_PATHS = 256
 HH_ACC_LEN = 16
 HH_ACC_SUM, HH_ACC_SUMSQ, HH_ACC_DSUM, HH_ACC_NPATHS = 0, 1, 2, 10
@@ -93,6 +94,11 @@ SYMBOLS = [
     ("hh_lsm_solve", C.c_int, [_vp, C.POINTER(hh_model), C.POINTER(hh_config), C.c_int32, C.c_double, C.POINTER(hh_lsm_result), _vp, _vp, _vp]),
     ("hh_lsm_solve_grid", C.c_int, [_vp, C.POINTER(hh_model), _vp, C.c_uint64, C.c_uint32, C.c_int32, C.c_double, C.POINTER(hh_lsm_result), _vp, _vp]),
     ("hh_heston_exact_grid", C.c_int, [_vp, C.POINTER(hh_model), C.POINTER(hh_config), _vp, _vp, C.c_int32, C.POINTER(hh_result)]),
+    ("hh_lsm_shard_xchg_elems", C.c_size_t, [C.c_uint32, C.c_int32]),
+    ("hh_lsm_shard_begin", C.c_int, [_vp, C.POINTER(hh_model), C.POINTER(hh_config), C.c_int32, C.c_double, _vp]),
+    ("hh_lsm_shard_phase", C.c_int, [_vp, C.c_int32, C.c_uint32, _vp, _vp]),
+    ("hh_lsm_shard_finish", C.c_int, [_vp, _vp, _vp, _vp, _vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    ("hh_lsm_finalize", C.c_int, [_vp, C.POINTER(hh_lsm_result)]),
     ("hh_replay_elems", C.c_size_t, [C.c_uint64, C.c_uint32, C.c_int32]),
     ("hh_replay_pack", C.c_int, [_vp, C.c_int32, C.c_uint64, C.c_uint32, _vp, C.c_int32, _vp]),
     ("hh_wiener_fill", C.c_int, [_vp, C.c_int32, C.c_double, C.c_double, C.c_uint32, C.c_uint64, _vp, C.c_int32, _vp]),

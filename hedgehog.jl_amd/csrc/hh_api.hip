@@ -46,6 +46,15 @@ struct hh_ctx {
   size_t lsm_tau_cap = 0;
   double* lsm_scratch = nullptr;
   size_t lsm_scratch_cap = 0;
+  // sharded LSM in progress (hh_lsm_shard_begin .. hh_lsm_shard_finish)
+  struct {
+    bool active = false;
+    hh_model m{};
+    uint64_t ntot = 0;
+    uint32_t n_steps = 0;
+    int32_t degree = 0;
+    double step_discount = 1.0;
+  } shard;
   double* accum = nullptr;       // device, HH_ACC_LEN
   double* accum_host = nullptr;  // pinned, HH_ACC_LEN
   // optional per-launch timing of the simulation kernel (hh_ctx_enable_timing)
@@ -775,6 +784,128 @@ int hh_lsm_solve(hh_ctx* ctx, const hh_model* m, const hh_config* c, int32_t deg
                                hipMemcpyDeviceToHost, ctx->stream));
     HH_HIP(ctx, hipStreamSynchronize(ctx->stream));
   }
+  return HH_OK;
+}
+
+// ---- LSM on an ensemble sharded over several devices ------------------------------------------------
+
+size_t hh_lsm_shard_xchg_elems(uint32_t n_steps, int32_t degree) {
+  return (size_t)(n_steps + 1) * (size_t)(2 * (degree < 1 ? 1 : degree) + 1);
+}
+
+static int shard_phase(hh_ctx* ctx, int phase, uint32_t t, const double* in_dev, double* out_dev) {
+  const auto& sh = ctx->shard;
+  HH_HIP(ctx, hh::launch_lsm_phase(phase, t, ctx->lsm_grid, sh.ntot, sh.n_steps, sh.m.strike, sh.m.cp,
+                                   sh.step_discount, sh.degree, ctx->lsm_tau, ctx->lsm_val,
+                                   ctx->lsm_scratch, ctx->records, in_dev, out_dev, ctx->stream));
+  return HH_OK;
+}
+
+int hh_lsm_shard_begin(hh_ctx* ctx, const hh_model* m, const hh_config* c, int32_t degree,
+                       double step_discount, double* xchg_dev) {
+  if (!ctx) return HH_ERR_INVALID;
+  std::lock_guard<std::recursive_mutex> lock__(ctx->mu);
+  ctx->shard.active = false;
+  if (!m || !c || !xchg_dev) return fail(ctx, HH_ERR_INVALID, "hh_lsm_shard_begin: NULL argument");
+  const bool gbm = c->dynamics == HH_LOGNORMAL && c->strategy == HH_EXACT_LAW;
+  const bool heston = c->dynamics == HH_HESTON && c->strategy == HH_BROADIE_KAYA;
+  if (!gbm && !heston)
+    return fail(ctx, HH_ERR_UNSUPPORTED,
+                "LSM needs LognormalDynamics + BlackScholesExact or HestonDynamics + "
+                "HestonBroadieKaya paths");
+  if (c->noise_mode != HH_NOISE_GENERATE || c->n_partials != 0)
+    return fail(ctx, HH_ERR_UNSUPPORTED, "LSM: GENERATE noise, no dual partials");
+  int rc = lsm_check_scalars(ctx, m, c, degree, step_discount);
+  if (rc) return rc;
+  HH_HIP(ctx, hipSetDevice(ctx->device));
+  const uint64_t ntot = c->n_paths * (c->antithetic ? 2 : 1);
+  if (gbm) {
+    const size_t grid_elems = hh_lsm_grid_elems(c->n_paths, c->n_steps, c->antithetic);
+    if ((rc = ensure(ctx, ctx->lsm_grid, ctx->lsm_grid_cap, grid_elems))) return rc;
+    const uint64_t* seeds_dev = nullptr;
+    if ((rc = stage_path_seeds(ctx, c, &seeds_dev))) return rc;
+    HH_HIP(ctx, hh::launch_gbm_grid(seeds_dev, c->n_paths, c->n_steps, m->S0, m->r_drift, m->sigma,
+                                    m->T, c->antithetic, ctx->lsm_grid, ctx->stream));
+  } else {
+    if ((rc = run_heston_grid(ctx, m, c))) return rc;
+  }
+  if ((rc = ensure(ctx, ctx->lsm_val, ctx->lsm_val_cap, (size_t)ntot))) return rc;
+  if ((rc = ensure(ctx, ctx->lsm_tau, ctx->lsm_tau_cap, (size_t)ntot))) return rc;
+  if ((rc = ensure(ctx, ctx->lsm_scratch, ctx->lsm_scratch_cap,
+                   hh::lsm_scratch_doubles(ntot, c->n_steps, degree))))
+    return rc;
+  if ((rc = ensure(ctx, ctx->records, ctx->records_cap, (size_t)hh::lsm_chunks(ntot) * hh::kRecStride)))
+    return rc;
+  ctx->shard.m = *m;
+  ctx->shard.ntot = ntot;
+  ctx->shard.n_steps = c->n_steps;
+  ctx->shard.degree = degree;
+  ctx->shard.step_discount = step_discount;
+  if ((rc = shard_phase(ctx, hh::kLsmPhaseStats, 0, nullptr, xchg_dev))) return rc;
+  ctx->shard.active = true;
+  return HH_OK;
+}
+
+int hh_lsm_shard_phase(hh_ctx* ctx, int32_t phase, uint32_t t, const double* in_dev, double* out_dev) {
+  if (!ctx) return HH_ERR_INVALID;
+  std::lock_guard<std::recursive_mutex> lock__(ctx->mu);
+  if (!ctx->shard.active) return fail(ctx, HH_ERR_INVALID, "no sharded LSM in progress");
+  if (phase != HH_LSM_PHASE_POW && phase != HH_LSM_PHASE_INIT && phase != HH_LSM_PHASE_STEP)
+    return fail(ctx, HH_ERR_INVALID, "unknown LSM phase %d", phase);
+  if (!in_dev) return fail(ctx, HH_ERR_INVALID, "hh_lsm_shard_phase: in_dev is NULL");
+  const bool emits = phase != HH_LSM_PHASE_STEP ? (phase == HH_LSM_PHASE_POW || ctx->shard.n_steps >= 2)
+                                                : t >= 2;
+  if (emits && !out_dev) return fail(ctx, HH_ERR_INVALID, "hh_lsm_shard_phase: out_dev is NULL");
+  if (phase == HH_LSM_PHASE_STEP && (t < 1 || t >= ctx->shard.n_steps))
+    return fail(ctx, HH_ERR_INVALID, "LSM step index %u outside 1..n_steps-1", t);
+  HH_HIP(ctx, hipSetDevice(ctx->device));
+  return shard_phase(ctx, phase, t, in_dev, out_dev);
+}
+
+int hh_lsm_shard_finish(hh_ctx* ctx, double* accum_dev, int32_t* stop_time, double* stop_value,
+                        double* spot_grid, uint32_t* rows_regressed, uint32_t* rows_skipped) {
+  if (!ctx) return HH_ERR_INVALID;
+  std::lock_guard<std::recursive_mutex> lock__(ctx->mu);
+  if (!ctx->shard.active) return fail(ctx, HH_ERR_INVALID, "no sharded LSM in progress");
+  if (!accum_dev) return fail(ctx, HH_ERR_INVALID, "accum_dev is NULL");
+  HH_HIP(ctx, hipSetDevice(ctx->device));
+  const auto& sh = ctx->shard;
+  int rc = shard_phase(ctx, hh::kLsmPhaseFinal, 0, nullptr, nullptr);
+  if (rc) return rc;
+  HH_HIP(ctx, hh::launch_reduce_records(ctx->records, hh::lsm_chunks(sh.ntot), (double)sh.ntot,
+                                        accum_dev, ctx->stream));
+  const size_t nscr = hh::lsm_scratch_doubles(sh.ntot, sh.n_steps, sh.degree);
+  double counters[2] = {0, 0};
+  HH_HIP(ctx, hipMemcpyAsync(counters, ctx->lsm_scratch + nscr - 2, 2 * sizeof(double),
+                             hipMemcpyDeviceToHost, ctx->stream));
+  if (stop_time)
+    HH_HIP(ctx, hipMemcpyAsync(stop_time, ctx->lsm_tau, sh.ntot * sizeof(int32_t),
+                               hipMemcpyDeviceToHost, ctx->stream));
+  if (stop_value)
+    HH_HIP(ctx, hipMemcpyAsync(stop_value, ctx->lsm_val, sh.ntot * sizeof(double),
+                               hipMemcpyDeviceToHost, ctx->stream));
+  if (spot_grid)
+    HH_HIP(ctx, hipMemcpyAsync(spot_grid, ctx->lsm_grid,
+                               (size_t)(sh.n_steps + 1) * sh.ntot * sizeof(double),
+                               hipMemcpyDeviceToHost, ctx->stream));
+  HH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (rows_regressed) *rows_regressed = (uint32_t)counters[0];
+  if (rows_skipped) *rows_skipped = (uint32_t)counters[1];
+  ctx->shard.active = false;
+  return HH_OK;
+}
+
+int hh_lsm_finalize(const double* acc, hh_lsm_result* out) {
+  if (!acc || !out) return HH_ERR_INVALID;
+  const double n = acc[HH_ACC_NPATHS];
+  if (!(n >= 1.0)) return HH_ERR_INVALID;
+  const double mean = acc[HH_ACC_SUM] / n;
+  double var = n > 1.0 ? (acc[HH_ACC_SUMSQ] - n * mean * mean) / (n - 1.0) : 0.0;
+  if (!(var > 0.0)) var = 0.0;
+  std::memset(out, 0, sizeof(*out));
+  out->price = mean;  // price = mean(discount^t * val) (least_squares_montecarlo.jl:133-134)
+  out->std_error = std::sqrt(var / n);
+  out->n_paths_total = (uint64_t)n;
   return HH_OK;
 }
 

@@ -104,6 +104,16 @@ int launch_carr_madan(const hh_model& m, int dynamics, int compat_sqrt_alpha, do
 // LSM (hh_lsm.hip)
 uint32_t lsm_chunks(uint64_t ntot);
 size_t lsm_scratch_doubles(uint64_t ntot, uint32_t n_steps, int degree);
+// The induction cut where it needs GLOBAL sums, for ensembles sharded over several devices: between
+// two phases the host all-reduces (SUM) the device vector the phase left in vec_out and hands it to
+// the next phase as vec_in.  Stats: - -> [rows][3];  Pow: [rows][3] -> [rows][2D+1];
+// Init: [rows][2D+1] -> [D+1] (moment sums of row n_steps-1);  Step(t): [D+1] of row t -> [D+1] of
+// row t-1 (nothing for t = 1);  Final: per-workgroup records of the discounted stopped values.
+enum { kLsmPhaseStats = 0, kLsmPhasePow = 1, kLsmPhaseInit = 2, kLsmPhaseStep = 3, kLsmPhaseFinal = 4 };
+int launch_lsm_phase(int phase, uint32_t t, const double* grid, uint64_t ntot, uint32_t n_steps,
+                     double strike, double cp, double step_discount, int degree, int32_t* tau,
+                     double* val, double* scratch, double* records, const double* vec_in,
+                     double* vec_out, hipStream_t s);
 int launch_gbm_grid(const uint64_t* seeds_dev, uint64_t n_paths, uint32_t n_steps, double S0,
                     double r, double sigma, double T, int anti, double* grid, hipStream_t s);
 int launch_lsm(const double* grid, uint64_t ntot, uint32_t n_steps, double strike, double cp,

@@ -137,20 +137,48 @@ __global__ __launch_bounds__(256) void lsm_stats_kernel(const double* __restrict
   }
 }
 
+// count, mean, std of the in-the-money spots of a row from (n, Σx, Σx²)
+__device__ __forceinline__ RowStat rowstat_of(const double (&t)[3]) {
+  RowStat r{t[0], 0.0, 1.0};
+  if (t[0] > 0.0) {
+    r.mu = t[1] / t[0];
+    const double var = t[2] / t[0] - r.mu * r.mu;
+    r.sd = var > 0.0 ? sqrt(var) : 1.0;
+  }
+  return r;
+}
+
 __global__ __launch_bounds__(256) void lsm_rowstat_kernel(const double* __restrict__ rec,
                                                           uint32_t n_chunks,
                                                           RowStat* __restrict__ rs) {
   const uint32_t row = blockIdx.x;
   double t[3];
   reduce_records<3>(rec + (size_t)row * n_chunks * 3, n_chunks, t);
+  if (threadIdx.x == 0) rs[row] = rowstat_of(t);
+}
+
+// sharded form: the sums leave the device (all-reduce over the ranks) and come back
+__global__ __launch_bounds__(256) void lsm_rowstat_from_sums_kernel(const double* __restrict__ sums,
+                                                                    uint32_t rows,
+                                                                    RowStat* __restrict__ rs) {
+  const uint32_t row = blockIdx.x * 256 + threadIdx.x;
+  if (row < rows) {
+    const double t[3] = {sums[row * 3], sums[row * 3 + 1], sums[row * 3 + 2]};
+    rs[row] = rowstat_of(t);
+  }
+}
+
+// out[row][NV] = Σ_chunk rec[row][chunk][NV], same order as the in-kernel reductions (grid = rows)
+template <int NV>
+__global__ __launch_bounds__(256) void lsm_sum_records_kernel(const double* __restrict__ rec,
+                                                              uint32_t n_chunks,
+                                                              double* __restrict__ out) {
+  const uint32_t row = blockIdx.x;
+  double t[NV];
+  reduce_records<NV>(rec + (size_t)row * n_chunks * NV, n_chunks, t);
   if (threadIdx.x == 0) {
-    RowStat r{t[0], 0.0, 1.0};
-    if (t[0] > 0.0) {
-      r.mu = t[1] / t[0];
-      const double var = t[2] / t[0] - r.mu * r.mu;
-      r.sd = var > 0.0 ? sqrt(var) : 1.0;
-    }
-    rs[row] = r;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) out[(size_t)row * NV + i] = t[i];
   }
 }
 
@@ -218,6 +246,7 @@ struct LsmStepArgs {
   const double* P;   // [row][2D+1]
   double* recB;      // [row][chunk][D+1]: partial Σ z^k y of the row
   const double* disc_pow;  // [k] = exp(ln_disc·k), k = 0..n_steps: discount over k exercise dates
+  const double* B_given;   // sharded solve: the GLOBAL moment sums of the row (D+1 doubles), else NULL
   double* counters;  // [0] rows regressed, [1] rows skipped (no in-the-money path)
 };
 
@@ -311,7 +340,12 @@ __global__ __launch_bounds__(256) void lsm_step_kernel(const LsmStepArgs a, uint
     }
   }
   double B[N];
-  reduce_records<N>(a.recB + (size_t)t * a.n_chunks * N, a.n_chunks, B);
+  if (a.B_given) {  // summed over the ranks by the host between two launches
+#pragma unroll
+    for (int i = 0; i < N; ++i) B[i] = a.B_given[i];
+  } else {
+    reduce_records<N>(a.recB + (size_t)t * a.n_chunks * N, a.n_chunks, B);
+  }
   if (threadIdx.x == 0) {
     have_fit = 0;
     if (r.n > 0.0) {  // isempty(in_the_money) && continue (:120)
@@ -426,29 +460,111 @@ __global__ __launch_bounds__(256) void lsm_final_kernel(const int32_t* __restric
   }
 }
 
-template <int D, int Q>
-void run_lsm_steps(const LsmStepArgs& a, hipStream_t s) {
-  const dim3 b(256);
-  hipLaunchKernelGGL((lsm_init_kernel<D, Q>), dim3(a.n_chunks), b, 0, s, a);
-  for (uint32_t t = a.n_steps - 1; t >= 1; --t)  // for i = nsteps:-1:2, t = i-1 (:112-113)
-    hipLaunchKernelGGL((lsm_step_kernel<D, Q>), dim3(a.n_chunks), b, 0, s, a, t);
+// ---- launch sequences ---------------------------------------------------------------------------
+
+// where the pieces of the caller's scratch buffer are (lsm_scratch_doubles() doubles)
+struct LsmLayout {
+  double* rec_stats;  // [rows][ch1][3]
+  RowStat* rs;        // [rows]
+  double* rec_pow;    // [rows][ch1][2D+1]
+  double* P;          // [rows][2D+1]
+  double* recB;       // [rows][ch][D+1]
+  double* disc_pow;   // [rows]
+  double* counters;   // [2]
+  uint32_t rows, ch1, per_wg;
+};
+
+LsmLayout lsm_layout(double* scratch, uint64_t ntot, uint32_t n_steps, int degree) {
+  const size_t rows = (size_t)n_steps + 1, ch = lsm_chunks(ntot), nv = 2 * (size_t)degree + 1;
+  LsmLayout L{};
+  L.rec_stats = scratch;
+  L.rs = reinterpret_cast<RowStat*>(L.rec_stats + rows * ch * 3);
+  L.rec_pow = reinterpret_cast<double*>(L.rs) + rows * 3;
+  L.P = L.rec_pow + rows * ch * nv;
+  L.recB = L.P + rows * nv;
+  L.disc_pow = L.recB + rows * ch * (degree + 1);
+  L.counters = L.disc_pow + rows;
+  L.rows = (uint32_t)rows;
+  L.per_wg = lsm_one_off_paths(ntot);
+  L.ch1 = (uint32_t)((ntot + L.per_wg - 1) / L.per_wg);
+  return L;
+}
+
+LsmStepArgs lsm_step_args(const LsmLayout& L, const double* grid, uint64_t ntot, uint32_t n_steps,
+                          double strike, double cp, double step_discount, int32_t* tau, double* val) {
+  LsmStepArgs a{};
+  a.grid = grid; a.ntot = ntot; a.strike = strike; a.cp = cp; a.ln_disc = log(step_discount);
+  a.n_steps = n_steps; a.tau = tau; a.val = val; a.rs = L.rs; a.P = L.P; a.recB = L.recB;
+  a.disc_pow = L.disc_pow; a.counters = L.counters;
+  const bool wide = ntot >= kLsmWideFrom;
+  a.n_chunks = wide ? (uint32_t)((ntot + 256 * HH_LSM_WIDE_Q - 1) / (256 * HH_LSM_WIDE_Q))
+                    : lsm_chunks(ntot);
+  return a;
 }
 
 template <int D>
-int run_lsm(LsmStepArgs a, double* rec_pow, hipStream_t s) {
-  const dim3 b(256);
-  const uint32_t rows = a.n_steps + 1, per_wg = lsm_one_off_paths(a.ntot);
-  const uint32_t ch = (uint32_t)((a.ntot + per_wg - 1) / per_wg);
-  hipLaunchKernelGGL(lsm_pow_kernel<D>, dim3(ch, rows), b, 0, s, a.grid, a.ntot, a.strike, a.cp, ch,
-                     per_wg, a.rs, rec_pow);
-  hipLaunchKernelGGL(lsm_powsum_kernel<D>, dim3(rows), b, 0, s, rec_pow, ch,
-                     const_cast<double*>(a.P));
-  if (a.ntot >= kLsmWideFrom) {
-    a.n_chunks = (uint32_t)((a.ntot + 256 * HH_LSM_WIDE_Q - 1) / (256 * HH_LSM_WIDE_Q));
-    run_lsm_steps<D, HH_LSM_WIDE_Q>(a, s);
-  } else {
-    a.n_chunks = lsm_chunks(a.ntot);
-    run_lsm_steps<D, 4>(a, s);
+void launch_pow(const LsmLayout& L, const LsmStepArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(lsm_pow_kernel<D>, dim3(L.ch1, L.rows), dim3(256), 0, s, a.grid, a.ntot, a.strike,
+                     a.cp, L.ch1, L.per_wg, a.rs, L.rec_pow);
+}
+
+template <int D>
+void launch_init(const LsmStepArgs& a, hipStream_t s) {
+  if (a.ntot >= kLsmWideFrom)
+    hipLaunchKernelGGL((lsm_init_kernel<D, HH_LSM_WIDE_Q>), dim3(a.n_chunks), dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL((lsm_init_kernel<D, 4>), dim3(a.n_chunks), dim3(256), 0, s, a);
+}
+
+template <int D>
+void launch_step(const LsmStepArgs& a, uint32_t t, hipStream_t s) {
+  if (a.ntot >= kLsmWideFrom)
+    hipLaunchKernelGGL((lsm_step_kernel<D, HH_LSM_WIDE_Q>), dim3(a.n_chunks), dim3(256), 0, s, a, t);
+  else
+    hipLaunchKernelGGL((lsm_step_kernel<D, 4>), dim3(a.n_chunks), dim3(256), 0, s, a, t);
+}
+
+// the whole induction on one device
+template <int D>
+int run_lsm(const LsmLayout& L, const LsmStepArgs& a, hipStream_t s) {
+  launch_pow<D>(L, a, s);
+  hipLaunchKernelGGL(lsm_powsum_kernel<D>, dim3(L.rows), dim3(256), 0, s, L.rec_pow, L.ch1, L.P);
+  launch_init<D>(a, s);
+  for (uint32_t t = a.n_steps - 1; t >= 1; --t)  // for i = nsteps:-1:2, t = i-1 (:112-113)
+    launch_step<D>(a, t, s);
+  return (int)hipGetLastError();
+}
+
+// one phase of the sharded induction (see hh_kernels.h); vec_in / vec_out are device vectors
+template <int D>
+int run_lsm_phase(const LsmLayout& L, LsmStepArgs a, int phase, uint32_t t, const double* vec_in,
+                  double* vec_out, hipStream_t s) {
+  constexpr int N = D + 1, NV = 2 * D + 1;
+  switch (phase) {
+    case kLsmPhasePow:  // global row sums in -> row statistics; local power sums out
+      hipLaunchKernelGGL(lsm_rowstat_from_sums_kernel, dim3((L.rows + 255) / 256), dim3(256), 0, s,
+                         vec_in, L.rows, L.rs);
+      launch_pow<D>(L, a, s);
+      hipLaunchKernelGGL(lsm_powsum_kernel<D>, dim3(L.rows), dim3(256), 0, s, L.rec_pow, L.ch1, vec_out);
+      break;
+    case kLsmPhaseInit: {  // global power sums in; stopping at expiry; local moment sums of row n-1 out
+      hipError_t e = hipMemcpyAsync(L.P, vec_in, (size_t)L.rows * NV * sizeof(double),
+                                    hipMemcpyDeviceToDevice, s);
+      if (e != hipSuccess) return (int)e;
+      launch_init<D>(a, s);
+      if (a.n_steps >= 2)
+        hipLaunchKernelGGL(lsm_sum_records_kernel<N>, dim3(1), dim3(256), 0, s,
+                           a.recB + (size_t)(a.n_steps - 1) * a.n_chunks * N, a.n_chunks, vec_out);
+      break;
+    }
+    case kLsmPhaseStep:  // global moment sums of row t in; decisions at t; local sums of row t-1 out
+      a.B_given = vec_in;
+      launch_step<D>(a, t, s);
+      if (t >= 2)
+        hipLaunchKernelGGL(lsm_sum_records_kernel<N>, dim3(1), dim3(256), 0, s,
+                           a.recB + (size_t)(t - 1) * a.n_chunks * N, a.n_chunks, vec_out);
+      break;
+    default: return (int)hipErrorInvalidValue;
   }
   return (int)hipGetLastError();
 }
@@ -483,49 +599,73 @@ int launch_gbm_grid(const uint64_t* seeds_dev, uint64_t n_paths, uint32_t n_step
 // Backward induction on a device-resident grid.  `scratch` has lsm_scratch_doubles() doubles,
 // `records` lsm_chunks() x kRecStride; on return `records` holds the per-workgroup Σ, Σ² of the
 // discounted stopped values and scratch's last two doubles the regressed / skipped row counts.
+#define HH_LSM_DISPATCH(degree, CALL)            \
+  switch (degree) {                                \
+    case 1: rc = CALL(1); break;                   \
+    case 2: rc = CALL(2); break;                   \
+    case 3: rc = CALL(3); break;                   \
+    case 4: rc = CALL(4); break;                   \
+    case 5: rc = CALL(5); break;                   \
+    case 6: rc = CALL(6); break;                   \
+    case 7: rc = CALL(7); break;                   \
+    default: rc = CALL(8); break;                  \
+  }
+
 int launch_lsm(const double* grid, uint64_t ntot, uint32_t n_steps, double strike, double cp,
                double step_discount, int degree, int32_t* tau, double* val, double* scratch,
                double* records, hipStream_t s) {
   if (degree < 1 || degree > kLsmMaxDeg) return (int)hipErrorInvalidValue;
-  const size_t rows = (size_t)n_steps + 1, ch = lsm_chunks(ntot), nv = 2 * (size_t)degree + 1;
-  double* rec_stats = scratch;
-  RowStat* rs = reinterpret_cast<RowStat*>(rec_stats + rows * ch * 3);
-  double* rec_pow = reinterpret_cast<double*>(rs) + rows * 3;
-  double* P = rec_pow + rows * ch * nv;
-  double* recB = P + rows * nv;
-  double* disc_pow = recB + rows * ch * (degree + 1);
-  double* counters = disc_pow + rows;
-
-  hipError_t e = hipMemsetAsync(counters, 0, 2 * sizeof(double), s);
+  const LsmLayout L = lsm_layout(scratch, ntot, n_steps, degree);
+  hipError_t e = hipMemsetAsync(L.counters, 0, 2 * sizeof(double), s);
   if (e != hipSuccess) return (int)e;
   const dim3 b(256);
-  const uint32_t per_wg = lsm_one_off_paths(ntot);
-  const uint32_t ch1 = (uint32_t)((ntot + per_wg - 1) / per_wg);
-  hipLaunchKernelGGL(lsm_stats_kernel, dim3(ch1, (unsigned)rows), b, 0, s, grid, ntot, strike, cp, ch1,
-                     per_wg, rec_stats);
-  hipLaunchKernelGGL(lsm_rowstat_kernel, dim3((unsigned)rows), b, 0, s, rec_stats, ch1, rs);
-
-  LsmStepArgs a{};
-  a.grid = grid; a.ntot = ntot; a.strike = strike; a.cp = cp; a.ln_disc = log(step_discount);
-  a.n_steps = n_steps; a.n_chunks = (uint32_t)ch; a.tau = tau; a.val = val; a.rs = rs; a.P = P;
-  a.recB = recB; a.disc_pow = disc_pow; a.counters = counters;
-  hipLaunchKernelGGL(lsm_disc_kernel, dim3((unsigned)((rows + 255) / 256)), b, 0, s, a.ln_disc, n_steps,
-                     disc_pow);
+  hipLaunchKernelGGL(lsm_stats_kernel, dim3(L.ch1, L.rows), b, 0, s, grid, ntot, strike, cp, L.ch1,
+                     L.per_wg, L.rec_stats);
+  hipLaunchKernelGGL(lsm_rowstat_kernel, dim3(L.rows), b, 0, s, L.rec_stats, L.ch1, L.rs);
+  const LsmStepArgs a = lsm_step_args(L, grid, ntot, n_steps, strike, cp, step_discount, tau, val);
+  hipLaunchKernelGGL(lsm_disc_kernel, dim3((L.rows + 255) / 256), b, 0, s, a.ln_disc, n_steps,
+                     L.disc_pow);
   int rc = 0;
-  switch (degree) {
-    case 1: rc = run_lsm<1>(a, rec_pow, s); break;
-    case 2: rc = run_lsm<2>(a, rec_pow, s); break;
-    case 3: rc = run_lsm<3>(a, rec_pow, s); break;
-    case 4: rc = run_lsm<4>(a, rec_pow, s); break;
-    case 5: rc = run_lsm<5>(a, rec_pow, s); break;
-    case 6: rc = run_lsm<6>(a, rec_pow, s); break;
-    case 7: rc = run_lsm<7>(a, rec_pow, s); break;
-    default: rc = run_lsm<8>(a, rec_pow, s); break;
-  }
+#define HH_CALL(D) run_lsm<D>(L, a, s)
+  HH_LSM_DISPATCH(degree, HH_CALL)
+#undef HH_CALL
   if (rc) return rc;
-  hipLaunchKernelGGL(lsm_final_kernel, dim3((unsigned)ch), b, 0, s, tau, val, ntot, a.ln_disc,
+  hipLaunchKernelGGL(lsm_final_kernel, dim3(lsm_chunks(ntot)), b, 0, s, tau, val, ntot, a.ln_disc,
                      records);
   return (int)hipGetLastError();
+}
+
+// Sharded induction, one phase per call (hh_kernels.h).  kLsmPhaseStats: local row sums
+// (n, Σx, Σx² of the in-the-money spots of every row) -> vec_out[rows][3]; also the discount table and
+// the counters.  kLsmPhaseFinal: per-workgroup Σ, Σ² of the discounted stopped values -> records.
+int launch_lsm_phase(int phase, uint32_t t, const double* grid, uint64_t ntot, uint32_t n_steps,
+                     double strike, double cp, double step_discount, int degree, int32_t* tau,
+                     double* val, double* scratch, double* records, const double* vec_in,
+                     double* vec_out, hipStream_t s) {
+  if (degree < 1 || degree > kLsmMaxDeg) return (int)hipErrorInvalidValue;
+  const LsmLayout L = lsm_layout(scratch, ntot, n_steps, degree);
+  const LsmStepArgs a = lsm_step_args(L, grid, ntot, n_steps, strike, cp, step_discount, tau, val);
+  const dim3 b(256);
+  if (phase == kLsmPhaseStats) {
+    hipError_t e = hipMemsetAsync(L.counters, 0, 2 * sizeof(double), s);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(lsm_stats_kernel, dim3(L.ch1, L.rows), b, 0, s, grid, ntot, strike, cp, L.ch1,
+                       L.per_wg, L.rec_stats);
+    hipLaunchKernelGGL(lsm_sum_records_kernel<3>, dim3(L.rows), b, 0, s, L.rec_stats, L.ch1, vec_out);
+    hipLaunchKernelGGL(lsm_disc_kernel, dim3((L.rows + 255) / 256), b, 0, s, a.ln_disc, n_steps,
+                       L.disc_pow);
+    return (int)hipGetLastError();
+  }
+  if (phase == kLsmPhaseFinal) {
+    hipLaunchKernelGGL(lsm_final_kernel, dim3(lsm_chunks(ntot)), b, 0, s, tau, val, ntot, a.ln_disc,
+                       records);
+    return (int)hipGetLastError();
+  }
+  int rc = 0;
+#define HH_CALL(D) run_lsm_phase<D>(L, a, phase, t, vec_in, vec_out, s)
+  HH_LSM_DISPATCH(degree, HH_CALL)
+#undef HH_CALL
+  return rc;
 }
 
 }  // namespace hh

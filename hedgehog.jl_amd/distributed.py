@@ -69,3 +69,82 @@ def solve_sharded(prob, method: MonteCarlo, group=None, accumulate=None) -> Mont
     del keep, seeds
     return MonteCarloSolution(prob, method, _price_from(res, discount, P), None,
                               std_error=res.std_error, result=res)
+
+
+def _all_reduce_device(t, group):
+    """SUM all-reduce of a device tensor: in place over RCCL ("nccl"), through host memory when the
+    group's backend cannot take device tensors (gloo — the CPU-side rehearsal of the exchange)."""
+    import torch.distributed as dist
+    if dist.get_backend(group) == "nccl":
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        return
+    h = t.cpu()
+    dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+    t.copy_(h)
+
+
+def solve_lsm_sharded(prob, method, group=None, stopping_info: bool = False):
+    """solve(prob, ::LSM) (least_squares_montecarlo.jl:99-136) with the trajectories sharded over the
+    ranks of `group`.  Unlike the European solve this path HAS exchange steps: the regression of
+    every exercise date needs sums over all trajectories, so the induction runs in phases
+    (`hh_lsm_shard_*`, include/hedgehog_mc.h) with one small SUM all-reduce between consecutive
+    phases — 2 + (steps-1) + 1 collectives of at most (steps+1)·(2·degree+1) doubles.  Every rank
+    returns the same price; stopping_info (if asked) is the rank's own shard."""
+    import torch
+    import torch.distributed as dist
+
+    from .lsm import LSMSolution, _lsm_structs
+    from .dates import MILLISECONDS_IN_YEAR_365
+    from .domain import American, VanillaOption, df
+    from .montecarlo import MethodError
+
+    payoff, m = prob.payoff, prob.market_inputs
+    if not (isinstance(payoff, VanillaOption) and isinstance(payoff.exercise_style, American)):
+        raise MethodError("solve(::PricingProblem, ::LSM) needs an American VanillaOption")
+    mc = method.mc_method
+    model, c, T = _lsm_structs(prob, mc)
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    start, stop = shard_range(mc.config.trajectories, rank, world)
+    if stop <= start:
+        raise ValueError("every rank needs at least one trajectory")
+    seeds = np.ascontiguousarray(mc.config.seeds[start:stop])
+    c.n_paths, c.seeds, c.seeds_len = stop - start, seeds.ctypes.data, seeds.size
+    steps, degree = mc.config.steps, method.degree
+    step_discount = float(df(m.rate, m.referenceDate + (T / steps) * MILLISECONDS_IN_YEAR_365))
+
+    dev = torch.device("cuda", mc.device)
+    ctx = _ffi.get_context(mc.device)
+    ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+    lib, h = ctx.lib, ctx.handle
+    x = torch.zeros(lib.hh_lsm_shard_xchg_elems(steps, degree), dtype=torch.float64, device=dev)
+    rows, nv, nb = steps + 1, 2 * degree + 1, degree + 1
+
+    def exchange(n):
+        if world > 1:
+            _all_reduce_device(x[:n], group)
+
+    ctx.check(lib.hh_lsm_shard_begin(h, C.byref(model), C.byref(c), degree, step_discount, x.data_ptr()))
+    exchange(rows * 3)
+    ctx.check(lib.hh_lsm_shard_phase(h, _ffi.HH_LSM_PHASE_POW, 0, x.data_ptr(), x.data_ptr()))
+    exchange(rows * nv)
+    ctx.check(lib.hh_lsm_shard_phase(h, _ffi.HH_LSM_PHASE_INIT, 0, x.data_ptr(), x.data_ptr()))
+    for t in range(steps - 1, 0, -1):
+        exchange(nb)
+        ctx.check(lib.hh_lsm_shard_phase(h, _ffi.HH_LSM_PHASE_STEP, t, x.data_ptr(), x.data_ptr()))
+    acc = torch.zeros(_ffi.HH_ACC_LEN, dtype=torch.float64, device=dev)
+    ntot = (stop - start) * (2 if c.antithetic else 1)
+    tau = np.empty(ntot, dtype=np.int32) if stopping_info else None
+    val = np.empty(ntot) if stopping_info else None
+    ctx.check(lib.hh_lsm_shard_finish(h, acc.data_ptr(), tau.ctypes.data if stopping_info else None,
+                                      val.ctypes.data if stopping_info else None, None, None, None))
+    if world > 1:
+        _all_reduce_device(acc, group)
+    acc_host = np.ascontiguousarray(acc.cpu().numpy())
+    res = _ffi.hh_lsm_result()
+    rc = lib.hh_lsm_finalize(acc_host.ctypes.data, C.byref(res))
+    if rc != 0:
+        raise _ffi.HedgehogMCError(rc, "hh_lsm_finalize failed")
+    del seeds
+    return LSMSolution(prob, method, res.price, (tau, val) if stopping_info else None, None,
+                       std_error=res.std_error, result=res)

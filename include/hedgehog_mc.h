@@ -224,6 +224,37 @@ int hh_lsm_solve_grid(hh_ctx* ctx, const hh_model* model, const double* spot_gri
                       hh_lsm_result* out, int32_t* stop_time, double* stop_value);
 
 /*
+ * The same solve for an ensemble SHARDED over several devices (one process and one hh_ctx per
+ * device, trajectories split by contiguous ranges as for hh_mc_accumulate).  The backward induction
+ * needs sums over ALL trajectories at three points — the in-the-money statistics of every row, the
+ * power sums of every row, and the moment sums Σ z^k y of each exercise date — so the solve is cut
+ * exactly there: every call leaves a vector of LOCAL sums in device memory, the host all-reduces it
+ * (SUM) over the ranks (torch.distributed / RCCL), and hands the GLOBAL vector to the next call:
+ *
+ *   hh_lsm_shard_begin(cfg of THIS shard)            ->  out [n_steps+1][3]
+ *   hh_lsm_shard_phase(HH_LSM_PHASE_POW,  0, in, out):   in [n_steps+1][3]        out [n_steps+1][2D+1]
+ *   hh_lsm_shard_phase(HH_LSM_PHASE_INIT, 0, in, out):   in [n_steps+1][2D+1]     out [D+1]  (row n_steps-1)
+ *   for t = n_steps-1 .. 1:
+ *   hh_lsm_shard_phase(HH_LSM_PHASE_STEP, t, in, out):   in [D+1] of row t        out [D+1] of row t-1
+ *                                                                                  (nothing for t = 1)
+ *   hh_lsm_shard_finish(accum_dev)                   ->  accum_dev[HH_ACC_LEN]: Σ, Σ² of the discounted
+ *                                                        stopped values and the local trajectory count
+ *   hh_lsm_finalize(all-reduced accumulator, host)   ->  price, std_error, n_paths_total
+ *
+ * in / out are device pointers (they may alias); hh_lsm_shard_xchg_elems() doubles hold the largest
+ * of them.  With one rank (no all-reduce) the sequence reproduces hh_lsm_solve bit for bit.  The
+ * optional host outputs of hh_lsm_shard_finish are this shard's stopping_info / spot rows.
+ */
+enum hh_lsm_phase { HH_LSM_PHASE_POW = 1, HH_LSM_PHASE_INIT = 2, HH_LSM_PHASE_STEP = 3 };
+size_t hh_lsm_shard_xchg_elems(uint32_t n_steps, int32_t degree);
+int hh_lsm_shard_begin(hh_ctx* ctx, const hh_model* model, const hh_config* cfg, int32_t degree,
+                       double step_discount, double* out_dev);
+int hh_lsm_shard_phase(hh_ctx* ctx, int32_t phase, uint32_t t, const double* in_dev, double* out_dev);
+int hh_lsm_shard_finish(hh_ctx* ctx, double* accum_dev, int32_t* stop_time, double* stop_value,
+                        double* spot_grid, uint32_t* rows_regressed, uint32_t* rows_skipped);
+int hh_lsm_finalize(const double* accum_host, hh_lsm_result* out);
+
+/*
  * Per-date EXACT Heston paths: the NoiseProblem that sde_problem(::PricingProblem, ::HestonDynamics,
  * ::HestonBroadieKaya) builds (src/pricing_methods/montecarlo.jl:209-231) on the HestonNoise process
  * (src/distributions/heston.jl:82-91), stepped with dt = T/n_steps by simulate_paths (:342-353):
