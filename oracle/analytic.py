@@ -1,6 +1,11 @@
 """Closed-form / Fourier prices the reference's own Monte Carlo tests compare against.
 
 TEST INFRASTRUCTURE ONLY (see oracle/hh_oracle.c header): imported by tests/, never by the product.
+PARITY STATUS: bs_price is PINNED by the reference's own known answers (QuantLib values of
+test/unit/black_scholes.jl:93-127, tests/golden/reference_known_answers.json) and crr_price by its
+regression values (test/unit/binomial_tree.jl:18,26); the Carr–Madan / Heston-CF restatement has no
+golden vector in the reference (its tests compare it with Black–Scholes and with Monte Carlo only):
+parity unpinned, cross-checked here against bs_price at zero vol-of-vol and against put-call parity.
 
 Restates, with numpy/scipy:
   * BlackScholesAnalytic        /root/reference/src/pricing_methods/black_scholes.jl:38-64
