@@ -5,7 +5,8 @@ PARITY STATUS: bs_price is PINNED by the reference's own known answers (QuantLib
 test/unit/black_scholes.jl:93-127, tests/golden/reference_known_answers.json) and crr_price by its
 regression values (test/unit/binomial_tree.jl:18,26); the Carr–Madan / Heston-CF restatement has no
 golden vector in the reference (its tests compare it with Black–Scholes and with Monte Carlo only):
-parity unpinned, cross-checked here against bs_price at zero vol-of-vol and against put-call parity.
+parity unpinned, cross-checked against bs_price at vanishing vol-of-vol and against put-call parity
+(tests/test_oracle_pins.py).
 
 Restates, with numpy/scipy:
   * BlackScholesAnalytic        /root/reference/src/pricing_methods/black_scholes.jl:38-64

@@ -277,3 +277,19 @@ def test_oracle_reproduces_committed_replay_fixture(oracle):
     assert r.price == pytest.approx(meta["price"], rel=1e-14)
     c0 = o.make_config(HES, EM, n, steps, em_split=0, noise_mode=1, replay=dW, replay_layout=1)
     assert np.max(np.abs(oracle.mc_solve(m, c0)[1] - ST) / ST) > 1e-6  # the other step form differs
+
+
+def test_analytic_checkers_agree_like_the_reference_price_agreement():
+    """test/agreement/price_agreement.jl: CRR(100) vs BlackScholesAnalytic (atol 1e-3, :2-25) on the
+    European put K=1.1, r=0.2, S=1, σ=0.4; and the Fourier price against Black–Scholes (:27-54,
+    atol 1e-6 there; 5e-6 here) — through the Heston restatement with the vol-of-vol switched off
+    (σ_v → 0, V0 = θ = σ²: the variance stays at σ²), plus put-call parity of the Fourier prices."""
+    assert analytic.crr_price(1.0, 1.1, 0.2, 0.4, 366 / 365, 100, cp=-1.0, american=False) == \
+        pytest.approx(analytic.bs_price(1.0, 1.1, 0.2, 0.4, 366 / 365, cp=-1.0), abs=1e-3)
+    S, K, r, sig, T = 100.0, 100.0, 0.2, 0.4, 1.0
+    # (σ_v = 1e-3: smaller values lose digits in the CF's 1/σ_v² terms, larger ones move the price)
+    cm = analytic.carr_madan_heston(S, K, r, sig**2, 1.0, sig**2, 1e-3, 0.0, T, bound=32.0)
+    assert cm == pytest.approx(analytic.bs_price(S, K, r, sig, T), abs=5e-6)
+    call = analytic.carr_madan_heston(100, 95, 0.03, 0.04, 2.0, 0.04, 0.3, -0.7, 1.0, bound=400)
+    put = analytic.carr_madan_heston(100, 95, 0.03, 0.04, 2.0, 0.04, 0.3, -0.7, 1.0, cp=-1.0, bound=400)
+    assert call - put == pytest.approx(100 - 95 * math.exp(-0.03), abs=1e-8)
