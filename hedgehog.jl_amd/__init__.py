@@ -10,7 +10,7 @@ from .analytic import (AnalyticSolution, BlackScholesAnalytic, CarrMadan, solve_
                        solve_carr_madan)
 from .basket import BasketPricingProblem, BasketPricingSolution, solve_basket
 from .dates import Date, DateTime, add_years, to_ticks, yearfrac
-from .dual import Dual
+from .dual import Dual, partials_of, value_of
 from .greeks import (BatchGreekProblem, FDBackward, FDCentral, FDForward, FiniteDifference,
                      ForwardAD, GreekProblem, GreekResult, PropertyLens, SecondOrderGreekProblem, SpotLens,
                      VolLens,

@@ -58,8 +58,11 @@ def solve_sharded(prob, method: MonteCarlo, group=None, accumulate=None) -> Mont
     acc = (accumulate or _hip_accumulate)(model, c, method.device)
     if not isinstance(acc, torch.Tensor):
         acc = torch.as_tensor(np.asarray(acc, dtype=np.float64))
-    if world > 1:
-        dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=group)  # the path's one exchange
+    if world > 1:  # the path's one exchange
+        if acc.is_cuda:
+            _all_reduce_device(acc, group)
+        else:
+            dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=group)
     acc_host = np.ascontiguousarray(acc.detach().cpu().numpy())
     res = _ffi.hh_result()
     lib = _ffi.load_library()

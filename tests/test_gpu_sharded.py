@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 
 import hedgehog_jl_amd as hh
-from tests.lsm_shard_worker import problem
+from tests.shard_worker import problem
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -46,7 +46,7 @@ def test_two_ranks_equal_the_single_solve(case, tmp_path):
     world, port = 2, _free_port()
     outs = [str(tmp_path / f"r{r}.json") for r in range(world)]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "lsm_shard_worker.py"),
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "shard_worker.py"),
                                str(r), str(world), str(port), outs[r], json.dumps(case)],
                               env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
              for r in range(world)]
@@ -72,3 +72,29 @@ def test_two_ranks_equal_the_single_solve(case, tmp_path):
     np.testing.assert_allclose(val[same], single.stopping_info[1][same], rtol=1e-12)
     assert res[0]["price"] == pytest.approx(single.price, rel=2e-4 if not same.all() else 1e-11)
     assert res[0]["std_error"] == pytest.approx(single.std_error, rel=1e-3)
+
+
+@pytest.mark.parametrize("case", [dict(model="european", n=70_001, steps=40, anti=1, P=3),
+                                  dict(model="european", n=5_000, steps=16, anti=0, P=0)],
+                         ids=["greeks-antithetic", "plain"])
+def test_two_ranks_european_solve_sharded_on_the_gpu(case, tmp_path):
+    """solve_sharded (the European path: ONE all-reduce of the accumulator vector) with the HIP
+    kernels in both ranks — two processes on this GPU, gloo — against the single solve."""
+    from tests.shard_worker import european_problem
+    world, port = 2, _free_port()
+    outs = [str(tmp_path / f"e{r}.json") for r in range(world)]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "shard_worker.py"),
+                               str(r), str(world), str(port), outs[r], json.dumps(case)],
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in range(world)]
+    logs = [p.communicate(timeout=300)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)[-3000:]
+    res = [json.load(open(o)) for o in outs]
+    prob, method = european_problem(case)
+    single = hh.solve(prob, method, ensemble=False)
+    assert res[0] == res[1] and res[0]["n_total"] == case["n"]
+    assert res[0]["price"] == pytest.approx(hh.value_of(single.price), rel=1e-12)
+    assert res[0]["std_error"] == pytest.approx(single.std_error, rel=1e-9)
+    for k in range(case["P"]):
+        assert res[0]["dprice"][k] == pytest.approx(hh.partials_of(single.price, case["P"])[k], rel=1e-11)
