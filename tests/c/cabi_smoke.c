@@ -8,6 +8,7 @@
  *   - accumulate + finalize split == hh_mc_solve
  *   - a fused 3-partial Greek pass returns the same price
  *   - error codes and hh_last_error for bad arguments
+ *   - exact Heston grid -> LSM on the device grid; the phased (sharded) LSM with one rank == fused
  */
 #include <math.h>
 #include <stdio.h>
@@ -94,6 +95,56 @@ int main(void) {
   CHECK(hh_mc_solve(ctx, &m, &bad, &gen, NULL) == HH_ERR_UNSUPPORTED, "unsupported pair");
   CHECK(strlen(hh_last_error(ctx)) > 0, "error text");
   CHECK(hh_mc_solve(NULL, &m, &c, &gen, NULL) == HH_ERR_INVALID, "NULL ctx");
+
+  /* per-date exact Heston paths left in device memory, LSM on that grid, and the same American
+     put through the sharded (phased) sequence with ONE rank: bit-identical to the fused solve */
+  {
+    const uint64_t NG = 4000;
+    const uint32_t MG = 6;
+    hh_config cgd = c;
+    cgd.strategy = HH_BROADIE_KAYA;
+    cgd.n_paths = NG;
+    cgd.n_steps = MG;
+    cgd.seeds_len = N;
+    hh_model mp = m;
+    mp.cp = -1.0;
+    void *d_spot = NULL, *d_x = NULL, *d_acc2 = NULL;
+    const size_t gel = hh_lsm_grid_elems(NG, MG, 0);
+    CHECK(hh_device_malloc(ctx, gel * sizeof(double), &d_spot) == HH_OK, hh_last_error(ctx));
+    hh_result gr;
+    CHECK(hh_heston_exact_grid(ctx, &mp, &cgd, (double*)d_spot, NULL, 1, &gr) == HH_OK,
+          hh_last_error(ctx));
+    CHECK(gr.n_paths_done == NG && gr.bk_cf_terms > 0, "grid counters");
+    const double D = exp(-mp.r_drift * mp.T / MG);
+    hh_lsm_result fused, ongrid, phased;
+    CHECK(hh_lsm_solve(ctx, &mp, &cgd, 3, D, &fused, NULL, NULL, NULL) == HH_OK, hh_last_error(ctx));
+    CHECK(hh_lsm_solve_grid(ctx, &mp, (const double*)d_spot, NG, MG, 3, D, &ongrid, NULL, NULL) == HH_OK,
+          hh_last_error(ctx));
+    CHECK(ongrid.price == fused.price && ongrid.std_error == fused.std_error, "LSM on a caller grid");
+    const size_t xel = hh_lsm_shard_xchg_elems(MG, 3);
+    CHECK(hh_device_malloc(ctx, xel * sizeof(double), &d_x) == HH_OK, hh_last_error(ctx));
+    CHECK(hh_device_malloc(ctx, HH_ACC_LEN * sizeof(double), &d_acc2) == HH_OK, hh_last_error(ctx));
+    CHECK(hh_lsm_shard_begin(ctx, &mp, &cgd, 3, D, (double*)d_x) == HH_OK, hh_last_error(ctx));
+    CHECK(hh_lsm_shard_phase(ctx, HH_LSM_PHASE_POW, 0, (const double*)d_x, (double*)d_x) == HH_OK,
+          hh_last_error(ctx));
+    CHECK(hh_lsm_shard_phase(ctx, HH_LSM_PHASE_INIT, 0, (const double*)d_x, (double*)d_x) == HH_OK,
+          hh_last_error(ctx));
+    for (uint32_t t = MG - 1; t >= 1; --t)
+      CHECK(hh_lsm_shard_phase(ctx, HH_LSM_PHASE_STEP, t, (const double*)d_x, (double*)d_x) == HH_OK,
+            hh_last_error(ctx));
+    uint32_t regressed = 0, skipped = 0;
+    CHECK(hh_lsm_shard_finish(ctx, (double*)d_acc2, NULL, NULL, NULL, &regressed, &skipped) == HH_OK,
+          hh_last_error(ctx));
+    double acc2[HH_ACC_LEN];
+    CHECK(hh_memcpy_d2h(ctx, acc2, d_acc2, sizeof(acc2)) == HH_OK, hh_last_error(ctx));
+    CHECK(hh_lsm_finalize(acc2, &phased) == HH_OK, "lsm finalize");
+    CHECK(phased.price == fused.price && phased.std_error == fused.std_error, "phased LSM == fused");
+    CHECK(regressed + skipped == MG - 1 && phased.n_paths_total == NG, "phased LSM counters");
+    CHECK(hh_lsm_shard_phase(ctx, HH_LSM_PHASE_POW, 0, (const double*)d_x, (double*)d_x) ==
+              HH_ERR_INVALID, "phase without begin");
+    CHECK(hh_device_free(ctx, d_spot) == HH_OK && hh_device_free(ctx, d_x) == HH_OK &&
+          hh_device_free(ctx, d_acc2) == HH_OK, "free");
+  }
 
   CHECK(hh_device_free(ctx, d_seeds) == HH_OK && hh_device_free(ctx, d_dw) == HH_OK &&
         hh_device_free(ctx, d_acc) == HH_OK, "free");
