@@ -239,6 +239,12 @@ struct VecOf<2> {
 #ifndef HH_REPLAY_LDS
 #define HH_REPLAY_LDS 4  // chunks in each wave's LDS ring; 0 = two-chunk register pipeline instead
 #endif
+#ifndef HH_REPLAY_PPT
+#define HH_REPLAY_PPT 2  // trajectories per lane of the price-only REPLAY kernel (experiment knob)
+#endif
+#ifndef HH_REPLAY_PAD_KIB
+#define HH_REPLAY_PAD_KIB 0  // LDS allocated only to cap the occupancy of the register pipeline
+#endif
 #ifndef HH_REPLAY_PIPE
 #define HH_REPLAY_PIPE 0  // standard ring: 0 = drain all LDS-DMA before each chunk is read
 #endif
@@ -414,6 +420,10 @@ __global__ __launch_bounds__(kTile / PPT, REPLAY ? HH_REPLAY_MINW : 1) void eule
       compute(A, n_chunks * kChunk);
     }
     } else {
+    if constexpr (HH_REPLAY_PAD_KIB > 0 && P == 0 && !ANTI) {  // occupancy cap (never taken branch)
+      __shared__ double occupancy_pad[HH_REPLAY_PAD_KIB > 0 ? HH_REPLAY_PAD_KIB * 128 : 1];
+      if (a.n_steps == 0xFFFFFFFFu) occupancy_pad[tid] = 0.0;
+    }
     uint32_t s = 0;
     load(A, 0);
     while (s < n_steps) {
@@ -759,7 +769,7 @@ constexpr uint32_t kDeepRingTiles = 512;
 
 template <class M, int P, bool REPLAY, bool ANTI>
 static int launch_euler_t(const SimArgs<P>& a, hipStream_t s) {
-  constexpr int PPT = REPLAY ? 2 : 1;
+  constexpr int PPT = !REPLAY ? 1 : (P == 0 && !ANTI) ? HH_REPLAY_PPT : 2;
   constexpr int RING = !REPLAY ? 0 : ANTI ? HH_REPLAY_LDS_ANTI : P > 0 ? HH_REPLAY_LDS_DUAL
                                                                      : HH_REPLAY_LDS;
   const dim3 g(a.n_tiles), b(kTile / PPT);
