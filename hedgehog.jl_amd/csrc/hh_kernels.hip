@@ -245,6 +245,12 @@ struct VecOf<2> {
 #ifndef HH_REPLAY_PAD_KIB
 #define HH_REPLAY_PAD_KIB 0  // LDS allocated only to cap the occupancy of the register pipeline
 #endif
+#ifndef HH_REPLAY_PAD_ANTI_KIB
+#define HH_REPLAY_PAD_ANTI_KIB 0
+#endif
+#ifndef HH_REPLAY_PAD_DUAL_KIB
+#define HH_REPLAY_PAD_DUAL_KIB 24  // dual-partial kernels: 12 waves per CU (0.65 -> 0.62 ms with one carried derivative)
+#endif
 #ifndef HH_REPLAY_PIPE
 #define HH_REPLAY_PIPE 0  // standard ring: 0 = drain all LDS-DMA before each chunk is read
 #endif
@@ -420,8 +426,11 @@ __global__ __launch_bounds__(kTile / PPT, REPLAY ? HH_REPLAY_MINW : 1) void eule
       compute(A, n_chunks * kChunk);
     }
     } else {
-    if constexpr (HH_REPLAY_PAD_KIB > 0 && P == 0 && !ANTI) {  // occupancy cap (never taken branch)
-      __shared__ double occupancy_pad[HH_REPLAY_PAD_KIB > 0 ? HH_REPLAY_PAD_KIB * 128 : 1];
+    // LDS allocated only to cap the occupancy (the branch is never taken): fewer concurrent streams
+    // per CU read HBM faster (tools/ubench/hbm_read_sweep.hip)
+    constexpr int kPadKib = ANTI ? HH_REPLAY_PAD_ANTI_KIB : P > 0 ? HH_REPLAY_PAD_DUAL_KIB : HH_REPLAY_PAD_KIB;
+    if constexpr (kPadKib > 0) {
+      __shared__ double occupancy_pad[kPadKib > 0 ? kPadKib * 128 : 1];
       if (a.n_steps == 0xFFFFFFFFu) occupancy_pad[tid] = 0.0;
     }
     uint32_t s = 0;
