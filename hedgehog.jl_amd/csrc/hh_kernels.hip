@@ -237,13 +237,18 @@ struct VecOf<2> {
 #define HH_REPLAY_MINW 1
 #endif
 #ifndef HH_REPLAY_LDS
-#define HH_REPLAY_LDS 4  // chunks in each wave's LDS ring; 0 = two-chunk register pipeline instead
+#define HH_REPLAY_LDS 0  // > 0: the price-only kernel streams through a per-wave LDS ring of that
+                          // many chunks filled by LDS-DMA (needs HH_REPLAY_PPT = 2); measured, kept
+                          // for A/B (tools/tune_replay.py), not shipped — see DESIGN.md §5
 #endif
 #ifndef HH_REPLAY_PPT
-#define HH_REPLAY_PPT 2  // trajectories per lane of the price-only REPLAY kernel (experiment knob)
+#define HH_REPLAY_PPT 1  // trajectories per lane of the price-only REPLAY kernel: 256-thread workgroups
+#endif
+#ifndef HH_REPLAY_CHUNK_PRICE
+#define HH_REPLAY_CHUNK_PRICE 4
 #endif
 #ifndef HH_REPLAY_PAD_KIB
-#define HH_REPLAY_PAD_KIB 0  // LDS allocated only to cap the occupancy of the register pipeline
+#define HH_REPLAY_PAD_KIB 79  // LDS allocated only to cap the occupancy: 2 workgroups = 8 waves per CU
 #endif
 #ifndef HH_REPLAY_PAD_ANTI_KIB
 #define HH_REPLAY_PAD_ANTI_KIB 0
@@ -263,7 +268,6 @@ struct VecOf<2> {
 #ifndef HH_REPLAY_LDS_DUAL
 #define HH_REPLAY_LDS_DUAL 0  // ... and for the kernels carrying dual partials
 #endif
-constexpr int kChunk = HH_REPLAY_CHUNK;  // steps per register chunk of the REPLAY pipeline
 
 template <class Vec>
 __device__ __forceinline__ Vec stream_load(const double* p) {
@@ -299,6 +303,8 @@ __global__ __launch_bounds__(kTile / PPT, REPLAY ? HH_REPLAY_MINW : 1) void eule
     // the tile's increments: element (step, comp, lane) at ((step*NC + comp)*256 + lane)
     const double* __restrict__ base =
         a.replay + (size_t)tile * n_steps * NC * kTile + (size_t)tid * PPT;
+    // steps per chunk: the price-only kernel (one trajectory per lane) moves 4 steps at a time
+    constexpr int kChunk = (P == 0 && !ANTI && RING == 0) ? HH_REPLAY_CHUNK_PRICE : HH_REPLAY_CHUNK;
     Vec A[kChunk][NC], B[kChunk][NC];
 
     auto load = [&](Vec(&buf)[kChunk][NC], uint32_t s0) {

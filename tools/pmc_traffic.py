@@ -3,8 +3,9 @@
 --kernel-trace only) into profiles/pmc_traffic.json, which bench.py reports as roofline.traffic.
 
 gfx950 corrections (MI355X_MICROARCH.md §HBM): the counters are in KiB; FETCH_SIZE reports exactly
-half of the bytes of a wide coalesced streaming read (16 B per lane, which is what the REPLAY
-kernel issues), so the read side is doubled; WRITE_SIZE is exact for streaming stores (checked here
+half of the bytes of a wide coalesced streaming read, so the read side is doubled (calibrated for
+this kernel: 8 B per lane, a wave covers 4 full 128-B lines; raw count identical to the 16 B/lane
+form on the same 4.032 GB buffer); WRITE_SIZE is exact for streaming stores (checked here
 against wiener_fill_kernel, whose store volume is known exactly).
 
 usage: tools/pmc_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> [tag]
@@ -15,7 +16,7 @@ import json
 import os
 import sys
 
-KERNEL = "euler_kernel<hh::HestonModel<0, true>, 0, true, false, 2, 4, false>"  # price-only REPLAY, drain ring
+KERNEL = "euler_kernel<hh::HestonModel<0, true>, 0, true, false, 1, 0, false>"  # price-only REPLAY (256 threads)
 
 
 def per_kernel(path, counter):
@@ -42,7 +43,7 @@ def main():
         "read_bytes_corrected": 2.0 * f_kib * 1024.0,
         "write_bytes": w_kib * 1024.0,
         "hbm_bytes_per_launch": 2.0 * f_kib * 1024.0 + w_kib * 1024.0,
-        "correction": "FETCH_SIZE x2 (gfx950, 16 B/lane coalesced streaming reads), KiB -> bytes",
+        "correction": "FETCH_SIZE x2 (gfx950: 128-B requests of a coalesced streaming read tallied at 64 B; the 8 B/lane loads of this kernel give the same raw count as the 16 B/lane kernel it replaced on the same buffer), KiB -> bytes",
         "calibration": {"wiener_fill_kernel_WRITE_SIZE_bytes": write[fill][0] * 1024.0 if fill else None,
                         "expected_bytes": 3907 * 252 * 2 * 256 * 8},
         "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py "

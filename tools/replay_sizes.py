@@ -25,10 +25,11 @@ for n in [int(x) for x in (sys.argv[1:] or ["100000", "1000000", "4000000", "100
     c = _ffi.make_config(1, 0, n, steps, noise_mode=1)
     c.replay, c.replay_on_device, c.replay_len = rep.data_ptr(), 1, rep.numel()
     ctx.enable_timing(True)
-    for _ in range(12):
+    for _ in range(int(os.environ.get('HH_SIZES_LAUNCHES', '12'))):
         ctx.check(lib.hh_mc_accumulate(h, C.byref(m), C.byref(c), acc.data_ptr(), None))
     ctx.synchronize()
     t = np.array(ctx.read_timings())
+    t = t[len(t) // 4:]  # past the first launches
     ctx.enable_timing(False)
     gbs = 16e-9 * n * steps / (t * 1e-3)
     out[n] = dict(ms=[round(float(x), 4) for x in t], GBs_median=round(float(np.median(gbs)), 1),
