@@ -332,25 +332,23 @@ __global__ __launch_bounds__(kTile / PPT, REPLAY ? HH_REPLAY_MINW : 1) void eule
       }
     };
 
-    // Which REPLAY pipeline (measurements: DESIGN.md §5, tools/tune_replay.py, tools/replay_sizes.py).
-    // RING > 0: each wave moves its half-tile (128 trajectories = 1 KiB per step and component)
-    // through a PRIVATE ring of RING chunks in LDS, filled by LDS-DMA (global_load_lds_dwordx4: 16 B
-    // per lane straight into LDS, no VGPR staging).  A wave reads back only what it wrote itself, so
-    // there is no workgroup barrier in the loop, only s_waitcnt.
-    //  * PIPE = false, the form used when the grid fills the chip: the wave DRAINS its LDS-DMA
-    //    (vmcnt(0)) before reading a chunk, so its own loads never overlap its own arithmetic;
-    //    overlap comes from the other waves of the CU, whose number the ring's LDS footprint caps
-    //    (4 x 2 steps x 2 components x 1 KiB x 2 waves = 32 KiB per workgroup -> 8 waves per CU,
-    //    32 KiB in flight per CU).  That is the fastest point found at 10^6 trajectories (6.9 TB/s):
-    //    more waves, more bytes per wave or a pipelined ring all put more requests in flight and
-    //    LOWER the achieved bandwidth (6.4-6.7 TB/s).
-    //  * PIPE = true, for grids that cannot fill the chip: counted waits keep the RING-1 younger
-    //    chunks in flight while chunk k is consumed (28 KiB per wave at RING = 8): 1.6x the drain
-    //    form's bandwidth at 10^5 trajectories.  The read-back then has to be invisible to the
-    //    compiler (inline ds_read_b128): it treats any LDS read it knows about as aliasing ALL
-    //    outstanding LDS-DMA and puts s_waitcnt vmcnt(0) in front of it.
-    // RING = 0 (dual partials, antithetic pairs): two register chunks, load(B) || compute(A) — with
-    // more arithmetic per step the LDS forms measured slower (0.81 vs 0.72 ms, 0.76 vs 0.70 ms).
+    // Which REPLAY pipeline (measurements: DESIGN.md §5, tools/tune_replay.py, tools/replay_sizes.py,
+    // tools/ubench/hbm_read_sweep.hip).
+    // RING = 0, what ships: two register chunks, load(B) || compute(A), and an LDS allocation that
+    // is never touched — HBM delivers most when a CU runs few concurrent 1 MB streams, so the
+    // occupancy is capped from outside: 79 KiB (2 workgroups of 256 threads = 8 waves per CU) for the
+    // price-only kernel, 24 KiB (12 waves) for the dual-partial kernels, none for the antithetic one.
+    // RING > 0 (-DHH_REPLAY_LDS, price-only kernel with PPT = 2): each wave moves its half-tile
+    // through a PRIVATE ring of RING chunks in LDS filled by LDS-DMA (global_load_lds_dwordx4: 16 B
+    // per lane straight into LDS, no VGPR staging, no workgroup barrier).  It ties with the shipped
+    // form at 10^6 trajectories — because its LDS footprint happens to cap the occupancy the same
+    // way — and loses at every smaller size; kept for A/B.
+    //  * PIPE = false: the wave DRAINS its LDS-DMA (vmcnt(0)) before reading a chunk, so its own
+    //    loads never overlap its own arithmetic (4 slots x 2 steps = 32 KiB per workgroup).
+    //  * PIPE = true, used for grids of <= kDeepRingTiles workgroups: counted waits keep the RING-1
+    //    younger chunks in flight.  The read-back then has to be invisible to the compiler (inline
+    //    ds_read_b128): it treats any LDS read it knows about as aliasing ALL outstanding LDS-DMA
+    //    and puts s_waitcnt vmcnt(0) in front of it.
     constexpr int R = RING;
     constexpr bool kUseLds = R > 0 && PPT == 2;
     if constexpr (kUseLds) {
