@@ -244,6 +244,15 @@ struct VecOf<2> {
 #ifndef HH_REPLAY_PPT
 #define HH_REPLAY_PPT 1  // trajectories per lane of the price-only REPLAY kernel: 256-thread workgroups
 #endif
+#ifndef HH_REPLAY_PPT_ANTI
+#define HH_REPLAY_PPT_ANTI 2
+#endif
+#ifndef HH_REPLAY_PPT_DUAL
+#define HH_REPLAY_PPT_DUAL 2
+#endif
+#ifndef HH_REPLAY_CHUNK_PPT1
+#define HH_REPLAY_CHUNK_PPT1 4
+#endif
 #ifndef HH_REPLAY_CHUNK_PRICE
 #define HH_REPLAY_CHUNK_PRICE 4
 #endif
@@ -304,7 +313,7 @@ __global__ __launch_bounds__(kTile / PPT, REPLAY ? HH_REPLAY_MINW : 1) void eule
     const double* __restrict__ base =
         a.replay + (size_t)tile * n_steps * NC * kTile + (size_t)tid * PPT;
     // steps per chunk: the price-only kernel (one trajectory per lane) moves 4 steps at a time
-    constexpr int kChunk = (P == 0 && !ANTI && RING == 0) ? HH_REPLAY_CHUNK_PRICE : HH_REPLAY_CHUNK;
+    constexpr int kChunk = (P == 0 && !ANTI && RING == 0) ? HH_REPLAY_CHUNK_PRICE : (PPT == 1 ? HH_REPLAY_CHUNK_PPT1 : HH_REPLAY_CHUNK);
     Vec A[kChunk][NC], B[kChunk][NC];
 
     auto load = [&](Vec(&buf)[kChunk][NC], uint32_t s0) {
@@ -782,7 +791,7 @@ constexpr uint32_t kDeepRingTiles = 512;
 
 template <class M, int P, bool REPLAY, bool ANTI>
 static int launch_euler_t(const SimArgs<P>& a, hipStream_t s) {
-  constexpr int PPT = !REPLAY ? 1 : (P == 0 && !ANTI) ? HH_REPLAY_PPT : 2;
+  constexpr int PPT = !REPLAY ? 1 : (P == 0 && !ANTI) ? HH_REPLAY_PPT : (P == 0 ? HH_REPLAY_PPT_ANTI : HH_REPLAY_PPT_DUAL);
   constexpr int RING = !REPLAY ? 0 : ANTI ? HH_REPLAY_LDS_ANTI : P > 0 ? HH_REPLAY_LDS_DUAL
                                                                      : HH_REPLAY_LDS;
   const dim3 g(a.n_tiles), b(kTile / PPT);
