@@ -659,7 +659,10 @@ __global__ __launch_bounds__(kTile) void wiener_fill_kernel(double rho, double r
   }
 }
 
-constexpr int kPackSteps = 8;
+#ifndef HH_PACK_STEPS
+#define HH_PACK_STEPS 4  // steps per workgroup of the path-major -> tile-major repack (4.6 TB/s read+write; 8: 4.2, 16: 2.8)
+#endif
+constexpr int kPackSteps = HH_PACK_STEPS;
 
 // src[path][step][comp] -> dst[tile][step][comp][256], transposed through LDS so that both the
 // reads (along step·comp) and the writes (along path) are contiguous per wave.
