@@ -235,3 +235,17 @@ def test_rate_curve_against_the_reference_test_vectors():
     tau = 365 / 365
     assert hh.zero_rate(flat, t1) == pytest.approx(r, abs=g["atol"])                       # :61
     assert hh.df(flat, t1) == pytest.approx(math.exp(-r * tau), abs=g["atol"])              # :62
+
+
+@pytest.mark.skipif(__import__("shutil").which("hipcc") is None, reason="needs hipcc")
+def test_optional_ring_form_of_the_replay_kernel_still_compiles(tmp_path):
+    """The LDS-DMA ring form of the price-only REPLAY kernel is kept behind compile-time knobs for
+    A/B runs (tools/tune_replay.py): it must keep compiling for gfx950."""
+    import subprocess
+    src = os.path.join(ROOT, "hedgehog.jl_amd", "csrc", "hh_kernels.hip")
+    out = tmp_path / "ring.o"
+    proc = subprocess.run(["hipcc", "-c", "-O1", "-std=c++17", "--offload-arch=gfx950",
+                           "-ffp-contract=off", "-DHH_REPLAY_LDS=4", "-DHH_REPLAY_PPT=2",
+                           "-DHH_REPLAY_PAD_KIB=0", src, "-o", str(out)],
+                          capture_output=True, text=True)
+    assert proc.returncode == 0, proc.stderr[-2000:]
