@@ -260,6 +260,31 @@ def main():
                 "fourier": [0.65565115, 40.7248418, 56.3225943]},
         }
 
+        # the rows widened beyond the headline path: one timing each, same C-ABI
+        import math
+        n_l, st_l = 1_000_000, 100
+        m_l = _ffi.make_model(S0=100.0, sigma=0.2, r=0.05, T=1.0, strike=100.0, cp=-1.0)
+        c_l = _ffi.make_config(_ffi.HH_LOGNORMAL, _ffi.HH_EXACT_LAW, n_l, st_l, antithetic=1)
+        c_l.seeds, c_l.seeds_on_device, c_l.seeds_len = seeds.data_ptr(), 1, n_paths
+        r_l = _ffi.hh_lsm_result()
+        for _ in range(3):
+            ctx.check(lib.hh_lsm_solve(h, C.byref(m_l), C.byref(c_l), 5, math.exp(-0.05 / st_l),
+                                       C.byref(r_l), None, None, None))
+        n_g, st_g = 200_000, 12
+        c_g = _ffi.make_config(_ffi.HH_HESTON, _ffi.HH_BROADIE_KAYA, n_g, st_g)
+        c_g.seeds, c_g.seeds_on_device, c_g.seeds_len = seeds.data_ptr(), 1, n_paths
+        r_g = _ffi.hh_result()
+        for _ in range(2):
+            ctx.check(lib.hh_heston_exact_grid(h, C.byref(model), C.byref(c_g), None, None, 0,
+                                               C.byref(r_g)))
+        out["widened_rows"] = {
+            "lsm_american_put_2e6_paths_x_100_dates": {"kernel_ms": r_l.kernel_ms, "price": r_l.price,
+                                                       "std_error": r_l.std_error},
+            "heston_exact_grid_2e5_paths_x_12_dates": {
+                "kernel_ms": r_g.kernel_ms, "transitions_per_s": n_g * st_g / (r_g.kernel_ms * 1e-3),
+                "cf_terms_per_transition": r_g.bk_cf_terms / (n_g * st_g)},
+        }
+
     # ---- bounded-sample checks against the CPU oracle (rank 0, N = 1 only) ------------------
     if world == 1 and not args.no_cpu_baseline:
         from tests import oracle_ffi  # the ONLY use of the oracle here: checker + timed CPU baseline
