@@ -16,6 +16,8 @@ Rank 0 prints ONE JSON line.  Besides the contract's keys it carries
   cpu_baseline  the CPU oracle (oracle/hh_oracle.c, a port) timed on this host on a bounded sample
   generate      the same workload with the increments drawn in-kernel from Philox (VALU-bound)
   price_check   |price - CPU reference| on identical draws (bounded sample of the same buffer)
+  other_configs kernel times of BASELINE configs 2, 4, 5 (N = 1 only)
+  widened_rows  kernel times of the rows widened beyond the headline path: LSM, exact Heston grid
 """
 from __future__ import annotations
 
