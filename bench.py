@@ -5,19 +5,33 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One "step" = one complete pass of the path over one batch: every rank integrates its 10^6
-trajectories x 252 Euler steps from Wiener increments already resident in HBM (REPLAY, the mode the
-HBM roofline is quoted for: 16 algorithmic bytes per path-step), reduces the discounted payoff
-sums, and (N > 1) all-reduces the 16-double accumulator vector over RCCL.  Paths shard
-embarrassingly: weak scaling, 10^6 paths per GPU.
+`--gpus N` with N > 1 and no RANK in the environment starts N ranks itself (one child process per
+GPU, rendezvous on 127.0.0.1) BEFORE anything touches a GPU; under torch.distributed.run the ranks
+are taken from the environment and must agree with --gpus.  A box with fewer than N GPUs is an
+error, never a silent single-rank run.
+
+One "step" = one complete pass of the path over one batch: every rank integrates its trajectories
+x 252 Euler steps from Wiener increments already resident in HBM (REPLAY, the mode the HBM roofline
+is quoted for: 16 algorithmic bytes per path-step), reduces the discounted payoff sums, and (N > 1)
+all-reduces the 16-double accumulator vector over RCCL — the path's only exchange.
+  default            weak scaling: --paths (10^6) trajectories per GPU
+  --global-paths G   strong scaling: G trajectories split over the ranks by contiguous ranges
+                     (hedgehog_jl_amd.shard_range), e.g. north_star's 10^7
 
 Rank 0 prints ONE JSON line.  Besides the contract's keys it carries
-  roofline      dominant kernel (euler_kernel REPLAY): algorithmic bytes / HIP-event time vs 8 TB/s
-  cpu_baseline  the CPU oracle (oracle/hh_oracle.c, a port) timed on this host on a bounded sample
-  generate      the same workload with the increments drawn in-kernel from Philox (VALU-bound)
-  price_check   |price - CPU reference| on identical draws (bounded sample of the same buffer)
-  other_configs kernel times of BASELINE configs 2, 4, 5 (N = 1 only)
-  widened_rows  kernel times of the rows widened beyond the headline path: LSM, exact Heston grid
+  roofline        dominant kernel (euler_kernel REPLAY): algorithmic bytes / HIP-event time vs 8 TB/s
+  cpu_baseline    the CPU oracle (oracle/hh_oracle.c, a port) timed on this host on a bounded sample
+  generate        the same workload with the increments drawn in-kernel from Philox — what a caller
+                  of the drop-in solve() gets (VALU-bound)
+  config5_greeks  BASELINE config 5 (Δ, ∂V0, ρ in one fused pass) under the same N ranks
+  strong_scaling  10^7 global trajectories split over the N ranks (when run in the weak default)
+  price_check     |price - CPU reference| on identical draws (bounded sample of the same buffer)
+  other_configs   BASELINE configs 2 and 4, each with its own roofline entry (N = 1 only)
+  widened_rows    LSM and the exact Heston grid, each with a roofline entry (N = 1 only)
+Every roofline entry: {bound, achieved, peak, unit, frac}; HBM-bound kernels price algorithmic
+bytes against 8 TB/s; VALU-bound kernels price SQ_INSTS_VALU x 4 SIMD-cycles (an fp64 FMA holds a
+SIMD's vector pipe for 4 cycles) against 1024 SIMDs x 2.4 GHz, the instruction counts being read
+from profiles/valu_insts.json (a rocprofv3 --pmc pass, file-sourced and labelled so).
 """
 from __future__ import annotations
 
@@ -25,6 +39,8 @@ import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -37,44 +53,236 @@ import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 BYTES_PER_PATH_STEP = 16.0   # two fp64 increments read once
+SIMD_CYCLES_PEAK = 256 * 4 * 2.4e9  # 256 CUs x 4 SIMDs x 2.4 GHz max clock (MI355X_MICROARCH.md)
+VALU_CYCLES_PER_INST = 4.0   # wave64 fp64 FMA: 4 cycles on a SIMD (78.6 TFLOP/s fp64 vector peak)
 
 # benchmark problem H252
 H252 = dict(S0=100.0, V0=0.04, kappa=2.0, theta=0.04, sigma=0.3, rho=-0.7, r=0.03, T=1.0,
             strike=100.0, cp=1.0)
 H252_ANALYTIC = 9.242521073959068  # Carr–Madan restatement, SURVEY.md §8c (sanity band only)
+H252_GREEKS_FOURIER = [0.65565115, 40.7248418, 56.3225943]  # ∂S0, ∂V0, ∂r
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    # 200 timed steps after 20 warm-ups (0.25 s in all): the first ~25 launches of a fresh process
-    # run 3-8 % slower than the steady state (clock / memory-system transient), whichever kernel form
+    # 200 timed steps after 20 warm-ups (0.25 s in all) when no flags are given
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--paths", type=int, default=1_000_000, help="trajectories per GPU")
+    ap.add_argument("--paths", type=int, default=1_000_000, help="trajectories per GPU (weak scaling)")
+    ap.add_argument("--global-paths", type=int, default=0,
+                    help="strong scaling: this many trajectories in all, split over the ranks")
     ap.add_argument("--nsteps", type=int, default=252, help="Euler steps per trajectory")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra", action="store_true", help="skip the other BASELINE configs")
+    ap.add_argument("--no-extra", action="store_true", help="skip everything but the headline lines")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    return ap.parse_args()
+    ap.add_argument("--ramp-ms", type=float, default=30.0,
+                    help="GPU time spent on the same kernel before the W warm-up steps, so that the "
+                         "timed region runs at the clock a pricing service sees in steady state "
+                         "(the first ~15 ms of a fresh process run 3-8 %% slower); reported as "
+                         "clock_ramp_ms, 0 disables")
+    # rehearsal knobs (tests): ranks on one GPU need gloo (RCCL refuses two ranks per device)
+    ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl")
+    ap.add_argument("--devices", default="", help="comma list: device ordinal of each local rank")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="launcher/rendezvous/sharding only, no GPU work (CPU test of the N-rank path)")
+    return ap.parse_args(argv)
+
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _device_list(args):
+    if args.devices:
+        devs = [int(x) for x in args.devices.split(",")]
+        if len(devs) != args.gpus:
+            sys.exit(f"bench.py: --devices lists {len(devs)} ordinals for --gpus {args.gpus}")
+        return devs
+    return list(range(args.gpus))
+
+
+def launch(args) -> int:
+    """Parent of an N-rank run: starts one child per rank, rank 0's stdout is ours.  Nothing here
+    initialises a GPU (torch.cuda.device_count() does not, on this image)."""
+    devs = _device_list(args)
+    if not args.rehearse:
+        have = torch.cuda.device_count()
+        if have <= max(devs):
+            print(f"bench.py: --gpus {args.gpus} needs device ordinals {devs} but this host has "
+                  f"{have} GPU(s); refusing to run fewer ranks than asked", file=sys.stderr)
+            return 2
+        if args.backend == "nccl" and len(set(devs)) != len(devs):
+            print("bench.py: RCCL needs one device per rank (use --backend gloo to rehearse ranks "
+                  "on a shared GPU)", file=sys.stderr)
+            return 2
+    port = _free_port()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0",
+                   HH_BENCH_CHILD="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]],
+                                      env=env, stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    deadline = time.time() + 1500
+    pending = list(procs)
+    while pending and time.time() < deadline:
+        for p in list(pending):
+            code = p.poll()
+            if code is None:
+                continue
+            pending.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                for q in pending:  # one rank failed: the others would wait in a collective forever
+                    q.terminate()
+        time.sleep(0.05)
+    for p in pending:
+        p.kill()
+        rc = rc or 124
+    return rc
+
+
+class Dist:
+    """The process group of this run (or none), with the two collectives the bench needs."""
+
+    def __init__(self, args):
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.backend = args.backend
+        self.pg = None
+        if self.world != args.gpus:
+            sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={self.world}: the launcher and "
+                     "the flag must agree")
+        devs = _device_list(args)
+        self.device_index = devs[self.local_rank] if self.local_rank < len(devs) else self.local_rank
+        if "RANK" in os.environ:  # launched by us or by torch.distributed.run (also with 1 rank)
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29500")
+            kw = {}
+            if args.backend == "nccl" and not args.rehearse:
+                torch.cuda.set_device(self.device_index)
+                kw["device_id"] = torch.device("cuda", self.device_index)
+            dist.init_process_group("gloo" if args.rehearse else args.backend, rank=self.rank,
+                                    world_size=self.world, **kw)
+            self.pg = dist
+
+    @property
+    def on(self):
+        return self.pg is not None
+
+    def all_reduce_sum(self, t, async_op=False):
+        """SUM all-reduce of a device tensor: in place over RCCL; through host memory under gloo."""
+        if self.pg is None:
+            return None
+        if t.is_cuda and self.backend == "gloo":
+            h = t.cpu()
+            self.pg.all_reduce(h)
+            t.copy_(h)
+            return None
+        return self.pg.all_reduce(t, async_op=async_op)
+
+    def max_float(self, x, dev):
+        if self.pg is None:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device="cpu" if self.backend == "gloo" else dev)
+        self.pg.all_reduce(t, op=self.pg.ReduceOp.MAX)
+        return float(t.item())
+
+    def count_ranks(self, dev):
+        """ranks that really take part in the collective: an all-reduce of ones"""
+        if self.pg is None:
+            return 1
+        t = torch.ones(1, dtype=torch.float64, device=dev)
+        self.all_reduce_sum(t)
+        return int(round(float(t.item())))
+
+    def barrier(self):
+        if self.pg is not None:
+            self.pg.barrier()
+
+    def close(self):
+        if self.pg is not None:
+            self.pg.barrier()
+            self.pg.destroy_process_group()
+            self.pg = None
+
+
+def shard_of(n_global, rank, world):
+    """contiguous ranges of ceil(N/G) trajectories (hedgehog_jl_amd.shard_range)"""
+    per = -(-n_global // world)
+    a = min(n_global, rank * per)
+    return a, min(n_global, a + per)
+
+
+def rehearse(args, d):
+    """Launcher + rendezvous + collective + sharding with no GPU: what the CPU test runs."""
+    n_global = args.global_paths or args.paths * d.world
+    a, b = shard_of(n_global, d.rank, d.world) if args.global_paths else \
+        (d.rank * args.paths, (d.rank + 1) * args.paths)
+    ranks = d.count_ranks("cpu")
+    cover = torch.tensor([float(b - a)], dtype=torch.float64)
+    d.all_reduce_sum(cover)
+    d.close()
+    if d.rank == 0:
+        print(json.dumps({"rehearsal": True, "n_gpus": d.world, "rccl_ranks": ranks,
+                          "backend": "gloo", "scaling": "strong" if args.global_paths else "weak",
+                          "global_paths": n_global, "paths_covered": int(cover.item()),
+                          "shard_rank0": [a, b], "value": None}), flush=True)
+
+
+def valu_insts():
+    """VALU wave-instructions per launch of the VALU-bound kernels (rocprofv3 --pmc SQ_INSTS_VALU,
+    tools/valu_insts.py) — file-sourced, the time beside it is measured live."""
+    p = os.path.join(ROOT, "profiles", "valu_insts.json")
+    try:
+        return json.load(open(p))
+    except Exception:
+        return {}
+
+
+def hbm_roofline(kernel, bytes_per_launch, ms, **extra):
+    ach = bytes_per_launch / (ms * 1e-3) / 1e9
+    r = {"bound": "hbm", "kernel": kernel, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+         "frac": ach / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": bytes_per_launch,
+         "kernel_ms": ms}
+    r.update(extra)
+    return r
+
+
+def valu_roofline(kernel, key, units, ms, table):
+    """fp64-VALU issue fraction: SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x 2.4 GHz x time)."""
+    ent = table.get(key)
+    if not ent:
+        return {"bound": "valu", "kernel": kernel, "achieved": None, "peak": SIMD_CYCLES_PEAK / 1e9,
+                "unit": "G SIMD-cycles/s", "frac": None, "kernel_ms": ms,
+                "note": "no instruction count for this kernel in profiles/valu_insts.json"}
+    insts = ent["valu_insts_per_unit"] * units
+    ach = insts * VALU_CYCLES_PER_INST / (ms * 1e-3)
+    return {"bound": "valu", "kernel": kernel, "achieved": ach / 1e9, "peak": SIMD_CYCLES_PEAK / 1e9,
+            "unit": "G SIMD-cycles/s", "frac": ach / SIMD_CYCLES_PEAK, "kernel_ms": ms,
+            "valu_insts_per_unit": ent["valu_insts_per_unit"], "unit_of_work": ent.get("unit"),
+            "insts_source": "profiles/valu_insts.json (" + ent.get("source", "rocprofv3 --pmc") + ")"}
 
 
 def main():
     args = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = None
-    if world > 1 or "RANK" in os.environ:  # launched by torch.distributed.run (also with 1 rank)
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29500")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(0)
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(launch(args))
+    d = Dist(args)
+    if args.rehearse:
+        rehearse(args, d)
+        return
+    rank, world = d.rank, d.world
+    if not torch.cuda.is_available() or torch.cuda.device_count() <= d.device_index:
+        sys.exit(f"bench.py: rank {rank} needs cuda:{d.device_index}; there is no CPU fallback")
+    torch.cuda.set_device(d.device_index)
+    dev = torch.device("cuda", d.device_index)
 
     import hedgehog_jl_amd as hh
     from hedgehog_jl_amd import _ffi
@@ -83,43 +291,46 @@ def main():
     lib, h = ctx.lib, ctx.handle
     stream = torch.cuda.current_stream(dev)
     ctx.set_stream(stream.cuda_stream)
+    rccl_ranks = d.count_ranks(dev)
+    if rccl_ranks != world:
+        sys.exit(f"bench.py: all-reduce of ones gave {rccl_ranks}, expected {world}")
 
-    n_paths, n_steps = args.paths, args.nsteps
-    # seeds[i] = global 1-based trajectory index; shard = contiguous range
-    g0 = rank * n_paths
-    seeds = torch.arange(g0 + 1, g0 + n_paths + 1, dtype=torch.int64, device=dev)
+    n_steps = args.nsteps
     model = _ffi.make_model(**H252)
 
-    # synthetic input, generated on the device BEFORE the timed region: correlated increments
-    n_el = lib.hh_replay_elems(n_paths, n_steps, _ffi.HH_HESTON)
-    dW = torch.empty(n_el, dtype=torch.float64, device=dev)
-    ctx.check(lib.hh_wiener_fill(h, _ffi.HH_HESTON, model.rho, model.T, n_steps, n_paths,
-                                 seeds.data_ptr(), 1, dW.data_ptr()))
-    accum = torch.zeros(_ffi.HH_ACC_LEN, dtype=torch.float64, device=dev)
+    class Shard:
+        """This rank's trajectories [g0, g0 + n) and their increments, resident in HBM."""
 
-    def config(noise):
-        c = _ffi.make_config(_ffi.HH_HESTON, _ffi.HH_EULER_MARUYAMA, n_paths, n_steps,
-                             noise_mode=noise)
-        c.seeds, c.seeds_on_device = seeds.data_ptr(), 1
-        c.replay, c.replay_on_device = dW.data_ptr(), 1
-        return c
+        def __init__(self, g0, n):
+            self.g0, self.n = g0, n
+            # seeds[i] = global 1-based trajectory index (BASELINE.md §3)
+            self.seeds = torch.arange(g0 + 1, g0 + n + 1, dtype=torch.int64, device=dev)
+            n_el = lib.hh_replay_elems(n, n_steps, _ffi.HH_HESTON)
+            self.dW = torch.empty(n_el, dtype=torch.float64, device=dev)
+            ctx.check(lib.hh_wiener_fill(h, _ffi.HH_HESTON, model.rho, model.T, n_steps, n,
+                                         self.seeds.data_ptr(), 1, self.dW.data_ptr()))
 
-    cfg_rep, cfg_gen = config(_ffi.HH_NOISE_REPLAY), config(_ffi.HH_NOISE_GENERATE)
+        def config(self, noise, n_partials=0):
+            c = _ffi.make_config(_ffi.HH_HESTON, _ffi.HH_EULER_MARUYAMA, self.n, n_steps,
+                                 noise_mode=noise, n_partials=n_partials)
+            c.seeds, c.seeds_on_device, c.seeds_len = self.seeds.data_ptr(), 1, self.n
+            c.replay, c.replay_on_device, c.replay_len = self.dW.data_ptr(), 1, self.dW.numel()
+            return c
 
     # Steps are independent pricing jobs: the (latency-bound, 128-byte) all-reduce of step k is
     # issued asynchronously on RCCL's stream and overlaps the simulation kernel of step k+1; two
     # accumulator buffers alternate, and every all-reduce has completed before the clock stops.
-    accums = [accum, torch.zeros_like(accum)]
+    accums = [torch.zeros(_ffi.HH_ACC_LEN, dtype=torch.float64, device=dev) for _ in range(2)]
     pending = [None, None]
 
-    def step(cfg, i):
+    def step(mdl, cfg, i):
         b = i & 1
         if pending[b] is not None:
             pending[b].wait()
             pending[b] = None
-        ctx.check(lib.hh_mc_accumulate(h, C.byref(model), C.byref(cfg), accums[b].data_ptr(), None))
-        if dist is not None:  # the path's one exchange: 16 doubles, SUM
-            pending[b] = dist.all_reduce(accums[b], async_op=True)
+        ctx.check(lib.hh_mc_accumulate(h, C.byref(mdl), C.byref(cfg), accums[b].data_ptr(), None))
+        if d.on:  # the path's one exchange: 16 doubles, SUM
+            pending[b] = d.all_reduce_sum(accums[b], async_op=True)
         return b
 
     def drain():
@@ -128,60 +339,74 @@ def main():
                 pending[b].wait()
                 pending[b] = None
 
-    def timed(cfg, k, w):
+    def timed(mdl, cfg, k, w, ramp_ms=0.0):
+        """W untimed warm-up steps, then EXACTLY k steps between barrier + synchronize on both
+        sides; MAX over ranks.  -> (seconds, per-launch kernel ms, accumulator, ramp ms spent)"""
+        ramp = 0.0
+        if ramp_ms > 0.0:  # bring the device to its steady clock on the same kernel (disclosed)
+            t0 = time.perf_counter()
+            i = 0
+            while (time.perf_counter() - t0) * 1e3 < ramp_ms:
+                for _ in range(8):
+                    step(mdl, cfg, i)
+                    i += 1
+                drain()
+                torch.cuda.synchronize(dev)
+            ramp = (time.perf_counter() - t0) * 1e3
         last = 0
         for i in range(w):
-            step(cfg, i)
+            step(mdl, cfg, i)
         drain()
         ctx.enable_timing(True)
-        if dist is not None:
-            dist.barrier()
+        d.barrier()
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
         for i in range(k):
-            last = step(cfg, i)
+            last = step(mdl, cfg, i)
         drain()
         torch.cuda.synchronize(dev)
-        if dist is not None:
-            dist.barrier()
+        d.barrier()
         dt = time.perf_counter() - t0
         kern_ms = ctx.read_timings()
         ctx.enable_timing(False)
-        if dist is not None:
-            t = torch.tensor([dt], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-        accum.copy_(accums[last])
-        return dt, kern_ms
+        dt = d.max_float(dt, dev)
+        return dt, kern_ms, accums[last].cpu().numpy().copy(), d.max_float(ramp, dev)
 
-    dt_rep, kern_rep = timed(cfg_rep, args.steps, args.warmup)
-    acc_rep = accum.cpu().numpy().copy()
-    dt_gen, kern_gen = timed(cfg_gen, args.steps, args.warmup)
-    acc_gen = accum.cpu().numpy().copy()
+    def finalize(mdl, cfg, acc):
+        r = _ffi.hh_result()
+        lib.hh_mc_finalize(C.byref(mdl), C.byref(cfg), acc.ctypes.data, C.byref(r))
+        return r
 
-    # every collective of the run is behind us: all ranks leave the process group together, here;
-    # rank 0 then measures the single-GPU extras (other configs, CPU baseline) on its own
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
-        dist = None
-    if rank != 0:
-        return
+    # ---- the headline workload ------------------------------------------------------------------
+    strong = args.global_paths > 0
+    if strong:
+        g0, g1 = shard_of(args.global_paths, rank, world)
+        if g1 <= g0:
+            sys.exit("bench.py: --global-paths leaves a rank without trajectories")
+        n_global = args.global_paths
+    else:
+        g0, g1 = rank * args.paths, (rank + 1) * args.paths
+        n_global = world * args.paths
+    sh = Shard(g0, g1 - g0)
+    n_paths = sh.n
+    cfg_rep, cfg_gen = sh.config(_ffi.HH_NOISE_REPLAY), sh.config(_ffi.HH_NOISE_GENERATE)
 
-    total_path_steps = float(world) * n_paths * n_steps
+    dt_rep, kern_rep, acc_rep, ramp_ms = timed(model, cfg_rep, args.steps, args.warmup, args.ramp_ms)
+    dt_gen, kern_gen, acc_gen, _ = timed(model, cfg_gen, args.steps, args.warmup)
+    res, res_gen = finalize(model, cfg_rep, acc_rep), finalize(model, cfg_gen, acc_gen)
+    total_path_steps = float(n_global) * n_steps
     value = total_path_steps * args.steps / dt_rep
-    res = _ffi.hh_result()
-    lib.hh_mc_finalize(C.byref(model), C.byref(cfg_rep), acc_rep.ctypes.data, C.byref(res))
-    res_gen = _ffi.hh_result()
-    lib.hh_mc_finalize(C.byref(model), C.byref(cfg_gen), acc_gen.ctypes.data, C.byref(res_gen))
+    vt = valu_insts() if rank == 0 else {}
 
-    kern_s = float(np.mean(kern_rep)) * 1e-3
-    achieved = BYTES_PER_PATH_STEP * n_paths * n_steps / kern_s / 1e9
-    traffic = None
+    kern_ms = float(np.mean(kern_rep))
+    traffic, traffic_source = None, None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(tpath):
-        try:
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+    if os.path.exists(tpath) and n_paths == 1_000_000 and n_steps == 252:
+        try:  # PMC counters cannot be read from inside this process: a committed rocprofv3 pass
+            tj = json.load(open(tpath))
+            traffic = tj.get("hbm_bytes_per_launch")
+            traffic_source = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, " \
+                             "separate passes, same workload; not measured in this run)"
         except Exception:
             traffic = None
 
@@ -190,38 +415,92 @@ def main():
         "value": value,
         "unit": "path-steps/s",
         "n_gpus": world,
+        "rccl_ranks": rccl_ranks,
         "steps": args.steps,
         "warmup": args.warmup,
+        "clock_ramp_ms": ramp_ms,
         "ms_per_step": dt_rep / args.steps * 1e3,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if strong else "weak",
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic (Philox-generated correlated Wiener increments, resident in HBM)",
         "config": {"workload": "HestonDynamics EulerMaruyama European call H252 "
-                               "(configs[2]): %d paths x %d steps per GPU, NoVarianceReduction, "
-                               "noise REPLAY" % (n_paths, n_steps),
-                   "paths_per_gpu": n_paths, "n_steps": n_steps, "global_paths": world * n_paths,
+                               "(configs[2]): %d paths x %d steps %s, NoVarianceReduction, "
+                               "noise REPLAY" % (n_paths if not strong else n_global, n_steps,
+                                                 "in all" if strong else "per GPU"),
+                   "paths_per_gpu": n_paths, "n_steps": n_steps, "global_paths": n_global,
+                   "backend": "rccl" if args.backend == "nccl" else args.backend,
                    "parallelism": "path-sharded x%d, one 16-double all-reduce" % world},
         "price": res.price,
         "std_error": res.std_error,
         "analytic_carr_madan": H252_ANALYTIC,
-        "roofline": {
-            "bound": "hbm", "kernel": "euler_kernel<HestonModel,REPLAY>",
-            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-            "algorithmic_bytes_per_launch": BYTES_PER_PATH_STEP * n_paths * n_steps,
-            "kernel_ms_avg": kern_s * 1e3, "kernel_ms_min": float(np.min(kern_rep)),
-            "launches_timed": len(kern_rep)},
+        "roofline": dict(hbm_roofline("euler_kernel<HestonModel,REPLAY> (rank 0's launches)",
+                                      BYTES_PER_PATH_STEP * n_paths * n_steps, kern_ms),
+                         traffic=traffic, traffic_source=traffic_source,
+                         kernel_ms_avg=kern_ms, kernel_ms_min=float(np.min(kern_rep)),
+                         launches_timed=len(kern_rep)),
         "generate": {
             "value": total_path_steps * args.steps / dt_gen, "unit": "path-steps/s",
+            "what": "the same workload with in-kernel Philox — the mode hh.solve() / the Julia "
+                    "solve_hip() use by default; REPLAY needs the caller's increments",
             "ms_per_step": dt_gen / args.steps * 1e3,
-            "kernel_ms_avg": float(np.mean(kern_gen)), "bound": "valu (Philox + Box-Muller, fp64)",
             "price": res_gen.price,
-            "rel_diff_vs_replay": abs(res_gen.price - res.price) / abs(res.price)},
+            "rel_diff_vs_replay": abs(res_gen.price - res.price) / abs(res.price),
+            "roofline": valu_roofline("euler_kernel<HestonModel,GENERATE>", "heston_euler_generate",
+                                      float(n_paths) * n_steps, float(np.mean(kern_gen)), vt)},
     }
 
-    # ---- the other BASELINE.json configurations, a few launches each (rank 0, N = 1 only) -----
+    if not args.no_extra:
+        # ---- BASELINE config 5 under the same N ranks: Δ, ∂V0, ρ in one fused pass ---------------
+        sd = {"S0": [1, 0, 0], "V0": [0, 1, 0], "r_drift": [0, 0, 1],
+              "discount": [0, 0, -float(np.exp(-H252["r"] * H252["T"]))]}
+        m5 = _ffi.make_model(**H252, seeds=sd, n_partials=3)
+        c5 = sh.config(_ffi.HH_NOISE_REPLAY, n_partials=3)
+        k5 = min(args.steps, 50)
+        dt5, kern5, acc5, _ = timed(m5, c5, k5, min(args.warmup, 5))
+        r5 = finalize(m5, c5, acc5)
+        t5 = float(np.mean(kern5))
+        out["config5_greeks"] = {
+            "what": "BatchGreekProblem (Δ, ∂V0, ρ) as 3 dual partials through Heston Euler, REPLAY, "
+                    "%d ranks, one all-reduce of the same 16 doubles" % world,
+            "value": total_path_steps * k5 / dt5, "unit": "path-steps/s", "steps": k5,
+            "ms_per_step": dt5 / k5 * 1e3, "price": r5.price,
+            "greeks": [r5.dprice[k] for k in range(3)], "fourier": H252_GREEKS_FOURIER,
+            "roofline": hbm_roofline("euler_kernel<HestonModel,P=1,REPLAY> (one carried derivative)",
+                                     BYTES_PER_PATH_STEP * n_paths * n_steps, t5)}
+
+        # ---- strong scaling on north_star's 10^7 trajectories (when the headline ran weak) ---------
+        if not strong:
+            del cfg_rep, cfg_gen, c5
+            G = 10_000_000
+            a, b = shard_of(G, rank, world)
+            sh = None
+            torch.cuda.empty_cache()
+            sh = Shard(a, b - a)
+            cs = sh.config(_ffi.HH_NOISE_REPLAY)
+            ks = min(args.steps, 40 if world == 1 else 100)
+            dts, kerns, accs, _ = timed(model, cs, ks, min(args.warmup, 5))
+            rs = finalize(model, cs, accs)
+            out["strong_scaling"] = {
+                "global_paths": G, "paths_this_rank": sh.n, "scaling": "strong", "steps": ks,
+                "value": float(G) * n_steps * ks / dts, "unit": "path-steps/s",
+                "ms_per_step": dts / ks * 1e3, "price": rs.price, "std_error": rs.std_error,
+                "roofline": hbm_roofline("euler_kernel<HestonModel,REPLAY> (rank 0's shard)",
+                                         BYTES_PER_PATH_STEP * sh.n * n_steps,
+                                         float(np.mean(kerns)))}
+            del cs
+            sh = None
+            torch.cuda.empty_cache()
+            sh = Shard(g0, g1 - g0)  # the headline shard again, for the single-GPU extras below
+
+    # every collective of the run is behind us: all ranks leave the process group together, here;
+    # rank 0 then measures the single-GPU extras (other configs, CPU baseline) on its own
+    d.close()
+    if rank != 0:
+        return
+
+    accum = accums[0]
     if world == 1 and not args.no_extra:
         def kernel_ms(mdl, cfg, reps=5):
             ctx.check(lib.hh_mc_accumulate(h, C.byref(mdl), C.byref(cfg), accum.data_ptr(), None))
@@ -230,36 +509,34 @@ def main():
                 ctx.check(lib.hh_mc_accumulate(h, C.byref(mdl), C.byref(cfg), accum.data_ptr(), None))
             t = float(np.median(ctx.read_timings()))
             ctx.enable_timing(False)
-            r = _ffi.hh_result()
-            a = accum.cpu().numpy().copy()
-            lib.hh_mc_finalize(C.byref(mdl), C.byref(cfg), a.ctypes.data, C.byref(r))
-            return t, r
+            return t, finalize(mdl, cfg, accum.cpu().numpy().copy())
 
-        sd = {"S0": [1, 0, 0], "V0": [0, 1, 0], "r_drift": [0, 0, 1],
-              "discount": [0, 0, -float(np.exp(-H252["r"] * H252["T"]))]}
-        m5 = _ffi.make_model(**H252, seeds=sd, n_partials=3)
-        c5 = config(_ffi.HH_NOISE_REPLAY)
-        c5.n_partials = 3
-        t5, r5 = kernel_ms(m5, c5)
         c4 = _ffi.make_config(_ffi.HH_HESTON, _ffi.HH_BROADIE_KAYA, n_paths)
-        c4.seeds, c4.seeds_on_device = seeds.data_ptr(), 1
+        c4.seeds, c4.seeds_on_device = sh.seeds.data_ptr(), 1
         t4, r4 = kernel_ms(model, c4, reps=3)
         m2 = _ffi.make_model(S0=100.0, sigma=0.2, r=0.05, T=1.0, strike=100.0)
         c2 = _ffi.make_config(_ffi.HH_LOGNORMAL, _ffi.HH_EXACT_LAW, n_paths)
-        c2.seeds, c2.seeds_on_device = seeds.data_ptr(), 1
+        c2.seeds, c2.seeds_on_device = sh.seeds.data_ptr(), 1
         t2, r2 = kernel_ms(m2, c2)
+        ca = sh.config(_ffi.HH_NOISE_REPLAY)
+        ca.antithetic = 1
+        ta, ra = kernel_ms(model, ca)
         out["other_configs"] = {
-            "config2_lognormal_exact": {"paths_per_s": n_paths / (t2 * 1e-3), "kernel_ms": t2,
-                                        "price": r2.price, "analytic": 10.450583572185565},
-            "config4_broadie_kaya": {"paths_per_s": n_paths / (t4 * 1e-3), "kernel_ms": t4,
-                                     "price": r4.price, "std_error": r4.std_error,
-                                     "cf_terms_per_path": r4.bk_cf_terms / n_paths,
-                                     "bisect_fallbacks": int(r4.bk_bisect_fallback)},
-            "config5_greeks_delta_dV0_rho_replay": {
-                "path_steps_per_s": n_paths * n_steps / (t5 * 1e-3), "kernel_ms": t5,
-                "hbm_GBs": BYTES_PER_PATH_STEP * n_paths * n_steps / (t5 * 1e-3) / 1e9,
-                "greeks": [r5.dprice[k] for k in range(3)],
-                "fourier": [0.65565115, 40.7248418, 56.3225943]},
+            "config2_lognormal_exact": {
+                "paths_per_s": n_paths / (t2 * 1e-3), "kernel_ms": t2, "price": r2.price,
+                "analytic": 10.450583572185565,
+                "roofline": valu_roofline("exact_gbm_kernel", "lognormal_exact", float(n_paths), t2, vt)},
+            "config4_broadie_kaya": {
+                "paths_per_s": n_paths / (t4 * 1e-3), "kernel_ms": t4, "price": r4.price,
+                "std_error": r4.std_error, "cf_terms_per_path": r4.bk_cf_terms / n_paths,
+                "bisect_fallbacks": int(r4.bk_bisect_fallback),
+                "roofline": valu_roofline("bk_kernel + bk_scan_kernel + bk_fallback_kernel",
+                                          "broadie_kaya", float(n_paths), t4, vt)},
+            "config3_antithetic_replay": {
+                "integrated_path_steps_per_s": 2.0 * n_paths * n_steps / (ta * 1e-3),
+                "kernel_ms": ta, "price": ra.price, "std_error": ra.std_error,
+                "roofline": hbm_roofline("euler_kernel<HestonModel,REPLAY,ANTI>",
+                                         BYTES_PER_PATH_STEP * n_paths * n_steps, ta)},
         }
 
         # the rows widened beyond the headline path: one timing each, same C-ABI
@@ -267,24 +544,33 @@ def main():
         n_l, st_l = 1_000_000, 100
         m_l = _ffi.make_model(S0=100.0, sigma=0.2, r=0.05, T=1.0, strike=100.0, cp=-1.0)
         c_l = _ffi.make_config(_ffi.HH_LOGNORMAL, _ffi.HH_EXACT_LAW, n_l, st_l, antithetic=1)
-        c_l.seeds, c_l.seeds_on_device, c_l.seeds_len = seeds.data_ptr(), 1, n_paths
+        c_l.seeds, c_l.seeds_on_device, c_l.seeds_len = sh.seeds.data_ptr(), 1, n_paths
         r_l = _ffi.hh_lsm_result()
-        for _ in range(3):
+        t_l = []
+        for _ in range(4):
             ctx.check(lib.hh_lsm_solve(h, C.byref(m_l), C.byref(c_l), 5, math.exp(-0.05 / st_l),
                                        C.byref(r_l), None, None, None))
+            t_l.append(r_l.kernel_ms)
+        t_lsm = float(np.min(t_l[1:]))
         n_g, st_g = 200_000, 12
         c_g = _ffi.make_config(_ffi.HH_HESTON, _ffi.HH_BROADIE_KAYA, n_g, st_g)
-        c_g.seeds, c_g.seeds_on_device, c_g.seeds_len = seeds.data_ptr(), 1, n_paths
+        c_g.seeds, c_g.seeds_on_device, c_g.seeds_len = sh.seeds.data_ptr(), 1, n_paths
         r_g = _ffi.hh_result()
         for _ in range(2):
             ctx.check(lib.hh_heston_exact_grid(h, C.byref(model), C.byref(c_g), None, None, 0,
                                                C.byref(r_g)))
         out["widened_rows"] = {
-            "lsm_american_put_2e6_paths_x_100_dates": {"kernel_ms": r_l.kernel_ms, "price": r_l.price,
-                                                       "std_error": r_l.std_error},
+            "lsm_american_put_2e6_paths_x_100_dates": {
+                "kernel_ms": t_lsm, "price": r_l.price, "std_error": r_l.std_error,
+                # the spot grid written once by the path kernel and read once by the backward
+                # induction: 2 x 8 B per (trajectory, date)
+                "roofline": hbm_roofline("gbm_grid_kernel + LSM backward induction (whole chain)",
+                                         16.0 * 2 * n_l * (st_l + 1), t_lsm)},
             "heston_exact_grid_2e5_paths_x_12_dates": {
                 "kernel_ms": r_g.kernel_ms, "transitions_per_s": n_g * st_g / (r_g.kernel_ms * 1e-3),
-                "cf_terms_per_transition": r_g.bk_cf_terms / (n_g * st_g)},
+                "cf_terms_per_transition": r_g.bk_cf_terms / (n_g * st_g),
+                "roofline": valu_roofline("bk_kernel chain, one transition per date",
+                                          "heston_exact_grid", float(n_g) * st_g, r_g.kernel_ms, vt)},
         }
 
     # ---- bounded-sample checks against the CPU oracle (rank 0, N = 1 only) ------------------
@@ -294,9 +580,9 @@ def main():
         tiles = 200                                   # 51,200 trajectories of the SAME buffer
         ns = min(n_paths, tiles * _ffi.HH_TILE_PATHS)
         n_s_el = lib.hh_replay_elems(ns, n_steps, _ffi.HH_HESTON)
-        dW_s = dW[:n_s_el].cpu().numpy()
+        dW_s = sh.dW[:n_s_el].cpu().numpy()
         c_s = _ffi.make_config(_ffi.HH_HESTON, _ffi.HH_EULER_MARUYAMA, ns, n_steps,
-                            noise_mode=_ffi.HH_NOISE_REPLAY, replay=dW_s)
+                               noise_mode=_ffi.HH_NOISE_REPLAY, replay=dW_s)
         r_gpu = _ffi.hh_result()
         ctx.check(lib.hh_mc_solve(h, C.byref(model), C.byref(c_s), C.byref(r_gpu), None))
         threads = orc.num_threads()

@@ -7,6 +7,7 @@ independent of the sharding, so N-GPU and 1-GPU results differ only by the order
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -23,6 +24,40 @@ def shard_range(n_paths: int, rank: int, world: int):
     return start, min(n_paths, start + per)
 
 
+_checked_groups: set = set()
+
+
+def rank_device(default: int, group=None, device=None) -> int:
+    """HIP device ordinal this rank computes on.  An explicit `device` wins; inside an initialised
+    process group of more than one rank it is LOCAL_RANK (what torch.distributed.run exports), else
+    torch's current device; a single process keeps `default` (MonteCarlo.device).  An RCCL ("nccl")
+    group whose ranks share a device is rejected — the all-reduce would fail with a duplicate-GPU
+    error or, worse, serialise every shard on one GPU (checked once per group)."""
+    import torch
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return int(default if device is None else device)
+    if device is None:
+        if "LOCAL_RANK" in os.environ:
+            device = int(os.environ["LOCAL_RANK"])
+        elif torch.cuda.is_available():
+            device = torch.cuda.current_device()
+        else:
+            device = default
+    device = int(device)
+    if dist.get_backend(group) == "nccl" and id(group) not in _checked_groups:
+        import socket
+        mine = (socket.gethostname(), device)
+        everyone = [None] * dist.get_world_size(group)
+        dist.all_gather_object(everyone, mine, group=group)
+        if len(set(everyone)) != len(everyone):
+            raise ValueError(f"RCCL needs one GPU per rank, but the ranks of this group sit on "
+                             f"{everyone}: start one process per GPU (torch.distributed.run sets "
+                             f"LOCAL_RANK) or pass device= explicitly")
+        _checked_groups.add(id(group))
+    return device
+
+
 def _hip_accumulate(model, cfg, device):
     """Default accumulate: HIP kernels, accumulators left in HBM as a torch tensor."""
     import torch
@@ -35,9 +70,11 @@ def _hip_accumulate(model, cfg, device):
     return acc
 
 
-def solve_sharded(prob, method: MonteCarlo, group=None, accumulate=None) -> MonteCarloSolution:
+def solve_sharded(prob, method: MonteCarlo, group=None, accumulate=None,
+                  device=None) -> MonteCarloSolution:
     """solve(prob, method) with the trajectories of `method.config` sharded over the ranks of
     `group` (default: the world).  Every rank returns the same MonteCarloSolution (ensemble=None).
+    The rank's GPU is `device`, else LOCAL_RANK (see rank_device).
 
     `accumulate(model, cfg, device) -> tensor[HH_ACC_LEN]` is the per-shard kernel driver; the
     default runs the HIP path (and raises without a GPU).  Tests inject a CPU checker here to
@@ -55,7 +92,7 @@ def solve_sharded(prob, method: MonteCarlo, group=None, accumulate=None) -> Mont
         seeds = np.ascontiguousarray(seeds[start:stop] if stop > start else seeds[:1])
     c.seeds = seeds.ctypes.data
     c.seeds_len = seeds.size
-    acc = (accumulate or _hip_accumulate)(model, c, method.device)
+    acc = (accumulate or _hip_accumulate)(model, c, rank_device(method.device, group, device))
     if not isinstance(acc, torch.Tensor):
         acc = torch.as_tensor(np.asarray(acc, dtype=np.float64))
     if world > 1:  # the path's one exchange
@@ -86,7 +123,7 @@ def _all_reduce_device(t, group):
     t.copy_(h)
 
 
-def solve_lsm_sharded(prob, method, group=None, stopping_info: bool = False):
+def solve_lsm_sharded(prob, method, group=None, stopping_info: bool = False, device=None):
     """solve(prob, ::LSM) (least_squares_montecarlo.jl:99-136) with the trajectories sharded over the
     ranks of `group`.  Unlike the European solve this path HAS exchange steps: the regression of
     every exercise date needs sums over all trajectories, so the induction runs in phases
@@ -116,8 +153,9 @@ def solve_lsm_sharded(prob, method, group=None, stopping_info: bool = False):
     steps, degree = mc.config.steps, method.degree
     step_discount = float(df(m.rate, m.referenceDate + (T / steps) * MILLISECONDS_IN_YEAR_365))
 
-    dev = torch.device("cuda", mc.device)
-    ctx = _ffi.get_context(mc.device)
+    dev_index = rank_device(mc.device, group, device)
+    dev = torch.device("cuda", dev_index)
+    ctx = _ffi.get_context(dev_index)
     ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
     lib, h = ctx.lib, ctx.handle
     x = torch.zeros(lib.hh_lsm_shard_xchg_elems(steps, degree), dtype=torch.float64, device=dev)

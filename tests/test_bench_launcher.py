@@ -1,0 +1,104 @@
+"""bench.py --gpus N must really run N ranks (the driver's scaling run depends on it).
+
+CPU part: the launcher, the 127.0.0.1 rendezvous, the all-reduce that counts the ranks and the
+shard ranges, rehearsed without a GPU (`--rehearse`, gloo).  GPU part: N > the box's GPUs fails
+loudly; two ranks on the one GPU of the test box (gloo standing in for RCCL, which refuses two
+ranks per device) run the real kernels and price exactly what one process prices."""
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def run_bench(*flags, env=None, timeout=600):
+    e = {k: v for k, v in os.environ.items()
+         if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    e.update(env or {})
+    p = subprocess.run([sys.executable, BENCH, *flags], env=e, capture_output=True, text=True,
+                       timeout=timeout)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    return p, (json.loads(lines[-1]) if lines else None)
+
+
+@pytest.mark.timeout(300)
+def test_launcher_starts_n_ranks_weak():
+    p, out = run_bench("--gpus", "2", "--rehearse")
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert len([ln for ln in p.stdout.splitlines() if ln.startswith("{")]) == 1  # rank 0 only
+    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["scaling"] == "weak"
+    assert out["global_paths"] == 2_000_000 and out["paths_covered"] == 2_000_000
+
+
+@pytest.mark.timeout(300)
+def test_launcher_strong_scaling_ranges_cover_the_ensemble():
+    p, out = run_bench("--gpus", "3", "--rehearse", "--global-paths", "10000000")
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert out["n_gpus"] == 3 and out["rccl_ranks"] == 3 and out["scaling"] == "strong"
+    assert out["paths_covered"] == 10_000_000 and out["shard_rank0"] == [0, 3_333_334]
+
+
+@pytest.mark.timeout(300)
+def test_rank_count_must_agree_with_the_flag():
+    # as torch.distributed.run would start it, but with a --gpus that disagrees: loud, non-zero
+    p, out = run_bench("--gpus", "2", "--rehearse",
+                       env=dict(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1",
+                                MASTER_PORT="29611"))
+    assert p.returncode != 0 and out is None
+    assert "WORLD_SIZE" in p.stderr
+
+
+@pytest.mark.timeout(300)
+def test_more_ranks_than_gpus_is_refused():
+    import torch
+    have = torch.cuda.device_count()
+    p, out = run_bench("--gpus", str(max(have, 1) + 1), "--steps", "2", "--warmup", "1")
+    assert p.returncode == 2 and out is None
+    assert "refusing" in p.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_two_ranks_on_this_gpu_price_what_one_process_prices(hhlib):
+    from hedgehog_jl_amd import _ffi
+    n = 100_000
+    p, out = run_bench("--gpus", "2", "--backend", "gloo", "--devices", "0,0", "--paths", str(n),
+                       "--steps", "3", "--warmup", "1", "--ramp-ms", "0", "--no-cpu-baseline")
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["scaling"] == "weak"
+    assert out["config"]["global_paths"] == 2 * n
+    # one process, the whole ensemble, increments drawn in-kernel from the same seeds
+    m = _ffi.make_model()
+    c = _ffi.make_config(_ffi.HH_HESTON, _ffi.HH_EULER_MARUYAMA, 2 * n, 252,
+                         seeds=np.arange(1, 2 * n + 1, dtype=np.uint64))
+    r = _ffi.hh_result()
+    hhlib.check(hhlib.lib.hh_mc_solve(hhlib.handle, C.byref(m), C.byref(c), C.byref(r), None))
+    assert out["price"] == pytest.approx(r.price, rel=1e-12)
+    assert out["generate"]["price"] == pytest.approx(r.price, rel=1e-12)
+    g = out["config5_greeks"]
+    assert g["price"] == pytest.approx(r.price, rel=1e-12)
+    assert g["greeks"][0] == pytest.approx(0.6557, abs=0.02)  # Δ of the H252 call
+    s = out["strong_scaling"]
+    assert s["global_paths"] == 10_000_000 and s["paths_this_rank"] == 5_000_000
+    assert s["price"] == pytest.approx(9.2425, abs=0.05)
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_one_rank_line_keeps_the_contract(hhlib):
+    p, out = run_bench("--gpus", "1", "--steps", "5", "--warmup", "2", "--no-cpu-baseline",
+                       "--no-extra")
+    assert p.returncode == 0, p.stderr[-3000:]
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
+                "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in out
+    assert out["n_gpus"] == 1 and out["rccl_ranks"] == 1 and out["steps"] == 5
+    rf = out["roofline"]
+    assert rf["bound"] == "hbm" and rf["frac"] == pytest.approx(rf["achieved"] / rf["peak"])
+    assert rf["launches_timed"] == 5

@@ -54,9 +54,18 @@ def _problems():
 def _worker(rank, world, port, out):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ["LOCAL_RANK"] = str(rank)  # what torch.distributed.run exports
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         res = []
+        seen = []
+
+        def on_my_gpu(model, cfg, device):  # the shard must be driven on LOCAL_RANK's device,
+            seen.append(device)             # not on MonteCarlo.device's default 0
+            return _oracle_accumulate(model, cfg, device)
+
+        sol = hh.solve_sharded(*_problems()[0], accumulate=on_my_gpu)
+        assert seen == [rank] and hh.rank_device(0) == rank and hh.rank_device(0, device=5) == 5
         for prob, method in _problems():
             sol = hh.solve_sharded(prob, method, accumulate=_oracle_accumulate)
             res.append((sol.price, sol.std_error, int(sol.result.n_paths_done)))
