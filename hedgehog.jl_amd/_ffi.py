@@ -63,7 +63,12 @@ class hh_result(C.Structure):
 class hh_lsm_result(C.Structure):
     _fields_ = [("price", C.c_double), ("std_error", C.c_double), ("n_paths_total", C.c_uint64),
                 ("rows_regressed", C.c_uint32), ("rows_skipped", C.c_uint32),
-                ("kernel_ms", C.c_double), ("total_ms", C.c_double)]
+                ("kernel_ms", C.c_double), ("total_ms", C.c_double),
+                ("form", C.c_int32), ("reserved_", C.c_int32)]
+
+
+HH_OPT_LSM_FORM = 1
+HH_LSM_FORM_PER_DATE, HH_LSM_FORM_PERSISTENT = 0, 1
 
 
 class HedgehogMCError(RuntimeError):
@@ -84,6 +89,7 @@ SYMBOLS = [
     ("hh_ctx_set_stream", C.c_int, [_vp, _vp]),
     ("hh_ctx_reset_stream", C.c_int, [_vp]),
     ("hh_last_error", C.c_char_p, [_vp]),
+    ("hh_ctx_set_option", C.c_int, [_vp, C.c_int32, C.c_int64]),
     ("hh_mc_solve", C.c_int, [_vp, C.POINTER(hh_model), C.POINTER(hh_config), C.POINTER(hh_result), _vp]),
     ("hh_mc_accumulate", C.c_int, [_vp, C.POINTER(hh_model), C.POINTER(hh_config), _vp, _vp]),
     ("hh_mc_finalize", C.c_int, [C.POINTER(hh_model), C.POINTER(hh_config), _vp, C.POINTER(hh_result)]),
@@ -162,6 +168,9 @@ class Context:
             self.check(self.lib.hh_ctx_reset_stream(self.handle))
         else:
             self.check(self.lib.hh_ctx_set_stream(self.handle, _vp(stream)))
+
+    def set_option(self, option: int, value: int):
+        self.check(self.lib.hh_ctx_set_option(self.handle, int(option), int(value)))
 
     def synchronize(self):
         self.check(self.lib.hh_ctx_synchronize(self.handle))

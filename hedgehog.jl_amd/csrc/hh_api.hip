@@ -55,6 +55,8 @@ struct hh_ctx {
     int32_t degree = 0;
     double step_discount = 1.0;
   } shard;
+  int lsm_form = hh::kLsmFormPersistent;  // hh_ctx_set_option(HH_OPT_LSM_FORM)
+  uint64_t lsm_persistent_fallbacks = 0;  // persistent launches that gave up and were redone per date
   double* accum = nullptr;       // device, HH_ACC_LEN
   double* accum_host = nullptr;  // pinned, HH_ACC_LEN
   // optional per-launch timing of the simulation kernel (hh_ctx_enable_timing)
@@ -244,6 +246,20 @@ int hh_ctx_reset_stream(hh_ctx* ctx) {
 }
 
 const char* hh_last_error(const hh_ctx* ctx) { return ctx ? ctx->err : kNoCtx; }
+
+int hh_ctx_set_option(hh_ctx* ctx, int32_t option, int64_t value) {
+  if (!ctx) return HH_ERR_INVALID;
+  std::lock_guard<std::recursive_mutex> lock__(ctx->mu);
+  switch (option) {
+    case HH_OPT_LSM_FORM:
+      if (value != HH_LSM_FORM_PER_DATE && value != HH_LSM_FORM_PERSISTENT)
+        return fail(ctx, HH_ERR_INVALID, "HH_OPT_LSM_FORM: 0 (launch per date) or 1 (one launch)");
+      ctx->lsm_form = (int)value;
+      return HH_OK;
+    default:
+      return fail(ctx, HH_ERR_INVALID, "unknown option %d", option);
+  }
+}
 
 int hh_ctx_synchronize(hh_ctx* ctx) {
   if (!ctx) return HH_ERR_INVALID;
@@ -582,9 +598,24 @@ static int lsm_on_grid(hh_ctx* ctx, const double* grid_dev, uint64_t ntot, uint3
   const size_t nscr = hh::lsm_scratch_doubles(ntot, n_steps, degree);
   if ((rc = ensure(ctx, ctx->lsm_scratch, ctx->lsm_scratch_cap, nscr))) return rc;
   if ((rc = ensure(ctx, ctx->records, ctx->records_cap, (size_t)ch * hh::kRecStride))) return rc;
+  int form_used = hh::kLsmFormPerDate;
   HH_HIP(ctx, hh::launch_lsm(grid_dev, ntot, n_steps, m->strike, m->cp, step_discount, degree,
                              ctx->lsm_tau, ctx->lsm_val, ctx->lsm_scratch, ctx->records,
-                             ctx->stream));
+                             ctx->stream, ctx->lsm_form, &form_used));
+  if (form_used == hh::kLsmFormPersistent) {
+    // the one-launch form leaves a word behind when its workgroups could not all be resident
+    // together (another kernel held CUs): nothing was written then, and the per-date form runs
+    unsigned int gave_up = 0;
+    HH_HIP(ctx, hipMemcpyAsync(&gave_up, hh::lsm_persistent_status(ctx->lsm_scratch),
+                               sizeof(gave_up), hipMemcpyDeviceToHost, ctx->stream));
+    HH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (gave_up) {
+      ++ctx->lsm_persistent_fallbacks;
+      HH_HIP(ctx, hh::launch_lsm(grid_dev, ntot, n_steps, m->strike, m->cp, step_discount, degree,
+                                 ctx->lsm_tau, ctx->lsm_val, ctx->lsm_scratch, ctx->records,
+                                 ctx->stream, hh::kLsmFormPerDate, &form_used));
+    }
+  }
   HH_HIP(ctx, hh::launch_reduce_records(ctx->records, ch, (double)ntot, ctx->accum, ctx->stream));
   HH_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
   double counters[2] = {0, 0};
@@ -608,6 +639,7 @@ static int lsm_on_grid(hh_ctx* ctx, const double* grid_dev, uint64_t ntot, uint3
   out->n_paths_total = ntot;
   out->rows_regressed = (uint32_t)counters[0];
   out->rows_skipped = (uint32_t)counters[1];
+  out->form = form_used;
   float ms = 0.f;
   HH_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
   out->kernel_ms = ms;

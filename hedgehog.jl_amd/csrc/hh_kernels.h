@@ -116,9 +116,17 @@ int launch_lsm_phase(int phase, uint32_t t, const double* grid, uint64_t ntot, u
                      double* vec_out, hipStream_t s);
 int launch_gbm_grid(const uint64_t* seeds_dev, uint64_t n_paths, uint32_t n_steps, double S0,
                     double r, double sigma, double T, int anti, double* grid, hipStream_t s);
+// form: kLsmFormPersistent = the whole backward induction in ONE launch when the ensemble fits the
+// chip (else it falls back by itself), kLsmFormPerDate = one launch per exercise date.  *form_used
+// says which was enqueued; after a persistent launch the caller synchronises and reads the word at
+// lsm_persistent_status(scratch): non-zero = a workgroup gave up waiting (the grid was not
+// co-resident) and nothing was written — run the per-date form instead.  Both forms give
+// bit-identical results.
+enum { kLsmFormPerDate = 0, kLsmFormPersistent = 1 };
 int launch_lsm(const double* grid, uint64_t ntot, uint32_t n_steps, double strike, double cp,
                double step_discount, int degree, int32_t* tau, double* val, double* scratch,
-               double* records, hipStream_t s);
+               double* records, hipStream_t s, int form, int* form_used);
+const unsigned int* lsm_persistent_status(const double* scratch);
 int launch_wiener_fill(int dynamics, double rho, double sqrt_dt, uint32_t n_steps, uint64_t n_paths,
                        const uint64_t* seeds_dev, double* dst, hipStream_t s);
 int launch_replay_pack(int ncomp, uint64_t n_paths, uint32_t n_steps, const double* src_dev,

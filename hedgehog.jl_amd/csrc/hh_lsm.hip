@@ -3,17 +3,35 @@
 // American,…}}, ::LSM), src/pricing_methods/least_squares_montecarlo.jl:99-165, on the paths of
 // sde_problem(::LognormalDynamics, ::BlackScholesExact) (montecarlo.jl:140-159, antithetic :270-284).
 //
-// Layout: spot grid S[step][path] (step-major: every backward step streams two contiguous rows),
+// Layout: spot grid S[step][path] (step-major: every backward step streams contiguous rows),
 // per-path stopping state tau[path] (int32), val[path] (fp64).
 //
-// The backward induction is serial in time but data-parallel over paths; each step is ONE launch:
-//   reduce last launch's partial moment sums Σ z^k y  ->  solve the (d+1)x(d+1) normal equations
-//   (every workgroup redundantly, same order => same coefficients)  ->  exercise decision for its
-//   own paths  ->  its partial moment sums for the NEXT (earlier) row.
-// Everything that depends on the spots only (in-the-money count, mean, std, power sums Σ z^k of every
-// row) is precomputed for all rows in three launches.  The regression is done in the standardised
-// variable z = (x - mean)/std: same polynomial space as Polynomials.fit(x, y, degree) (:126), so the
-// fitted function is the same; its Gram matrix is well conditioned in fp64.
+// The backward induction is serial in time and data-parallel over paths.  What couples the paths
+// is, per exercise date t, a handful of sums over ALL of them: the in-the-money statistics
+// (n, Σx, Σx²) that standardise the regressor z = (x - mean)/std, the power sums Σ z^k (the Gram
+// matrix of Polynomials.fit(x, y, degree), :126, in the z basis — same polynomial space, well
+// conditioned in fp64) and the moment sums Σ z^k y.  Two forms compute them, with the SAME
+// summation tree (so their coefficients, stopping decisions and prices are bit-identical):
+//
+//  * ONE PERSISTENT LAUNCH (lsm_persistent_kernel; ensembles of up to 256 chunks): every
+//    workgroup keeps the stopping state of its trajectories in registers for the whole induction
+//    and reads every row of the grid exactly once.  Per date the workgroups publish one record
+//    {Σ z^k y of row t-1, Σ z^k of row t-1, statistics of row t-2} and gather everybody's — an
+//    all-gather by write-through stores + per-record epoch tags polled with sc1 loads (the
+//    hand-off of cdna_hip_programming.md §6 Guideline 16, row 1 of its table) — then each of them
+//    reduces the records in the fixed order, solves the normal equations redundantly and takes the
+//    exercise decisions of its own trajectories.  No launch, no re-load of tau / val / spots, no
+//    separate passes for the statistics and the power sums.
+//  * ONE LAUNCH PER DATE (lsm_step_kernel & co.): statistics and power sums of every row in one-off
+//    launches, then a launch per exercise date.  Used for larger ensembles, when the persistent
+//    grid cannot be resident, and — cut at the global sums — for ensembles sharded over several
+//    GPUs (launch_lsm_phase), where the host all-reduces between launches.
+//
+// Summation tree (independent of the form and of the GPU): chunk = 1024 lanes x Q trajectories
+// (trajectory = chunk·1024·Q + j·1024 + lane; Q = 1 up to 2^18 trajectories, else 8); a lane adds
+// its Q terms in order j; a wave adds its 64 lanes by the butterfly (l, l^32), (l, l^16), …; the
+// chunk adds its 16 waves in order; the records of the chunks are dealt to 256 lanes (r, r+256, …,
+// added in order) which are summed by the same butterfly and, over their 4 waves, in order.
 #include <cmath>
 
 #include "hh_kernels.h"
@@ -23,18 +41,19 @@ namespace hh {
 
 namespace {
 
-constexpr int kLsmChunk = 1024;  // paths per workgroup (256 threads x 4) of the one-off kernels
-// The backward-step kernels take Q paths per thread: 4, or 16 for large ensembles — every workgroup
-// re-reduces all workgroups' partial moment sums at the start of a step, n_chunks²·(D+1) reads per
-// exercise date, which at 2·10⁶ paths and 1024-path chunks is more traffic than the paths themselves
-#ifndef HH_LSM_WIDE_Q
-#define HH_LSM_WIDE_Q 8
-#endif
-constexpr uint64_t kLsmWideFrom = 1ull << 19;  // ensembles from this size on use Q = HH_LSM_WIDE_Q
-// paths per workgroup of the one-off row-statistics kernels (grid = chunks x rows): with 1024 the
-// workgroup reductions of the 3 / 2D+1 sums cost more than reading the paths
-inline uint32_t lsm_one_off_paths(uint64_t ntot) { return ntot >= kLsmWideFrom ? 8192u : 1024u; }
+constexpr int kLsmFinalChunk = 1024;  // paths per workgroup of the final Σ, Σ² kernel (16-double records)
+constexpr int kLsmWg = 1024;          // threads per workgroup of every kernel that forms canonical sums
+constexpr int kLsmWaves = kLsmWg / 64;
 constexpr int kLsmMaxDeg = 8;
+constexpr uint64_t kLsmQ1Max = 1ull << 18;  // up to here one trajectory per lane, beyond it 8
+constexpr int kLsmMaxResident = 256;        // chunks the persistent form handles (one per workgroup)
+constexpr int kLsmRing = 4;                 // record slots of the persistent all-gather (2 suffice)
+
+inline int lsm_q(uint64_t ntot) { return ntot <= kLsmQ1Max ? 1 : 8; }
+inline uint32_t lsm_nch(uint64_t ntot) {
+  const uint64_t per = (uint64_t)kLsmWg * lsm_q(ntot);
+  return (uint32_t)((ntot + per - 1) / per);
+}
 
 // ---- full path grid -----------------------------------------------------------------------
 
@@ -68,93 +87,347 @@ __global__ __launch_bounds__(256) void gbm_grid_kernel(const uint64_t* __restric
   }
 }
 
-// ---- helpers --------------------------------------------------------------------------------
+// ---- the canonical reductions ----------------------------------------------------------------
 
-template <int N>
-__device__ __forceinline__ void block_sum(double (&v)[N], double (&out)[N]) {
-  // all threads receive the workgroup sums (fixed order: wave tree, then waves 0..3)
-  __shared__ double sm[4][N];
-  __syncthreads();  // protect sm from a previous use
+constexpr int pow2_ge(int n) { return n <= 1 ? 1 : n <= 2 ? 2 : n <= 4 ? 4 : n <= 8 ? 8 : n <= 16 ? 16 : n <= 32 ? 32 : 64; }
+constexpr int log2_of(int p) { return p <= 1 ? 0 : 1 + log2_of(p / 2); }
+
+// 64 lanes x P2 values -> P2 totals, each the butterfly tree ((l, l^32), (l, l^16), …, (l, l^1)) over
+// the lanes.  While more than one value is left per lane the exchange also TRANSPOSES: the lower
+// lane of a pair keeps the first half of the values, the upper lane the second half, so a step
+// moves half as many values as the one before (P2 + log2(64/P2) exchanges instead of 6·P2).  The
+// tree — and so every bit of the totals — is the same for every P2.  On return the total of value i
+// is a[0] of the lanes with (lane >> (6 - log2 P2)) == i.
+template <int P2>
+__device__ __forceinline__ void wave_reduce_multi(double (&a)[P2]) {
+  const int lane = threadIdx.x & 63;
+  int cnt = P2;
 #pragma unroll
-  for (int i = 0; i < N; ++i) {
+  for (int off = 32; off >= 1; off >>= 1) {
+    if (cnt > 1) {
+      const int h = cnt / 2;
+      const bool upper = (lane & off) != 0;
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v[i] += __shfl_down(v[i], off, 64);
+      for (int i = 0; i < P2 / 2; ++i) {
+        if (i < h) {
+          // both elements into registers first: written as `upper ? a[i] : a[i + h]` the compiler
+          // selects the ADDRESS, which makes `a` a dynamically indexed array in scratch memory
+          const double lo = a[i], hi = a[i + h];
+          const double send = upper ? lo : hi;
+          const double keep = upper ? hi : lo;
+          a[i] = keep + __shfl_xor(send, off, 64);
+        }
+      }
+      cnt = h;
+    } else {
+      a[0] += __shfl_xor(a[0], off, 64);
+    }
   }
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (lane == 0) {
-#pragma unroll
-    for (int i = 0; i < N; ++i) sm[wave][i] = v[i];
-  }
-  __syncthreads();
-#pragma unroll
-  for (int i = 0; i < N; ++i) out[i] = ((sm[0][i] + sm[1][i]) + sm[2][i]) + sm[3][i];
 }
 
-// sum NV-vectors written by `n_rec` workgroups (rec[r*NV + i]) — every workgroup does this in the
-// same order, so all of them obtain bit-identical totals
-template <int NV>
-__device__ __forceinline__ void reduce_records(const double* __restrict__ rec, uint32_t n_rec,
-                                               double (&tot)[NV]) {
-  double v[NV];
-#pragma unroll
-  for (int i = 0; i < NV; ++i) v[i] = 0.0;
-  for (uint32_t r = threadIdx.x; r < n_rec; r += 256) {
-#pragma unroll
-    for (int i = 0; i < NV; ++i) v[i] += rec[(size_t)r * NV + i];
+// NW waves x 64 lanes x P2 values -> tot[P2] in LDS (valid for every thread after the call):
+// wave butterflies, then the waves in order 0, 1, …  `scratch` holds NW·P2 doubles.  All threads of
+// the workgroup must call it (waves >= NW only take part in the barriers).
+template <int P2, int NW>
+__device__ __forceinline__ void block_reduce_multi(double (&a)[P2], double* scratch, double* tot) {
+  constexpr int kShift = 6 - log2_of(P2);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (wave < NW) {
+    wave_reduce_multi<P2>(a);
+    if ((lane & ((1 << kShift) - 1)) == 0) scratch[wave * P2 + (lane >> kShift)] = a[0];
   }
-  block_sum<NV>(v, tot);
+  __syncthreads();
+  if (threadIdx.x < P2) {
+    double t = scratch[threadIdx.x];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) t += scratch[w * P2 + threadIdx.x];
+    tot[threadIdx.x] = t;
+  }
+  __syncthreads();
+}
+
+// records of the chunks, rec[r·stride + i] (i < NV), dealt to lanes 0..255 and summed: tot[NV]
+template <int NV, int P2>
+__device__ __forceinline__ void reduce_chunk_records(const double* __restrict__ rec, uint32_t n_rec,
+                                                     int stride, double* scratch, double* tot) {
+  double a[P2];
+#pragma unroll
+  for (int i = 0; i < P2; ++i) a[i] = 0.0;
+  if (threadIdx.x < 256) {
+    for (uint32_t r = threadIdx.x; r < n_rec; r += 256) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) a[i] += rec[(size_t)r * stride + i];
+    }
+  }
+  block_reduce_multi<P2, 4>(a, scratch, tot);
 }
 
 struct RowStat {
-  double n, mu, sd;
+  double n, mu, isd;  // count, mean, 1/std of the in-the-money spots: z = (x - mu)·isd
 };
 
-// ---- precompute: per-row in-the-money statistics and power sums --------------------------------
-
-__global__ __launch_bounds__(256) void lsm_stats_kernel(const double* __restrict__ grid,
-                                                        uint64_t ntot, double strike, double cp,
-                                                        uint32_t n_chunks, uint32_t per_wg,
-                                                        double* __restrict__ rec /*[row][chunk][3]*/) {
-  const uint32_t chunk = blockIdx.x, row = blockIdx.y;
-  const double* S = grid + (size_t)row * ntot;
-  double v[3] = {0, 0, 0};
-  for (uint32_t j = 0; j < per_wg / 256; ++j) {
-    const uint64_t p = (uint64_t)chunk * per_wg + j * 256 + threadIdx.x;
-    if (p < ntot) {
-      const double x = S[p];
-      if (cp * (x - strike) > 0.0) {
-        v[0] += 1.0;
-        v[1] += x;
-        v[2] = fma(x, x, v[2]);
-      }
-    }
-  }
-  double t[3];
-  block_sum<3>(v, t);
-  if (threadIdx.x == 0) {
-    double* o = rec + ((size_t)row * n_chunks + chunk) * 3;
-    o[0] = t[0]; o[1] = t[1]; o[2] = t[2];
-  }
-}
-
-// count, mean, std of the in-the-money spots of a row from (n, Σx, Σx²)
-__device__ __forceinline__ RowStat rowstat_of(const double (&t)[3]) {
-  RowStat r{t[0], 0.0, 1.0};
-  if (t[0] > 0.0) {
-    r.mu = t[1] / t[0];
-    const double var = t[2] / t[0] - r.mu * r.mu;
-    r.sd = var > 0.0 ? sqrt(var) : 1.0;
+// from (n, Σx, Σx²); one division per ROW here instead of one per trajectory and date
+__device__ __forceinline__ RowStat rowstat_of(double n, double sx, double sxx) {
+  RowStat r{n, 0.0, 1.0};
+  if (n > 0.0) {
+    r.mu = sx / n;
+    const double var = sxx / n - r.mu * r.mu;
+    r.isd = var > 0.0 ? 1.0 / sqrt(var) : 1.0;
   }
   return r;
 }
 
-__global__ __launch_bounds__(256) void lsm_rowstat_kernel(const double* __restrict__ rec,
-                                                          uint32_t n_chunks,
-                                                          RowStat* __restrict__ rs) {
+// per-lane terms; every form calls exactly these, in trajectory order j = 0..Q-1
+__device__ __forceinline__ void add_stats(double x, double cp, double strike, double* v) {
+  if (cp * (x - strike) > 0.0) {
+    v[0] += 1.0;
+    v[1] += x;
+    v[2] = fma(x, x, v[2]);
+  }
+}
+template <int D>
+__device__ __forceinline__ void add_powers(double x, double cp, double strike, const RowStat& r,
+                                           double* v) {  // v[2D+1] += z^i
+  if (cp * (x - strike) > 0.0) {
+    const double z = (x - r.mu) * r.isd;
+    double pw = 1.0;
+#pragma unroll
+    for (int i = 0; i <= 2 * D; ++i) {
+      v[i] += pw;
+      pw *= z;
+    }
+  }
+}
+// the same without Σ z^0 (the count n): v[k-1] += z^k, k = 1..2D, the products formed exactly as above
+template <int D>
+__device__ __forceinline__ void add_powers_from1(double x, double cp, double strike, const RowStat& r,
+                                                 double* v) {
+  if (cp * (x - strike) > 0.0) {
+    const double z = (x - r.mu) * r.isd;
+    double pw = z;  // = 1.0 * z
+#pragma unroll
+    for (int i = 0; i < 2 * D; ++i) {
+      v[i] += pw;
+      pw *= z;
+    }
+  }
+}
+// Σ z^i y, y = D^(tau - row) val (least_squares_montecarlo.jl:115-116); tau >= row + 1
+template <int D>
+__device__ __forceinline__ void add_moments(double x, double cp, double strike, const RowStat& r,
+                                            double y, double* v) {  // v[D+1]
+  if (cp * (x - strike) > 0.0) {
+    const double z = (x - r.mu) * r.isd;
+    double pw = y;
+#pragma unroll
+    for (int i = 0; i <= D; ++i) {
+      v[i] += pw;
+      pw *= z;
+    }
+  }
+}
+
+// Normal equations G c = B, G_jk = P[j+k] = Σ z^(j+k); Gaussian elimination with partial pivoting,
+// rank-deficient columns (fewer distinct in-the-money spots than coefficients) dropped.  One
+// thread; every workgroup of either form runs it on the same B, P and so gets the same coef.
+template <int D>
+__device__ void solve_normal_equations(const double* B, const double* P, double* coef) {
+  constexpr int N = D + 1;
+  double M[N][N + 1];
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) M[j][k] = P[j + k];
+    M[j][N] = B[j];
+  }
+  double scale = 0.0;
+#pragma unroll
+  for (int j = 0; j < N; ++j) scale = fmax(scale, fabs(M[j][j]));
+  bool dead[N];
+#pragma unroll
+  for (int c = 0; c < N; ++c) {
+    int piv = c;
+    double best = fabs(M[c][c]);
+#pragma unroll
+    for (int j = 0; j < N; ++j)
+      if (j > c && fabs(M[j][c]) > best) {
+        best = fabs(M[j][c]);
+        piv = j;
+      }
+#pragma unroll
+    for (int j = 0; j < N; ++j)
+      if (j == piv && piv != c) {
+#pragma unroll
+        for (int k = 0; k <= N; ++k) {
+          const double tmp = M[c][k];
+          M[c][k] = M[j][k];
+          M[j][k] = tmp;
+        }
+      }
+    dead[c] = !(best > 1e-13 * scale);
+    if (!dead[c]) {
+      const double inv = 1.0 / M[c][c];
+#pragma unroll
+      for (int j = 0; j < N; ++j)
+        if (j > c) {
+          const double f = M[j][c] * inv;
+#pragma unroll
+          for (int k = 0; k <= N; ++k)
+            if (k >= c) M[j][k] = fma(-f, M[c][k], M[j][k]);
+        }
+    }
+  }
+  double cf[N];
+#pragma unroll
+  for (int c = N - 1; c >= 0; --c) {
+    double s = M[c][N];
+#pragma unroll
+    for (int k = 0; k < N; ++k)
+      if (k > c) s = fma(-M[c][k], cf[k], s);
+    cf[c] = dead[c] ? 0.0 : s / M[c][c];
+  }
+#pragma unroll
+  for (int c = 0; c < N; ++c) coef[c] = cf[c];
+}
+
+// the same elimination with the rows spread over the lanes of one wave (lane j holds row j in
+// registers, pivot rows travel by v_readlane): the same operations on the same operands in the same
+// order per element — bit-identical coefficients — in a fraction of the dependent-instruction count
+// (the one-thread form spends most of its time in the 64-bit selects of the row swaps).  Called by
+// all 64 lanes of a wave; coef written by lane 0.
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), lane);
+  const int hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+template <int D>
+__device__ void solve_normal_equations_wave(const double* B, const double* P, double* coef) {
+  constexpr int N = D + 1;
+  const int lane = threadIdx.x & 63;
+  const int row = lane < N ? lane : 0;  // lanes >= N mirror row 0 and are never read
+  double r[N + 1];
+#pragma unroll
+  for (int k = 0; k < N; ++k) r[k] = P[row + k];
+  r[N] = B[row];
+  double scale = 0.0;
+#pragma unroll
+  for (int j = 0; j < N; ++j) scale = fmax(scale, fabs(P[2 * j]));
+  bool dead[N];
+#pragma unroll
+  for (int c = 0; c < N; ++c) {
+    int piv = c;
+    double best = fabs(readlane_f64(r[c], c));
+#pragma unroll
+    for (int j = c + 1; j < N; ++j) {
+      const double vj = fabs(readlane_f64(r[c], j));
+      if (vj > best) {
+        best = vj;
+        piv = j;
+      }
+    }
+    piv = __builtin_amdgcn_readfirstlane(piv);
+    double prow[N + 1];  // the pivot row (wave-uniform); it stays in lane c's registers as row c
+#pragma unroll
+    for (int k = c; k <= N; ++k) {
+      prow[k] = readlane_f64(r[k], piv);
+      const double ck = readlane_f64(r[k], c);
+      if (piv != c) r[k] = lane == c ? prow[k] : lane == piv ? ck : r[k];
+    }
+    dead[c] = !(best > 1e-13 * scale);
+    if (!dead[c]) {
+      const double inv = 1.0 / prow[c];
+      if (lane > c) {
+        const double f = r[c] * inv;
+#pragma unroll
+        for (int k = c; k <= N; ++k) r[k] = fma(-f, prow[k], r[k]);
+      }
+    }
+  }
+  // back-substitution: lane c holds the final row c; every lane runs the same instructions on its
+  // own row and lane c's quotient is broadcast
+  double cf[N];
+#pragma unroll
+  for (int c = N - 1; c >= 0; --c) {
+    double s = r[N];
+#pragma unroll
+    for (int k = c + 1; k < N; ++k) s = fma(-r[k], cf[k], s);
+    cf[c] = dead[c] ? 0.0 : readlane_f64(s / r[c], c);
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int c = 0; c < N; ++c) coef[c] = cf[c];
+  }
+}
+
+#ifndef HH_LSM_WAVE_SOLVE
+#define HH_LSM_WAVE_SOLVE 1
+#endif
+// timing diagnostics only (results are WRONG with any bit set; tools/lsm_breakdown.py builds variants):
+// 1 = the gather does not wait for the tags, 2 = no solve, 4 = no partial sums / reductions / publish
+#ifndef HH_LSM_DEBUG
+#define HH_LSM_DEBUG 0
+#endif
+
+// coefficients of row t into LDS (coef[D+1], *have_fit) from the global sums; all threads call it
+template <int D>
+__device__ __forceinline__ void fit_row(double n_itm, const double* B, const double* P, double* coef,
+                                        int* have_fit) {
+#if HH_LSM_WAVE_SOLVE
+  if (threadIdx.x < 64) {
+    if (n_itm > 0.0 && !(HH_LSM_DEBUG & 2)) solve_normal_equations_wave<D>(B, P, coef);  // isempty(in_the_money) && continue (:120)
+    if (threadIdx.x == 0) *have_fit = n_itm > 0.0 ? 1 : 0;
+  }
+#else
+  if (threadIdx.x == 0) {
+    if (n_itm > 0.0) solve_normal_equations<D>(B, P, coef);
+    *have_fit = n_itm > 0.0 ? 1 : 0;
+  }
+#endif
+  __syncthreads();
+}
+
+// exercise decision of one trajectory at row t (update_stopping_info!, :163-164)
+template <int D>
+__device__ __forceinline__ bool exercise_now(double x, double cp, double strike, const RowStat& r,
+                                             const double* coef, double& pay) {
+  pay = cp * (x - strike);
+  if (!(pay > 0.0)) return false;
+  const double z = (x - r.mu) * r.isd;
+  double cont = coef[D];  // cont_value = poly(x) (:127), Horner in z
+#pragma unroll
+  for (int c = D - 1; c >= 0; --c) cont = fma(cont, z, coef[c]);
+  return pay > cont;
+}
+
+// ---- one launch per date: per-row statistics and power sums (one-off), then the steps -----------
+
+template <int Q>
+__global__ __launch_bounds__(kLsmWg) void lsm_stats_kernel(const double* __restrict__ grid,
+                                                           uint64_t ntot, double strike, double cp,
+                                                           uint32_t n_chunks,
+                                                           double* __restrict__ rec /*[row][chunk][3]*/) {
+  __shared__ double scratch[kLsmWaves * 4], tot[4];
+  const uint32_t chunk = blockIdx.x, row = blockIdx.y;
+  const double* S = grid + (size_t)row * ntot;
+  double v[4] = {0, 0, 0, 0};
+#pragma unroll
+  for (int j = 0; j < Q; ++j) {
+    const uint64_t p = (uint64_t)chunk * (kLsmWg * Q) + (uint64_t)j * kLsmWg + threadIdx.x;
+    if (p < ntot) add_stats(S[p], cp, strike, v);
+  }
+  block_reduce_multi<4, kLsmWaves>(v, scratch, tot);
+  if (threadIdx.x < 3) rec[((size_t)row * n_chunks + chunk) * 3 + threadIdx.x] = tot[threadIdx.x];
+}
+
+// rs[row] from the chunk records of the row (grid = rows)
+__global__ __launch_bounds__(kLsmWg) void lsm_rowstat_kernel(const double* __restrict__ rec,
+                                                             uint32_t n_chunks,
+                                                             RowStat* __restrict__ rs) {
+  __shared__ double scratch[4 * 4], tot[4];
   const uint32_t row = blockIdx.x;
-  double t[3];
-  reduce_records<3>(rec + (size_t)row * n_chunks * 3, n_chunks, t);
-  if (threadIdx.x == 0) rs[row] = rowstat_of(t);
+  reduce_chunk_records<3, 4>(rec + (size_t)row * n_chunks * 3, n_chunks, 3, scratch, tot);
+  if (threadIdx.x == 0) rs[row] = rowstat_of(tot[0], tot[1], tot[2]);
 }
 
 // sharded form: the sums leave the device (all-reduce over the ranks) and come back
@@ -162,84 +435,48 @@ __global__ __launch_bounds__(256) void lsm_rowstat_from_sums_kernel(const double
                                                                     uint32_t rows,
                                                                     RowStat* __restrict__ rs) {
   const uint32_t row = blockIdx.x * 256 + threadIdx.x;
-  if (row < rows) {
-    const double t[3] = {sums[row * 3], sums[row * 3 + 1], sums[row * 3 + 2]};
-    rs[row] = rowstat_of(t);
-  }
+  if (row < rows) rs[row] = rowstat_of(sums[row * 3], sums[row * 3 + 1], sums[row * 3 + 2]);
 }
 
-// out[row][NV] = Σ_chunk rec[row][chunk][NV], same order as the in-kernel reductions (grid = rows)
+// out[row][NV] = canonical sum over the chunk records rec[row][chunk][NV] (grid = rows)
 template <int NV>
-__global__ __launch_bounds__(256) void lsm_sum_records_kernel(const double* __restrict__ rec,
-                                                              uint32_t n_chunks,
-                                                              double* __restrict__ out) {
+__global__ __launch_bounds__(kLsmWg) void lsm_sum_records_kernel(const double* __restrict__ rec,
+                                                                 uint32_t n_chunks,
+                                                                 double* __restrict__ out) {
+  constexpr int P2 = pow2_ge(NV);
+  __shared__ double scratch[4 * P2], tot[P2];
   const uint32_t row = blockIdx.x;
-  double t[NV];
-  reduce_records<NV>(rec + (size_t)row * n_chunks * NV, n_chunks, t);
-  if (threadIdx.x == 0) {
-#pragma unroll
-    for (int i = 0; i < NV; ++i) out[(size_t)row * NV + i] = t[i];
-  }
+  reduce_chunk_records<NV, P2>(rec + (size_t)row * n_chunks * NV, n_chunks, NV, scratch, tot);
+  if (threadIdx.x < NV) out[(size_t)row * NV + threadIdx.x] = tot[threadIdx.x];
 }
 
-template <int D>
-__global__ __launch_bounds__(256) void lsm_pow_kernel(const double* __restrict__ grid, uint64_t ntot,
-                                                      double strike, double cp, uint32_t n_chunks,
-                                                      uint32_t per_wg,
-                                                      const RowStat* __restrict__ rs,
-                                                      double* __restrict__ rec /*[row][chunk][2D+1]*/) {
-  constexpr int NV = 2 * D + 1;
+template <int D, int Q>
+__global__ __launch_bounds__(kLsmWg) void lsm_pow_kernel(const double* __restrict__ grid, uint64_t ntot,
+                                                         double strike, double cp, uint32_t n_chunks,
+                                                         const RowStat* __restrict__ rs,
+                                                         double* __restrict__ rec /*[row][chunk][2D+1]*/) {
+  constexpr int NV = 2 * D + 1, P2 = pow2_ge(NV);
+  __shared__ double scratch[kLsmWaves * P2], tot[P2];
   const uint32_t chunk = blockIdx.x, row = blockIdx.y;
   const double* S = grid + (size_t)row * ntot;
   const RowStat r = rs[row];
-  double v[NV];
+  double v[P2];
 #pragma unroll
-  for (int i = 0; i < NV; ++i) v[i] = 0.0;
-  for (uint32_t j = 0; j < per_wg / 256; ++j) {
-    const uint64_t p = (uint64_t)chunk * per_wg + j * 256 + threadIdx.x;
-    if (p < ntot) {
-      const double x = S[p];
-      if (cp * (x - strike) > 0.0) {
-        const double z = (x - r.mu) / r.sd;
-        double pw = 1.0;
+  for (int i = 0; i < P2; ++i) v[i] = 0.0;
 #pragma unroll
-        for (int i = 0; i < NV; ++i) {
-          v[i] += pw;
-          pw *= z;
-        }
-      }
-    }
+  for (int j = 0; j < Q; ++j) {
+    const uint64_t p = (uint64_t)chunk * (kLsmWg * Q) + (uint64_t)j * kLsmWg + threadIdx.x;
+    if (p < ntot) add_powers<D>(S[p], cp, strike, r, v);
   }
-  double t[NV];
-  block_sum<NV>(v, t);
-  if (threadIdx.x == 0) {
-    double* o = rec + ((size_t)row * n_chunks + chunk) * NV;
-#pragma unroll
-    for (int i = 0; i < NV; ++i) o[i] = t[i];
-  }
+  block_reduce_multi<P2, kLsmWaves>(v, scratch, tot);
+  if (threadIdx.x < NV) rec[((size_t)row * n_chunks + chunk) * NV + threadIdx.x] = tot[threadIdx.x];
 }
-
-template <int D>
-__global__ __launch_bounds__(256) void lsm_powsum_kernel(const double* __restrict__ rec,
-                                                         uint32_t n_chunks,
-                                                         double* __restrict__ P /*[row][2D+1]*/) {
-  constexpr int NV = 2 * D + 1;
-  const uint32_t row = blockIdx.x;
-  double t[NV];
-  reduce_records<NV>(rec + (size_t)row * n_chunks * NV, n_chunks, t);
-  if (threadIdx.x == 0) {
-#pragma unroll
-    for (int i = 0; i < NV; ++i) P[(size_t)row * NV + i] = t[i];
-  }
-}
-
-// ---- backward induction -----------------------------------------------------------------------
 
 struct LsmStepArgs {
   const double* grid;
   uint64_t ntot;
   double strike, cp, ln_disc;  // ln of the per-step discount factor
-  uint32_t n_steps, n_chunks;  // n_chunks: workgroups of the step kernels (256·Q paths each)
+  uint32_t n_steps, n_chunks;  // n_chunks: canonical chunks (1024·Q trajectories each)
   int32_t* tau;
   double* val;
   const RowStat* rs;
@@ -256,51 +493,39 @@ __global__ __launch_bounds__(256) void lsm_disc_kernel(double ln_disc, uint32_t 
   if (k <= n) out[k] = exp(ln_disc * (double)k);
 }
 
-// contribution of this workgroup's paths to Σ z^k y of `row`, y = D^(tau - row) val
-// (least_squares_montecarlo.jl:115-116), written to recB[row][chunk]
+// this chunk's contribution to Σ z^k y of `row`, written to recB[row][chunk]
 template <int D, int Q>
 __device__ __forceinline__ void emit_moments(const LsmStepArgs& a, uint32_t row, const int (&tau)[Q],
-                                             const double (&val)[Q], const double (&xrow)[Q]) {
+                                             const double (&val)[Q], const double (&xrow)[Q],
+                                             double* scratch, double* tot) {
+  constexpr int NV = D + 1, P2 = pow2_ge(NV);
   const RowStat r = a.rs[row];
-  double v[D + 1];
+  double v[P2];
 #pragma unroll
-  for (int i = 0; i <= D; ++i) v[i] = 0.0;
+  for (int i = 0; i < P2; ++i) v[i] = 0.0;
 #pragma unroll
   for (int j = 0; j < Q; ++j) {
-    const uint64_t p = (uint64_t)blockIdx.x * (256 * Q) + j * 256 + threadIdx.x;
-    if (p < a.ntot) {
-      const double x = xrow[j];  // S[row][p], loaded by the caller
-      if (a.cp * (x - a.strike) > 0.0) {
-        const double z = (x - r.mu) / r.sd;
-        const double y = a.disc_pow[tau[j] - (int)row] * val[j];  // tau >= row + 1
-        double pw = y;
-#pragma unroll
-        for (int i = 0; i <= D; ++i) {
-          v[i] += pw;
-          pw *= z;
-        }
-      }
-    }
+    const uint64_t p = (uint64_t)blockIdx.x * (kLsmWg * Q) + (uint64_t)j * kLsmWg + threadIdx.x;
+    if (p < a.ntot)
+      add_moments<D>(xrow[j], a.cp, a.strike, r, a.disc_pow[tau[j] - (int)row] * val[j], v);
   }
-  double t[D + 1];
-  block_sum<D + 1>(v, t);
-  if (threadIdx.x == 0) {
-    double* o = a.recB + ((size_t)row * a.n_chunks + blockIdx.x) * (D + 1);
-#pragma unroll
-    for (int i = 0; i <= D; ++i) o[i] = t[i];
-  }
+  block_reduce_multi<P2, kLsmWaves>(v, scratch, tot);
+  if (threadIdx.x < NV)
+    a.recB[((size_t)row * a.n_chunks + blockIdx.x) * NV + threadIdx.x] = tot[threadIdx.x];
 }
 
 // stopping_info = [(nsteps, payoff(S_T))] (:109), and the moment sums of row nsteps-1
 template <int D, int Q>
-__global__ __launch_bounds__(256) void lsm_init_kernel(const LsmStepArgs a) {
+__global__ __launch_bounds__(kLsmWg) void lsm_init_kernel(const LsmStepArgs a) {
+  constexpr int P2 = pow2_ge(D + 1);
+  __shared__ double scratch[kLsmWaves * P2], tot[P2];
   const double* S = a.grid + (size_t)a.n_steps * a.ntot;
   const double* Sn = a.grid + (size_t)(a.n_steps >= 2 ? a.n_steps - 1 : a.n_steps) * a.ntot;
   int tau[Q];
   double val[Q], xn[Q];
 #pragma unroll
   for (int j = 0; j < Q; ++j) {
-    const uint64_t p = (uint64_t)blockIdx.x * (256 * Q) + j * 256 + threadIdx.x;
+    const uint64_t p = (uint64_t)blockIdx.x * (kLsmWg * Q) + (uint64_t)j * kLsmWg + threadIdx.x;
     tau[j] = (int)a.n_steps;
     val[j] = xn[j] = 0.0;
     if (p < a.ntot) {
@@ -311,25 +536,25 @@ __global__ __launch_bounds__(256) void lsm_init_kernel(const LsmStepArgs a) {
       a.val[p] = val[j];
     }
   }
-  if (a.n_steps >= 2) emit_moments<D, Q>(a, a.n_steps - 1, tau, val, xn);
+  if (a.n_steps >= 2) emit_moments<D, Q>(a, a.n_steps - 1, tau, val, xn, scratch, tot);
 }
 
 // one backward step at time index t (the reference's loop body for i = t+1, :112-131)
 template <int D, int Q>
-__global__ __launch_bounds__(256) void lsm_step_kernel(const LsmStepArgs a, uint32_t t) {
-  constexpr int N = D + 1;
-  const RowStat r = a.rs[t];
-  __shared__ double coef[N];
+__global__ __launch_bounds__(kLsmWg) void lsm_step_kernel(const LsmStepArgs a, uint32_t t) {
+  constexpr int N = D + 1, P2 = pow2_ge(N);
+  __shared__ double scratch[kLsmWaves * P2], tot[P2], coef[N], Pt[2 * D + 1];
   __shared__ int have_fit;
-  // this workgroup's paths first: the loads are in flight while the moment sums are reduced and the
-  // normal equations solved (a serial prologue of several microseconds in every workgroup)
+  const RowStat r = a.rs[t];
+  // this chunk's trajectories first: the loads are in flight while the moment sums are reduced and
+  // the normal equations solved
   const double* S = a.grid + (size_t)t * a.ntot;
   const double* Sn = a.grid + (size_t)(t >= 2 ? t - 1 : t) * a.ntot;  // row of the next step
   int tau[Q];
   double val[Q], xs[Q], xn[Q];
 #pragma unroll
   for (int j = 0; j < Q; ++j) {
-    const uint64_t p = (uint64_t)blockIdx.x * (256 * Q) + j * 256 + threadIdx.x;
+    const uint64_t p = (uint64_t)blockIdx.x * (kLsmWg * Q) + (uint64_t)j * kLsmWg + threadIdx.x;
     tau[j] = 0;
     val[j] = xs[j] = xn[j] = 0.0;
     if (p < a.ntot) {
@@ -339,101 +564,31 @@ __global__ __launch_bounds__(256) void lsm_step_kernel(const LsmStepArgs a, uint
       xn[j] = Sn[p];
     }
   }
-  double B[N];
   if (a.B_given) {  // summed over the ranks by the host between two launches
-#pragma unroll
-    for (int i = 0; i < N; ++i) B[i] = a.B_given[i];
+    if (threadIdx.x < N) tot[threadIdx.x] = a.B_given[threadIdx.x];
   } else {
-    reduce_records<N>(a.recB + (size_t)t * a.n_chunks * N, a.n_chunks, B);
+    reduce_chunk_records<N, P2>(a.recB + (size_t)t * a.n_chunks * N, a.n_chunks, N, scratch, tot);
   }
-  if (threadIdx.x == 0) {
-    have_fit = 0;
-    if (r.n > 0.0) {  // isempty(in_the_money) && continue (:120)
-      // normal equations G c = B, G_jk = Σ z^(j+k); Gaussian elimination with partial pivoting
-      const double* P = a.P + (size_t)t * (2 * D + 1);
-      double M[N][N + 1];
-#pragma unroll
-      for (int j = 0; j < N; ++j) {
-#pragma unroll
-        for (int k = 0; k < N; ++k) M[j][k] = P[j + k];
-        M[j][N] = B[j];
-      }
-      double scale = 0.0;
-#pragma unroll
-      for (int j = 0; j < N; ++j) scale = fmax(scale, fabs(M[j][j]));
-      bool dead[N];
-#pragma unroll
-      for (int c = 0; c < N; ++c) {
-        int piv = c;
-        double best = fabs(M[c][c]);
-#pragma unroll
-        for (int j = 0; j < N; ++j)
-          if (j > c && fabs(M[j][c]) > best) {
-            best = fabs(M[j][c]);
-            piv = j;
-          }
-#pragma unroll
-        for (int j = 0; j < N; ++j)
-          if (j == piv && piv != c) {
-#pragma unroll
-            for (int k = 0; k <= N; ++k) {
-              const double tmp = M[c][k];
-              M[c][k] = M[j][k];
-              M[j][k] = tmp;
-            }
-          }
-        // rank deficiency (fewer distinct in-the-money spots than coefficients): drop the column
-        dead[c] = !(best > 1e-13 * scale);
-        if (!dead[c]) {
-          const double inv = 1.0 / M[c][c];
-#pragma unroll
-          for (int j = 0; j < N; ++j)
-            if (j > c) {
-              const double f = M[j][c] * inv;
-#pragma unroll
-              for (int k = 0; k <= N; ++k)
-                if (k >= c) M[j][k] = fma(-f, M[c][k], M[j][k]);
-            }
-        }
-      }
-      double cf[N];
-#pragma unroll
-      for (int c = N - 1; c >= 0; --c) {
-        double s = M[c][N];
-#pragma unroll
-        for (int k = 0; k < N; ++k)
-          if (k > c) s = fma(-M[c][k], cf[k], s);
-        cf[c] = dead[c] ? 0.0 : s / M[c][c];
-      }
-#pragma unroll
-      for (int c = 0; c < N; ++c) coef[c] = cf[c];
-      have_fit = 1;
-    }
-    if (blockIdx.x == 0) a.counters[r.n > 0.0 ? 0 : 1] += 1.0;
-  }
+  if (threadIdx.x < 2 * D + 1) Pt[threadIdx.x] = a.P[(size_t)t * (2 * D + 1) + threadIdx.x];
   __syncthreads();
+  fit_row<D>(r.n, tot, Pt, coef, &have_fit);
+  if (blockIdx.x == 0 && threadIdx.x == 0) a.counters[r.n > 0.0 ? 0 : 1] += 1.0;
 
+  if (have_fit) {
 #pragma unroll
-  for (int j = 0; j < Q; ++j) {
-    const uint64_t p = (uint64_t)blockIdx.x * (256 * Q) + j * 256 + threadIdx.x;
-    if (p < a.ntot) {
-      const double x = xs[j];
-      const double pay = a.cp * (x - a.strike);
-      if (have_fit && pay > 0.0) {
-        const double z = (x - r.mu) / r.sd;
-        double cont = coef[D];  // cont_value = poly(x) (:127), Horner in z
-#pragma unroll
-        for (int c = D - 1; c >= 0; --c) cont = fma(cont, z, coef[c]);
-        if (pay > cont) {  // update_stopping_info! (:163-164)
-          tau[j] = (int)t;
-          val[j] = pay;
-          a.tau[p] = tau[j];
-          a.val[p] = pay;
-        }
+    for (int j = 0; j < Q; ++j) {
+      const uint64_t p = (uint64_t)blockIdx.x * (kLsmWg * Q) + (uint64_t)j * kLsmWg + threadIdx.x;
+      double pay;
+      if (p < a.ntot && exercise_now<D>(xs[j], a.cp, a.strike, r, coef, pay)) {
+        tau[j] = (int)t;
+        val[j] = pay;
+        a.tau[p] = tau[j];
+        a.val[p] = pay;
       }
     }
   }
-  if (t >= 2) emit_moments<D, Q>(a, t - 1, tau, val, xn);
+  __syncthreads();  // tot / scratch are reused below
+  if (t >= 2) emit_moments<D, Q>(a, t - 1, tau, val, xn, scratch, tot);
 }
 
 // discounted_values = discount^t * val (:133): per-workgroup Σ and Σ² into 16-double records
@@ -441,22 +596,292 @@ __global__ __launch_bounds__(256) void lsm_final_kernel(const int32_t* __restric
                                                         const double* __restrict__ val,
                                                         uint64_t ntot, double ln_disc,
                                                         double* __restrict__ records) {
+  __shared__ double scratch[4 * 2], tot[2];
   double v[2] = {0, 0};
   for (int j = 0; j < 4; ++j) {
-    const uint64_t p = (uint64_t)blockIdx.x * kLsmChunk + j * 256 + threadIdx.x;
+    const uint64_t p = (uint64_t)blockIdx.x * kLsmFinalChunk + j * 256 + threadIdx.x;
     if (p < ntot) {
       const double d = exp(ln_disc * (double)tau[p]) * val[p];
       v[0] += d;
       v[1] = fma(d, d, v[1]);
     }
   }
-  double t[2];
-  block_sum<2>(v, t);
+  block_reduce_multi<2, 4>(v, scratch, tot);
   if (threadIdx.x == 0) {
     double* rec = records + (size_t)blockIdx.x * kRecStride;
     for (int i = 0; i < kRecStride; ++i) rec[i] = 0.0;
-    rec[HH_ACC_SUM] = t[0];
-    rec[HH_ACC_SUMSQ] = t[1];
+    rec[HH_ACC_SUM] = tot[0];
+    rec[HH_ACC_SUMSQ] = tot[1];
+  }
+}
+
+// ---- one persistent launch ---------------------------------------------------------------------
+
+using gu64 = __attribute__((address_space(1))) unsigned long long;
+using gu32 = __attribute__((address_space(1))) unsigned int;
+
+struct LsmPersistArgs {
+  const double* grid;
+  uint64_t ntot;
+  double strike, cp;
+  uint32_t n_steps, n_chunks;
+  int32_t* tau;
+  double* val;
+  const double* disc_pow;
+  double* counters;
+  // all-gather state, zeroed by a memset node ahead of every launch
+  unsigned long long* rec;  // [kLsmRing][n_chunks][P2] records (fp64 bit patterns), write-through
+  unsigned int* tags;       // [kLsmRing][n_chunks] epoch of the record in that slot (0 = none yet)
+  unsigned int* status;     // [0] != 0: a workgroup gave up waiting (the grid was not co-resident)
+  unsigned long long spin_ticks;  // bound of every wait, in s_memrealtime ticks (100 MHz)
+};
+
+// Record of an epoch e (row t = M - e + 1), 32 doubles in two groups of 16 — the groups are formed,
+// reduced and gathered separately, which halves the registers a lane needs for its partial sums:
+//   group A  [0, D]  Σ z^k y of row t (k = 0..D)      [12, 14]  (n, Σx, Σx²) of row t-1
+//   group B  [16 + k - 1]  Σ z^k of row t, k = 1..2D  (Σ z^0 is the in-the-money count n)
+// Epoch 1 carries only the statistics of row M-1.
+constexpr int kRecP2 = 32, kGrp = 16, kOffStats = 12;
+
+// publish this workgroup's record for epoch e: write-through (sc1) stores by ONE wave, drained,
+// then the tag by one lane (Guideline 16, recipe R1)
+__device__ __forceinline__ void publish_record(const LsmPersistArgs& a, uint32_t e, const double* tot) {
+  if (threadIdx.x < 64) {
+    const size_t slot = (size_t)(e % kLsmRing) * a.n_chunks + blockIdx.x;
+    if (threadIdx.x < kRecP2)
+      __hip_atomic_store((gu64*)(a.rec + slot * kRecP2 + threadIdx.x),
+                         (unsigned long long)__double_as_longlong(tot[threadIdx.x]), __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (threadIdx.x == 0)
+      __hip_atomic_store((gu32*)(a.tags + slot), e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// gather the records of epoch e from every workgroup and reduce them in the canonical order: lane
+// r < 256 of waves 0-3 takes group A of record r, lane r of waves 4-7 group B; each polls the tag of
+// its record and then (and only then) loads its half with sc1 loads.  tot[32] on return.  Returns
+// false — for every thread of the workgroup — when a wait ran out or another workgroup gave up; the
+// caller leaves the kernel.
+__device__ __forceinline__ bool gather_records(const LsmPersistArgs& a, uint32_t e, double* scratch,
+                                               double* tot, int* ok_flag) {
+  double v[kGrp];
+#pragma unroll
+  for (int i = 0; i < kGrp; ++i) v[i] = 0.0;
+  if (threadIdx.x == 0) *ok_flag = 1;
+  __syncthreads();
+  const int wave = threadIdx.x >> 6;
+  if (threadIdx.x < 512) {
+    const int g = threadIdx.x >> 8;           // group A or B
+    const uint32_t r = threadIdx.x & 255u;    // record
+    const bool mine = r < a.n_chunks;
+    const size_t slot = (size_t)(e % kLsmRing) * a.n_chunks + r;
+    bool ok = true;
+    if (__any(mine)) {
+      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+      unsigned spins = 0;
+      while (true) {
+        const unsigned tag = mine ? __hip_atomic_load((gu32*)(a.tags + slot), __ATOMIC_RELAXED,
+                                                      __HIP_MEMORY_SCOPE_AGENT)
+                                  : e;
+        if (__all(tag == e) || (HH_LSM_DEBUG & 1)) break;
+        __builtin_amdgcn_s_sleep(1);
+        if ((++spins & 63u) == 0) {  // bounded: every wave reaches an exit
+          const unsigned gave_up = __hip_atomic_load((gu32*)a.status, __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_AGENT);
+          if (gave_up != 0 || __builtin_amdgcn_s_memrealtime() - t0 > a.spin_ticks) {
+            ok = false;
+            break;
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // no instruction: keeps the loads below the poll
+    if (ok && mine) {
+#pragma unroll
+      for (int i = 0; i < kGrp; ++i)
+        v[i] = __longlong_as_double((long long)__hip_atomic_load(
+            (gu64*)(a.rec + slot * kRecP2 + g * kGrp + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    }
+    if (!ok && (threadIdx.x & 63) == 0) {
+      __hip_atomic_store((gu32*)a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      *ok_flag = 0;
+    }
+    wave_reduce_multi<kGrp>(v);
+    if ((threadIdx.x & 3) == 0) scratch[wave * kGrp + ((threadIdx.x & 63) >> 2)] = v[0];
+  }
+  __syncthreads();
+  if (threadIdx.x < kRecP2) {  // the four waves of a group, in order
+    const int g = threadIdx.x >> 4, i = threadIdx.x & 15;
+    double t = scratch[(4 * g) * kGrp + i];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) t += scratch[(4 * g + w) * kGrp + i];
+    tot[threadIdx.x] = t;
+  }
+  __syncthreads();
+  return *ok_flag != 0;
+}
+
+template <int D, int Q>
+__global__ __launch_bounds__(kLsmWg) void lsm_persistent_kernel(const LsmPersistArgs a) {
+  constexpr int N = D + 1;
+  static_assert(N <= kOffStats && 2 * D <= kGrp, "record layout");
+  __shared__ double scratch[kLsmWaves * kGrp], tot[kRecP2], coef[N], Pt[2 * D + 1];
+  // rows t-1 and t-2 of this workgroup's trajectories wait here (a lane only ever touches its own
+  // slots): registers hold the stopping state and row t, the partial sums need the rest
+  __shared__ double xl[2][Q * kLsmWg];
+  __shared__ int have_fit, ok_flag;
+  const uint32_t M = a.n_steps;
+  const uint64_t p0 = (uint64_t)blockIdx.x * (kLsmWg * Q) + threadIdx.x;
+  auto row_ptr = [&](uint32_t row) { return a.grid + (size_t)row * a.ntot; };
+  auto live = [&](int j) { return p0 + (uint64_t)j * kLsmWg < a.ntot; };
+
+  int tau[Q];
+  double val[Q], xs[Q];  // xs = row t, where the next decisions are taken
+  {
+    const double* SM = row_ptr(M);
+    const double* S1 = row_ptr(M >= 2 ? M - 1 : M);
+    const double* S2 = row_ptr(M >= 3 ? M - 2 : M);
+#pragma unroll
+    for (int j = 0; j < Q; ++j) {
+      const uint64_t p = p0 + (uint64_t)j * kLsmWg;
+      tau[j] = (int)M;
+      val[j] = xs[j] = 0.0;
+      double x2 = 0.0;
+      if (p < a.ntot) {
+        const double m = a.cp * (SM[p] - a.strike);  // stopping_info = [(nsteps, payoff(S_T))] (:109)
+        val[j] = m > 0.0 ? m : 0.0;
+        xs[j] = S1[p];
+        x2 = S2[p];
+      }
+      xl[0][j * kLsmWg + threadIdx.x] = x2;  // row M-2
+    }
+  }
+  int cur = 0;  // xl[cur] = row t-1, xl[cur ^ 1] receives row t-2
+  double regressed = 0.0, skipped = 0.0;
+  bool alive = true;
+  if (M >= 2) {
+    {  // epoch 1: statistics of row M-1
+      double v[kGrp];
+#pragma unroll
+      for (int i = 0; i < kGrp; ++i) v[i] = 0.0;
+#pragma unroll
+      for (int j = 0; j < Q; ++j)
+        if (live(j)) add_stats(xs[j], a.cp, a.strike, v + kOffStats);
+      block_reduce_multi<kGrp, kLsmWaves>(v, scratch, tot);
+      if (threadIdx.x < kGrp) tot[kGrp + threadIdx.x] = 0.0;
+      __syncthreads();
+      publish_record(a, 1u, tot);
+      alive = gather_records(a, 1u, scratch, tot, &ok_flag);
+    }
+    RowStat r_cur = rowstat_of(tot[kOffStats], tot[kOffStats + 1], tot[kOffStats + 2]);  // row M-1
+    RowStat r_next = r_cur;
+    __syncthreads();  // tot is rewritten below
+    if (alive) {  // epoch 2: sums of row M-1 (tau = M everywhere), statistics of row M-2
+      const double d1 = a.disc_pow[1];
+      {
+        double v[kGrp];
+#pragma unroll
+        for (int i = 0; i < kGrp; ++i) v[i] = 0.0;
+#pragma unroll
+        for (int j = 0; j < Q; ++j) {
+          if (live(j)) {
+            add_moments<D>(xs[j], a.cp, a.strike, r_cur, d1 * val[j], v);
+            if (M >= 3) add_stats(xl[0][j * kLsmWg + threadIdx.x], a.cp, a.strike, v + kOffStats);
+          }
+        }
+        block_reduce_multi<kGrp, kLsmWaves>(v, scratch, tot);
+      }
+      {
+        double w[kGrp];
+#pragma unroll
+        for (int i = 0; i < kGrp; ++i) w[i] = 0.0;
+#pragma unroll
+        for (int j = 0; j < Q; ++j)
+          if (live(j)) add_powers_from1<D>(xs[j], a.cp, a.strike, r_cur, w);
+        block_reduce_multi<kGrp, kLsmWaves>(w, scratch, tot + kGrp);
+      }
+      publish_record(a, 2u, tot);
+    }
+    // for i = nsteps:-1:2, t = i-1 (:112-113)
+    for (uint32_t t = M - 1; alive && t >= 1; --t) {
+      const uint32_t e = M - t + 1;  // epoch whose records hold the sums of row t
+      double sv[3] = {0.0, 0.0, 0.0};
+      if (t >= 3) {  // row t-2: its statistics need nothing from the gather
+        const double* S2 = row_ptr(t - 2);
+#pragma unroll
+        for (int j = 0; j < Q; ++j) {
+          const uint64_t p = p0 + (uint64_t)j * kLsmWg;
+          const double x = p < a.ntot ? S2[p] : 0.0;
+          xl[cur ^ 1][j * kLsmWg + threadIdx.x] = x;
+          if (p < a.ntot) add_stats(x, a.cp, a.strike, sv);
+        }
+      }
+      alive = gather_records(a, e, scratch, tot, &ok_flag);
+      if (!alive) break;
+      if (t >= 2) r_next = rowstat_of(tot[kOffStats], tot[kOffStats + 1], tot[kOffStats + 2]);  // row t-1
+      // Gram matrix entries of row t: P[0] = n, P[k] from group B
+      if (threadIdx.x == 0) Pt[0] = r_cur.n;
+      if (threadIdx.x >= 1 && threadIdx.x <= 2 * D) Pt[threadIdx.x] = tot[kGrp + threadIdx.x - 1];
+      __syncthreads();
+      fit_row<D>(r_cur.n, tot, Pt, coef, &have_fit);
+      if (r_cur.n > 0.0) regressed += 1.0; else skipped += 1.0;
+      if (have_fit) {
+#pragma unroll
+        for (int j = 0; j < Q; ++j) {
+          double pay;
+          if (live(j) && exercise_now<D>(xs[j], a.cp, a.strike, r_cur, coef, pay)) {
+            tau[j] = (int)t;
+            val[j] = pay;
+          }
+        }
+      }
+      if (t >= 2) {
+        // sums of row t-1 (xl[cur]) with the stopping state as of now; statistics of row t-2 (sv);
+        // row t-1 moves into the registers on the way: it is the next decision row
+#pragma unroll
+        for (int j = 0; j < Q; ++j) xs[j] = xl[cur][j * kLsmWg + threadIdx.x];
+        if (!(HH_LSM_DEBUG & 4)) {
+        {
+          double v[kGrp];
+#pragma unroll
+          for (int i = 0; i < kGrp; ++i) v[i] = 0.0;
+          v[kOffStats] = sv[0]; v[kOffStats + 1] = sv[1]; v[kOffStats + 2] = sv[2];
+#pragma unroll
+          for (int j = 0; j < Q; ++j)
+            if (live(j))
+              add_moments<D>(xs[j], a.cp, a.strike, r_next,
+                             a.disc_pow[tau[j] - (int)(t - 1)] * val[j], v);
+          block_reduce_multi<kGrp, kLsmWaves>(v, scratch, tot);
+        }
+        {
+          double w[kGrp];
+#pragma unroll
+          for (int i = 0; i < kGrp; ++i) w[i] = 0.0;
+#pragma unroll
+          for (int j = 0; j < Q; ++j)
+            if (live(j)) add_powers_from1<D>(xs[j], a.cp, a.strike, r_next, w);
+          block_reduce_multi<kGrp, kLsmWaves>(w, scratch, tot + kGrp);
+        }
+        publish_record(a, e + 1, tot);
+        }
+        cur ^= 1;
+        r_cur = r_next;
+      }
+    }
+  }
+  if (!alive) return;  // the host sees status != 0 and runs the launch-per-date form instead
+#pragma unroll
+  for (int j = 0; j < Q; ++j) {
+    const uint64_t p = p0 + (uint64_t)j * kLsmWg;
+    if (p < a.ntot) {
+      a.tau[p] = tau[j];
+      a.val[p] = val[j];
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    a.counters[0] = regressed;
+    a.counters[1] = skipped;
   }
 }
 
@@ -464,29 +889,36 @@ __global__ __launch_bounds__(256) void lsm_final_kernel(const int32_t* __restric
 
 // where the pieces of the caller's scratch buffer are (lsm_scratch_doubles() doubles)
 struct LsmLayout {
-  double* rec_stats;  // [rows][ch1][3]
+  double* rec_stats;  // [rows][nch][3]
   RowStat* rs;        // [rows]
-  double* rec_pow;    // [rows][ch1][2D+1]
+  double* rec_pow;    // [rows][nch][2D+1]
   double* P;          // [rows][2D+1]
-  double* recB;       // [rows][ch][D+1]
+  double* recB;       // [rows][nch][D+1]
   double* disc_pow;   // [rows]
+  double* sync;       // persistent form: tags + status (memset per launch), then the record ring
   double* counters;   // [2]
-  uint32_t rows, ch1, per_wg;
+  uint32_t rows, nch;
+  int q;
 };
 
+constexpr size_t kSyncWords = (size_t)kLsmRing * kLsmMaxResident + 4;       // uint32: tags, status
+constexpr size_t kSyncDoubles = (kSyncWords * 4 + 15) / 16 * 2;             // padded to 16 bytes
+constexpr size_t kRingDoubles = (size_t)kLsmRing * kLsmMaxResident * 32;    // records of 32 doubles
+
 LsmLayout lsm_layout(double* scratch, uint64_t ntot, uint32_t n_steps, int degree) {
-  const size_t rows = (size_t)n_steps + 1, ch = lsm_chunks(ntot), nv = 2 * (size_t)degree + 1;
+  const size_t rows = (size_t)n_steps + 1, ch = lsm_nch(ntot), nv = 2 * (size_t)degree + 1;
   LsmLayout L{};
-  L.rec_stats = scratch;
+  L.sync = scratch;  // at the allocation's start: the per-launch memset covers exactly this block
+  L.rec_stats = L.sync + kSyncDoubles + kRingDoubles;
   L.rs = reinterpret_cast<RowStat*>(L.rec_stats + rows * ch * 3);
-  L.rec_pow = reinterpret_cast<double*>(L.rs) + rows * 3;
+  L.rec_pow = reinterpret_cast<double*>(L.rs) + rows * 3;  // RowStat = 3 doubles
   L.P = L.rec_pow + rows * ch * nv;
   L.recB = L.P + rows * nv;
   L.disc_pow = L.recB + rows * ch * (degree + 1);
   L.counters = L.disc_pow + rows;
   L.rows = (uint32_t)rows;
-  L.per_wg = lsm_one_off_paths(ntot);
-  L.ch1 = (uint32_t)((ntot + L.per_wg - 1) / L.per_wg);
+  L.nch = (uint32_t)ch;
+  L.q = lsm_q(ntot);
   return L;
 }
 
@@ -496,42 +928,83 @@ LsmStepArgs lsm_step_args(const LsmLayout& L, const double* grid, uint64_t ntot,
   a.grid = grid; a.ntot = ntot; a.strike = strike; a.cp = cp; a.ln_disc = log(step_discount);
   a.n_steps = n_steps; a.tau = tau; a.val = val; a.rs = L.rs; a.P = L.P; a.recB = L.recB;
   a.disc_pow = L.disc_pow; a.counters = L.counters;
-  const bool wide = ntot >= kLsmWideFrom;
-  a.n_chunks = wide ? (uint32_t)((ntot + 256 * HH_LSM_WIDE_Q - 1) / (256 * HH_LSM_WIDE_Q))
-                    : lsm_chunks(ntot);
+  a.n_chunks = L.nch;
   return a;
+}
+
+void launch_stats(const LsmLayout& L, const LsmStepArgs& a, hipStream_t s) {
+  const dim3 g(L.nch, L.rows), b(kLsmWg);
+  if (L.q == 1)
+    hipLaunchKernelGGL(lsm_stats_kernel<1>, g, b, 0, s, a.grid, a.ntot, a.strike, a.cp, L.nch, L.rec_stats);
+  else
+    hipLaunchKernelGGL(lsm_stats_kernel<8>, g, b, 0, s, a.grid, a.ntot, a.strike, a.cp, L.nch, L.rec_stats);
 }
 
 template <int D>
 void launch_pow(const LsmLayout& L, const LsmStepArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL(lsm_pow_kernel<D>, dim3(L.ch1, L.rows), dim3(256), 0, s, a.grid, a.ntot, a.strike,
-                     a.cp, L.ch1, L.per_wg, a.rs, L.rec_pow);
+  const dim3 g(L.nch, L.rows), b(kLsmWg);
+  if (L.q == 1)
+    hipLaunchKernelGGL((lsm_pow_kernel<D, 1>), g, b, 0, s, a.grid, a.ntot, a.strike, a.cp, L.nch, a.rs, L.rec_pow);
+  else
+    hipLaunchKernelGGL((lsm_pow_kernel<D, 8>), g, b, 0, s, a.grid, a.ntot, a.strike, a.cp, L.nch, a.rs, L.rec_pow);
 }
 
 template <int D>
-void launch_init(const LsmStepArgs& a, hipStream_t s) {
-  if (a.ntot >= kLsmWideFrom)
-    hipLaunchKernelGGL((lsm_init_kernel<D, HH_LSM_WIDE_Q>), dim3(a.n_chunks), dim3(256), 0, s, a);
-  else
-    hipLaunchKernelGGL((lsm_init_kernel<D, 4>), dim3(a.n_chunks), dim3(256), 0, s, a);
+void launch_init(const LsmLayout& L, const LsmStepArgs& a, hipStream_t s) {
+  if (L.q == 1) hipLaunchKernelGGL((lsm_init_kernel<D, 1>), dim3(a.n_chunks), dim3(kLsmWg), 0, s, a);
+  else hipLaunchKernelGGL((lsm_init_kernel<D, 8>), dim3(a.n_chunks), dim3(kLsmWg), 0, s, a);
 }
 
 template <int D>
-void launch_step(const LsmStepArgs& a, uint32_t t, hipStream_t s) {
-  if (a.ntot >= kLsmWideFrom)
-    hipLaunchKernelGGL((lsm_step_kernel<D, HH_LSM_WIDE_Q>), dim3(a.n_chunks), dim3(256), 0, s, a, t);
-  else
-    hipLaunchKernelGGL((lsm_step_kernel<D, 4>), dim3(a.n_chunks), dim3(256), 0, s, a, t);
+void launch_step(const LsmLayout& L, const LsmStepArgs& a, uint32_t t, hipStream_t s) {
+  if (L.q == 1) hipLaunchKernelGGL((lsm_step_kernel<D, 1>), dim3(a.n_chunks), dim3(kLsmWg), 0, s, a, t);
+  else hipLaunchKernelGGL((lsm_step_kernel<D, 8>), dim3(a.n_chunks), dim3(kLsmWg), 0, s, a, t);
 }
 
-// the whole induction on one device
+// the whole induction on one device, one launch per date
 template <int D>
 int run_lsm(const LsmLayout& L, const LsmStepArgs& a, hipStream_t s) {
+  launch_stats(L, a, s);
+  hipLaunchKernelGGL(lsm_rowstat_kernel, dim3(L.rows), dim3(kLsmWg), 0, s, L.rec_stats, L.nch, L.rs);
   launch_pow<D>(L, a, s);
-  hipLaunchKernelGGL(lsm_powsum_kernel<D>, dim3(L.rows), dim3(256), 0, s, L.rec_pow, L.ch1, L.P);
-  launch_init<D>(a, s);
+  hipLaunchKernelGGL(lsm_sum_records_kernel<2 * D + 1>, dim3(L.rows), dim3(kLsmWg), 0, s, L.rec_pow,
+                     L.nch, L.P);
+  launch_init<D>(L, a, s);
   for (uint32_t t = a.n_steps - 1; t >= 1; --t)  // for i = nsteps:-1:2, t = i-1 (:112-113)
-    launch_step<D>(a, t, s);
+    launch_step<D>(L, a, t, s);
+  return (int)hipGetLastError();
+}
+
+// can `blocks` workgroups of this kernel be resident together?  (one per CU is what the register
+// budget of a 1024-thread workgroup allows; the occupancy query is the authority)
+template <class K>
+bool grid_fits(K kernel, uint32_t blocks) {
+  int dev = 0, cus = 0, per_cu = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return false;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kLsmWg, 0) != hipSuccess) return false;
+  return per_cu >= 1 && blocks <= (uint32_t)cus;  // counted at ONE workgroup per CU, whatever the query allows
+}
+
+// the whole induction in one launch; 1 = not applicable here (too many chunks for the chip)
+template <int D>
+int run_lsm_persistent(const LsmLayout& L, const LsmStepArgs& s_args, hipStream_t s) {
+  if (L.nch > (uint32_t)kLsmMaxResident) return 1;
+  LsmPersistArgs a{};
+  a.grid = s_args.grid; a.ntot = s_args.ntot; a.strike = s_args.strike; a.cp = s_args.cp;
+  a.n_steps = s_args.n_steps; a.n_chunks = L.nch; a.tau = s_args.tau; a.val = s_args.val;
+  a.disc_pow = L.disc_pow; a.counters = L.counters;
+  a.tags = reinterpret_cast<unsigned int*>(L.sync);
+  a.status = a.tags + (size_t)kLsmRing * kLsmMaxResident;
+  a.rec = reinterpret_cast<unsigned long long*>(L.sync + kSyncDoubles);
+  a.spin_ticks = 100000000ull;  // 1 s of the 100 MHz constant clock
+  const bool fits = L.q == 1 ? grid_fits(lsm_persistent_kernel<D, 1>, L.nch)
+                             : grid_fits(lsm_persistent_kernel<D, 8>, L.nch);
+  if (!fits) return 1;
+  hipError_t e = hipMemsetAsync(L.sync, 0, kSyncDoubles * sizeof(double), s);
+  if (e != hipSuccess) return (int)e;
+  if (L.q == 1) hipLaunchKernelGGL((lsm_persistent_kernel<D, 1>), dim3(L.nch), dim3(kLsmWg), 0, s, a);
+  else hipLaunchKernelGGL((lsm_persistent_kernel<D, 8>), dim3(L.nch), dim3(kLsmWg), 0, s, a);
   return (int)hipGetLastError();
 }
 
@@ -545,23 +1018,24 @@ int run_lsm_phase(const LsmLayout& L, LsmStepArgs a, int phase, uint32_t t, cons
       hipLaunchKernelGGL(lsm_rowstat_from_sums_kernel, dim3((L.rows + 255) / 256), dim3(256), 0, s,
                          vec_in, L.rows, L.rs);
       launch_pow<D>(L, a, s);
-      hipLaunchKernelGGL(lsm_powsum_kernel<D>, dim3(L.rows), dim3(256), 0, s, L.rec_pow, L.ch1, vec_out);
+      hipLaunchKernelGGL(lsm_sum_records_kernel<NV>, dim3(L.rows), dim3(kLsmWg), 0, s, L.rec_pow,
+                         L.nch, vec_out);
       break;
     case kLsmPhaseInit: {  // global power sums in; stopping at expiry; local moment sums of row n-1 out
       hipError_t e = hipMemcpyAsync(L.P, vec_in, (size_t)L.rows * NV * sizeof(double),
                                     hipMemcpyDeviceToDevice, s);
       if (e != hipSuccess) return (int)e;
-      launch_init<D>(a, s);
+      launch_init<D>(L, a, s);
       if (a.n_steps >= 2)
-        hipLaunchKernelGGL(lsm_sum_records_kernel<N>, dim3(1), dim3(256), 0, s,
+        hipLaunchKernelGGL(lsm_sum_records_kernel<N>, dim3(1), dim3(kLsmWg), 0, s,
                            a.recB + (size_t)(a.n_steps - 1) * a.n_chunks * N, a.n_chunks, vec_out);
       break;
     }
     case kLsmPhaseStep:  // global moment sums of row t in; decisions at t; local sums of row t-1 out
       a.B_given = vec_in;
-      launch_step<D>(a, t, s);
+      launch_step<D>(L, a, t, s);
       if (t >= 2)
-        hipLaunchKernelGGL(lsm_sum_records_kernel<N>, dim3(1), dim3(256), 0, s,
+        hipLaunchKernelGGL(lsm_sum_records_kernel<N>, dim3(1), dim3(kLsmWg), 0, s,
                            a.recB + (size_t)(t - 1) * a.n_chunks * N, a.n_chunks, vec_out);
       break;
     default: return (int)hipErrorInvalidValue;
@@ -571,15 +1045,16 @@ int run_lsm_phase(const LsmLayout& L, LsmStepArgs a, int phase, uint32_t t, cons
 
 }  // namespace
 
-uint32_t lsm_chunks(uint64_t ntot) { return (uint32_t)((ntot + kLsmChunk - 1) / kLsmChunk); }
+uint32_t lsm_chunks(uint64_t ntot) { return (uint32_t)((ntot + kLsmFinalChunk - 1) / kLsmFinalChunk); }
 
 // scratch sizes in doubles, for the caller (hh_api.hip) to allocate
 size_t lsm_scratch_doubles(uint64_t ntot, uint32_t n_steps, int degree) {
-  const size_t rows = (size_t)n_steps + 1, ch = lsm_chunks(ntot);
+  const size_t rows = (size_t)n_steps + 1, ch = lsm_nch(ntot);
   const size_t nv = 2 * (size_t)degree + 1;
-  // rec_stats [rows][ch][3] | rowstat [rows][3] | rec_pow [rows][ch][nv] | P [rows][nv] |
+  // sync | ring | rec_stats [rows][ch][3] | rowstat [rows][3] | rec_pow [rows][ch][nv] | P [rows][nv] |
   // recB [rows][ch][degree+1] | disc_pow [rows] | counters [2]
-  return rows * ch * 3 + rows * 3 + rows * ch * nv + rows * nv + rows * ch * (degree + 1) + rows + 2;
+  return kSyncDoubles + kRingDoubles + rows * ch * 3 + rows * 3 + rows * ch * nv + rows * nv +
+         rows * ch * (degree + 1) + rows + 2;
 }
 
 int launch_gbm_grid(const uint64_t* seeds_dev, uint64_t n_paths, uint32_t n_steps, double S0,
@@ -596,9 +1071,6 @@ int launch_gbm_grid(const uint64_t* seeds_dev, uint64_t n_paths, uint32_t n_step
   return (int)hipGetLastError();
 }
 
-// Backward induction on a device-resident grid.  `scratch` has lsm_scratch_doubles() doubles,
-// `records` lsm_chunks() x kRecStride; on return `records` holds the per-workgroup Σ, Σ² of the
-// discounted stopped values and scratch's last two doubles the regressed / skipped row counts.
 #define HH_LSM_DISPATCH(degree, CALL)            \
   switch (degree) {                                \
     case 1: rc = CALL(1); break;                   \
@@ -611,28 +1083,44 @@ int launch_gbm_grid(const uint64_t* seeds_dev, uint64_t n_paths, uint32_t n_step
     default: rc = CALL(8); break;                  \
   }
 
+// Backward induction on a device-resident grid.  `scratch` has lsm_scratch_doubles() doubles,
+// `records` lsm_chunks() x kRecStride; on return `records` holds the per-workgroup Σ, Σ² of the
+// discounted stopped values and scratch's last two doubles the regressed / skipped row counts.
+// form: kLsmFormPersistent enqueues the one-launch form when the ensemble fits it (*form_used tells;
+// the caller must then check lsm_persistent_status after synchronising) — kLsmFormPerDate never does.
 int launch_lsm(const double* grid, uint64_t ntot, uint32_t n_steps, double strike, double cp,
                double step_discount, int degree, int32_t* tau, double* val, double* scratch,
-               double* records, hipStream_t s) {
+               double* records, hipStream_t s, int form, int* form_used) {
   if (degree < 1 || degree > kLsmMaxDeg) return (int)hipErrorInvalidValue;
   const LsmLayout L = lsm_layout(scratch, ntot, n_steps, degree);
   hipError_t e = hipMemsetAsync(L.counters, 0, 2 * sizeof(double), s);
   if (e != hipSuccess) return (int)e;
   const dim3 b(256);
-  hipLaunchKernelGGL(lsm_stats_kernel, dim3(L.ch1, L.rows), b, 0, s, grid, ntot, strike, cp, L.ch1,
-                     L.per_wg, L.rec_stats);
-  hipLaunchKernelGGL(lsm_rowstat_kernel, dim3(L.rows), b, 0, s, L.rec_stats, L.ch1, L.rs);
   const LsmStepArgs a = lsm_step_args(L, grid, ntot, n_steps, strike, cp, step_discount, tau, val);
   hipLaunchKernelGGL(lsm_disc_kernel, dim3((L.rows + 255) / 256), b, 0, s, a.ln_disc, n_steps,
                      L.disc_pow);
-  int rc = 0;
-#define HH_CALL(D) run_lsm<D>(L, a, s)
-  HH_LSM_DISPATCH(degree, HH_CALL)
+  int rc = 1;
+  if (form == kLsmFormPersistent) {
+#define HH_CALL(D) run_lsm_persistent<D>(L, a, s)
+    HH_LSM_DISPATCH(degree, HH_CALL)
 #undef HH_CALL
-  if (rc) return rc;
+    if (rc != 0 && rc != 1) return rc;
+  }
+  if (form_used) *form_used = rc == 0 ? kLsmFormPersistent : kLsmFormPerDate;
+  if (rc == 1) {
+#define HH_CALL(D) run_lsm<D>(L, a, s)
+    HH_LSM_DISPATCH(degree, HH_CALL)
+#undef HH_CALL
+    if (rc) return rc;
+  }
   hipLaunchKernelGGL(lsm_final_kernel, dim3(lsm_chunks(ntot)), b, 0, s, tau, val, ntot, a.ln_disc,
                      records);
   return (int)hipGetLastError();
+}
+
+// device address of the word the persistent form sets when a workgroup gave up waiting
+const unsigned int* lsm_persistent_status(const double* scratch) {
+  return reinterpret_cast<const unsigned int*>(scratch) + (size_t)kLsmRing * kLsmMaxResident;
 }
 
 // Sharded induction, one phase per call (hh_kernels.h).  kLsmPhaseStats: local row sums
@@ -649,9 +1137,9 @@ int launch_lsm_phase(int phase, uint32_t t, const double* grid, uint64_t ntot, u
   if (phase == kLsmPhaseStats) {
     hipError_t e = hipMemsetAsync(L.counters, 0, 2 * sizeof(double), s);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(lsm_stats_kernel, dim3(L.ch1, L.rows), b, 0, s, grid, ntot, strike, cp, L.ch1,
-                       L.per_wg, L.rec_stats);
-    hipLaunchKernelGGL(lsm_sum_records_kernel<3>, dim3(L.rows), b, 0, s, L.rec_stats, L.ch1, vec_out);
+    launch_stats(L, a, s);
+    hipLaunchKernelGGL(lsm_sum_records_kernel<3>, dim3(L.rows), dim3(kLsmWg), 0, s, L.rec_stats, L.nch,
+                       vec_out);
     hipLaunchKernelGGL(lsm_disc_kernel, dim3((L.rows + 255) / 256), b, 0, s, a.ln_disc, n_steps,
                        L.disc_pow);
     return (int)hipGetLastError();

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define HH_ABI_VERSION 1
+#define HH_ABI_VERSION 2
 #define HH_MAX_PARTIALS 8   /* max. number of dual-number partials carried through one solve    */
 #define HH_TILE_PATHS 256   /* paths per tile of the tile-major REPLAY layout (see below)        */
 #define HH_ACC_LEN 16       /* doubles in the accumulator vector exchanged between GPUs          */
@@ -143,6 +143,15 @@ void hh_ctx_destroy(hh_ctx* ctx);
 int hh_ctx_set_stream(hh_ctx* ctx, void* hip_stream);
 int hh_ctx_reset_stream(hh_ctx* ctx);
 const char* hh_last_error(const hh_ctx* ctx); /* NUL-terminated, owned by ctx (or static if NULL) */
+/* Build options of a context (none changes a result).  HH_OPT_LSM_FORM: how hh_lsm_solve /
+ * hh_lsm_solve_grid run the backward induction — HH_LSM_FORM_PERSISTENT (default): ONE launch that
+ * keeps every trajectory's stopping state in registers and reads each row of the grid once, for
+ * ensembles of up to 2^18 (one trajectory per lane) or 2^21 (eight) trajectories, falling back by
+ * itself beyond that or when its workgroups cannot all be resident; HH_LSM_FORM_PER_DATE: one
+ * launch per exercise date.  Both give bit-identical prices and stopping decisions. */
+enum hh_option { HH_OPT_LSM_FORM = 1 };
+enum hh_lsm_form { HH_LSM_FORM_PER_DATE = 0, HH_LSM_FORM_PERSISTENT = 1 };
+int hh_ctx_set_option(hh_ctx* ctx, int32_t option, int64_t value);
 
 /*
  * Replaces the body of solve(prob, ::MonteCarlo) (montecarlo.jl:478-493): simulate, payoff,
@@ -209,6 +218,8 @@ typedef struct hh_lsm_result {
   uint64_t n_paths_total;
   uint32_t rows_regressed, rows_skipped; /* time rows with / without an in-the-money path */
   double kernel_ms, total_ms;
+  int32_t form;      /* enum hh_lsm_form the backward induction ran in (sharded phases: per date) */
+  int32_t reserved_;
 } hh_lsm_result;
 size_t hh_lsm_grid_elems(uint64_t n_paths, uint32_t n_steps, int32_t antithetic);
 int hh_lsm_solve(hh_ctx* ctx, const hh_model* model, const hh_config* cfg, int32_t degree,
