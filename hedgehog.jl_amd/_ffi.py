@@ -68,7 +68,7 @@ class hh_lsm_result(C.Structure):
 
 
 HH_OPT_LSM_FORM = 1
-HH_LSM_FORM_PER_DATE, HH_LSM_FORM_PERSISTENT = 0, 1
+HH_LSM_FORM_PER_DATE, HH_LSM_FORM_PERSISTENT, HH_LSM_FORM_AUTO = 0, 1, 2
 
 
 class HedgehogMCError(RuntimeError):
@@ -105,6 +105,7 @@ SYMBOLS = [
     ("hh_lsm_shard_phase", C.c_int, [_vp, C.c_int32, C.c_uint32, _vp, _vp]),
     ("hh_lsm_shard_finish", C.c_int, [_vp, _vp, _vp, _vp, _vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     ("hh_lsm_finalize", C.c_int, [_vp, C.POINTER(hh_lsm_result)]),
+    ("hh_lsm_debug_read", C.c_int, [_vp, C.c_uint64, C.c_uint32, C.c_int32, _vp]),
     ("hh_replay_elems", C.c_size_t, [C.c_uint64, C.c_uint32, C.c_int32]),
     ("hh_replay_pack", C.c_int, [_vp, C.c_int32, C.c_uint64, C.c_uint32, _vp, C.c_int32, _vp]),
     ("hh_wiener_fill", C.c_int, [_vp, C.c_int32, C.c_double, C.c_double, C.c_uint32, C.c_uint64, _vp, C.c_int32, _vp]),

@@ -55,7 +55,7 @@ struct hh_ctx {
     int32_t degree = 0;
     double step_discount = 1.0;
   } shard;
-  int lsm_form = hh::kLsmFormPersistent;  // hh_ctx_set_option(HH_OPT_LSM_FORM)
+  int lsm_form = hh::kLsmFormAuto;  // hh_ctx_set_option(HH_OPT_LSM_FORM)
   uint64_t lsm_persistent_fallbacks = 0;  // persistent launches that gave up and were redone per date
   double* accum = nullptr;       // device, HH_ACC_LEN
   double* accum_host = nullptr;  // pinned, HH_ACC_LEN
@@ -252,8 +252,8 @@ int hh_ctx_set_option(hh_ctx* ctx, int32_t option, int64_t value) {
   std::lock_guard<std::recursive_mutex> lock__(ctx->mu);
   switch (option) {
     case HH_OPT_LSM_FORM:
-      if (value != HH_LSM_FORM_PER_DATE && value != HH_LSM_FORM_PERSISTENT)
-        return fail(ctx, HH_ERR_INVALID, "HH_OPT_LSM_FORM: 0 (launch per date) or 1 (one launch)");
+      if (value != HH_LSM_FORM_PER_DATE && value != HH_LSM_FORM_PERSISTENT && value != HH_LSM_FORM_AUTO)
+        return fail(ctx, HH_ERR_INVALID, "HH_OPT_LSM_FORM: 0 (launch per date), 1 (one launch) or 2 (auto)");
       ctx->lsm_form = (int)value;
       return HH_OK;
     default:
@@ -621,7 +621,7 @@ static int lsm_on_grid(hh_ctx* ctx, const double* grid_dev, uint64_t ntot, uint3
   double counters[2] = {0, 0};
   HH_HIP(ctx, hipMemcpyAsync(ctx->accum_host, ctx->accum, HH_ACC_LEN * sizeof(double),
                              hipMemcpyDeviceToHost, ctx->stream));
-  HH_HIP(ctx, hipMemcpyAsync(counters, ctx->lsm_scratch + nscr - 2, 2 * sizeof(double),
+  HH_HIP(ctx, hipMemcpyAsync(counters, ctx->lsm_scratch + nscr - 2 - hh::kLsmStampSlotsApi, 2 * sizeof(double),
                              hipMemcpyDeviceToHost, ctx->stream));
   if (stop_time)
     HH_HIP(ctx, hipMemcpyAsync(stop_time, ctx->lsm_tau, ntot * sizeof(int32_t),
@@ -908,7 +908,7 @@ int hh_lsm_shard_finish(hh_ctx* ctx, double* accum_dev, int32_t* stop_time, doub
                                         accum_dev, ctx->stream));
   const size_t nscr = hh::lsm_scratch_doubles(sh.ntot, sh.n_steps, sh.degree);
   double counters[2] = {0, 0};
-  HH_HIP(ctx, hipMemcpyAsync(counters, ctx->lsm_scratch + nscr - 2, 2 * sizeof(double),
+  HH_HIP(ctx, hipMemcpyAsync(counters, ctx->lsm_scratch + nscr - 2 - hh::kLsmStampSlotsApi, 2 * sizeof(double),
                              hipMemcpyDeviceToHost, ctx->stream));
   if (stop_time)
     HH_HIP(ctx, hipMemcpyAsync(stop_time, ctx->lsm_tau, sh.ntot * sizeof(int32_t),
@@ -924,6 +924,20 @@ int hh_lsm_shard_finish(hh_ctx* ctx, double* accum_dev, int32_t* stop_time, doub
   if (rows_regressed) *rows_regressed = (uint32_t)counters[0];
   if (rows_skipped) *rows_skipped = (uint32_t)counters[1];
   ctx->shard.active = false;
+  return HH_OK;
+}
+
+int hh_lsm_debug_read(hh_ctx* ctx, uint64_t n_paths_total, uint32_t n_steps, int32_t degree,
+                      double* out8) {
+  if (!ctx || !out8) return HH_ERR_INVALID;
+  std::lock_guard<std::recursive_mutex> lock__(ctx->mu);
+  HH_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t nscr = hh::lsm_scratch_doubles(n_paths_total, n_steps, degree);
+  if (!ctx->lsm_scratch || ctx->lsm_scratch_cap < nscr)
+    return fail(ctx, HH_ERR_INVALID, "hh_lsm_debug_read: no LSM solve of that shape has run");
+  HH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  HH_HIP(ctx, hipMemcpy(out8, ctx->lsm_scratch + nscr - hh::kLsmStampSlotsApi,
+                        hh::kLsmStampSlotsApi * sizeof(double), hipMemcpyDeviceToHost));
   return HH_OK;
 }
 

@@ -13,25 +13,37 @@
 // conditioned in fp64) and the moment sums Σ z^k y.  Two forms compute them, with the SAME
 // summation tree (so their coefficients, stopping decisions and prices are bit-identical):
 //
-//  * ONE PERSISTENT LAUNCH (lsm_persistent_kernel; ensembles of up to 256 chunks): every
-//    workgroup keeps the stopping state of its trajectories in registers for the whole induction
-//    and reads every row of the grid exactly once.  Per date the workgroups publish one record
-//    {Σ z^k y of row t-1, Σ z^k of row t-1, statistics of row t-2} and gather everybody's — an
-//    all-gather by write-through stores + per-record epoch tags polled with sc1 loads (the
-//    hand-off of cdna_hip_programming.md §6 Guideline 16, row 1 of its table) — then each of them
-//    reduces the records in the fixed order, solves the normal equations redundantly and takes the
-//    exercise decisions of its own trajectories.  No launch, no re-load of tau / val / spots, no
-//    separate passes for the statistics and the power sums.
+//  * ONE PERSISTENT LAUNCH (lsm_persistent_kernel; ensembles of up to 256 chunks = 2^21
+//    trajectories): every workgroup keeps the stopping state and the current row of its
+//    trajectories in registers for the whole induction (512 threads x 16 trajectories, 256
+//    registers per lane; rows t-1 and t-2 wait in 128 KiB of LDS) and reads every row of the grid
+//    exactly once.  Per date the workgroups publish one 32-double record {Σ z^k y and Σ z^k of row
+//    t-1, statistics of row t-2} and gather everybody's — an all-gather by write-through (sc1)
+//    stores + per-record epoch tags polled with sc1 loads (the hand-off of
+//    cdna_hip_programming.md §6 Guideline 16, row 1 of its table; records value-major so that a
+//    gathering wave reads contiguous lines) — then each of them reduces the records in the fixed
+//    order, solves the normal equations redundantly (one wave, rows spread over its lanes) and
+//    takes the exercise decisions of its own trajectories.  No launch, no re-load of tau / val /
+//    spots, no separate passes for the statistics and the power sums.  Every wait is bounded
+//    (s_memrealtime): if the grid is not co-resident the kernel gives up, the host sees a status
+//    word and runs the other form.
 //  * ONE LAUNCH PER DATE (lsm_step_kernel & co.): statistics and power sums of every row in one-off
-//    launches, then a launch per exercise date.  Used for larger ensembles, when the persistent
-//    grid cannot be resident, and — cut at the global sums — for ensembles sharded over several
-//    GPUs (launch_lsm_phase), where the host all-reduces between launches.
+//    launches, then a launch per exercise date.  Used for larger ensembles, for small ones (up to
+//    2^18 trajectories a kernel boundary, ~1.5 µs, is a cheaper synchronisation than the in-kernel
+//    all-gather, ~3.5 µs), when the persistent grid cannot be resident, and — cut at the global
+//    sums — for ensembles sharded over several GPUs (launch_lsm_phase), where the host all-reduces
+//    between launches.
+//  Measured, 2·10^6 trajectories x 100 dates, degree 5 (profiles/r02_lsm_*): 2.05 ms in one launch
+//  (13.9 µs per date: all-gather 3.5, workgroup totals + publish 3.2, moment sums 2.6, power sums
+//  1.3, row issue 1.2, solve 1.2, decisions 0.8) against 3.75 ms with a launch per date and 4.3 ms
+//  for round 1's launch-per-date form.
 //
-// Summation tree (independent of the form and of the GPU): chunk = 1024 lanes x Q trajectories
-// (trajectory = chunk·1024·Q + j·1024 + lane; Q = 1 up to 2^18 trajectories, else 8); a lane adds
-// its Q terms in order j; a wave adds its 64 lanes by the butterfly (l, l^32), (l, l^16), …; the
-// chunk adds its 16 waves in order; the records of the chunks are dealt to 256 lanes (r, r+256, …,
-// added in order) which are summed by the same butterfly and, over their 4 waves, in order.
+// Summation tree (independent of the form and of the GPU): chunk = 512 lanes x Q trajectories
+// (trajectory = chunk·512·Q + j·512 + lane; Q = 2 up to 2^18 trajectories, else 16); a lane adds
+// its Q terms in order j (out-of-the-money terms are exact zeros); a wave adds its 64 lanes by the
+// butterfly (l, l^32), (l, l^16), …; the chunk adds its 8 waves in order; the records of the chunks
+// are dealt to 256 lanes (r, r+256, …, added in order) which are summed by the same butterfly and,
+// over their 4 waves, in order.
 #include <cmath>
 
 #include "hh_kernels.h"
@@ -42,14 +54,18 @@ namespace hh {
 namespace {
 
 constexpr int kLsmFinalChunk = 1024;  // paths per workgroup of the final Σ, Σ² kernel (16-double records)
-constexpr int kLsmWg = 1024;          // threads per workgroup of every kernel that forms canonical sums
+#ifndef HH_LSM_WG
+#define HH_LSM_WG 512
+#endif
+constexpr int kLsmWg = HH_LSM_WG;     // threads per workgroup of every kernel that forms canonical sums
+constexpr int kLsmQSmall = 1024 / kLsmWg, kLsmQLarge = 8192 / kLsmWg;  // trajectories per lane
 constexpr int kLsmWaves = kLsmWg / 64;
 constexpr int kLsmMaxDeg = 8;
-constexpr uint64_t kLsmQ1Max = 1ull << 18;  // up to here one trajectory per lane, beyond it 8
+constexpr uint64_t kLsmQ1Max = 1ull << 18;  // up to here chunks of 1024 trajectories, beyond it 8192
 constexpr int kLsmMaxResident = 256;        // chunks the persistent form handles (one per workgroup)
 constexpr int kLsmRing = 4;                 // record slots of the persistent all-gather (2 suffice)
 
-inline int lsm_q(uint64_t ntot) { return ntot <= kLsmQ1Max ? 1 : 8; }
+inline int lsm_q(uint64_t ntot) { return ntot <= kLsmQ1Max ? kLsmQSmall : kLsmQLarge; }
 inline uint32_t lsm_nch(uint64_t ntot) {
   const uint64_t per = (uint64_t)kLsmWg * lsm_q(ntot);
   return (uint32_t)((ntot + per - 1) / per);
@@ -146,6 +162,28 @@ __device__ __forceinline__ void block_reduce_multi(double (&a)[P2], double* scra
   __syncthreads();
 }
 
+// The same reduction in two pieces, so that several groups of values share ONE pair of barriers:
+// wave_part() per group (butterfly, totals of this wave into scratch[wave][off ..]), then
+// finish_block<TOT>() once.  scratch holds NW·TOT doubles.  Bit-identical to block_reduce_multi.
+template <int P2, int TOT>
+__device__ __forceinline__ void wave_part(double (&a)[P2], double* scratch, int off) {
+  constexpr int kShift = 6 - log2_of(P2);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  wave_reduce_multi<P2>(a);
+  if ((lane & ((1 << kShift) - 1)) == 0) scratch[wave * TOT + off + (lane >> kShift)] = a[0];
+}
+template <int TOT, int NW>
+__device__ __forceinline__ void finish_block(const double* scratch, double* tot) {
+  __syncthreads();
+  if (threadIdx.x < TOT) {
+    double t = scratch[threadIdx.x];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) t += scratch[w * TOT + threadIdx.x];
+    tot[threadIdx.x] = t;
+  }
+  __syncthreads();
+}
+
 // records of the chunks, rec[r·stride + i] (i < NV), dealt to lanes 0..255 and summed: tot[NV]
 template <int NV, int P2>
 __device__ __forceinline__ void reduce_chunk_records(const double* __restrict__ rec, uint32_t n_rec,
@@ -177,100 +215,94 @@ __device__ __forceinline__ RowStat rowstat_of(double n, double sx, double sxx) {
   return r;
 }
 
-// per-lane terms; every form calls exactly these, in trajectory order j = 0..Q-1
-__device__ __forceinline__ void add_stats(double x, double cp, double strike, double* v) {
-  if (cp * (x - strike) > 0.0) {
-    v[0] += 1.0;
-    v[1] += x;
-    v[2] = fma(x, x, v[2]);
-  }
+// Per-lane terms; every form calls exactly these, in trajectory order j = 0..Q-1.  Branch-free: a
+// trajectory that is out of the money (or beyond the ensemble: `live` false) adds exact zeros, which
+// leave every partial sum bit for bit as it was — so the compiler can interleave the dependent
+// chains of a lane's trajectories instead of serialising them behind one branch each.
+__device__ __forceinline__ bool in_the_money(double x, double cp, double strike, bool live) {
+  return live && cp * (x - strike) > 0.0;  // payoff_t .> 0 (:118-119)
+}
+__device__ __forceinline__ void add_stats(double x, double cp, double strike, bool live, double* v) {
+  const bool itm = in_the_money(x, cp, strike, live);
+  const double xm = itm ? x : 0.0;
+  v[0] += itm ? 1.0 : 0.0;
+  v[1] += xm;
+  v[2] = fma(xm, xm, v[2]);
 }
 template <int D>
-__device__ __forceinline__ void add_powers(double x, double cp, double strike, const RowStat& r,
-                                           double* v) {  // v[2D+1] += z^i
-  if (cp * (x - strike) > 0.0) {
-    const double z = (x - r.mu) * r.isd;
-    double pw = 1.0;
+__device__ __forceinline__ void add_powers(double x, double cp, double strike, bool live,
+                                           const RowStat& r, double* v) {  // v[2D+1] += z^i
+  const double z = (x - r.mu) * r.isd;
+  double pw = in_the_money(x, cp, strike, live) ? 1.0 : 0.0;
 #pragma unroll
-    for (int i = 0; i <= 2 * D; ++i) {
-      v[i] += pw;
-      pw *= z;
-    }
+  for (int i = 0; i <= 2 * D; ++i) {
+    v[i] += pw;
+    pw *= z;
   }
 }
 // the same without Σ z^0 (the count n): v[k-1] += z^k, k = 1..2D, the products formed exactly as above
 template <int D>
-__device__ __forceinline__ void add_powers_from1(double x, double cp, double strike, const RowStat& r,
-                                                 double* v) {
-  if (cp * (x - strike) > 0.0) {
-    const double z = (x - r.mu) * r.isd;
-    double pw = z;  // = 1.0 * z
+__device__ __forceinline__ void add_powers_from1(double x, double cp, double strike, bool live,
+                                                 const RowStat& r, double* v) {
+  const double z = (x - r.mu) * r.isd;
+  double pw = in_the_money(x, cp, strike, live) ? z : 0.0;  // = 1.0 * z
 #pragma unroll
-    for (int i = 0; i < 2 * D; ++i) {
-      v[i] += pw;
-      pw *= z;
-    }
+  for (int i = 0; i < 2 * D; ++i) {
+    v[i] += pw;
+    pw *= z;
   }
 }
 // Σ z^i y, y = D^(tau - row) val (least_squares_montecarlo.jl:115-116); tau >= row + 1
 template <int D>
-__device__ __forceinline__ void add_moments(double x, double cp, double strike, const RowStat& r,
-                                            double y, double* v) {  // v[D+1]
-  if (cp * (x - strike) > 0.0) {
-    const double z = (x - r.mu) * r.isd;
-    double pw = y;
+__device__ __forceinline__ void add_moments(double x, double cp, double strike, bool live,
+                                            const RowStat& r, double y, double* v) {  // v[D+1]
+  const double z = (x - r.mu) * r.isd;
+  double pw = in_the_money(x, cp, strike, live) ? y : 0.0;
 #pragma unroll
-    for (int i = 0; i <= D; ++i) {
-      v[i] += pw;
-      pw *= z;
-    }
+  for (int i = 0; i <= D; ++i) {
+    v[i] += pw;
+    pw *= z;
   }
 }
 
-// Normal equations G c = B, G_jk = P[j+k] = Σ z^(j+k); Gaussian elimination with partial pivoting,
-// rank-deficient columns (fewer distinct in-the-money spots than coefficients) dropped.  One
-// thread; every workgroup of either form runs it on the same B, P and so gets the same coef.
+// 1/x to <= 1 ulp: hardware reciprocal + two Newton steps (5 dependent instructions; the IEEE
+// division sequence is ~12).  Pivots are far from the overflow / underflow thresholds.
+__device__ __forceinline__ double rcp_nr(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  return fma(fma(-x, r, 1.0), r, r);
+}
+
+// Normal equations G c = B, G_jk = P[j+k] = Σ z^(j+k) (P[0] = the in-the-money count, handed over
+// separately as p0; Pm1 points at P[1]).  G is a Gram matrix — symmetric positive (semi-)definite —
+// so elimination needs no pivoting (it is the LDLᵀ factorisation, stable as it stands); a column
+// whose pivot has vanished against the matrix scale (fewer distinct in-the-money spots than
+// coefficients) is dropped, its coefficient 0.  Every workgroup of either form runs this on the same
+// sums and so obtains the same coefficients.  One-thread form:
 template <int D>
-__device__ void solve_normal_equations(const double* B, const double* P, double* coef) {
+__device__ void solve_normal_equations(const double* B, double p0, const double* Pm1, double* coef) {
   constexpr int N = D + 1;
+  auto Pv = [&](int i) { return i == 0 ? p0 : Pm1[i - 1]; };
   double M[N][N + 1];
 #pragma unroll
   for (int j = 0; j < N; ++j) {
 #pragma unroll
-    for (int k = 0; k < N; ++k) M[j][k] = P[j + k];
+    for (int k = 0; k < N; ++k) M[j][k] = Pv(j + k);
     M[j][N] = B[j];
   }
   double scale = 0.0;
 #pragma unroll
   for (int j = 0; j < N; ++j) scale = fmax(scale, fabs(M[j][j]));
-  bool dead[N];
+  double inv[N];
 #pragma unroll
   for (int c = 0; c < N; ++c) {
-    int piv = c;
-    double best = fabs(M[c][c]);
-#pragma unroll
-    for (int j = 0; j < N; ++j)
-      if (j > c && fabs(M[j][c]) > best) {
-        best = fabs(M[j][c]);
-        piv = j;
-      }
-#pragma unroll
-    for (int j = 0; j < N; ++j)
-      if (j == piv && piv != c) {
-#pragma unroll
-        for (int k = 0; k <= N; ++k) {
-          const double tmp = M[c][k];
-          M[c][k] = M[j][k];
-          M[j][k] = tmp;
-        }
-      }
-    dead[c] = !(best > 1e-13 * scale);
-    if (!dead[c]) {
-      const double inv = 1.0 / M[c][c];
+    const bool dead = !(M[c][c] > 1e-13 * scale);
+    inv[c] = dead ? 0.0 : rcp_nr(M[c][c]);
+    if (!dead) {
 #pragma unroll
       for (int j = 0; j < N; ++j)
         if (j > c) {
-          const double f = M[j][c] * inv;
+          const double f = M[j][c] * inv[c];
 #pragma unroll
           for (int k = 0; k <= N; ++k)
             if (k >= c) M[j][k] = fma(-f, M[c][k], M[j][k]);
@@ -284,17 +316,16 @@ __device__ void solve_normal_equations(const double* B, const double* P, double*
 #pragma unroll
     for (int k = 0; k < N; ++k)
       if (k > c) s = fma(-M[c][k], cf[k], s);
-    cf[c] = dead[c] ? 0.0 : s / M[c][c];
+    cf[c] = s * inv[c];  // 0 for a dropped column
   }
 #pragma unroll
   for (int c = 0; c < N; ++c) coef[c] = cf[c];
 }
 
-// the same elimination with the rows spread over the lanes of one wave (lane j holds row j in
-// registers, pivot rows travel by v_readlane): the same operations on the same operands in the same
-// order per element — bit-identical coefficients — in a fraction of the dependent-instruction count
-// (the one-thread form spends most of its time in the 64-bit selects of the row swaps).  Called by
-// all 64 lanes of a wave; coef written by lane 0.
+// The same elimination with the rows spread over the lanes of one wave (lane j holds row j in
+// registers, the pivot row travels by v_readlane): the same operations on the same operands in the
+// same order per element — bit-identical coefficients — at ~300 instructions, most of them
+// independent across the lanes.  Called by all 64 lanes of a wave; coef written by lane 0.
 __device__ __forceinline__ double readlane_f64(double v, int lane) {
   const long long b = __double_as_longlong(v);
   const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), lane);
@@ -302,57 +333,42 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
   return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 template <int D>
-__device__ void solve_normal_equations_wave(const double* B, const double* P, double* coef) {
+__device__ void solve_normal_equations_wave(const double* B, double p0, const double* Pm1,
+                                            double* coef) {
   constexpr int N = D + 1;
   const int lane = threadIdx.x & 63;
   const int row = lane < N ? lane : 0;  // lanes >= N mirror row 0 and are never read
+  auto Pv = [&](int i) { return i == 0 ? p0 : Pm1[i - 1]; };
   double r[N + 1];
 #pragma unroll
-  for (int k = 0; k < N; ++k) r[k] = P[row + k];
+  for (int k = 0; k < N; ++k) r[k] = Pv(row + k);
   r[N] = B[row];
   double scale = 0.0;
 #pragma unroll
-  for (int j = 0; j < N; ++j) scale = fmax(scale, fabs(P[2 * j]));
-  bool dead[N];
+  for (int j = 0; j < N; ++j) scale = fmax(scale, fabs(Pv(2 * j)));
+  double inv[N];
 #pragma unroll
   for (int c = 0; c < N; ++c) {
-    int piv = c;
-    double best = fabs(readlane_f64(r[c], c));
+    double prow[N + 1];  // row c (wave-uniform); final, since only the rows below it change from here
 #pragma unroll
-    for (int j = c + 1; j < N; ++j) {
-      const double vj = fabs(readlane_f64(r[c], j));
-      if (vj > best) {
-        best = vj;
-        piv = j;
-      }
-    }
-    piv = __builtin_amdgcn_readfirstlane(piv);
-    double prow[N + 1];  // the pivot row (wave-uniform); it stays in lane c's registers as row c
+    for (int k = c; k <= N; ++k) prow[k] = readlane_f64(r[k], c);
+    const bool dead = !(prow[c] > 1e-13 * scale);
+    inv[c] = dead ? 0.0 : rcp_nr(prow[c]);
+    if (!dead && lane > c) {
+      const double f = r[c] * inv[c];
 #pragma unroll
-    for (int k = c; k <= N; ++k) {
-      prow[k] = readlane_f64(r[k], piv);
-      const double ck = readlane_f64(r[k], c);
-      if (piv != c) r[k] = lane == c ? prow[k] : lane == piv ? ck : r[k];
-    }
-    dead[c] = !(best > 1e-13 * scale);
-    if (!dead[c]) {
-      const double inv = 1.0 / prow[c];
-      if (lane > c) {
-        const double f = r[c] * inv;
-#pragma unroll
-        for (int k = c; k <= N; ++k) r[k] = fma(-f, prow[k], r[k]);
-      }
+      for (int k = c; k <= N; ++k) r[k] = fma(-f, prow[k], r[k]);
     }
   }
   // back-substitution: lane c holds the final row c; every lane runs the same instructions on its
-  // own row and lane c's quotient is broadcast
+  // own row and lane c's product is broadcast
   double cf[N];
 #pragma unroll
   for (int c = N - 1; c >= 0; --c) {
     double s = r[N];
 #pragma unroll
     for (int k = c + 1; k < N; ++k) s = fma(-r[k], cf[k], s);
-    cf[c] = dead[c] ? 0.0 : readlane_f64(s / r[c], c);
+    cf[c] = readlane_f64(s * inv[c], c);  // 0 for a dropped column
   }
   if (lane == 0) {
 #pragma unroll
@@ -368,36 +384,44 @@ __device__ void solve_normal_equations_wave(const double* B, const double* P, do
 #ifndef HH_LSM_DEBUG
 #define HH_LSM_DEBUG 0
 #endif
+// 1: diagnostic build that stamps the phases of a date (s_memrealtime, 100 MHz) in thread 0 of one
+// workgroup and leaves the totals behind the row counters (tools/lsm_breakdown.py reads them through
+// hh_lsm_debug_read); in the shipped build no stamp executes
+#ifndef HH_LSM_STAMPS
+#define HH_LSM_STAMPS 0
+#endif
+constexpr int kLsmStampSlots = 8;
 
-// coefficients of row t into LDS (coef[D+1], *have_fit) from the global sums; all threads call it
+// coefficients of row t into LDS (coef[D+1], *have_fit) from the global sums B[0..D], P[0] = n_itm,
+// P[1..2D] = Pm1[0..]; all threads call it
 template <int D>
-__device__ __forceinline__ void fit_row(double n_itm, const double* B, const double* P, double* coef,
+__device__ __forceinline__ void fit_row(double n_itm, const double* B, const double* Pm1, double* coef,
                                         int* have_fit) {
 #if HH_LSM_WAVE_SOLVE
   if (threadIdx.x < 64) {
-    if (n_itm > 0.0 && !(HH_LSM_DEBUG & 2)) solve_normal_equations_wave<D>(B, P, coef);  // isempty(in_the_money) && continue (:120)
+    if (n_itm > 0.0 && !(HH_LSM_DEBUG & 2))
+      solve_normal_equations_wave<D>(B, n_itm, Pm1, coef);  // isempty(in_the_money) && continue (:120)
     if (threadIdx.x == 0) *have_fit = n_itm > 0.0 ? 1 : 0;
   }
 #else
   if (threadIdx.x == 0) {
-    if (n_itm > 0.0) solve_normal_equations<D>(B, P, coef);
+    if (n_itm > 0.0) solve_normal_equations<D>(B, n_itm, Pm1, coef);
     *have_fit = n_itm > 0.0 ? 1 : 0;
   }
 #endif
   __syncthreads();
 }
 
-// exercise decision of one trajectory at row t (update_stopping_info!, :163-164)
+// exercise decision of one trajectory at row t (update_stopping_info!, :163-164); branch-free
 template <int D>
-__device__ __forceinline__ bool exercise_now(double x, double cp, double strike, const RowStat& r,
-                                             const double* coef, double& pay) {
+__device__ __forceinline__ bool exercise_now(double x, double cp, double strike, bool live,
+                                             const RowStat& r, const double* coef, double& pay) {
   pay = cp * (x - strike);
-  if (!(pay > 0.0)) return false;
   const double z = (x - r.mu) * r.isd;
   double cont = coef[D];  // cont_value = poly(x) (:127), Horner in z
 #pragma unroll
   for (int c = D - 1; c >= 0; --c) cont = fma(cont, z, coef[c]);
-  return pay > cont;
+  return live && pay > 0.0 && pay > cont;
 }
 
 // ---- one launch per date: per-row statistics and power sums (one-off), then the steps -----------
@@ -414,7 +438,8 @@ __global__ __launch_bounds__(kLsmWg) void lsm_stats_kernel(const double* __restr
 #pragma unroll
   for (int j = 0; j < Q; ++j) {
     const uint64_t p = (uint64_t)chunk * (kLsmWg * Q) + (uint64_t)j * kLsmWg + threadIdx.x;
-    if (p < ntot) add_stats(S[p], cp, strike, v);
+    const bool lv = p < ntot;
+    add_stats(lv ? S[p] : 0.0, cp, strike, lv, v);
   }
   block_reduce_multi<4, kLsmWaves>(v, scratch, tot);
   if (threadIdx.x < 3) rec[((size_t)row * n_chunks + chunk) * 3 + threadIdx.x] = tot[threadIdx.x];
@@ -466,7 +491,8 @@ __global__ __launch_bounds__(kLsmWg) void lsm_pow_kernel(const double* __restric
 #pragma unroll
   for (int j = 0; j < Q; ++j) {
     const uint64_t p = (uint64_t)chunk * (kLsmWg * Q) + (uint64_t)j * kLsmWg + threadIdx.x;
-    if (p < ntot) add_powers<D>(S[p], cp, strike, r, v);
+    const bool lv = p < ntot;
+    add_powers<D>(lv ? S[p] : 0.0, cp, strike, lv, r, v);
   }
   block_reduce_multi<P2, kLsmWaves>(v, scratch, tot);
   if (threadIdx.x < NV) rec[((size_t)row * n_chunks + chunk) * NV + threadIdx.x] = tot[threadIdx.x];
@@ -493,22 +519,12 @@ __global__ __launch_bounds__(256) void lsm_disc_kernel(double ln_disc, uint32_t 
   if (k <= n) out[k] = exp(ln_disc * (double)k);
 }
 
-// this chunk's contribution to Σ z^k y of `row`, written to recB[row][chunk]
-template <int D, int Q>
-__device__ __forceinline__ void emit_moments(const LsmStepArgs& a, uint32_t row, const int (&tau)[Q],
-                                             const double (&val)[Q], const double (&xrow)[Q],
-                                             double* scratch, double* tot) {
+// write this chunk's partial Σ z^k y of `row` (lane partials in v) to recB[row][chunk]
+template <int D>
+__device__ __forceinline__ void store_moments(const LsmStepArgs& a, uint32_t row,
+                                              double (&v)[pow2_ge(D + 1)], double* scratch,
+                                              double* tot) {
   constexpr int NV = D + 1, P2 = pow2_ge(NV);
-  const RowStat r = a.rs[row];
-  double v[P2];
-#pragma unroll
-  for (int i = 0; i < P2; ++i) v[i] = 0.0;
-#pragma unroll
-  for (int j = 0; j < Q; ++j) {
-    const uint64_t p = (uint64_t)blockIdx.x * (kLsmWg * Q) + (uint64_t)j * kLsmWg + threadIdx.x;
-    if (p < a.ntot)
-      add_moments<D>(xrow[j], a.cp, a.strike, r, a.disc_pow[tau[j] - (int)row] * val[j], v);
-  }
   block_reduce_multi<P2, kLsmWaves>(v, scratch, tot);
   if (threadIdx.x < NV)
     a.recB[((size_t)row * a.n_chunks + blockIdx.x) * NV + threadIdx.x] = tot[threadIdx.x];
@@ -519,51 +535,42 @@ template <int D, int Q>
 __global__ __launch_bounds__(kLsmWg) void lsm_init_kernel(const LsmStepArgs a) {
   constexpr int P2 = pow2_ge(D + 1);
   __shared__ double scratch[kLsmWaves * P2], tot[P2];
-  const double* S = a.grid + (size_t)a.n_steps * a.ntot;
-  const double* Sn = a.grid + (size_t)(a.n_steps >= 2 ? a.n_steps - 1 : a.n_steps) * a.ntot;
-  int tau[Q];
-  double val[Q], xn[Q];
+  const uint32_t M = a.n_steps;
+  const double* S = a.grid + (size_t)M * a.ntot;
+  const double* Sn = a.grid + (size_t)(M >= 2 ? M - 1 : M) * a.ntot;
+  const RowStat r = a.rs[M >= 2 ? M - 1 : M];
+  const double d1 = a.disc_pow[1];
+  double v[P2];
+#pragma unroll
+  for (int i = 0; i < P2; ++i) v[i] = 0.0;
 #pragma unroll
   for (int j = 0; j < Q; ++j) {
     const uint64_t p = (uint64_t)blockIdx.x * (kLsmWg * Q) + (uint64_t)j * kLsmWg + threadIdx.x;
-    tau[j] = (int)a.n_steps;
-    val[j] = xn[j] = 0.0;
-    if (p < a.ntot) {
-      xn[j] = Sn[p];
-      const double m = a.cp * (S[p] - a.strike);
-      val[j] = m > 0.0 ? m : 0.0;
-      a.tau[p] = tau[j];
-      a.val[p] = val[j];
+    const bool lv = p < a.ntot;
+    const double m = a.cp * ((lv ? S[p] : 0.0) - a.strike);
+    const double val = m > 0.0 ? m : 0.0;
+    if (lv) {
+      a.tau[p] = (int)M;
+      a.val[p] = val;
     }
+    if (M >= 2) add_moments<D>(lv ? Sn[p] : 0.0, a.cp, a.strike, lv, r, d1 * val, v);
   }
-  if (a.n_steps >= 2) emit_moments<D, Q>(a, a.n_steps - 1, tau, val, xn, scratch, tot);
+  if (M >= 2) store_moments<D>(a, M - 1, v, scratch, tot);
 }
 
-// one backward step at time index t (the reference's loop body for i = t+1, :112-131)
+// one backward step at time index t (the reference's loop body for i = t+1, :112-131): decisions at
+// row t, then this chunk's moment sums of row t-1 with the stopping state as of now.  One pass over
+// the chunk's trajectories, nothing kept per trajectory (the persistent form is the one that keeps
+// the state in registers).
 template <int D, int Q>
 __global__ __launch_bounds__(kLsmWg) void lsm_step_kernel(const LsmStepArgs a, uint32_t t) {
   constexpr int N = D + 1, P2 = pow2_ge(N);
   __shared__ double scratch[kLsmWaves * P2], tot[P2], coef[N], Pt[2 * D + 1];
   __shared__ int have_fit;
   const RowStat r = a.rs[t];
-  // this chunk's trajectories first: the loads are in flight while the moment sums are reduced and
-  // the normal equations solved
+  const RowStat rn = a.rs[t >= 2 ? t - 1 : t];
   const double* S = a.grid + (size_t)t * a.ntot;
   const double* Sn = a.grid + (size_t)(t >= 2 ? t - 1 : t) * a.ntot;  // row of the next step
-  int tau[Q];
-  double val[Q], xs[Q], xn[Q];
-#pragma unroll
-  for (int j = 0; j < Q; ++j) {
-    const uint64_t p = (uint64_t)blockIdx.x * (kLsmWg * Q) + (uint64_t)j * kLsmWg + threadIdx.x;
-    tau[j] = 0;
-    val[j] = xs[j] = xn[j] = 0.0;
-    if (p < a.ntot) {
-      tau[j] = a.tau[p];
-      val[j] = a.val[p];
-      xs[j] = S[p];
-      xn[j] = Sn[p];
-    }
-  }
   if (a.B_given) {  // summed over the ranks by the host between two launches
     if (threadIdx.x < N) tot[threadIdx.x] = a.B_given[threadIdx.x];
   } else {
@@ -571,24 +578,31 @@ __global__ __launch_bounds__(kLsmWg) void lsm_step_kernel(const LsmStepArgs a, u
   }
   if (threadIdx.x < 2 * D + 1) Pt[threadIdx.x] = a.P[(size_t)t * (2 * D + 1) + threadIdx.x];
   __syncthreads();
-  fit_row<D>(r.n, tot, Pt, coef, &have_fit);
+  fit_row<D>(r.n, tot, Pt + 1, coef, &have_fit);  // P[0] = Σ 1 = r.n exactly
   if (blockIdx.x == 0 && threadIdx.x == 0) a.counters[r.n > 0.0 ? 0 : 1] += 1.0;
+  const bool fit = have_fit != 0;
 
-  if (have_fit) {
+  double v[P2];
 #pragma unroll
-    for (int j = 0; j < Q; ++j) {
-      const uint64_t p = (uint64_t)blockIdx.x * (kLsmWg * Q) + (uint64_t)j * kLsmWg + threadIdx.x;
-      double pay;
-      if (p < a.ntot && exercise_now<D>(xs[j], a.cp, a.strike, r, coef, pay)) {
-        tau[j] = (int)t;
-        val[j] = pay;
-        a.tau[p] = tau[j];
-        a.val[p] = pay;
-      }
+  for (int i = 0; i < P2; ++i) v[i] = 0.0;
+#pragma unroll
+  for (int j = 0; j < Q; ++j) {
+    const uint64_t p = (uint64_t)blockIdx.x * (kLsmWg * Q) + (uint64_t)j * kLsmWg + threadIdx.x;
+    const bool lv = p < a.ntot;
+    int tau = lv ? a.tau[p] : (int)t;
+    double val = lv ? a.val[p] : 0.0;
+    double pay;
+    if (fit && exercise_now<D>(lv ? S[p] : 0.0, a.cp, a.strike, lv, r, coef, pay)) {
+      tau = (int)t;
+      val = pay;
+      a.tau[p] = tau;
+      a.val[p] = pay;
     }
+    if (t >= 2)
+      add_moments<D>(lv ? Sn[p] : 0.0, a.cp, a.strike, lv, rn, a.disc_pow[tau - (int)(t - 1)] * val, v);
   }
-  __syncthreads();  // tot / scratch are reused below
-  if (t >= 2) emit_moments<D, Q>(a, t - 1, tau, val, xn, scratch, tot);
+  __syncthreads();  // tot (the sums of row t) was read by fit_row's wave
+  if (t >= 2) store_moments<D>(a, t - 1, v, scratch, tot);
 }
 
 // discounted_values = discount^t * val (:133): per-workgroup Σ and Σ² into 16-double records
@@ -630,7 +644,9 @@ struct LsmPersistArgs {
   const double* disc_pow;
   double* counters;
   // all-gather state, zeroed by a memset node ahead of every launch
-  unsigned long long* rec;  // [kLsmRing][n_chunks][P2] records (fp64 bit patterns), write-through
+  unsigned long long* rec;  // [kLsmRing][32 values][n_chunks] (fp64 bit patterns), write-through:
+                            // value-major, so that the 64 lanes of a gathering wave — one record
+                            // each — read 512 contiguous bytes per value
   unsigned int* tags;       // [kLsmRing][n_chunks] epoch of the record in that slot (0 = none yet)
   unsigned int* status;     // [0] != 0: a workgroup gave up waiting (the grid was not co-resident)
   unsigned long long spin_ticks;  // bound of every wait, in s_memrealtime ticks (100 MHz)
@@ -642,19 +658,21 @@ struct LsmPersistArgs {
 //   group B  [16 + k - 1]  Σ z^k of row t, k = 1..2D  (Σ z^0 is the in-the-money count n)
 // Epoch 1 carries only the statistics of row M-1.
 constexpr int kRecP2 = 32, kGrp = 16, kOffStats = 12;
+constexpr int kDiscLds = 1024;
 
 // publish this workgroup's record for epoch e: write-through (sc1) stores by ONE wave, drained,
 // then the tag by one lane (Guideline 16, recipe R1)
 __device__ __forceinline__ void publish_record(const LsmPersistArgs& a, uint32_t e, const double* tot) {
   if (threadIdx.x < 64) {
-    const size_t slot = (size_t)(e % kLsmRing) * a.n_chunks + blockIdx.x;
+    const size_t ring = e % kLsmRing;
     if (threadIdx.x < kRecP2)
-      __hip_atomic_store((gu64*)(a.rec + slot * kRecP2 + threadIdx.x),
+      __hip_atomic_store((gu64*)(a.rec + (ring * kRecP2 + threadIdx.x) * a.n_chunks + blockIdx.x),
                          (unsigned long long)__double_as_longlong(tot[threadIdx.x]), __ATOMIC_RELAXED,
                          __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (threadIdx.x == 0)
-      __hip_atomic_store((gu32*)(a.tags + slot), e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store((gu32*)(a.tags + ring * a.n_chunks + blockIdx.x), e, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -671,11 +689,13 @@ __device__ __forceinline__ bool gather_records(const LsmPersistArgs& a, uint32_t
   if (threadIdx.x == 0) *ok_flag = 1;
   __syncthreads();
   const int wave = threadIdx.x >> 6;
+  static_assert(kLsmWg >= 512, "the gather uses 8 waves");
   if (threadIdx.x < 512) {
     const int g = threadIdx.x >> 8;           // group A or B
     const uint32_t r = threadIdx.x & 255u;    // record
     const bool mine = r < a.n_chunks;
-    const size_t slot = (size_t)(e % kLsmRing) * a.n_chunks + r;
+    const size_t ring = e % kLsmRing;
+    const size_t slot = ring * a.n_chunks + r;
     bool ok = true;
     if (__any(mine)) {
       const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
@@ -701,7 +721,8 @@ __device__ __forceinline__ bool gather_records(const LsmPersistArgs& a, uint32_t
 #pragma unroll
       for (int i = 0; i < kGrp; ++i)
         v[i] = __longlong_as_double((long long)__hip_atomic_load(
-            (gu64*)(a.rec + slot * kRecP2 + g * kGrp + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            (gu64*)(a.rec + (ring * kRecP2 + g * kGrp + i) * a.n_chunks + r), __ATOMIC_RELAXED,
+            __HIP_MEMORY_SCOPE_AGENT));
     }
     if (!ok && (threadIdx.x & 63) == 0) {
       __hip_atomic_store((gu32*)a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -722,11 +743,18 @@ __device__ __forceinline__ bool gather_records(const LsmPersistArgs& a, uint32_t
   return *ok_flag != 0;
 }
 
+// Register budget: 512 threads = 2 waves per SIMD = 256 registers per lane for the form with 16
+// trajectories per lane (stopping state + row t of all of them live in registers); the form with 2
+// per lane is held to 128 (4 waves per SIMD) — it needs ~105, and between 129 and 256 the register
+// allocator starts using AGPRs, which v_readlane (the wave-parallel solve) cannot read (hipcc 7.2
+// stops with "Illegal instruction detected: Operand has incorrect register class").
 template <int D, int Q>
-__global__ __launch_bounds__(kLsmWg) void lsm_persistent_kernel(const LsmPersistArgs a) {
+__global__ __launch_bounds__(kLsmWg, (Q * kLsmWg > 1024 ? 2 : 4)) void lsm_persistent_kernel(
+    const LsmPersistArgs a) {
   constexpr int N = D + 1;
   static_assert(N <= kOffStats && 2 * D <= kGrp, "record layout");
-  __shared__ double scratch[kLsmWaves * kGrp], tot[kRecP2], coef[N], Pt[2 * D + 1];
+  __shared__ double scratch[kLsmWaves * kRecP2], tot[kRecP2], coef[N];
+  __shared__ double dtab[kDiscLds];  // discount^k, k <= n_steps, when the table fits
   // rows t-1 and t-2 of this workgroup's trajectories wait here (a lane only ever touches its own
   // slots): registers hold the stopping state and row t, the partial sums need the rest
   __shared__ double xl[2][Q * kLsmWg];
@@ -735,6 +763,10 @@ __global__ __launch_bounds__(kLsmWg) void lsm_persistent_kernel(const LsmPersist
   const uint64_t p0 = (uint64_t)blockIdx.x * (kLsmWg * Q) + threadIdx.x;
   auto row_ptr = [&](uint32_t row) { return a.grid + (size_t)row * a.ntot; };
   auto live = [&](int j) { return p0 + (uint64_t)j * kLsmWg < a.ntot; };
+  const bool disc_lds = M < (uint32_t)kDiscLds;
+  if (disc_lds)
+    for (uint32_t k = threadIdx.x; k <= M; k += kLsmWg) dtab[k] = a.disc_pow[k];
+  auto disc = [&](int k) { return disc_lds ? dtab[k] : a.disc_pow[k]; };
 
   int tau[Q];
   double val[Q], xs[Q];  // xs = row t, where the next decisions are taken
@@ -759,6 +791,18 @@ __global__ __launch_bounds__(kLsmWg) void lsm_persistent_kernel(const LsmPersist
   }
   int cur = 0;  // xl[cur] = row t-1, xl[cur ^ 1] receives row t-2
   double regressed = 0.0, skipped = 0.0;
+#if HH_LSM_STAMPS
+  unsigned long long st_acc[kLsmStampSlots] = {}, st_t0 = __builtin_amdgcn_s_memrealtime();
+  const bool st_me = blockIdx.x == gridDim.x / 2 && threadIdx.x == 0;
+#define HH_STAMP(k)                                                  \
+  if (st_me) {                                                       \
+    const unsigned long long now = __builtin_amdgcn_s_memrealtime(); \
+    st_acc[k] += now - st_t0;                                        \
+    st_t0 = now;                                                     \
+  }
+#else
+#define HH_STAMP(k)
+#endif
   bool alive = true;
   if (M >= 2) {
     {  // epoch 1: statistics of row M-1
@@ -767,10 +811,13 @@ __global__ __launch_bounds__(kLsmWg) void lsm_persistent_kernel(const LsmPersist
       for (int i = 0; i < kGrp; ++i) v[i] = 0.0;
 #pragma unroll
       for (int j = 0; j < Q; ++j)
-        if (live(j)) add_stats(xs[j], a.cp, a.strike, v + kOffStats);
-      block_reduce_multi<kGrp, kLsmWaves>(v, scratch, tot);
-      if (threadIdx.x < kGrp) tot[kGrp + threadIdx.x] = 0.0;
-      __syncthreads();
+        add_stats(xs[j], a.cp, a.strike, live(j), v + kOffStats);
+      double w[kGrp];
+#pragma unroll
+      for (int i = 0; i < kGrp; ++i) w[i] = 0.0;
+      wave_part<kGrp, kRecP2>(v, scratch, 0);
+      wave_part<kGrp, kRecP2>(w, scratch, kGrp);
+      finish_block<kRecP2, kLsmWaves>(scratch, tot);
       publish_record(a, 1u, tot);
       alive = gather_records(a, 1u, scratch, tot, &ok_flag);
     }
@@ -778,19 +825,17 @@ __global__ __launch_bounds__(kLsmWg) void lsm_persistent_kernel(const LsmPersist
     RowStat r_next = r_cur;
     __syncthreads();  // tot is rewritten below
     if (alive) {  // epoch 2: sums of row M-1 (tau = M everywhere), statistics of row M-2
-      const double d1 = a.disc_pow[1];
+      const double d1 = disc(1);
       {
         double v[kGrp];
 #pragma unroll
         for (int i = 0; i < kGrp; ++i) v[i] = 0.0;
 #pragma unroll
         for (int j = 0; j < Q; ++j) {
-          if (live(j)) {
-            add_moments<D>(xs[j], a.cp, a.strike, r_cur, d1 * val[j], v);
-            if (M >= 3) add_stats(xl[0][j * kLsmWg + threadIdx.x], a.cp, a.strike, v + kOffStats);
-          }
+          add_moments<D>(xs[j], a.cp, a.strike, live(j), r_cur, d1 * val[j], v);
+          if (M >= 3) add_stats(xl[0][j * kLsmWg + threadIdx.x], a.cp, a.strike, live(j), v + kOffStats);
         }
-        block_reduce_multi<kGrp, kLsmWaves>(v, scratch, tot);
+        wave_part<kGrp, kRecP2>(v, scratch, 0);
       }
       {
         double w[kGrp];
@@ -798,44 +843,43 @@ __global__ __launch_bounds__(kLsmWg) void lsm_persistent_kernel(const LsmPersist
         for (int i = 0; i < kGrp; ++i) w[i] = 0.0;
 #pragma unroll
         for (int j = 0; j < Q; ++j)
-          if (live(j)) add_powers_from1<D>(xs[j], a.cp, a.strike, r_cur, w);
-        block_reduce_multi<kGrp, kLsmWaves>(w, scratch, tot + kGrp);
+          add_powers_from1<D>(xs[j], a.cp, a.strike, live(j), r_cur, w);
+        wave_part<kGrp, kRecP2>(w, scratch, kGrp);
       }
+      finish_block<kRecP2, kLsmWaves>(scratch, tot);
       publish_record(a, 2u, tot);
     }
     // for i = nsteps:-1:2, t = i-1 (:112-113)
     for (uint32_t t = M - 1; alive && t >= 1; --t) {
       const uint32_t e = M - t + 1;  // epoch whose records hold the sums of row t
-      double sv[3] = {0.0, 0.0, 0.0};
-      if (t >= 3) {  // row t-2: its statistics need nothing from the gather
+      HH_STAMP(7)
+      double xin[Q];  // row t-2: issued here, in flight behind the gather, the solve and the decisions
+      if (t >= 3) {
         const double* S2 = row_ptr(t - 2);
 #pragma unroll
-        for (int j = 0; j < Q; ++j) {
+        for (int j = 0; j < Q; ++j) {  // clamped, not guarded: 16 loads issue back to back
           const uint64_t p = p0 + (uint64_t)j * kLsmWg;
-          const double x = p < a.ntot ? S2[p] : 0.0;
-          xl[cur ^ 1][j * kLsmWg + threadIdx.x] = x;
-          if (p < a.ntot) add_stats(x, a.cp, a.strike, sv);
+          xin[j] = S2[p < a.ntot ? p : a.ntot - 1];
         }
       }
+      HH_STAMP(0)  // row t-2 issued
       alive = gather_records(a, e, scratch, tot, &ok_flag);
+      HH_STAMP(1)  // all-gather: wait, loads, reduction
       if (!alive) break;
       if (t >= 2) r_next = rowstat_of(tot[kOffStats], tot[kOffStats + 1], tot[kOffStats + 2]);  // row t-1
-      // Gram matrix entries of row t: P[0] = n, P[k] from group B
-      if (threadIdx.x == 0) Pt[0] = r_cur.n;
-      if (threadIdx.x >= 1 && threadIdx.x <= 2 * D) Pt[threadIdx.x] = tot[kGrp + threadIdx.x - 1];
-      __syncthreads();
-      fit_row<D>(r_cur.n, tot, Pt, coef, &have_fit);
+      fit_row<D>(r_cur.n, tot, tot + kGrp, coef, &have_fit);  // Gram entries: P[0] = n, P[k] = group B
+      HH_STAMP(2)  // normal equations
       if (r_cur.n > 0.0) regressed += 1.0; else skipped += 1.0;
       if (have_fit) {
 #pragma unroll
         for (int j = 0; j < Q; ++j) {
           double pay;
-          if (live(j) && exercise_now<D>(xs[j], a.cp, a.strike, r_cur, coef, pay)) {
-            tau[j] = (int)t;
-            val[j] = pay;
-          }
+          const bool ex = exercise_now<D>(xs[j], a.cp, a.strike, live(j), r_cur, coef, pay);
+          tau[j] = ex ? (int)t : tau[j];
+          val[j] = ex ? pay : val[j];
         }
       }
+      HH_STAMP(3)  // exercise decisions
       if (t >= 2) {
         // sums of row t-1 (xl[cur]) with the stopping state as of now; statistics of row t-2 (sv);
         // row t-1 moves into the registers on the way: it is the next decision row
@@ -846,24 +890,31 @@ __global__ __launch_bounds__(kLsmWg) void lsm_persistent_kernel(const LsmPersist
           double v[kGrp];
 #pragma unroll
           for (int i = 0; i < kGrp; ++i) v[i] = 0.0;
-          v[kOffStats] = sv[0]; v[kOffStats + 1] = sv[1]; v[kOffStats + 2] = sv[2];
+          if (t >= 3) {  // row t-2 has landed: park it in LDS (it becomes row t-1 next), its statistics
+#pragma unroll
+            for (int j = 0; j < Q; ++j) {
+              xl[cur ^ 1][j * kLsmWg + threadIdx.x] = xin[j];
+              add_stats(xin[j], a.cp, a.strike, live(j), v + kOffStats);
+            }
+          }
 #pragma unroll
           for (int j = 0; j < Q; ++j)
-            if (live(j))
-              add_moments<D>(xs[j], a.cp, a.strike, r_next,
-                             a.disc_pow[tau[j] - (int)(t - 1)] * val[j], v);
-          block_reduce_multi<kGrp, kLsmWaves>(v, scratch, tot);
+            add_moments<D>(xs[j], a.cp, a.strike, live(j), r_next, disc(tau[j] - (int)(t - 1)) * val[j], v);
+          wave_part<kGrp, kRecP2>(v, scratch, 0);
         }
+        HH_STAMP(4)  // moment sums + their wave butterfly
         {
           double w[kGrp];
 #pragma unroll
           for (int i = 0; i < kGrp; ++i) w[i] = 0.0;
 #pragma unroll
-          for (int j = 0; j < Q; ++j)
-            if (live(j)) add_powers_from1<D>(xs[j], a.cp, a.strike, r_next, w);
-          block_reduce_multi<kGrp, kLsmWaves>(w, scratch, tot + kGrp);
+          for (int j = 0; j < Q; ++j) add_powers_from1<D>(xs[j], a.cp, a.strike, live(j), r_next, w);
+          wave_part<kGrp, kRecP2>(w, scratch, kGrp);
         }
+        HH_STAMP(5)  // power sums + their wave butterfly
+        finish_block<kRecP2, kLsmWaves>(scratch, tot);
         publish_record(a, e + 1, tot);
+        HH_STAMP(6)  // workgroup totals, publish
         }
         cur ^= 1;
         r_cur = r_next;
@@ -883,7 +934,12 @@ __global__ __launch_bounds__(kLsmWg) void lsm_persistent_kernel(const LsmPersist
     a.counters[0] = regressed;
     a.counters[1] = skipped;
   }
+#if HH_LSM_STAMPS
+  if (st_me)
+    for (int k = 0; k < kLsmStampSlots; ++k) a.counters[2 + k] = (double)st_acc[k];
+#endif
 }
+#undef HH_STAMP
 
 // ---- launch sequences ---------------------------------------------------------------------------
 
@@ -934,31 +990,31 @@ LsmStepArgs lsm_step_args(const LsmLayout& L, const double* grid, uint64_t ntot,
 
 void launch_stats(const LsmLayout& L, const LsmStepArgs& a, hipStream_t s) {
   const dim3 g(L.nch, L.rows), b(kLsmWg);
-  if (L.q == 1)
-    hipLaunchKernelGGL(lsm_stats_kernel<1>, g, b, 0, s, a.grid, a.ntot, a.strike, a.cp, L.nch, L.rec_stats);
+  if (L.q == kLsmQSmall)
+    hipLaunchKernelGGL(lsm_stats_kernel<kLsmQSmall>, g, b, 0, s, a.grid, a.ntot, a.strike, a.cp, L.nch, L.rec_stats);
   else
-    hipLaunchKernelGGL(lsm_stats_kernel<8>, g, b, 0, s, a.grid, a.ntot, a.strike, a.cp, L.nch, L.rec_stats);
+    hipLaunchKernelGGL(lsm_stats_kernel<kLsmQLarge>, g, b, 0, s, a.grid, a.ntot, a.strike, a.cp, L.nch, L.rec_stats);
 }
 
 template <int D>
 void launch_pow(const LsmLayout& L, const LsmStepArgs& a, hipStream_t s) {
   const dim3 g(L.nch, L.rows), b(kLsmWg);
-  if (L.q == 1)
-    hipLaunchKernelGGL((lsm_pow_kernel<D, 1>), g, b, 0, s, a.grid, a.ntot, a.strike, a.cp, L.nch, a.rs, L.rec_pow);
+  if (L.q == kLsmQSmall)
+    hipLaunchKernelGGL((lsm_pow_kernel<D, kLsmQSmall>), g, b, 0, s, a.grid, a.ntot, a.strike, a.cp, L.nch, a.rs, L.rec_pow);
   else
-    hipLaunchKernelGGL((lsm_pow_kernel<D, 8>), g, b, 0, s, a.grid, a.ntot, a.strike, a.cp, L.nch, a.rs, L.rec_pow);
+    hipLaunchKernelGGL((lsm_pow_kernel<D, kLsmQLarge>), g, b, 0, s, a.grid, a.ntot, a.strike, a.cp, L.nch, a.rs, L.rec_pow);
 }
 
 template <int D>
 void launch_init(const LsmLayout& L, const LsmStepArgs& a, hipStream_t s) {
-  if (L.q == 1) hipLaunchKernelGGL((lsm_init_kernel<D, 1>), dim3(a.n_chunks), dim3(kLsmWg), 0, s, a);
-  else hipLaunchKernelGGL((lsm_init_kernel<D, 8>), dim3(a.n_chunks), dim3(kLsmWg), 0, s, a);
+  if (L.q == kLsmQSmall) hipLaunchKernelGGL((lsm_init_kernel<D, kLsmQSmall>), dim3(a.n_chunks), dim3(kLsmWg), 0, s, a);
+  else hipLaunchKernelGGL((lsm_init_kernel<D, kLsmQLarge>), dim3(a.n_chunks), dim3(kLsmWg), 0, s, a);
 }
 
 template <int D>
 void launch_step(const LsmLayout& L, const LsmStepArgs& a, uint32_t t, hipStream_t s) {
-  if (L.q == 1) hipLaunchKernelGGL((lsm_step_kernel<D, 1>), dim3(a.n_chunks), dim3(kLsmWg), 0, s, a, t);
-  else hipLaunchKernelGGL((lsm_step_kernel<D, 8>), dim3(a.n_chunks), dim3(kLsmWg), 0, s, a, t);
+  if (L.q == kLsmQSmall) hipLaunchKernelGGL((lsm_step_kernel<D, kLsmQSmall>), dim3(a.n_chunks), dim3(kLsmWg), 0, s, a, t);
+  else hipLaunchKernelGGL((lsm_step_kernel<D, kLsmQLarge>), dim3(a.n_chunks), dim3(kLsmWg), 0, s, a, t);
 }
 
 // the whole induction on one device, one launch per date
@@ -998,13 +1054,13 @@ int run_lsm_persistent(const LsmLayout& L, const LsmStepArgs& s_args, hipStream_
   a.status = a.tags + (size_t)kLsmRing * kLsmMaxResident;
   a.rec = reinterpret_cast<unsigned long long*>(L.sync + kSyncDoubles);
   a.spin_ticks = 100000000ull;  // 1 s of the 100 MHz constant clock
-  const bool fits = L.q == 1 ? grid_fits(lsm_persistent_kernel<D, 1>, L.nch)
-                             : grid_fits(lsm_persistent_kernel<D, 8>, L.nch);
+  const bool fits = L.q == kLsmQSmall ? grid_fits(lsm_persistent_kernel<D, kLsmQSmall>, L.nch)
+                             : grid_fits(lsm_persistent_kernel<D, kLsmQLarge>, L.nch);
   if (!fits) return 1;
   hipError_t e = hipMemsetAsync(L.sync, 0, kSyncDoubles * sizeof(double), s);
   if (e != hipSuccess) return (int)e;
-  if (L.q == 1) hipLaunchKernelGGL((lsm_persistent_kernel<D, 1>), dim3(L.nch), dim3(kLsmWg), 0, s, a);
-  else hipLaunchKernelGGL((lsm_persistent_kernel<D, 8>), dim3(L.nch), dim3(kLsmWg), 0, s, a);
+  if (L.q == kLsmQSmall) hipLaunchKernelGGL((lsm_persistent_kernel<D, kLsmQSmall>), dim3(L.nch), dim3(kLsmWg), 0, s, a);
+  else hipLaunchKernelGGL((lsm_persistent_kernel<D, kLsmQLarge>), dim3(L.nch), dim3(kLsmWg), 0, s, a);
   return (int)hipGetLastError();
 }
 
@@ -1052,9 +1108,9 @@ size_t lsm_scratch_doubles(uint64_t ntot, uint32_t n_steps, int degree) {
   const size_t rows = (size_t)n_steps + 1, ch = lsm_nch(ntot);
   const size_t nv = 2 * (size_t)degree + 1;
   // sync | ring | rec_stats [rows][ch][3] | rowstat [rows][3] | rec_pow [rows][ch][nv] | P [rows][nv] |
-  // recB [rows][ch][degree+1] | disc_pow [rows] | counters [2]
+  // recB [rows][ch][degree+1] | disc_pow [rows] | counters [2] | phase stamps of a diagnostic build [8]
   return kSyncDoubles + kRingDoubles + rows * ch * 3 + rows * 3 + rows * ch * nv + rows * nv +
-         rows * ch * (degree + 1) + rows + 2;
+         rows * ch * (degree + 1) + rows + 2 + kLsmStampSlots;
 }
 
 int launch_gbm_grid(const uint64_t* seeds_dev, uint64_t n_paths, uint32_t n_steps, double S0,
@@ -1093,14 +1149,14 @@ int launch_lsm(const double* grid, uint64_t ntot, uint32_t n_steps, double strik
                double* records, hipStream_t s, int form, int* form_used) {
   if (degree < 1 || degree > kLsmMaxDeg) return (int)hipErrorInvalidValue;
   const LsmLayout L = lsm_layout(scratch, ntot, n_steps, degree);
-  hipError_t e = hipMemsetAsync(L.counters, 0, 2 * sizeof(double), s);
+  hipError_t e = hipMemsetAsync(L.counters, 0, (2 + kLsmStampSlots) * sizeof(double), s);
   if (e != hipSuccess) return (int)e;
   const dim3 b(256);
   const LsmStepArgs a = lsm_step_args(L, grid, ntot, n_steps, strike, cp, step_discount, tau, val);
   hipLaunchKernelGGL(lsm_disc_kernel, dim3((L.rows + 255) / 256), b, 0, s, a.ln_disc, n_steps,
                      L.disc_pow);
   int rc = 1;
-  if (form == kLsmFormPersistent) {
+  if (form == kLsmFormPersistent || (form == kLsmFormAuto && L.q == kLsmQLarge)) {
 #define HH_CALL(D) run_lsm_persistent<D>(L, a, s)
     HH_LSM_DISPATCH(degree, HH_CALL)
 #undef HH_CALL
@@ -1135,7 +1191,7 @@ int launch_lsm_phase(int phase, uint32_t t, const double* grid, uint64_t ntot, u
   const LsmStepArgs a = lsm_step_args(L, grid, ntot, n_steps, strike, cp, step_discount, tau, val);
   const dim3 b(256);
   if (phase == kLsmPhaseStats) {
-    hipError_t e = hipMemsetAsync(L.counters, 0, 2 * sizeof(double), s);
+    hipError_t e = hipMemsetAsync(L.counters, 0, (2 + kLsmStampSlots) * sizeof(double), s);
     if (e != hipSuccess) return (int)e;
     launch_stats(L, a, s);
     hipLaunchKernelGGL(lsm_sum_records_kernel<3>, dim3(L.rows), dim3(kLsmWg), 0, s, L.rec_stats, L.nch,

@@ -73,7 +73,7 @@ def test_one_launch_and_launch_per_date_agree_bit_for_bit(hhlib, n, steps, anti,
                                 want_grid=False)
             assert out[form][0].form == form
     finally:
-        hhlib.set_option(_ffi.HH_OPT_LSM_FORM, _ffi.HH_LSM_FORM_PERSISTENT)
+        hhlib.set_option(_ffi.HH_OPT_LSM_FORM, _ffi.HH_LSM_FORM_AUTO)
     (ra, ta, va, _, _), (rb, tb, vb, _, _) = out[1], out[0]
     np.testing.assert_array_equal(ta, tb)
     np.testing.assert_array_equal(va, vb)

@@ -35,6 +35,6 @@ for n in sizes:
         line.append(f"{name} (ran as form {res.form}): {np.median(ks[2:]):.3f} ms events, "
                     f"{np.median(ws[2:]):.3f} ms wall")
         prices.append(res.price)
-    ctx.set_option(_ffi.HH_OPT_LSM_FORM, _ffi.HH_LSM_FORM_PERSISTENT)
+    ctx.set_option(_ffi.HH_OPT_LSM_FORM, _ffi.HH_LSM_FORM_AUTO)
     print(f"n={n:8d} x2 antithetic, {steps} dates: " + " | ".join(line) +
           f" | price {prices[0]:.6f} identical={prices[0] == prices[1]}", flush=True)
