@@ -135,8 +135,6 @@ int validate(hh_ctx* ctx, const hh_model* m, const hh_config* c) {
       return fail(ctx, HH_ERR_UNSUPPORTED, "HestonBroadieKaya has no antithetic form");
     if (c->n_partials)
       return fail(ctx, HH_ERR_UNSUPPORTED, "HestonBroadieKaya does not carry dual partials");
-    if (c->noise_mode != HH_NOISE_GENERATE)
-      return fail(ctx, HH_ERR_UNSUPPORTED, "HestonBroadieKaya has no REPLAY mode");
     if (m->sigma == 0.0 || m->kappa == 0.0 || !(m->V0 > 0.0))
       return fail(ctx, HH_ERR_INVALID, "HestonBroadieKaya needs sigma != 0, kappa != 0, V0 > 0");
   }
@@ -147,6 +145,7 @@ int validate(hh_ctx* ctx, const hh_model* m, const hh_config* c) {
       return fail(ctx, HH_ERR_INVALID, "replay buffer must be 16-byte aligned");
     if (c->replay_len) {  // operand shape: what the kernels (or the packer) will index
       uint64_t need = c->n_paths;  // exact law: one normal per trajectory
+      if (c->strategy == HH_BROADIE_KAYA) need = 3 * c->n_paths;  // V_T | u | Z
       if (euler)
         need = c->replay_layout == HH_REPLAY_PATH_MAJOR
                    ? c->n_paths * (uint64_t)c->n_steps * (uint64_t)ncomp_of(c->dynamics)
@@ -323,7 +322,8 @@ static int run_simulation(hh_ctx* ctx, const hh_model* m, const hh_config* c, do
   int rc = HH_OK;
   const uint32_t n_tiles = hh::tiles_for(c->n_paths);
   const bool bk = c->strategy == HH_BROADIE_KAYA;
-  rc = ensure(ctx, ctx->records, ctx->records_cap, (size_t)n_tiles * hh::kRecStride * (bk ? 2 : 1));
+  rc = ensure(ctx, ctx->records, ctx->records_cap,
+              (size_t)(bk ? hh::bk_record_count(c->n_paths) : n_tiles) * hh::kRecStride);
   if (rc) return rc;
 
   hh::DevicePtrs p{};
@@ -345,6 +345,18 @@ static int run_simulation(hh_ctx* ctx, const hh_model* m, const hh_config* c, do
       HH_HIP(ctx, hipMemcpyAsync(ctx->seeds, c->seeds, need * sizeof(uint64_t),
                                  hipMemcpyHostToDevice, ctx->stream));
       p.seeds = ctx->seeds;
+    }
+  } else if (bk) {
+    // the trajectory's three draws [V_T | u | Z], n_paths each (heston.jl:246-259 order)
+    const size_t n3 = (size_t)3 * c->n_paths;
+    if (c->replay_on_device) {
+      p.replay = c->replay;
+    } else {
+      rc = ensure(ctx, ctx->replay, ctx->replay_cap, n3);
+      if (rc) return rc;
+      HH_HIP(ctx, hipMemcpyAsync(ctx->replay, c->replay, n3 * sizeof(double), hipMemcpyHostToDevice,
+                                 ctx->stream));
+      p.replay = ctx->replay;
     }
   } else {
     const uint32_t steps = (c->strategy == HH_EULER_MARUYAMA) ? c->n_steps : 1;
@@ -425,7 +437,8 @@ int hh_mc_accumulate(hh_ctx* ctx, const hh_model* m, const hh_config* c, double*
   HH_HIP(ctx, hipSetDevice(ctx->device));
   rc = run_simulation(ctx, m, c, terminal, false, nullptr);
   if (rc) return rc;
-  const uint32_t n_rec = hh::tiles_for(c->n_paths) * (c->strategy == HH_BROADIE_KAYA ? 2u : 1u);
+  const uint32_t n_rec = c->strategy == HH_BROADIE_KAYA ? hh::bk_record_count(c->n_paths)
+                                                        : hh::tiles_for(c->n_paths);
   HH_HIP(ctx, hh::launch_reduce_records(ctx->records, n_rec, (double)c->n_paths, accum_dev,
                                         ctx->stream, 1, m, c));
   return copy_back_terminal(ctx, c, terminal);
@@ -471,6 +484,11 @@ int hh_mc_accumulate_basket(hh_ctx* ctx, const hh_model* m, const hh_config* c,
   HH_HIP(ctx, hh::launch_basket_payoffs(b, n_payoffs, (uint32_t)n_active, ctx->stream));
   HH_HIP(ctx, hh::launch_reduce_records(ctx->basket_records, b.n_chunks, (double)c->n_paths,
                                         accum_dev, ctx->stream, n_payoffs, m, c, true));
+  if (c->strategy == HH_BROADIE_KAYA) {  // the simulation's fall-back / series counters, for every payoff
+    HH_HIP(ctx, hh::launch_reduce_records(ctx->records, hh::bk_record_count(c->n_paths),
+                                          (double)c->n_paths, ctx->accum, ctx->stream, 1, m, c));
+    HH_HIP(ctx, hh::launch_copy_bk_counters(ctx->accum, accum_dev, n_payoffs, ctx->stream));
+  }
   return copy_back_terminal(ctx, c, terminal);
 }
 
@@ -698,7 +716,7 @@ static int run_heston_grid(hh_ctx* ctx, const hh_model* m, const hh_config* c) {
   int rc;
   if ((rc = ensure(ctx, ctx->lsm_grid, ctx->lsm_grid_cap, grid_elems))) return rc;
   if ((rc = ensure(ctx, ctx->heston_var, ctx->heston_var_cap, grid_elems))) return rc;
-  if ((rc = ensure(ctx, ctx->records, ctx->records_cap, (size_t)n_tiles * hh::kRecStride * 2)))
+  if ((rc = ensure(ctx, ctx->records, ctx->records_cap, (size_t)hh::bk_record_count(n) * hh::kRecStride)))
     return rc;
   if ((rc = ensure(ctx, ctx->bk_scratch, ctx->bk_scratch_cap, hh::bk_scratch_bytes(n)))) return rc;
   if ((rc = ensure(ctx, ctx->basket_accum, ctx->basket_accum_cap, (size_t)c->n_steps * HH_ACC_LEN)))
@@ -718,7 +736,7 @@ static int run_heston_grid(hh_ctx* ctx, const hh_model* m, const hh_config* c) {
                               ctx->lsm_grid + (size_t)(k + 1) * n,
                               ctx->heston_var + (size_t)(k + 1) * n, k};
     HH_HIP(ctx, hh::launch_bk(step_model, step_cfg, p, ctx->stream, &tr));
-    HH_HIP(ctx, hh::launch_reduce_records(ctx->records, 2 * n_tiles, (double)n,
+    HH_HIP(ctx, hh::launch_reduce_records(ctx->records, hh::bk_record_count(n), (double)n,
                                           ctx->basket_accum + (size_t)k * HH_ACC_LEN, ctx->stream,
                                           1, &step_model, &step_cfg));
   }

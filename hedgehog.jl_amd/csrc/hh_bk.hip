@@ -8,6 +8,13 @@
 //   3. log S_T = μ + sqrt((1-ρ²)∫V)·Z                         heston.jl:278-300
 // then S_T = exp(.), payoff and the workgroup reduction as in hh_kernels.hip.
 //
+// Launch structure: bk_draw_kernel (the trajectory's three draws V_T, u, Z — or the caller's, in
+// REPLAY mode — and the normal quantile of u) -> bk_kernel (characteristic function, moments, secant
+// inversion) -> bk_scan_kernel -> bk_fallback_kernel (bisection ladder for the flagged trajectories).
+// The draws live in their own launch because the NCχ² sampler's library calls (pow, lgamma, log,
+// normcdfinv) and the CF arithmetic are two different register-hungry programs: together they cost
+// 228 registers per lane (2 waves per SIMD); apart, the CF kernels fit 128 (4 waves).
+//
 // Third-party pieces of the reference restated here from their published algorithms (DESIGN.md
 // "Broadie–Kaya"): complex log I_ν(z) for real ν > -1 (power series / Hankel asymptotics /
 // backward ratio recurrence), NCχ² (normal shift for d > 1, else Poisson mixture; Marsaglia–Tsang
@@ -27,6 +34,9 @@ constexpr int kCoef = 32;
 constexpr double kPi = 3.14159265358979323846;
 constexpr double kTwoPi = 6.28318530717958647692;
 constexpr double kSeriesR = 13.0;  // |z| below which the power series is used for the base order
+
+constexpr int kPackedGrid = 256;  // workgroups of the packed (grid-stride) ladder kernel
+constexpr int kHeavyGrid = 64;    // … of the fall-back kernel (empty with the reference's controls)
 
 struct BkArgs {
   // model
@@ -54,7 +64,13 @@ struct BkArgs {
   double* out_var;
   uint32_t step;
   double* records;                 // [2·n_tiles][kRecStride]: phase 1, then phase 2
-  unsigned long long* fail_mask;   // [n_tiles][4] ballots of the trajectories left to phase 2
+  double* draws;                   // [4][draw_stride]: Z, u, normal quantile of u, V_T per trajectory
+  size_t draw_stride;
+  const double* replay;            // REPLAY: the caller's [3][n_paths] V_T, u, Z (device), else NULL
+  double* rec;                     // [4][draw_stride]: h, initial_guess, max_guess, series length
+  unsigned long long* fail_mask;   // [n_tiles][4] ballots: secant failed, the ladder is left (bk_ladder_kernel)
+  unsigned long long* long_mask;   // [n_tiles][4] ballots: series longer than the cache, not inverted yet
+                                   //              (bk_fallback_kernel runs these whole)
   double* phi_cache;               // [cache_cap][cache_stride] cached Re ϕ(h·j), one column per lane
   size_t cache_stride;
   int cache_cap;
@@ -92,17 +108,17 @@ __device__ __forceinline__ cx csqrt(cx z) {
   const double t = sqrt(0.5 * (r - z.re));
   return {fabs(z.im) * rcp_nr(2.0 * t), copysign(t, z.im)};
 }
-// sin, cos: the range-specialised pair of hh_math.h; the library routine (with its full-range
-// reduction) only beyond |x| = 2^20, which no parameter set of the tests reaches
+// sin, cos: the range-specialised pair of hh_math.h; beyond |x| = 2^20 (which no parameter set of
+// the tests reaches) its three-term reduction, good to 2^45
 __device__ __forceinline__ void sincos_cf(double x, double& s, double& c) {
   if (fabs(x) <= 0x1p20) {
     fm::sincos(x, s, c);
   } else {
-    sincos(x, &s, &c);
+    fm::sincos_wide(x, s, c);
   }
 }
 __device__ __forceinline__ cx cexp(cx z) {
-  const double e = exp(z.re);
+  const double e = fm::exp(z.re);
   double s, c;
   sincos_cf(z.im, s, c);
   return {e * c, e * s};
@@ -362,54 +378,60 @@ __device__ int poisson(double mu, const PathDraws& dr, int& it) {
   }
 }
 
-// everything a trajectory needs before the CDF inversion: draws, V_T, CF iterator, moments
-struct PathSetup {
-  double Z, u, VT, V0, logS0;
-  CfIter cf;
-  PhiCache cache;
-  double initial_guess, max_guess, h;
-};
-
-__device__ void bk_setup(const BkArgs& p, uint64_t path, PathSetup& s) {
-  s.cache.col = p.phi_cache + ((size_t)blockIdx.x * kTile + threadIdx.x);
-  s.cache.stride = p.cache_stride;
-  s.cache.cap = p.cache_cap;
-  s.cache.filled = 0;
-  s.cache.j_stop = 0;
-  s.cache.theta_run = __builtin_nan("");
-  s.cache.theta_cap = __builtin_nan("");
-  // terminal law: ONE stream, seeds[1], indexed by trajectory (montecarlo.jl:456); grid: the
-  // trajectory's own seed (montecarlo.jl:331), indexed by the transition
-  const bool grid = p.in_var != nullptr;
-  const uint64_t key = grid ? p.seeds[path] : p.seeds[0];
-  const uint64_t G = grid ? (uint64_t)p.step : p.path_offset + path;
-  s.V0 = grid ? p.in_var[path] : p.V0;
-  s.logS0 = grid ? log(p.in_spot[path]) : p.logS0;  // heston.jl:84: S = exp(W[1]), then log(S0) :289
-  const double lam = p.lam_num * s.V0 / p.lam_den;  // heston.jl:129
-  const PathDraws dr{(uint32_t)key, (uint32_t)(key >> 32), (uint32_t)G, (uint32_t)(G >> 32)};
-  double zshift, u_boost;
-  dr.normals(0u, s.Z, zshift);
-  dr.uniforms(1u, s.u, u_boost);
-
-  // 1. V_T (heston.jl:131)
-  int it = 0;
-  double chi;
-  if (p.d > 1.0) {
-    const double g = gamma_any(0.5 * (p.d - 1.0), dr, it, u_boost);
-    const double sh = zshift + sqrt(lam);
-    chi = sh * sh + 2.0 * g;
+// The three draws of a trajectory (reference order, heston.jl:246-259: V_T from the NCχ² law, then u
+// inside sample_from_cf, then Z inside sample_log_S_T) and the normal quantile of u, left in
+// draws[4][stride] for the CF kernels.  REPLAY: V_T, u, Z are the caller's (replay[3][n_paths]) —
+// the seam through which the reference's own draws reach sample_from_cf / inverse_cdf per trajectory.
+template <bool REPLAY>
+__global__ __launch_bounds__(kTile) void bk_draw_kernel(const BkArgs p) {
+  const uint64_t path = (uint64_t)blockIdx.x * kTile + threadIdx.x;
+  if (path >= p.n_paths) return;
+  double Z, u, VT;
+  if constexpr (REPLAY) {
+    VT = p.replay[path];
+    u = p.replay[p.n_paths + path];
+    Z = p.replay[2 * p.n_paths + path];
   } else {
-    const int n = poisson(0.5 * lam, dr, it);
-    chi = 2.0 * gamma_any(0.5 * p.d + (double)n, dr, it, u_boost);
+    // terminal law: ONE stream, seeds[1], indexed by trajectory (montecarlo.jl:456); grid: the
+    // trajectory's own seed (montecarlo.jl:331), indexed by the transition
+    const bool grid = p.in_var != nullptr;
+    const uint64_t key = grid ? p.seeds[path] : p.seeds[0];
+    const uint64_t G = grid ? (uint64_t)p.step : p.path_offset + path;
+    const double V0 = grid ? p.in_var[path] : p.V0;
+    const double lam = p.lam_num * V0 / p.lam_den;  // heston.jl:129
+    const PathDraws dr{(uint32_t)key, (uint32_t)(key >> 32), (uint32_t)G, (uint32_t)(G >> 32)};
+    double zshift, u_boost;
+    dr.normals(0u, Z, zshift);
+    dr.uniforms(1u, u, u_boost);
+    // V_T (heston.jl:131)
+    int it = 0;
+    double chi;
+    if (p.d > 1.0) {
+      const double g = gamma_any(0.5 * (p.d - 1.0), dr, it, u_boost);
+      const double sh = zshift + sqrt(lam);
+      chi = sh * sh + 2.0 * g;
+    } else {
+      const int n = poisson(0.5 * lam, dr, it);
+      chi = 2.0 * gamma_any(0.5 * p.d + (double)n, dr, it, u_boost);
+    }
+    VT = p.cscale * chi;
   }
-  s.VT = p.cscale * chi;
+  double* d = p.draws + path;  // trajectory index == lane index of the CF kernels' tiles
+  d[0] = Z;
+  d[p.draw_stride] = u;
+  d[2 * p.draw_stride] = normcdfinv(u);  // quantile(Normal(), u) (sample_from_cf.jl:33)
+  d[3 * p.draw_stride] = VT;
+}
 
-  // 2. HestonCFIterator (heston.jl:165-176) and the moment heuristics (sample_from_cf.jl:31-37)
-  s.cf.VT = s.VT;
-  s.cf.sqrtV0VT = sqrt(s.V0 * s.VT);
-  s.cf.sumV = (s.V0 + s.VT) / p.sigma2;
-  const LogMul Ik = besseli_logmul(p, {p.nuk_factor * s.cf.sqrtV0VT, 0.0}, 0.0);
-  s.cf.logI_k = Ik.lg.re + log(Ik.mul.re);  // real, positive argument: I_ν > 0
+// HestonCFIterator (heston.jl:165-176) and the moment heuristics (sample_from_cf.jl:31-37) of one
+// trajectory, from its start variance, its V_T and the normal quantile of its uniform
+__device__ __forceinline__ void cf_setup(const BkArgs& p, double V0, double VT, double q_u, CfIter& cf,
+                                         double& initial_guess, double& max_guess, double& h) {
+  cf.VT = VT;
+  cf.sqrtV0VT = sqrt(V0 * VT);
+  cf.sumV = (V0 + VT) / p.sigma2;
+  const LogMul Ik = besseli_logmul(p, {p.nuk_factor * cf.sqrtV0VT, 0.0}, 0.0);
+  cf.logI_k = Ik.lg.re + fm::log(Ik.mul.re);  // real, positive argument: I_ν > 0
   // moments_from_cf (sample_from_cf.jl:50-61): mean = Re(-i ϕ'(0)), variance = Re(-ϕ''(0)) - mean²
   // by central differences of step hm over ϕ(hm), ϕ(0), ϕ(-hm).  The law is real, so ϕ(-a) is the
   // conjugate of ϕ(a) — operation by operation, also in floating point — and is not evaluated.
@@ -418,28 +440,54 @@ __device__ void bk_setup(const BkArgs& p, uint64_t path, PathSetup& s) {
   // formed from numbers 1e-10 apart.
   double th = __builtin_nan("");
   const double hm = p.moment_h;
-  const cx pp = evaluate_chf(p, s.cf, hm, th);
-  const cx p0 = evaluate_chf(p, s.cf, 0.0, th);
+  const cx pp = evaluate_chf(p, cf, hm, th);
+  const cx p0 = evaluate_chf(p, cf, 0.0, th);
   const double mean = pp.im / hm;                                          // (ϕ₊ - ϕ₋)/(2h)
   const double var = -(2.0 * (pp.re - p0.re) / (hm * hm)) - mean * mean;  // (ϕ₊ - 2ϕ₀ + ϕ₋)/h²
   const double sd = sqrt(fmax(var, 1e-12));
-  const double normal_sample = mean + sd * normcdfinv(s.u);
-  s.initial_guess = normal_sample > 0.0 ? normal_sample : mean * 0.01;
-  s.max_guess = mean + 11.0 * sd;
-  s.h = kPi / (mean + p.n_sigma * sd);
+  const double normal_sample = mean + sd * q_u;
+  initial_guess = normal_sample > 0.0 ? normal_sample : mean * 0.01;
+  max_guess = mean + 11.0 * sd;
+  h = kPi / (mean + p.n_sigma * sd);
+}
+
+// everything a trajectory of the fall-back kernel needs before the CDF inversion
+struct PathSetup {
+  double Z, u, VT, V0, logS0;
+  CfIter cf;
+  PhiCache cache;
+  double initial_guess, max_guess, h;
+};
+
+__device__ void bk_setup(const BkArgs& p, uint64_t path, PathSetup& s) {
+  s.cache.col = p.phi_cache + path;  // the trajectory's own column, filled again from the start
+  s.cache.stride = p.cache_stride;
+  s.cache.cap = p.cache_cap;
+  s.cache.filled = 0;
+  s.cache.j_stop = 0;
+  s.cache.theta_run = __builtin_nan("");
+  s.cache.theta_cap = __builtin_nan("");
+  const bool grid = p.in_var != nullptr;
+  s.V0 = grid ? p.in_var[path] : p.V0;
+  s.logS0 = grid ? fm::log(p.in_spot[path]) : p.logS0;  // heston.jl:84: S = exp(W[1]), then log(S0) :289
+  const double* d = p.draws + path;
+  s.Z = d[0];
+  s.u = d[p.draw_stride];
+  s.VT = d[3 * p.draw_stride];
+  cf_setup(p, s.V0, s.VT, d[2 * p.draw_stride], s.cf, s.initial_guess, s.max_guess, s.h);
 }
 
 // 3. log S_T (heston.jl:288-297), S_T = exp(.) (montecarlo.jl:384), payoff
-__device__ __forceinline__ double bk_finish(const BkArgs& p, const PathSetup& s, double IV,
-                                            uint64_t path) {
-  const double mu = s.logS0 + p.r * p.T - 0.5 * IV +
-                    (p.rho / p.sigma) * (s.VT - s.V0 - p.kappa * p.theta * p.T + p.kappa * IV);
+__device__ __forceinline__ double bk_finish(const BkArgs& p, double logS0, double V0, double VT,
+                                            double Z, double IV, uint64_t path) {
+  const double mu = logS0 + p.r * p.T - 0.5 * IV +
+                    (p.rho / p.sigma) * (VT - V0 - p.kappa * p.theta * p.T + p.kappa * IV);
   const double sigma2 = (1.0 - p.rho * p.rho) * IV;
-  const double S = exp(mu + sqrt(sigma2) * s.Z);
+  const double S = fm::exp(mu + sqrt(sigma2) * Z);
   if (p.terminal) p.terminal[path] = S;
   if (p.out_spot) {
     p.out_spot[path] = S;
-    p.out_var[path] = s.VT;
+    p.out_var[path] = VT;
   }
   const double m = p.cp * (S - p.strike);
   return m > 0.0 ? m : 0.0;
@@ -475,138 +523,263 @@ __device__ __forceinline__ void bk_store_record(double (&acc)[6], double* rec) {
   }
 }
 
-// Phase 1: every trajectory up to and including the secant iteration of inverse_cdf
-// (sample_from_cf.jl:116-122).  A trajectory whose secant fails is NOT finished here: one such lane
-// would keep its whole wave in the ~15-evaluation bisection ladder (2 % of the paths fail, so 3 out
-// of 4 waves would).  It is flagged in a per-wave ballot instead and finished, densely packed, by
-// bk_fallback_kernel.  Flags are ballots in trajectory order, so the result is bit-reproducible.
-__global__ __launch_bounds__(kTile) void bk_kernel(const BkArgs p) {
+// secant of inverse_cdf (sample_from_cf.jl:116-122) on a CDF given as a callable: Order2 restated as
+// the secant iteration from (x0 + dx, x0), dx = h + |x0| h², h = eps^(1/3)
+template <class Cdf>
+__device__ __forceinline__ bool secant_inverse(Cdf&& cdf, double u, double guess, double atol,
+                                               int maxiter, double& root) {
+  const double hs = 6.0554544523933395e-06;
+  double x1 = guess;
+  double x0 = x1 + hs + fabs(x1) * hs * hs;
+  double f0 = cdf(x0) - u;
+  double f1 = cdf(x1) - u;
+  int evals = 2;
+  bool ok = false;
+  while (true) {
+    if (fabs(f1) <= atol) {
+      ok = true;
+      break;
+    }
+    if (evals >= maxiter || f1 == f0) break;
+    const double x2 = x1 - f1 * (x1 - x0) / (f1 - f0);
+    if (!isfinite(x2)) break;
+    x0 = x1;
+    f0 = f1;
+    x1 = x2;
+    f1 = cdf(x2) - u;
+    ++evals;
+  }
+  root = x1;
+  return ok && !(x1 < 0.0);
+}
+
+// Series kernel: the characteristic-function work of a trajectory — CF iterator, moments, and the
+// series terms Re ϕ(h·j), j = 1 … J (J set by the reference's stopping rule, sample_from_cf.jl:88),
+// evaluated ONCE in the reference's order with its continuous phase unwrapping and left in the
+// trajectory's column of the cache.  Nothing here depends on the CDF argument, so the root search
+// needs none of the complex Bessel machinery: it runs in its own, light kernel.  Everything a lane
+// keeps here is the CF state — that is what fits 128 registers (4 waves per SIMD).
+__global__ __launch_bounds__(kTile) void bk_series_kernel(const BkArgs p) {
+  const uint64_t path = (uint64_t)blockIdx.x * kTile + threadIdx.x;
+  if (path >= p.n_paths) return;
+  const bool grid = p.in_var != nullptr;
+  const double V0 = grid ? p.in_var[path] : p.V0;
+  const double* d = p.draws + path;
+  const double q_u = d[2 * p.draw_stride];
+  const double VT = d[3 * p.draw_stride];
+  CfIter cf;
+  double h, initial_guess, max_guess;
+  cf_setup(p, V0, VT, q_u, cf, initial_guess, max_guess, h);
+  double* col = p.phi_cache + path;
+  const double stop = kPi * p.cf_tol / 2.0;
+  double theta = __builtin_nan("");
+  int j_stop = 0;  // 0: longer than the cache — the fall-back kernel runs this trajectory whole
+  for (int j = 1; j <= p.cache_cap; ++j) {
+    const cx phi = evaluate_chf(p, cf, h * (double)j, theta);
+    col[(size_t)(j - 1) * p.cache_stride] = phi.re;
+    if (!(cabs(phi) >= stop * (double)j)) {  // |ϕ|/j < π·tol/2; also leaves on NaN
+      j_stop = j;
+      break;
+    }
+  }
+  double* r = p.rec + path;
+  r[0] = h;
+  r[p.draw_stride] = initial_guess;
+  r[2 * p.draw_stride] = max_guess;
+  r[3 * p.draw_stride] = (double)j_stop;
+}
+
+// The first kRegTerms series terms of a trajectory, held in registers for all the CDF evaluations of
+// its root search (H252: 10-13 terms, ~5 evaluations by the secant, ~13 by the ladder): the cache
+// column is read once instead of once per evaluation.
+constexpr int kRegTerms = 16;
+__device__ __forceinline__ void load_terms(const double* col, size_t stride, int j_stop,
+                                           double (&t)[kRegTerms]) {
+#pragma unroll
+  for (int j = 0; j < kRegTerms; ++j) t[j] = j < j_stop ? col[(size_t)j * stride] : 0.0;
+}
+
+// cdf_from_cf (sample_from_cf.jl:75-96) on the cached terms: same values, same summation order as
+// cdf_from_cf() above, one rotation step per term; terms beyond the registers come from the column
+__device__ __forceinline__ double cdf_cached(const double (&t)[kRegTerms], const double* col,
+                                             size_t stride, int j_stop, double h, double x,
+                                             double& n_terms) {
+  if (x < 0.0) return 0.0;
+  double result = h * x / kPi;
+  const double pref = 2.0 / kPi;
+  double s1, c1;
+  sincos_cf(h * x, s1, c1);
+  double sj = s1, cj = c1;
+#pragma unroll
+  for (int j = 1; j <= kRegTerms; ++j) {
+    if (j <= j_stop) {
+      result += pref * sj * rcp_nr((double)j) * t[j - 1];
+      n_terms += 1.0;
+    }
+    const double sn = fma(sj, c1, cj * s1);
+    cj = fma(cj, c1, -(sj * s1));
+    sj = sn;
+  }
+  for (int j = kRegTerms + 1; j <= j_stop; ++j) {
+    result += pref * sj * rcp_nr((double)j) * col[(size_t)(j - 1) * stride];
+    n_terms += 1.0;
+    if (j == j_stop) break;
+    const double sn = fma(sj, c1, cj * s1);
+    cj = fma(cj, c1, -(sj * s1));
+    sj = sn;
+    if ((j & 31) == 0) sincos_cf(h * x * (double)(j + 1), sj, cj);  // re-anchor long series
+  }
+  return result;
+}
+
+// Inversion kernel: the secant iteration of inverse_cdf on the cached series, then log S_T and the
+// payoff.  A trajectory whose secant fails is NOT finished here: one such lane would keep its whole
+// wave in the ~15-evaluation bisection ladder (2 % of the paths fail, so 3 out of 4 waves would).
+// It is flagged in a per-wave ballot instead and finished, densely packed, by bk_fallback_kernel;
+// so is a trajectory whose series did not fit the cache.  Flags are ballots in trajectory order, so
+// the result is bit-reproducible.
+__global__ __launch_bounds__(kTile) void bk_invert_kernel(const BkArgs p) {
   const uint32_t tile = blockIdx.x, tid = threadIdx.x;
   const uint64_t path = (uint64_t)tile * kTile + tid;
   double acc[6] = {0, 0, 0, 0, 0, 0};  // Σp, Σp², newton_fail, bisect, maxguess, cf_terms
-  bool failed = false;
+  bool failed = false, too_long = false;
 
   if (path < p.n_paths) {
-    PathSetup s;
-    bk_setup(p, path, s);
-    double n_terms = 0.0;
-    // secant from (x0 + dx, x0), dx = h + |x0| h², h = eps^(1/3)
-    const double hs = 6.0554544523933395e-06;
-    double x1 = s.initial_guess;
-    double x0 = x1 + hs + fabs(x1) * hs * hs;
-    double f0 = cdf_from_cf(p, s.cf, x0, s.h, s.cache, n_terms) - s.u;
-    double f1 = cdf_from_cf(p, s.cf, x1, s.h, s.cache, n_terms) - s.u;
-    int evals = 2;
-    bool ok = false;
-    while (true) {
-      if (fabs(f1) <= p.atol) {
-        ok = true;
-        break;
-      }
-      if (evals >= p.newton_maxiter || f1 == f0) break;
-      const double x2 = x1 - f1 * (x1 - x0) / (f1 - f0);
-      if (!isfinite(x2)) break;
-      x0 = x1;
-      f0 = f1;
-      x1 = x2;
-      f1 = cdf_from_cf(p, s.cf, x2, s.h, s.cache, n_terms) - s.u;
-      ++evals;
-    }
-    acc[5] = n_terms;
-    if (ok && !(x1 < 0.0)) {
-      const double pay = bk_finish(p, s, x1, path);
-      acc[0] = pay;
-      acc[1] = pay * pay;
+    const double* r = p.rec + path;
+    const double h = r[0], guess = r[p.draw_stride];
+    const int j_stop = (int)r[3 * p.draw_stride];
+    const double u = p.draws[p.draw_stride + path];
+    if (j_stop == 0) {
+      too_long = true;
     } else {
-      failed = true;
-      acc[2] = 1.0;
+      const double* col = p.phi_cache + path;
+      double t[kRegTerms];
+      load_terms(col, p.cache_stride, j_stop, t);
+      double n_terms = 0.0, IV;
+      const bool ok = secant_inverse(
+          [&](double x) { return cdf_cached(t, col, p.cache_stride, j_stop, h, x, n_terms); }, u, guess,
+          p.atol, p.newton_maxiter, IV);
+      acc[5] = n_terms;
+      if (ok) {
+        const bool grid = p.in_var != nullptr;
+        const double V0 = grid ? p.in_var[path] : p.V0;
+        const double logS0 = grid ? fm::log(p.in_spot[path]) : p.logS0;  // heston.jl:84, :289
+        const double pay = bk_finish(p, logS0, V0, p.draws[3 * p.draw_stride + path], p.draws[path],
+                                     IV, path);
+        acc[0] = pay;
+        acc[1] = pay * pay;
+      } else {
+        failed = true;
+        acc[2] = 1.0;
+      }
     }
   }
-  const unsigned long long mask = __ballot(failed);
-  if ((tid & 63) == 0) p.fail_mask[(size_t)tile * (kTile / 64) + (tid >> 6)] = mask;
+  const unsigned long long m_fail = __ballot(failed), m_long = __ballot(too_long);
+  if ((tid & 63) == 0) {
+    p.fail_mask[(size_t)tile * (kTile / 64) + (tid >> 6)] = m_fail;
+    p.long_mask[(size_t)tile * (kTile / 64) + (tid >> 6)] = m_long;
+  }
   bk_store_record(acc, p.records + (size_t)tile * kRecStride);
 }
 
-// exclusive prefix sum of the per-tile failure counts (single workgroup; n_tiles is small)
-__global__ __launch_bounds__(256) void bk_scan_kernel(const unsigned long long* __restrict__ mask,
-                                                      uint32_t n_tiles,
-                                                      uint32_t* __restrict__ prefix) {
-  __shared__ uint32_t sm[256];
-  __shared__ uint32_t carry;
-  if (threadIdx.x == 0) carry = 0;
-  __syncthreads();
-  for (uint32_t base = 0; base < n_tiles; base += 256) {
-    const uint32_t t = base + threadIdx.x;
+// exclusive prefix sums of the per-tile counts of both ballot arrays (one workgroup: every thread
+// adds up a run of consecutive tiles, one 256-wide scan, then the runs are expanded)
+__global__ __launch_bounds__(256) void bk_scan_kernel(const unsigned long long* __restrict__ mask_a,
+                                                      const unsigned long long* __restrict__ mask_b,
+                                                      uint32_t n_tiles, uint32_t* __restrict__ prefix_a,
+                                                      uint32_t* __restrict__ prefix_b) {
+  __shared__ uint32_t sm[2][256];
+  const uint32_t per = (n_tiles + 255) / 256;
+  const uint32_t t0 = threadIdx.x * per, t1 = min(t0 + per, n_tiles);
+  auto count = [](const unsigned long long* m, uint32_t t) {
     uint32_t c = 0;
-    if (t < n_tiles) {
 #pragma unroll
-      for (int w = 0; w < kTile / 64; ++w) c += (uint32_t)__popcll(mask[(size_t)t * (kTile / 64) + w]);
-    }
-    sm[threadIdx.x] = c;
+    for (int w = 0; w < kTile / 64; ++w) c += (uint32_t)__popcll(m[(size_t)t * (kTile / 64) + w]);
+    return c;
+  };
+  uint32_t ca = 0, cb = 0;
+  for (uint32_t t = t0; t < t1; ++t) {
+    ca += count(mask_a, t);
+    cb += count(mask_b, t);
+  }
+  sm[0][threadIdx.x] = ca;
+  sm[1][threadIdx.x] = cb;
+  __syncthreads();
+  for (int off = 1; off < 256; off <<= 1) {  // Hillis–Steele inclusive scan of the run totals
+    const uint32_t va = threadIdx.x >= (unsigned)off ? sm[0][threadIdx.x - off] : 0;
+    const uint32_t vb = threadIdx.x >= (unsigned)off ? sm[1][threadIdx.x - off] : 0;
     __syncthreads();
-    for (int off = 1; off < 256; off <<= 1) {  // Hillis–Steele inclusive scan
-      const uint32_t v = threadIdx.x >= (unsigned)off ? sm[threadIdx.x - off] : 0;
-      __syncthreads();
-      sm[threadIdx.x] += v;
-      __syncthreads();
-    }
-    if (t < n_tiles) prefix[t] = carry + sm[threadIdx.x] - c;
-    __syncthreads();
-    if (threadIdx.x == 255) carry += sm[255];
+    sm[0][threadIdx.x] += va;
+    sm[1][threadIdx.x] += vb;
     __syncthreads();
   }
-  if (threadIdx.x == 0) prefix[n_tiles] = carry;
+  uint32_t ra = sm[0][threadIdx.x] - ca, rb = sm[1][threadIdx.x] - cb;  // exclusive, start of the run
+  for (uint32_t t = t0; t < t1; ++t) {
+    prefix_a[t] = ra;
+    prefix_b[t] = rb;
+    ra += count(mask_a, t);
+    rb += count(mask_b, t);
+  }
+  if (threadIdx.x == 255) {
+    prefix_a[n_tiles] = sm[0][255];
+    prefix_b[n_tiles] = sm[1][255];
+  }
 }
 
-// Phase 2: the fall-back ladder (sample_from_cf.jl:123-133) for the flagged trajectories, one per
-// lane, in trajectory order.
-__global__ __launch_bounds__(kTile) void bk_fallback_kernel(const BkArgs p, uint32_t n_tiles,
-                                                            const uint32_t* __restrict__ prefix) {
-  const uint32_t total = prefix[n_tiles];
-  const uint32_t g = blockIdx.x * kTile + threadIdx.x;
-  double* rec = p.records + (size_t)(n_tiles + blockIdx.x) * kRecStride;
-  if (blockIdx.x * (uint32_t)kTile >= total) {  // nothing for this workgroup (uniform branch)
-    if (threadIdx.x == 0)
-      for (int i = 0; i < kRecStride; ++i) rec[i] = 0.0;
-    return;
+// trajectory of packed work item g: the last tile t with prefix[t] <= g, then the (g - prefix[t])-th
+// set bit of its 4 ballots
+__device__ __forceinline__ uint64_t packed_path(const unsigned long long* mask, const uint32_t* prefix,
+                                                uint32_t n_tiles, uint32_t g) {
+  uint32_t lo = 0, hi = n_tiles;  // invariant: prefix[lo] <= g < prefix[hi]
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (prefix[mid] <= g) lo = mid; else hi = mid;
   }
-  double acc[6] = {0, 0, 0, 0, 0, 0};
-  if (g < total) {
-    // tile = last t with prefix[t] <= g, then the (g - prefix[t])-th set bit of its 4 ballots
-    uint32_t lo = 0, hi = n_tiles;  // invariant: prefix[lo] <= g < prefix[hi]
-    while (hi - lo > 1) {
-      const uint32_t mid = (lo + hi) >> 1;
-      if (prefix[mid] <= g) lo = mid; else hi = mid;
+  uint32_t r = g - prefix[lo];
+  uint32_t bit = 0;
+  for (int w = 0; w < kTile / 64; ++w) {
+    unsigned long long mk = mask[(size_t)lo * (kTile / 64) + w];
+    const uint32_t c = (uint32_t)__popcll(mk);
+    if (r < c) {
+      for (uint32_t i = 0; i < r; ++i) mk &= mk - 1;  // drop the r lowest set bits
+      bit = (uint32_t)w * 64u + (uint32_t)(__ffsll((long long)mk) - 1);
+      break;
     }
-    uint32_t r = g - prefix[lo];
-    uint32_t bit = 0;
-    for (int w = 0; w < kTile / 64; ++w) {
-      unsigned long long mk = p.fail_mask[(size_t)lo * (kTile / 64) + w];
-      const uint32_t c = (uint32_t)__popcll(mk);
-      if (r < c) {
-        for (uint32_t i = 0; i < r; ++i) mk &= mk - 1;  // drop the r lowest set bits
-        bit = (uint32_t)w * 64u + (uint32_t)(__ffsll((long long)mk) - 1);
-        break;
-      }
-      r -= c;
-    }
-    const uint64_t path = (uint64_t)lo * kTile + bit;
+    r -= c;
+  }
+  return (uint64_t)lo * kTile + bit;
+}
 
-    PathSetup s;
-    bk_setup(p, path, s);
-    double n_terms = 0.0;
-    double IV;
-    double fa = cdf_from_cf(p, s.cf, 0.0, s.h, s.cache, n_terms) - s.u;
-    const double fb = cdf_from_cf(p, s.cf, s.max_guess, s.h, s.cache, n_terms) - s.u;
+// Ladder kernel: the fall-back of inverse_cdf (sample_from_cf.jl:123-133) for the trajectories whose
+// secant failed, densely packed (one per lane, in trajectory order), on the cached series terms —
+// no characteristic-function arithmetic, so it is as light as the inversion kernel.  Work items are
+// taken with a grid stride: the grid does not depend on how many there are.
+__global__ __launch_bounds__(kTile) void bk_ladder_kernel(const BkArgs p, uint32_t n_tiles,
+                                                          const uint32_t* __restrict__ prefix) {
+  const uint32_t total = prefix[n_tiles];
+  double acc[6] = {0, 0, 0, 0, 0, 0};
+  for (uint32_t g = blockIdx.x * kTile + threadIdx.x; g < total; g += gridDim.x * kTile) {
+    const uint64_t path = packed_path(p.fail_mask, prefix, n_tiles, g);
+    const double* r = p.rec + path;
+    const double h = r[0], max_guess = r[2 * p.draw_stride];
+    const int j_stop = (int)r[3 * p.draw_stride];
+    const double u = p.draws[p.draw_stride + path];
+    const double* col = p.phi_cache + path;
+    double t[kRegTerms];
+    load_terms(col, p.cache_stride, j_stop, t);
+    double n_terms = 0.0, IV;
+    auto cdf = [&](double x) { return cdf_cached(t, col, p.cache_stride, j_stop, h, x, n_terms); };
+    double fa = cdf(0.0) - u;
+    const double fb = cdf(max_guess) - u;
     if (fa * fb > 0.0) {
-      acc[4] = 1.0;
-      IV = s.max_guess;  // sample_from_cf.jl:124-126
+      acc[4] += 1.0;
+      IV = max_guess;  // sample_from_cf.jl:124-126
     } else {
-      acc[3] = 1.0;
-      double lo_x = 0.0, hi_x = s.max_guess;
+      acc[3] += 1.0;
+      double lo_x = 0.0, hi_x = max_guess;
       for (int i = 0; i < p.bisect_maxiter; ++i) {
         const double mid = 0.5 * (lo_x + hi_x);
-        const double fm = cdf_from_cf(p, s.cf, mid, s.h, s.cache, n_terms) - s.u;
+        const double fm = cdf(mid) - u;
         if (fm == 0.0) {
           lo_x = hi_x = mid;
           break;
@@ -621,12 +794,68 @@ __global__ __launch_bounds__(kTile) void bk_fallback_kernel(const BkArgs p, uint
       }
       IV = 0.5 * (lo_x + hi_x);
     }
-    acc[5] = n_terms;
-    const double pay = bk_finish(p, s, IV, path);
-    acc[0] = pay;
-    acc[1] = pay * pay;
+    acc[5] += n_terms;
+    const bool grid = p.in_var != nullptr;
+    const double V0 = grid ? p.in_var[path] : p.V0;
+    const double logS0 = grid ? fm::log(p.in_spot[path]) : p.logS0;
+    const double pay = bk_finish(p, logS0, V0, p.draws[3 * p.draw_stride + path], p.draws[path], IV, path);
+    acc[0] += pay;
+    acc[1] = fma(pay, pay, acc[1]);
   }
-  bk_store_record(acc, rec);
+  bk_store_record(acc, p.records + (size_t)(n_tiles + blockIdx.x) * kRecStride);
+}
+
+// Fall-back kernel: trajectories whose series did not fit the cache (cf_tol far below the reference's
+// default) run whole here — secant, then the ladder if it fails — evaluating the terms beyond the
+// cache on every use, as the reference does with all of them.  Densely packed, grid stride; with
+// the default controls there are none and the launch returns at once.
+__global__ __launch_bounds__(kTile) void bk_fallback_kernel(const BkArgs p, uint32_t n_tiles,
+                                                            const uint32_t* __restrict__ prefix) {
+  const uint32_t total = prefix[n_tiles];
+  double acc[6] = {0, 0, 0, 0, 0, 0};
+  for (uint32_t g = blockIdx.x * kTile + threadIdx.x; g < total; g += gridDim.x * kTile) {
+    const uint64_t path = packed_path(p.long_mask, prefix, n_tiles, g);
+    PathSetup s;
+    bk_setup(p, path, s);
+    double n_terms = 0.0;
+    double IV;
+    const bool done =
+        secant_inverse([&](double x) { return cdf_from_cf(p, s.cf, x, s.h, s.cache, n_terms); }, s.u,
+                       s.initial_guess, p.atol, p.newton_maxiter, IV);
+    if (!done) {  // the fall-back ladder (sample_from_cf.jl:123-133)
+      acc[2] += 1.0;
+      double fa = cdf_from_cf(p, s.cf, 0.0, s.h, s.cache, n_terms) - s.u;
+      const double fb = cdf_from_cf(p, s.cf, s.max_guess, s.h, s.cache, n_terms) - s.u;
+      if (fa * fb > 0.0) {
+        acc[4] += 1.0;
+        IV = s.max_guess;  // sample_from_cf.jl:124-126
+      } else {
+        acc[3] += 1.0;
+        double lo_x = 0.0, hi_x = s.max_guess;
+        for (int i = 0; i < p.bisect_maxiter; ++i) {
+          const double mid = 0.5 * (lo_x + hi_x);
+          const double fm = cdf_from_cf(p, s.cf, mid, s.h, s.cache, n_terms) - s.u;
+          if (fm == 0.0) {
+            lo_x = hi_x = mid;
+            break;
+          }
+          if ((fm < 0.0) == (fa < 0.0)) {
+            lo_x = mid;
+            fa = fm;
+          } else {
+            hi_x = mid;
+          }
+          if (hi_x - lo_x <= p.atol) break;
+        }
+        IV = 0.5 * (lo_x + hi_x);
+      }
+    }
+    acc[5] += n_terms;
+    const double pay = bk_finish(p, s.logS0, s.V0, s.VT, s.Z, IV, path);
+    acc[0] += pay;
+    acc[1] = fma(pay, pay, acc[1]);
+  }
+  bk_store_record(acc, p.records + (size_t)(n_tiles + kPackedGrid + blockIdx.x) * kRecStride);
 }
 
 __global__ __launch_bounds__(256) void fill_rows_kernel(double* __restrict__ spot0,
@@ -663,7 +892,7 @@ static int phi_cache_cap(size_t n_tiles) {
 }
 
 static size_t bk_flags_bytes(size_t n_tiles) {
-  size_t b = n_tiles * (kTile / 64) * sizeof(unsigned long long) + (n_tiles + 1) * sizeof(uint32_t);
+  size_t b = 2 * n_tiles * (kTile / 64) * sizeof(unsigned long long) + 2 * (n_tiles + 1) * sizeof(uint32_t);
   return (b + 255) & ~(size_t)255;
 }
 
@@ -673,9 +902,14 @@ int launch_fill_rows(double* spot0, double* var0, uint64_t n, double S0, double 
   return (int)hipGetLastError();
 }
 
+uint32_t bk_record_count(uint64_t n_paths) {
+  return tiles_for(n_paths) + (uint32_t)kPackedGrid + (uint32_t)kHeavyGrid;
+}
+
 size_t bk_scratch_bytes(uint64_t n_paths) {
   const size_t n_tiles = tiles_for(n_paths);
-  return bk_flags_bytes(n_tiles) + n_tiles * kTile * sizeof(double) * (size_t)phi_cache_cap(n_tiles);
+  // ballots + prefix | cached series terms [cap][lanes] | draws [4][lanes] | rec [4][lanes]
+  return bk_flags_bytes(n_tiles) + n_tiles * kTile * sizeof(double) * ((size_t)phi_cache_cap(n_tiles) + 8);
 }
 
 int launch_bk(const hh_model& m, const hh_config& c, const DevicePtrs& ptr, hipStream_t s,
@@ -717,15 +951,31 @@ int launch_bk(const hh_model& m, const hh_config& c, const DevicePtrs& ptr, hipS
   a.terminal = ptr.terminal;
   a.records = ptr.records;
   const uint32_t n_tiles = tiles_for(c.n_paths);
-  a.fail_mask = reinterpret_cast<unsigned long long*>(ptr.bk_scratch);
-  uint32_t* prefix = reinterpret_cast<uint32_t*>(a.fail_mask + (size_t)n_tiles * (kTile / 64));
-  a.phi_cache = reinterpret_cast<double*>(reinterpret_cast<unsigned char*>(ptr.bk_scratch) +
-                                          bk_flags_bytes(n_tiles));
-  a.cache_stride = (size_t)n_tiles * kTile;
+  // scratch: ballots (fail, long) + prefix | cached series terms [cap][lanes] | draws [4][lanes] | rec [4][lanes]
+  const size_t lanes = (size_t)n_tiles * kTile;
+  unsigned char* base = reinterpret_cast<unsigned char*>(ptr.bk_scratch);
+  a.fail_mask = reinterpret_cast<unsigned long long*>(base);
+  a.long_mask = a.fail_mask + (size_t)n_tiles * (kTile / 64);
+  uint32_t* prefix = reinterpret_cast<uint32_t*>(a.long_mask + (size_t)n_tiles * (kTile / 64));
+  uint32_t* prefix_long = prefix + n_tiles + 1;
+  a.phi_cache = reinterpret_cast<double*>(base + bk_flags_bytes(n_tiles));
+  a.cache_stride = lanes;
   a.cache_cap = phi_cache_cap(n_tiles);
-  hipLaunchKernelGGL(bk_kernel, dim3(n_tiles), dim3(kTile), 0, s, a);
-  hipLaunchKernelGGL(bk_scan_kernel, dim3(1), dim3(256), 0, s, a.fail_mask, n_tiles, prefix);
-  hipLaunchKernelGGL(bk_fallback_kernel, dim3(n_tiles), dim3(kTile), 0, s, a, n_tiles, prefix);
+  a.draws = a.phi_cache + lanes * (size_t)a.cache_cap;
+  a.rec = a.draws + 4 * lanes;
+  a.draw_stride = lanes;
+  a.replay = c.noise_mode == HH_NOISE_REPLAY ? ptr.replay : nullptr;
+  const dim3 g(n_tiles), b(kTile);
+  if (a.replay)
+    hipLaunchKernelGGL(bk_draw_kernel<true>, g, b, 0, s, a);
+  else
+    hipLaunchKernelGGL(bk_draw_kernel<false>, g, b, 0, s, a);
+  hipLaunchKernelGGL(bk_series_kernel, g, b, 0, s, a);
+  hipLaunchKernelGGL(bk_invert_kernel, g, b, 0, s, a);
+  hipLaunchKernelGGL(bk_scan_kernel, dim3(1), dim3(256), 0, s, a.fail_mask, a.long_mask, n_tiles, prefix,
+                     prefix_long);
+  hipLaunchKernelGGL(bk_ladder_kernel, dim3(kPackedGrid), b, 0, s, a, n_tiles, prefix);
+  hipLaunchKernelGGL(bk_fallback_kernel, dim3(kHeavyGrid), b, 0, s, a, n_tiles, prefix_long);
   return (int)hipGetLastError();
 }
 

@@ -88,7 +88,10 @@ struct BkTransition {
 };
 int launch_bk(const hh_model& m, const hh_config& c, const DevicePtrs& p, hipStream_t s,
               const BkTransition* tr = nullptr);
-size_t bk_scratch_bytes(uint64_t n_paths);  // BK writes 2·tiles_for(n_paths) records
+size_t bk_scratch_bytes(uint64_t n_paths);
+uint32_t bk_record_count(uint64_t n_paths);  // records the Broadie–Kaya chain writes (inversion tiles + packed kernels)
+// the four Broadie–Kaya counter slots of `src` (HH_ACC_LEN doubles) into each of n_groups accumulators
+int launch_copy_bk_counters(const double* src, double* accum, uint32_t n_groups, hipStream_t s);
 // row 0 of the exact Heston grid: spot0[i] = S0, var0[i] = V0
 int launch_fill_rows(double* spot0, double* var0, uint64_t n, double S0, double V0, hipStream_t s);
 // m, c given: finish the dual partials (active slots re-ordered, passive ones in closed form)

@@ -256,14 +256,29 @@ struct VecOf<2> {
 #ifndef HH_REPLAY_CHUNK_PRICE
 #define HH_REPLAY_CHUNK_PRICE 4
 #endif
+// Occupancy of the REPLAY kernels.  HBM delivers most when a CU runs few concurrent 1 MB streams
+// (tools/ubench/hbm_read_sweep.hip), so the REPLAY variants are held BELOW what their register count
+// would allow — by the compiler's own occupancy control, amdgpu_waves_per_eu(1, max): the kernel
+// descriptor then reserves ⌊512 / max⌋ registers per lane and the hardware admits at most `max`
+// waves per SIMD, whatever else the kernel declares.  (Round 1 obtained the same caps as a side
+// effect of an untouched LDS allocation — HH_REPLAY_PAD_*_KIB, still here for A/B, default off.)
+#ifndef HH_REPLAY_MAXW
+#define HH_REPLAY_MAXW 2       // price-only: 2 waves per SIMD = 2 workgroups of 256 threads = 8 waves per CU
+#endif
+#ifndef HH_REPLAY_MAXW_DUAL
+#define HH_REPLAY_MAXW_DUAL 2  // dual-partial kernels: 2 waves per SIMD too (one carried derivative: 0.609 ms against 0.623 at 3 and 0.663 uncapped)
+#endif
+#ifndef HH_REPLAY_MAXW_ANTI
+#define HH_REPLAY_MAXW_ANTI 8  // antithetic: indifferent (0.629 vs 0.625 ms), left at the register limit
+#endif
 #ifndef HH_REPLAY_PAD_KIB
-#define HH_REPLAY_PAD_KIB 79  // LDS allocated only to cap the occupancy: 2 workgroups = 8 waves per CU
+#define HH_REPLAY_PAD_KIB 0
 #endif
 #ifndef HH_REPLAY_PAD_ANTI_KIB
 #define HH_REPLAY_PAD_ANTI_KIB 0
 #endif
 #ifndef HH_REPLAY_PAD_DUAL_KIB
-#define HH_REPLAY_PAD_DUAL_KIB 24  // dual-partial kernels: 12 waves per CU (0.65 -> 0.62 ms with one carried derivative)
+#define HH_REPLAY_PAD_DUAL_KIB 0
 #endif
 #ifndef HH_REPLAY_PIPE
 #define HH_REPLAY_PIPE 0  // standard ring: 0 = drain all LDS-DMA before each chunk is read
@@ -288,8 +303,13 @@ __device__ __forceinline__ Vec stream_load(const double* p) {
 }
 
 // RING: chunks in each wave's LDS ring of the REPLAY stream (0 = register pipeline), see below
+constexpr int replay_max_waves(bool replay, bool anti, int p) {
+  return !replay ? 8 : anti ? HH_REPLAY_MAXW_ANTI : p > 0 ? HH_REPLAY_MAXW_DUAL : HH_REPLAY_MAXW;
+}
 template <class M, int P, bool REPLAY, bool ANTI, int PPT, int RING, bool PIPE>
-__global__ __launch_bounds__(kTile / PPT, REPLAY ? HH_REPLAY_MINW : 1) void euler_kernel(
+__global__ __launch_bounds__(kTile / PPT)
+__attribute__((amdgpu_waves_per_eu(REPLAY ? HH_REPLAY_MINW : 1,
+                                   replay_max_waves(REPLAY, ANTI, P)))) void euler_kernel(
     const SimArgs<P> a) {
   constexpr int NC = M::NCOMP;
   using State = typename M::State;
@@ -343,10 +363,9 @@ __global__ __launch_bounds__(kTile / PPT, REPLAY ? HH_REPLAY_MINW : 1) void eule
 
     // Which REPLAY pipeline (measurements: DESIGN.md §5, tools/tune_replay.py, tools/replay_sizes.py,
     // tools/ubench/hbm_read_sweep.hip).
-    // RING = 0, what ships: two register chunks, load(B) || compute(A), and an LDS allocation that
-    // is never touched — HBM delivers most when a CU runs few concurrent 1 MB streams, so the
-    // occupancy is capped from outside: 79 KiB (2 workgroups of 256 threads = 8 waves per CU) for the
-    // price-only kernel, 24 KiB (12 waves) for the dual-partial kernels, none for the antithetic one.
+    // RING = 0, what ships: two register chunks, load(B) || compute(A), with the occupancy capped by
+    // amdgpu_waves_per_eu (see HH_REPLAY_MAXW above): 8 waves per CU for the price-only kernel, 12
+    // for the dual-partial kernels, uncapped for the antithetic one.
     // RING > 0 (-DHH_REPLAY_LDS, price-only kernel with PPT = 2): each wave moves its half-tile
     // through a PRIVATE ring of RING chunks in LDS filled by LDS-DMA (global_load_lds_dwordx4: 16 B
     // per lane straight into LDS, no VGPR staging, no workgroup barrier).  It ties with the shipped
@@ -439,8 +458,7 @@ __global__ __launch_bounds__(kTile / PPT, REPLAY ? HH_REPLAY_MINW : 1) void eule
       compute(A, n_chunks * kChunk);
     }
     } else {
-    // LDS allocated only to cap the occupancy (the branch is never taken): fewer concurrent streams
-    // per CU read HBM faster (tools/ubench/hbm_read_sweep.hip)
+    // A/B only (HH_REPLAY_PAD_*_KIB > 0): LDS allocated to cap the occupancy, never touched
     constexpr int kPadKib = ANTI ? HH_REPLAY_PAD_ANTI_KIB : P > 0 ? HH_REPLAY_PAD_DUAL_KIB : HH_REPLAY_PAD_KIB;
     if constexpr (kPadKib > 0) {
       __shared__ double occupancy_pad[kPadKib > 0 ? kPadKib * 128 : 1];
@@ -914,6 +932,22 @@ __global__ __launch_bounds__(256) void basket_payoff_kernel(const BasketArgs b) 
     acc[3 + P] += wN;
   }
   block_reduce_store<4 + P, 4, 2>(acc, b.records + ((size_t)k * b.n_chunks + chunk) * kRecStride);
+}
+
+// a basket on Broadie–Kaya samples: the simulation's own counters (fall-backs, series terms) belong
+// to every payoff's result
+__global__ void copy_bk_counters_kernel(const double* __restrict__ src, double* __restrict__ accum,
+                                        uint32_t n_groups) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n_groups) return;
+  for (int i = HH_ACC_BK_NEWTON_FAIL; i <= HH_ACC_BK_CF_TERMS; ++i)
+    accum[(size_t)k * kRecStride + i] = src[i];
+}
+
+int launch_copy_bk_counters(const double* src, double* accum, uint32_t n_groups, hipStream_t s) {
+  hipLaunchKernelGGL(copy_bk_counters_kernel, dim3((n_groups + 255) / 256), dim3(256), 0, s, src, accum,
+                     n_groups);
+  return (int)hipGetLastError();
 }
 
 int launch_basket_payoffs(const BasketArgs& b, uint32_t n_payoffs, uint32_t n_active_partials,

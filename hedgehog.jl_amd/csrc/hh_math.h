@@ -48,11 +48,8 @@ HH_MATH_FN double fma_c(double p, double z, double c) {
 #endif
 }
 
-// sin and cos of x, |x| <= 2^20 (error of the two-term reduction: |n|·2e-33)
-HH_MATH_FN void sincos(double x, double& sn, double& cs) {
-  const double n = rint(x * 6.36619772367581382433e-01);  // 2/π
-  double r = fma(n, -1.57079632679489655800e+00, x);      // exact cancellation
-  r = fma(n, -6.12323399573676603587e-17, r);
+// sin r, cos r for |r| <= π/4 (+ rounding of the reduction), rotated into quadrant q (mod 4)
+HH_MATH_FN void sincos_reduced(double r, int q, double& sn, double& cs) {
   const double z = r * r;
   double ps = 1.58969099521155010221e-10;
   ps = fma_c(ps, z, -2.50507602534068634195e-08);
@@ -70,11 +67,59 @@ HH_MATH_FN void sincos(double x, double& sn, double& cs) {
   const double hz = 0.5 * z;
   const double w = 1.0 - hz;
   const double cr = w + (((1.0 - w) - hz) + z * (z * pc));
-  const int q = (int)n;
   const bool swap = q & 1;
   const double s0 = swap ? cr : sr, c0 = swap ? sr : cr;
   sn = (q & 2) ? -s0 : s0;
   cs = ((q + 1) & 2) ? -c0 : c0;
+}
+
+// sin and cos of x, |x| <= 2^20 (error of the two-term reduction: |n|·2e-33)
+HH_MATH_FN void sincos(double x, double& sn, double& cs) {
+  const double n = rint(x * 6.36619772367581382433e-01);  // 2/π
+  double r = fma(n, -1.57079632679489655800e+00, x);      // exact cancellation
+  r = fma(n, -6.12323399573676603587e-17, r);
+  sincos_reduced(r, (int)n, sn, cs);
+}
+
+// The same for |x| <= 2^45: three-term reduction (π/2 = c1 + c2 + c3 to 2^-161; each fma rounds the
+// exact difference once, so the reduced argument carries |n|·5.6e-50 + 2^-53 of absolute error) and
+// the quadrant taken from n mod 4 in floating point.  Replaces the device library's full-range
+// sincos (Payne–Hanek: ~150 instructions and some 30 more live registers in the Broadie–Kaya
+// kernel) for the arguments beyond 2^20 that only extreme parameter sets produce; beyond 2^45 an
+// fp64 angle no longer determines its sine (spacing of the arguments > 2π·1e-3).
+HH_MATH_FN void sincos_wide(double x, double& sn, double& cs) {
+  const double n = rint(x * 6.36619772367581382433e-01);
+  double r = fma(n, -1.57079632679489655800e+00, x);
+  r = fma(n, -6.12323399573676603587e-17, r);
+  r = fma(n, 1.49738490485916983294e-33, r);
+  const double nq = n - 4.0 * rint(n * 0.25);  // n mod 4 in [-2, 2]
+  sincos_reduced(r, (int)nq, sn, cs);
+}
+
+// e^x: x = k ln2 + r, |r| <= ln2 / 2; e^r = 1 + r + r² q(r), q the degree-11 Taylor polynomial
+// (remainder r^14/14! < 6e-18); 2^k by v_ldexp_f64, which also delivers the overflow to +inf and
+// the gradual underflow to 0.  <= 1.5 ulp.  The device library's exp carries a table-free
+// double-double kernel: about three times the instructions and registers.
+HH_MATH_FN double exp(double x) {
+  const double xc = fmin(fmax(x, -1100.0), 1100.0);  // keeps k inside int; saturates anyway
+  const double k = rint(xc * 1.44269504088896338700e+00);
+  double r = fma(k, -6.93147180369123816490e-01, xc);  // ln2 high part (trailing zeros: k·hi exact)
+  r = fma(k, -1.90821492927058770002e-10, r);
+  double q = 1.6059043836821613e-10;            // 1/13!
+  q = fma_c(q, r, 2.08767569878681e-09);       // 1/12!
+  q = fma_c(q, r, 2.505210838544172e-08);
+  q = fma_c(q, r, 2.755731922398589e-07);
+  q = fma_c(q, r, 2.7557319223985893e-06);
+  q = fma_c(q, r, 2.48015873015873e-05);
+  q = fma_c(q, r, 1.984126984126984e-04);
+  q = fma_c(q, r, 1.388888888888889e-03);
+  q = fma_c(q, r, 8.333333333333333e-03);
+  q = fma_c(q, r, 4.1666666666666664e-02);
+  q = fma_c(q, r, 1.6666666666666666e-01);
+  q = fma_c(q, r, 0.5);
+  const double er = 1.0 + fma(r * r, q, r);
+  const double y = ldexp(er, (int)k);
+  return x != x ? x : y;
 }
 
 // ln x for positive, normal x

@@ -304,7 +304,11 @@ int hh_heston_exact_grid(hh_ctx* ctx, const hh_model* model, const hh_config* cf
  * For Heston the increments are the CORRELATED ones, cov = dt·[1 ρ; ρ 1] (heston.jl:18-20).
  * Exact lognormal law (HH_EXACT_LAW) in REPLAY mode: `replay` holds ONE standard normal per
  * trajectory, n_paths doubles (x = μ + σ̃·z, montecarlo.jl:302,413); no padding required.
- * Broadie–Kaya has no REPLAY mode.
+ * Broadie–Kaya (HH_BROADIE_KAYA) in REPLAY mode: `replay` holds the three draws the reference makes
+ * per trajectory, in its order (heston.jl:246-259) — V_T = c·rand(NoncentralChisq(d, λ)) (:125-133),
+ * the uniform u of sample_from_cf (sample_from_cf.jl:29) and the normal Z of sample_log_S_T
+ * (heston.jl:296) — as [V_T | u | Z], 3·n_paths doubles.  Everything downstream of the draws
+ * (moments_from_cf, cdf_from_cf, inverse_cdf, log S_T) then runs on the reference's own numbers.
  */
 size_t hh_replay_elems(uint64_t n_paths, uint32_t n_steps, int32_t dynamics);
 int hh_replay_pack(hh_ctx* ctx, int32_t dynamics, uint64_t n_paths, uint32_t n_steps,

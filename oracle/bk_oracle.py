@@ -361,19 +361,23 @@ def sample_log_S_T(V_T, integral_V, Z, d):
     return mu + math.sqrt(sigma2) * Z
 
 
-def rand_path(dist, key: int, G: int, stats=None, counter=None, sequential=False, **kw):
-    """heston.jl:246-259 for trajectory G -> (log S_T, V_T, ∫V)."""
-    dr = Draws(key, G)
-    V_T = sample_V_T(dr, dist)
-    u, _ = dr.uniforms(1)
-    Z, _ = dr.normals(0)
+def rand_path(dist, key: int, G: int, stats=None, counter=None, sequential=False, draws=None, **kw):
+    """heston.jl:246-259 for trajectory G -> (log S_T, V_T, ∫V).  draws = (V_T, u, Z): the
+    trajectory's three draws supplied by the caller (HH_NOISE_REPLAY) instead of drawn here."""
+    if draws is not None:
+        V_T, u, Z = (float(x) for x in draws)
+    else:
+        dr = Draws(key, G)
+        V_T = sample_V_T(dr, dist)
+        u, _ = dr.uniforms(1)
+        Z, _ = dr.normals(0)
     it = HestonCFIterator(V_T, dist)
     I = sample_from_cf(u, it, stats=stats, counter=counter, sequential=sequential, **kw)
     return sample_log_S_T(V_T, I, Z, dist), V_T, I
 
 
 def mc_solve(S0, V0, kappa, theta, sigma, rho, r, T, strike, cp, discount, n_paths, seed0,
-             path_offset=0, **kw):
+             path_offset=0, replay=None, **kw):
     """solve(prob, MonteCarlo(HestonDynamics(), HestonBroadieKaya(), cfg)), montecarlo.jl:454-493.
     Returns dict(price, std_error, terminal, V_T, integral_V, stats, cf_terms)."""
     dist = LogHestonDistribution(S0, V0, kappa, theta, sigma, rho, r, T)
@@ -384,7 +388,9 @@ def mc_solve(S0, V0, kappa, theta, sigma, rho, r, T, strike, cp, discount, n_pat
     VT = np.empty(n_paths)
     IV = np.empty(n_paths)
     for i in range(n_paths):
-        logS[i], VT[i], IV[i] = rand_path(dist, int(seed0), path_offset + i, stats, counter, **kw)
+        dr = None if replay is None else (replay[0][i], replay[1][i], replay[2][i])  # [V_T | u | Z]
+        logS[i], VT[i], IV[i] = rand_path(dist, int(seed0), path_offset + i, stats, counter,
+                                          draws=dr, **kw)
     S = np.exp(logS)  # final_sample(law, sample, NoVR) = exp.(sample)  montecarlo.jl:384
     pay = np.maximum(cp * (S - strike), 0.0)
     price = discount * pay.mean()

@@ -19,7 +19,7 @@ int main() {
   std::mt19937_64 rng(12345);
   std::uniform_real_distribution<double> U(0.0, 1.0);
   const int N = 2000000;
-  double e_sin = 0, e_cos = 0, e_log = 0, e_at = 0;
+  double e_sin = 0, e_cos = 0, e_log = 0, e_at = 0, e_exp = 0, e_wsin = 0, e_wcos = 0;
   for (int i = 0; i < N; ++i) {
     // angles: dense near 0, up to +-2^20 on a log scale
     const double mag = std::exp2(-30.0 + 50.0 * U(rng));
@@ -30,6 +30,21 @@ int main() {
     const long double ws = sinl((long double)x), wc = cosl((long double)x);
     e_sin = std::fmax(e_sin, fabsl(ws) > 1e-6L ? ulp_err(s, ws) : (double)(fabsl(s - ws) / 1.2e-22L));
     e_cos = std::fmax(e_cos, fabsl(wc) > 1e-6L ? ulp_err(c, wc) : (double)(fabsl(c - wc) / 1.2e-22L));
+    {  // the wide reduction: up to +-2^45, where an angle still determines its sine to ~1e-3
+      const double wm = std::exp2(18.0 + 27.0 * U(rng));
+      const double wx = (U(rng) < 0.5 ? -wm : wm);
+      double ws2, wc2;
+      hh::fm::sincos_wide(wx, ws2, wc2);
+      const long double rs = sinl((long double)wx), rc = cosl((long double)wx);
+      e_wsin = std::fmax(e_wsin, fabsl(rs) > 1e-6L ? ulp_err(ws2, rs) : (double)(fabsl(ws2 - rs) / 1.2e-22L));
+      e_wcos = std::fmax(e_wcos, fabsl(rc) > 1e-6L ? ulp_err(wc2, rc) : (double)(fabsl(wc2 - rc) / 1.2e-22L));
+      hh::fm::sincos_wide(x, ws2, wc2);  // and it agrees with the narrow form on the narrow range
+      e_wsin = std::fmax(e_wsin, fabsl(ws) > 1e-6L ? ulp_err(ws2, ws) : (double)(fabsl(ws2 - ws) / 1.2e-22L));
+      const double ex = (U(rng) < 0.1 ? 1400.0 : 60.0) * (U(rng) - 0.5) * (U(rng) < 0.3 ? std::exp2(-20.0 * U(rng)) : 1.0);
+      const long double we = expl((long double)ex);
+      const double ge = hh::fm::exp(ex);
+      if (we > 1e-300L && we < 1e300L) e_exp = std::fmax(e_exp, ulp_err(ge, we));
+    }
     const double lx = std::exp2(-600.0 + 1200.0 * U(rng)) * (1.0 + U(rng));
     e_log = std::fmax(e_log, ulp_err(hh::fm::log(lx), logl((long double)lx)));
     const double lx1 = 1.0 + (U(rng) - 0.5) * std::exp2(-40.0 * U(rng));  // around 1
@@ -43,6 +58,11 @@ int main() {
                            {0.4375, 1}, {0.6875, 1}, {1, 0.4375}, {1e-300, 1}, {1, 1e-300}};
   for (auto& p : pts)
     e_at = std::fmax(e_at, ulp_err(hh::fm::atan2(p[0], p[1]), atan2l((long double)p[0], (long double)p[1])));
-  std::printf("sin %d %.3f\ncos %d %.3f\nlog %d %.3f\natan2 %d %.3f\n", N, e_sin, N, e_cos, N, e_log, N, e_at);
+  // saturation and special values of exp
+  if (!(hh::fm::exp(-2000.0) == 0.0) || !std::isinf(hh::fm::exp(2000.0)) || !(hh::fm::exp(0.0) == 1.0) ||
+      !std::isnan(hh::fm::exp(std::nan(""))) || !(hh::fm::exp(-745.0) > 0.0))
+    e_exp = 1e9;
+  std::printf("sin %d %.3f\ncos %d %.3f\nlog %d %.3f\natan2 %d %.3f\nexp %d %.3f\nwsin %d %.3f\nwcos %d %.3f\n", N, e_sin,
+              N, e_cos, N, e_log, N, e_at, N, e_exp, N, e_wsin, N, e_wcos);
   return 0;
 }

@@ -112,4 +112,8 @@ def test_basket_on_broadie_kaya_samples(hhlib):
         hhlib.check(hhlib.lib.hh_mc_solve(hhlib.handle, C.byref(mk), C.byref(c), C.byref(single),
                                           None))
         assert res[k].price == pytest.approx(single.price, rel=1e-12)
-        assert res[k].bk_newton_fail == 0  # counters belong to the simulation, not to a payoff
+        # the simulation's diagnostics (fall-backs, series terms) come with every payoff
+        assert res[k].bk_newton_fail == single.bk_newton_fail > 0
+        assert res[k].bk_bisect_fallback == single.bk_bisect_fallback
+        assert res[k].bk_maxguess_fallback == single.bk_maxguess_fallback
+        assert res[k].bk_cf_terms == single.bk_cf_terms > 10 * n

@@ -76,6 +76,46 @@ def test_bk_matches_oracle_per_path(hhlib, name):
     assert res.bk_cf_terms == pytest.approx(ref["cf_terms"], rel=0.02 if PATH_RTOL[name] <= 1e-7 else 0.1)
 
 
+@pytest.mark.parametrize("name", ["h252", "q2", "large_nu"])
+@pytest.mark.parametrize("on_device", [0, 1])
+def test_bk_replay_of_the_callers_draws(hhlib, name, on_device):
+    """HH_NOISE_REPLAY for Broadie–Kaya: the three draws per trajectory (V_T, u, Z — the reference's
+    own, once julia/parity_replay.jl has exported them) come from the caller; here from scipy's
+    noncentral chi-squared sampler, i.e. from no code of this repository.  Everything downstream
+    (moments, CDF series, inverse_cdf, log S_T) against the oracle on the same draws."""
+    import scipy.stats as st
+    import torch
+    prm = PARAMS[name]
+    n = 500
+    rng = np.random.default_rng(7)
+    k, th, sg, T, V0 = prm["kappa"], prm["theta"], prm["sigma"], prm["T"], prm["V0"]
+    em1 = -math.expm1(-k * T)
+    d, lam = 4 * k * th / sg**2, 4 * k * math.exp(-k * T) * V0 / (sg**2 * em1)
+    VT = sg**2 * em1 / (4 * k) * st.ncx2.rvs(d, lam, size=n, random_state=rng)  # heston.jl:128-131
+    draws = np.ascontiguousarray(np.stack([VT, rng.uniform(size=n), rng.standard_normal(n)]))
+    m = o.make_model(**prm)
+    c = o.make_config(_ffi.HH_HESTON, _ffi.HH_BROADIE_KAYA, n, noise_mode=_ffi.HH_NOISE_REPLAY,
+                      replay=draws.ravel())
+    dev = None
+    if on_device:
+        dev = torch.from_numpy(draws.ravel().copy()).to("cuda:0")
+        c.replay, c.replay_on_device = dev.data_ptr(), 1
+    res = _ffi.hh_result()
+    term = np.zeros(n)
+    hhlib.check(hhlib.lib.hh_mc_solve(hhlib.handle, C.byref(m), C.byref(c), C.byref(res),
+                                      term.ctypes.data))
+    ref = bk_oracle.mc_solve(**prm, discount=m.discount, n_paths=n, seed0=0, replay=draws)
+    rel = np.abs(term - ref["terminal"]) / ref["terminal"]
+    assert np.all(np.isfinite(term))
+    assert np.mean(rel > PATH_RTOL[name]) <= 0.02, (np.sort(rel)[-10:], np.median(rel), name)
+    assert res.price == pytest.approx(ref["price"], rel=1e-4)
+    # a buffer shorter than 3·n_paths is refused on the host, not read out of bounds on the device
+    c2 = o.make_config(_ffi.HH_HESTON, _ffi.HH_BROADIE_KAYA, n, noise_mode=_ffi.HH_NOISE_REPLAY,
+                       replay=draws.ravel()[:2 * n])
+    assert hhlib.lib.hh_mc_solve(hhlib.handle, C.byref(m), C.byref(c2), C.byref(res), None) == _ffi.HH_ERR_INVALID
+    del dev
+
+
 def test_bk_sharding_is_invisible(hhlib):
     prm = PARAMS["h252"]
     full = gpu_bk(hhlib, prm, 1000, 11)[1]
