@@ -15,7 +15,7 @@ struct hh_ctx {
   int device = 0;
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_switch = nullptr;
   double* records = nullptr;
   size_t records_cap = 0;  // in records
   uint64_t* seeds = nullptr;
@@ -106,11 +106,20 @@ int ensure(hh_ctx* ctx, T*& buf, size_t& cap, size_t need) {
 
 int ncomp_of(int dynamics) { return dynamics == HH_HESTON ? 2 : 1; }
 
+// launch limits (documented in hedgehog_mc.h): threads per launch < 2^32, grid.y <= 65535
+constexpr uint64_t kMaxPaths = (1ull << 32) - 256;
+constexpr uint32_t kMaxEulerSteps = 4u * 65535u;  // replay_pack_kernel: 4 steps per grid.y
+constexpr uint32_t kMaxGridSteps = 65534u;        // LSM / exact grid: one grid.y per row, n_steps + 1 rows
+
 int validate(hh_ctx* ctx, const hh_model* m, const hh_config* c) {
   if (!m || !c) return fail(ctx, HH_ERR_INVALID, "model/config is NULL");
   if (c->n_paths == 0) return fail(ctx, HH_ERR_INVALID, "n_paths must be >= 1");
-  // one workgroup per 256 trajectories: the tile count must fit a grid dimension (< 2^31)
-  if (c->n_paths > (1ull << 38)) return fail(ctx, HH_ERR_INVALID, "n_paths too large (max 2^38)");
+  // one 256-thread workgroup per 256 trajectories: HIP rejects a launch of 2^32 threads or more
+  if (c->n_paths > kMaxPaths)
+    return fail(ctx, HH_ERR_INVALID, "n_paths too large (max 2^32 - 256 per call; shard the ensemble)");
+  // grid.y of the REPLAY repack / fill kernels (4 and 16 steps per workgroup) is limited to 65535
+  if (c->strategy == HH_EULER_MARUYAMA && c->n_steps > kMaxEulerSteps)
+    return fail(ctx, HH_ERR_INVALID, "n_steps too large (max %u)", kMaxEulerSteps);
   if (c->n_partials > HH_MAX_PARTIALS)
     return fail(ctx, HH_ERR_INVALID, "n_partials %u > HH_MAX_PARTIALS", c->n_partials);
   const bool logn = c->dynamics == HH_LOGNORMAL, hest = c->dynamics == HH_HESTON;
@@ -189,6 +198,7 @@ int hh_ctx_create(hh_ctx** out, int device_id) {
   if (hipSetDevice(device_id) != hipSuccess ||
       hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->ev_switch, hipEventDisableTiming) != hipSuccess ||
       hipMalloc((void**)&ctx->accum, HH_ACC_LEN * sizeof(double)) != hipSuccess ||
       hipHostMalloc((void**)&ctx->accum_host, HH_ACC_LEN * sizeof(double), hipHostMallocDefault) !=
           hipSuccess) {
@@ -203,7 +213,9 @@ int hh_ctx_create(hh_ctx** out, int device_id) {
 void hh_ctx_destroy(hh_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
-  (void)hipStreamSynchronize(ctx->stream);
+  // a borrowed stream may be gone already: wait for the device (hipFree below synchronises anyway)
+  if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
+  (void)hipDeviceSynchronize();
   if (ctx->records) (void)hipFree(ctx->records);
   if (ctx->seeds) (void)hipFree(ctx->seeds);
   if (ctx->replay) (void)hipFree(ctx->replay);
@@ -224,24 +236,34 @@ void hh_ctx_destroy(hh_ctx* ctx) {
   for (auto& pr : ctx->tev)
     for (auto& e : pr)
       if (e) (void)hipEventDestroy(e);
+  if (ctx->ev_switch) (void)hipEventDestroy(ctx->ev_switch);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
 }
 
+// Work already queued on the stream being left still uses the ctx's scratch buffers (records, staged
+// seeds / increments): the stream taken up next waits for it (an event, no host synchronisation).
+static int switch_stream(hh_ctx* ctx, hipStream_t next) {
+  if (next == ctx->stream) return HH_OK;
+  HH_HIP(ctx, hipSetDevice(ctx->device));
+  HH_HIP(ctx, hipEventRecord(ctx->ev_switch, ctx->stream));
+  HH_HIP(ctx, hipStreamWaitEvent(next, ctx->ev_switch, 0));
+  ctx->stream = next;
+  return HH_OK;
+}
+
 int hh_ctx_set_stream(hh_ctx* ctx, void* hip_stream) {
   if (!ctx) return HH_ERR_INVALID;
   std::lock_guard<std::recursive_mutex> lock__(ctx->mu);
-  ctx->stream = (hipStream_t)hip_stream;  // NULL is the device's default (null) stream
-  return HH_OK;
+  return switch_stream(ctx, (hipStream_t)hip_stream);  // NULL is the device's default (null) stream
 }
 
 int hh_ctx_reset_stream(hh_ctx* ctx) {
   if (!ctx) return HH_ERR_INVALID;
   std::lock_guard<std::recursive_mutex> lock__(ctx->mu);
-  ctx->stream = ctx->own_stream;
-  return HH_OK;
+  return switch_stream(ctx, ctx->own_stream);
 }
 
 const char* hh_last_error(const hh_ctx* ctx) { return ctx ? ctx->err : kNoCtx; }
@@ -276,7 +298,7 @@ int hh_replay_pack(hh_ctx* ctx, int32_t dynamics, uint64_t n_paths, uint32_t n_s
                    const double* src, int32_t src_on_device, double* dst) {
   if (!ctx) return HH_ERR_INVALID;
   std::lock_guard<std::recursive_mutex> lock__(ctx->mu);
-  if (!src || !dst || n_paths == 0 || n_steps == 0)
+  if (!src || !dst || n_paths == 0 || n_steps == 0 || n_paths > kMaxPaths || n_steps > kMaxEulerSteps)
     return fail(ctx, HH_ERR_INVALID, "hh_replay_pack: bad arguments");
   HH_HIP(ctx, hipSetDevice(ctx->device));
   const int nc = ncomp_of(dynamics);
@@ -297,7 +319,8 @@ int hh_wiener_fill(hh_ctx* ctx, int32_t dynamics, double rho, double T, uint32_t
                    uint64_t n_paths, const uint64_t* seeds, int32_t seeds_on_device, double* dst) {
   if (!ctx) return HH_ERR_INVALID;
   std::lock_guard<std::recursive_mutex> lock__(ctx->mu);
-  if (!seeds || !dst || n_paths == 0 || n_steps == 0 || !(T > 0.0) || !(std::fabs(rho) <= 1.0))
+  if (!seeds || !dst || n_paths == 0 || n_steps == 0 || !(T > 0.0) || !(std::fabs(rho) <= 1.0) ||
+      n_paths > kMaxPaths || n_steps > kMaxEulerSteps)
     return fail(ctx, HH_ERR_INVALID, "hh_wiener_fill: bad arguments");
   HH_HIP(ctx, hipSetDevice(ctx->device));
   const uint64_t* seeds_dev = seeds;
@@ -670,8 +693,9 @@ static int lsm_check_scalars(hh_ctx* ctx, const hh_model* m, const hh_config* c,
                              double step_discount) {
   if (c->n_paths == 0 || c->n_steps == 0 || degree < 1 || degree > 8)
     return fail(ctx, HH_ERR_INVALID, "LSM: n_paths, n_steps >= 1, 1 <= degree <= 8");
-  // one workgroup per 256 trajectories: the tile count must fit a grid dimension (< 2^31)
-  if (c->n_paths > (1ull << 38)) return fail(ctx, HH_ERR_INVALID, "n_paths too large (max 2^38)");
+  if (c->n_paths > kMaxPaths / 2 || c->n_steps > kMaxGridSteps)
+    return fail(ctx, HH_ERR_INVALID, "LSM: at most 2^31 - 128 trajectories (x2 antithetic) and %u steps",
+                kMaxGridSteps);
   if (!(m->S0 > 0.0) || !(m->T > 0.0) || (m->cp != 1.0 && m->cp != -1.0) ||
       !(step_discount > 0.0) || !std::isfinite(step_discount))
     return fail(ctx, HH_ERR_INVALID, "LSM: bad model scalars");
@@ -704,8 +728,9 @@ static int run_heston_grid(hh_ctx* ctx, const hh_model* m, const hh_config* c) {
   if (c->noise_mode != HH_NOISE_GENERATE || c->n_partials != 0 || c->antithetic)
     return fail(ctx, HH_ERR_UNSUPPORTED,
                 "exact Heston grid: GENERATE noise, no dual partials, no antithetic form");
-  if (c->n_paths == 0 || c->n_steps == 0 || c->n_paths > (1ull << 38))
-    return fail(ctx, HH_ERR_INVALID, "exact Heston grid: n_paths, n_steps >= 1");
+  if (c->n_paths == 0 || c->n_steps == 0 || c->n_paths > kMaxPaths || c->n_steps > kMaxGridSteps)
+    return fail(ctx, HH_ERR_INVALID, "exact Heston grid: 1 <= n_paths <= 2^32 - 256, 1 <= n_steps <= %u",
+                kMaxGridSteps);
   if (!(m->S0 > 0.0) || !(m->T > 0.0) || !std::isfinite(m->S0) || !std::isfinite(m->T) ||
       !(std::fabs(m->rho) <= 1.0) || m->sigma == 0.0 || m->kappa == 0.0 || !(m->V0 > 0.0))
     return fail(ctx, HH_ERR_INVALID,

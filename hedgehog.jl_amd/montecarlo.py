@@ -71,8 +71,12 @@ class SimulationConfig:
 
 @dataclass(frozen=True)
 class MonteCarlo(AbstractPricingMethod):
-    """montecarlo.jl:127-131.  `em_split` / `compat_sqrt_alpha` / `device` are build options with
-    the reference's behaviour as default (quirks Q1, EM split form)."""
+    """montecarlo.jl:127-131.  `em_split` / `compat_sqrt_alpha` / `device` are build options.
+    em_split=True is the split-step form SURVEY §8a-4 attributes to StochasticDiffEq's EM() (the
+    reference's behaviour as far as it can be read without running it).  compat_sqrt_alpha=False is
+    NOT the reference's behaviour: it is the CORRECTED exact-lognormal drift (r - σ²/2)·T; the
+    reference computes (r - σ²/2)·√T (montecarlo.jl:302, quirk Q1), which compat_sqrt_alpha=True
+    reproduces bug for bug — use that for parity runs at T != 1 (at T = 1 both coincide)."""
     dynamics: Any
     strategy: Any
     config: SimulationConfig

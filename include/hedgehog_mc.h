@@ -99,7 +99,10 @@ typedef struct hh_config {
   int32_t terminal_on_device;
   uint32_t n_steps;          /* SimulationConfig.steps (montecarlo.jl:60); exact laws ignore it   */
   uint32_t n_partials;       /* 0..HH_MAX_PARTIALS                                                */
-  uint64_t n_paths;          /* SimulationConfig.trajectories of THIS shard (1 .. 2^38)           */
+  uint64_t n_paths;          /* SimulationConfig.trajectories of THIS shard: 1 .. 2^32 - 256 per
+                                call (one 256-thread workgroup per 256 trajectories, < 2^32
+                                threads per launch); larger ensembles are sharded by path_offset.
+                                n_steps: Euler at most 262 140; LSM / exact grid at most 65 534   */
   uint64_t path_offset;      /* global index of this shard's first trajectory (exact laws draw by
                                 global index from ONE key, montecarlo.jl:456, so results do not
                                 depend on the sharding)                                           */
@@ -128,7 +131,10 @@ typedef struct hh_result {
   uint64_t n_paths_done;
   uint64_t bk_newton_fail, bk_bisect_fallback, bk_maxguess_fallback, bk_cf_terms;
   double kernel_ms;           /* HIP-event time of everything the call enqueued: staging copies
-                                 of host seeds / increments, simulation, record reduction         */
+                                 of host seeds / increments, simulation, record reduction; the
+                                 FIRST call of a size also grows the ctx's scratch buffers
+                                 (hipMalloc / hipFree synchronise) inside this bracket — use
+                                 hh_ctx_enable_timing for the simulation kernel alone             */
   double total_ms;            /* host wall time of the call                                       */
 } hh_result;
 
@@ -139,7 +145,9 @@ int hh_ctx_create(hh_ctx** out, int device_id);
 void hh_ctx_destroy(hh_ctx* ctx);
 /* Borrow an external hipStream_t (e.g. PyTorch's current stream).  NULL is a valid handle: the
  * device's default (null) stream — which is what PyTorch uses unless told otherwise.
- * hh_ctx_reset_stream goes back to the ctx's own non-blocking stream. */
+ * hh_ctx_reset_stream goes back to the ctx's own non-blocking stream.  A switch orders the new
+ * stream behind whatever the ctx still has queued on the old one (the asynchronous entry points
+ * share the ctx's scratch buffers); the borrowed stream must stay alive until then. */
 int hh_ctx_set_stream(hh_ctx* ctx, void* hip_stream);
 int hh_ctx_reset_stream(hh_ctx* ctx);
 const char* hh_last_error(const hh_ctx* ctx); /* NUL-terminated, owned by ctx (or static if NULL) */

@@ -8,6 +8,13 @@
 #     include("julia/HedgehogMC.jl"); using .HedgehogMC
 #     HedgehogMC.install!()          # route Hedgehog.solve(::PricingProblem, ::MonteCarlo) to the GPU
 #     sol = Hedgehog.solve(prob, MonteCarlo(HestonDynamics(), EulerMaruyama(), cfg))
+#     G   = Hedgehog.solve(BatchGreekProblem(prob, lenses), ForwardAD(), mc)    # ONE fused pass
+#
+# What is bound (include/hedgehog_mc.h, HH_ABI_VERSION 2): hh_mc_solve (solve_hip, with the REPLAY
+# keywords), hh_mc_accumulate + hh_mc_finalize (solve_sharded_hip), hh_mc_solve_basket, hh_carr_madan,
+# hh_lsm_solve, hh_heston_exact_grid, hh_replay_elems, the device-memory helpers.  The struct mirrors
+# below are checked field by field against the C header by tests/test_julia_layout.py (offsets from
+# a compiled offsetof dump), so a drift between the two shows up on the CPU, without Julia.
 module HedgehogMC
 
 using Hedgehog
@@ -21,6 +28,10 @@ const LIB = Ref{String}(get(ENV, "HEDGEHOG_MC_LIB",
                             joinpath(@__DIR__, "..", "hedgehog.jl_amd", "lib", "libhedgehog_mc.so")))
 
 const HH_MAX_PARTIALS = 8
+const HH_ACC_LEN = 16
+const HH_ABI_VERSION = 2
+const HH_NOISE_GENERATE, HH_NOISE_REPLAY = Int32(0), Int32(1)
+const HH_REPLAY_TILE_MAJOR, HH_REPLAY_PATH_MAJOR = Int32(0), Int32(1)
 
 # ---- C structs (layout of include/hedgehog_mc.h) ---------------------------------------------
 struct HHModel
@@ -114,16 +125,26 @@ function _resolve(payoff, m, method::MonteCarlo)
             DT = _dualtype(scal...))
 end
 
-# hh_model / hh_config from a resolved problem; the caller holds r.seedvecs and r.seeds in GC.@preserve
-function _structs(r; em_split::Bool = true, compat_sqrt_alpha::Bool = false)
+# hh_model / hh_config from a resolved problem; the caller holds r.seedvecs, r.seeds (and `replay`)
+# in GC.@preserve.  n_paths / path_offset / seed_offset describe a shard (solve_sharded_hip).
+# replay: Wiener increments (Euler: path-major [path][step][comp] as diff(sol.W.W) gives them, or the
+# tile-major layout of hh_replay_elems), standard normals (exact law) or [V_T | u | Z] (Broadie–Kaya).
+function _structs(r; em_split::Bool = true, compat_sqrt_alpha::Bool = false,
+                  replay::Union{Nothing,Vector{Float64}} = nothing,
+                  replay_layout::Int32 = HH_REPLAY_PATH_MAJOR,
+                  n_paths::Int = r.n, path_offset::Int = 0, seed_offset::Int = 0)
     ptr(i) = (r.P == 0 || all(iszero, r.seedvecs[i])) ? Ptr{Cdouble}(C_NULL) : pointer(r.seedvecs[i])
     v = map(_val, r.scal)
     model = HHModel(v[1], v[2], v[3], v[4], v[5], r.rho, v[6], v[7], r.T, v[8], r.cp,
                     ptr(1), ptr(2), ptr(3), ptr(4), ptr(5), ptr(6), ptr(7), ptr(8))
+    noise = replay === nothing ? HH_NOISE_GENERATE : HH_NOISE_REPLAY
     config = HHConfig(r.dynamics, r.strategy, r.anti, em_split, compat_sqrt_alpha,
-                      0, 0, 0, 0, 0, UInt32(r.steps), UInt32(r.P), UInt64(r.n), UInt64(0),
-                      pointer(r.seeds), Ptr{Cdouble}(C_NULL), 0.0, 0.0, 0.0, 0.0, 0, 0,
-                      UInt64(length(r.seeds)), UInt64(0))
+                      noise, replay_layout, 0, 0, 0, UInt32(r.steps), UInt32(r.P), UInt64(n_paths),
+                      UInt64(path_offset), pointer(r.seeds) + 8 * seed_offset,
+                      replay === nothing ? Ptr{Cdouble}(C_NULL) : pointer(replay),
+                      0.0, 0.0, 0.0, 0.0, 0, 0,
+                      UInt64(length(r.seeds) - seed_offset),
+                      UInt64(replay === nothing ? 0 : length(replay)))
     return model, config
 end
 
@@ -133,15 +154,18 @@ _price(r, res::HHResult) = r.DT === nothing ? res.price :
 # ---- solve(prob, ::MonteCarlo) on the GPU (montecarlo.jl:478-493) -------------------------------
 function solve_hip(prob::PricingProblem{VanillaOption{TS,TE,European,C,Spot},I},
                    method::MonteCarlo; ensemble::Bool = true,
-                   em_split::Bool = true, compat_sqrt_alpha::Bool = false) where {TS,TE,C,I}
+                   em_split::Bool = true, compat_sqrt_alpha::Bool = false,
+                   replay::Union{Nothing,AbstractArray{Float64}} = nothing,
+                   replay_layout::Int32 = HH_REPLAY_PATH_MAJOR) where {TS,TE,C,I}
     r = _resolve(prob.payoff, prob.market_inputs, method)
     r === nothing && throw(MethodError(Hedgehog.solve, (prob, method)))
     terminal = ensemble ? Vector{Float64}(undef, r.anti ? 2r.n : r.n) : Float64[]
     res = Ref{HHResult}()
     ctx = context()
     seedvecs, seeds = r.seedvecs, r.seeds
-    GC.@preserve seedvecs seeds terminal begin
-        model, config = _structs(r; em_split, compat_sqrt_alpha)
+    rep = replay === nothing ? nothing : collect(Float64, vec(replay))   # noise replay (montecarlo.jl:258,370)
+    GC.@preserve seedvecs seeds terminal rep begin
+        model, config = _structs(r; em_split, compat_sqrt_alpha, replay = rep, replay_layout)
         rc = ccall((:hh_mc_solve, LIB[]), Cint,
                    (Ptr{Cvoid}, Ref{HHModel}, Ref{HHConfig}, Ref{HHResult}, Ptr{Cdouble}),
                    ctx.handle, model, config, res,
@@ -151,6 +175,121 @@ function solve_hip(prob::PricingProblem{VanillaOption{TS,TE,European,C,Spot},I},
     end
     ens = !ensemble ? nothing : r.anti ? (terminal[1:r.n], terminal[r.n+1:2r.n]) : terminal
     return MonteCarloSolution(prob, method, _price(r, res[]), ens)       # pricing_solutions.jl:22-27
+end
+
+# ---- BatchGreekProblem + ForwardAD in ONE pass (greeks_problem.jl:559-568) ------------------------
+"""
+    solve_batch_greeks_hip(gprob::BatchGreekProblem, mc::MonteCarlo) -> Dict(lens => greek)
+
+The reference loops over the lenses and runs one full dual-number simulation per lens
+(greeks_problem.jl:567, each `ForwardDiff.derivative` at :258-260).  Here every lens seeds ONE
+partial of the same `Dual{Tag,Float64,L}` — `set(prob, lens, Dual(lens(prob), e_k))` — and a single
+`hh_mc_solve` with `n_partials = L` returns all the derivatives: the kernels carry only the
+directions that reach the diffusion, the rest is finished in closed form (include/hedgehog_mc.h,
+`hh_model`).  Result and key type are the reference's: `Dict(lens => greek)`.
+"""
+struct HipBatchTag end
+
+function solve_batch_greeks_hip(gprob::Hedgehog.BatchGreekProblem, mc::MonteCarlo)
+    prob = gprob.pricing_problem
+    lenses = collect(gprob.lenses)
+    L = length(lenses)
+    L <= HH_MAX_PARTIALS || error("at most $HH_MAX_PARTIALS lenses per fused pass")
+    DT = ForwardDiff.Dual{HipBatchTag,Float64,L}
+    p = prob
+    for (k, lens) in enumerate(lenses)
+        x0 = Float64(lens(prob))
+        p = Hedgehog.set(p, lens, DT(x0, ForwardDiff.Partials(ntuple(j -> j == k ? 1.0 : 0.0, L))))
+    end
+    price = solve_hip(p, mc; ensemble = false).price           # a Dual carrying all L partials
+    parts = ForwardDiff.partials(price)
+    return Dict(lens => parts[k] for (k, lens) in enumerate(lenses))
+end
+
+# ---- path-sharded solve: hh_mc_accumulate -> (all-reduce) -> hh_mc_finalize ------------------------
+"""
+    solve_sharded_hip(prob, method; rank, world, allreduce! = identity, device = rank)
+
+One rank's part of a multi-GPU solve (one Julia process per GPU): trajectories
+`[rank·⌈N/G⌉, min(N, (rank+1)·⌈N/G⌉))` (SURVEY §8e), seeds sliced by the same range, exact laws
+offset by `path_offset`; the HH_ACC_LEN-double accumulator vector is summed over the ranks by
+`allreduce!(acc::Vector{Float64})` (e.g. `MPI.Allreduce!(acc, +, comm)` — the path's ONE exchange;
+any SUM all-reduce works, the vector is 128 bytes) and finalised on the host.  Every rank returns the
+same `MonteCarloSolution` (no ensemble).
+"""
+function solve_sharded_hip(prob::PricingProblem{VanillaOption{TS,TE,European,C,Spot},I},
+                           method::MonteCarlo; rank::Integer, world::Integer,
+                           allreduce! = identity, device::Integer = rank) where {TS,TE,C,I}
+    r = _resolve(prob.payoff, prob.market_inputs, method)
+    r === nothing && throw(MethodError(Hedgehog.solve, (prob, method)))
+    per = cld(r.n, world)
+    start = min(r.n, rank * per)
+    stop = min(r.n, start + per)
+    ctx = Context(device)
+    acc = zeros(Float64, HH_ACC_LEN)
+    dev_acc = Ref{Ptr{Cvoid}}(C_NULL)
+    seedvecs, seeds = r.seedvecs, r.seeds
+    euler = r.strategy == 0
+    GC.@preserve seedvecs seeds acc begin
+        model, config = _structs(r; n_paths = stop - start, path_offset = start,
+                                 seed_offset = euler ? start : 0)
+        if stop > start
+            rc = ccall((:hh_device_malloc, LIB[]), Cint, (Ptr{Cvoid}, Csize_t, Ref{Ptr{Cvoid}}),
+                       ctx.handle, 8 * HH_ACC_LEN, dev_acc)
+            rc == 0 || error("hh_device_malloc failed ($rc): $(last_error(ctx))")
+            rc = ccall((:hh_mc_accumulate, LIB[]), Cint,
+                       (Ptr{Cvoid}, Ref{HHModel}, Ref{HHConfig}, Ptr{Cvoid}, Ptr{Cdouble}),
+                       ctx.handle, model, config, dev_acc[], Ptr{Cdouble}(C_NULL))
+            rc == -2 && throw(MethodError(Hedgehog.solve, (prob, method)))
+            rc == 0 || error("hh_mc_accumulate failed ($rc): $(last_error(ctx))")
+            rc = ccall((:hh_memcpy_d2h, LIB[]), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Csize_t),
+                       ctx.handle, pointer(acc), dev_acc[], 8 * HH_ACC_LEN)
+            rc == 0 || error("hh_memcpy_d2h failed ($rc): $(last_error(ctx))")
+            ccall((:hh_device_free, LIB[]), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), ctx.handle, dev_acc[])
+        end
+        allreduce!(acc)                                        # SUM over the ranks, in place
+        res = Ref{HHResult}()
+        rc = ccall((:hh_mc_finalize, LIB[]), Cint,
+                   (Ref{HHModel}, Ref{HHConfig}, Ptr{Cdouble}, Ref{HHResult}),
+                   model, config, pointer(acc), res)
+        rc == 0 || error("hh_mc_finalize failed ($rc)")
+        return MonteCarloSolution(prob, method, _price(r, res[]), nothing)
+    end
+end
+
+# ---- Carr–Madan on the device (src/pricing_methods/carr_madan.jl:47-71) ----------------------------
+"""
+    carr_madan_hip(prob, method::Hedgehog.CarrMadan; compat_sqrt_alpha = false)
+
+`hh_carr_madan`: the damped Fourier price the reference's Monte Carlo tests compare against
+(α = method.α, bound = method.bound), for Heston or lognormal dynamics.
+"""
+function carr_madan_hip(prob::PricingProblem{VanillaOption{TS,TE,European,C,Spot},I},
+                        method::Hedgehog.CarrMadan; compat_sqrt_alpha::Bool = false) where {TS,TE,C,I}
+    m, payoff = prob.market_inputs, prob.payoff
+    T = yearfrac(m.rate.reference_date, payoff.expiry)
+    r = zero_rate(m.rate, payoff.expiry)
+    D = df(m.rate, payoff.expiry)
+    none = ntuple(_ -> Ptr{Cdouble}(C_NULL), 8)
+    if m isa HestonInputs
+        dynamics = Int32(1)
+        model = HHModel(Float64(m.spot), Float64(m.V0), Float64(m.κ), Float64(m.θ), Float64(m.σ),
+                        Float64(m.ρ), Float64(r), Float64(D), Float64(T), Float64(payoff.strike),
+                        payoff.call_put(), none...)
+    else
+        dynamics = Int32(0)
+        model = HHModel(Float64(m.spot), 0.0, 0.0, 0.0, Float64(get_vol(m.sigma, nothing, nothing)), 0.0,
+                        Float64(r), Float64(D), Float64(T), Float64(payoff.strike), payoff.call_put(),
+                        none...)
+    end
+    out = Ref{Cdouble}(0.0)
+    ctx = context()
+    rc = ccall((:hh_carr_madan, LIB[]), Cint,
+               (Ptr{Cvoid}, Ref{HHModel}, Int32, Int32, Cdouble, Cdouble, Ref{Cdouble}),
+               ctx.handle, model, dynamics, Int32(compat_sqrt_alpha), Float64(method.α),
+               Float64(method.bound), out)
+    rc == 0 || error("hh_carr_madan failed ($rc): $(last_error(ctx))")
+    return Hedgehog.AnalyticSolution(prob, method, out[])
 end
 
 # ---- same-expiry baskets (src/calibration/basket.jl:35-38) ---------------------------------------
@@ -199,6 +338,7 @@ struct HHLsmResult
     n_paths_total::UInt64
     rows_regressed::UInt32; rows_skipped::UInt32
     kernel_ms::Cdouble; total_ms::Cdouble
+    form::Int32; reserved_::Int32
 end
 
 """
@@ -279,14 +419,24 @@ end
     install!()
 
 Overwrite `Hedgehog.solve(::PricingProblem{<:VanillaOption{…,European,…,Spot}}, ::MonteCarlo)`
-(montecarlo.jl:478-481) with the GPU implementation.  `GreekProblem`/`BatchGreekProblem`/
-`FiniteDifference` solvers (greeks_problem.jl:249-329, 559-568) then run through it unchanged.
+(montecarlo.jl:478-481) with the GPU implementation and add the fused
+`solve(::BatchGreekProblem, ::ForwardAD, ::MonteCarlo)`.  `GreekProblem` and `FiniteDifference`
+solvers (greeks_problem.jl:249-329) then run through the first unchanged.
 """
 function install!()
+    ccall((:hh_abi_version, LIB[]), Cint, ()) == HH_ABI_VERSION ||
+        error("libhedgehog_mc.so has another ABI version than this file ($HH_ABI_VERSION)")
     @eval Hedgehog function solve(
         prob::PricingProblem{VanillaOption{TS,TE,European,C,Spot},I}, method::MonteCarlo,
     ) where {TS,TE,C,I<:AbstractMarketInputs}
         return $(solve_hip)(prob, method)
+    end
+    # the fused form of greeks_problem.jl:559-568 (more specific than the reference's generic method:
+    # ForwardAD + MonteCarlo); FiniteDifference / analytic methods keep the reference's loop
+    @eval Hedgehog function solve(
+        gprob::BatchGreekProblem{P,L}, ::ForwardAD, pricing_method::MonteCarlo,
+    ) where {P,L}
+        return $(solve_batch_greeks_hip)(gprob, pricing_method)
     end
     return nothing
 end

@@ -360,23 +360,70 @@ def test_mixed_active_and_passive_directions(hhlib, oracle, dyn, strategy, anti)
 
 
 def test_reference_replay_exchange_format(capsys):
-    """tools/check_reference_replay.py on the committed format self-test (oracle-generated with
-    em_split=1): the matching step form agrees to rounding, the other one does not."""
+    """tools/check_reference_replay.py on the committed format self-test (oracle-generated, Euler cases
+    with em_split=1): every case of julia/parity_replay.jl's manifest — Euler Heston / lognormal,
+    antithetic, AD Greeks, exact law, Broadie–Kaya draws, LSM grid — goes through its REPLAY seam of
+    the C-ABI and meets its bar; for the Heston Euler case the other step form does not."""
+    import importlib.util
     import os
-    import runpy
-    import sys
 
     from tests.conftest import ROOT
-    meta = os.path.join(ROOT, "tests", "golden", "replay_selftest", "meta.json")
-    argv = sys.argv
-    sys.argv = ["check_reference_replay.py", meta]
+    spec = importlib.util.spec_from_file_location(
+        "check_reference_replay", os.path.join(ROOT, "tools", "check_reference_replay.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    bad = mod.main(os.path.join(ROOT, "tests", "golden", "replay_selftest", "manifest.json"))
+    out = capsys.readouterr().out
+    lines = {ln.split()[1]: ln for ln in out.splitlines() if ln.startswith("case ")}
+    assert bad == 0, out
+    assert set(lines) == {"heston_euler", "heston_euler_antithetic", "heston_euler_greeks",
+                          "lognormal_euler", "exact_lognormal", "broadie_kaya", "lsm_put"}
+    assert all(" OK: " in ln for ln in lines.values()), out
+    h = lines["heston_euler"]
+    e1 = float(h.split("em_split=1=max_rel_S=")[1].split(",")[0])
+    e0 = float(h.split("em_split=0=max_rel_S=")[1].split(",")[0])
+    assert e1 < 1e-12 and e0 > 1e-6
+    assert "same_stopping_time=1.00000" in lines["lsm_put"] or "same_stopping_time=0.99" in lines["lsm_put"]
+
+
+def test_launch_limits_are_argument_errors(hhlib):
+    """Sizes beyond what one launch can address (2^32 threads, grid.y 65535) come back as
+    HH_ERR_INVALID with a message, not as an opaque launch failure."""
+    m = o.make_model()
+    res = _ffi.hh_result()
+    c = o.make_config(HES, EM, 2**32, 10, seeds=[1])
+    assert hhlib.lib.hh_mc_solve(hhlib.handle, C.byref(m), C.byref(c), C.byref(res), None) == _ffi.HH_ERR_INVALID
+    assert b"n_paths too large" in hhlib.lib.hh_last_error(hhlib.handle)
+    c = o.make_config(HES, EM, 1000, 4 * 65535 + 1, seeds=seeds_for(1000, 0))
+    assert hhlib.lib.hh_mc_solve(hhlib.handle, C.byref(m), C.byref(c), C.byref(res), None) == _ffi.HH_ERR_INVALID
+    assert b"n_steps too large" in hhlib.lib.hh_last_error(hhlib.handle)
+    lres = _ffi.hh_lsm_result()
+    c = o.make_config(0, 1, 1000, 65535, seeds=seeds_for(1000, 0))
+    assert hhlib.lib.hh_lsm_solve(hhlib.handle, C.byref(m), C.byref(c), 3, 0.999, C.byref(lres), None, None,
+                                  None) == _ffi.HH_ERR_INVALID
+
+
+def test_stream_switch_orders_queued_work(hhlib, oracle):
+    """hh_ctx_set_stream / reset_stream between two asynchronous accumulates: the second runs on
+    another stream but reuses the ctx's scratch records — it must wait for the first."""
+    import torch
+    dev = torch.device("cuda", 0)
+    m = o.make_model()
+    side = torch.cuda.Stream(dev)
+    accs = torch.zeros(2, _ffi.HH_ACC_LEN, dtype=torch.float64, device=dev)
+    cfgs = [o.make_config(HES, EM, 200_000, 120, seeds=seeds_for(200_000, 3)),
+            o.make_config(HES, EM, 777, 5, seeds=seeds_for(777, 4))]
     try:
-        runpy.run_path(os.path.join(ROOT, "tools", "check_reference_replay.py"), run_name="__main__")
+        hhlib.check(hhlib.lib.hh_mc_accumulate(hhlib.handle, C.byref(m), C.byref(cfgs[0]), accs[0].data_ptr(), None))
+        hhlib.set_stream(side.cuda_stream)   # the long solve is still running on the ctx's own stream
+        hhlib.check(hhlib.lib.hh_mc_accumulate(hhlib.handle, C.byref(m), C.byref(cfgs[1]), accs[1].data_ptr(), None))
+        hhlib.synchronize()
+        torch.cuda.synchronize(dev)
     finally:
-        sys.argv = argv
-    lines = [ln for ln in capsys.readouterr().out.splitlines() if ln.startswith("em_split")]
-    err = {ln.split(":")[0]: float(ln.split("= ")[1].split(",")[0]) for ln in lines}
-    assert err["em_split=1"] < 1e-12 and err["em_split=0"] > 1e-6
+        hhlib.set_stream(None)
+    for k in (0, 1):
+        want = oracle.mc_solve(m, cfgs[k], want_terminal=False)[2]
+        np.testing.assert_allclose(accs[k].cpu().numpy()[:2], want[:2], rtol=1e-11)
 
 
 def test_context_shared_between_threads(hhlib, oracle):

@@ -3,6 +3,7 @@ the HIP path (test/agreement/montecarlo_black_scholes.jl, montecarlo_heston.jl,
 greeks_agreement.jl:170-241), plus full-size property checks of BASELINE.json's configurations."""
 import numpy as np
 import pytest
+from scipy.stats import norm
 
 import hedgehog_jl_amd as hh
 from oracle import analytic
@@ -45,6 +46,63 @@ def test_black_scholes_mc_vs_analytic(strategy):
         assert np.mean(prices) == pytest.approx(ref, rel=0.02)
         var[type(vr).__name__] = np.var(prices)
     assert var["NoVarianceReduction"] / var["Antithetic"] > 1.0
+
+
+def test_exact_law_at_T_not_one_bug_for_bug_and_corrected():
+    """Quirk Q1 (montecarlo.jl:302): the reference's exact lognormal law has mean log S0 + (r - σ²/2)·√T.
+    compat_sqrt_alpha=True reproduces that law (what a parity run against Hedgehog.jl needs at
+    T != 1), the default uses ·T; at T = 4 the two differ grossly and each matches ITS closed form."""
+    import math
+    ref = hh.Date(2020, 1, 1)
+    prob = bs_problem(ref=ref, expiry=hh.Date(2023, 12, 31))   # 1460 days: T = 4 under ACT/365
+    T = hh.yearfrac(ref, hh.Date(2023, 12, 31))
+    assert T == pytest.approx(4.0)
+    n = 400_000
+    cfg = hh.SimulationConfig(n, seeds=np.arange(1, n + 1))
+    S, K, r, sg = 100.0, 100.0, 0.05, 0.2
+    want_of = {}
+    for compat in (False, True):
+        sol = hh.solve(prob, hh.MonteCarlo(hh.LognormalDynamics(), hh.BlackScholesExact(), cfg,
+                                           compat_sqrt_alpha=compat))
+        mu = math.log(S) + (r - 0.5 * sg * sg) * (math.sqrt(T) if compat else T)
+        sd = sg * math.sqrt(T)
+        # E[max(S - K, 0)] for log S ~ N(mu, sd²), discounted at r·T
+        d1 = (mu + sd * sd - math.log(K)) / sd
+        want = math.exp(-r * T) * (math.exp(mu + 0.5 * sd * sd) * norm.cdf(d1) -
+                                   K * norm.cdf(d1 - sd))
+        want_of[compat] = want
+        assert abs(sol.price - want) < 4 * sol.std_error, (compat, sol.price, want)
+        assert np.log(sol.ensemble).mean() == pytest.approx(mu, abs=4 * sd / math.sqrt(n))
+    # the corrected law is Black–Scholes'
+    assert want_of[False] == pytest.approx(analytic.bs_price(S, K, r, sg, T), rel=1e-12)
+
+
+def test_config1_exact_workload_against_the_oracle(hhlib, oracle):
+    """BASELINE.json configs[0] at ITS size: examples/montecarlo_black_scholes.jl:9-26 — European put,
+    S = K = 1, r = 0.03, σ = 0.04, expiry one (leap) year out, MonteCarlo(LognormalDynamics(),
+    EulerMaruyama(), SimulationConfig(10_000; steps = 100)) — through the host mirror, every
+    terminal sample and the price against the CPU oracle on the same seeds, and the price against
+    BlackScholesAnalytic (0.005165653284670465)."""
+    import ctypes as C
+
+    from hedgehog_jl_amd import _ffi
+    from tests import oracle_ffi as o
+    ref = hh.Date(2020, 1, 1)
+    payoff = hh.VanillaOption(1.0, hh.add_years(ref, 1), hh.European(), hh.Put(), hh.Spot())
+    prob = hh.PricingProblem(payoff, hh.BlackScholesInputs(ref, 0.03, 1.0, 0.04))
+    seeds = np.random.default_rng(2024).integers(0, 2**63, 10_000).astype(np.uint64)
+    for vr in (hh.NoVarianceReduction(), hh.Antithetic()):
+        cfg = hh.SimulationConfig(10_000, steps=100, seeds=seeds, variance_reduction=vr)
+        sol = hh.solve(prob, hh.MonteCarlo(hh.LognormalDynamics(), hh.EulerMaruyama(), cfg))
+        anti = isinstance(vr, hh.Antithetic)
+        m = o.make_model(S0=1.0, sigma=0.04, r=0.03, T=366 / 365, strike=1.0, cp=-1.0)
+        c = o.make_config(_ffi.HH_LOGNORMAL, _ffi.HH_EULER_MARUYAMA, 10_000, 100, antithetic=int(anti),
+                          seeds=seeds)
+        r, t, _ = oracle.mc_solve(m, c)
+        ens = np.concatenate(sol.ensemble) if anti else sol.ensemble
+        np.testing.assert_allclose(ens, t, rtol=1e-12)
+        assert sol.price == pytest.approx(r.price, rel=1e-11)
+        assert abs(sol.price - 0.005165653284670465) < 4 * sol.std_error + 1e-5   # + Euler bias at dt = 1/100
 
 
 def test_solution_is_consistent_with_its_ensemble():

@@ -1,0 +1,129 @@
+"""Static check of the Julia side of the boundary: the `struct` mirrors in
+julia/HedgehogMC.jl must have the C layout of include/hedgehog_mc.h.  No Julia is needed: the C side
+is measured (a generated offsetof / sizeof dump compiled with gcc), the Julia side is computed from
+the field types with the C layout rules Julia uses for isbits structs; the ctypes mirror of the
+Python host is held to the same dump.  Also: every C entry point the Julia file `ccall`s exists in
+the header with that name."""
+import ctypes as C
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "hedgehog_mc.h")
+JULIA = os.path.join(ROOT, "julia", "HedgehogMC.jl")
+PAIRS = {"hh_model": "HHModel", "hh_config": "HHConfig", "hh_result": "HHResult",
+         "hh_lsm_result": "HHLsmResult"}
+
+
+def c_structs():
+    """{struct: [field names in order]} parsed from the header (comments stripped)."""
+    src = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    out = {}
+    for m in re.finditer(r"typedef struct (\w+) \{(.*?)\} \1;", src, flags=re.S):
+        fields = []
+        for decl in m.group(2).split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            names = decl.split(None, 1)[1] if not decl.startswith("const") else decl.split(None, 2)[2]
+            for n in names.split(","):
+                fields.append(re.sub(r"\[.*\]", "", n).replace("*", "").strip())
+        out[m.group(1)] = fields
+    return out
+
+
+def measured_layout(tmp_path):
+    structs = c_structs()
+    lines = ['#include <stddef.h>', '#include <stdio.h>', f'#include "{HEADER}"', "int main(void) {"]
+    for s, fields in structs.items():
+        lines.append(f'  printf("{s} sizeof %zu\\n", sizeof({s}));')
+        for f in fields:
+            lines.append(f'  printf("{s} {f} %zu %zu\\n", offsetof({s}, {f}), sizeof((({s}*)0)->{f}));')
+    lines += ["  return 0;", "}"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c11", "-Wall", "-Werror", str(src), "-o", str(exe)], check=True)
+    out = {}
+    for ln in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines():
+        s, f, *nums = ln.split()
+        out.setdefault(s, {"fields": []})
+        if f == "sizeof":
+            out[s]["size"] = int(nums[0])
+        else:
+            out[s]["fields"].append((f, int(nums[0]), int(nums[1])))
+    return out
+
+
+JL_TYPES = {"Cdouble": (8, 8), "Float64": (8, 8), "Int32": (4, 4), "UInt32": (4, 4), "Cint": (4, 4),
+            "UInt64": (8, 8), "Int64": (8, 8)}
+
+
+def jl_type(t):
+    t = t.strip()
+    if t.startswith("Ptr{"):
+        return 8, 8
+    m = re.fullmatch(r"NTuple\{(\d+),\s*(\w+)\}", t)
+    if m:
+        sz, al = JL_TYPES[m.group(2)]
+        return int(m.group(1)) * sz, al
+    return JL_TYPES[t]
+
+
+def julia_layout():
+    src = open(JULIA).read()
+    out = {}
+    for m in re.finditer(r"^struct (HH\w+)\n(.*?)^end", src, flags=re.S | re.M):
+        off, fields, maxal = 0, [], 1
+        for decl in re.split(r"[;\n]", m.group(2)):
+            decl = decl.split("#")[0].strip()
+            if not decl:
+                continue
+            name, typ = decl.split("::")
+            size, al = jl_type(typ)
+            off = (off + al - 1) // al * al
+            fields.append((name.strip(), off, size))
+            off += size
+            maxal = max(maxal, al)
+        out[m.group(1)] = {"fields": fields, "size": (off + maxal - 1) // maxal * maxal}
+    return out
+
+
+@pytest.mark.skipif(shutil.which("gcc") is None, reason="needs gcc")
+def test_julia_struct_mirrors_have_the_c_layout(tmp_path):
+    c, jl = measured_layout(tmp_path), julia_layout()
+    for cname, jname in PAIRS.items():
+        assert jname in jl, f"julia/HedgehogMC.jl has no struct {jname}"
+        assert jl[jname]["size"] == c[cname]["size"], (cname, jl[jname]["size"], c[cname]["size"])
+        assert jl[jname]["fields"] == c[cname]["fields"], (cname, jl[jname]["fields"], c[cname]["fields"])
+
+
+@pytest.mark.skipif(shutil.which("gcc") is None, reason="needs gcc")
+def test_ctypes_mirrors_have_the_c_layout(tmp_path):
+    from hedgehog_jl_amd import _ffi
+    c = measured_layout(tmp_path)
+    for cname in PAIRS:
+        cls = getattr(_ffi, cname)
+        assert C.sizeof(cls) == c[cname]["size"]
+        got = [(n, getattr(cls, n).offset, getattr(cls, n).size) for n, _ in cls._fields_]
+        assert got == c[cname]["fields"], cname
+
+
+def test_every_ccall_of_the_julia_layer_is_a_declared_entry_point():
+    hdr = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    declared = set(re.findall(r"\b(hh_\w+)\s*\(", hdr))
+    called = set(re.findall(r"ccall\(\(:(hh_\w+),", open(JULIA).read()))
+    assert called and called <= declared, called - declared
+    # what VERDICT r1 #5 asks the Julia layer to bind
+    assert {"hh_mc_solve", "hh_mc_accumulate", "hh_mc_finalize", "hh_carr_madan", "hh_mc_solve_basket",
+            "hh_lsm_solve", "hh_heston_exact_grid", "hh_abi_version"} <= called
+    src = open(JULIA).read()
+    for needle in ("function solve_batch_greeks_hip", "BatchGreekProblem{P,L}, ::ForwardAD, pricing_method::MonteCarlo",
+                   "function solve_sharded_hip", "replay_layout", "HH_NOISE_REPLAY"):
+        assert needle in src, needle
+    abi = re.search(r"#define HH_ABI_VERSION (\d+)", open(HEADER).read()).group(1)
+    assert "const HH_ABI_VERSION = " + abi in src

@@ -260,23 +260,51 @@ def test_bk_oracle_like_reference():
 
 
 def test_oracle_reproduces_committed_replay_fixture(oracle):
-    """tests/golden/replay_selftest (made by tests/golden/make_replay_selftest.py): the oracle must
-    reproduce the stored terminal samples and price from the stored increments — guards
-    the oracle, the path-major layout and the exchange format of julia/parity_replay.jl."""
+    """tests/golden/replay_selftest (made by tests/golden/make_replay_selftest.py): the oracles must
+    reproduce every case of the committed manifest from its stored draws — guards the oracles, the
+    REPLAY layouts and the exchange format of julia/parity_replay.jl on the CPU."""
+    from oracle import bk_oracle, lsm_oracle
     base = os.path.join(os.path.dirname(__file__), "golden", "replay_selftest")
-    meta = json.load(open(os.path.join(base, "meta.json")))
-    n, steps = meta["n_paths"], meta["n_steps"]
-    dW = np.fromfile(os.path.join(base, meta["dW"]), dtype="<f8")
-    ST = np.fromfile(os.path.join(base, meta["ST"]), dtype="<f8")
-    m = o.make_model(S0=meta["S0"], V0=meta["V0"], kappa=meta["kappa"], theta=meta["theta"],
-                     sigma=meta["sigma"], rho=meta["rho"], r=meta["r"], T=meta["T"],
-                     strike=meta["strike"], cp=meta["cp"])
-    c = o.make_config(HES, EM, n, steps, em_split=1, noise_mode=1, replay=dW, replay_layout=1)
-    r, t, _ = oracle.mc_solve(m, c)
-    np.testing.assert_allclose(t, ST, rtol=1e-14)  # identical up to the host libm's exp()
-    assert r.price == pytest.approx(meta["price"], rel=1e-14)
-    c0 = o.make_config(HES, EM, n, steps, em_split=0, noise_mode=1, replay=dW, replay_layout=1)
-    assert np.max(np.abs(oracle.mc_solve(m, c0)[1] - ST) / ST) > 1e-6  # the other step form differs
+    man = json.load(open(os.path.join(base, "manifest.json")))
+    kinds = [c["kind"] for c in man["cases"]]
+    assert set(kinds) == {"euler", "exact_lognormal", "bk", "lsm"} and "NOT reference output" in man["generated_by"]
+    f8 = lambda name: np.fromfile(os.path.join(base, name), dtype="<f8")
+    for cs in man["cases"]:
+        if cs["kind"] == "euler":
+            dyn = HES if cs["dynamics"] == "heston" else 0
+            names = list(cs["greeks"])
+            P = len(names)
+            sd = {g: [1.0 if j == k else 0.0 for j in range(P)] for k, g in enumerate(names)}
+            m = o.make_model(**cs["model"], seeds=sd, n_partials=P) if P else o.make_model(**cs["model"])
+            c = o.make_config(dyn, EM, cs["n_paths"], cs["n_steps"], antithetic=int(cs["antithetic"]),
+                              em_split=1, noise_mode=1, replay=f8(cs["dW"]), replay_layout=1, n_partials=P)
+            r, t, _ = oracle.mc_solve(m, c)
+            np.testing.assert_allclose(t, f8(cs["ST"]), rtol=1e-14)  # identical up to the host libm's exp()
+            assert r.price == pytest.approx(cs["price"], rel=1e-14)
+            for k, g in enumerate(names):
+                assert r.dprice[k] == pytest.approx(cs["greeks"][g], rel=1e-13)
+            if dyn == HES and not P and not cs["antithetic"]:  # the other step form differs
+                c0 = o.make_config(HES, EM, cs["n_paths"], cs["n_steps"], em_split=0, noise_mode=1,
+                                   replay=f8(cs["dW"]), replay_layout=1)
+                assert np.max(np.abs(oracle.mc_solve(m, c0)[1] - f8(cs["ST"])) / f8(cs["ST"])) > 1e-6
+        elif cs["kind"] == "exact_lognormal":
+            m = o.make_model(**cs["model"])
+            c = o.make_config(0, 1, cs["n_paths"], noise_mode=1, replay=f8(cs["z"]), compat_sqrt_alpha=1)
+            r, t, _ = oracle.mc_solve(m, c)
+            np.testing.assert_allclose(t, f8(cs["ST"]), rtol=1e-14)
+        elif cs["kind"] == "bk":
+            n = cs["n_paths"]
+            mj = cs["model"]
+            ref = bk_oracle.mc_solve(**mj, discount=math.exp(-mj["r"] * mj["T"]), n_paths=n, seed0=0,
+                                     replay=f8(cs["draws"]).reshape(3, n))
+            np.testing.assert_allclose(ref["terminal"], f8(cs["ST"]), rtol=1e-12)
+        else:
+            n, steps = cs["n_paths"], cs["n_steps"]
+            ref = lsm_oracle.lsm_solve(f8(cs["grid"]).reshape(steps + 1, n), cs["strike"], cs["cp"],
+                                       cs["step_discount"], cs["degree"])
+            np.testing.assert_array_equal(ref["stop_time"],
+                                          np.fromfile(os.path.join(base, cs["tau"]), dtype="<i4"))
+            assert ref["price"] == pytest.approx(cs["price"], rel=1e-13)
 
 
 def test_analytic_checkers_agree_like_the_reference_price_agreement():

@@ -12,6 +12,18 @@ import torch
 
 from hedgehog_jl_amd import _ffi
 
+if len(sys.argv) > 1 and sys.argv[1] == "grid":  # the per-date exact Heston grid instead (2e5 x 12)
+    n_g, st_g = 200_000, 12
+    ctx = _ffi.Context(0)
+    m = _ffi.make_model()
+    c = _ffi.make_config(_ffi.HH_HESTON, _ffi.HH_BROADIE_KAYA, n_g, st_g,
+                         seeds=np.arange(1, n_g + 1, dtype=np.uint64))
+    r = _ffi.hh_result()
+    for _ in range(3):
+        ctx.check(ctx.lib.hh_heston_exact_grid(ctx.handle, C.byref(m), C.byref(c), None, None, 0, C.byref(r)))
+    print(f"exact Heston grid {n_g} x {st_g}: {r.kernel_ms:.3f} ms, {n_g * st_g / r.kernel_ms / 1e3:.3e} transitions/s, "
+          f"cf terms per transition {r.bk_cf_terms / (n_g * st_g):.2f}")
+    sys.exit(0)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 dev = torch.device("cuda", 0)
 ctx = _ffi.Context(0)

@@ -1,10 +1,18 @@
 #!/usr/bin/env python3
 """Per-trajectory parity of the HIP path against draws exported from the REFERENCE itself
-(julia/parity_replay.jl).  Usage, on the MI355X box:  python tools/check_reference_replay.py meta.json
+(julia/parity_replay.jl).  Usage, on the MI355X box:
 
-Feeds the exported increments through HH_NOISE_REPLAY (path-major layout) for both Euler step forms
-and prints max |S_gpu - S_ref| / S_ref and |price_gpu - price_ref| / price_ref; the form that matches
-to ~1e-12 is the integrator's.  This is the check that would turn "parity unpinned" into "pinned"."""
+    python tools/check_reference_replay.py out_dir/manifest.json        # every case
+    python tools/check_reference_replay.py tests/golden/replay_selftest/manifest.json   # the format self-test
+
+Each case feeds the exported draws through HH_NOISE_REPLAY (or the exported spot grid through
+hh_lsm_solve_grid) and prints one line `case <name>: key=value ...`; the exit code is non-zero when a
+case misses its bar.  Bars: terminal samples 1e-10 relative per trajectory (fp64 arithmetic in a
+different order of fused operations), price 1e-10, AD Greeks 1e-8, Broadie–Kaya samples 1e-7 on 98 %
+of the trajectories (the |F(x) - u| <= 1e-4 stopping rule may flip on rounding), LSM stopping times
+identical on 99.8 %.  For the Euler cases both step forms are tried: the one that matches is
+StochasticDiffEq's EM() — this settles `em_split`.  Run on the reference's export this
+is the check that turns "parity unpinned" into "pinned"."""
 import ctypes as C
 import json
 import os
@@ -17,28 +25,125 @@ import hedgehog_jl_amd as hh  # noqa: E402
 from hedgehog_jl_amd import _ffi  # noqa: E402
 
 
-def main():
-    meta = json.load(open(sys.argv[1]))
-    base = os.path.dirname(os.path.abspath(sys.argv[1]))
-    n, steps = meta["n_paths"], meta["n_steps"]
-    dW = np.fromfile(os.path.join(base, meta["dW"]), dtype="<f8")
-    assert dW.size == n * steps * 2, "dW.bin must hold n_paths*n_steps*2 doubles ([path][step][comp])"
-    S_ref = np.fromfile(os.path.join(base, meta["ST"]), dtype="<f8")
-    ctx = hh.get_context(0)
-    m = _ffi.make_model(S0=meta["S0"], V0=meta["V0"], kappa=meta["kappa"], theta=meta["theta"],
-                        sigma=meta["sigma"], rho=meta["rho"], r=meta["r"], T=meta["T"],
-                        strike=meta["strike"], cp=meta["cp"])
+def _f8(base, name):
+    return np.fromfile(os.path.join(base, name), dtype="<f8")
+
+
+def _model(mj, **seeds):
+    keys = dict(S0=100.0, V0=0.04, kappa=2.0, theta=0.04, sigma=0.3, rho=-0.7, r=0.03, T=1.0,
+                strike=100.0, cp=1.0)
+    keys.update({k: v for k, v in mj.items() if k in keys})
+    return _ffi.make_model(**keys, **seeds)
+
+
+def check_euler(ctx, base, cs):
+    n, steps, anti = cs["n_paths"], cs["n_steps"], int(bool(cs.get("antithetic", False)))
+    heston = cs.get("dynamics", "heston") == "heston"
+    dyn = _ffi.HH_HESTON if heston else _ffi.HH_LOGNORMAL
+    dW = _f8(base, cs["dW"])
+    assert dW.size == n * steps * (2 if heston else 1), "dW must hold [path][step][comp] doubles"
+    ST = _f8(base, cs["ST"])
+    assert ST.size == n * (1 + anti)
+    greeks = cs.get("greeks") or {}
+    names = [g for g in ("S0", "V0", "sigma", "r_drift") if g in greeks]
+    P = len(names)
+    seeds = {g: [1.0 if j == k else 0.0 for j in range(P)] for k, g in enumerate(names)}
+    m = _model(cs["model"], seeds=seeds, n_partials=P) if P else _model(cs["model"])
+    out, ok = {}, False
     for split in (1, 0):
-        c = _ffi.make_config(_ffi.HH_HESTON, _ffi.HH_EULER_MARUYAMA, n, steps, em_split=split,
+        c = _ffi.make_config(dyn, _ffi.HH_EULER_MARUYAMA, n, steps, antithetic=anti, em_split=split,
                              noise_mode=_ffi.HH_NOISE_REPLAY, replay=dW,
-                             replay_layout=_ffi.HH_REPLAY_PATH_MAJOR)
+                             replay_layout=_ffi.HH_REPLAY_PATH_MAJOR, n_partials=P)
         res = _ffi.hh_result()
-        term = np.zeros(n)
-        ctx.check(ctx.lib.hh_mc_solve(ctx.handle, C.byref(m), C.byref(c), C.byref(res),
-                                      term.ctypes.data))
-        print(f"em_split={split}: max rel |S_gpu-S_ref| = {np.max(np.abs(term - S_ref) / S_ref):.3e}, "
-              f"price rel err = {abs(res.price - meta['price']) / abs(meta['price']):.3e}")
+        term = np.zeros(n * (1 + anti))
+        ctx.check(ctx.lib.hh_mc_solve(ctx.handle, C.byref(m), C.byref(c), C.byref(res), term.ctypes.data))
+        e_s = float(np.max(np.abs(term - ST) / ST))
+        e_p = abs(res.price - cs["price"]) / abs(cs["price"])
+        e_g = max([abs(res.dprice[k] - greeks[g]) / abs(greeks[g]) for k, g in enumerate(names)] or [0.0])
+        out[f"em_split={split}"] = f"max_rel_S={e_s:.3e},price={e_p:.3e}" + (f",greeks={e_g:.3e}" if P else "")
+        ok = ok or (e_s < 1e-10 and e_p < 1e-10 and e_g < 1e-8)
+        if heston is False:
+            break  # the diffusion is constant: both forms coincide
+    return ok, out
+
+
+def check_exact(ctx, base, cs):
+    n = cs["n_paths"]
+    z, ST = _f8(base, cs["z"]), _f8(base, cs["ST"])
+    m = _model(cs["model"])
+    c = _ffi.make_config(_ffi.HH_LOGNORMAL, _ffi.HH_EXACT_LAW, n, noise_mode=_ffi.HH_NOISE_REPLAY,
+                         replay=z, compat_sqrt_alpha=int(bool(cs.get("compat_sqrt_alpha", True))))
+    res = _ffi.hh_result()
+    term = np.zeros(n)
+    ctx.check(ctx.lib.hh_mc_solve(ctx.handle, C.byref(m), C.byref(c), C.byref(res), term.ctypes.data))
+    e_s = float(np.max(np.abs(term - ST) / ST))
+    e_p = abs(res.price - cs["price"]) / abs(cs["price"])
+    # z was recovered from the reference's samples by (x - mean)/std: one rounding each way
+    return e_s < 1e-12 and e_p < 1e-12, {"max_rel_S": f"{e_s:.3e}", "price": f"{e_p:.3e}"}
+
+
+def check_bk(ctx, base, cs):
+    n = cs["n_paths"]
+    draws, ST = _f8(base, cs["draws"]), _f8(base, cs["ST"])
+    assert draws.size == 3 * n, "draws must hold [V_T | u | Z]"
+    m = _model(cs["model"])
+    c = _ffi.make_config(_ffi.HH_HESTON, _ffi.HH_BROADIE_KAYA, n, noise_mode=_ffi.HH_NOISE_REPLAY,
+                         replay=draws)
+    res = _ffi.hh_result()
+    term = np.zeros(n)
+    ctx.check(ctx.lib.hh_mc_solve(ctx.handle, C.byref(m), C.byref(c), C.byref(res), term.ctypes.data))
+    rel = np.abs(term - ST) / ST
+    frac = float(np.mean(rel > 1e-7))
+    e_p = abs(res.price - cs["price"]) / abs(cs["price"])
+    return frac <= 0.02 and e_p < 1e-4, {"frac_beyond_1e-7": f"{frac:.4f}", "median_rel_S": f"{np.median(rel):.3e}",
+                                         "price": f"{e_p:.3e}", "newton_fail": int(res.bk_newton_fail)}
+
+
+def check_lsm(ctx, base, cs):
+    n, steps = cs["n_paths"], cs["n_steps"]
+    grid = _f8(base, cs["grid"])
+    assert grid.size == (steps + 1) * n, "grid must hold [n_steps+1][n_paths]"
+    tau_ref = np.fromfile(os.path.join(base, cs["tau"]), dtype="<i4")
+    val_ref = _f8(base, cs["val"])
+    dev = C.c_void_p()
+    ctx.check(ctx.lib.hh_device_malloc(ctx.handle, grid.nbytes, C.byref(dev)))
+    try:
+        ctx.check(ctx.lib.hh_memcpy_h2d(ctx.handle, dev, grid.ctypes.data, grid.nbytes))
+        m = _ffi.make_model(strike=cs["strike"], cp=cs["cp"])
+        res = _ffi.hh_lsm_result()
+        tau, val = np.zeros(n, dtype=np.int32), np.zeros(n)
+        ctx.check(ctx.lib.hh_lsm_solve_grid(ctx.handle, C.byref(m), dev, n, steps, cs["degree"],
+                                            cs["step_discount"], C.byref(res), tau.ctypes.data,
+                                            val.ctypes.data))
+    finally:
+        ctx.lib.hh_device_free(ctx.handle, dev)
+    same = tau == tau_ref
+    e_v = float(np.max(np.abs(val[same] - val_ref[same]) / np.maximum(np.abs(val_ref[same]), 1e-300))) \
+        if same.any() else 0.0
+    e_p = abs(res.price - cs["price"]) / abs(cs["price"])
+    ok = same.mean() >= 0.998 and e_v < 1e-12 and e_p < (1e-10 if same.all() else 5e-4)
+    return ok, {"same_stopping_time": f"{same.mean():.5f}", "max_rel_val": f"{e_v:.3e}", "price": f"{e_p:.3e}"}
+
+
+CHECKS = {"euler": check_euler, "exact_lognormal": check_exact, "bk": check_bk, "lsm": check_lsm}
+
+
+def main(path):
+    man = json.load(open(path))
+    base = os.path.dirname(os.path.abspath(path))
+    if "cases" not in man:  # round-1 single-case file: Heston Euler, no variance reduction
+        man = {"cases": [dict(man, name="heston_euler", kind="euler", dynamics="heston",
+                              model={k: man[k] for k in ("S0", "strike", "r", "V0", "kappa", "theta",
+                                                         "sigma", "rho", "T", "cp")})]}
+    ctx = hh.get_context(0)
+    bad = 0
+    for cs in man["cases"]:
+        ok, info = CHECKS[cs["kind"]](ctx, base, cs)
+        bad += not ok
+        print(f"case {cs['name']} [{cs['kind']}] {'OK' if ok else 'MISMATCH'}: " +
+              " ".join(f"{k}={v}" for k, v in info.items()), flush=True)
+    return bad
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(1 if main(sys.argv[1]) else 0)
