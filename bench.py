@@ -343,14 +343,15 @@ def main():
         """W untimed warm-up steps, then EXACTLY k steps between barrier + synchronize on both
         sides; MAX over ranks.  -> (seconds, per-launch kernel ms, accumulator, ramp ms spent)"""
         ramp = 0.0
-        if ramp_ms > 0.0:  # bring the device to its steady clock on the same kernel (disclosed)
+        if ramp_ms > 0.0:
+            # bring the device to its steady clock on the same kernel (disclosed as clock_ramp_ms).
+            # Kernel launches only, NO collective: every rank loops on its own clock, so the ranks
+            # run different numbers of iterations
             t0 = time.perf_counter()
-            i = 0
             while (time.perf_counter() - t0) * 1e3 < ramp_ms:
                 for _ in range(8):
-                    step(mdl, cfg, i)
-                    i += 1
-                drain()
+                    ctx.check(lib.hh_mc_accumulate(h, C.byref(mdl), C.byref(cfg),
+                                                   accums[0].data_ptr(), None))
                 torch.cuda.synchronize(dev)
             ramp = (time.perf_counter() - t0) * 1e3
         last = 0
