@@ -146,6 +146,21 @@ def launch(args) -> int:
     return rc
 
 
+class _StdoutToStderr:
+    """RCCL prints a version banner on the process's stdout when its first communicator comes up;
+    rank 0's stdout is reserved for the ONE JSON line, so fd 1 points at stderr until then."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
+
 class Dist:
     """The process group of this run (or none), with the two collectives the bench needs."""
 
@@ -161,6 +176,7 @@ class Dist:
         devs = _device_list(args)
         self.device_index = devs[self.local_rank] if self.local_rank < len(devs) else self.local_rank
         if "RANK" in os.environ:  # launched by us or by torch.distributed.run (also with 1 rank)
+            sys.stdout.flush()
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29500")
@@ -291,7 +307,9 @@ def main():
     lib, h = ctx.lib, ctx.handle
     stream = torch.cuda.current_stream(dev)
     ctx.set_stream(stream.cuda_stream)
-    rccl_ranks = d.count_ranks(dev)
+    with _StdoutToStderr():  # the first collective brings RCCL's communicator (and its banner) up
+        rccl_ranks = d.count_ranks(dev)
+        torch.cuda.synchronize(dev)
     if rccl_ranks != world:
         sys.exit(f"bench.py: all-reduce of ones gave {rccl_ranks}, expected {world}")
 
