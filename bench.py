@@ -184,8 +184,9 @@ class Dist:
             if args.backend == "nccl" and not args.rehearse:
                 torch.cuda.set_device(self.device_index)
                 kw["device_id"] = torch.device("cuda", self.device_index)
-            dist.init_process_group("gloo" if args.rehearse else args.backend, rank=self.rank,
-                                    world_size=self.world, **kw)
+            with _StdoutToStderr():  # device_id= brings the communicator up here already
+                dist.init_process_group("gloo" if args.rehearse else args.backend, rank=self.rank,
+                                        world_size=self.world, **kw)
             self.pg = dist
 
     @property

@@ -58,6 +58,7 @@ def test_lsm_matches_oracle(hhlib, anti, cp, K, degree, n, steps):
     (140_000, 12, 1, 4, -1.0),     # 280 000 trajectories: 35 chunks of eight per lane
     (262_144, 5, 0, 1, 1.0),       # exactly the last size with one trajectory per lane (256 chunks)
     (300_000, 25, 0, 5, -1.0),     # 37 chunks, the last one ragged
+    (1_048_576, 4, 1, 2, -1.0),    # 2^21 trajectories: 256 chunks, one workgroup on EVERY CU of the chip
 ])
 def test_one_launch_and_launch_per_date_agree_bit_for_bit(hhlib, n, steps, anti, degree, cp):
     """The persistent form (one launch, stopping state in registers, an in-kernel all-gather per
