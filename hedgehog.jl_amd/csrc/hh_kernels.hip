@@ -244,11 +244,14 @@ struct VecOf<2> {
 #ifndef HH_REPLAY_PPT
 #define HH_REPLAY_PPT 1  // trajectories per lane of the price-only REPLAY kernel: 256-thread workgroups
 #endif
+// one trajectory per lane (256-thread workgroups, 8-byte loads) for the antithetic and dual-partial
+// kernels too: 0.608 against 0.627 ms (antithetic) and 0.597 against 0.611 ms (one carried
+// derivative) with two per lane (round 2 A/B, profiles/r02_b_replay_shape_ab.txt)
 #ifndef HH_REPLAY_PPT_ANTI
-#define HH_REPLAY_PPT_ANTI 2
+#define HH_REPLAY_PPT_ANTI 1
 #endif
 #ifndef HH_REPLAY_PPT_DUAL
-#define HH_REPLAY_PPT_DUAL 2
+#define HH_REPLAY_PPT_DUAL 1
 #endif
 #ifndef HH_REPLAY_CHUNK_PPT1
 #define HH_REPLAY_CHUNK_PPT1 4
@@ -266,7 +269,8 @@ struct VecOf<2> {
 #define HH_REPLAY_MAXW 2       // price-only: 2 waves per SIMD = 2 workgroups of 256 threads = 8 waves per CU
 #endif
 #ifndef HH_REPLAY_MAXW_DUAL
-#define HH_REPLAY_MAXW_DUAL 2  // dual-partial kernels: 2 waves per SIMD too (one carried derivative: 0.609 ms against 0.623 at 3 and 0.663 uncapped)
+#define HH_REPLAY_MAXW_DUAL 3  // dual-partial kernels (one trajectory per lane): 3 waves per SIMD, 0.597 ms with one carried
+                               // derivative against 0.646 at 2; with two trajectories per lane it was 0.609 at 2, 0.623 at 3, 0.663 uncapped
 #endif
 #ifndef HH_REPLAY_MAXW_ANTI
 #define HH_REPLAY_MAXW_ANTI 8  // antithetic: indifferent (0.629 vs 0.625 ms), left at the register limit

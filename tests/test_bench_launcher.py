@@ -102,3 +102,33 @@ def test_one_rank_line_keeps_the_contract(hhlib):
     rf = out["roofline"]
     assert rf["bound"] == "hbm" and rf["frac"] == pytest.approx(rf["achieved"] / rf["peak"])
     assert rf["launches_timed"] == 5
+
+
+def _n_gpus():
+    import torch
+    return torch.cuda.device_count()
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(_n_gpus() < 2, reason="needs two GPUs: RCCL refuses two ranks on one device")
+@pytest.mark.timeout(900)
+def test_two_ranks_over_rccl_price_what_one_process_prices(hhlib):
+    """The real thing (runs wherever the box has >= 2 GPUs; the single-GPU test box skips it): two
+    ranks, one GPU each, the 16-double all-reduce over RCCL — weak and strong scaling lines."""
+    from hedgehog_jl_amd import _ffi
+    n = 100_000
+    p, out = run_bench("--gpus", "2", "--paths", str(n), "--steps", "3", "--warmup", "1",
+                       "--ramp-ms", "0", "--no-cpu-baseline")
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["config"]["backend"] == "rccl"
+    m = _ffi.make_model()
+    c = _ffi.make_config(_ffi.HH_HESTON, _ffi.HH_EULER_MARUYAMA, 2 * n, 252,
+                         seeds=np.arange(1, 2 * n + 1, dtype=np.uint64))
+    r = _ffi.hh_result()
+    hhlib.check(hhlib.lib.hh_mc_solve(hhlib.handle, C.byref(m), C.byref(c), C.byref(r), None))
+    assert out["price"] == pytest.approx(r.price, rel=1e-12)
+    assert out["strong_scaling"]["paths_this_rank"] == 5_000_000
+    p, out = run_bench("--gpus", "2", "--global-paths", str(2 * n), "--steps", "3", "--warmup", "1",
+                       "--ramp-ms", "0", "--no-cpu-baseline", "--no-extra")
+    assert p.returncode == 0 and out["scaling"] == "strong" and out["config"]["paths_per_gpu"] == n
+    assert out["price"] == pytest.approx(r.price, rel=1e-12)
