@@ -38,6 +38,7 @@ struct SimArgs {
   uint64_t path_offset;
   uint32_t n_steps;
   uint32_t n_tiles;
+  uint32_t tail_from;     // REPLAY: tiles from here on pipeline deeper (the grid's tail)
   const uint64_t* seeds;  // device
   const double* replay;   // device, tile-major
   double* terminal;       // device or nullptr

@@ -12,6 +12,8 @@
 // register pipeline; GENERATE draws them in registers from Philox keyed by the trajectory seed.
 // Every workgroup leaves one record of partial sums; a second tiny kernel adds the records in a
 // fixed order, so results are bit-reproducible for a given (n_paths, sharding).
+#include <type_traits>
+
 #include "hh_kernels.h"
 #include "hh_rng.h"
 
@@ -275,6 +277,12 @@ struct VecOf<2> {
 #ifndef HH_REPLAY_MAXW_ANTI
 #define HH_REPLAY_MAXW_ANTI 8  // antithetic: indifferent (0.629 vs 0.625 ms), left at the register limit
 #endif
+#ifndef HH_REPLAY_CHUNK_TAIL
+#define HH_REPLAY_CHUNK_TAIL 4   // steps per chunk of the price-only kernel's last HH_REPLAY_TAIL_TILES workgroups
+#endif
+#ifndef HH_REPLAY_TAIL_TILES
+#define HH_REPLAY_TAIL_TILES 512
+#endif
 #ifndef HH_REPLAY_PAD_KIB
 #define HH_REPLAY_PAD_KIB 0
 #endif
@@ -468,17 +476,53 @@ __attribute__((amdgpu_waves_per_eu(REPLAY ? HH_REPLAY_MINW : 1,
       __shared__ double occupancy_pad[kPadKib > 0 ? kPadKib * 128 : 1];
       if (a.n_steps == 0xFFFFFFFFu) occupancy_pad[tid] = 0.0;
     }
-    uint32_t s = 0;
-    load(A, 0);
-    while (s < n_steps) {
-      load(B, s + kChunk);
-      compute(A, s);
-      s += kChunk;
-      if (s >= n_steps) break;
-      load(A, s + kChunk);
-      compute(B, s);
-      s += kChunk;
-    }
+    // The last workgroups of a grid run while the chip empties: fewer streams are open, so each has
+    // to keep more bytes in flight to hold the bandwidth up — they pipeline HH_REPLAY_CHUNK_TAIL steps
+    // per chunk instead of kChunk (registers are there: the occupancy cap leaves a wave 256).
+    auto pipeline = [&](auto depth) {
+      constexpr int CH = decltype(depth)::value;
+      Vec X[CH][NC], Y[CH][NC];
+      auto ld = [&](Vec(&buf)[CH][NC], uint32_t s0) {
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+          if (s0 + u < n_steps) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+              buf[u][c] = stream_load<Vec>(base + ((size_t)(s0 + u) * NC + c) * kTile);
+          }
+        }
+      };
+      auto go = [&](const Vec(&buf)[CH][NC], uint32_t s0) {
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+          if (s0 + u < n_steps) {
+#pragma unroll
+            for (int j = 0; j < PPT; ++j) {
+              const double d1 = VecOf<PPT>::get(buf[u][0], j);
+              const double d2 = NC > 1 ? VecOf<PPT>::get(buf[u][NC - 1], j) : 0.0;
+              M::step(st[j], a, d1, d2);
+              if constexpr (ANTI) M::step(sa[j], a, -d1, -d2);  // montecarlo.jl:258: -W
+            }
+          }
+        }
+      };
+      uint32_t s = 0;
+      ld(X, 0);
+      while (s < n_steps) {
+        ld(Y, s + CH);
+        go(X, s);
+        s += CH;
+        if (s >= n_steps) break;
+        ld(X, s + CH);
+        go(Y, s);
+        s += CH;
+      }
+    };
+    constexpr int kTail = (P == 0 && !ANTI && PPT == 1) ? HH_REPLAY_CHUNK_TAIL : kChunk;
+    if (kTail != kChunk && tile >= a.tail_from)
+      pipeline(std::integral_constant<int, kTail>{});
+    else
+      pipeline(std::integral_constant<int, kChunk>{});
     }
   } else {
     uint64_t key[PPT];
@@ -801,6 +845,7 @@ static SimArgs<P> make_args(const hh_model& m, const hh_config& c, const DeviceP
   a.path_offset = c.path_offset;
   a.n_steps = c.n_steps;
   a.n_tiles = tiles_for(c.n_paths);
+  a.tail_from = a.n_tiles > (uint32_t)HH_REPLAY_TAIL_TILES ? a.n_tiles - (uint32_t)HH_REPLAY_TAIL_TILES : 0u;
   a.seeds = p.seeds;
   a.replay = p.replay;
   a.terminal = p.terminal;
