@@ -639,38 +639,37 @@ static int lsm_on_grid(hh_ctx* ctx, const double* grid_dev, uint64_t ntot, uint3
   const size_t nscr = hh::lsm_scratch_doubles(ntot, n_steps, degree);
   if ((rc = ensure(ctx, ctx->lsm_scratch, ctx->lsm_scratch_cap, nscr))) return rc;
   if ((rc = ensure(ctx, ctx->records, ctx->records_cap, (size_t)ch * hh::kRecStride))) return rc;
+  // enqueue the induction, the final reduction and every copy back, then synchronise ONCE; the
+  // one-launch form leaves a word behind when its workgroups could not all be resident together
+  // (another kernel held CUs): nothing was written then, and the launch-per-date form runs instead
   int form_used = hh::kLsmFormPerDate;
-  HH_HIP(ctx, hh::launch_lsm(grid_dev, ntot, n_steps, m->strike, m->cp, step_discount, degree,
-                             ctx->lsm_tau, ctx->lsm_val, ctx->lsm_scratch, ctx->records,
-                             ctx->stream, ctx->lsm_form, &form_used));
-  if (form_used == hh::kLsmFormPersistent) {
-    // the one-launch form leaves a word behind when its workgroups could not all be resident
-    // together (another kernel held CUs): nothing was written then, and the per-date form runs
-    unsigned int gave_up = 0;
-    HH_HIP(ctx, hipMemcpyAsync(&gave_up, hh::lsm_persistent_status(ctx->lsm_scratch),
-                               sizeof(gave_up), hipMemcpyDeviceToHost, ctx->stream));
-    HH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (gave_up) {
-      ++ctx->lsm_persistent_fallbacks;
-      HH_HIP(ctx, hh::launch_lsm(grid_dev, ntot, n_steps, m->strike, m->cp, step_discount, degree,
-                                 ctx->lsm_tau, ctx->lsm_val, ctx->lsm_scratch, ctx->records,
-                                 ctx->stream, hh::kLsmFormPerDate, &form_used));
-    }
-  }
-  HH_HIP(ctx, hh::launch_reduce_records(ctx->records, ch, (double)ntot, ctx->accum, ctx->stream));
-  HH_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
   double counters[2] = {0, 0};
-  HH_HIP(ctx, hipMemcpyAsync(ctx->accum_host, ctx->accum, HH_ACC_LEN * sizeof(double),
-                             hipMemcpyDeviceToHost, ctx->stream));
-  HH_HIP(ctx, hipMemcpyAsync(counters, ctx->lsm_scratch + nscr - 2 - hh::kLsmStampSlotsApi, 2 * sizeof(double),
-                             hipMemcpyDeviceToHost, ctx->stream));
-  if (stop_time)
-    HH_HIP(ctx, hipMemcpyAsync(stop_time, ctx->lsm_tau, ntot * sizeof(int32_t),
+  unsigned int gave_up = 0;
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    const int form = attempt == 0 ? ctx->lsm_form : hh::kLsmFormPerDate;
+    HH_HIP(ctx, hh::launch_lsm(grid_dev, ntot, n_steps, m->strike, m->cp, step_discount, degree,
+                               ctx->lsm_tau, ctx->lsm_val, ctx->lsm_scratch, ctx->records,
+                               ctx->stream, form, &form_used));
+    HH_HIP(ctx, hh::launch_reduce_records(ctx->records, ch, (double)ntot, ctx->accum, ctx->stream));
+    HH_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    gave_up = 0;
+    if (form_used == hh::kLsmFormPersistent)
+      HH_HIP(ctx, hipMemcpyAsync(&gave_up, hh::lsm_persistent_status(ctx->lsm_scratch),
+                                 sizeof(gave_up), hipMemcpyDeviceToHost, ctx->stream));
+    HH_HIP(ctx, hipMemcpyAsync(ctx->accum_host, ctx->accum, HH_ACC_LEN * sizeof(double),
                                hipMemcpyDeviceToHost, ctx->stream));
-  if (stop_value)
-    HH_HIP(ctx, hipMemcpyAsync(stop_value, ctx->lsm_val, ntot * sizeof(double),
-                               hipMemcpyDeviceToHost, ctx->stream));
-  HH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    HH_HIP(ctx, hipMemcpyAsync(counters, ctx->lsm_scratch + nscr - 2 - hh::kLsmStampSlotsApi,
+                               2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (stop_time)
+      HH_HIP(ctx, hipMemcpyAsync(stop_time, ctx->lsm_tau, ntot * sizeof(int32_t),
+                                 hipMemcpyDeviceToHost, ctx->stream));
+    if (stop_value)
+      HH_HIP(ctx, hipMemcpyAsync(stop_value, ctx->lsm_val, ntot * sizeof(double),
+                                 hipMemcpyDeviceToHost, ctx->stream));
+    HH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (!gave_up) break;
+    ++ctx->lsm_persistent_fallbacks;
+  }
   const double n = (double)ntot, mean = ctx->accum_host[HH_ACC_SUM] / n;
   double var = n > 1.0 ? (ctx->accum_host[HH_ACC_SUMSQ] - n * mean * mean) / (n - 1.0) : 0.0;
   if (!(var > 0.0)) var = 0.0;
