@@ -412,7 +412,7 @@ def main():
     cfg_rep, cfg_gen = sh.config(_ffi.HH_NOISE_REPLAY), sh.config(_ffi.HH_NOISE_GENERATE)
 
     dt_rep, kern_rep, acc_rep, ramp_ms = timed(model, cfg_rep, args.steps, args.warmup, args.ramp_ms)
-    dt_gen, kern_gen, acc_gen, _ = timed(model, cfg_gen, args.steps, args.warmup)
+    dt_gen, kern_gen, acc_gen, _ = timed(model, cfg_gen, args.steps, args.warmup, args.ramp_ms)
     res, res_gen = finalize(model, cfg_rep, acc_rep), finalize(model, cfg_gen, acc_gen)
     total_path_steps = float(n_global) * n_steps
     value = total_path_steps * args.steps / dt_rep
@@ -478,7 +478,7 @@ def main():
         m5 = _ffi.make_model(**H252, seeds=sd, n_partials=3)
         c5 = sh.config(_ffi.HH_NOISE_REPLAY, n_partials=3)
         k5 = min(args.steps, 50)
-        dt5, kern5, acc5, _ = timed(m5, c5, k5, min(args.warmup, 5))
+        dt5, kern5, acc5, _ = timed(m5, c5, k5, min(args.warmup, 5), args.ramp_ms)
         r5 = finalize(m5, c5, acc5)
         t5 = float(np.mean(kern5))
         out["config5_greeks"] = {
@@ -500,7 +500,7 @@ def main():
             sh = Shard(a, b - a)
             cs = sh.config(_ffi.HH_NOISE_REPLAY)
             ks = min(args.steps, 40 if world == 1 else 100)
-            dts, kerns, accs, _ = timed(model, cs, ks, min(args.warmup, 5))
+            dts, kerns, accs, _ = timed(model, cs, ks, min(args.warmup, 5), args.ramp_ms)
             rs = finalize(model, cs, accs)
             out["strong_scaling"] = {
                 "global_paths": G, "paths_this_rank": sh.n, "scaling": "strong", "steps": ks,
@@ -522,8 +522,15 @@ def main():
 
     accum = accums[0]
     if world == 1 and not args.no_extra:
-        def kernel_ms(mdl, cfg, reps=5):
-            ctx.check(lib.hh_mc_accumulate(h, C.byref(mdl), C.byref(cfg), accum.data_ptr(), None))
+        def kernel_ms(mdl, cfg, reps=10, warm_ms=15.0):
+            # each kernel is timed at ITS steady clock: the chip's clock follows the load of the last
+            # milliseconds, and a VALU-heavy kernel measured right behind a memory-bound one (or the
+            # reverse) reads 10-25 % off for its first ~10 ms
+            t0 = time.perf_counter()
+            while (time.perf_counter() - t0) * 1e3 < warm_ms:
+                for _ in range(4):
+                    ctx.check(lib.hh_mc_accumulate(h, C.byref(mdl), C.byref(cfg), accum.data_ptr(), None))
+                torch.cuda.synchronize(dev)
             ctx.enable_timing(True)
             for _ in range(reps):
                 ctx.check(lib.hh_mc_accumulate(h, C.byref(mdl), C.byref(cfg), accum.data_ptr(), None))
@@ -533,7 +540,7 @@ def main():
 
         c4 = _ffi.make_config(_ffi.HH_HESTON, _ffi.HH_BROADIE_KAYA, n_paths)
         c4.seeds, c4.seeds_on_device = sh.seeds.data_ptr(), 1
-        t4, r4 = kernel_ms(model, c4, reps=3)
+        t4, r4 = kernel_ms(model, c4, reps=5)
         m2 = _ffi.make_model(S0=100.0, sigma=0.2, r=0.05, T=1.0, strike=100.0)
         c2 = _ffi.make_config(_ffi.HH_LOGNORMAL, _ffi.HH_EXACT_LAW, n_paths)
         c2.seeds, c2.seeds_on_device = sh.seeds.data_ptr(), 1
