@@ -503,7 +503,7 @@ struct LsmStepArgs {
   const double* grid;
   uint64_t ntot;
   double strike, cp, ln_disc;  // ln of the per-step discount factor
-  uint32_t n_steps, n_chunks;  // n_chunks: canonical chunks (1024·Q trajectories each)
+  uint32_t n_steps, n_chunks;  // n_chunks: canonical chunks (512·Q trajectories each: 1024 or 8192)
   int32_t* tau;
   double* val;
   const RowStat* rs;
