@@ -198,8 +198,11 @@ function solve_batch_greeks_hip(gprob::Hedgehog.BatchGreekProblem, mc::MonteCarl
     DT = ForwardDiff.Dual{HipBatchTag,Float64,L}
     p = prob
     for (k, lens) in enumerate(lenses)
-        x0 = Float64(lens(prob))
-        p = Hedgehog.set(p, lens, DT(x0, ForwardDiff.Partials(ntuple(j -> j == k ? 1.0 : 0.0, L))))
+        x = lens(p)                                 # already a Dual when two lenses read the same input
+        e = ForwardDiff.Partials(ntuple(j -> j == k ? 1.0 : 0.0, L))
+        xd = x isa ForwardDiff.Dual ? DT(ForwardDiff.value(x), ForwardDiff.partials(x) + e) :
+                                      DT(Float64(x), e)
+        p = Hedgehog.set(p, lens, xd)
     end
     price = solve_hip(p, mc; ensemble = false).price           # a Dual carrying all L partials
     parts = ForwardDiff.partials(price)
