@@ -35,7 +35,7 @@
 //    between launches.
 //  Measured, 2·10^6 trajectories x 100 dates, degree 5 (profiles/r02_lsm_*): 2.05 ms in one launch
 //  (13.9 µs per date: all-gather 3.5, workgroup totals + publish 3.2, moment sums 2.6, power sums
-//  1.3, row issue 1.2, solve 1.2, decisions 0.8) against 3.75 ms with a launch per date and 4.3 ms
+//  1.3, row issue 1.2, solve 1.2, decisions 0.8) against 3.1 ms with a launch per date and 4.3 ms
 //  for round 1's launch-per-date form.
 //
 // Summation tree (independent of the form and of the GPU): chunk = 512 lanes x Q trajectories
@@ -572,6 +572,19 @@ __global__ __launch_bounds__(kLsmWg) void lsm_step_kernel(const LsmStepArgs a, u
   const RowStat rn = a.rs[t >= 2 ? t - 1 : t];
   const double* S = a.grid + (size_t)t * a.ntot;
   const double* Sn = a.grid + (size_t)(t >= 2 ? t - 1 : t) * a.ntot;  // row of the next step
+  // this chunk's trajectories first (clamped addresses: the loads issue back to back): they are in
+  // flight while the moment sums are reduced and the normal equations solved
+  int tau[Q];
+  double val[Q], xs[Q], xn[Q];
+#pragma unroll
+  for (int j = 0; j < Q; ++j) {
+    const uint64_t p = (uint64_t)blockIdx.x * (kLsmWg * Q) + (uint64_t)j * kLsmWg + threadIdx.x;
+    const uint64_t pc = p < a.ntot ? p : a.ntot - 1;
+    tau[j] = a.tau[pc];
+    val[j] = a.val[pc];
+    xs[j] = S[pc];
+    xn[j] = Sn[pc];
+  }
   if (a.B_given) {  // summed over the ranks by the host between two launches
     if (threadIdx.x < N) tot[threadIdx.x] = a.B_given[threadIdx.x];
   } else {
@@ -590,17 +603,15 @@ __global__ __launch_bounds__(kLsmWg) void lsm_step_kernel(const LsmStepArgs a, u
   for (int j = 0; j < Q; ++j) {
     const uint64_t p = (uint64_t)blockIdx.x * (kLsmWg * Q) + (uint64_t)j * kLsmWg + threadIdx.x;
     const bool lv = p < a.ntot;
-    int tau = lv ? a.tau[p] : (int)t;
-    double val = lv ? a.val[p] : 0.0;
     double pay;
-    if (fit && exercise_now<D>(lv ? S[p] : 0.0, a.cp, a.strike, lv, r, coef, pay)) {
-      tau = (int)t;
-      val = pay;
-      a.tau[p] = tau;
+    if (fit && exercise_now<D>(xs[j], a.cp, a.strike, lv, r, coef, pay)) {
+      tau[j] = (int)t;
+      val[j] = pay;
+      a.tau[p] = (int)t;
       a.val[p] = pay;
     }
     if (t >= 2)
-      add_moments<D>(lv ? Sn[p] : 0.0, a.cp, a.strike, lv, rn, a.disc_pow[tau - (int)(t - 1)] * val, v);
+      add_moments<D>(xn[j], a.cp, a.strike, lv, rn, a.disc_pow[tau[j] - (int)(t - 1)] * val[j], v);
   }
   __syncthreads();  // tot (the sums of row t) was read by fit_row's wave
   if (t >= 2) store_moments<D>(a, t - 1, v, scratch, tot);

@@ -160,9 +160,9 @@ const char* hh_last_error(const hh_ctx* ctx); /* NUL-terminated, owned by ctx (o
  *                           workgroups cannot all be resident;
  *   HH_LSM_FORM_PER_DATE    one launch per exercise date;
  *   HH_LSM_FORM_AUTO        (default) the persistent form above 2^18 trajectories — where not
- *                           re-loading the state pays (2·10^6 x 100 dates: 2.05 vs 3.75 ms) — and a
+ *                           re-loading the state pays (2·10^6 x 100 dates: 2.0 vs 3.1 ms) — and a
  *                           launch per date below, where a kernel boundary is the cheaper
- *                           synchronisation (10^5 x 100: 0.72 vs 0.81 ms).
+ *                           synchronisation (10^5 x 100: 0.66 vs 0.79 ms).
  * All forms give bit-identical prices and stopping decisions. */
 enum hh_option { HH_OPT_LSM_FORM = 1 };
 enum hh_lsm_form { HH_LSM_FORM_PER_DATE = 0, HH_LSM_FORM_PERSISTENT = 1, HH_LSM_FORM_AUTO = 2 };
