@@ -56,7 +56,10 @@ struct DevicePtrs {
 };
 
 // several payoffs on ONE set of terminal samples (basket.jl:35-38, same-expiry payoffs)
-constexpr int kBasketChunk = 4096;  // trajectories per workgroup of basket_payoff_kernel
+#ifndef HH_BASKET_CHUNK
+#define HH_BASKET_CHUNK 4096
+#endif
+constexpr int kBasketChunk = HH_BASKET_CHUNK;  // trajectories per workgroup of basket_payoff_kernel
 struct BasketArgs {
   const double* terminal;    // [n_paths] (+ [n_paths] mirrored)
   const double* terminal_d;  // [P][n_total] or nullptr

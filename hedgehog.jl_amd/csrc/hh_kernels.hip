@@ -936,51 +936,102 @@ int launch_reduce_records(const double* records, uint32_t n_records, double n_pa
 // trajectories, so one simulation + this kernel is result-equivalent.
 // ------------------------------------------------------------------------------------------
 
+// Block -> (chunk, payoff).  Every payoff re-reads the same terminal samples; workgroups are dealt
+// round-robin over the 8 XCDs by their linear index (MI355X_MICROARCH.md, dispatch), so the chunks
+// are spread such that chunk c is ALWAYS handled on XCD c mod 8, whatever the payoff: each XCD's
+// private L2 then holds one eighth of the samples (1 MB of 8 at 10^6 trajectories) for all payoffs,
+// instead of every L2 streaming all of them.  Placement is for speed only: results do not depend on it.
+#ifndef HH_BASKET_XCD
+#define HH_BASKET_XCD 1
+#endif
+#ifndef HH_BASKET_KB
+#define HH_BASKET_KB 4
+#endif
+constexpr int kBasketKB = HH_BASKET_KB;  // payoffs a workgroup evaluates on each sample it loads
+
+// One workgroup = one chunk of samples x kBasketKB payoffs: a sample (and its tangents) is loaded once
+// and every payoff of the group is evaluated on it from registers, so the re-read of the samples
+// shrinks by kBasketKB and the kernel is bound by its fp64 selects and adds.  Each payoff keeps its own
+// accumulators, lane order and record, so its sums are those of a one-payoff launch bit for bit.
 template <int P>
-__global__ __launch_bounds__(256) void basket_payoff_kernel(const BasketArgs b) {
-  const uint32_t chunk = blockIdx.x, k = blockIdx.y;
-  const double strike = b.strikes[k], cp = b.cps[k];
-  const uint64_t n_total = b.antithetic ? 2 * b.n_paths : b.n_paths;
-  double acc[4 + P];
+__global__ __launch_bounds__(256) void basket_payoff_kernel(const BasketArgs b, const uint32_t n_payoffs) {
+#if HH_BASKET_XCD
+  const uint32_t per_xcd = (b.n_chunks + 7u) / 8u;           // chunks an XCD owns
+  const uint32_t xcd = blockIdx.x & 7u, idx = blockIdx.x >> 3;
+  const uint32_t grp = idx / per_xcd, chunk = (idx % per_xcd) * 8u + xcd;
+  if (chunk >= b.n_chunks) return;                           // padding of the last group of eight
+#else
+  const uint32_t chunk = blockIdx.x, grp = blockIdx.y;
+#endif
+  const uint32_t k0 = grp * kBasketKB;
+  double strike[kBasketKB], cp[kBasketKB];
 #pragma unroll
-  for (int i = 0; i < 4 + P; ++i) acc[i] = 0.0;
+  for (int g = 0; g < kBasketKB; ++g) {                      // a short last group repeats its last payoff
+    const uint32_t k = min(k0 + g, n_payoffs - 1);
+    strike[g] = b.strikes[k];
+    cp[g] = b.cps[k];
+  }
+  const uint64_t n_total = b.antithetic ? 2 * b.n_paths : b.n_paths;
+  double acc[kBasketKB][4 + P];
+#pragma unroll
+  for (int g = 0; g < kBasketKB; ++g)
+#pragma unroll
+    for (int i = 0; i < 4 + P; ++i) acc[g][i] = 0.0;
   const uint64_t i0 = (uint64_t)chunk * kBasketChunk;
   for (uint32_t j = threadIdx.x; j < (uint32_t)kBasketChunk; j += 256) {
     const uint64_t i = i0 + j;
     if (i >= b.n_paths) break;
     const double S = b.terminal[i];
-    const double m = cp * (S - strike);
-    const bool itm = m > 0.0;
-    double p = itm ? m : 0.0;
-    double wS = itm ? cp * S : 0.0, wN = itm ? cp : 0.0;
-    double pd[P > 0 ? P : 1];
+    double Sa = 0.0, d[P > 0 ? P : 1], da[P > 0 ? P : 1];
     if constexpr (P > 0) {  // terminal_d holds dS_T = S·∂x of the ACTIVE directions
 #pragma unroll
-      for (int q = 0; q < P; ++q) pd[q] = itm ? cp * b.terminal_d[(uint64_t)q * n_total + i] : 0.0;
+      for (int q = 0; q < P; ++q) d[q] = b.terminal_d[(uint64_t)q * n_total + i];
     }
     if (b.antithetic) {
-      const double Sa = b.terminal[b.n_paths + i];
-      const double ma = cp * (Sa - strike);
-      const bool itma = ma > 0.0;
-      p = (p + (itma ? ma : 0.0)) / 2;
-      wS = (wS + (itma ? cp * Sa : 0.0)) / 2;
-      wN = (wN + (itma ? cp : 0.0)) / 2;
+      Sa = b.terminal[b.n_paths + i];
       if constexpr (P > 0) {
 #pragma unroll
-        for (int q = 0; q < P; ++q)
-          pd[q] = (pd[q] + (itma ? cp * b.terminal_d[(uint64_t)q * n_total + b.n_paths + i] : 0.0)) / 2;
+        for (int q = 0; q < P; ++q) da[q] = b.terminal_d[(uint64_t)q * n_total + b.n_paths + i];
       }
     }
-    acc[0] += p;
-    acc[1] = fma(p, p, acc[1]);
-    if constexpr (P > 0) {
 #pragma unroll
-      for (int q = 0; q < P; ++q) acc[2 + q] += pd[q];
+    for (int g = 0; g < kBasketKB; ++g) {
+      const double m = cp[g] * (S - strike[g]);
+      const bool itm = m > 0.0;
+      double p = itm ? m : 0.0;
+      double wS = itm ? cp[g] * S : 0.0, wN = itm ? cp[g] : 0.0;
+      double pd[P > 0 ? P : 1];
+      if constexpr (P > 0) {
+#pragma unroll
+        for (int q = 0; q < P; ++q) pd[q] = itm ? cp[g] * d[q] : 0.0;
+      }
+      if (b.antithetic) {
+        const double ma = cp[g] * (Sa - strike[g]);
+        const bool itma = ma > 0.0;
+        p = (p + (itma ? ma : 0.0)) / 2;
+        wS = (wS + (itma ? cp[g] * Sa : 0.0)) / 2;
+        wN = (wN + (itma ? cp[g] : 0.0)) / 2;
+        if constexpr (P > 0) {
+#pragma unroll
+          for (int q = 0; q < P; ++q) pd[q] = (pd[q] + (itma ? cp[g] * da[q] : 0.0)) / 2;
+        }
+      }
+      acc[g][0] += p;
+      acc[g][1] = fma(p, p, acc[g][1]);
+      if constexpr (P > 0) {
+#pragma unroll
+        for (int q = 0; q < P; ++q) acc[g][2 + q] += pd[q];
+      }
+      acc[g][2 + P] += wS;
+      acc[g][3 + P] += wN;
     }
-    acc[2 + P] += wS;
-    acc[3 + P] += wN;
   }
-  block_reduce_store<4 + P, 4, 2>(acc, b.records + ((size_t)k * b.n_chunks + chunk) * kRecStride);
+#pragma unroll
+  for (int g = 0; g < kBasketKB; ++g) {
+    if (k0 + g >= n_payoffs) break;                          // uniform over the workgroup
+    if (g) __syncthreads();                                  // the reduction's LDS staging is reused
+    block_reduce_store<4 + P, 4, 2>(acc[g], b.records + ((size_t)(k0 + g) * b.n_chunks + chunk) * kRecStride);
+  }
 }
 
 // a basket on Broadie–Kaya samples: the simulation's own counters (fall-backs, series terms) belong
@@ -1001,13 +1052,20 @@ int launch_copy_bk_counters(const double* src, double* accum, uint32_t n_groups,
 
 int launch_basket_payoffs(const BasketArgs& b, uint32_t n_payoffs, uint32_t n_active_partials,
                           hipStream_t s) {
-  const dim3 grid(b.n_chunks, n_payoffs), block(256);
+  const uint32_t n_groups = (n_payoffs + kBasketKB - 1) / kBasketKB;
+  // a 1-D grid: 2^31 workgroups is 3.5·10^13 payoff evaluations; beyond that the caller splits the basket
+  if ((uint64_t)((b.n_chunks + 7u) / 8u) * 8u * n_groups > 0x7fffffffull) return (int)hipErrorInvalidConfiguration;
+#if HH_BASKET_XCD
+  const dim3 grid(((b.n_chunks + 7u) / 8u) * 8u * n_groups), block(256);
+#else
+  const dim3 grid(b.n_chunks, n_groups), block(256);
+#endif
   switch (pad_partials(n_active_partials)) {
-    case 0: hipLaunchKernelGGL(basket_payoff_kernel<0>, grid, block, 0, s, b); break;
-    case 1: hipLaunchKernelGGL(basket_payoff_kernel<1>, grid, block, 0, s, b); break;
-    case 2: hipLaunchKernelGGL(basket_payoff_kernel<2>, grid, block, 0, s, b); break;
-    case 3: hipLaunchKernelGGL(basket_payoff_kernel<3>, grid, block, 0, s, b); break;
-    default: hipLaunchKernelGGL(basket_payoff_kernel<4>, grid, block, 0, s, b); break;
+    case 0: hipLaunchKernelGGL(basket_payoff_kernel<0>, grid, block, 0, s, b, n_payoffs); break;
+    case 1: hipLaunchKernelGGL(basket_payoff_kernel<1>, grid, block, 0, s, b, n_payoffs); break;
+    case 2: hipLaunchKernelGGL(basket_payoff_kernel<2>, grid, block, 0, s, b, n_payoffs); break;
+    case 3: hipLaunchKernelGGL(basket_payoff_kernel<3>, grid, block, 0, s, b, n_payoffs); break;
+    default: hipLaunchKernelGGL(basket_payoff_kernel<4>, grid, block, 0, s, b, n_payoffs); break;
   }
   return (int)hipGetLastError();
 }
