@@ -736,7 +736,6 @@ static int run_heston_grid(hh_ctx* ctx, const hh_model* m, const hh_config* c) {
                 "exact Heston grid: S0, T, V0 > 0, |rho| <= 1, sigma != 0, kappa != 0");
   const uint64_t n = c->n_paths;
   const size_t grid_elems = (size_t)(c->n_steps + 1) * n;
-  const uint32_t n_tiles = hh::tiles_for(n);
   int rc;
   if ((rc = ensure(ctx, ctx->lsm_grid, ctx->lsm_grid_cap, grid_elems))) return rc;
   if ((rc = ensure(ctx, ctx->heston_var, ctx->heston_var_cap, grid_elems))) return rc;

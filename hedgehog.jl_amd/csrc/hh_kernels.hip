@@ -346,7 +346,7 @@ __attribute__((amdgpu_waves_per_eu(REPLAY ? HH_REPLAY_MINW : 1,
         a.replay + (size_t)tile * n_steps * NC * kTile + (size_t)tid * PPT;
     // steps per chunk: the price-only kernel (one trajectory per lane) moves 4 steps at a time
     constexpr int kChunk = (P == 0 && !ANTI && RING == 0) ? HH_REPLAY_CHUNK_PRICE : (PPT == 1 ? HH_REPLAY_CHUNK_PPT1 : HH_REPLAY_CHUNK);
-    Vec A[kChunk][NC], B[kChunk][NC];
+    [[maybe_unused]] Vec A[kChunk][NC], B[kChunk][NC];
 
     auto load = [&](Vec(&buf)[kChunk][NC], uint32_t s0) {
 #pragma unroll

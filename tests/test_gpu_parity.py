@@ -75,14 +75,12 @@ def test_replay_ragged_above_the_small_grid_threshold(hhlib, oracle, dyn, n_step
     check(rg, tg, ro, to, 0, 1e-12, 1e-12)
 
 
-@pytest.mark.parametrize("dyn", [GBM, HES])
+# the step form only matters where the diffusion depends on the state: (GBM, classic) is not a case
+@pytest.mark.parametrize("dyn,split", [(GBM, 1), (HES, 1), (HES, 0)])
 @pytest.mark.parametrize("anti", [0, 1])
 @pytest.mark.parametrize("noise", [GEN, REP])
 @pytest.mark.parametrize("P", [0, 1, 3, 5])
-@pytest.mark.parametrize("split", [1, 0])
 def test_euler_matrix(hhlib, oracle, dyn, anti, noise, P, split):
-    if dyn == GBM and split == 0:
-        pytest.skip("split is irrelevant for constant diffusion")
     n_paths, n_steps = 3000, 50
     seeds = seeds_for(n_paths, 7)
     names = ["S0", "sigma", "r_drift", "strike", "V0"] if dyn == GBM else \
