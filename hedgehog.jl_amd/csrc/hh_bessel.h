@@ -1,0 +1,266 @@
+// Modified Bessel function I_ν(z), real order ν > -1, complex argument — the special function of the
+// Broadie–Kaya characteristic function (heston.jl:184-212 calls besseli through SpecialFunctions.jl,
+// i.e. AMOS, which is not reproducible here: restated from the published expansions, DLMF §10).
+//
+//   I_ν(z) = exp(lg) · mul    the part that can be huge or tiny stays a logarithm, the O(1) sum stays a
+//                             factor: the CF exponentiates log I anyway, so log(sum) would be wasted
+//
+//   |z| <  13              ascending series (10.25.2) at order ν
+//   |z| >= 13, 2ν² + 10    Hankel expansion (10.40.5) at order ν
+//   in between (ν >= 1)    Hankel expansion at the base order ν0 = ν - floor(ν), then the ratios
+//                          I_{ν0+k+1}/I_{ν0+k} from the backward recurrence (minimal solution)
+//
+// Both sums are evaluated by Horner's rule with the number of terms fixed BEFORE the loop from |z|
+// (tables made on the host from ν), instead of term by term with a convergence test: 6 VALU
+// instructions per series term and 4 per Hankel term, against ≈ 25 and ≈ 16 — the CF kernel spends
+// most of its time here.  Each sum is split into its even and odd half: two independent Horner
+// chains for the same instruction count (a lone chain leaves the fp64 pipe waiting on itself).  The
+// loop runs to the longest count among the lanes of the wave, so its counter is uniform and the
+// coefficients come from the scalar cache, two steps per load, fetched one iteration ahead.
+//
+// Compiles for the host too (tests/c/bessel_check.cpp checks it against mpmath references).
+#pragma once
+#include "hh_math.h"
+
+namespace hh {
+
+struct cx {
+  double re, im;
+};
+HH_MATH_FN cx operator+(cx a, cx b) { return {a.re + b.re, a.im + b.im}; }
+HH_MATH_FN cx operator*(cx a, cx b) { return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
+HH_MATH_FN cx operator*(double s, cx a) { return {s * a.re, s * a.im}; }
+HH_MATH_FN cx cdiv(cx a, cx b) {
+  const double inv = fm::rcp(fma(b.re, b.re, b.im * b.im));
+  return {(a.re * b.re + a.im * b.im) * inv, (a.im * b.re - a.re * b.im) * inv};
+}
+// |a| without hypot's range scaling (31 instructions): the moduli taken here (γ, ν_γ, ϕ, series
+// sums) are far from the overflow / underflow thresholds of a² + b²
+HH_MATH_FN double cabs(cx a) { return sqrt(fma(a.re, a.re, a.im * a.im)); }
+// sin, cos: the range-specialised pair of hh_math.h; beyond |x| = 2^20 (which no parameter set of
+// the tests reaches) its three-term reduction, good to 2^45
+HH_MATH_FN void sincos_cf(double x, double& s, double& c) {
+  if (fabs(x) <= 0x1p20) {
+    fm::sincos(x, s, c);
+  } else {
+    fm::sincos_wide(x, s, c);
+  }
+}
+HH_MATH_FN cx cexp(cx z) {
+  const double e = fm::exp(z.re);
+  double s, c;
+  sincos_cf(z.im, s, c);
+  return {e * c, e * s};
+}
+HH_MATH_FN cx clog(cx z) { return {fm::log(cabs(z)), fm::atan2(z.im, z.re)}; }
+
+constexpr int kHankelTerms = 32;   // a_0 … a_31
+constexpr int kHankelPairs = 16;   // Horner steps over (a_2m, a_2m+1)
+constexpr int kSeriesTerms = 32;   // most terms of the ascending series (29 are reached at |z| = 13)
+constexpr double kSeriesR = 13.0;  // |z| below which the ascending series is used
+constexpr double kBesselPi = 3.14159265358979323846;
+constexpr double kBesselTwoPi = 6.28318530717958647692;
+
+// Everything that depends on the order alone (host-made, bessel_table()).
+struct BesselTable {
+  double nu, lgam;                   // order, lgamma(ν + 1)
+  double hankel[kHankelTerms];       // a_k(ν)  (DLMF 10.17.1)
+  double hankel_rmin[kHankelPairs];  // [M]: |z| from which the sum cut after k = 2M+1 has converged
+  // ascending series split by parity, c_k = 1 / (k (k + ν)):  [2m] = c_{2m-1} c_{2m} (even half),
+  // [2m+1] = c_{2m} c_{2m+1} (odd half), m >= 1
+  double series_de[kSeriesTerms + 4];
+  double series_c1;                  // c_1
+};
+
+// terms of the ascending series needed at |z| = r: the first omitted term (r²/4)^k / (k! (ν+1)_k),
+// k = N+1, is below 2^-58 of the largest term for N = 11.6 + 1.4 r, for every ν > -1 and r < 13
+// (bessel_table() checks the bound for its ν when it builds the table; tests/test_bessel_host.py
+// sweeps ν)
+#if defined(__HIPCC__)
+__host__ __device__ __forceinline__
+#else
+static inline
+#endif
+int series_terms(double r) {
+  const int n = (int)(11.6 + 1.4 * r);
+  return n < kSeriesTerms ? n : kSeriesTerms;
+}
+
+// host: fills the table for one order; returns false when the term-count bound above does not hold
+static inline bool bessel_table(double nu, BesselTable& t) {
+  t.nu = nu;
+  t.lgam = lgamma(nu + 1.0);
+  const double mu = 4.0 * nu * nu;
+  long double a[kHankelTerms + 2];
+  a[0] = 1.0L;
+  for (int k = 1; k < kHankelTerms + 2; ++k) {
+    const long double o = 2.0L * k - 1.0L;
+    a[k] = a[k - 1] * ((long double)mu - o * o) / (8.0L * k);
+  }
+  for (int k = 0; k < kHankelTerms; ++k) t.hankel[k] = (double)a[k];
+  for (int M = 0; M < kHankelPairs; ++M) {
+    // first omitted term |a_{2M+2}| / r^{2M+2} < 2^-55
+    const int k = 2 * M + 2;
+    const long double mag = fabsl(a[k]);
+    t.hankel_rmin[M] = mag == 0.0L ? 0.0 : (double)powl(mag * 0x1p55L, 1.0L / k);
+  }
+  auto c = [nu](int k) { return 1.0L / ((long double)k * ((long double)k + (long double)nu)); };
+  t.series_de[0] = t.series_de[1] = 0.0;
+  for (int m = 1; 2 * m + 1 < kSeriesTerms + 4; ++m) {
+    t.series_de[2 * m] = (double)(c(2 * m - 1) * c(2 * m));
+    t.series_de[2 * m + 1] = (double)(c(2 * m) * c(2 * m + 1));
+  }
+  t.series_c1 = (double)c(1);
+  bool ok = true;
+  for (int i = 1; i <= (int)(kSeriesR * 16.0); ++i) {  // first omitted term against the bound
+    const long double r = i / 16.0L, q = 0.25L * r * r;
+    const int N = series_terms((double)r);
+    long double term = 1.0L, largest = 1.0L;
+    for (int k = 1; k <= N + 1; ++k) {
+      term *= q / ((long double)k * (k + (long double)nu));
+      if (k <= N && term > largest) largest = term;
+    }
+    if (term > 0x1p-57L * largest) ok = false;
+  }
+  return ok;
+}
+
+// the largest n (0 … 63) among the active lanes of the wave
+HH_MATH_FN int wave_max6(int n) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  int r = 0;
+#pragma unroll
+  for (int b = 5; b >= 0; --b) {
+    const int c = r | (1 << b);
+    if (__ballot(n >= c) != 0ull) r = c;
+  }
+  return r;
+#else
+  return n;
+#endif
+}
+
+struct LogMul {
+  cx lg, mul;
+};
+
+// One Horner step of two independent complex chains with real coefficients: X = X·u + cx, Y = Y·u + cy
+HH_MATH_FN void horner2(cx& X, cx& Y, cx u, double cx_, double cy_) {
+  X = {fma(X.re, u.re, fma(-X.im, u.im, cx_)), fma(X.re, u.im, X.im * u.re)};
+  Y = {fma(Y.re, u.re, fma(-Y.im, u.im, cy_)), fma(Y.re, u.im, Y.im * u.re)};
+}
+
+// I_ν(z) by the ascending series (DLMF 10.25.2), Re z >= 0, |z| = r < kSeriesR, arg z = phi:
+//   I = (z/2)^ν / Γ(ν+1) · Σ_k T_k,  T_k = q^k / (k! (ν+1)_k) = T_{k-1} c_k q,  q = z²/4.
+// Even and odd terms apart, Q = q²:  Σ T_2m = 1 + d_1 Q (1 + d_2 Q (1 + …)),  d_m = c_{2m-1} c_{2m};
+//                                    Σ T_2m+1 = c_1 q (1 + e_1 Q (1 + e_2 Q (1 + …))),  e_m = c_{2m} c_{2m+1}
+HH_MATH_FN LogMul besseli_series(const BesselTable& t, cx z, double r, double phi) {
+  const cx q = 0.25 * (z * z);
+  const cx Q = q * q;
+  const int Mh = (series_terms(r) + 1) >> 1;  // steps of each half
+  cx A = {1.0, 0.0}, B = {1.0, 0.0};
+  int m = (wave_max6(Mh) + 1) & ~1;            // even: steps (m, m-1) down to (2, 1)
+  const double* tab = t.series_de;
+  double d0 = tab[2 * m], e0 = tab[2 * m + 1], d1 = tab[2 * m - 2], e1 = tab[2 * m - 1];
+  while (true) {
+    const double dm = d0, em = e0, dn = d1, en = e1;
+    const int mn = m - 2;
+    if (mn >= 2) {  // the next two steps' coefficients, one iteration ahead of their use
+      d0 = tab[2 * mn]; e0 = tab[2 * mn + 1]; d1 = tab[2 * mn - 2]; e1 = tab[2 * mn - 1];
+    }
+    if (m <= Mh) {  // X = 1 + c Q X
+      const cx qa = Q * A, qb = Q * B;
+      A = {fma(dm, qa.re, 1.0), dm * qa.im};
+      B = {fma(em, qb.re, 1.0), em * qb.im};
+    }
+    if (m - 1 <= Mh) {
+      const cx qa = Q * A, qb = Q * B;
+      A = {fma(dn, qa.re, 1.0), dn * qa.im};
+      B = {fma(en, qb.re, 1.0), en * qb.im};
+    }
+    if (mn < 2) break;
+    m = mn;
+  }
+  const cx S = A + t.series_c1 * (q * B);
+  return {{t.nu * fm::log(0.5 * r) - t.lgam, t.nu * phi}, S};
+}
+
+// I_ν(z) by the Hankel expansion (DLMF 10.40.5), Re z >= 0, |z| = r >= kSeriesR:
+//   I = e^z/sqrt(2πz) [S1 + e^{-2z ± iπ(ν+1/2)} S2],  S2 = Σ a_k w^k,  S1 = Σ (-1)^k a_k w^k,  w = 1/z,
+// upper sign for Im z >= 0.  With E = Σ a_2m u^m, O = Σ a_2m+1 u^m, u = w²: S2 = E + wO, S1 = E - wO.
+// The sums are cut after k = 2M+1 where the next term is below 2^-55 — or, for r < 15.5 where the
+// expansion does not get that far, at its smallest term k ≈ 2r.
+HH_MATH_FN LogMul besseli_asym(const BesselTable& t, cx z, double r, double phi) {
+  const cx w = cdiv({1.0, 0.0}, z);
+  const cx u = w * w;
+  int M = (int)(r - 0.5);
+  M = M < kHankelPairs - 1 ? M : kHankelPairs - 1;
+  for (int m = kHankelPairs - 2; m >= 3; --m) M = r >= t.hankel_rmin[m] ? m : M;  // (unrolled: constant bounds)
+  cx E = {0.0, 0.0}, O = {0.0, 0.0};
+  int m = wave_max6(M) | 1;  // odd: steps (m, m-1) down to (1, 0)
+  const double* tab = t.hankel;
+  double a0 = tab[2 * m], a1 = tab[2 * m + 1], b0 = tab[2 * m - 2], b1 = tab[2 * m - 1];
+  while (true) {
+    const double ae = a0, ao = a1, be = b0, bo = b1;
+    const int mn = m - 2;
+    if (mn >= 1) {  // the next two steps' coefficients, one iteration ahead of their use
+      a0 = tab[2 * mn]; a1 = tab[2 * mn + 1]; b0 = tab[2 * mn - 2]; b1 = tab[2 * mn - 1];
+    }
+    if (m <= M) horner2(E, O, u, ae, ao);
+    if (m - 1 <= M) horner2(E, O, u, be, bo);
+    if (mn < 1) break;
+    m = mn;
+  }
+  const cx wO = w * O;
+  cx m1 = {E.re - wO.re, E.im - wO.im};
+  if (z.re < 18.5) {  // else e^{-2 Re z} < 1e-16: the second sum is below rounding
+    const double ph = (z.im >= 0.0 ? kBesselPi : -kBesselPi) * (t.nu + 0.5);
+    const cx e2 = cexp({-2.0 * z.re, -2.0 * z.im + ph});
+    m1 = m1 + e2 * cx{E.re + wO.re, E.im + wO.im};
+  }
+  return {{z.re - 0.5 * fm::log(kBesselTwoPi * r), z.im - 0.5 * phi}, m1};
+}
+
+// I_ν(z) = exp(lg)·mul for real ν > -1 and complex z != 0 with arg z = phi given by the caller
+// (principal branch; Im lg is defined modulo 2π — callers exponentiate).  t = table of ν,
+// t0 = table of ν0 = ν - n_int (the same table when n_int = 0).
+HH_MATH_FN LogMul besseli_logmul(const BesselTable& t, const BesselTable& t0, int n_int, cx z, double phi) {
+  double refl = 0.0;
+  if (z.re < 0.0) {  // I_ν(w e^{±iπ}) = e^{±iπν} I_ν(w)  (DLMF 10.34.1)
+    const double pi_s = z.im >= 0.0 ? kBesselPi : -kBesselPi;
+    refl = pi_s * t.nu;
+    phi -= pi_s;
+    z = {-z.re, -z.im};
+  }
+  const double r = cabs(z);
+  LogMul res;
+  if (r < kSeriesR) {
+    res = besseli_series(t, z, r, phi);
+  } else if (n_int == 0 || r >= 2.0 * t.nu * t.nu + 10.0) {
+    res = besseli_asym(t, z, r, phi);
+  } else {
+    // base order ν0, then I_ν = I_ν0 · Π_{k<n} I_{ν0+k+1}/I_{ν0+k}; the ratios come from the backward
+    // recurrence r_k = 1 / (2(ν0+k+1)/z + r_{k+1}), the minimal solution for Re z >= 0
+    res = besseli_asym(t0, z, r, phi);
+    const cx w = cdiv({2.0, 0.0}, z);
+    const int n = n_int;
+    int N = n + (int)r + 30;
+    if (N > 4000) N = 4000;
+    cx rk = {0.0, 0.0};
+    for (int k = N - 1; k >= 0; --k) {
+      const double o = t0.nu + (double)k + 1.0;
+      rk = cdiv({1.0, 0.0}, {o * w.re + rk.re, o * w.im + rk.im});
+      if (k < n) {
+        if (n <= 16) {  // |r_k| < 1: a short product cannot leave the fp64 range
+          res.mul = res.mul * rk;
+        } else {
+          res.lg = res.lg + clog(rk);
+        }
+      }
+    }
+  }
+  res.lg.im += refl;
+  return res;
+}
+
+}  // namespace hh

@@ -22,6 +22,7 @@
 // loop lengths are data dependent, so lanes of a wave diverge — see DESIGN.md for the measured cost.
 #include <cmath>
 
+#include "hh_bessel.h"
 #include "hh_kernels.h"
 #include "hh_math.h"
 #include "hh_rng.h"
@@ -30,10 +31,8 @@ namespace hh {
 
 namespace {
 
-constexpr int kCoef = 32;
-constexpr double kPi = 3.14159265358979323846;
-constexpr double kTwoPi = 6.28318530717958647692;
-constexpr double kSeriesR = 13.0;  // |z| below which the power series is used for the base order
+constexpr double kPi = kBesselPi;
+constexpr double kTwoPi = kBesselTwoPi;
 
 constexpr int kPackedGrid = 256;  // workgroups of the packed (grid-stride) ladder kernel
 constexpr int kHeavyGrid = 64;    // … of the fall-back kernel (empty with the reference's controls)
@@ -45,10 +44,9 @@ struct BkArgs {
   double d, lam_num, lam_den, cscale;
   // HestonCFIterator constants (heston.jl:167-172)
   double nu, zeta_k, eta_k, nuk_factor;  // ν_κ = nuk_factor·sqrt(V0·VT)
-  // Bessel helpers (host-precomputed: they depend on ν only)
-  double nu0, lgam_nu0p1;
+  // Bessel tables (host-made: they depend on ν only) of ν and of the base order ν0 = ν - n_int
   int n_int;
-  double coef_nu[kCoef], coef_nu0[kCoef];  // Hankel coefficients a_k(ν), a_k(ν0)
+  BesselTable bes_nu, bes_nu0;
   // controls (sample_from_cf.jl:27,50,75,105-113)
   double n_sigma, cf_tol, atol, moment_h;
   int newton_maxiter, bisect_maxiter;
@@ -76,28 +74,9 @@ struct BkArgs {
   int cache_cap;
 };
 
-struct cx {
-  double re, im;
-};
-__device__ __forceinline__ cx operator+(cx a, cx b) { return {a.re + b.re, a.im + b.im}; }
-__device__ __forceinline__ cx operator*(cx a, cx b) {
-  return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re};
-}
-__device__ __forceinline__ cx operator*(double s, cx a) { return {s * a.re, s * a.im}; }
 // 1/x to <= 1 ulp: hardware reciprocal + two Newton steps (5 instructions; the IEEE division
 // sequence is 12).  The quantities divided here are moderate in size: no scaling needed.
-__device__ __forceinline__ double rcp_nr(double x) {
-  double r = __builtin_amdgcn_rcp(x);
-  r = fma(fma(-x, r, 1.0), r, r);
-  return fma(fma(-x, r, 1.0), r, r);
-}
-__device__ __forceinline__ cx cdiv(cx a, cx b) {
-  const double inv = rcp_nr(fma(b.re, b.re, b.im * b.im));
-  return {(a.re * b.re + a.im * b.im) * inv, (a.im * b.re - a.re * b.im) * inv};
-}
-// |a| without hypot's range scaling (31 instructions): the moduli taken here (γ, ν_γ, ϕ, series
-// sums) are far from the overflow / underflow thresholds of a² + b²
-__device__ __forceinline__ double cabs(cx a) { return sqrt(fma(a.re, a.re, a.im * a.im)); }
+__device__ __forceinline__ double rcp_nr(double x) { return fm::rcp(x); }
 __device__ __forceinline__ cx csqrt(cx z) {
   const double r = cabs(z);
   if (r == 0.0) return {0.0, 0.0};
@@ -107,108 +86,6 @@ __device__ __forceinline__ cx csqrt(cx z) {
   }
   const double t = sqrt(0.5 * (r - z.re));
   return {fabs(z.im) * rcp_nr(2.0 * t), copysign(t, z.im)};
-}
-// sin, cos: the range-specialised pair of hh_math.h; beyond |x| = 2^20 (which no parameter set of
-// the tests reaches) its three-term reduction, good to 2^45
-__device__ __forceinline__ void sincos_cf(double x, double& s, double& c) {
-  if (fabs(x) <= 0x1p20) {
-    fm::sincos(x, s, c);
-  } else {
-    fm::sincos_wide(x, s, c);
-  }
-}
-__device__ __forceinline__ cx cexp(cx z) {
-  const double e = fm::exp(z.re);
-  double s, c;
-  sincos_cf(z.im, s, c);
-  return {e * c, e * s};
-}
-__device__ __forceinline__ cx clog(cx z) { return {fm::log(cabs(z)), fm::atan2(z.im, z.re)}; }
-
-// I_ν(z) = exp(lg) · mul: the part that can be huge or tiny stays a logarithm, the O(1) series sum
-// stays a factor — the CF needs exp(log I) only, so log(sum) followed by exp would be wasted work
-struct LogMul {
-  cx lg, mul;
-};
-
-// I_ν(z) by the ascending series (DLMF 10.25.2), order ν0 in (-1, 1), Re z >= 0, |z| = r < kSeriesR,
-// arg z = phi:  I = (z/2)^ν0 / Γ(ν0+1) · Σ (z²/4)^k / (k! (ν0+1)_k)
-__device__ LogMul besseli_series(double nu0, double lgam, cx z, double r, double phi) {
-  const cx q = 0.25 * (z * z);
-  cx t = {1.0, 0.0}, S = {1.0, 0.0};
-  for (int k = 1; k < 200; ++k) {
-    t = rcp_nr((double)k * ((double)k + nu0)) * (t * q);
-    S = S + t;
-    if (fabs(t.re) + fabs(t.im) < 1e-17 * (fabs(S.re) + fabs(S.im))) break;
-  }
-  return {{nu0 * fm::log(0.5 * r) - lgam, nu0 * phi}, S};
-}
-
-// I_ν(z) by the Hankel expansion (DLMF 10.40.5), Re z >= 0, |z| = r large; coef[k] = a_k(ν)
-__device__ LogMul besseli_asym(double nu, const double* coef, cx z, double r, double phi) {
-  const cx w = cdiv({1.0, 0.0}, z);
-  cx p = {1.0, 0.0}, S1 = {1.0, 0.0}, S2 = {1.0, 0.0};
-  double last = 1e300, sgn = -1.0;
-  for (int k = 1; k < kCoef; ++k) {
-    p = p * w;
-    const cx t = coef[k] * p;
-    const double mag = fabs(t.re) + fabs(t.im);
-    if (mag > last) break;  // the expansion has started to diverge
-    S1 = S1 + sgn * t;
-    S2 = S2 + t;
-    sgn = -sgn;
-    last = mag;
-    if (mag < 1e-17) break;
-  }
-  // I = e^z/sqrt(2πz) [S1 + e^{-2z ± iπ(ν+1/2)} S2], upper sign for Im z >= 0
-  const double ph = (z.im >= 0.0 ? kPi : -kPi) * (nu + 0.5);
-  cx m = S1;
-  if (z.re < 18.5) {  // e^{-2 Re z} < 1e-16: the second sum is below rounding
-    const cx e2 = cexp({-2.0 * z.re, -2.0 * z.im + ph});
-    m = m + e2 * S2;
-  }
-  return {{z.re - 0.5 * fm::log(kTwoPi * r), z.im - 0.5 * phi}, m};
-}
-
-// I_ν(z) = exp(lg)·mul for real ν > -1 and complex z != 0 with arg z = phi given by the caller
-// (principal branch; Im lg is defined modulo 2π — callers exponentiate)
-__device__ LogMul besseli_logmul(const BkArgs& a, cx z, double phi) {
-  double refl = 0.0;
-  if (z.re < 0.0) {  // I_ν(w e^{±iπ}) = e^{±iπν} I_ν(w)  (DLMF 10.34.1)
-    const double pi_s = z.im >= 0.0 ? kPi : -kPi;
-    refl = pi_s * a.nu;
-    phi -= pi_s;
-    z = {-z.re, -z.im};
-  }
-  const double r = cabs(z);
-  LogMul res;
-  if (a.n_int == 0 || (r >= kSeriesR && r >= 2.0 * a.nu * a.nu + 10.0)) {
-    res = (r < kSeriesR) ? besseli_series(a.nu0, a.lgam_nu0p1, z, r, phi)
-                         : besseli_asym(a.nu, a.coef_nu, z, r, phi);
-  } else {
-    // base order ν0 = ν - n, then I_ν = I_ν0 · Π_{k<n} I_{ν0+k+1}/I_{ν0+k}; the ratios come from
-    // the backward recurrence r_k = 1 / (2(ν0+k+1)/z + r_{k+1}), the minimal solution for Re z >= 0
-    res = (r < kSeriesR) ? besseli_series(a.nu0, a.lgam_nu0p1, z, r, phi)
-                         : besseli_asym(a.nu0, a.coef_nu0, z, r, phi);
-    const cx w = cdiv({2.0, 0.0}, z);
-    const int n = a.n_int;
-    int N = n + (int)r + 30;
-    if (N > 4000) N = 4000;
-    cx rk = {0.0, 0.0};
-    for (int k = N - 1; k >= 0; --k) {
-      const double o = a.nu0 + (double)k + 1.0;
-      rk = cdiv({1.0, 0.0}, {o * w.re + rk.re, o * w.im + rk.im});
-      if (k < n) {
-        if (n <= 16) {  // |r_k| < 1: a short product cannot leave the fp64 range
-          res.mul = res.mul * rk;
-        } else {
-          res.lg = res.lg + clog(rk);
-        }
-      }
-    }
-  }
-  res.lg.im += refl;
-  return res;
 }
 
 // per-trajectory CF state: HestonCFIterator (heston.jl:150-157)
@@ -239,7 +116,7 @@ __device__ cx evaluate_chf(const BkArgs& p, const CfIter& it, double a, double& 
     thu = theta_prev + dl;
   }
   theta_prev = thu;
-  LogMul I = besseli_logmul(p, nu_g, th);  // principal branch at |ν_γ| cis(θ_unwrapped)
+  LogMul I = besseli_logmul(p.bes_nu, p.bes_nu0, p.n_int, nu_g, th);  // principal branch at |ν_γ| cis(θ_unwrapped)
   I.lg.im += p.nu * (thu - th);            // + i ν (θ_unwrapped − θ)  (heston.jl:207)
   // ϕ = e^{-(γ-κ)T/2} (ζκ/ζγ) · exp((V0+VT)/σ² (ηκ-ηγ)) · Iγ / Iκ
   const cx ex = {-0.5 * (g.re - p.kappa) * p.T + it.sumV * (p.eta_k - eta_g.re) + I.lg.re - it.logI_k,
@@ -430,7 +307,7 @@ __device__ __forceinline__ void cf_setup(const BkArgs& p, double V0, double VT, 
   cf.VT = VT;
   cf.sqrtV0VT = sqrt(V0 * VT);
   cf.sumV = (V0 + VT) / p.sigma2;
-  const LogMul Ik = besseli_logmul(p, {p.nuk_factor * cf.sqrtV0VT, 0.0}, 0.0);
+  const LogMul Ik = besseli_logmul(p.bes_nu, p.bes_nu0, p.n_int, {p.nuk_factor * cf.sqrtV0VT, 0.0}, 0.0);
   cf.logI_k = Ik.lg.re + fm::log(Ik.mul.re);  // real, positive argument: I_ν > 0
   // moments_from_cf (sample_from_cf.jl:50-61): mean = Re(-i ϕ'(0)), variance = Re(-ϕ''(0)) - mean²
   // by central differences of step hm over ϕ(hm), ϕ(0), ϕ(-hm).  The law is real, so ϕ(-a) is the
@@ -577,7 +454,8 @@ __global__ __launch_bounds__(kTile) void bk_series_kernel(const BkArgs p) {
   for (int j = 1; j <= p.cache_cap; ++j) {
     const cx phi = evaluate_chf(p, cf, h * (double)j, theta);
     col[(size_t)(j - 1) * p.cache_stride] = phi.re;
-    if (!(cabs(phi) >= stop * (double)j)) {  // |ϕ|/j < π·tol/2; also leaves on NaN
+    const double sj = stop * (double)j;
+    if (!(fma(phi.re, phi.re, phi.im * phi.im) >= sj * sj)) {  // |ϕ|/j < π·tol/2, squared; also leaves on NaN
       j_stop = j;
       break;
     }
@@ -868,16 +746,6 @@ __global__ __launch_bounds__(256) void fill_rows_kernel(double* __restrict__ spo
   }
 }
 
-void hankel_coefficients(double nu, double* coef) {
-  // a_0 = 1, a_k = a_{k-1} (4ν² − (2k−1)²) / (8k)   (DLMF 10.17.1)
-  const double mu = 4.0 * nu * nu;
-  coef[0] = 1.0;
-  for (int k = 1; k < kCoef; ++k) {
-    const double o = 2.0 * k - 1.0;
-    coef[k] = coef[k - 1] * (mu - o * o) / (8.0 * k);
-  }
-}
-
 }  // namespace
 
 constexpr int kPhiCapMax = 64;                   // series terms cached per trajectory
@@ -935,10 +803,8 @@ int launch_bk(const hh_model& m, const hh_config& c, const DevicePtrs& ptr, hipS
   if (!(a.d > 0.0) || !std::isfinite(a.d) || !(a.lam_num * m.V0 / a.lam_den >= 0.0))
     return (int)hipErrorInvalidValue;
   a.n_int = a.nu >= 1.0 ? (int)floor(a.nu) : 0;
-  a.nu0 = a.nu - a.n_int;
-  a.lgam_nu0p1 = lgamma(a.nu0 + 1.0);
-  hankel_coefficients(a.nu, a.coef_nu);
-  hankel_coefficients(a.nu0, a.coef_nu0);
+  if (!bessel_table(a.nu, a.bes_nu) || !bessel_table(a.nu - a.n_int, a.bes_nu0))
+    return (int)hipErrorInvalidValue;  // the series-length bound of hh_bessel.h does not hold: not for ν > -1
   a.n_sigma = c.bk_n_sigma > 0.0 ? c.bk_n_sigma : 5.0;
   a.cf_tol = c.bk_cf_tol > 0.0 ? c.bk_cf_tol : 1e-3;
   a.atol = c.bk_atol > 0.0 ? c.bk_atol : 1e-4;
