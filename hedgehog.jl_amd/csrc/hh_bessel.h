@@ -140,6 +140,18 @@ HH_MATH_FN int wave_max6(int n) {
 #endif
 }
 
+// A value that IS the same in every active lane, said so to the compiler: table indices derived from
+// wave_max6() are uniform by construction, but inside the divergent loops of a grid-stride kernel the
+// compiler cannot prove it — and then copies the by-value kernel-argument tables to scratch to index
+// them per lane (1.9 KB per lane in bk_fallback_kernel).  readfirstlane keeps them scalar loads.
+HH_MATH_FN int uniform_index(int i) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_readfirstlane(i);
+#else
+  return i;
+#endif
+}
+
 struct LogMul {
   cx lg, mul;
 };
@@ -159,12 +171,12 @@ HH_MATH_FN LogMul besseli_series(const BesselTable& t, cx z, double r, double ph
   const cx Q = q * q;
   const int Mh = (series_terms(r) + 1) >> 1;  // steps of each half
   cx A = {1.0, 0.0}, B = {1.0, 0.0};
-  int m = (wave_max6(Mh) + 1) & ~1;            // even: steps (m, m-1) down to (2, 1)
+  int m = uniform_index((wave_max6(Mh) + 1) & ~1);  // even: steps (m, m-1) down to (2, 1)
   const double* tab = t.series_de;
   double d0 = tab[2 * m], e0 = tab[2 * m + 1], d1 = tab[2 * m - 2], e1 = tab[2 * m - 1];
   while (true) {
     const double dm = d0, em = e0, dn = d1, en = e1;
-    const int mn = m - 2;
+    const int mn = uniform_index(m - 2);
     if (mn >= 2) {  // the next two steps' coefficients, one iteration ahead of their use
       d0 = tab[2 * mn]; e0 = tab[2 * mn + 1]; d1 = tab[2 * mn - 2]; e1 = tab[2 * mn - 1];
     }
@@ -197,12 +209,12 @@ HH_MATH_FN LogMul besseli_asym(const BesselTable& t, cx z, double r, double phi)
   M = M < kHankelPairs - 1 ? M : kHankelPairs - 1;
   for (int m = kHankelPairs - 2; m >= 3; --m) M = r >= t.hankel_rmin[m] ? m : M;  // (unrolled: constant bounds)
   cx E = {0.0, 0.0}, O = {0.0, 0.0};
-  int m = wave_max6(M) | 1;  // odd: steps (m, m-1) down to (1, 0)
+  int m = uniform_index(wave_max6(M) | 1);  // odd: steps (m, m-1) down to (1, 0)
   const double* tab = t.hankel;
   double a0 = tab[2 * m], a1 = tab[2 * m + 1], b0 = tab[2 * m - 2], b1 = tab[2 * m - 1];
   while (true) {
     const double ae = a0, ao = a1, be = b0, bo = b1;
-    const int mn = m - 2;
+    const int mn = uniform_index(m - 2);
     if (mn >= 1) {  // the next two steps' coefficients, one iteration ahead of their use
       a0 = tab[2 * mn]; a1 = tab[2 * mn + 1]; b0 = tab[2 * mn - 2]; b1 = tab[2 * mn - 1];
     }

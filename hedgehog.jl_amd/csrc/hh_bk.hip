@@ -9,8 +9,10 @@
 // then S_T = exp(.), payoff and the workgroup reduction as in hh_kernels.hip.
 //
 // Launch structure: bk_draw_kernel (the trajectory's three draws V_T, u, Z — or the caller's, in
-// REPLAY mode — and the normal quantile of u) -> bk_kernel (characteristic function, moments, secant
-// inversion) -> bk_scan_kernel -> bk_fallback_kernel (bisection ladder for the flagged trajectories).
+// REPLAY mode — and the normal quantile of u) -> bk_series_kernel (characteristic function, moments,
+// series terms) -> bk_invert_kernel (secant inversion on the cached terms) -> bk_scan_kernel ->
+// bk_ladder_kernel (bisection ladder for the flagged trajectories, packed) -> bk_fallback_kernel
+// (trajectories whose series outgrew the term cache; none with the reference's controls).
 // The draws live in their own launch because the NCχ² sampler's library calls (pow, lgamma, log,
 // normcdfinv) and the CF arithmetic are two different register-hungry programs: together they cost
 // 228 registers per lane (2 waves per SIMD); apart, the CF kernels fit 128 (4 waves).
@@ -69,9 +71,14 @@ struct BkArgs {
   unsigned long long* fail_mask;   // [n_tiles][4] ballots: secant failed, the ladder is left (bk_ladder_kernel)
   unsigned long long* long_mask;   // [n_tiles][4] ballots: series longer than the cache, not inverted yet
                                    //              (bk_fallback_kernel runs these whole)
+  uint32_t* tile_counts;           // [n_tiles] set bits of a tile's ballots: fail | long << 16
   double* phi_cache;               // [cache_cap][cache_stride] cached Re ϕ(h·j), one column per lane
   size_t cache_stride;
   int cache_cap;
+  void* args_dev;                  // a copy of this struct in device memory (written by bk_scan_kernel)
+                                   // for bk_fallback_kernel, whose code is too large to inline: passing
+                                   // a by-value kernel argument by reference to its functions would put
+                                   // a 2 KB copy per lane in scratch
 };
 
 // 1/x to <= 1 ulp: hardware reciprocal + two Newton steps (5 instructions; the IEEE division
@@ -370,17 +377,25 @@ __device__ __forceinline__ double bk_finish(const BkArgs& p, double logS0, doubl
   return m > 0.0 ? m : 0.0;
 }
 
-__device__ __forceinline__ void bk_store_record(double (&acc)[6], double* rec) {
+// (tile_count, when given, receives the tile's number of failed | too-long trajectories: the sums of
+// the 0/1 flags in acc[2] and `n_long` — what bk_scan_kernel needs, without re-reading the ballots)
+__device__ __forceinline__ void bk_store_record(double (&acc)[6], double* rec, uint32_t* tile_count = nullptr,
+                                                double n_long = 0.0) {
+  if (tile_count) {  // uniform
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) n_long += __shfl_down(n_long, off, 64);
+  }
 #pragma unroll
   for (int i = 0; i < 6; ++i) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) acc[i] += __shfl_down(acc[i], off, 64);
   }
-  __shared__ double sm[kTile / 64][6];
+  __shared__ double sm[kTile / 64][7];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (lane == 0) {
 #pragma unroll
     for (int i = 0; i < 6; ++i) sm[wave][i] = acc[i];
+    sm[wave][6] = n_long;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -389,6 +404,11 @@ __device__ __forceinline__ void bk_store_record(double (&acc)[6], double* rec) {
     for (int i = 0; i < 6; ++i) {
       t[i] = sm[0][i];
       for (int w = 1; w < kTile / 64; ++w) t[i] += sm[w][i];
+    }
+    if (tile_count) {
+      double nl = sm[0][6];
+      for (int w = 1; w < kTile / 64; ++w) nl += sm[w][6];
+      *tile_count = (uint32_t)t[2] | ((uint32_t)nl << 16);
     }
     for (int i = 0; i < kRecStride; ++i) rec[i] = 0.0;
     rec[HH_ACC_SUM] = t[0];
@@ -430,27 +450,28 @@ __device__ __forceinline__ bool secant_inverse(Cdf&& cdf, double u, double guess
   return ok && !(x1 < 0.0);
 }
 
-// Series kernel: the characteristic-function work of a trajectory — CF iterator, moments, and the
+// Series phase: the characteristic-function work of a trajectory — CF iterator, moments, and the
 // series terms Re ϕ(h·j), j = 1 … J (J set by the reference's stopping rule, sample_from_cf.jl:88),
 // evaluated ONCE in the reference's order with its continuous phase unwrapping and left in the
 // trajectory's column of the cache.  Nothing here depends on the CDF argument, so the root search
-// needs none of the complex Bessel machinery: it runs in its own, light kernel.  Everything a lane
-// keeps here is the CF state — that is what fits 128 registers (4 waves per SIMD).
-__global__ __launch_bounds__(kTile) void bk_series_kernel(const BkArgs p) {
-  const uint64_t path = (uint64_t)blockIdx.x * kTile + threadIdx.x;
-  if (path >= p.n_paths) return;
+// needs none of the complex Bessel machinery.  Everything a lane keeps here is the CF state — that
+// is what fits 128 registers (4 waves per SIMD).  Returns h, the secant's first guess and the series
+// length (0: longer than the cache — the fall-back kernel runs this trajectory whole); leaves them
+// with max_guess in rec[] for the ladder kernel.
+__device__ __forceinline__ void series_phase(const BkArgs& p, uint64_t path, double& h, double& initial_guess,
+                                             int& j_stop) {
   const bool grid = p.in_var != nullptr;
   const double V0 = grid ? p.in_var[path] : p.V0;
   const double* d = p.draws + path;
   const double q_u = d[2 * p.draw_stride];
   const double VT = d[3 * p.draw_stride];
   CfIter cf;
-  double h, initial_guess, max_guess;
+  double max_guess;
   cf_setup(p, V0, VT, q_u, cf, initial_guess, max_guess, h);
   double* col = p.phi_cache + path;
   const double stop = kPi * p.cf_tol / 2.0;
   double theta = __builtin_nan("");
-  int j_stop = 0;  // 0: longer than the cache — the fall-back kernel runs this trajectory whole
+  j_stop = 0;
   for (int j = 1; j <= p.cache_cap; ++j) {
     const cx phi = evaluate_chf(p, cf, h * (double)j, theta);
     col[(size_t)(j - 1) * p.cache_stride] = phi.re;
@@ -510,22 +531,17 @@ __device__ __forceinline__ double cdf_cached(const double (&t)[kRegTerms], const
   return result;
 }
 
-// Inversion kernel: the secant iteration of inverse_cdf on the cached series, then log S_T and the
+// Inversion phase: the secant iteration of inverse_cdf on the cached series, then log S_T and the
 // payoff.  A trajectory whose secant fails is NOT finished here: one such lane would keep its whole
 // wave in the ~15-evaluation bisection ladder (2 % of the paths fail, so 3 out of 4 waves would).
-// It is flagged in a per-wave ballot instead and finished, densely packed, by bk_fallback_kernel;
-// so is a trajectory whose series did not fit the cache.  Flags are ballots in trajectory order, so
-// the result is bit-reproducible.
-__global__ __launch_bounds__(kTile) void bk_invert_kernel(const BkArgs p) {
-  const uint32_t tile = blockIdx.x, tid = threadIdx.x;
-  const uint64_t path = (uint64_t)tile * kTile + tid;
+// It is flagged in a per-wave ballot instead and finished, densely packed, by bk_ladder_kernel;
+// so is a trajectory whose series did not fit the cache (bk_fallback_kernel).  Flags are ballots in
+// trajectory order, so the result is bit-reproducible.  Called by every thread of the workgroup.
+__device__ __forceinline__ void invert_phase(const BkArgs& p, uint32_t tile, uint32_t tid, uint64_t path,
+                                             bool live, double h, double guess, int j_stop) {
   double acc[6] = {0, 0, 0, 0, 0, 0};  // Σp, Σp², newton_fail, bisect, maxguess, cf_terms
   bool failed = false, too_long = false;
-
-  if (path < p.n_paths) {
-    const double* r = p.rec + path;
-    const double h = r[0], guess = r[p.draw_stride];
-    const int j_stop = (int)r[3 * p.draw_stride];
+  if (live) {
     const double u = p.draws[p.draw_stride + path];
     if (j_stop == 0) {
       too_long = true;
@@ -557,50 +573,108 @@ __global__ __launch_bounds__(kTile) void bk_invert_kernel(const BkArgs p) {
     p.fail_mask[(size_t)tile * (kTile / 64) + (tid >> 6)] = m_fail;
     p.long_mask[(size_t)tile * (kTile / 64) + (tid >> 6)] = m_long;
   }
-  bk_store_record(acc, p.records + (size_t)tile * kRecStride);
+  bk_store_record(acc, p.records + (size_t)tile * kRecStride, p.tile_counts + tile, too_long ? 1.0 : 0.0);
 }
 
-// exclusive prefix sums of the per-tile counts of both ballot arrays (one workgroup: every thread
-// adds up a run of consecutive tiles, one 256-wide scan, then the runs are expanded)
-__global__ __launch_bounds__(256) void bk_scan_kernel(const unsigned long long* __restrict__ mask_a,
-                                                      const unsigned long long* __restrict__ mask_b,
-                                                      uint32_t n_tiles, uint32_t* __restrict__ prefix_a,
-                                                      uint32_t* __restrict__ prefix_b) {
-  __shared__ uint32_t sm[2][256];
-  const uint32_t per = (n_tiles + 255) / 256;
-  const uint32_t t0 = threadIdx.x * per, t1 = min(t0 + per, n_tiles);
-  auto count = [](const unsigned long long* m, uint32_t t) {
-    uint32_t c = 0;
-#pragma unroll
-    for (int w = 0; w < kTile / 64; ++w) c += (uint32_t)__popcll(m[(size_t)t * (kTile / 64) + w]);
-    return c;
-  };
+// Two forms of the CF work (HH_BK_FUSED):
+//  1  ONE kernel, series phase then inversion phase per trajectory.  The inversion re-reads the terms
+//     the lane has just written (L2 hits) while other waves of the CU are still in their series phase,
+//     so its memory latency — 2/3 of a stand-alone inversion kernel's time — hides behind their
+//     arithmetic; the series state is dead by then, so the register count is the series phase's.
+//  0  two kernels, bk_series_kernel then bk_invert_kernel.
+#ifndef HH_BK_FUSED
+#define HH_BK_FUSED 1
+#endif
+__global__ __launch_bounds__(kTile) void bk_cf_kernel(const BkArgs p) {
+  const uint32_t tile = blockIdx.x, tid = threadIdx.x;
+  const uint64_t path = (uint64_t)tile * kTile + tid;
+  const bool live = path < p.n_paths;
+  double h = 0.0, guess = 0.0;
+  int j_stop = 0;
+  if (live) series_phase(p, path, h, guess, j_stop);
+  invert_phase(p, tile, tid, path, live, h, guess, j_stop);
+}
+__global__ __launch_bounds__(kTile) void bk_series_kernel(const BkArgs p) {
+  const uint64_t path = (uint64_t)blockIdx.x * kTile + threadIdx.x;
+  if (path >= p.n_paths) return;
+  double h, guess;
+  int j_stop;
+  series_phase(p, path, h, guess, j_stop);
+}
+__global__ __launch_bounds__(kTile) void bk_invert_kernel(const BkArgs p) {
+  const uint32_t tile = blockIdx.x, tid = threadIdx.x;
+  const uint64_t path = (uint64_t)tile * kTile + tid;
+  const bool live = path < p.n_paths;
+  double h = 0.0, guess = 0.0;
+  int j_stop = 0;
+  if (live) {
+    const double* r = p.rec + path;
+    h = r[0];
+    guess = r[p.draw_stride];
+    j_stop = (int)r[3 * p.draw_stride];
+  }
+  invert_phase(p, tile, tid, path, live, h, guess, j_stop);
+}
+
+// exclusive prefix sums of the per-tile counts of both ballot arrays (bk_invert_kernel leaves the counts,
+// 4 bytes per tile: a single workgroup reading the 64 bytes of ballots per tile instead is bound by
+// what one CU can pull, 16 µs at 10^6 trajectories).  ONE workgroup of 1024 threads: every thread adds
+// up a run of consecutive tiles, the run totals are scanned (shuffles inside a wave, then the 16 wave
+// totals), then the runs are expanded.  Its last thread also leaves the copy of the argument block
+// bk_fallback_kernel reads (BkArgs::args_dev).
+constexpr int kScanThreads = 1024;
+__global__ __launch_bounds__(kScanThreads) void bk_scan_kernel(const BkArgs p, uint32_t n_tiles,
+                                                               uint32_t* __restrict__ prefix_a,
+                                                               uint32_t* __restrict__ prefix_b) {
+  __shared__ uint32_t wsum[2][kScanThreads / 64];
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  if (tid == kScanThreads - 1) __builtin_memcpy(p.args_dev, &p, sizeof(BkArgs));
+  const uint32_t* __restrict__ cnt = p.tile_counts;
+  const uint32_t per = (n_tiles + kScanThreads - 1) / kScanThreads;
+  const uint32_t t0 = min(tid * per, n_tiles), t1 = min(t0 + per, n_tiles);
   uint32_t ca = 0, cb = 0;
+#pragma unroll 4
   for (uint32_t t = t0; t < t1; ++t) {
-    ca += count(mask_a, t);
-    cb += count(mask_b, t);
+    const uint32_t c = cnt[t];
+    ca += c & 0xffffu;
+    cb += c >> 16;
   }
-  sm[0][threadIdx.x] = ca;
-  sm[1][threadIdx.x] = cb;
+  uint32_t ia = ca, ib = cb;  // inclusive scan of the run totals inside the wave
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t va = __shfl_up(ia, off, 64), vb = __shfl_up(ib, off, 64);
+    if (lane >= (uint32_t)off) {
+      ia += va;
+      ib += vb;
+    }
+  }
+  if (lane == 63) {
+    wsum[0][wave] = ia;
+    wsum[1][wave] = ib;
+  }
   __syncthreads();
-  for (int off = 1; off < 256; off <<= 1) {  // Hillis–Steele inclusive scan of the run totals
-    const uint32_t va = threadIdx.x >= (unsigned)off ? sm[0][threadIdx.x - off] : 0;
-    const uint32_t vb = threadIdx.x >= (unsigned)off ? sm[1][threadIdx.x - off] : 0;
-    __syncthreads();
-    sm[0][threadIdx.x] += va;
-    sm[1][threadIdx.x] += vb;
-    __syncthreads();
+  uint32_t ba = 0, bb = 0, ta = 0, tb = 0;  // totals of the waves before this one; of all waves
+#pragma unroll
+  for (uint32_t w = 0; w < kScanThreads / 64; ++w) {
+    const uint32_t xa = wsum[0][w], xb = wsum[1][w];
+    if (w < wave) {
+      ba += xa;
+      bb += xb;
+    }
+    ta += xa;
+    tb += xb;
   }
-  uint32_t ra = sm[0][threadIdx.x] - ca, rb = sm[1][threadIdx.x] - cb;  // exclusive, start of the run
+  uint32_t ra = ba + ia - ca, rb = bb + ib - cb;  // exclusive: start of this thread's run
   for (uint32_t t = t0; t < t1; ++t) {
+    const uint32_t c = cnt[t];
     prefix_a[t] = ra;
     prefix_b[t] = rb;
-    ra += count(mask_a, t);
-    rb += count(mask_b, t);
+    ra += c & 0xffffu;
+    rb += c >> 16;
   }
-  if (threadIdx.x == 255) {
-    prefix_a[n_tiles] = sm[0][255];
-    prefix_b[n_tiles] = sm[1][255];
+  if (tid == 0) {
+    prefix_a[n_tiles] = ta;
+    prefix_b[n_tiles] = tb;
   }
 }
 
@@ -687,9 +761,11 @@ __global__ __launch_bounds__(kTile) void bk_ladder_kernel(const BkArgs p, uint32
 // default) run whole here — secant, then the ladder if it fails — evaluating the terms beyond the
 // cache on every use, as the reference does with all of them.  Densely packed, grid stride; with
 // the default controls there are none and the launch returns at once.
-__global__ __launch_bounds__(kTile) void bk_fallback_kernel(const BkArgs p, uint32_t n_tiles,
+__global__ __launch_bounds__(kTile) void bk_fallback_kernel(const BkArgs* __restrict__ args,
+                                                            uint32_t n_tiles,
                                                             const uint32_t* __restrict__ prefix) {
   const uint32_t total = prefix[n_tiles];
+  const BkArgs& p = *args;
   double acc[6] = {0, 0, 0, 0, 0, 0};
   for (uint32_t g = blockIdx.x * kTile + threadIdx.x; g < total; g += gridDim.x * kTile) {
     const uint64_t path = packed_path(p.long_mask, prefix, n_tiles, g);
@@ -759,9 +835,16 @@ static int phi_cache_cap(size_t n_tiles) {
   return (int)cap;
 }
 
-static size_t bk_flags_bytes(size_t n_tiles) {
-  size_t b = 2 * n_tiles * (kTile / 64) * sizeof(unsigned long long) + 2 * (n_tiles + 1) * sizeof(uint32_t);
+// ballots (fail, long) | prefix sums (fail, long) | tile counts | device copy of the argument block
+static size_t bk_masks_bytes(size_t n_tiles) {
+  return 2 * n_tiles * (kTile / 64) * sizeof(unsigned long long);
+}
+static size_t bk_args_offset(size_t n_tiles) {  // … + prefix sums [2][n_tiles+1] + tile counts [n_tiles]
+  const size_t b = bk_masks_bytes(n_tiles) + (2 * (n_tiles + 1) + n_tiles) * sizeof(uint32_t);
   return (b + 255) & ~(size_t)255;
+}
+static size_t bk_flags_bytes(size_t n_tiles) {
+  return bk_args_offset(n_tiles) + ((sizeof(BkArgs) + 255) & ~(size_t)255);
 }
 
 int launch_fill_rows(double* spot0, double* var0, uint64_t n, double S0, double V0, hipStream_t s) {
@@ -824,6 +907,8 @@ int launch_bk(const hh_model& m, const hh_config& c, const DevicePtrs& ptr, hipS
   a.long_mask = a.fail_mask + (size_t)n_tiles * (kTile / 64);
   uint32_t* prefix = reinterpret_cast<uint32_t*>(a.long_mask + (size_t)n_tiles * (kTile / 64));
   uint32_t* prefix_long = prefix + n_tiles + 1;
+  a.tile_counts = prefix_long + n_tiles + 1;
+  a.args_dev = base + bk_args_offset(n_tiles);
   a.phi_cache = reinterpret_cast<double*>(base + bk_flags_bytes(n_tiles));
   a.cache_stride = lanes;
   a.cache_cap = phi_cache_cap(n_tiles);
@@ -836,12 +921,16 @@ int launch_bk(const hh_model& m, const hh_config& c, const DevicePtrs& ptr, hipS
     hipLaunchKernelGGL(bk_draw_kernel<true>, g, b, 0, s, a);
   else
     hipLaunchKernelGGL(bk_draw_kernel<false>, g, b, 0, s, a);
+#if HH_BK_FUSED
+  hipLaunchKernelGGL(bk_cf_kernel, g, b, 0, s, a);
+#else
   hipLaunchKernelGGL(bk_series_kernel, g, b, 0, s, a);
   hipLaunchKernelGGL(bk_invert_kernel, g, b, 0, s, a);
-  hipLaunchKernelGGL(bk_scan_kernel, dim3(1), dim3(256), 0, s, a.fail_mask, a.long_mask, n_tiles, prefix,
-                     prefix_long);
+#endif
+  hipLaunchKernelGGL(bk_scan_kernel, dim3(1), dim3(kScanThreads), 0, s, a, n_tiles, prefix, prefix_long);
   hipLaunchKernelGGL(bk_ladder_kernel, dim3(kPackedGrid), b, 0, s, a, n_tiles, prefix);
-  hipLaunchKernelGGL(bk_fallback_kernel, dim3(kHeavyGrid), b, 0, s, a, n_tiles, prefix_long);
+  hipLaunchKernelGGL(bk_fallback_kernel, dim3(kHeavyGrid), b, 0, s,
+                     static_cast<const BkArgs*>(a.args_dev), n_tiles, prefix_long);
   return (int)hipGetLastError();
 }
 

@@ -44,7 +44,7 @@ def main():
     out = {
         "heston_euler_generate": {"valu_insts_per_unit": gen / (N * M), "unit": "path-step", "source": src},
         "lognormal_exact": {"valu_insts_per_unit": exact / N, "unit": "path", "source": src},
-        "broadie_kaya": {"valu_insts_per_unit": bk / N, "unit": "path (draw + series + invert + scan + ladder + fall-back kernels)",
+        "broadie_kaya": {"valu_insts_per_unit": bk / N, "unit": "path (draw + cf (series, inversion) + scan + ladder + fall-back kernels)",
                          "source": src},
         "heston_exact_grid": {"valu_insts_per_unit": grid / 200_000, "unit": "transition (the same chain per date)",
                               "source": src},
