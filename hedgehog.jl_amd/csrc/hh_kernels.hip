@@ -315,8 +315,11 @@ __device__ __forceinline__ Vec stream_load(const double* p) {
 }
 
 // RING: chunks in each wave's LDS ring of the REPLAY stream (0 = register pipeline), see below
+#ifndef HH_REPLAY_MAXW_DUAL_WIDE
+#define HH_REPLAY_MAXW_DUAL_WIDE HH_REPLAY_MAXW_DUAL  // two or more carried derivatives
+#endif
 constexpr int replay_max_waves(bool replay, bool anti, int p) {
-  return !replay ? 8 : anti ? HH_REPLAY_MAXW_ANTI : p > 0 ? HH_REPLAY_MAXW_DUAL : HH_REPLAY_MAXW;
+  return !replay ? 8 : anti ? HH_REPLAY_MAXW_ANTI : p > 1 ? HH_REPLAY_MAXW_DUAL_WIDE : p > 0 ? HH_REPLAY_MAXW_DUAL : HH_REPLAY_MAXW;
 }
 template <class M, int P, bool REPLAY, bool ANTI, int PPT, int RING, bool PIPE>
 __global__ __launch_bounds__(kTile / PPT)
@@ -506,16 +509,60 @@ __attribute__((amdgpu_waves_per_eu(REPLAY ? HH_REPLAY_MINW : 1,
           }
         }
       };
+      // Steady state on FULL chunks, loads unguarded: with a load under `if (step < n_steps)` the
+      // compiler cannot count how many younger loads are certainly in flight when chunk X is consumed,
+      // and waits for ALL of them (s_waitcnt vmcnt(0)/(1) right after issuing Y) — a wave then never
+      // overlaps its own loads with its own arithmetic.  Unguarded, the wait is vmcnt(CH·NC): X has
+      // landed, Y stays in flight behind the arithmetic of X.
+      auto ldf = [&](Vec(&buf)[CH][NC], uint32_t s0) {
+#pragma unroll
+        for (int u = 0; u < CH; ++u)
+#pragma unroll
+          for (int c = 0; c < NC; ++c)
+            buf[u][c] = stream_load<Vec>(base + ((size_t)(s0 + u) * NC + c) * kTile);
+      };
+      auto gof = [&](const Vec(&buf)[CH][NC]) {
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+#pragma unroll
+          for (int j = 0; j < PPT; ++j) {
+            const double d1 = VecOf<PPT>::get(buf[u][0], j);
+            const double d2 = NC > 1 ? VecOf<PPT>::get(buf[u][NC - 1], j) : 0.0;
+            M::step(st[j], a, d1, d2);
+            if constexpr (ANTI) M::step(sa[j], a, -d1, -d2);  // montecarlo.jl:258: -W
+          }
+        }
+      };
       uint32_t s = 0;
-      ld(X, 0);
-      while (s < n_steps) {
-        ld(Y, s + CH);
-        go(X, s);
+#ifndef HH_REPLAY_COUNTED
+#define HH_REPLAY_COUNTED 1
+#endif
+      if (HH_REPLAY_COUNTED && n_steps >= 2u * CH) {
+        ldf(X, 0);
+        while (s + 3u * CH <= n_steps) {  // chunks s, s+CH and s+2CH are full
+          ldf(Y, s + CH);
+          gof(X);
+          ldf(X, s + 2u * CH);
+          gof(Y);
+          s += 2u * CH;
+        }
+        ld(Y, s + CH);  // fewer than 2·CH steps beyond chunk X: guarded
+        gof(X);
         s += CH;
-        if (s >= n_steps) break;
         ld(X, s + CH);
         go(Y, s);
-        s += CH;
+        go(X, s + CH);
+      } else {  // short runs (and -DHH_REPLAY_COUNTED=0, the all-guarded form, for A/B)
+        ld(X, 0);
+        while (s < n_steps) {
+          ld(Y, s + CH);
+          go(X, s);
+          s += CH;
+          if (s >= n_steps) break;
+          ld(X, s + CH);
+          go(Y, s);
+          s += CH;
+        }
       }
     };
     constexpr int kTail = (P == 0 && !ANTI && PPT == 1) ? HH_REPLAY_CHUNK_TAIL : kChunk;

@@ -86,6 +86,16 @@ def main():
     run("config5_greeks3_replay", m5, rep_cfg(n_partials=3), N * M, "path-steps/s")
     out["config5_greeks3_replay"]["hbm_GBs"] = 16e-9 * out["config5_greeks3_replay"]["throughput"]
     out["config5_greeks3_replay"]["fourier_targets"] = [0.65565115, 40.7248418, 56.3225943]
+    # the full Heston gradient in one pass (calibration's use of AD): ∂/∂(S0, V0, κ, θ, σ, r) — four
+    # carried basis derivatives (V0, κ, θ, σ), two passive directions
+    e6 = lambda k: [1.0 if j == k else 0.0 for j in range(6)]
+    sd6 = {"S0": e6(0), "V0": e6(1), "kappa": e6(2), "theta": e6(3), "sigma": e6(4), "r_drift": e6(5),
+           "discount": [0, 0, 0, 0, 0, -float(np.exp(-0.03))]}
+    m6 = _ffi.make_model(seeds=sd6, n_partials=6)
+    run("heston_full_gradient6_generate", m6, dev_cfg(_ffi.make_config(1, 0, N, M, n_partials=6)), N * M,
+        "path-steps/s")
+    run("heston_full_gradient6_replay", m6, rep_cfg(n_partials=6), N * M, "path-steps/s")
+    out["heston_full_gradient6_replay"]["hbm_GBs"] = 16e-9 * out["heston_full_gradient6_replay"]["throughput"]
     del dW
     # config 4: Broadie–Kaya 10^6
     c4 = _ffi.make_config(1, 2, N)
