@@ -1,0 +1,69 @@
+"""Randomised parity: model parameters, sizes and options drawn by hypothesis, the HIP path (through
+the C-ABI) against the CPU oracle on identical seeds / increments.  The fixed-parameter tests of
+test_gpu_parity.py pin the arithmetic on the reference's own parameter sets; this one looks for a
+dependence on the VALUES (clipped variances, deep in / out of the money strikes, negative vol-of-vol
+as in SURVEY Q2, correlation at ±1, tiny and long maturities, ragged sizes).
+
+Tolerances as in test_gpu_parity.py: REPLAY 1e-12, GENERATE 1e-11 (different libm), Greeks 1e-9
+(relative to the Greek or to price / parameter, whichever is larger)."""
+import numpy as np
+import pytest
+from hypothesis import HealthCheck, given, settings
+from hypothesis import strategies as st
+
+from hedgehog_jl_amd import _ffi
+from tests import oracle_ffi as o
+from tests.test_gpu_parity import gpu_solve, seeds_for
+
+pytestmark = pytest.mark.gpu
+
+GBM, HES = _ffi.HH_LOGNORMAL, _ffi.HH_HESTON
+EM, EXACT = _ffi.HH_EULER_MARUYAMA, _ffi.HH_EXACT_LAW
+GEN, REP = _ffi.HH_NOISE_GENERATE, _ffi.HH_NOISE_REPLAY
+
+model_st = st.fixed_dictionaries(dict(
+    S0=st.floats(1.0, 500.0), V0=st.floats(1e-4, 1.5), kappa=st.floats(0.01, 8.0),
+    theta=st.floats(1e-3, 0.5), sigma=st.floats(-1.0, 1.0).filter(lambda x: abs(x) > 1e-3),
+    rho=st.sampled_from([-1.0, -0.7, -0.3, 0.0, 0.04, 0.6, 1.0]), r=st.floats(-0.02, 0.1),
+    T=st.floats(0.01, 5.0), moneyness=st.floats(0.5, 1.6), cp=st.sampled_from([1.0, -1.0])))
+
+
+def _run(hhlib, oracle, prm, dyn, n_paths, n_steps, anti, split, noise, P, salt):
+    prm = dict(prm)
+    prm["strike"] = prm["S0"] * prm.pop("moneyness")
+    if dyn == GBM:
+        prm["sigma"] = abs(prm["sigma"])  # a lognormal volatility
+    names = (["S0", "sigma", "r_drift"] if dyn == GBM else ["S0", "V0", "kappa", "theta", "sigma", "r_drift"])[:P]
+    sd = {nm: [1.0 if j == k else 0.0 for j in range(P)] for k, nm in enumerate(names)}
+    seeds = seeds_for(n_paths, salt)
+    m = o.make_model(seeds=sd, n_partials=P, **prm)
+    rep = oracle.wiener_fill(dyn, m.rho, m.T, n_steps, seeds) if noise == REP else None
+    c = o.make_config(dyn, EM, n_paths, n_steps, antithetic=anti, em_split=split, noise_mode=noise,
+                      seeds=seeds, replay=rep, n_partials=P)
+    rg, tg = gpu_solve(hhlib, m, c)
+    ro, to, _ = oracle.mc_solve(m, c)
+    tol = 1e-12 if noise == REP else 1e-11
+    # a sample is exp(x_T): rounding of x_T (|x_T| up to ~10) reappears scaled by |x_T|
+    np.testing.assert_allclose(tg, to, rtol=20 * tol, atol=0)
+    assert rg.price == pytest.approx(ro.price, rel=20 * tol, abs=1e-13 * prm["S0"])
+    for k, nm in enumerate(names):
+        scale = max(abs(ro.dprice[k]), abs(ro.price) / max(abs(getattr(m, nm)), 1e-2))
+        assert abs(rg.dprice[k] - ro.dprice[k]) <= 1e-9 * scale + 1e-13 * prm["S0"], (nm, rg.dprice[k], ro.dprice[k])
+
+
+@settings(max_examples=60, deadline=None, derandomize=True,
+          suppress_health_check=[HealthCheck.function_scoped_fixture])
+@given(prm=model_st, n_paths=st.sampled_from([1, 63, 257, 1000, 2049]),
+       n_steps=st.sampled_from([1, 2, 7, 8, 9, 16, 50]), anti=st.booleans(), split=st.booleans(),
+       noise=st.sampled_from([GEN, REP]), P=st.sampled_from([0, 0, 2, 6]), salt=st.integers(0, 2**32))
+def test_heston_euler_random_models(hhlib, oracle, prm, n_paths, n_steps, anti, split, noise, P, salt):
+    _run(hhlib, oracle, prm, HES, n_paths, n_steps, int(anti), int(split), noise, P, salt)
+
+
+@settings(max_examples=30, deadline=None, derandomize=True,
+          suppress_health_check=[HealthCheck.function_scoped_fixture])
+@given(prm=model_st, n_paths=st.sampled_from([1, 255, 1000, 2049]),
+       n_steps=st.sampled_from([1, 2, 3, 8, 9, 33]), anti=st.booleans(),
+       noise=st.sampled_from([GEN, REP]), P=st.sampled_from([0, 3]), salt=st.integers(0, 2**32))
+def test_lognormal_euler_random_models(hhlib, oracle, prm, n_paths, n_steps, anti, noise, P, salt):
+    _run(hhlib, oracle, prm, GBM, n_paths, n_steps, int(anti), 1, noise, P, salt)
