@@ -186,14 +186,77 @@ class Context:
         self.check(self.lib.hh_ctx_read_timings(self.handle, buf, 256, C.byref(n)))
         return [buf[i] for i in range(n.value)]
 
+    # a few recycled device buffers by exact size (the sample buffers of repeated solves)
+    _POOL_MAX = 4
+
+    def pool_take(self, nbytes: int):
+        pool = self.__dict__.setdefault("_pool", [])
+        for i, (p, n) in enumerate(pool):
+            if n == nbytes:
+                del pool[i]
+                return p
+        return None
+
+    def pool_put(self, ptr: int, nbytes: int) -> bool:
+        pool = self.__dict__.setdefault("_pool", [])
+        if len(pool) >= self._POOL_MAX:
+            old_p, _ = pool.pop(0)
+            self.lib.hh_device_free(self.handle, _vp(old_p))
+        pool.append((ptr, nbytes))
+        return True
+
     def close(self):
         if getattr(self, "handle", None):
+            for p, _ in self.__dict__.get("_pool", []):
+                self.lib.hh_device_free(self.handle, _vp(p))
+            self.__dict__["_pool"] = []
             self.lib.hh_ctx_destroy(self.handle)
             self.handle = None
 
     def __del__(self):  # pragma: no cover
         try:
             self.close()
+        except Exception:
+            pass
+
+
+class DeviceBuffer:
+    """Device memory of a Context (hh_device_malloc / hh_device_free), released with the object."""
+
+    def __init__(self, ctx: Context, nbytes: int, pooled: bool = False):
+        self.ctx, self.nbytes, self._pooled = ctx, int(nbytes), pooled
+        self.ptr = ctx.pool_take(self.nbytes) if pooled else None
+        if self.ptr is None:
+            p = _vp()
+            ctx.check(ctx.lib.hh_device_malloc(ctx.handle, max(self.nbytes, 8), C.byref(p)))
+            self.ptr = p.value
+
+    def upload(self, arr):
+        assert arr.flags.c_contiguous and arr.nbytes <= self.nbytes
+        self.ctx.check(self.ctx.lib.hh_memcpy_h2d(self.ctx.handle, _vp(self.ptr), _vp(arr.ctypes.data), arr.nbytes))
+        return self
+
+    def download(self, arr):
+        assert arr.flags.c_contiguous and arr.nbytes <= self.nbytes
+        self.ctx.check(self.ctx.lib.hh_memcpy_d2h(self.ctx.handle, _vp(arr.ctypes.data), _vp(self.ptr), arr.nbytes))
+        return arr
+
+    def free(self):
+        if getattr(self, "ptr", None) and getattr(self.ctx, "handle", None):
+            self.ctx.lib.hh_device_free(self.ctx.handle, _vp(self.ptr))
+        self.ptr = None
+
+    def recycle(self):
+        """Hand the memory back to the context's pool (hipMalloc / hipFree cost 0.1-0.3 ms each and
+        synchronise: a solve that allocates its sample buffer afresh pays more than the download)."""
+        if getattr(self, "ptr", None) and getattr(self.ctx, "handle", None) and self.ctx.pool_put(self.ptr, self.nbytes):
+            self.ptr = None
+        else:
+            self.free()
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.recycle() if getattr(self, "_pooled", False) else self.free()
         except Exception:
             pass
 

@@ -54,7 +54,8 @@ def solve_basket(prob: BasketPricingProblem, method: MonteCarlo, ensemble: bool 
         K = len(idx)
         strikes = (C.c_double * K)(*[float(payoffs[i].strike) for i in idx])
         cps = (C.c_double * K)(*[payoffs[i].call_put() for i in idx])
-        c.seeds = cfg.seeds.ctypes.data
+        seeds_dev = cfg.device_seeds(ctx)  # uploaded once per config, not once per objective evaluation
+        c.seeds, c.seeds_on_device = seeds_dev.ptr, 1
         c.seeds_len = cfg.seeds.size
         anti = bool(c.antithetic)
         term = np.empty(c.n_paths * (2 if anti else 1)) if ensemble else None

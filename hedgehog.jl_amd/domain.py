@@ -233,14 +233,31 @@ class PricingProblem:
     market_inputs: Any
 
 
-@dataclass(frozen=True)
 class MonteCarloSolution:
     """pricing_solutions.jl:22-27; `ensemble` holds the samples at expiry (a pair when antithetic).
 
-    `std_error`, `result` are build extensions (the reference computes no standard error)."""
-    problem: Any
-    method: Any
-    price: Any
-    ensemble: Any
-    std_error: float = field(default=float("nan"), compare=False)
-    result: Any = field(default=None, compare=False, repr=False)
+    `std_error`, `result` are build extensions (the reference computes no standard error).  The
+    samples stay in device memory until `ensemble` is first read (most callers only read `price`;
+    the download is 8 MB per 10^6 trajectories): `fetch` is the callable that brings them over."""
+    __slots__ = ("problem", "method", "price", "std_error", "result", "_ensemble", "_fetch")
+
+    def __init__(self, problem, method, price, ensemble=None, std_error=float("nan"), result=None,
+                 fetch=None):
+        self.problem, self.method, self.price = problem, method, price
+        self.std_error, self.result = std_error, result
+        self._ensemble, self._fetch = ensemble, fetch
+
+    @property
+    def ensemble(self):
+        if self._fetch is not None:
+            self._ensemble, self._fetch = self._fetch(), None
+        return self._ensemble
+
+    def __eq__(self, other):
+        return isinstance(other, MonteCarloSolution) and \
+            (self.problem, self.method, self.price) == (other.problem, other.method, other.price)
+
+    __hash__ = None
+
+    def __repr__(self):
+        return f"MonteCarloSolution(problem={self.problem!r}, method={self.method!r}, price={self.price!r})"

@@ -52,7 +52,13 @@ class SimulationConfig:
         if seeds is None:  # montecarlo.jl:77: rand(UInt64, trajectories)
             seeds = np.random.default_rng().integers(0, 2**64, size=int(trajectories),
                                                      dtype=np.uint64)
-        seeds = np.ascontiguousarray(np.asarray(seeds).astype(np.uint64, copy=False))
+        if isinstance(seeds, np.ndarray) and seeds.dtype == np.uint64 and not seeds.flags.writeable \
+                and seeds.flags.c_contiguous:
+            pass  # already a frozen seed vector (replace(), slices of another config): shared
+        else:     # the config's OWN copy, read-only: its device copies (below) can never go stale
+            seeds = np.array(np.asarray(seeds).astype(np.uint64, copy=False), dtype=np.uint64, order="C",
+                             copy=True)
+            seeds.flags.writeable = False
         if len(seeds) < trajectories:  # montecarlo.jl:65-66
             raise ValueError(f"Number of seeds ({len(seeds)}) must be ≥ number of trajectories "
                              f"({trajectories}).")
@@ -60,6 +66,16 @@ class SimulationConfig:
         self.steps = int(steps)
         self.variance_reduction = variance_reduction
         self.seeds = seeds
+        self._seeds_dev = {}
+
+    def device_seeds(self, ctx):
+        """The seed vector in the memory of ctx's device, uploaded on first use and kept with the
+        config: repeated solves (Greeks by finite differences, calibration loops) do not move the
+        8 MB per 10^6 trajectories again.  `seeds` is read-only, so the copy cannot go stale."""
+        buf = self._seeds_dev.get(id(ctx))
+        if buf is None or buf.ptr is None or buf.ctx is not ctx:
+            buf = self._seeds_dev[id(ctx)] = _ffi.DeviceBuffer(ctx, self.seeds.nbytes).upload(self.seeds)
+        return buf
 
     def replace(self, **kw):
         """Accessors' `@set config.seeds = …` (test/agreement/montecarlo_heston.jl:87)."""
@@ -173,9 +189,9 @@ def solve_montecarlo(prob: PricingProblem, method: MonteCarlo, ensemble: bool = 
     model, c, keep, P, discount = _model_and_config(prob, method)
     cfg = method.config
     ctx = _ffi.get_context(method.device)
-    seeds = cfg.seeds
-    c.seeds = seeds.ctypes.data
-    c.seeds_len = seeds.size
+    seeds_dev = cfg.device_seeds(ctx)
+    c.seeds, c.seeds_on_device = seeds_dev.ptr, 1
+    c.seeds_len = cfg.seeds.size
     if replay is not None:
         replay = np.ascontiguousarray(replay, dtype=np.float64)
         c.noise_mode = _ffi.HH_NOISE_REPLAY
@@ -183,16 +199,19 @@ def solve_montecarlo(prob: PricingProblem, method: MonteCarlo, ensemble: bool = 
         c.replay = replay.ctypes.data
         c.replay_len = replay.size
     anti = bool(c.antithetic)
-    term = None
-    term_ptr = None
-    if ensemble:
-        term = np.empty(c.n_paths * (2 if anti else 1), dtype=np.float64)
-        term_ptr = term.ctypes.data
+    term_dev, fetch = None, None
+    n_paths = int(c.n_paths)
+    if ensemble:  # the samples stay on the device until MonteCarloSolution.ensemble is read
+        term_dev = _ffi.DeviceBuffer(ctx, 8 * n_paths * (2 if anti else 1), pooled=True)
+        c.terminal_on_device = 1
+
+        def fetch(buf=term_dev):  # montecarlo.jl:398-402: vector, or tuple of two for antithetic
+            term = buf.download(np.empty(n_paths * (2 if anti else 1), dtype=np.float64))
+            buf.recycle()
+            return (term[:n_paths], term[n_paths:]) if anti else term
     res = _ffi.hh_result()
-    ctx.check(ctx.lib.hh_mc_solve(ctx.handle, C.byref(model), C.byref(c), C.byref(res), term_ptr))
-    del keep
-    ens = None
-    if term is not None:  # montecarlo.jl:398-402: vector, or tuple of two for antithetic
-        ens = (term[:c.n_paths], term[c.n_paths:]) if anti else term
-    return MonteCarloSolution(prob, method, _price_from(res, discount, P), ens,
-                              std_error=res.std_error, result=res)
+    ctx.check(ctx.lib.hh_mc_solve(ctx.handle, C.byref(model), C.byref(c), C.byref(res),
+                                  term_dev.ptr if term_dev else None))
+    del keep, seeds_dev
+    return MonteCarloSolution(prob, method, _price_from(res, discount, P), None,
+                              std_error=res.std_error, result=res, fetch=fetch)

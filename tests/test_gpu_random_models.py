@@ -4,8 +4,14 @@ test_gpu_parity.py pin the arithmetic on the reference's own parameter sets; thi
 dependence on the VALUES (clipped variances, deep in / out of the money strikes, negative vol-of-vol
 as in SURVEY Q2, correlation at ±1, tiny and long maturities, ragged sizes).
 
-Tolerances as in test_gpu_parity.py: REPLAY 1e-12, GENERATE 1e-11 (different libm), Greeks 1e-9
-(relative to the Greek or to price / parameter, whichever is larger)."""
+Tolerances.  REPLAY (identical increments, identical operations): samples and price 2e-11 (rounding of
+x_T reappears in exp(x_T) scaled by |x_T|), Greeks 1e-9 relative to the Greek or to price / parameter,
+whichever is larger.  GENERATE: the normals of the two sides differ in the last bit (different libm
+behind log / sincos), and the scheme is ILL-CONDITIONED where the variance touches its clip — v = 1e-17
+against v = 0 after a cancellation is sqrt(v⁺) = 3e-9 against 0, and ∂sqrt(v)/∂v = 1/(2 sqrt v) is
+unbounded there (hypothesis finds such models at once: V0 = 1e-4, κ = 0.01, σ = 0.5 moves one sample
+in 257 by 3e-9 and gives ∂price/∂V0 = -1.3e6 ± 4e-3).  So GENERATE is held to 1e-6 here; the 1e-11
+bar on the reference's own parameter sets is test_gpu_parity.py's."""
 import numpy as np
 import pytest
 from hypothesis import HealthCheck, given, settings
@@ -42,16 +48,15 @@ def _run(hhlib, oracle, prm, dyn, n_paths, n_steps, anti, split, noise, P, salt)
                       seeds=seeds, replay=rep, n_partials=P)
     rg, tg = gpu_solve(hhlib, m, c)
     ro, to, _ = oracle.mc_solve(m, c)
-    tol = 1e-12 if noise == REP else 1e-11
-    # a sample is exp(x_T): rounding of x_T (|x_T| up to ~10) reappears scaled by |x_T|
-    np.testing.assert_allclose(tg, to, rtol=20 * tol, atol=0)
-    assert rg.price == pytest.approx(ro.price, rel=20 * tol, abs=1e-13 * prm["S0"])
+    tol, tol_d = (2e-11, 1e-9) if noise == REP else (1e-6, 1e-6)
+    np.testing.assert_allclose(tg, to, rtol=tol, atol=0)
+    assert rg.price == pytest.approx(ro.price, rel=tol, abs=1e-13 * prm["S0"])
     for k, nm in enumerate(names):
         scale = max(abs(ro.dprice[k]), abs(ro.price) / max(abs(getattr(m, nm)), 1e-2))
-        assert abs(rg.dprice[k] - ro.dprice[k]) <= 1e-9 * scale + 1e-13 * prm["S0"], (nm, rg.dprice[k], ro.dprice[k])
+        assert abs(rg.dprice[k] - ro.dprice[k]) <= tol_d * scale + 1e-13 * prm["S0"], (nm, rg.dprice[k], ro.dprice[k])
 
 
-@settings(max_examples=60, deadline=None, derandomize=True,
+@settings(max_examples=60, deadline=None, derandomize=True, database=None,
           suppress_health_check=[HealthCheck.function_scoped_fixture])
 @given(prm=model_st, n_paths=st.sampled_from([1, 63, 257, 1000, 2049]),
        n_steps=st.sampled_from([1, 2, 7, 8, 9, 16, 50]), anti=st.booleans(), split=st.booleans(),
@@ -60,7 +65,7 @@ def test_heston_euler_random_models(hhlib, oracle, prm, n_paths, n_steps, anti, 
     _run(hhlib, oracle, prm, HES, n_paths, n_steps, int(anti), int(split), noise, P, salt)
 
 
-@settings(max_examples=30, deadline=None, derandomize=True,
+@settings(max_examples=30, deadline=None, derandomize=True, database=None,
           suppress_health_check=[HealthCheck.function_scoped_fixture])
 @given(prm=model_st, n_paths=st.sampled_from([1, 255, 1000, 2049]),
        n_steps=st.sampled_from([1, 2, 3, 8, 9, 33]), anti=st.booleans(),

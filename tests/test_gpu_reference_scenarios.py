@@ -118,6 +118,25 @@ def test_solution_is_consistent_with_its_ensemble():
             pay = prob.payoff(sol.ensemble)
         assert sol.price == pytest.approx(D * pay.mean(), rel=1e-12)
         assert sol.problem is prob and sol.method.config is cfg
+        assert sol.ensemble is sol.ensemble  # downloaded once, on the first read
+
+
+def test_repeated_solves_reuse_the_device_seeds_and_sample_buffers():
+    """The host mirror keeps a config's seeds on the device and recycles the sample buffer: a second
+    solve gives the same price and samples, and solves whose samples are never read leave nothing
+    behind but the pool's few buffers."""
+    prob = heston_problem()
+    cfg = hh.SimulationConfig(20_000, steps=20, seeds=np.arange(1, 20_001))
+    method = hh.MonteCarlo(hh.HestonDynamics(), hh.EulerMaruyama(), cfg)
+    a = hh.solve(prob, method)
+    ens_a = a.ensemble.copy()
+    for _ in range(20):
+        b = hh.solve(prob, method)  # samples never read: the buffer goes back to the pool with `b`
+    assert b.price == a.price
+    np.testing.assert_array_equal(b.ensemble, ens_a)
+    ctx = hh.get_context(0)
+    assert len(cfg._seeds_dev) == 1 and len(ctx.__dict__.get("_pool", [])) <= ctx._POOL_MAX
+    assert hh.solve(prob, method, ensemble=False).ensemble is None
 
 
 def test_heston_euler_vs_carr_madan():

@@ -40,6 +40,15 @@ def test_simulation_config_contract():
         hh.SimulationConfig(10, seeds=[1, 2, 3])
     c2 = cfg.replace(seeds=np.arange(20), variance_reduction=hh.Antithetic())
     assert c2.trajectories == 10 and isinstance(c2.variance_reduction, hh.Antithetic)
+    # the config owns a frozen copy of its seeds (its device copies are cached with it): the caller's
+    # array stays the caller's, and a config made from a config shares the frozen vector
+    mine = np.arange(1, 11, dtype=np.uint64)
+    c3 = hh.SimulationConfig(10, seeds=mine)
+    mine[0] = 99
+    assert c3.seeds[0] == 1 and mine.flags.writeable and not c3.seeds.flags.writeable
+    with pytest.raises(ValueError):
+        c3.seeds[0] = 5
+    assert c3.replace(steps=7).seeds is c3.seeds
 
 
 def test_model_packing_heston_euler():
