@@ -758,7 +758,7 @@ static int run_heston_grid(hh_ctx* ctx, const hh_model* m, const hh_config* c) {
     const hh::BkTransition tr{ctx->lsm_grid + (size_t)k * n, ctx->heston_var + (size_t)k * n,
                               ctx->lsm_grid + (size_t)(k + 1) * n,
                               ctx->heston_var + (size_t)(k + 1) * n, k};
-    HH_HIP(ctx, hh::launch_bk(step_model, step_cfg, p, ctx->stream, &tr));
+    HH_HIP(ctx, hh::launch_bk(step_model, step_cfg, p, ctx->stream, &tr, /*upload_tables=*/k == 0));
     HH_HIP(ctx, hh::launch_reduce_records(ctx->records, hh::bk_record_count(n), (double)n,
                                           ctx->basket_accum + (size_t)k * HH_ACC_LEN, ctx->stream,
                                           1, &step_model, &step_cfg));

@@ -6,9 +6,15 @@
 //                             factor: the CF exponentiates log I anyway, so log(sum) would be wasted
 //
 //   |z| <  13              ascending series (10.25.2) at order ν
-//   |z| >= 13, 2ν² + 10    Hankel expansion (10.40.5) at order ν
-//   in between (ν >= 1)    Hankel expansion at the base order ν0 = ν - floor(ν), then the ratios
-//                          I_{ν0+k+1}/I_{ν0+k} from the backward recurrence (minimal solution)
+//   |z| >= R_h(ν)          Hankel expansion (10.40.5) at order ν;  R_h = max(13, ν²/6 + 13): its terms behave
+//                          like (ν²/2|z|)^k / k!, 31 of them reach 1e-19 from there
+//   13 <= |z| < R_h        (orders ν >= 1 only) the ascending series again where its terms do not cancel by
+//                          more than e^14: I_ν(|z|)/|I_ν(z)| <= min(exp(|z| - Re z), exp((Im z)²/(2(ν+1)))), so
+//                          where |z| - Re z <= 14 or (Im z)² <= 28 (ν+1), and |z| < R_t(ν), the reach of the
+//                          coefficient table (63 terms); arguments of the CF are mostly of this kind —
+//   else                   Hankel expansion at the base order ν0 = ν - floor(ν), then the ratios
+//                          I_{ν0+k+1}/I_{ν0+k} from the backward recurrence (minimal solution): |z| + ν + 30
+//                          complex divisions, the expensive way
 //
 // Both sums are evaluated by Horner's rule with the number of terms fixed BEFORE the loop from |z|
 // (tables made on the host from ν), instead of term by term with a convergence test: 6 VALU
@@ -56,14 +62,18 @@ HH_MATH_FN cx clog(cx z) { return {fm::log(cabs(z)), fm::atan2(z.im, z.re)}; }
 
 constexpr int kHankelTerms = 32;   // a_0 … a_31
 constexpr int kHankelPairs = 16;   // Horner steps over (a_2m, a_2m+1)
-constexpr int kSeriesTerms = 32;   // most terms of the ascending series (29 are reached at |z| = 13)
-constexpr double kSeriesR = 13.0;  // |z| below which the ascending series is used
+constexpr int kSeriesTerms = 64;   // size of the series table: at most 63 terms (29 at |z| = 13, ν < 1)
+constexpr double kSeriesR = 13.0;  // least |z| at which the series hands over (orders below 6)
 constexpr double kBesselPi = 3.14159265358979323846;
 constexpr double kBesselTwoPi = 6.28318530717958647692;
 
 // Everything that depends on the order alone (host-made, bessel_table()).
 struct BesselTable {
   double nu, lgam;                   // order, lgamma(ν + 1)
+  double series_rmax, hankel_from;   // R_t(ν), R_h(ν) above
+  double series_im2;                 // 28 (ν + 1)
+  double series_n0, series_n1;       // series length at |z| = r: n0 + n1·r (the first omitted term is then
+                                     // below 2^-57 of the largest one, for every r < R_t at THIS ν)
   double hankel[kHankelTerms];       // a_k(ν)  (DLMF 10.17.1)
   double hankel_rmin[kHankelPairs];  // [M]: |z| from which the sum cut after k = 2M+1 has converged
   // ascending series split by parity, c_k = 1 / (k (k + ν)):  [2m] = c_{2m-1} c_{2m} (even half),
@@ -72,24 +82,19 @@ struct BesselTable {
   double series_c1;                  // c_1
 };
 
-// terms of the ascending series needed at |z| = r: the first omitted term (r²/4)^k / (k! (ν+1)_k),
-// k = N+1, is below 2^-58 of the largest term for N = 11.6 + 1.4 r, for every ν > -1 and r < 13
-// (bessel_table() checks the bound for its ν when it builds the table; tests/test_bessel_host.py
-// sweeps ν)
-#if defined(__HIPCC__)
-__host__ __device__ __forceinline__
-#else
-static inline
-#endif
-int series_terms(double r) {
-  const int n = (int)(11.6 + 1.4 * r);
+HH_MATH_FN int series_terms(const BesselTable& t, double r) {
+  const int n = (int)fma(t.series_n1, r, t.series_n0);
   return n < kSeriesTerms ? n : kSeriesTerms;
 }
 
-// host: fills the table for one order; returns false when the term-count bound above does not hold
+// host: fills the table for one order; returns false when no series length within kSeriesTerms
+// meets the bound on [0, R_s) (not for ν > -1 up to a few hundred)
 static inline bool bessel_table(double nu, BesselTable& t) {
   t.nu = nu;
   t.lgam = lgamma(nu + 1.0);
+  const double rh = nu * nu / 6.0 + 13.0;
+  t.hankel_from = rh > kSeriesR ? rh : kSeriesR;
+  t.series_im2 = 28.0 * (nu + 1.0);
   const double mu = 4.0 * nu * nu;
   long double a[kHankelTerms + 2];
   a[0] = 1.0L;
@@ -111,18 +116,44 @@ static inline bool bessel_table(double nu, BesselTable& t) {
     t.series_de[2 * m + 1] = (double)(c(2 * m) * c(2 * m + 1));
   }
   t.series_c1 = (double)c(1);
-  bool ok = true;
-  for (int i = 1; i <= (int)(kSeriesR * 16.0); ++i) {  // first omitted term against the bound
-    const long double r = i / 16.0L, q = 0.25L * r * r;
-    const int N = series_terms((double)r);
+  // terms needed at r: the smallest N past the largest term with T_{N+1} < 2^-57 max_k T_k, for r up to
+  // R_h or as far as the table reaches (R_t); then the line n0 + n1 r above all of them on (0, R_t]
+  // with the least mean (the loop length a lane computes from its r)
+  constexpr int kGrid = 8;
+  int need[4096];
+  int npts = 0;
+  for (int i = 1; i <= 4096 && (double)(i - 1) / kGrid < t.hankel_from; ++i) {
+    const long double r = (long double)i / kGrid, q = 0.25L * r * r;
     long double term = 1.0L, largest = 1.0L;
-    for (int k = 1; k <= N + 1; ++k) {
+    int k_largest = 0, N = -1;
+    for (int k = 1; k < 400; ++k) {
       term *= q / ((long double)k * (k + (long double)nu));
-      if (k <= N && term > largest) largest = term;
+      if (term > largest) { largest = term; k_largest = k; }
+      else if (k > k_largest && term < 0x1p-57L * largest) { N = k - 1; break; }
     }
-    if (term > 0x1p-57L * largest) ok = false;
+    if (N < 0 || N + 3 > kSeriesTerms) break;
+    need[npts++] = N;
   }
-  return ok;
+  if (npts < (int)(kSeriesR * kGrid)) return false;  // the table must reach |z| = 13
+  t.series_rmax = (double)npts / kGrid;
+  if (t.series_rmax > t.hankel_from) t.series_rmax = t.hankel_from;
+  double best_n0 = 0.0, best_n1 = 0.0, best_sum = 1e300;
+  for (int j = 0; j <= 30; ++j) {
+    const double n1 = 0.1 * j;
+    double n0 = 0.0;
+    for (int i = 1; i <= npts; ++i) {
+      const double v = need[i - 1] + 1.0 - n1 * ((double)(i - 1) / kGrid);  // holds on [r_{i-1}, r_i]
+      if (v > n0) n0 = v;
+    }
+    const double sum = n0 + 0.5 * n1 * t.series_rmax;  // mean length over the range
+    if (sum < best_sum && n0 + n1 * t.series_rmax + 1.0 <= (double)kSeriesTerms) {
+      best_sum = sum; best_n0 = n0; best_n1 = n1;
+    }
+  }
+  if (best_sum == 1e300) return false;
+  t.series_n0 = best_n0 + 0.01;
+  t.series_n1 = best_n1;
+  return true;
 }
 
 // the largest n (0 … 63) among the active lanes of the wave
@@ -162,14 +193,14 @@ HH_MATH_FN void horner2(cx& X, cx& Y, cx u, double cx_, double cy_) {
   Y = {fma(Y.re, u.re, fma(-Y.im, u.im, cy_)), fma(Y.re, u.im, Y.im * u.re)};
 }
 
-// I_ν(z) by the ascending series (DLMF 10.25.2), Re z >= 0, |z| = r < kSeriesR, arg z = phi:
+// I_ν(z) by the ascending series (DLMF 10.25.2), Re z >= 0, |z| = r < t.series_rmax (R_t), arg z = phi:
 //   I = (z/2)^ν / Γ(ν+1) · Σ_k T_k,  T_k = q^k / (k! (ν+1)_k) = T_{k-1} c_k q,  q = z²/4.
 // Even and odd terms apart, Q = q²:  Σ T_2m = 1 + d_1 Q (1 + d_2 Q (1 + …)),  d_m = c_{2m-1} c_{2m};
 //                                    Σ T_2m+1 = c_1 q (1 + e_1 Q (1 + e_2 Q (1 + …))),  e_m = c_{2m} c_{2m+1}
 HH_MATH_FN LogMul besseli_series(const BesselTable& t, cx z, double r, double phi) {
   const cx q = 0.25 * (z * z);
   const cx Q = q * q;
-  const int Mh = (series_terms(r) + 1) >> 1;  // steps of each half
+  const int Mh = (series_terms(t, r) + 1) >> 1;  // steps of each half
   cx A = {1.0, 0.0}, B = {1.0, 0.0};
   int m = uniform_index((wave_max6(Mh) + 1) & ~1);  // even: steps (m, m-1) down to (2, 1)
   const double* tab = t.series_de;
@@ -197,7 +228,7 @@ HH_MATH_FN LogMul besseli_series(const BesselTable& t, cx z, double r, double ph
   return {{t.nu * fm::log(0.5 * r) - t.lgam, t.nu * phi}, S};
 }
 
-// I_ν(z) by the Hankel expansion (DLMF 10.40.5), Re z >= 0, |z| = r >= kSeriesR:
+// I_ν(z) by the Hankel expansion (DLMF 10.40.5), Re z >= 0, |z| = r >= t.hankel_from:
 //   I = e^z/sqrt(2πz) [S1 + e^{-2z ± iπ(ν+1/2)} S2],  S2 = Σ a_k w^k,  S1 = Σ (-1)^k a_k w^k,  w = 1/z,
 // upper sign for Im z >= 0.  With E = Σ a_2m u^m, O = Σ a_2m+1 u^m, u = w²: S2 = E + wO, S1 = E - wO.
 // The sums are cut after k = 2M+1 where the next term is below 2^-55 — or, for r < 15.5 where the
@@ -248,27 +279,38 @@ HH_MATH_FN LogMul besseli_logmul(const BesselTable& t, const BesselTable& t0, in
   LogMul res;
   if (r < kSeriesR) {
     res = besseli_series(t, z, r, phi);
-  } else if (n_int == 0 || r >= 2.0 * t.nu * t.nu + 10.0) {
+  } else if (n_int == 0 || r >= t.hankel_from) {
     res = besseli_asym(t, z, r, phi);
+  } else if (r < t.series_rmax && (r - z.re <= 14.0 || z.im * z.im <= t.series_im2)) {
+    res = besseli_series(t, z, r, phi);
   } else {
     // base order ν0, then I_ν = I_ν0 · Π_{k<n} I_{ν0+k+1}/I_{ν0+k}; the ratios come from the backward
-    // recurrence r_k = 1 / (2(ν0+k+1)/z + r_{k+1}), the minimal solution for Re z >= 0
+    // recurrence r_k = 1 / (2(ν0+k+1)/z + r_{k+1}), the minimal solution for Re z >= 0.  |r_k| < 1: the
+    // product is taken 32 ratios at a time and folded into the logarithm (a product of 32 cannot leave
+    // the fp64 range; one complex log per ratio was 115 instructions each).
     res = besseli_asym(t0, z, r, phi);
     const cx w = cdiv({2.0, 0.0}, z);
     const int n = n_int;
     int N = n + (int)r + 30;
     if (N > 4000) N = 4000;
-    cx rk = {0.0, 0.0};
+    cx rk = {0.0, 0.0}, prod = {1.0, 0.0};
+    int in_prod = 0;
     for (int k = N - 1; k >= 0; --k) {
       const double o = t0.nu + (double)k + 1.0;
       rk = cdiv({1.0, 0.0}, {o * w.re + rk.re, o * w.im + rk.im});
       if (k < n) {
-        if (n <= 16) {  // |r_k| < 1: a short product cannot leave the fp64 range
-          res.mul = res.mul * rk;
-        } else {
-          res.lg = res.lg + clog(rk);
+        prod = prod * rk;
+        if (++in_prod == 32) {
+          res.lg = res.lg + clog(prod);
+          prod = {1.0, 0.0};
+          in_prod = 0;
         }
       }
+    }
+    if (n <= 16) {
+      res.mul = res.mul * prod;
+    } else if (in_prod > 0) {
+      res.lg = res.lg + clog(prod);
     }
   }
   res.lg.im += refl;

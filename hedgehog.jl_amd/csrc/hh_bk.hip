@@ -39,6 +39,10 @@ constexpr double kTwoPi = kBesselTwoPi;
 constexpr int kPackedGrid = 256;  // workgroups of the packed (grid-stride) ladder kernel
 constexpr int kHeavyGrid = 64;    // … of the fall-back kernel (empty with the reference's controls)
 
+struct BkTables {
+  BesselTable t[2];  // order ν, base order ν0
+};
+
 struct BkArgs {
   // model
   double kappa, theta, sigma, sigma2, inv_sigma2, rho, V0, T, logS0, r, strike, cp;
@@ -46,9 +50,14 @@ struct BkArgs {
   double d, lam_num, lam_den, cscale;
   // HestonCFIterator constants (heston.jl:167-172)
   double nu, zeta_k, eta_k, nuk_factor;  // ν_κ = nuk_factor·sqrt(V0·VT)
-  // Bessel tables (host-made: they depend on ν only) of ν and of the base order ν0 = ν - n_int
+  // Bessel tables (host-made: they depend on ν only) of ν and of the base order ν0 = ν - n_int, in
+  // device memory (written by bk_tables_kernel), handed to the kernels that evaluate the CF as an
+  // argument of their own.  NOT by value in this block: with 2 KB of tables in the kernel arguments, indexed in loops, the
+  // compiler keeps the block in the argument segment only while it can follow every use — one more
+  // inlined copy of the CF code and the whole block is copied to scratch, per lane, at kernel entry
+  // (2.4 KB per lane; the CF kernel ran 2.2x slower).
   int n_int;
-  BesselTable bes_nu, bes_nu0;
+  const BkTables* tabs_dev;
   // controls (sample_from_cf.jl:27,50,75,105-113)
   double n_sigma, cf_tol, atol, moment_h;
   int newton_maxiter, bisect_maxiter;
@@ -101,7 +110,8 @@ struct CfIter {
 };
 
 // evaluate_chf (heston.jl:184-212).  theta_prev = NaN starts a new unwrapping sequence.
-__device__ cx evaluate_chf(const BkArgs& p, const CfIter& it, double a, double& theta_prev) {
+__device__ __forceinline__ cx evaluate_chf(const BkArgs& p, const BesselTable* bt, const CfIter& it, double a,
+                                           double& theta_prev) {
   const cx g = csqrt({p.kappa * p.kappa, -2.0 * p.sigma2 * a});
   const cx eh = cexp({-0.5 * g.re * p.T, -0.5 * g.im * p.T});  // exp(-γT/2)
   const cx e = eh * eh;                                          // exp(-γT)
@@ -123,7 +133,7 @@ __device__ cx evaluate_chf(const BkArgs& p, const CfIter& it, double a, double& 
     thu = theta_prev + dl;
   }
   theta_prev = thu;
-  LogMul I = besseli_logmul(p.bes_nu, p.bes_nu0, p.n_int, nu_g, th);  // principal branch at |ν_γ| cis(θ_unwrapped)
+  LogMul I = besseli_logmul(bt[0], bt[1], p.n_int, nu_g, th);  // principal branch at |ν_γ| cis(θ_unwrapped)
   I.lg.im += p.nu * (thu - th);            // + i ν (θ_unwrapped − θ)  (heston.jl:207)
   // ϕ = e^{-(γ-κ)T/2} (ζκ/ζγ) · exp((V0+VT)/σ² (ηκ-ηγ)) · Iγ / Iκ
   const cx ex = {-0.5 * (g.re - p.kappa) * p.T + it.sumV * (p.eta_k - eta_g.re) + I.lg.re - it.logI_k,
@@ -148,7 +158,7 @@ struct PhiCache {
 };
 
 // cdf_from_cf (sample_from_cf.jl:75-96)
-__device__ double cdf_from_cf(const BkArgs& p, const CfIter& it, double x, double h, PhiCache& c,
+__device__ double cdf_from_cf(const BkArgs& p, const BesselTable* bt, const CfIter& it, double x, double h, PhiCache& c,
                               double& n_terms) {
   if (x < 0.0) return 0.0;
   double result = h * x / kPi;
@@ -168,7 +178,7 @@ __device__ double cdf_from_cf(const BkArgs& p, const CfIter& it, double x, doubl
       last = j == c.j_stop;
     } else {
       double& th = (j <= c.cap || c.filled < c.cap) ? c.theta_run : theta_tail;
-      const cx phi = evaluate_chf(p, it, aj, th);
+      const cx phi = evaluate_chf(p, bt, it, aj, th);
       re = phi.re;
       last = !(cabs(phi) >= stop * (double)j);  // |ϕ|/j < π·tol/2 (sample_from_cf.jl:88); also leaves on NaN
       if (j > c.filled) {  // first time this term is seen
@@ -309,12 +319,12 @@ __global__ __launch_bounds__(kTile) void bk_draw_kernel(const BkArgs p) {
 
 // HestonCFIterator (heston.jl:165-176) and the moment heuristics (sample_from_cf.jl:31-37) of one
 // trajectory, from its start variance, its V_T and the normal quantile of its uniform
-__device__ __forceinline__ void cf_setup(const BkArgs& p, double V0, double VT, double q_u, CfIter& cf,
+__device__ __forceinline__ void cf_setup(const BkArgs& p, const BesselTable* bt, double V0, double VT, double q_u, CfIter& cf,
                                          double& initial_guess, double& max_guess, double& h) {
   cf.VT = VT;
   cf.sqrtV0VT = sqrt(V0 * VT);
   cf.sumV = (V0 + VT) / p.sigma2;
-  const LogMul Ik = besseli_logmul(p.bes_nu, p.bes_nu0, p.n_int, {p.nuk_factor * cf.sqrtV0VT, 0.0}, 0.0);
+  const LogMul Ik = besseli_logmul(bt[0], bt[1], p.n_int, {p.nuk_factor * cf.sqrtV0VT, 0.0}, 0.0);
   cf.logI_k = Ik.lg.re + fm::log(Ik.mul.re);  // real, positive argument: I_ν > 0
   // moments_from_cf (sample_from_cf.jl:50-61): mean = Re(-i ϕ'(0)), variance = Re(-ϕ''(0)) - mean²
   // by central differences of step hm over ϕ(hm), ϕ(0), ϕ(-hm).  The law is real, so ϕ(-a) is the
@@ -324,8 +334,8 @@ __device__ __forceinline__ void cf_setup(const BkArgs& p, double V0, double VT, 
   // formed from numbers 1e-10 apart.
   double th = __builtin_nan("");
   const double hm = p.moment_h;
-  const cx pp = evaluate_chf(p, cf, hm, th);
-  const cx p0 = evaluate_chf(p, cf, 0.0, th);
+  const cx pp = evaluate_chf(p, bt, cf, hm, th);
+  const cx p0 = evaluate_chf(p, bt, cf, 0.0, th);
   const double mean = pp.im / hm;                                          // (ϕ₊ - ϕ₋)/(2h)
   const double var = -(2.0 * (pp.re - p0.re) / (hm * hm)) - mean * mean;  // (ϕ₊ - 2ϕ₀ + ϕ₋)/h²
   const double sd = sqrt(fmax(var, 1e-12));
@@ -343,7 +353,7 @@ struct PathSetup {
   double initial_guess, max_guess, h;
 };
 
-__device__ void bk_setup(const BkArgs& p, uint64_t path, PathSetup& s) {
+__device__ void bk_setup(const BkArgs& p, const BesselTable* bt, uint64_t path, PathSetup& s) {
   s.cache.col = p.phi_cache + path;  // the trajectory's own column, filled again from the start
   s.cache.stride = p.cache_stride;
   s.cache.cap = p.cache_cap;
@@ -358,7 +368,7 @@ __device__ void bk_setup(const BkArgs& p, uint64_t path, PathSetup& s) {
   s.Z = d[0];
   s.u = d[p.draw_stride];
   s.VT = d[3 * p.draw_stride];
-  cf_setup(p, s.V0, s.VT, d[2 * p.draw_stride], s.cf, s.initial_guess, s.max_guess, s.h);
+  cf_setup(p, bt, s.V0, s.VT, d[2 * p.draw_stride], s.cf, s.initial_guess, s.max_guess, s.h);
 }
 
 // 3. log S_T (heston.jl:288-297), S_T = exp(.) (montecarlo.jl:384), payoff
@@ -458,7 +468,7 @@ __device__ __forceinline__ bool secant_inverse(Cdf&& cdf, double u, double guess
 // is what fits 128 registers (4 waves per SIMD).  Returns h, the secant's first guess and the series
 // length (0: longer than the cache — the fall-back kernel runs this trajectory whole); leaves them
 // with max_guess in rec[] for the ladder kernel.
-__device__ __forceinline__ void series_phase(const BkArgs& p, uint64_t path, double& h, double& initial_guess,
+__device__ __forceinline__ void series_phase(const BkArgs& p, const BesselTable* bt, uint64_t path, double& h, double& initial_guess,
                                              int& j_stop) {
   const bool grid = p.in_var != nullptr;
   const double V0 = grid ? p.in_var[path] : p.V0;
@@ -467,13 +477,13 @@ __device__ __forceinline__ void series_phase(const BkArgs& p, uint64_t path, dou
   const double VT = d[3 * p.draw_stride];
   CfIter cf;
   double max_guess;
-  cf_setup(p, V0, VT, q_u, cf, initial_guess, max_guess, h);
+  cf_setup(p, bt, V0, VT, q_u, cf, initial_guess, max_guess, h);
   double* col = p.phi_cache + path;
   const double stop = kPi * p.cf_tol / 2.0;
   double theta = __builtin_nan("");
   j_stop = 0;
   for (int j = 1; j <= p.cache_cap; ++j) {
-    const cx phi = evaluate_chf(p, cf, h * (double)j, theta);
+    const cx phi = evaluate_chf(p, bt, cf, h * (double)j, theta);
     col[(size_t)(j - 1) * p.cache_stride] = phi.re;
     const double sj = stop * (double)j;
     if (!(fma(phi.re, phi.re, phi.im * phi.im) >= sj * sj)) {  // |ϕ|/j < π·tol/2, squared; also leaves on NaN
@@ -585,21 +595,27 @@ __device__ __forceinline__ void invert_phase(const BkArgs& p, uint32_t tile, uin
 #ifndef HH_BK_FUSED
 #define HH_BK_FUSED 1
 #endif
-__global__ __launch_bounds__(kTile) void bk_cf_kernel(const BkArgs p) {
+// (tabs: the Bessel tables, a `const __restrict__` kernel argument of its own so that the compiler
+// knows them read-only and un-aliased: their uniform-index reads are then scalar loads, as they were
+// from the argument block; staged in LDS instead, the per-order scalars and the coefficients in
+// flight sit in VGPRs and the kernel needs 192)
+__global__ __launch_bounds__(kTile) void bk_cf_kernel(const BkArgs p, const BkTables* __restrict__ tabs) {
   const uint32_t tile = blockIdx.x, tid = threadIdx.x;
   const uint64_t path = (uint64_t)tile * kTile + tid;
   const bool live = path < p.n_paths;
+  const BesselTable* bt = tabs->t;
   double h = 0.0, guess = 0.0;
   int j_stop = 0;
-  if (live) series_phase(p, path, h, guess, j_stop);
+  if (live) series_phase(p, bt, path, h, guess, j_stop);
   invert_phase(p, tile, tid, path, live, h, guess, j_stop);
 }
-__global__ __launch_bounds__(kTile) void bk_series_kernel(const BkArgs p) {
+__global__ __launch_bounds__(kTile) void bk_series_kernel(const BkArgs p, const BkTables* __restrict__ tabs) {
   const uint64_t path = (uint64_t)blockIdx.x * kTile + threadIdx.x;
+  const BesselTable* bt = tabs->t;
   if (path >= p.n_paths) return;
   double h, guess;
   int j_stop;
-  series_phase(p, path, h, guess, j_stop);
+  series_phase(p, bt, path, h, guess, j_stop);
 }
 __global__ __launch_bounds__(kTile) void bk_invert_kernel(const BkArgs p) {
   const uint32_t tile = blockIdx.x, tid = threadIdx.x;
@@ -762,24 +778,26 @@ __global__ __launch_bounds__(kTile) void bk_ladder_kernel(const BkArgs p, uint32
 // cache on every use, as the reference does with all of them.  Densely packed, grid stride; with
 // the default controls there are none and the launch returns at once.
 __global__ __launch_bounds__(kTile) void bk_fallback_kernel(const BkArgs* __restrict__ args,
+                                                            const BkTables* __restrict__ tabs,
                                                             uint32_t n_tiles,
                                                             const uint32_t* __restrict__ prefix) {
   const uint32_t total = prefix[n_tiles];
   const BkArgs& p = *args;
+  const BesselTable* bt = tabs->t;
   double acc[6] = {0, 0, 0, 0, 0, 0};
   for (uint32_t g = blockIdx.x * kTile + threadIdx.x; g < total; g += gridDim.x * kTile) {
     const uint64_t path = packed_path(p.long_mask, prefix, n_tiles, g);
     PathSetup s;
-    bk_setup(p, path, s);
+    bk_setup(p, bt, path, s);
     double n_terms = 0.0;
     double IV;
     const bool done =
-        secant_inverse([&](double x) { return cdf_from_cf(p, s.cf, x, s.h, s.cache, n_terms); }, s.u,
+        secant_inverse([&](double x) { return cdf_from_cf(p, bt, s.cf, x, s.h, s.cache, n_terms); }, s.u,
                        s.initial_guess, p.atol, p.newton_maxiter, IV);
     if (!done) {  // the fall-back ladder (sample_from_cf.jl:123-133)
       acc[2] += 1.0;
-      double fa = cdf_from_cf(p, s.cf, 0.0, s.h, s.cache, n_terms) - s.u;
-      const double fb = cdf_from_cf(p, s.cf, s.max_guess, s.h, s.cache, n_terms) - s.u;
+      double fa = cdf_from_cf(p, bt, s.cf, 0.0, s.h, s.cache, n_terms) - s.u;
+      const double fb = cdf_from_cf(p, bt, s.cf, s.max_guess, s.h, s.cache, n_terms) - s.u;
       if (fa * fb > 0.0) {
         acc[4] += 1.0;
         IV = s.max_guess;  // sample_from_cf.jl:124-126
@@ -788,7 +806,7 @@ __global__ __launch_bounds__(kTile) void bk_fallback_kernel(const BkArgs* __rest
         double lo_x = 0.0, hi_x = s.max_guess;
         for (int i = 0; i < p.bisect_maxiter; ++i) {
           const double mid = 0.5 * (lo_x + hi_x);
-          const double fm = cdf_from_cf(p, s.cf, mid, s.h, s.cache, n_terms) - s.u;
+          const double fm = cdf_from_cf(p, bt, s.cf, mid, s.h, s.cache, n_terms) - s.u;
           if (fm == 0.0) {
             lo_x = hi_x = mid;
             break;
@@ -810,6 +828,16 @@ __global__ __launch_bounds__(kTile) void bk_fallback_kernel(const BkArgs* __rest
     acc[1] = fma(pay, pay, acc[1]);
   }
   bk_store_record(acc, p.records + (size_t)(n_tiles + kPackedGrid + blockIdx.x) * kRecStride);
+}
+
+// The host-made tables into device memory: ONE lane, constant indices (a lane-indexed read of the
+// by-value argument would again send the block through scratch), the compiler batches the scalar loads.
+__global__ __launch_bounds__(64) void bk_tables_kernel(const BkTables t, BkTables* __restrict__ dst) {
+  if (threadIdx.x != 0) return;
+  const double* src = reinterpret_cast<const double*>(&t);
+  double* out = reinterpret_cast<double*>(dst);
+#pragma unroll
+  for (size_t i = 0; i < sizeof(BkTables) / sizeof(double); ++i) out[i] = src[i];
 }
 
 __global__ __launch_bounds__(256) void fill_rows_kernel(double* __restrict__ spot0,
@@ -835,7 +863,7 @@ static int phi_cache_cap(size_t n_tiles) {
   return (int)cap;
 }
 
-// ballots (fail, long) | prefix sums (fail, long) | tile counts | device copy of the argument block
+// ballots (fail, long) | prefix sums (fail, long) | tile counts | device copy of the argument block | Bessel tables
 static size_t bk_masks_bytes(size_t n_tiles) {
   return 2 * n_tiles * (kTile / 64) * sizeof(unsigned long long);
 }
@@ -843,8 +871,11 @@ static size_t bk_args_offset(size_t n_tiles) {  // … + prefix sums [2][n_tiles
   const size_t b = bk_masks_bytes(n_tiles) + (2 * (n_tiles + 1) + n_tiles) * sizeof(uint32_t);
   return (b + 255) & ~(size_t)255;
 }
-static size_t bk_flags_bytes(size_t n_tiles) {
+static size_t bk_tables_offset(size_t n_tiles) {
   return bk_args_offset(n_tiles) + ((sizeof(BkArgs) + 255) & ~(size_t)255);
+}
+static size_t bk_flags_bytes(size_t n_tiles) {
+  return bk_tables_offset(n_tiles) + ((sizeof(BkTables) + 255) & ~(size_t)255);
 }
 
 int launch_fill_rows(double* spot0, double* var0, uint64_t n, double S0, double V0, hipStream_t s) {
@@ -864,7 +895,7 @@ size_t bk_scratch_bytes(uint64_t n_paths) {
 }
 
 int launch_bk(const hh_model& m, const hh_config& c, const DevicePtrs& ptr, hipStream_t s,
-              const BkTransition* tr) {
+              const BkTransition* tr, bool upload_tables) {
   BkArgs a{};
   if (tr) {
     a.in_spot = tr->in_spot; a.in_var = tr->in_var;
@@ -886,8 +917,9 @@ int launch_bk(const hh_model& m, const hh_config& c, const DevicePtrs& ptr, hipS
   if (!(a.d > 0.0) || !std::isfinite(a.d) || !(a.lam_num * m.V0 / a.lam_den >= 0.0))
     return (int)hipErrorInvalidValue;
   a.n_int = a.nu >= 1.0 ? (int)floor(a.nu) : 0;
-  if (!bessel_table(a.nu, a.bes_nu) || !bessel_table(a.nu - a.n_int, a.bes_nu0))
-    return (int)hipErrorInvalidValue;  // the series-length bound of hh_bessel.h does not hold: not for ν > -1
+  BkTables tabs;
+  if (upload_tables && (!bessel_table(a.nu, tabs.t[0]) || !bessel_table(a.nu - a.n_int, tabs.t[1])))
+    return (int)hipErrorInvalidValue;  // the series table of hh_bessel.h does not reach |z| = 13: not for ν > -1
   a.n_sigma = c.bk_n_sigma > 0.0 ? c.bk_n_sigma : 5.0;
   a.cf_tol = c.bk_cf_tol > 0.0 ? c.bk_cf_tol : 1e-3;
   a.atol = c.bk_atol > 0.0 ? c.bk_atol : 1e-4;
@@ -909,6 +941,8 @@ int launch_bk(const hh_model& m, const hh_config& c, const DevicePtrs& ptr, hipS
   uint32_t* prefix_long = prefix + n_tiles + 1;
   a.tile_counts = prefix_long + n_tiles + 1;
   a.args_dev = base + bk_args_offset(n_tiles);
+  BkTables* tabs_dev = reinterpret_cast<BkTables*>(base + bk_tables_offset(n_tiles));
+  a.tabs_dev = tabs_dev;
   a.phi_cache = reinterpret_cast<double*>(base + bk_flags_bytes(n_tiles));
   a.cache_stride = lanes;
   a.cache_cap = phi_cache_cap(n_tiles);
@@ -917,20 +951,22 @@ int launch_bk(const hh_model& m, const hh_config& c, const DevicePtrs& ptr, hipS
   a.draw_stride = lanes;
   a.replay = c.noise_mode == HH_NOISE_REPLAY ? ptr.replay : nullptr;
   const dim3 g(n_tiles), b(kTile);
+  if (upload_tables) hipLaunchKernelGGL(bk_tables_kernel, dim3(1), dim3(64), 0, s, tabs, tabs_dev);
   if (a.replay)
     hipLaunchKernelGGL(bk_draw_kernel<true>, g, b, 0, s, a);
   else
     hipLaunchKernelGGL(bk_draw_kernel<false>, g, b, 0, s, a);
 #if HH_BK_FUSED
-  hipLaunchKernelGGL(bk_cf_kernel, g, b, 0, s, a);
+  hipLaunchKernelGGL(bk_cf_kernel, g, b, 0, s, a, static_cast<const BkTables*>(tabs_dev));
 #else
-  hipLaunchKernelGGL(bk_series_kernel, g, b, 0, s, a);
+  hipLaunchKernelGGL(bk_series_kernel, g, b, 0, s, a, static_cast<const BkTables*>(tabs_dev));
   hipLaunchKernelGGL(bk_invert_kernel, g, b, 0, s, a);
 #endif
   hipLaunchKernelGGL(bk_scan_kernel, dim3(1), dim3(kScanThreads), 0, s, a, n_tiles, prefix, prefix_long);
   hipLaunchKernelGGL(bk_ladder_kernel, dim3(kPackedGrid), b, 0, s, a, n_tiles, prefix);
   hipLaunchKernelGGL(bk_fallback_kernel, dim3(kHeavyGrid), b, 0, s,
-                     static_cast<const BkArgs*>(a.args_dev), n_tiles, prefix_long);
+                     static_cast<const BkArgs*>(a.args_dev), static_cast<const BkTables*>(tabs_dev), n_tiles,
+                     prefix_long);
   return (int)hipGetLastError();
 }
 

@@ -90,8 +90,10 @@ struct BkTransition {
   double* out_var;
   uint32_t step;
 };
+// upload_tables = false: the Bessel tables of this (κ, θ, σ) are already in p.bk_scratch from an earlier
+// launch_bk on the SAME scratch buffer and trajectory count (the dates of one exact grid)
 int launch_bk(const hh_model& m, const hh_config& c, const DevicePtrs& p, hipStream_t s,
-              const BkTransition* tr = nullptr);
+              const BkTransition* tr = nullptr, bool upload_tables = true);
 size_t bk_scratch_bytes(uint64_t n_paths);
 uint32_t bk_record_count(uint64_t n_paths);  // records the Broadie–Kaya chain writes (inversion tiles + packed kernels)
 // the four Broadie–Kaya counter slots of `src` (HH_ACC_LEN doubles) into each of n_groups accumulators

@@ -30,6 +30,13 @@ PARAMS = {
     # low vol-of-vol: d = 32, ν = 15 (ratio recurrence), put
     "large_nu": dict(S0=100.0, V0=0.05, kappa=2.0, theta=0.04, sigma=0.1, rho=-0.3, r=0.02, T=0.5,
                      strike=105.0, cp=-1.0),
+    # d = 128, ν = 63: arguments |z| ~ 50 between the series' plain range and the Hankel range of the
+    # order — the ascending series where its terms do not cancel, else base order + ratio recurrence
+    "nu_63": dict(S0=100.0, V0=0.04, kappa=2.0, theta=0.04, sigma=0.05, rho=-0.3, r=0.02, T=1.0,
+                  strike=100.0, cp=1.0),
+    # ν = 15 at a monthly step: |z| ~ 200, beyond the order's Hankel threshold ν²/6 + 13
+    "large_nu_short_T": dict(S0=100.0, V0=0.05, kappa=2.0, theta=0.04, sigma=0.1, rho=-0.3, r=0.02,
+                             T=1.0 / 12.0, strike=100.0, cp=1.0),
     # integer Bessel orders: d = 4 (ν = 1, one ratio step on top of I_0) and d = 2 (ν = 0)
     "nu_one": dict(S0=100.0, V0=0.06, kappa=1.0, theta=0.09, sigma=0.3, rho=-0.4, r=0.02, T=1.5,
                    strike=95.0, cp=1.0),
@@ -57,7 +64,7 @@ def gpu_bk(ctx, prm, n, seed, offset=0):
 # perturbation 1e-16 / ((var+mean²)·1e-4) of the moments, hence of the Fourier grid step and of the
 # sample.  With mean ≈ 0.02 (large_nu, short_T) that is ~1e-9..1e-7 whatever the implementation.
 PATH_RTOL = {"h252": 1e-7, "q2": 1e-7, "intended": 1e-7, "large_nu": 1e-5, "short_T": 1e-4,
-             "nu_one": 1e-7, "nu_zero": 1e-7}
+             "nu_one": 1e-7, "nu_zero": 1e-7, "nu_63": 1e-5, "large_nu_short_T": 1e-4}
 
 
 @pytest.mark.parametrize("name", list(PARAMS))
