@@ -8,9 +8,10 @@
 //   3. log S_T = μ + sqrt((1-ρ²)∫V)·Z                         heston.jl:278-300
 // then S_T = exp(.), payoff and the workgroup reduction as in hh_kernels.hip.
 //
-// Launch structure: bk_draw_kernel (the trajectory's three draws V_T, u, Z — or the caller's, in
-// REPLAY mode — and the normal quantile of u) -> bk_series_kernel (characteristic function, moments,
-// series terms) -> bk_invert_kernel (secant inversion on the cached terms) -> bk_scan_kernel ->
+// Launch structure: bk_tables_kernel (the Bessel tables of ν into device memory) -> bk_draw_kernel (the
+// trajectory's three draws V_T, u, Z — or the caller's, in REPLAY mode — and the normal quantile of u)
+// -> bk_cf_kernel (characteristic function, moments, series terms, then the secant inversion on the
+// cached terms; -DHH_BK_FUSED=0: bk_series_kernel and bk_invert_kernel apart) -> bk_scan_kernel ->
 // bk_ladder_kernel (bisection ladder for the flagged trajectories, packed) -> bk_fallback_kernel
 // (trajectories whose series outgrew the term cache; none with the reference's controls).
 // The draws live in their own launch because the NCχ² sampler's library calls (pow, lgamma, log,
@@ -632,7 +633,7 @@ __global__ __launch_bounds__(kTile) void bk_invert_kernel(const BkArgs p) {
   invert_phase(p, tile, tid, path, live, h, guess, j_stop);
 }
 
-// exclusive prefix sums of the per-tile counts of both ballot arrays (bk_invert_kernel leaves the counts,
+// exclusive prefix sums of the per-tile counts of both ballot arrays (the inversion phase leaves the counts,
 // 4 bytes per tile: a single workgroup reading the 64 bytes of ballots per tile instead is bound by
 // what one CU can pull, 16 µs at 10^6 trajectories).  ONE workgroup of 1024 threads: every thread adds
 // up a run of consecutive tiles, the run totals are scanned (shuffles inside a wave, then the 16 wave

@@ -22,8 +22,11 @@ PARAMS = {
     "monthly step of h252": dict(S0=100.0, V0=0.04, kappa=2.0, theta=0.04, sigma=0.3, rho=-0.7, r=0.03, T=1 / 12),
 }
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
+only = sys.argv[2] if len(sys.argv) > 2 else ""  # substring of the regime's name
 ctx = _ffi.get_context(0)
 for name, prm in PARAMS.items():
+    if only not in name:
+        continue
     m = _ffi.make_model(strike=100.0, cp=1.0, **prm)
     c = _ffi.make_config(_ffi.HH_HESTON, _ffi.HH_BROADIE_KAYA, n, seeds=np.array([7], dtype=np.uint64))
     r = _ffi.hh_result()
