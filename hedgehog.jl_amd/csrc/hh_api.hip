@@ -36,6 +36,7 @@ struct hh_ctx {
   size_t basket_accum_cap = 0;
   unsigned char* bk_scratch = nullptr;
   size_t bk_scratch_cap = 0;
+  hh::BkTableKey bk_table_key{};  // Bessel tables resident in bk_scratch (a new allocation has a new address)
   double* lsm_grid = nullptr;  // [n_steps+1][ntot]
   size_t lsm_grid_cap = 0;
   double* heston_var = nullptr;  // [n_steps+1][n_paths] variance rows of the exact Heston grid
@@ -355,6 +356,7 @@ static int run_simulation(hh_ctx* ctx, const hh_model* m, const hh_config* c, do
     rc = ensure(ctx, ctx->bk_scratch, ctx->bk_scratch_cap, hh::bk_scratch_bytes(c->n_paths));
     if (rc) return rc;
     p.bk_scratch = ctx->bk_scratch;
+    p.bk_table_key = &ctx->bk_table_key;
   }
 
   // seeds: per-trajectory for Euler (montecarlo.jl:331), seeds[1] only for the exact laws (:456)
@@ -747,6 +749,7 @@ static int run_heston_grid(hh_ctx* ctx, const hh_model* m, const hh_config* c) {
   hh::DevicePtrs p{};
   p.records = ctx->records;
   p.bk_scratch = ctx->bk_scratch;
+  p.bk_table_key = &ctx->bk_table_key;
   if ((rc = stage_path_seeds(ctx, c, &p.seeds))) return rc;
   HH_HIP(ctx, hh::launch_fill_rows(ctx->lsm_grid, ctx->heston_var, n, m->S0, m->V0, ctx->stream));
   hh_model step_model = *m;

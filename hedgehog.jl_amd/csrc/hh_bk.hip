@@ -918,9 +918,6 @@ int launch_bk(const hh_model& m, const hh_config& c, const DevicePtrs& ptr, hipS
   if (!(a.d > 0.0) || !std::isfinite(a.d) || !(a.lam_num * m.V0 / a.lam_den >= 0.0))
     return (int)hipErrorInvalidValue;
   a.n_int = a.nu >= 1.0 ? (int)floor(a.nu) : 0;
-  BkTables tabs;
-  if (upload_tables && (!bessel_table(a.nu, tabs.t[0]) || !bessel_table(a.nu - a.n_int, tabs.t[1])))
-    return (int)hipErrorInvalidValue;  // the series table of hh_bessel.h does not reach |z| = 13: not for ν > -1
   a.n_sigma = c.bk_n_sigma > 0.0 ? c.bk_n_sigma : 5.0;
   a.cf_tol = c.bk_cf_tol > 0.0 ? c.bk_cf_tol : 1e-3;
   a.atol = c.bk_atol > 0.0 ? c.bk_atol : 1e-4;
@@ -952,7 +949,16 @@ int launch_bk(const hh_model& m, const hh_config& c, const DevicePtrs& ptr, hipS
   a.draw_stride = lanes;
   a.replay = c.noise_mode == HH_NOISE_REPLAY ? ptr.replay : nullptr;
   const dim3 g(n_tiles), b(kTile);
-  if (upload_tables) hipLaunchKernelGGL(bk_tables_kernel, dim3(1), dim3(64), 0, s, tabs, tabs_dev);
+  // the tables depend on ν alone: repeated solves of one model (and the dates of a grid) find them in place
+  if (ptr.bk_table_key && ptr.bk_table_key->where == tabs_dev && ptr.bk_table_key->nu == a.nu)
+    upload_tables = false;
+  if (upload_tables) {
+    BkTables tabs;
+    if (!bessel_table(a.nu, tabs.t[0]) || !bessel_table(a.nu - a.n_int, tabs.t[1]))
+      return (int)hipErrorInvalidValue;  // the series table of hh_bessel.h does not reach |z| = 13: not for ν > -1
+    hipLaunchKernelGGL(bk_tables_kernel, dim3(1), dim3(64), 0, s, tabs, tabs_dev);
+    if (ptr.bk_table_key) *ptr.bk_table_key = BkTableKey{tabs_dev, a.nu};
+  }
   if (a.replay)
     hipLaunchKernelGGL(bk_draw_kernel<true>, g, b, 0, s, a);
   else

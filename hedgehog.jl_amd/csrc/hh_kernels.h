@@ -53,6 +53,13 @@ struct DevicePtrs {
   double* terminal_d;
   double* records;
   void* bk_scratch;  // Broadie–Kaya: bk_scratch_bytes() of device memory
+  // Broadie–Kaya: which Bessel tables bk_scratch holds (NULL = unknown, always uploaded): the owner of
+  // bk_scratch keeps one BkTableKey next to it, zero-initialised
+  struct BkTableKey* bk_table_key;
+};
+struct BkTableKey {
+  const void* where;  // address of the tables inside the scratch buffer
+  double nu;          // Bessel order they were made for
 };
 
 // several payoffs on ONE set of terminal samples (basket.jl:35-38, same-expiry payoffs)
