@@ -46,7 +46,8 @@ def test_lsm_matches_oracle(hhlib, anti, cp, K, degree, n, steps):
     # exercise decisions can differ only where payoff == fitted continuation to ~1e-9
     same = tau == ref["stop_time"]
     assert same.mean() >= 0.998
-    np.testing.assert_allclose(val[same], ref["stop_value"][same], rtol=1e-12)
+    # a stopping value is a payoff |S - K|: the grid's 1e-14 relative on S is 1e-14·S absolute on it
+    np.testing.assert_allclose(val[same], ref["stop_value"][same], rtol=1e-12, atol=1e-13 * S0)
     assert res.price == pytest.approx(ref["price"], rel=2e-4 if not same.all() else 1e-11)
     assert res.std_error == pytest.approx(ref["std_error"], rel=1e-3)
 
