@@ -610,6 +610,7 @@ __global__ __launch_bounds__(kTile) void bk_cf_kernel(const BkArgs p, const BkTa
   if (live) series_phase(p, bt, path, h, guess, j_stop);
   invert_phase(p, tile, tid, path, live, h, guess, j_stop);
 }
+#if !HH_BK_FUSED
 __global__ __launch_bounds__(kTile) void bk_series_kernel(const BkArgs p, const BkTables* __restrict__ tabs) {
   const uint64_t path = (uint64_t)blockIdx.x * kTile + threadIdx.x;
   const BesselTable* bt = tabs->t;
@@ -632,6 +633,7 @@ __global__ __launch_bounds__(kTile) void bk_invert_kernel(const BkArgs p) {
   }
   invert_phase(p, tile, tid, path, live, h, guess, j_stop);
 }
+#endif
 
 // exclusive prefix sums of the per-tile counts of both ballot arrays (the inversion phase leaves the counts,
 // 4 bytes per tile: a single workgroup reading the 64 bytes of ballots per tile instead is bound by
