@@ -311,6 +311,12 @@ __global__ __launch_bounds__(kTile) void bk_draw_kernel(const BkArgs p) {
     }
     VT = p.cscale * chi;
   }
+  // With d = 4κθ/σ² far below 1 the variance is absorbed at zero with real probability and the gamma
+  // draw u^(1/shape) underflows to an exact 0 (d = 0.012: 1.4 % of the trajectories).  The CF of ∫V has
+  // a finite limit for V_T -> 0 (the Bessel ratio tends to (ν_γ/ν_κ)^ν), but at V_T = 0 itself
+  // log I_ν(0) is ±inf and the ratio NaN — in the reference too (heston.jl:193,207), whose series loop
+  // then never ends.  The smallest variance kept is 2^-1000: the limit, to every digit.
+  VT = fmax(VT, 0x1p-1000);
   double* d = p.draws + path;  // trajectory index == lane index of the CF kernels' tiles
   d[0] = Z;
   d[p.draw_stride] = u;
@@ -323,7 +329,8 @@ __global__ __launch_bounds__(kTile) void bk_draw_kernel(const BkArgs p) {
 __device__ __forceinline__ void cf_setup(const BkArgs& p, const BesselTable* bt, double V0, double VT, double q_u, CfIter& cf,
                                          double& initial_guess, double& max_guess, double& h) {
   cf.VT = VT;
-  cf.sqrtV0VT = sqrt(V0 * VT);
+  const double v0vt = V0 * VT;  // (a grid's start variance can itself be the 2^-1000 floor: no underflow to 0)
+  cf.sqrtV0VT = v0vt >= 0x1p-960 ? sqrt(v0vt) : sqrt(V0) * sqrt(VT);
   cf.sumV = (V0 + VT) / p.sigma2;
   const LogMul Ik = besseli_logmul(bt[0], bt[1], p.n_int, {p.nuk_factor * cf.sqrtV0VT, 0.0}, 0.0);
   cf.logI_k = Ik.lg.re + fm::log(Ik.mul.re);  // real, positive argument: I_ν > 0

@@ -176,11 +176,23 @@ def sample_V_T(dr: Draws, dist):
     return c * noncentral_chisq(d, lam, dr)
 
 
+class OutsideReferenceRange(ArithmeticError):
+    """besseli(ν, z) under- or overflows in fp64: heston.jl:207's log(besseli(...)) is then ±Inf, the
+    characteristic function NaN, and the reference's `while true` series loop (sample_from_cf.jl:80-95)
+    never meets its stopping test.  The oracle stops here instead of looping with it."""
+
+
 def log_besseli(nu, z):
     """log(besseli(ν, z)) for complex z (array ok), formed through the scaled AMOS routine so that
-    large |Re z| does not overflow."""
+    large |Re z| does not overflow.  Raises OutsideReferenceRange where even the scaled function
+    leaves the fp64 range (large orders: I_ν(z) ~ (z/2)^ν / Γ(ν+1) underflows from ν ≈ 300 on)."""
     z = np.asarray(z, dtype=np.complex128)
-    return np.log(special.ive(nu, z)) + np.abs(z.real)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        out = np.log(special.ive(nu, z)) + np.abs(z.real)
+    if not np.all(np.isfinite(out)) and np.all(np.isfinite(z)):
+        raise OutsideReferenceRange(f"besseli({nu}, z) leaves the fp64 range for |z| in "
+                                    f"[{np.min(np.abs(z)):.3g}, {np.max(np.abs(z)):.3g}]")
+    return out
 
 
 class HestonCFIterator:

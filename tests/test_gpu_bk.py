@@ -169,3 +169,64 @@ def test_bk_long_series_beyond_the_term_cache(hhlib):
     assert np.mean(rel > 1e-7) <= 0.02, np.sort(rel)[-5:]
     assert res.bk_cf_terms == pytest.approx(ref["cf_terms"], rel=0.02)
     assert res.price == pytest.approx(ref["price"], rel=1e-5)
+
+
+def _bk_random_settings():
+    from hypothesis import HealthCheck, settings
+    # no shrinking phase: a failing example would re-run the (slow, pure-Python) oracle hundreds of times
+    from hypothesis import Phase
+    import os
+    return settings(max_examples=int(os.environ.get("HH_BK_RANDOM_EXAMPLES", "40")), deadline=None, derandomize=True, database=None,
+                    phases=[Phase.explicit, Phase.generate],
+                    suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow,
+                                           HealthCheck.filter_too_much])
+
+
+try:
+    from hypothesis import assume, given
+    from hypothesis import strategies as st
+except ImportError:  # pragma: no cover
+    given = None
+
+if given is not None:
+    @_bk_random_settings()
+    @given(kappa=st.floats(0.3, 4.0), theta=st.floats(0.01, 0.2), sigma=st.floats(0.05, 1.0),
+           rho=st.sampled_from([-0.9, -0.5, 0.0, 0.4]), V0=st.floats(0.005, 0.3), T=st.floats(0.05, 3.0),
+           cp=st.sampled_from([1.0, -1.0]), seed=st.integers(1, 2**31))
+    def test_bk_random_models(hhlib, kappa, theta, sigma, rho, V0, T, cp, seed):
+        """Random Heston parameters (Bessel orders ν = 2κθ/σ² − 1 from −0.98 to ~100, Bessel arguments
+        from 0.1 to several hundred: every branch of hh_bessel.h's dispatch in situ) against the
+        scipy / AMOS oracle on the same draws.  Per-path bars as in the fixed regimes above, at their
+        loose end: the median sample within 1e-5, 95 % within 1e-3 (the moment differences and the
+        |F(x) − u| <= 1e-4 stopping rule amplify rounding, see PATH_RTOL), the price within the mean
+        sample difference (the payoff is 1-Lipschitz).
+
+        Domain: where the REFERENCE works.  heston.jl:207 takes log(besseli(ν, ν_γ)) of the unscaled
+        function, which overflows beyond |Re ν_γ| ≈ 709 (NaN samples); and the variance of ∫V comes
+        from a second difference of ϕ with h = 1e-2 (sample_from_cf.jl:50-61) whose rounding is
+        amplified by 1e-12 / (var + mean²) — with mean ∫V ≈ V0·T below ~2e-3 the reference's own
+        moments are noise.  Such parameter sets are skipped; so are orders in the hundreds, where
+        besseli underflows and the reference never leaves its series loop (OutsideReferenceRange): the
+        kernels still return finite samples there (they carry log I_ν), which is all that can be
+        asked."""
+        em1 = -math.expm1(-kappa * T)
+        nu_k = 4 * kappa * math.exp(-0.5 * kappa * T) / (sigma**2 * em1) * math.sqrt(V0 * 3 * max(V0, theta))
+        assume(nu_k < 400.0 and min(V0, theta) * T > 2e-3)
+        prm = dict(S0=100.0, V0=V0, kappa=kappa, theta=theta, sigma=sigma, rho=rho, r=0.02, T=T,
+                   strike=100.0, cp=cp)
+        n = 120
+        res, term, D = gpu_bk(hhlib, prm, n, seed=seed)
+        try:
+            ref = bk_oracle.mc_solve(**prm, discount=D, n_paths=n, seed0=seed)
+        except bk_oracle.OutsideReferenceRange:
+            # ν in the hundreds: I_ν(z) itself underflows, the reference's log(besseli(…)) is -Inf and its
+            # series loop never ends (the oracle raises instead); the kernels carry log I_ν and go on
+            assert np.all(np.isfinite(term)) and np.all(term > 0)
+            return
+        assert np.all(np.isfinite(term)) and np.all(term > 0)
+        rel = np.abs(term - ref["terminal"]) / ref["terminal"]
+        nu = 2 * kappa * theta / sigma**2 - 1
+        assert np.median(rel) < 1e-5, (nu, np.median(rel), np.sort(rel)[-5:])  # 2e-6 at ν = -0.987, mean ∫V = 0.03
+        assert np.mean(rel > 1e-3) <= 0.05, (nu, np.sort(rel)[-8:])
+        # the payoff is 1-Lipschitz in S_T: the prices cannot differ by more than the mean sample difference
+        assert abs(res.price - ref["price"]) <= D * np.mean(np.abs(term - ref["terminal"])) * (1 + 1e-9) + 1e-9
