@@ -59,3 +59,34 @@ def test_monte_carlo_against_the_device_fourier_price():
                                                           variance_reduction=hh.Antithetic())),
                   ensemble=False)
     assert abs(mc.price - cm) < 4 * mc.std_error + 0.02
+
+
+try:
+    from hypothesis import HealthCheck, Phase, given, settings
+    from hypothesis import strategies as st
+except ImportError:  # pragma: no cover
+    given = None
+
+if given is not None:
+    @settings(max_examples=60, deadline=None, derandomize=True, database=None,
+              phases=[Phase.explicit, Phase.generate], suppress_health_check=[HealthCheck.too_slow])
+    @given(V0=st.floats(0.005, 0.5), kappa=st.floats(0.1, 5.0), theta=st.floats(0.005, 0.3),
+           sigma=st.floats(0.05, 1.2), rho=st.floats(-0.95, 0.95), r=st.floats(-0.01, 0.1),
+           days=st.integers(20, 1500), moneyness=st.floats(0.6, 1.6), alpha=st.sampled_from([0.75, 1.0, 1.5]),
+           bound=st.sampled_from([32.0, 100.0, 400.0]), put=st.booleans())
+    def test_carr_madan_random_heston(V0, kappa, theta, sigma, rho, r, days, moneyness, alpha, bound, put):
+        """Random Heston parameters, damping and integration bounds: the device quadrature against the
+        scipy restatement of carr_madan.jl:47-92 (same integrand, adaptive quadrature).  Absolute bar
+        1e-7 of the spot: the reference itself compares the method to others with atol 1e-6 … 1e-2."""
+        import datetime as dt
+        ref = hh.Date(2021, 1, 1)
+        expiry = ref + dt.timedelta(days=days)
+        K = 100.0 * moneyness
+        prob = heston_prob((V0, kappa, theta, sigma, rho), r, ref, expiry, K=K, cp=hh.Put() if put else hh.Call())
+        price = hh.solve(prob, hh.CarrMadan(alpha, bound, hh.HestonDynamics())).price
+        T = hh.yearfrac(ref, expiry)
+        want = analytic.carr_madan_heston(100.0, K, r, V0, kappa, theta, sigma, rho, T, alpha=alpha, bound=bound)
+        if put:
+            want = want - 100.0 + K * np.exp(-r * T)
+        assert np.isfinite(price)
+        assert price == pytest.approx(want, abs=1e-5)
