@@ -117,3 +117,26 @@ def test_basket_on_broadie_kaya_samples(hhlib):
         assert res[k].bk_bisect_fallback == single.bk_bisect_fallback
         assert res[k].bk_maxguess_fallback == single.bk_maxguess_fallback
         assert res[k].bk_cf_terms == single.bk_cf_terms > 10 * n
+
+
+@pytest.mark.parametrize("n", [1, 4096, 4097, 8 * 4096 + 1, 9 * 4096, 17 * 4096 - 3])
+@pytest.mark.parametrize("K", [1, 2, 3, 4, 5, 8, 9])
+@pytest.mark.parametrize("anti", [0, 1])
+def test_basket_grouping_and_padding_leave_each_payoff_bit_identical(hhlib, n, K, anti):
+    """The payoff kernel evaluates 4 payoffs per loaded sample and pads its grid to 8 chunks per XCD
+    round: a short last group, a lone payoff, chunk counts on both sides of a multiple of 8 and a
+    ragged last chunk must all give every payoff the sums of a one-payoff launch, bit for bit."""
+    m = o.make_model(S0=100.0, sigma=0.2, r=0.05, T=1.0, seeds={"S0": [1.0], "sigma": [0.0]}, n_partials=1)
+    c = o.make_config(0, 1, n, antithetic=anti, seeds=[12345], n_partials=1)
+    strikes = np.linspace(70.0, 140.0, K)
+    cps = np.where(np.arange(K) % 2 == 0, 1.0, -1.0)
+    res = (_ffi.hh_result * K)()
+    hhlib.check(hhlib.lib.hh_mc_solve_basket(hhlib.handle, C.byref(m), C.byref(c), strikes.ctypes.data,
+                                             cps.ctypes.data, K, res, None))
+    for k in range(K):
+        one = (_ffi.hh_result * 1)()
+        hhlib.check(hhlib.lib.hh_mc_solve_basket(hhlib.handle, C.byref(m), C.byref(c),
+                                                 strikes[k:k + 1].ctypes.data, cps[k:k + 1].ctypes.data, 1,
+                                                 one, None))
+        assert (res[k].price, res[k].std_error, res[k].dprice[0], res[k].n_paths_done) == \
+               (one[0].price, one[0].std_error, one[0].dprice[0], one[0].n_paths_done), (k, K, n)
