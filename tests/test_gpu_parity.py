@@ -471,3 +471,22 @@ def test_device_normals_against_libm_box_muller(hhlib, oracle):
     assert np.abs(want).max() > 5.0  # the sample does reach the tails
     z = got[live]
     assert abs(z.mean()) < 5 / np.sqrt(z.size) and abs(z.var() - 1) < 5 * np.sqrt(2 / z.size)
+
+
+@pytest.mark.parametrize("n_steps", [7, 8, 11, 12, 13, 15, 16, 17, 23, 24, 25])
+@pytest.mark.parametrize("dyn,anti,P", [(HES, 0, 0), (HES, 1, 0), (HES, 0, 1), (HES, 0, 4), (HES, 1, 3),
+                                        (GBM, 0, 0), (GBM, 1, 2)])
+def test_replay_pipeline_chunk_boundaries(hhlib, oracle, dyn, anti, P, n_steps):
+    """The REPLAY pipeline runs full 4-step chunks with unguarded loads (two in flight) and hands the
+    ragged end to guarded ones: step counts on both sides of 2, 3, 4 and 6 chunks, for every kernel
+    shape (price only, antithetic, carried derivatives), ragged last tile."""
+    n_paths = 256 * 3 + 101
+    seeds = seeds_for(n_paths, 11)
+    names = ["S0", "V0", "kappa", "theta", "sigma"] if dyn == HES else ["S0", "sigma"]
+    sd = {nm: [1.0 if j == k else 0.0 for j in range(P)] for k, nm in enumerate(names[:P])} if P else {}
+    m = o.make_model(sigma=0.2 if dyn == GBM else 0.3, seeds=sd, n_partials=P)
+    dW = oracle.wiener_fill(dyn, m.rho, m.T, n_steps, seeds)
+    c = o.make_config(dyn, EM, n_paths, n_steps, antithetic=anti, noise_mode=REP, replay=dW, n_partials=P)
+    rg, tg = gpu_solve(hhlib, m, c)
+    ro, to, _ = oracle.mc_solve(m, c)
+    check(rg, tg, ro, to, P, 1e-12, 1e-12)
