@@ -230,3 +230,33 @@ def test_grid_argument_errors(hhlib):
     c = o.make_config(_ffi.HH_HESTON, _ffi.HH_BROADIE_KAYA, 10, 2, seeds=seeds)
     assert call(c, bad) == _ffi.HH_ERR_INVALID
     assert call(c) == _ffi.HH_OK
+
+
+try:
+    from hypothesis import HealthCheck, Phase, given, settings
+    from hypothesis import strategies as st
+except ImportError:  # pragma: no cover
+    given = None
+
+if given is not None:
+    @settings(max_examples=30, deadline=None, derandomize=True, database=None,
+              phases=[Phase.explicit, Phase.generate],
+              suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
+    @given(kappa=st.floats(0.1, 5.0), theta=st.floats(0.005, 0.3), sigma=st.floats(0.05, 1.5),
+           rho=st.sampled_from([-0.9, -0.3, 0.0, 0.6]), V0=st.floats(0.001, 0.5), T=st.floats(0.1, 3.0),
+           steps=st.integers(1, 24), seed=st.integers(1, 2**31))
+    def test_exact_grid_random_models_stay_finite(hhlib, kappa, theta, sigma, rho, V0, T, steps, seed):
+        """Chains of transitions over random models, including the ones where the variance is absorbed at
+        zero (d = 4κθ/σ² ≪ 1: rows of the variance grid sit at the 2^-1000 floor and the next transition
+        starts there) and large Bessel orders / arguments (short steps, small vol-of-vol): every spot finite
+        and positive, every variance positive, the martingale E[S_t] = S0 e^{rt} within 5 standard errors
+        at the last date."""
+        prm = dict(S0=100.0, V0=V0, kappa=kappa, theta=theta, sigma=sigma, rho=rho, r=0.02, T=T)
+        n = 1500
+        seeds = np.random.default_rng(seed).integers(1, 2**63, n).astype(np.uint64)
+        spot, var, res = gpu_grid(hhlib, prm, seeds, steps)
+        assert np.all(np.isfinite(spot)) and np.all(spot > 0), (np.isnan(spot).sum(), (spot <= 0).sum())
+        assert np.all(np.isfinite(var)) and np.all(var > 0)
+        ST = spot[-1]
+        se = ST.std(ddof=1) / math.sqrt(n)
+        assert abs(ST.mean() - 100.0 * math.exp(0.02 * T)) < 5 * se + 0.05
