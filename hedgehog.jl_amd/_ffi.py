@@ -68,6 +68,7 @@ class hh_lsm_result(C.Structure):
 
 
 HH_OPT_LSM_FORM = 1
+HH_OPT_BK_TERM_CACHE = 2
 HH_LSM_FORM_PER_DATE, HH_LSM_FORM_PERSISTENT, HH_LSM_FORM_AUTO = 0, 1, 2
 
 

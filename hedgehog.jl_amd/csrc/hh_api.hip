@@ -57,6 +57,7 @@ struct hh_ctx {
     double step_discount = 1.0;
   } shard;
   int lsm_form = hh::kLsmFormAuto;  // hh_ctx_set_option(HH_OPT_LSM_FORM)
+  int bk_term_cache = 0;            // hh_ctx_set_option(HH_OPT_BK_TERM_CACHE); 0 = the default
   uint64_t lsm_persistent_fallbacks = 0;  // persistent launches that gave up and were redone per date
   double* accum = nullptr;       // device, HH_ACC_LEN
   double* accum_host = nullptr;  // pinned, HH_ACC_LEN
@@ -278,6 +279,11 @@ int hh_ctx_set_option(hh_ctx* ctx, int32_t option, int64_t value) {
         return fail(ctx, HH_ERR_INVALID, "HH_OPT_LSM_FORM: 0 (launch per date), 1 (one launch) or 2 (auto)");
       ctx->lsm_form = (int)value;
       return HH_OK;
+    case HH_OPT_BK_TERM_CACHE:
+      if (value < 8 || value > 1024)
+        return fail(ctx, HH_ERR_INVALID, "HH_OPT_BK_TERM_CACHE: 8 .. 1024 series terms per trajectory");
+      ctx->bk_term_cache = (int)value;
+      return HH_OK;
     default:
       return fail(ctx, HH_ERR_INVALID, "unknown option %d", option);
   }
@@ -353,10 +359,11 @@ static int run_simulation(hh_ctx* ctx, const hh_model* m, const hh_config* c, do
   hh::DevicePtrs p{};
   p.records = ctx->records;
   if (bk) {
-    rc = ensure(ctx, ctx->bk_scratch, ctx->bk_scratch_cap, hh::bk_scratch_bytes(c->n_paths));
+    rc = ensure(ctx, ctx->bk_scratch, ctx->bk_scratch_cap, hh::bk_scratch_bytes(c->n_paths, ctx->bk_term_cache));
     if (rc) return rc;
     p.bk_scratch = ctx->bk_scratch;
     p.bk_table_key = &ctx->bk_table_key;
+    p.bk_term_cache = ctx->bk_term_cache;
   }
 
   // seeds: per-trajectory for Euler (montecarlo.jl:331), seeds[1] only for the exact laws (:456)
@@ -743,13 +750,14 @@ static int run_heston_grid(hh_ctx* ctx, const hh_model* m, const hh_config* c) {
   if ((rc = ensure(ctx, ctx->heston_var, ctx->heston_var_cap, grid_elems))) return rc;
   if ((rc = ensure(ctx, ctx->records, ctx->records_cap, (size_t)hh::bk_record_count(n) * hh::kRecStride)))
     return rc;
-  if ((rc = ensure(ctx, ctx->bk_scratch, ctx->bk_scratch_cap, hh::bk_scratch_bytes(n)))) return rc;
+  if ((rc = ensure(ctx, ctx->bk_scratch, ctx->bk_scratch_cap, hh::bk_scratch_bytes(n, ctx->bk_term_cache)))) return rc;
   if ((rc = ensure(ctx, ctx->basket_accum, ctx->basket_accum_cap, (size_t)c->n_steps * HH_ACC_LEN)))
     return rc;
   hh::DevicePtrs p{};
   p.records = ctx->records;
   p.bk_scratch = ctx->bk_scratch;
   p.bk_table_key = &ctx->bk_table_key;
+  p.bk_term_cache = ctx->bk_term_cache;
   if ((rc = stage_path_seeds(ctx, c, &p.seeds))) return rc;
   HH_HIP(ctx, hh::launch_fill_rows(ctx->lsm_grid, ctx->heston_var, n, m->S0, m->V0, ctx->stream));
   hh_model step_model = *m;

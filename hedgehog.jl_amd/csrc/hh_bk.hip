@@ -38,7 +38,8 @@ constexpr double kPi = kBesselPi;
 constexpr double kTwoPi = kBesselTwoPi;
 
 constexpr int kPackedGrid = 256;  // workgroups of the packed (grid-stride) ladder kernel
-constexpr int kHeavyGrid = 64;    // … of the fall-back kernel (empty with the reference's controls)
+constexpr int kHeavyGrid = 512;   // … of the fall-back kernel: 2 per CU, what its 246 registers let be resident (it is empty
+                                  // with the reference's controls, and the whole job when no series fits the term cache)
 
 struct BkTables {
   BesselTable t[2];  // order ν, base order ν0
@@ -185,7 +186,7 @@ __device__ double cdf_from_cf(const BkArgs& p, const BesselTable* bt, const CfIt
       if (j > c.filled) {  // first time this term is seen
         c.filled = j;
         if (j <= c.cap) c.col[(size_t)(j - 1) * c.stride] = re;
-        if (j == c.cap) c.theta_cap = c.theta_run;
+        if (j == c.cap) c.theta_cap = theta_tail = c.theta_run;  // (theta_tail: this very call goes on beyond the cache)
         if (last) c.j_stop = j;
       }
     }
@@ -862,13 +863,15 @@ __global__ __launch_bounds__(256) void fill_rows_kernel(double* __restrict__ spo
 
 }  // namespace
 
-constexpr int kPhiCapMax = 64;                   // series terms cached per trajectory
 constexpr size_t kPhiBudget = (size_t)4 << 30;   // at most 4 GiB of device scratch for the cache
 
-static int phi_cache_cap(size_t n_tiles) {
+// series terms cached per trajectory: term_cache (HH_OPT_BK_TERM_CACHE; 0 = kBkTermCacheDefault) unless
+// the ensemble is so large that the cache would pass kPhiBudget
+static int phi_cache_cap(size_t n_tiles, int term_cache) {
   const size_t lanes = n_tiles * kTile;
   size_t cap = kPhiBudget / (lanes * sizeof(double));
-  if (cap > (size_t)kPhiCapMax) cap = kPhiCapMax;
+  const size_t want = term_cache > 0 ? (size_t)term_cache : (size_t)kBkTermCacheDefault;
+  if (cap > want) cap = want;
   if (cap < 8) cap = 8;
   return (int)cap;
 }
@@ -898,10 +901,10 @@ uint32_t bk_record_count(uint64_t n_paths) {
   return tiles_for(n_paths) + (uint32_t)kPackedGrid + (uint32_t)kHeavyGrid;
 }
 
-size_t bk_scratch_bytes(uint64_t n_paths) {
+size_t bk_scratch_bytes(uint64_t n_paths, int term_cache) {
   const size_t n_tiles = tiles_for(n_paths);
   // ballots + prefix | cached series terms [cap][lanes] | draws [4][lanes] | rec [4][lanes]
-  return bk_flags_bytes(n_tiles) + n_tiles * kTile * sizeof(double) * ((size_t)phi_cache_cap(n_tiles) + 8);
+  return bk_flags_bytes(n_tiles) + n_tiles * kTile * sizeof(double) * ((size_t)phi_cache_cap(n_tiles, term_cache) + 8);
 }
 
 int launch_bk(const hh_model& m, const hh_config& c, const DevicePtrs& ptr, hipStream_t s,
@@ -952,7 +955,7 @@ int launch_bk(const hh_model& m, const hh_config& c, const DevicePtrs& ptr, hipS
   a.tabs_dev = tabs_dev;
   a.phi_cache = reinterpret_cast<double*>(base + bk_flags_bytes(n_tiles));
   a.cache_stride = lanes;
-  a.cache_cap = phi_cache_cap(n_tiles);
+  a.cache_cap = phi_cache_cap(n_tiles, ptr.bk_term_cache);
   a.draws = a.phi_cache + lanes * (size_t)a.cache_cap;
   a.rec = a.draws + 4 * lanes;
   a.draw_stride = lanes;

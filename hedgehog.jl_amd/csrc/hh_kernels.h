@@ -56,6 +56,7 @@ struct DevicePtrs {
   // Broadie–Kaya: which Bessel tables bk_scratch holds (NULL = unknown, always uploaded): the owner of
   // bk_scratch keeps one BkTableKey next to it, zero-initialised
   struct BkTableKey* bk_table_key;
+  int bk_term_cache;  // Broadie–Kaya: cached series terms per trajectory at most (0 = default)
 };
 struct BkTableKey {
   const void* where;  // address of the tables inside the scratch buffer
@@ -101,7 +102,8 @@ struct BkTransition {
 // launch_bk on the SAME scratch buffer and trajectory count (the dates of one exact grid)
 int launch_bk(const hh_model& m, const hh_config& c, const DevicePtrs& p, hipStream_t s,
               const BkTransition* tr = nullptr, bool upload_tables = true);
-size_t bk_scratch_bytes(uint64_t n_paths);
+constexpr int kBkTermCacheDefault = 256;
+size_t bk_scratch_bytes(uint64_t n_paths, int term_cache = 0);
 uint32_t bk_record_count(uint64_t n_paths);  // records the Broadie–Kaya chain writes (inversion tiles + packed kernels)
 // the four Broadie–Kaya counter slots of `src` (HH_ACC_LEN doubles) into each of n_groups accumulators
 int launch_copy_bk_counters(const double* src, double* accum, uint32_t n_groups, hipStream_t s);

@@ -163,8 +163,15 @@ const char* hh_last_error(const hh_ctx* ctx); /* NUL-terminated, owned by ctx (o
  *                           re-loading the state pays (2·10^6 x 100 dates: 2.0 vs 3.1 ms) — and a
  *                           launch per date below, where a kernel boundary is the cheaper
  *                           synchronisation (10^5 x 100: 0.66 vs 0.79 ms).
- * All forms give bit-identical prices and stopping decisions. */
-enum hh_option { HH_OPT_LSM_FORM = 1 };
+ * All forms give bit-identical prices and stopping decisions.
+ *
+ * HH_OPT_BK_TERM_CACHE: how many CDF-series terms Re ϕ(h·j) per trajectory the Broadie–Kaya kernels
+ * keep (8 … 1024, default 256; 8 bytes x trajectories each, capped at 4 GiB in all).  Series that fit
+ * are evaluated once and inverted on the cached terms; a trajectory whose series is longer re-evaluates
+ * the whole series in every CDF call (as the reference does with all of them), in a separate, much
+ * slower kernel.  With the reference's controls the series has 10–15 terms (60 at short maturities,
+ * 100–250 for d = 4κθ/σ² ≪ 1 or cf_tol ≪ 1e-3). */
+enum hh_option { HH_OPT_LSM_FORM = 1, HH_OPT_BK_TERM_CACHE = 2 };
 enum hh_lsm_form { HH_LSM_FORM_PER_DATE = 0, HH_LSM_FORM_PERSISTENT = 1, HH_LSM_FORM_AUTO = 2 };
 int hh_ctx_set_option(hh_ctx* ctx, int32_t option, int64_t value);
 

@@ -149,10 +149,13 @@ def test_bk_full_size_vs_carr_madan(hhlib, name, cm_bound):
     assert res.n_paths_done == n and res.bk_maxguess_fallback < 0.01 * n
 
 
-def test_bk_long_series_beyond_the_term_cache(hhlib):
-    """cf_tol = 1e-6 makes the CDF series ~170 terms long, beyond the 64 cached Re ϕ_j per
-    trajectory: the tail is recomputed from the stored unwrapped angle and must still reproduce the
-    oracle, which re-evaluates every term in every CDF call as the reference does."""
+@pytest.mark.parametrize("term_cache", [32, 64, 256])
+def test_bk_long_series_beyond_the_term_cache(hhlib, term_cache):
+    """cf_tol = 1e-6 makes the CDF series ~170 terms long.  With 32 or 64 cached Re ϕ_j per trajectory
+    (HH_OPT_BK_TERM_CACHE) that is beyond the cache: the trajectories run whole in the fall-back kernel,
+    the tail recomputed from the stored unwrapped angle; with the default 256 they fit and are inverted
+    on the cached terms.  Either way the oracle must be reproduced, which re-evaluates every term in
+    every CDF call as the reference does."""
     prm = PARAMS["h252"]
     n = 300
     m = o.make_model(**prm)
@@ -160,8 +163,14 @@ def test_bk_long_series_beyond_the_term_cache(hhlib):
     c.bk_cf_tol, c.bk_atol, c.bk_newton_maxiter = 1e-6, 1e-6, 20
     res = _ffi.hh_result()
     term = np.zeros(n)
-    hhlib.check(hhlib.lib.hh_mc_solve(hhlib.handle, C.byref(m), C.byref(c), C.byref(res),
-                                      term.ctypes.data))
+    hhlib.set_option(_ffi.HH_OPT_BK_TERM_CACHE, term_cache)
+    try:
+        hhlib.check(hhlib.lib.hh_mc_solve(hhlib.handle, C.byref(m), C.byref(c), C.byref(res),
+                                          term.ctypes.data))
+    finally:
+        hhlib.set_option(_ffi.HH_OPT_BK_TERM_CACHE, 256)
+    with pytest.raises(_ffi.HedgehogMCError):
+        hhlib.set_option(_ffi.HH_OPT_BK_TERM_CACHE, 4)
     ref = bk_oracle.mc_solve(**prm, discount=m.discount, n_paths=n, seed0=31337, cf_tol=1e-6,
                              atol=1e-6, maxiter_newton=20)
     assert res.bk_cf_terms / n > 100

@@ -18,6 +18,8 @@ PARAMS = {
     "feller, nu 3": dict(S0=100.0, V0=0.04, kappa=2.0, theta=0.04, sigma=0.2, rho=-0.7, r=0.03, T=1.0),
     "large_nu (nu 15)": dict(S0=100.0, V0=0.05, kappa=2.0, theta=0.04, sigma=0.1, rho=-0.3, r=0.02, T=0.5),
     "nu 63": dict(S0=100.0, V0=0.04, kappa=2.0, theta=0.04, sigma=0.05, rho=-0.3, r=0.02, T=1.0),
+    "nu 475 (besseli underflows)": dict(S0=100.0, V0=0.0242, kappa=3.719, theta=0.16, sigma=0.05, rho=0.4, r=0.02, T=2.154),
+    "absorbed (nu -0.994)": dict(S0=100.0, V0=0.01, kappa=0.3, theta=0.01, sigma=1.0, rho=-0.9, r=0.02, T=1.9),
     "short_T (Hankel)": dict(S0=100.0, V0=0.09, kappa=1.0, theta=0.02, sigma=0.5, rho=-0.5, r=0.01, T=0.02),
     "monthly step of h252": dict(S0=100.0, V0=0.04, kappa=2.0, theta=0.04, sigma=0.3, rho=-0.7, r=0.03, T=1 / 12),
 }
