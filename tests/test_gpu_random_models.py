@@ -14,7 +14,7 @@ in 257 by 3e-9 and gives ∂price/∂V0 = -1.3e6 ± 4e-3).  So GENERATE is held 
 bar on the reference's own parameter sets is test_gpu_parity.py's."""
 import numpy as np
 import pytest
-from hypothesis import HealthCheck, given, settings
+from hypothesis import HealthCheck, Phase, given, settings
 from hypothesis import strategies as st
 
 from hedgehog_jl_amd import _ffi
@@ -56,8 +56,8 @@ def _run(hhlib, oracle, prm, dyn, n_paths, n_steps, anti, split, noise, P, salt)
         assert abs(rg.dprice[k] - ro.dprice[k]) <= tol_d * scale + 1e-13 * prm["S0"], (nm, rg.dprice[k], ro.dprice[k])
 
 
-@settings(max_examples=60, deadline=None, derandomize=True, database=None,
-          suppress_health_check=[HealthCheck.function_scoped_fixture])
+@settings(max_examples=int(__import__('os').environ.get('HH_EULER_RANDOM_EXAMPLES', '60')), deadline=None, derandomize=True, database=None,
+          phases=[Phase.explicit, Phase.generate], suppress_health_check=[HealthCheck.function_scoped_fixture])
 @given(prm=model_st, n_paths=st.sampled_from([1, 63, 257, 1000, 2049]),
        n_steps=st.sampled_from([1, 2, 7, 8, 9, 16, 50]), anti=st.booleans(), split=st.booleans(),
        noise=st.sampled_from([GEN, REP]), P=st.sampled_from([0, 0, 2, 6]), salt=st.integers(0, 2**32))
@@ -65,8 +65,8 @@ def test_heston_euler_random_models(hhlib, oracle, prm, n_paths, n_steps, anti, 
     _run(hhlib, oracle, prm, HES, n_paths, n_steps, int(anti), int(split), noise, P, salt)
 
 
-@settings(max_examples=30, deadline=None, derandomize=True, database=None,
-          suppress_health_check=[HealthCheck.function_scoped_fixture])
+@settings(max_examples=int(__import__('os').environ.get('HH_EULER_RANDOM_EXAMPLES', '60')) // 2, deadline=None, derandomize=True, database=None,
+          phases=[Phase.explicit, Phase.generate], suppress_health_check=[HealthCheck.function_scoped_fixture])
 @given(prm=model_st, n_paths=st.sampled_from([1, 255, 1000, 2049]),
        n_steps=st.sampled_from([1, 2, 3, 8, 9, 33]), anti=st.booleans(),
        noise=st.sampled_from([GEN, REP]), P=st.sampled_from([0, 3]), salt=st.integers(0, 2**32))
