@@ -33,7 +33,7 @@ def solve(*args, **kw):
         solve(gprob::GreekProblem, ::FiniteDifference, method)               greeks_problem.jl:318
         solve(gprob::SecondOrderGreekProblem, ::FiniteDifference, method)    greeks_problem.jl:396
         solve(gprob::BatchGreekProblem, ::GreekMethod, method)               greeks_problem.jl:559
-        solve(prob::BasketPricingProblem, method::MonteCarlo)                basket.jl:35
+        solve(prob::BasketPricingProblem, method::MonteCarlo | ::CarrMadan)  basket.jl:35
         solve(prob, ::CarrMadan) / solve(prob, ::BlackScholesAnalytic)       carr_madan.jl:47, black_scholes.jl:38
         solve(prob::PricingProblem{<:VanillaOption{…,American,…}}, ::LSM)     least_squares_montecarlo.jl:99
     """
@@ -47,7 +47,7 @@ def solve(*args, **kw):
         return solve_black_scholes(args[0], args[1])
     if len(args) == 2 and isinstance(args[0], PricingProblem) and isinstance(args[1], LSM):
         return solve_lsm(args[0], args[1], **kw)
-    if len(args) == 2 and isinstance(args[0], BasketPricingProblem) and isinstance(args[1], MonteCarlo):
+    if len(args) == 2 and isinstance(args[0], BasketPricingProblem) and isinstance(args[1], (MonteCarlo, CarrMadan)):
         return solve_basket(args[0], args[1], **kw)
     if len(args) == 3 and isinstance(args[0], GreekProblem):
         if isinstance(args[1], ForwardAD):

@@ -97,6 +97,8 @@ SYMBOLS = [
     ("hh_mc_accumulate_basket", C.c_int, [_vp, C.POINTER(hh_model), C.POINTER(hh_config), _vp, _vp, C.c_uint32, _vp, _vp]),
     ("hh_mc_solve_basket", C.c_int, [_vp, C.POINTER(hh_model), C.POINTER(hh_config), _vp, _vp, C.c_uint32, _vp, _vp]),
     ("hh_carr_madan", C.c_int, [_vp, C.POINTER(hh_model), C.c_int32, C.c_int32, C.c_double, C.c_double, C.POINTER(C.c_double)]),
+    ("hh_carr_madan_basket", C.c_int, [_vp, C.POINTER(hh_model), C.c_int32, C.c_int32, C.c_double, C.c_double,
+                                       _vp, _vp, _vp, _vp, _vp, C.c_uint32, _vp]),
     ("hh_lsm_grid_elems", C.c_size_t, [C.c_uint64, C.c_uint32, C.c_int32]),
     ("hh_lsm_solve", C.c_int, [_vp, C.POINTER(hh_model), C.POINTER(hh_config), C.c_int32, C.c_double, C.POINTER(hh_lsm_result), _vp, _vp, _vp]),
     ("hh_lsm_solve_grid", C.c_int, [_vp, C.POINTER(hh_model), _vp, C.c_uint64, C.c_uint32, C.c_int32, C.c_double, C.POINTER(hh_lsm_result), _vp, _vp]),

@@ -70,11 +70,8 @@ def solve_black_scholes(prob: PricingProblem, method: BlackScholesAnalytic) -> A
     return AnalyticSolution(prob, method, price)
 
 
-def solve_carr_madan(prob: PricingProblem, method: CarrMadan) -> AnalyticSolution:
-    """carr_madan.jl:47-71 with marginal_law (montecarlo.jl:293-320)."""
-    payoff, m = prob.payoff, prob.market_inputs
-    if not (isinstance(payoff, VanillaOption) and isinstance(payoff.exercise_style, European)):
-        raise MethodError("CarrMadan: European VanillaOption")
+def _carr_madan_model(m, method: CarrMadan):
+    """The model scalars every payoff on these market inputs shares (marginal_law, montecarlo.jl:293-320)."""
     model = _ffi.hh_model()
     if isinstance(method.dynamics, HestonDynamics) and isinstance(m, HestonInputs):
         dyn = _ffi.HH_HESTON
@@ -85,7 +82,43 @@ def solve_carr_madan(prob: PricingProblem, method: CarrMadan) -> AnalyticSolutio
         model.sigma = float(get_vol(m.sigma, None, None))
     else:
         raise MethodError("no marginal_law for this dynamics / market-input pair")
-    model.S0, model.strike, model.cp = float(m.spot), float(payoff.strike), payoff.call_put()
+    model.S0 = float(m.spot)
+    return model, dyn
+
+
+def solve_carr_madan_basket(payoffs, market_inputs, method: CarrMadan):
+    """solve(::BasketPricingProblem, ::CarrMadan) — basket.jl:35-38 over carr_madan.jl:47-71, the
+    calibration objective's inner loop (calibration.jl:75-88): every payoff's Fourier integral in ONE
+    launch (`hh_carr_madan_basket`, a workgroup per payoff).  Returns the prices in order."""
+    import numpy as np
+    m = market_inputs
+    payoffs = list(payoffs)
+    for payoff in payoffs:
+        if not (isinstance(payoff, VanillaOption) and isinstance(payoff.exercise_style, European)):
+            raise MethodError("CarrMadan: European VanillaOption")
+    model, dyn = _carr_madan_model(m, method)
+    K = len(payoffs)
+    strikes = np.array([float(p.strike) for p in payoffs])
+    cps = np.array([p.call_put() for p in payoffs], dtype=np.float64)
+    Ts = np.array([yearfrac(m.rate.reference_date, p.expiry) for p in payoffs])   # montecarlo.jl:301,317
+    rs = np.array([float(zero_rate(m.rate, p.expiry)) for p in payoffs])          # montecarlo.jl:299,318
+    Ds = np.array([float(df(m.rate, p.expiry)) for p in payoffs])                 # carr_madan.jl:89
+    out = np.empty(K)
+    ctx = _ffi.get_context(method.device)
+    ctx.check(ctx.lib.hh_carr_madan_basket(ctx.handle, C.byref(model), dyn, int(method.compat_sqrt_alpha),
+                                           float(method.α), float(method.bound), strikes.ctypes.data,
+                                           cps.ctypes.data, Ts.ctypes.data, rs.ctypes.data, Ds.ctypes.data,
+                                           K, out.ctypes.data))
+    return out
+
+
+def solve_carr_madan(prob: PricingProblem, method: CarrMadan) -> AnalyticSolution:
+    """carr_madan.jl:47-71 with marginal_law (montecarlo.jl:293-320)."""
+    payoff, m = prob.payoff, prob.market_inputs
+    if not (isinstance(payoff, VanillaOption) and isinstance(payoff.exercise_style, European)):
+        raise MethodError("CarrMadan: European VanillaOption")
+    model, dyn = _carr_madan_model(m, method)
+    model.strike, model.cp = float(payoff.strike), payoff.call_put()
     model.T = yearfrac(m.rate.reference_date, payoff.expiry)      # montecarlo.jl:301,317
     model.r_drift = float(zero_rate(m.rate, payoff.expiry))       # montecarlo.jl:299,318
     model.discount = float(df(m.rate, payoff.expiry))             # carr_madan.jl:89

@@ -34,8 +34,14 @@ class BasketPricingSolution:
     solutions: Any
 
 
-def solve_basket(prob: BasketPricingProblem, method: MonteCarlo, ensemble: bool = False):
-    """basket.jl:35-38 for a MonteCarlo method."""
+def solve_basket(prob: BasketPricingProblem, method, ensemble: bool = False):
+    """basket.jl:35-38 for a MonteCarlo method (one simulation per expiry group) or CarrMadan (every
+    Fourier integral in one launch)."""
+    from .analytic import AnalyticSolution, CarrMadan, solve_carr_madan_basket
+    if isinstance(method, CarrMadan):
+        prices = solve_carr_madan_basket(prob.payoffs, prob.market_inputs, method)
+        return BasketPricingSolution(prob, [AnalyticSolution(PricingProblem(p, prob.market_inputs), method, float(x))
+                                            for p, x in zip(prob.payoffs, prices)])
     payoffs = list(prob.payoffs)
     sols: list = [None] * len(payoffs)
     groups: dict = {}

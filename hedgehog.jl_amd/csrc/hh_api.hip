@@ -631,6 +631,48 @@ int hh_carr_madan(hh_ctx* ctx, const hh_model* m, int32_t dynamics, int32_t comp
   return HH_OK;
 }
 
+int hh_carr_madan_basket(hh_ctx* ctx, const hh_model* m, int32_t dynamics, int32_t compat_sqrt_alpha,
+                         double alpha, double bound, const double* strikes, const double* cps,
+                         const double* Ts, const double* r_drifts, const double* discounts,
+                         uint32_t n_payoffs, double* prices_out) {
+  if (!ctx) return HH_ERR_INVALID;
+  std::lock_guard<std::recursive_mutex> lock__(ctx->mu);
+  if (!m || !strikes || !cps || !Ts || !r_drifts || !discounts || !prices_out)
+    return fail(ctx, HH_ERR_INVALID, "hh_carr_madan_basket: NULL argument");
+  if (dynamics != HH_LOGNORMAL && dynamics != HH_HESTON)
+    return fail(ctx, HH_ERR_INVALID, "unknown dynamics %d", dynamics);
+  if (n_payoffs == 0 || n_payoffs > (1u << 20))
+    return fail(ctx, HH_ERR_INVALID, "hh_carr_madan_basket: 1 .. 2^20 payoffs per call");
+  if (!(m->S0 > 0.0) || !(alpha > 0.0) || !(bound > 0.0) || (dynamics == HH_HESTON && m->sigma == 0.0))
+    return fail(ctx, HH_ERR_INVALID, "hh_carr_madan_basket: bad scalars");
+  const size_t n = n_payoffs;
+  std::vector<double> host(5 * n);  // log K | T | r_drift | discount | (out)
+  for (size_t k = 0; k < n; ++k) {
+    if (!(strikes[k] > 0.0) || !(Ts[k] > 0.0) || (cps[k] != 1.0 && cps[k] != -1.0) ||
+        !std::isfinite(r_drifts[k]) || !(discounts[k] > 0.0))
+      return fail(ctx, HH_ERR_INVALID, "hh_carr_madan_basket: payoff %zu: strike, T, discount > 0, cp = +-1", k);
+    host[k] = std::log(strikes[k]);
+    host[n + k] = Ts[k];
+    host[2 * n + k] = r_drifts[k];
+    host[3 * n + k] = discounts[k];
+  }
+  HH_HIP(ctx, hipSetDevice(ctx->device));
+  int rc = ensure(ctx, ctx->payoffs, ctx->payoffs_cap, 5 * n);
+  if (rc) return rc;
+  HH_HIP(ctx, hipMemcpyAsync(ctx->payoffs, host.data(), 4 * n * sizeof(double), hipMemcpyHostToDevice,
+                             ctx->stream));
+  HH_HIP(ctx, hh::launch_carr_madan_basket(*m, dynamics, compat_sqrt_alpha, alpha, bound, ctx->payoffs,
+                                           n_payoffs, ctx->payoffs + 4 * n, ctx->stream));
+  HH_HIP(ctx, hipMemcpyAsync(host.data() + 4 * n, ctx->payoffs + 4 * n, n * sizeof(double),
+                             hipMemcpyDeviceToHost, ctx->stream));
+  HH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (size_t k = 0; k < n; ++k) {  // parity_transform (payoffs.jl:172-193): put = call − S + K·D
+    const double call = host[4 * n + k];
+    prices_out[k] = cps[k] > 0.0 ? call : call - m->S0 + strikes[k] * discounts[k];
+  }
+  return HH_OK;
+}
+
 size_t hh_lsm_grid_elems(uint64_t n_paths, uint32_t n_steps, int32_t antithetic) {
   return (size_t)(n_steps + 1) * n_paths * (antithetic ? 2 : 1);
 }

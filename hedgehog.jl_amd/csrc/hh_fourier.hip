@@ -53,6 +53,11 @@ struct FourierArgs {
   double law_mu, law_sd;                             // lognormal law (montecarlo.jl:293-303)
   double alpha, bound, logK, discount;
   double* out;  // [0] = damped-call integral (the call price)
+  // basket form (one workgroup per payoff): per-payoff scalars in device memory, [4][n]:
+  // log K, T, r_drift, discount; NULL = the fields above
+  const double* per_payoff;
+  uint32_t n_payoffs, compat_sqrt_alpha;
+  double sigma_ln;  // lognormal volatility (law_mu / law_sd are formed per payoff)
 };
 
 // heston.jl:307-319, complex argument u
@@ -96,7 +101,19 @@ __constant__ double kGLw[8] = {0.1894506104550684962853967, 0.182603415044923588
                                0.1246289712555338720524763, 0.0951585116824927848099251,
                                0.0622535239386478928628438, 0.0271524594117540948517806};
 
-__global__ __launch_bounds__(256) void carr_madan_kernel(const FourierArgs a) {
+__global__ __launch_bounds__(256) void carr_madan_kernel(const FourierArgs a0) {
+  FourierArgs a = a0;
+  if (a0.per_payoff) {  // payoff blockIdx.x of a basket: its expiry-dependent scalars
+    const uint32_t k = blockIdx.x, n = a0.n_payoffs;
+    a.logK = a0.per_payoff[k];
+    a.T = a0.per_payoff[n + k];
+    a.r = a0.per_payoff[2 * n + k];
+    a.discount = a0.per_payoff[3 * n + k];
+    const double sqT = sqrt(a.T), tmul = a0.compat_sqrt_alpha ? sqT : a.T;
+    a.law_mu = a.logS0 + (a.r - 0.5 * a0.sigma_ln * a0.sigma_ln) * tmul;  // montecarlo.jl:302
+    a.law_sd = a0.sigma_ln * sqT;
+    a.out = a0.out + k;
+  }
   const double w = 2.0 * a.bound / 256.0;  // panel width
   const double mid = -a.bound + (threadIdx.x + 0.5) * w, half = 0.5 * w;
   double s = 0.0;
@@ -112,6 +129,23 @@ __global__ __launch_bounds__(256) void carr_madan_kernel(const FourierArgs a) {
 }
 
 }  // namespace
+
+int launch_carr_madan_basket(const hh_model& m, int dynamics, int compat_sqrt_alpha, double alpha,
+                             double bound, const double* per_payoff_dev, uint32_t n_payoffs,
+                             double* out_dev, hipStream_t s) {
+  FourierArgs a{};
+  a.dynamics = dynamics;
+  a.logS0 = log(m.S0); a.V0 = m.V0; a.kappa = m.kappa; a.theta = m.theta; a.sigma = m.sigma;
+  a.rho = m.rho;
+  a.sigma_ln = m.sigma;
+  a.alpha = alpha; a.bound = bound;
+  a.out = out_dev;
+  a.per_payoff = per_payoff_dev;
+  a.n_payoffs = n_payoffs;
+  a.compat_sqrt_alpha = (uint32_t)(compat_sqrt_alpha != 0);
+  hipLaunchKernelGGL(carr_madan_kernel, dim3(n_payoffs), dim3(256), 0, s, a);
+  return (int)hipGetLastError();
+}
 
 int launch_carr_madan(const hh_model& m, int dynamics, int compat_sqrt_alpha, double alpha,
                       double bound, double* out_dev, hipStream_t s) {

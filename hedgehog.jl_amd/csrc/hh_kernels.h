@@ -119,6 +119,11 @@ int launch_basket_payoffs(const BasketArgs& b, uint32_t n_payoffs, uint32_t n_ac
 // Carr–Madan on the device (hh_fourier.hip)
 int launch_carr_madan(const hh_model& m, int dynamics, int compat_sqrt_alpha, double alpha,
                       double bound, double* out_dev, hipStream_t s);
+// n_payoffs Carr–Madan integrals in one launch (one workgroup each); per_payoff_dev = [4][n_payoffs]:
+// log K, T, r_drift, discount; out_dev[n_payoffs] receives the CALL prices
+int launch_carr_madan_basket(const hh_model& m, int dynamics, int compat_sqrt_alpha, double alpha,
+                             double bound, const double* per_payoff_dev, uint32_t n_payoffs,
+                             double* out_dev, hipStream_t s);
 // LSM (hh_lsm.hip)
 uint32_t lsm_chunks(uint64_t ntot);
 size_t lsm_scratch_doubles(uint64_t ntot, uint32_t n_steps, int degree);

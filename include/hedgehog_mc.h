@@ -222,6 +222,19 @@ int hh_mc_solve_basket(hh_ctx* ctx, const hh_model* model, const hh_config* cfg,
  */
 int hh_carr_madan(hh_ctx* ctx, const hh_model* model, int32_t dynamics, int32_t compat_sqrt_alpha,
                   double alpha, double bound, double* price_out);
+/*
+ * The same for a basket in ONE launch (one workgroup per payoff) — solve(::BasketPricingProblem,
+ * ::CarrMadan), i.e. src/calibration/basket.jl:35-38 over carr_madan.jl:47-92: what the calibration
+ * objective evaluates at every iterate (src/calibration/calibration.jl:75-88).  The payoffs share the
+ * model's parameters (S0 and V0, kappa, theta, sigma, rho — or the lognormal sigma); per payoff k:
+ * strikes[k], cps[k] (+1 call / -1 put), Ts[k] = yearfrac(rate.reference_date, expiry_k),
+ * r_drifts[k] = zero_rate(rate, expiry_k), discounts[k] = df(rate, expiry_k).  model->strike, cp, T,
+ * r_drift and discount are ignored.  1 .. 2^20 payoffs per call.
+ */
+int hh_carr_madan_basket(hh_ctx* ctx, const hh_model* model, int32_t dynamics,
+                         int32_t compat_sqrt_alpha, double alpha, double bound, const double* strikes,
+                         const double* cps, const double* Ts, const double* r_drifts,
+                         const double* discounts, uint32_t n_payoffs, double* prices_out);
 
 /*
  * Longstaff–Schwartz American pricing on the full path grid:

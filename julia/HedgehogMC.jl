@@ -12,7 +12,7 @@
 #
 # What is bound (include/hedgehog_mc.h, HH_ABI_VERSION 2): hh_mc_solve (solve_hip, with the REPLAY
 # keywords), hh_mc_accumulate + hh_mc_finalize (solve_sharded_hip), hh_mc_solve_basket, hh_carr_madan,
-# hh_lsm_solve, hh_heston_exact_grid, hh_replay_elems, the device-memory helpers.  The struct mirrors
+# hh_carr_madan_basket, hh_ctx_set_option, hh_lsm_solve, hh_heston_exact_grid, hh_replay_elems, the device-memory helpers.  The struct mirrors
 # below are checked field by field against the C header by tests/test_julia_layout.py (offsets from
 # a compiled offsetof dump), so a drift between the two shows up on the CPU, without Julia.
 module HedgehogMC
@@ -302,6 +302,45 @@ function carr_madan_hip(prob::PricingProblem{VanillaOption{TS,TE,European,C,Spot
                Float64(method.bound), out)
     rc == 0 || error("hh_carr_madan failed ($rc): $(last_error(ctx))")
     return Hedgehog.AnalyticSolution(prob, method, out[])
+end
+
+"""
+    carr_madan_basket_hip(prob::BasketPricingProblem, method::CarrMadan)
+
+`hh_carr_madan_basket`: every payoff's Fourier integral in ONE launch (a workgroup per payoff) —
+`solve(::BasketPricingProblem, ::CarrMadan)` (src/calibration/basket.jl:35-38), what the calibration
+objective evaluates at every iterate (src/calibration/calibration.jl:75-88).  Plain Float64 inputs
+only: an objective differentiated by ForwardDiff keeps the reference's own method.
+"""
+function carr_madan_basket_hip(prob::Hedgehog.BasketPricingProblem, method::Hedgehog.CarrMadan;
+                               compat_sqrt_alpha::Bool = false)
+    m = prob.market_inputs
+    n = length(prob.payoffs)
+    strikes = Float64[p.strike for p in prob.payoffs]
+    cps = Float64[p.call_put() for p in prob.payoffs]
+    Ts = Float64[yearfrac(m.rate.reference_date, p.expiry) for p in prob.payoffs]
+    rs = Float64[zero_rate(m.rate, p.expiry) for p in prob.payoffs]
+    Ds = Float64[df(m.rate, p.expiry) for p in prob.payoffs]
+    none = ntuple(_ -> Ptr{Cdouble}(C_NULL), 8)
+    if m isa HestonInputs
+        dynamics = Int32(1)
+        model = HHModel(Float64(m.spot), Float64(m.V0), Float64(m.κ), Float64(m.θ), Float64(m.σ),
+                        Float64(m.ρ), 0.0, 1.0, 1.0, 1.0, 1.0, none...)
+    else
+        dynamics = Int32(0)
+        model = HHModel(Float64(m.spot), 0.0, 0.0, 0.0, Float64(get_vol(m.sigma, nothing, nothing)), 0.0,
+                        0.0, 1.0, 1.0, 1.0, 1.0, none...)
+    end
+    out = Vector{Float64}(undef, n)
+    ctx = context()
+    rc = ccall((:hh_carr_madan_basket, LIB[]), Cint,
+               (Ptr{Cvoid}, Ref{HHModel}, Int32, Int32, Cdouble, Cdouble, Ptr{Cdouble}, Ptr{Cdouble},
+                Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, UInt32, Ptr{Cdouble}),
+               ctx.handle, model, dynamics, Int32(compat_sqrt_alpha), Float64(method.α),
+               Float64(method.bound), strikes, cps, Ts, rs, Ds, UInt32(n), out)
+    rc == 0 || error("hh_carr_madan_basket failed ($rc): $(last_error(ctx))")
+    sols = [Hedgehog.AnalyticSolution(PricingProblem(p, m), method, out[k]) for (k, p) in enumerate(prob.payoffs)]
+    return Hedgehog.BasketPricingSolution(prob, sols)
 end
 
 # ---- same-expiry baskets (src/calibration/basket.jl:35-38) ---------------------------------------

@@ -90,3 +90,27 @@ if given is not None:
             want = want - 100.0 + K * np.exp(-r * T)
         assert np.isfinite(price)
         assert price == pytest.approx(want, abs=1e-5)
+
+
+def test_carr_madan_basket_equals_single_solves():
+    """solve(::BasketPricingProblem, ::CarrMadan): every Fourier integral of the basket in one launch
+    (the calibration objective's inner loop, calibration.jl:75-88) equals the per-payoff solves bit for
+    bit — same integrand, same panels, same reduction — over strikes, expiries, calls and puts."""
+    ref = hh.Date(2021, 1, 1)
+    mkt = hh.HestonInputs(ref, 0.03, 100.0, 0.04, 2.0, 0.04, 0.3, -0.7)
+    payoffs = [hh.VanillaOption(K, e, hh.European(), cp, hh.Spot())
+               for e in (hh.Date(2021, 4, 1), hh.Date(2022, 1, 1), hh.Date(2024, 1, 1))
+               for K in (70.0, 95.0, 100.0, 130.0) for cp in (hh.Call(), hh.Put())]
+    method = hh.CarrMadan(1.0, 32.0, hh.HestonDynamics())
+    sol = hh.solve(hh.BasketPricingProblem(payoffs, mkt), method)
+    assert isinstance(sol, hh.BasketPricingSolution) and len(sol.solutions) == len(payoffs)
+    for p, s in zip(payoffs, sol.solutions):
+        assert s.price == hh.solve(hh.PricingProblem(p, mkt), method).price
+        assert s.problem.payoff is p
+    # the lognormal law, with the reference's √T quirk on and off (366-day expiry: they differ)
+    bs = hh.BlackScholesInputs(ref, 0.05, 100.0, 0.2)
+    pays = [hh.VanillaOption(K, hh.Date(2022, 1, 2), hh.European(), hh.Call(), hh.Spot()) for K in (90.0, 110.0)]
+    for compat in (False, True):
+        meth = hh.CarrMadan(1.0, 32.0, hh.LognormalDynamics(), compat_sqrt_alpha=compat)
+        got = [s.price for s in hh.solve(hh.BasketPricingProblem(pays, bs), meth).solutions]
+        assert got == [hh.solve(hh.PricingProblem(p, bs), meth).price for p in pays]
