@@ -69,6 +69,7 @@ class hh_lsm_result(C.Structure):
 
 HH_OPT_LSM_FORM = 1
 HH_OPT_BK_TERM_CACHE = 2
+HH_CM_GRAD_LEN = 8  # enum hh_cm_grad: S0, V0, kappa, theta, sigma, rho, r_drift, discount
 HH_LSM_FORM_PER_DATE, HH_LSM_FORM_PERSISTENT, HH_LSM_FORM_AUTO = 0, 1, 2
 
 
@@ -99,6 +100,8 @@ SYMBOLS = [
     ("hh_carr_madan", C.c_int, [_vp, C.POINTER(hh_model), C.c_int32, C.c_int32, C.c_double, C.c_double, C.POINTER(C.c_double)]),
     ("hh_carr_madan_basket", C.c_int, [_vp, C.POINTER(hh_model), C.c_int32, C.c_int32, C.c_double, C.c_double,
                                        _vp, _vp, _vp, _vp, _vp, C.c_uint32, _vp]),
+    ("hh_carr_madan_basket_grad", C.c_int, [_vp, C.POINTER(hh_model), C.c_int32, C.c_int32, C.c_double,
+                                            C.c_double, _vp, _vp, _vp, _vp, _vp, C.c_uint32, _vp, _vp]),
     ("hh_lsm_grid_elems", C.c_size_t, [C.c_uint64, C.c_uint32, C.c_int32]),
     ("hh_lsm_solve", C.c_int, [_vp, C.POINTER(hh_model), C.POINTER(hh_config), C.c_int32, C.c_double, C.POINTER(hh_lsm_result), _vp, _vp, _vp]),
     ("hh_lsm_solve_grid", C.c_int, [_vp, C.POINTER(hh_model), _vp, C.c_uint64, C.c_uint32, C.c_int32, C.c_double, C.POINTER(hh_lsm_result), _vp, _vp]),

@@ -71,19 +71,25 @@ def solve_black_scholes(prob: PricingProblem, method: BlackScholesAnalytic) -> A
 
 
 def _carr_madan_model(m, method: CarrMadan):
-    """The model scalars every payoff on these market inputs shares (marginal_law, montecarlo.jl:293-320)."""
+    """The model scalars every payoff on these market inputs shares (marginal_law, montecarlo.jl:293-320)
+    -> (hh_model of their VALUES, dynamics, the scalars themselves — possibly Dual — in the order of
+    enum hh_cm_grad: S0, V0, kappa, theta, sigma, rho)."""
+    from .dual import value_of
     model = _ffi.hh_model()
     if isinstance(method.dynamics, HestonDynamics) and isinstance(m, HestonInputs):
         dyn = _ffi.HH_HESTON
-        model.V0, model.kappa, model.theta = float(m.V0), float(m.κ), float(m.θ)
-        model.sigma, model.rho = float(m.σ), float(m.ρ)
+        scal = [m.spot, m.V0, m.κ, m.θ, m.σ, m.ρ]
+        model.V0, model.kappa, model.theta = value_of(m.V0), value_of(m.κ), value_of(m.θ)
+        model.sigma, model.rho = value_of(m.σ), value_of(m.ρ)
     elif isinstance(method.dynamics, LognormalDynamics) and isinstance(m, BlackScholesInputs):
         dyn = _ffi.HH_LOGNORMAL
-        model.sigma = float(get_vol(m.sigma, None, None))
+        vol = get_vol(m.sigma, None, None)
+        scal = [m.spot, 0.0, 0.0, 0.0, vol, 0.0]
+        model.sigma = value_of(vol)
     else:
         raise MethodError("no marginal_law for this dynamics / market-input pair")
-    model.S0 = float(m.spot)
-    return model, dyn
+    model.S0 = value_of(m.spot)
+    return model, dyn, scal
 
 
 def solve_carr_madan_basket(payoffs, market_inputs, method: CarrMadan):
@@ -96,20 +102,37 @@ def solve_carr_madan_basket(payoffs, market_inputs, method: CarrMadan):
     for payoff in payoffs:
         if not (isinstance(payoff, VanillaOption) and isinstance(payoff.exercise_style, European)):
             raise MethodError("CarrMadan: European VanillaOption")
-    model, dyn = _carr_madan_model(m, method)
+    from .dual import Dual, n_partials, partials_of, value_of
+    model, dyn, scal = _carr_madan_model(m, method)
     K = len(payoffs)
+    if any(isinstance(p.strike, Dual) for p in payoffs):
+        raise MethodError("CarrMadan basket: partials along a strike are not carried")
     strikes = np.array([float(p.strike) for p in payoffs])
     cps = np.array([p.call_put() for p in payoffs], dtype=np.float64)
     Ts = np.array([yearfrac(m.rate.reference_date, p.expiry) for p in payoffs])   # montecarlo.jl:301,317
-    rs = np.array([float(zero_rate(m.rate, p.expiry)) for p in payoffs])          # montecarlo.jl:299,318
-    Ds = np.array([float(df(m.rate, p.expiry)) for p in payoffs])                 # carr_madan.jl:89
+    r_k = [zero_rate(m.rate, p.expiry) for p in payoffs]                          # montecarlo.jl:299,318
+    D_k = [df(m.rate, p.expiry) for p in payoffs]                                 # carr_madan.jl:89
+    rs, Ds = np.array([value_of(x) for x in r_k]), np.array([value_of(x) for x in D_k])
     out = np.empty(K)
     ctx = _ffi.get_context(method.device)
-    ctx.check(ctx.lib.hh_carr_madan_basket(ctx.handle, C.byref(model), dyn, int(method.compat_sqrt_alpha),
-                                           float(method.α), float(method.bound), strikes.ctypes.data,
-                                           cps.ctypes.data, Ts.ctypes.data, rs.ctypes.data, Ds.ctypes.data,
-                                           K, out.ctypes.data))
-    return out
+    args = (ctx.handle, C.byref(model), dyn, int(method.compat_sqrt_alpha), float(method.α),
+            float(method.bound), strikes.ctypes.data, cps.ctypes.data, Ts.ctypes.data, rs.ctypes.data,
+            Ds.ctypes.data, K, out.ctypes.data)
+    P = n_partials(*scal, *r_k, *D_k)
+    if P == 0:
+        ctx.check(ctx.lib.hh_carr_madan_basket(*args))
+        return out
+    # a differentiated objective (calibration.jl:75-88 under AutoForwardDiff): the device returns the
+    # gradient along the eight scalars of enum hh_cm_grad, the Dual prices are assembled here
+    grad = np.empty((K, _ffi.HH_CM_GRAD_LEN))
+    ctx.check(ctx.lib.hh_carr_madan_basket_grad(*args, grad.ctypes.data))
+    seeds = np.array([partials_of(x, P) for x in scal])                # [6][P]
+    prices = []
+    for k in range(K):
+        d = grad[k, :6] @ seeds + grad[k, 6] * np.array(partials_of(r_k[k], P)) \
+            + grad[k, 7] * np.array(partials_of(D_k[k], P))
+        prices.append(Dual(out[k], tuple(d)))
+    return prices
 
 
 def solve_carr_madan(prob: PricingProblem, method: CarrMadan) -> AnalyticSolution:
@@ -117,7 +140,7 @@ def solve_carr_madan(prob: PricingProblem, method: CarrMadan) -> AnalyticSolutio
     payoff, m = prob.payoff, prob.market_inputs
     if not (isinstance(payoff, VanillaOption) and isinstance(payoff.exercise_style, European)):
         raise MethodError("CarrMadan: European VanillaOption")
-    model, dyn = _carr_madan_model(m, method)
+    model, dyn, _ = _carr_madan_model(m, method)
     model.strike, model.cp = float(payoff.strike), payoff.call_put()
     model.T = yearfrac(m.rate.reference_date, payoff.expiry)      # montecarlo.jl:301,317
     model.r_drift = float(zero_rate(m.rate, payoff.expiry))       # montecarlo.jl:299,318

@@ -40,7 +40,8 @@ def solve_basket(prob: BasketPricingProblem, method, ensemble: bool = False):
     from .analytic import AnalyticSolution, CarrMadan, solve_carr_madan_basket
     if isinstance(method, CarrMadan):
         prices = solve_carr_madan_basket(prob.payoffs, prob.market_inputs, method)
-        return BasketPricingSolution(prob, [AnalyticSolution(PricingProblem(p, prob.market_inputs), method, float(x))
+        return BasketPricingSolution(prob, [AnalyticSolution(PricingProblem(p, prob.market_inputs), method,
+                                                             x if isinstance(x, Dual) else float(x))
                                             for p, x in zip(prob.payoffs, prices)])
     payoffs = list(prob.payoffs)
     sols: list = [None] * len(payoffs)

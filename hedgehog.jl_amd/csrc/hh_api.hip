@@ -673,6 +673,60 @@ int hh_carr_madan_basket(hh_ctx* ctx, const hh_model* m, int32_t dynamics, int32
   return HH_OK;
 }
 
+int hh_carr_madan_basket_grad(hh_ctx* ctx, const hh_model* m, int32_t dynamics,
+                              int32_t compat_sqrt_alpha, double alpha, double bound,
+                              const double* strikes, const double* cps, const double* Ts,
+                              const double* r_drifts, const double* discounts, uint32_t n_payoffs,
+                              double* prices_out, double* grad_out) {
+  if (!ctx) return HH_ERR_INVALID;
+  std::lock_guard<std::recursive_mutex> lock__(ctx->mu);
+  if (!m || !strikes || !cps || !Ts || !r_drifts || !discounts || !prices_out || !grad_out)
+    return fail(ctx, HH_ERR_INVALID, "hh_carr_madan_basket_grad: NULL argument");
+  if (dynamics != HH_LOGNORMAL && dynamics != HH_HESTON)
+    return fail(ctx, HH_ERR_INVALID, "unknown dynamics %d", dynamics);
+  if (n_payoffs == 0 || n_payoffs > (1u << 20))
+    return fail(ctx, HH_ERR_INVALID, "hh_carr_madan_basket_grad: 1 .. 2^20 payoffs per call");
+  if (!(m->S0 > 0.0) || !(alpha > 0.0) || !(bound > 0.0) ||
+      (dynamics == HH_HESTON && (m->sigma == 0.0 || m->theta == 0.0)))
+    return fail(ctx, HH_ERR_INVALID, "hh_carr_madan_basket_grad: bad scalars (Heston: sigma, theta != 0)");
+  const size_t n = n_payoffs;
+  std::vector<double> host(4 * n + HH_CM_GRAD_LEN * n);  // log K | T | r_drift | discount | out [n][8]
+  for (size_t k = 0; k < n; ++k) {
+    if (!(strikes[k] > 0.0) || !(Ts[k] > 0.0) || (cps[k] != 1.0 && cps[k] != -1.0) ||
+        !std::isfinite(r_drifts[k]) || !(discounts[k] > 0.0))
+      return fail(ctx, HH_ERR_INVALID, "hh_carr_madan_basket_grad: payoff %zu: strike, T, discount > 0, cp = +-1", k);
+    host[k] = std::log(strikes[k]);
+    host[n + k] = Ts[k];
+    host[2 * n + k] = r_drifts[k];
+    host[3 * n + k] = discounts[k];
+  }
+  HH_HIP(ctx, hipSetDevice(ctx->device));
+  int rc = ensure(ctx, ctx->payoffs, ctx->payoffs_cap, 4 * n + HH_CM_GRAD_LEN * n);
+  if (rc) return rc;
+  double* out_dev = ctx->payoffs + 4 * n;
+  HH_HIP(ctx, hipMemcpyAsync(ctx->payoffs, host.data(), 4 * n * sizeof(double), hipMemcpyHostToDevice,
+                             ctx->stream));
+  HH_HIP(ctx, hh::launch_carr_madan_grad(*m, dynamics, compat_sqrt_alpha, alpha, bound, ctx->payoffs,
+                                         n_payoffs, out_dev, ctx->stream));
+  HH_HIP(ctx, hipMemcpyAsync(host.data() + 4 * n, out_dev, HH_CM_GRAD_LEN * n * sizeof(double),
+                             hipMemcpyDeviceToHost, ctx->stream));
+  HH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (size_t k = 0; k < n; ++k) {
+    const double* o = host.data() + 4 * n + HH_CM_GRAD_LEN * k;  // call, then d/d(S0 V0 κ θ σ ρ r_drift)
+    double* g = grad_out + HH_CM_GRAD_LEN * k;
+    for (int i = 0; i < 7; ++i) g[i] = o[1 + i];
+    g[HH_CM_GRAD_DISCOUNT] = o[0] / discounts[k];  // the price is linear in the discount factor
+    double price = o[0];
+    if (cps[k] < 0.0) {  // parity_transform (payoffs.jl:172-193): put = call − S + K·D
+      price = price - m->S0 + strikes[k] * discounts[k];
+      g[HH_CM_GRAD_S0] -= 1.0;
+      g[HH_CM_GRAD_DISCOUNT] += strikes[k];
+    }
+    prices_out[k] = price;
+  }
+  return HH_OK;
+}
+
 size_t hh_lsm_grid_elems(uint64_t n_paths, uint32_t n_steps, int32_t antithetic) {
   return (size_t)(n_steps + 1) * n_paths * (antithetic ? 2 : 1);
 }

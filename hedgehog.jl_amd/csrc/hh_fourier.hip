@@ -101,6 +101,183 @@ __constant__ double kGLw[8] = {0.1894506104550684962853967, 0.182603415044923588
                                0.1246289712555338720524763, 0.0951585116824927848099251,
                                0.0622535239386478928628438, 0.0271524594117540948517806};
 
+// ---- gradient of the price: complex numbers carrying P complex partials --------------------------
+// The reference differentiates its calibration objective with ForwardDiff, i.e. pushes Duals through
+// carr_madan.jl:47-92 and heston.jl:307-319.  Here the partials of the CF with respect to κ, σ, ρ are
+// carried through the same expressions (3 directions); V0, θ, S0 and the rate enter log ϕ linearly:
+//   log ϕ = C(κ,θ,σ,ρ) + V0·D(κ,σ,ρ) + iu (log S0 + rT),  C ∝ θ
+//   ∂ϕ/∂V0 = ϕ D,  ∂ϕ/∂θ = ϕ C/θ,  ∂ϕ/∂S0 = ϕ iu/S0,  ∂ϕ/∂r = ϕ iu T.
+template <int P>
+struct zd {
+  cz v;
+  cz d[P];
+};
+template <int P>
+__device__ __forceinline__ zd<P> operator+(const zd<P>& a, const zd<P>& b) {
+  zd<P> r;
+  r.v = a.v + b.v;
+#pragma unroll
+  for (int k = 0; k < P; ++k) r.d[k] = a.d[k] + b.d[k];
+  return r;
+}
+template <int P>
+__device__ __forceinline__ zd<P> operator-(const zd<P>& a, const zd<P>& b) {
+  zd<P> r;
+  r.v = a.v - b.v;
+#pragma unroll
+  for (int k = 0; k < P; ++k) r.d[k] = a.d[k] - b.d[k];
+  return r;
+}
+template <int P>
+__device__ __forceinline__ zd<P> operator*(const zd<P>& a, const zd<P>& b) {
+  zd<P> r;
+  r.v = a.v * b.v;
+#pragma unroll
+  for (int k = 0; k < P; ++k) r.d[k] = a.d[k] * b.v + a.v * b.d[k];
+  return r;
+}
+template <int P>
+__device__ __forceinline__ zd<P> operator*(cz s, const zd<P>& a) {
+  zd<P> r;
+  r.v = s * a.v;
+#pragma unroll
+  for (int k = 0; k < P; ++k) r.d[k] = s * a.d[k];
+  return r;
+}
+template <int P>
+__device__ __forceinline__ zd<P> operator*(double s, const zd<P>& a) {
+  return cz{s, 0.0} * a;
+}
+template <int P>
+__device__ __forceinline__ zd<P> zdivd(const zd<P>& a, const zd<P>& b) {
+  zd<P> r;
+  const cz ib = zdiv({1.0, 0.0}, b.v);
+  r.v = a.v * ib;
+#pragma unroll
+  for (int k = 0; k < P; ++k) r.d[k] = (a.d[k] - r.v * b.d[k]) * ib;
+  return r;
+}
+template <int P>
+__device__ __forceinline__ zd<P> zsqrtd(const zd<P>& a) {
+  zd<P> r;
+  r.v = zsqrt(a.v);
+  const cz h = zdiv({0.5, 0.0}, r.v);
+#pragma unroll
+  for (int k = 0; k < P; ++k) r.d[k] = a.d[k] * h;
+  return r;
+}
+template <int P>
+__device__ __forceinline__ zd<P> zexpd(const zd<P>& a) {
+  zd<P> r;
+  r.v = zexp(a.v);
+#pragma unroll
+  for (int k = 0; k < P; ++k) r.d[k] = r.v * a.d[k];
+  return r;
+}
+template <int P>
+__device__ __forceinline__ zd<P> zlogd(const zd<P>& a) {
+  zd<P> r;
+  r.v = zlog(a.v);
+  const cz ia = zdiv({1.0, 0.0}, a.v);
+#pragma unroll
+  for (int k = 0; k < P; ++k) r.d[k] = a.d[k] * ia;
+  return r;
+}
+template <int P>
+__device__ __forceinline__ zd<P> zconst(double x, int dir = -1) {  // a real parameter, seeded along `dir`
+  zd<P> r;
+  r.v = {x, 0.0};
+#pragma unroll
+  for (int k = 0; k < P; ++k) r.d[k] = {k == dir ? 1.0 : 0.0, 0.0};
+  return r;
+}
+
+// C and D of heston.jl:307-319 with their partials along (κ, σ, ρ); same expressions as heston_cf
+__device__ void heston_CD(const FourierArgs& a, cz u, zd<3>& C, zd<3>& Dv) {
+  const zd<3> kappa = zconst<3>(a.kappa, 0), sigma = zconst<3>(a.sigma, 1), rho = zconst<3>(a.rho, 2);
+  const cz iu = {-u.im, u.re};
+  const zd<3> rs = rho * sigma;
+  const zd<3> kri = kappa - iu * rs;                              // κ − ρσ·iu
+  const zd<3> s2 = sigma * sigma;
+  const zd<3> d1 = zsqrtd(kri * kri + (iu + u * u) * s2);
+  const zd<3> g = zdivd(kri - d1, kri + d1);
+  const zd<3> ed = zexpd(cz{-a.T, 0.0} * d1);
+  const zd<3> one = zconst<3>(1.0);
+  const zd<3> one_m_ged = one - g * ed;
+  const zd<3> kms = zdivd(kappa, s2);                             // κ/σ²  (· θ below)
+  C = a.theta * (kms * (a.T * (kri - d1) - 2.0 * zlogd(zdivd(one_m_ged, one - g))));
+  Dv = zdivd((kri - d1) * zdivd(one - ed, one_m_ged), s2);
+}
+
+// Price and gradient of one payoff per workgroup.  out[k][0] = call price, out[k][1..7] = its partials
+// along S0, V0, κ, θ, σ, ρ, r_drift (lognormal: S0, σ, r_drift in slots 1, 5, 7; the others 0).
+constexpr int kGradVals = 8;
+__global__ __launch_bounds__(256) void carr_madan_grad_kernel(const FourierArgs a0) {
+  FourierArgs a = a0;
+  const uint32_t kp = blockIdx.x, n = a0.n_payoffs;
+  a.logK = a0.per_payoff[kp];
+  a.T = a0.per_payoff[n + kp];
+  a.r = a0.per_payoff[2 * n + kp];
+  a.discount = a0.per_payoff[3 * n + kp];
+  const double sqT = sqrt(a.T), tmul = a0.compat_sqrt_alpha ? sqT : a.T;
+  a.law_mu = a.logS0 + (a.r - 0.5 * a0.sigma_ln * a0.sigma_ln) * tmul;
+  a.law_sd = a0.sigma_ln * sqT;
+  const double S0 = exp(a.logS0);
+  const double w = 2.0 * a.bound / 256.0;
+  const double mid = -a.bound + (threadIdx.x + 0.5) * w, half = 0.5 * w;
+  const double damp = exp(-a.alpha * a.logK) / 6.28318530717958647692;
+  double acc[kGradVals];
+#pragma unroll
+  for (int i = 0; i < kGradVals; ++i) acc[i] = 0.0;
+  auto node = [&](double v, double wt) {
+    const cz u = {v, -(a.alpha + 1.0)};
+    const cz iu = {-u.im, u.re};
+    const cz den = {a.alpha * a.alpha + a.alpha - v * v, v * (2.0 * a.alpha + 1.0)};
+    const cz kern = (wt * damp * a.discount) * (zdiv({1.0, 0.0}, den) * zexp({0.0, -v * a.logK}));
+    cz phi, dl[7];  // ∂ log ϕ along S0, V0, κ, θ, σ, ρ, r
+#pragma unroll
+    for (int i = 0; i < 7; ++i) dl[i] = {0.0, 0.0};
+    if (a.dynamics == HH_HESTON) {
+      zd<3> C, Dv;
+      heston_CD(a, u, C, Dv);
+      phi = zexp(C.v + a.V0 * Dv.v + (a.logS0 + a.r * a.T) * iu);
+      dl[0] = (1.0 / S0) * iu;
+      dl[1] = Dv.v;
+      dl[2] = C.d[0] + a.V0 * Dv.d[0];
+      dl[3] = (1.0 / a.theta) * C.v;
+      dl[4] = C.d[1] + a.V0 * Dv.d[1];
+      dl[5] = C.d[2] + a.V0 * Dv.d[2];
+      dl[6] = a.T * iu;
+    } else {  // sample_from_cf.jl:14-16: log ϕ = i t μ − σ_T² t²/2, μ = log S0 + (r − σ²/2)·tmul
+      const cz t = u, it = iu, t2 = t * t;
+      phi = zexp(a.law_mu * it - (0.5 * a.law_sd * a.law_sd) * t2);
+      dl[0] = (1.0 / S0) * it;
+      dl[4] = (-a0.sigma_ln * tmul) * it - (a0.sigma_ln * a.T) * t2;
+      dl[6] = tmul * it;
+    }
+    const cz base = kern * phi;
+    acc[0] += base.re;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) acc[1 + i] += (base * dl[i]).re;
+  };
+#pragma unroll 1
+  for (int k = 0; k < 8; ++k) {
+    node(mid - half * kGLx[k], kGLw[k] * half);
+    node(mid + half * kGLx[k], kGLw[k] * half);
+  }
+  __shared__ double sm[4][kGradVals];
+#pragma unroll
+  for (int i = 0; i < kGradVals; ++i) {
+    double s = acc[i];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6][i] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < kGradVals)
+    a0.out[(size_t)kp * kGradVals + threadIdx.x] =
+        ((sm[0][threadIdx.x] + sm[1][threadIdx.x]) + sm[2][threadIdx.x]) + sm[3][threadIdx.x];
+}
+
 __global__ __launch_bounds__(256) void carr_madan_kernel(const FourierArgs a0) {
   FourierArgs a = a0;
   if (a0.per_payoff) {  // payoff blockIdx.x of a basket: its expiry-dependent scalars
@@ -144,6 +321,23 @@ int launch_carr_madan_basket(const hh_model& m, int dynamics, int compat_sqrt_al
   a.n_payoffs = n_payoffs;
   a.compat_sqrt_alpha = (uint32_t)(compat_sqrt_alpha != 0);
   hipLaunchKernelGGL(carr_madan_kernel, dim3(n_payoffs), dim3(256), 0, s, a);
+  return (int)hipGetLastError();
+}
+
+int launch_carr_madan_grad(const hh_model& m, int dynamics, int compat_sqrt_alpha, double alpha,
+                           double bound, const double* per_payoff_dev, uint32_t n_payoffs,
+                           double* out_dev, hipStream_t s) {
+  FourierArgs a{};
+  a.dynamics = dynamics;
+  a.logS0 = log(m.S0); a.V0 = m.V0; a.kappa = m.kappa; a.theta = m.theta; a.sigma = m.sigma;
+  a.rho = m.rho;
+  a.sigma_ln = m.sigma;
+  a.alpha = alpha; a.bound = bound;
+  a.out = out_dev;
+  a.per_payoff = per_payoff_dev;
+  a.n_payoffs = n_payoffs;
+  a.compat_sqrt_alpha = (uint32_t)(compat_sqrt_alpha != 0);
+  hipLaunchKernelGGL(carr_madan_grad_kernel, dim3(n_payoffs), dim3(256), 0, s, a);
   return (int)hipGetLastError();
 }
 

@@ -121,6 +121,11 @@ int launch_carr_madan(const hh_model& m, int dynamics, int compat_sqrt_alpha, do
                       double bound, double* out_dev, hipStream_t s);
 // n_payoffs Carr–Madan integrals in one launch (one workgroup each); per_payoff_dev = [4][n_payoffs]:
 // log K, T, r_drift, discount; out_dev[n_payoffs] receives the CALL prices
+// the same with the gradient: out_dev[n_payoffs][8] = call price, then its partials along
+// S0, V0, kappa, theta, sigma, rho, r_drift
+int launch_carr_madan_grad(const hh_model& m, int dynamics, int compat_sqrt_alpha, double alpha,
+                           double bound, const double* per_payoff_dev, uint32_t n_payoffs,
+                           double* out_dev, hipStream_t s);
 int launch_carr_madan_basket(const hh_model& m, int dynamics, int compat_sqrt_alpha, double alpha,
                              double bound, const double* per_payoff_dev, uint32_t n_payoffs,
                              double* out_dev, hipStream_t s);

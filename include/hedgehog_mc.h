@@ -235,6 +235,21 @@ int hh_carr_madan_basket(hh_ctx* ctx, const hh_model* model, int32_t dynamics,
                          int32_t compat_sqrt_alpha, double alpha, double bound, const double* strikes,
                          const double* cps, const double* Ts, const double* r_drifts,
                          const double* discounts, uint32_t n_payoffs, double* prices_out);
+/*
+ * Prices AND their gradient in one launch — what a ForwardDiff-differentiated calibration objective
+ * (calibration.jl:75-88 with AutoForwardDiff) pushes through carr_madan.jl:47-92 and heston.jl:307-319
+ * as Dual numbers.  grad_out[k][HH_CM_GRAD_LEN] = ∂price_k / ∂(S0, V0, kappa, theta, sigma, rho,
+ * r_drift_k, discount_k) in that order (enum hh_cm_grad); the caller's Dual price is
+ * price + Σ_j grad[j]·(partials of parameter j), r_drift_k and discount_k being whatever its rate curve
+ * makes of its parameters.  Lognormal dynamics: sigma = the volatility; V0, kappa, theta, rho slots 0.
+ */
+enum hh_cm_grad { HH_CM_GRAD_S0 = 0, HH_CM_GRAD_V0, HH_CM_GRAD_KAPPA, HH_CM_GRAD_THETA, HH_CM_GRAD_SIGMA,
+                  HH_CM_GRAD_RHO, HH_CM_GRAD_R_DRIFT, HH_CM_GRAD_DISCOUNT, HH_CM_GRAD_LEN };
+int hh_carr_madan_basket_grad(hh_ctx* ctx, const hh_model* model, int32_t dynamics,
+                              int32_t compat_sqrt_alpha, double alpha, double bound,
+                              const double* strikes, const double* cps, const double* Ts,
+                              const double* r_drifts, const double* discounts, uint32_t n_payoffs,
+                              double* prices_out, double* grad_out);
 
 /*
  * Longstaff–Schwartz American pricing on the full path grid:

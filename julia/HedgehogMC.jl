@@ -12,7 +12,7 @@
 #
 # What is bound (include/hedgehog_mc.h, HH_ABI_VERSION 2): hh_mc_solve (solve_hip, with the REPLAY
 # keywords), hh_mc_accumulate + hh_mc_finalize (solve_sharded_hip), hh_mc_solve_basket, hh_carr_madan,
-# hh_carr_madan_basket, hh_ctx_set_option, hh_lsm_solve, hh_heston_exact_grid, hh_replay_elems, the device-memory helpers.  The struct mirrors
+# hh_carr_madan_basket (+ _grad), hh_ctx_set_option, hh_lsm_solve, hh_heston_exact_grid, hh_replay_elems, the device-memory helpers.  The struct mirrors
 # below are checked field by field against the C header by tests/test_julia_layout.py (offsets from
 # a compiled offsetof dump), so a drift between the two shows up on the CPU, without Julia.
 module HedgehogMC
@@ -309,8 +309,10 @@ end
 
 `hh_carr_madan_basket`: every payoff's Fourier integral in ONE launch (a workgroup per payoff) —
 `solve(::BasketPricingProblem, ::CarrMadan)` (src/calibration/basket.jl:35-38), what the calibration
-objective evaluates at every iterate (src/calibration/calibration.jl:75-88).  Plain Float64 inputs
-only: an objective differentiated by ForwardDiff keeps the reference's own method.
+objective evaluates at every iterate (src/calibration/calibration.jl:75-88).  When an input is a
+`ForwardDiff.Dual` (the objective under `AutoForwardDiff`), `hh_carr_madan_basket_grad` returns the
+gradient along (S0, V0, κ, θ, σ, ρ, r_drift_k, discount_k) with the prices and the Dual prices are
+assembled here: `price + Σ_j grad[j] · partials(parameter_j)`.
 """
 function carr_madan_basket_hip(prob::Hedgehog.BasketPricingProblem, method::Hedgehog.CarrMadan;
                                compat_sqrt_alpha::Bool = false)
@@ -319,27 +321,47 @@ function carr_madan_basket_hip(prob::Hedgehog.BasketPricingProblem, method::Hedg
     strikes = Float64[p.strike for p in prob.payoffs]
     cps = Float64[p.call_put() for p in prob.payoffs]
     Ts = Float64[yearfrac(m.rate.reference_date, p.expiry) for p in prob.payoffs]
-    rs = Float64[zero_rate(m.rate, p.expiry) for p in prob.payoffs]
-    Ds = Float64[df(m.rate, p.expiry) for p in prob.payoffs]
+    r_k = [zero_rate(m.rate, p.expiry) for p in prob.payoffs]
+    D_k = [df(m.rate, p.expiry) for p in prob.payoffs]
+    rs, Ds = Float64[_val(x) for x in r_k], Float64[_val(x) for x in D_k]
     none = ntuple(_ -> Ptr{Cdouble}(C_NULL), 8)
     if m isa HestonInputs
         dynamics = Int32(1)
-        model = HHModel(Float64(m.spot), Float64(m.V0), Float64(m.κ), Float64(m.θ), Float64(m.σ),
-                        Float64(m.ρ), 0.0, 1.0, 1.0, 1.0, 1.0, none...)
+        scal = (m.spot, m.V0, m.κ, m.θ, m.σ, m.ρ)
     else
         dynamics = Int32(0)
-        model = HHModel(Float64(m.spot), 0.0, 0.0, 0.0, Float64(get_vol(m.sigma, nothing, nothing)), 0.0,
-                        0.0, 1.0, 1.0, 1.0, 1.0, none...)
+        scal = (m.spot, 0.0, 0.0, 0.0, get_vol(m.sigma, nothing, nothing), 0.0)
     end
+    model = HHModel(Float64(_val(scal[1])), Float64(_val(scal[2])), Float64(_val(scal[3])),
+                    Float64(_val(scal[4])), Float64(_val(scal[5])), Float64(_val(scal[6])),
+                    0.0, 1.0, 1.0, 1.0, 1.0, none...)
     out = Vector{Float64}(undef, n)
     ctx = context()
-    rc = ccall((:hh_carr_madan_basket, LIB[]), Cint,
+    P = max(maximum(_npartials, scal), maximum(_npartials, r_k), maximum(_npartials, D_k))
+    mk(p, price) = Hedgehog.AnalyticSolution(PricingProblem(p, m), method, price)
+    if P == 0
+        rc = ccall((:hh_carr_madan_basket, LIB[]), Cint,
+                   (Ptr{Cvoid}, Ref{HHModel}, Int32, Int32, Cdouble, Cdouble, Ptr{Cdouble}, Ptr{Cdouble},
+                    Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, UInt32, Ptr{Cdouble}),
+                   ctx.handle, model, dynamics, Int32(compat_sqrt_alpha), Float64(method.α),
+                   Float64(method.bound), strikes, cps, Ts, rs, Ds, UInt32(n), out)
+        rc == 0 || error("hh_carr_madan_basket failed ($rc): $(last_error(ctx))")
+        return Hedgehog.BasketPricingSolution(prob, [mk(p, out[k]) for (k, p) in enumerate(prob.payoffs)])
+    end
+    grad = Matrix{Float64}(undef, 8, n)     # column k = hh_cm_grad of payoff k (C: [n][8])
+    rc = ccall((:hh_carr_madan_basket_grad, LIB[]), Cint,
                (Ptr{Cvoid}, Ref{HHModel}, Int32, Int32, Cdouble, Cdouble, Ptr{Cdouble}, Ptr{Cdouble},
-                Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, UInt32, Ptr{Cdouble}),
+                Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, UInt32, Ptr{Cdouble}, Ptr{Cdouble}),
                ctx.handle, model, dynamics, Int32(compat_sqrt_alpha), Float64(method.α),
-               Float64(method.bound), strikes, cps, Ts, rs, Ds, UInt32(n), out)
-    rc == 0 || error("hh_carr_madan_basket failed ($rc): $(last_error(ctx))")
-    sols = [Hedgehog.AnalyticSolution(PricingProblem(p, m), method, out[k]) for (k, p) in enumerate(prob.payoffs)]
+               Float64(method.bound), strikes, cps, Ts, rs, Ds, UInt32(n), out, grad)
+    rc == 0 || error("hh_carr_madan_basket_grad failed ($rc): $(last_error(ctx))")
+    DT = _dualtype(scal..., r_k..., D_k...)
+    seeds = [_partials(x, P) for x in scal]
+    sols = map(enumerate(prob.payoffs)) do (k, p)
+        sr, sD = _partials(r_k[k], P), _partials(D_k[k], P)
+        d = ntuple(q -> sum(grad[j, k] * seeds[j][q] for j in 1:6) + grad[7, k] * sr[q] + grad[8, k] * sD[q], P)
+        mk(p, DT(out[k], ForwardDiff.Partials(d)))
+    end
     return Hedgehog.BasketPricingSolution(prob, sols)
 end
 
@@ -488,6 +510,11 @@ function install!()
         gprob::BatchGreekProblem{P,L}, ::ForwardAD, pricing_method::MonteCarlo,
     ) where {P,L}
         return $(solve_batch_greeks_hip)(gprob, pricing_method)
+    end
+    # the calibration objective's inner loop (calibration.jl:75-88): every quote in one launch, Dual
+    # inputs (AutoForwardDiff) included
+    @eval Hedgehog function solve(prob::BasketPricingProblem, method::CarrMadan)
+        return $(carr_madan_basket_hip)(prob, method)
     end
     return nothing
 end
