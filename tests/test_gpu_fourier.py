@@ -201,3 +201,28 @@ def test_carr_madan_basket_returns_dual_prices():
         for s, p0, u, d in zip(sol.solutions, plain.solutions, up.solutions, dn.solutions):
             assert isinstance(s.price, Dual) and s.price.value == pytest.approx(p0.price, rel=1e-13)
             assert s.price.partials[j] == pytest.approx((u.price - d.price) / (2 * h), rel=5e-6, abs=5e-7), name
+
+
+if given is not None:
+    @settings(max_examples=40, deadline=None, derandomize=True, database=None,
+              phases=[Phase.explicit, Phase.generate], suppress_health_check=[HealthCheck.too_slow])
+    @given(V0=st.floats(0.01, 0.4), kappa=st.floats(0.2, 5.0), theta=st.floats(0.01, 0.3),
+           sigma=st.floats(0.1, 1.0), rho=st.floats(-0.9, 0.9), r=st.floats(0.0, 0.08),
+           T=st.floats(0.1, 4.0), moneyness=st.floats(0.7, 1.4), put=st.booleans())
+    def test_carr_madan_gradient_random_heston(V0, kappa, theta, sigma, rho, r, T, moneyness, put):
+        """The device gradient over random Heston parameters against central differences of the device
+        prices: the complex logarithm and square root of the CF stay on their branches (the formulation
+        with exp(-d1 T) of heston.jl:307-319) and so do their partials."""
+        from hedgehog_jl_amd import _ffi
+        ctx = hh.get_context(0)
+        base = dict(S0=100.0, V0=V0, kappa=kappa, theta=theta, sigma=sigma, rho=rho)
+        args = (np.array([100.0 * moneyness]), np.array([-1.0 if put else 1.0]), np.array([T]), np.array([r]))
+        price, grad = _cm_basket(ctx, base, _ffi.HH_HESTON, *args, grad=True)
+        assert np.isfinite(price[0]) and np.all(np.isfinite(grad))
+        for name, j in (("S0", 0), ("V0", 1), ("kappa", 2), ("theta", 3), ("sigma", 4), ("rho", 5)):
+            h = 2e-5 * max(abs(base[name]), 0.05)
+            up = _cm_basket(ctx, dict(base, **{name: base[name] + h}), _ffi.HH_HESTON, *args)[0]
+            dn = _cm_basket(ctx, dict(base, **{name: base[name] - h}), _ffi.HH_HESTON, *args)[0]
+            fd = (up - dn) / (2 * h)
+            scale = max(abs(fd), abs(price[0]) / max(abs(base[name]), 0.05), 1e-2)
+            assert abs(grad[0, j] - fd) <= 2e-5 * scale, (name, grad[0, j], fd)
