@@ -226,3 +226,18 @@ if given is not None:
             fd = (up - dn) / (2 * h)
             scale = max(abs(fd), abs(price[0]) / max(abs(base[name]), 0.05), 1e-2)
             assert abs(grad[0, j] - fd) <= 2e-5 * scale, (name, grad[0, j], fd)
+
+
+def test_heston_calibration_scenario_of_the_reference():
+    """test/unit/calibration.jl:38-108 on the device path: 51 Carr–Madan quotes from known Heston
+    parameters, start and bounds as there; the reference asks for each parameter within rtol 1e-1 — with
+    the exact Jacobian from the device the fit is to 1e-4."""
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location(
+        "heston_calibration", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                           "examples", "heston_calibration.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    x, sse, evals, wall = mod.calibrate()
+    np.testing.assert_allclose(x, mod.TRUE, rtol=1e-4)
+    assert sse < 1e-12 and evals < 200
