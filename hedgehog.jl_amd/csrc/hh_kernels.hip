@@ -78,17 +78,31 @@ struct HestonModel {
         const double r0 = __builtin_amdgcn_rcp(sq);
         inv2s = 0.5 * fma(r0, fma(-sq, r0, 1.0), r0);
       }
+      // The propagation of (dx, dv) is the same linear map for every direction, plus a forcing that
+      // differs by the direction's seeds: the map's coefficients are formed ONCE per step
+      //   Kvd = m·dv + f_k,        m = 1 - dt κ [v>0],   f_k = dκ_k·dt(θ - v+) + dt κ·dθ_k
+      //   dx' = dx + dt·dr_k - h·dv + e1·Kvd,            h = dt/2 [v>0],  e1 = dW1 / (2 sqrt w) [w>0]
+      //   dv' = e2·Kvd + dσ_k·(sqrt(w) dW2),             e2 = 1 + σ dW2 / (2 sqrt w) [w>0]
+      // (diffusion taken at u instead of K: the sqrt's tangent acts on dv, not on Kvd) — 6-7 fused
+      // operations per direction instead of 12; algebraically the step-by-step dual rules above.
+      const double A = a.dt * th_m_v, B = sq * dW2;
+      const double m = pos ? 1.0 - a.dt * a.kappa.v : 1.0;
+      const double h = pos ? 0.5 * a.dt : 0.0;
+      const double e1 = inv2s * dW1;
+      const double se2 = (a.sigma.v * inv2s) * dW2;
 #pragma unroll
       for (int k = 0; k < P; ++k) {
-        const double vpd = pos ? s.v.d[k] : 0.0;
-        const double Kxd = fma(a.dt, a.r.d[k] - 0.5 * vpd, s.x.d[k]);
-        const double fvd = fma(a.kappa.d[k], th_m_v, a.kappa.v * (a.theta.d[k] - vpd));
-        const double Kvd = fma(a.dt, fvd, s.v.d[k]);
-        const double wd = SPLIT ? (wpos ? Kvd : 0.0) : vpd;
-        const double sd = wd * inv2s;
-        const double gvd = fma(a.sigma.d[k], sq, a.sigma.v * sd);
-        s.x.d[k] = fma(sd, dW1, Kxd);
-        s.v.d[k] = fma(gvd, dW2, Kvd);
+        const double dv = s.v.d[k];
+        const double f = fma(a.kappa.d[k], A, (a.dt * a.kappa.v) * a.theta.d[k]);
+        const double Kvd = fma(m, dv, f);
+        const double x0 = s.x.d[k] + a.dt * a.r.d[k];
+        if constexpr (SPLIT) {
+          s.x.d[k] = fma(e1, Kvd, fma(-h, dv, x0));
+          s.v.d[k] = fma(se2, Kvd, fma(a.sigma.d[k], B, Kvd));
+        } else {
+          s.x.d[k] = fma(e1 - h, dv, x0);
+          s.v.d[k] = fma(se2, dv, fma(a.sigma.d[k], B, Kvd));
+        }
       }
     }
     s.x.v = fma(sq, dW1, Kx);
