@@ -140,11 +140,17 @@ def solve_carr_madan(prob: PricingProblem, method: CarrMadan) -> AnalyticSolutio
     payoff, m = prob.payoff, prob.market_inputs
     if not (isinstance(payoff, VanillaOption) and isinstance(payoff.exercise_style, European)):
         raise MethodError("CarrMadan: European VanillaOption")
-    model, dyn, _ = _carr_madan_model(m, method)
+    from .dual import n_partials
+    model, dyn, scal = _carr_madan_model(m, method)
+    r_k, D_k = zero_rate(m.rate, payoff.expiry), df(m.rate, payoff.expiry)
+    if n_partials(*scal, r_k, D_k) > 0:
+        # a Dual input (solve(GreekProblem(prob, lens), ForwardAD(), CarrMadan(...)), greeks_problem.jl:249-262):
+        # the price must carry the partials — the gradient form, as a basket of one
+        return AnalyticSolution(prob, method, solve_carr_madan_basket([payoff], m, method)[0])
     model.strike, model.cp = float(payoff.strike), payoff.call_put()
     model.T = yearfrac(m.rate.reference_date, payoff.expiry)      # montecarlo.jl:301,317
-    model.r_drift = float(zero_rate(m.rate, payoff.expiry))       # montecarlo.jl:299,318
-    model.discount = float(df(m.rate, payoff.expiry))             # carr_madan.jl:89
+    model.r_drift = float(r_k)                                    # montecarlo.jl:299,318
+    model.discount = float(D_k)                                   # carr_madan.jl:89
     out = C.c_double()
     ctx = _ffi.get_context(method.device)
     ctx.check(ctx.lib.hh_carr_madan(ctx.handle, C.byref(model), dyn, int(method.compat_sqrt_alpha),

@@ -282,6 +282,11 @@ function carr_madan_hip(prob::PricingProblem{VanillaOption{TS,TE,European,C,Spot
     T = yearfrac(m.rate.reference_date, payoff.expiry)
     r = zero_rate(m.rate, payoff.expiry)
     D = df(m.rate, payoff.expiry)
+    scal = m isa HestonInputs ? (m.spot, m.V0, m.κ, m.θ, m.σ, m.ρ, r, D) : (m.spot, get_vol(m.sigma, nothing, nothing), r, D)
+    if _dualtype(scal...) !== nothing   # greeks_problem.jl:249-262: the price must carry the partials
+        basket = Hedgehog.BasketPricingProblem([payoff], m)
+        return carr_madan_basket_hip(basket, method; compat_sqrt_alpha = compat_sqrt_alpha).solutions[1]
+    end
     none = ntuple(_ -> Ptr{Cdouble}(C_NULL), 8)
     if m isa HestonInputs
         dynamics = Int32(1)

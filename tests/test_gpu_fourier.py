@@ -241,3 +241,21 @@ def test_heston_calibration_scenario_of_the_reference():
     x, sse, evals, wall = mod.calibrate()
     np.testing.assert_allclose(x, mod.TRUE, rtol=1e-4)
     assert sse < 1e-12 and evals < 200
+
+
+def test_ad_greeks_through_carr_madan():
+    """solve(GreekProblem(prob, lens), ForwardAD(), CarrMadan(...)) (greeks_problem.jl:249-262): the Dual the
+    lens plants reaches the device as a gradient request and comes back as the price's partial — Δ, ∂V0
+    and ρ (drift and discount together, through the rate curve) of the H252 problem, against the values
+    the Monte Carlo Greek tests use as their Fourier targets, and against finite differences."""
+    prob = heston_prob((0.04, 2.0, 0.04, 0.3, -0.7), 0.03, hh.Date(2021, 1, 1), hh.Date(2022, 1, 1))
+    method = hh.CarrMadan(1.0, 400.0, hh.HestonDynamics())
+    lenses = (hh.optic("market_inputs.spot"), hh.optic("market_inputs.V0"), hh.optic("market_inputs.rate.rate"))
+    targets = (0.65565115, 40.7248418, 56.3225943)
+    for lens, want in zip(lenses, targets):
+        g = hh.solve(hh.GreekProblem(prob, lens), hh.ForwardAD(), method).greek
+        assert g == pytest.approx(want, rel=2e-7)
+        fd = hh.solve(hh.GreekProblem(prob, lens), hh.FiniteDifference(1e-5), method).greek
+        assert g == pytest.approx(fd, rel=1e-6)
+    batch = hh.solve(hh.BatchGreekProblem(prob, lenses), hh.ForwardAD(), method)
+    assert [batch[l] for l in lenses] == pytest.approx(list(targets), rel=2e-7)
