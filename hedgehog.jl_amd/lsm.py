@@ -58,6 +58,15 @@ def _lsm_structs(prob: PricingProblem, mc: MonteCarlo):
     """hh_model / hh_config of the path source behind an LSM solve (or a bare path simulation)."""
     payoff, m = prob.payoff, prob.market_inputs
     cfg = mc.config
+    from .dual import n_partials
+    inputs = [getattr(m, a) for a in ("spot", "V0", "κ", "θ", "σ", "ρ") if hasattr(m, a)] + [payoff.strike]
+    if isinstance(m, BlackScholesInputs):
+        inputs.append(get_vol(m.sigma, None, None))
+    if n_partials(*inputs, zero_rate(m.rate, 0.0)) > 0:
+        # stopping decisions are not differentiable and the kernels carry no partials along full paths:
+        # a Dual must not be dropped silently (float(Dual) would) — FiniteDifference works on plain solves
+        raise MethodError("ForwardAD through the full-path kernels (LSM, exact Heston paths) is not carried; "
+                          "use FiniteDifference")
     T = yearfrac(m.referenceDate, payoff.expiry)                       # :104, montecarlo.jl:147,219
     model = _ffi.hh_model()
     c = _ffi.hh_config()

@@ -258,3 +258,19 @@ def test_optional_ring_form_of_the_replay_kernel_still_compiles(tmp_path):
                            "-DHH_REPLAY_PAD_KIB=0", src, "-o", str(out)],
                           capture_output=True, text=True)
     assert proc.returncode == 0, proc.stderr[-2000:]
+
+
+def test_full_path_entry_points_refuse_duals_instead_of_dropping_them():
+    """float(Dual) is defined (value part), so a host layer that packs plain doubles would silently return a
+    price without partials: LSM and the exact Heston paths carry none, and say so."""
+    from hedgehog_jl_amd.dual import Dual
+    from hedgehog_jl_amd.lsm import _lsm_structs
+    ref, exp_ = hh.Date(2021, 1, 1), hh.Date(2022, 1, 1)
+    put = hh.VanillaOption(100.0, exp_, hh.American(), hh.Put(), hh.Spot())
+    mc = hh.MonteCarlo(hh.LognormalDynamics(), hh.BlackScholesExact(), hh.SimulationConfig(100, steps=10))
+    for mkt in (hh.BlackScholesInputs(ref, 0.05, Dual(100.0, (1.0,)), 0.2),
+                hh.BlackScholesInputs(ref, 0.05, 100.0, Dual(0.2, (1.0,))),
+                hh.BlackScholesInputs(ref, Dual(0.05, (1.0,)), 100.0, 0.2)):
+        with pytest.raises(hh.MethodError, match="FiniteDifference"):
+            _lsm_structs(hh.PricingProblem(put, mkt), mc)
+    _lsm_structs(hh.PricingProblem(put, hh.BlackScholesInputs(ref, 0.05, 100.0, 0.2)), mc)
