@@ -148,7 +148,12 @@ def solve_greek_ad(gprob: GreekProblem, pricing_method, solve):
     prob, lens = gprob.pricing_problem, gprob.wrt
     x0 = lens(prob)
     price = solve(set(prob, lens, _seed(x0, 0, 1)), pricing_method).price
-    return GreekResult(price.partials[0] if isinstance(price, Dual) else 0.0)
+    if not isinstance(price, Dual):
+        # the method took the Dual's value and returned a plain price (the closed-form host pricers do):
+        # a Greek of 0 would be a silent wrong answer
+        from .montecarlo import MethodError
+        raise MethodError(f"{type(pricing_method).__name__} does not carry dual partials: use FiniteDifference")
+    return GreekResult(price.partials[0])
 
 
 def solve_greek_fd(gprob: GreekProblem, method: FiniteDifference, pricing_method, solve):
