@@ -113,6 +113,13 @@ constexpr uint64_t kMaxPaths = (1ull << 32) - 256;
 constexpr uint32_t kMaxEulerSteps = 4u * 65535u;  // replay_pack_kernel: 4 steps per grid.y
 constexpr uint32_t kMaxGridSteps = 65534u;        // LSM / exact grid: one grid.y per row, n_steps + 1 rows
 
+// degrees of freedom of the noncentral chi-squared law of V_T (heston.jl:128): the Bessel order is
+// d/2 - 1, which must stay strictly above -1 in fp64 and within what the tables of hh_bessel.h cover
+static bool bk_law_ok(const hh_model* m) {
+  const double d = 4.0 * m->kappa * m->theta / (m->sigma * m->sigma);
+  return d >= 1e-8 && d <= 1e6;
+}
+
 int validate(hh_ctx* ctx, const hh_model* m, const hh_config* c) {
   if (!m || !c) return fail(ctx, HH_ERR_INVALID, "model/config is NULL");
   if (c->n_paths == 0) return fail(ctx, HH_ERR_INVALID, "n_paths must be >= 1");
@@ -137,6 +144,12 @@ int validate(hh_ctx* ctx, const hh_model* m, const hh_config* c) {
   if (!(m->T > 0.0) || !std::isfinite(m->T)) return fail(ctx, HH_ERR_INVALID, "T must be > 0");
   if (m->cp != 1.0 && m->cp != -1.0) return fail(ctx, HH_ERR_INVALID, "cp must be +1 or -1");
   if (hest && !(std::fabs(m->rho) <= 1.0)) return fail(ctx, HH_ERR_INVALID, "|rho| must be <= 1");
+  // the scalars the chosen dynamics reads (the reference would carry a NaN through to the price; here it
+  // is an argument error, before any launch)
+  if (!std::isfinite(m->sigma) || !std::isfinite(m->r_drift) || !std::isfinite(m->discount) ||
+      !std::isfinite(m->strike) ||
+      (hest && (!std::isfinite(m->V0) || !std::isfinite(m->kappa) || !std::isfinite(m->theta))))
+    return fail(ctx, HH_ERR_INVALID, "model scalars must be finite");
   if (c->strategy == HH_EULER_MARUYAMA && c->n_steps == 0)
     return fail(ctx, HH_ERR_INVALID, "n_steps must be >= 1 for EulerMaruyama");
   if (c->strategy == HH_BROADIE_KAYA) {
@@ -148,6 +161,10 @@ int validate(hh_ctx* ctx, const hh_model* m, const hh_config* c) {
       return fail(ctx, HH_ERR_UNSUPPORTED, "HestonBroadieKaya does not carry dual partials");
     if (m->sigma == 0.0 || m->kappa == 0.0 || !(m->V0 > 0.0))
       return fail(ctx, HH_ERR_INVALID, "HestonBroadieKaya needs sigma != 0, kappa != 0, V0 > 0");
+    // d = 4κθ/σ² degrees of freedom of the noncentral chi-squared law (heston.jl:128), λ >= 0 (:129)
+    if (!bk_law_ok(m))
+      return fail(ctx, HH_ERR_INVALID, "HestonBroadieKaya needs 1e-8 <= d = 4 kappa theta / sigma^2 <= 1e6 "
+                                       "(Bessel order d/2 - 1 strictly above -1, tables up to order 5e5)");
   }
   const bool euler = c->strategy == HH_EULER_MARUYAMA;
   if (c->noise_mode == HH_NOISE_REPLAY) {
@@ -836,9 +853,12 @@ static int run_heston_grid(hh_ctx* ctx, const hh_model* m, const hh_config* c) {
     return fail(ctx, HH_ERR_INVALID, "exact Heston grid: 1 <= n_paths <= 2^32 - 256, 1 <= n_steps <= %u",
                 kMaxGridSteps);
   if (!(m->S0 > 0.0) || !(m->T > 0.0) || !std::isfinite(m->S0) || !std::isfinite(m->T) ||
-      !(std::fabs(m->rho) <= 1.0) || m->sigma == 0.0 || m->kappa == 0.0 || !(m->V0 > 0.0))
+      !(std::fabs(m->rho) <= 1.0) || m->sigma == 0.0 || m->kappa == 0.0 || !(m->V0 > 0.0) ||
+      !std::isfinite(m->sigma) || !std::isfinite(m->kappa) || !std::isfinite(m->theta) ||
+      !std::isfinite(m->V0) || !std::isfinite(m->r_drift) ||
+      !bk_law_ok(m))
     return fail(ctx, HH_ERR_INVALID,
-                "exact Heston grid: S0, T, V0 > 0, |rho| <= 1, sigma != 0, kappa != 0");
+                "exact Heston grid: S0, T, V0 > 0, |rho| <= 1, 1e-8 <= 4 kappa theta / sigma^2 <= 1e6, all finite");
   const uint64_t n = c->n_paths;
   const size_t grid_elems = (size_t)(c->n_steps + 1) * n;
   int rc;

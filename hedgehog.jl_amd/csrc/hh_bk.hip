@@ -182,7 +182,13 @@ __device__ double cdf_from_cf(const BkArgs& p, const BesselTable* bt, const CfIt
       double& th = (j <= c.cap || c.filled < c.cap) ? c.theta_run : theta_tail;
       const cx phi = evaluate_chf(p, bt, it, aj, th);
       re = phi.re;
-      last = !(cabs(phi) >= stop * (double)j);  // |ϕ|/j < π·tol/2 (sample_from_cf.jl:88); also leaves on NaN
+      // |ϕ|/j < π·tol/2 (sample_from_cf.jl:88); also leaves on NaN and on an overflowed ϕ (a characteristic
+      // function is bounded by 1: inf would keep the reference's stopping test false for 10^6 terms)
+      // — and at term j_max = 2/(π·tol) + 1: |ϕ| <= 1 for a characteristic function, so the test MUST have
+      // been met by then; a computed |ϕ| above 1 (variances of 1e16, cancellation gone wrong) would otherwise
+      // run the series to its 10^6-term guard in every CDF evaluation
+      const double aphi = cabs(phi);
+      last = !(aphi >= stop * (double)j && aphi <= 0x1p100) || (double)j * stop > 1.0;
       if (j > c.filled) {  // first time this term is seen
         c.filled = j;
         if (j <= c.cap) c.col[(size_t)(j - 1) * c.stride] = re;
@@ -495,7 +501,8 @@ __device__ __forceinline__ void series_phase(const BkArgs& p, const BesselTable*
     const cx phi = evaluate_chf(p, bt, cf, h * (double)j, theta);
     col[(size_t)(j - 1) * p.cache_stride] = phi.re;
     const double sj = stop * (double)j;
-    if (!(fma(phi.re, phi.re, phi.im * phi.im) >= sj * sj)) {  // |ϕ|/j < π·tol/2, squared; also leaves on NaN
+    const double mag2 = fma(phi.re, phi.re, phi.im * phi.im);
+    if (!(mag2 >= sj * sj && mag2 <= 0x1p200)) {  // |ϕ|/j < π·tol/2, squared; also leaves on NaN / overflow
       j_stop = j;
       break;
     }
