@@ -115,3 +115,50 @@ def test_hostile_scalars_exact_grid(hhlib, which, vals, n_paths, n_steps):
     if rc == _ffi.HH_OK and all(1e-3 <= abs(prm[k]) <= 10.0 for k in ("V0", "kappa", "theta", "sigma", "T")) \
             and abs(prm["r"]) <= 1.0 and 1e-3 <= prm["S0"] <= 1e6:
         assert np.all(np.isfinite(spot)) and np.all(spot > 0)  # moderate inputs: moderate outputs
+
+
+@settings(max_examples=int(os.environ.get("HH_FUZZ_EXAMPLES", "80")), deadline=None, derandomize=True, database=None,
+          phases=[Phase.explicit, Phase.generate],
+          suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
+@given(strikes=st.lists(weird, min_size=1, max_size=6), cps=st.lists(st.sampled_from([1.0, -1.0, 0.0, 2.0]), min_size=6, max_size=6),
+       dynamics=st.sampled_from([0, 1]), strategy=st.sampled_from([0, 1, 2]), anti=st.sampled_from([0, 1]),
+       n_paths=st.sampled_from([1, 100, 4097]), K=st.sampled_from([0, 1, 5, 6]))
+def test_hostile_scalars_basket(hhlib, strikes, cps, dynamics, strategy, anti, n_paths, K):
+    strikes = np.array((strikes * 6)[:6], dtype=np.float64)
+    cps = np.array(cps, dtype=np.float64)
+    m = _ffi.make_model()
+    c = _ffi.make_config(dynamics, strategy, n_paths, 5, antithetic=anti,
+                         seeds=np.arange(1, n_paths + 1, dtype=np.uint64))
+    res = (_ffi.hh_result * 6)()
+    _trace("basket", list(strikes), list(cps), dynamics, strategy, anti, n_paths, K)
+    rc = hhlib.lib.hh_mc_solve_basket(hhlib.handle, C.byref(m), C.byref(c), strikes.ctypes.data, cps.ctypes.data,
+                                      K, res, None)
+    assert rc in (_ffi.HH_OK, _ffi.HH_ERR_INVALID, _ffi.HH_ERR_UNSUPPORTED), rc
+
+
+@settings(max_examples=int(os.environ.get("HH_FUZZ_EXAMPLES", "80")), deadline=None, derandomize=True, database=None,
+          phases=[Phase.explicit, Phase.generate],
+          suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
+@given(dynamics=st.sampled_from([0, 1]), strategy=st.sampled_from([0, 1, 2]), layout=st.sampled_from([0, 1, 4]),
+       n_paths=st.sampled_from([1, 255, 257, 700]), n_steps=st.sampled_from([1, 3, 9]), anti=st.sampled_from([0, 1]),
+       short=st.sampled_from([0, 1, 17]), fill=st.sampled_from([0.01, float("nan"), 1e300, -1e300]))
+def test_replay_buffers_of_every_shape(hhlib, dynamics, strategy, layout, n_paths, n_steps, anti, short, fill):
+    """REPLAY with buffers of the right size, and `short` elements too small (declared through replay_len):
+    accepted or refused on the host, never read out of bounds on the device."""
+    nc = 2 if dynamics == 1 else 1
+    if strategy == 0:
+        need = n_paths * n_steps * nc if layout == 1 else ((n_paths + 255) // 256) * n_steps * nc * 256
+    elif strategy == 2:
+        need = 3 * n_paths
+    else:
+        need = n_paths
+    buf = np.full(max(need - short, 1), fill)
+    m = _ffi.make_model()
+    c = _ffi.make_config(dynamics, strategy, n_paths, n_steps, antithetic=anti, noise_mode=_ffi.HH_NOISE_REPLAY,
+                         replay=buf, replay_layout=layout)
+    res = _ffi.hh_result()
+    _trace("replay", dynamics, strategy, layout, n_paths, n_steps, anti, short, fill)
+    rc = hhlib.lib.hh_mc_solve(hhlib.handle, C.byref(m), C.byref(c), C.byref(res), None)
+    assert rc in (_ffi.HH_OK, _ffi.HH_ERR_INVALID, _ffi.HH_ERR_UNSUPPORTED), rc
+    if short and need - short >= 1 and rc == _ffi.HH_OK:
+        raise AssertionError("a replay buffer shorter than the kernels index was accepted")
