@@ -586,7 +586,32 @@ def main():
         for _ in range(2):
             ctx.check(lib.hh_heston_exact_grid(h, C.byref(model), C.byref(c_g), None, None, 0,
                                                C.byref(r_g)))
+        # the calibration objective's inner loop (calibration.jl:75-88): 100 Heston quotes by
+        # Carr–Madan in ONE launch, plain and with the 5-parameter gradient; wall time per evaluation
+        import hedgehog_jl_amd as hh
+        from hedgehog_jl_amd.dual import Dual
+        ref_d = hh.Date(2021, 1, 1)
+        quotes = [hh.VanillaOption(float(K), e, hh.European(), hh.Call(), hh.Spot())
+                  for e in (hh.Date(2021, 4, 1), hh.Date(2021, 7, 1), hh.Date(2022, 1, 1), hh.Date(2023, 1, 1))
+                  for K in np.linspace(70.0, 140.0, 25)]
+        e5 = lambda j: tuple(1.0 if i == j else 0.0 for i in range(5))  # noqa: E731
+        mkts = (hh.HestonInputs(ref_d, 0.03, 100.0, 0.04, 2.0, 0.04, 0.3, -0.7),
+                hh.HestonInputs(ref_d, 0.03, 100.0, Dual(0.04, e5(0)), Dual(2.0, e5(1)), Dual(0.04, e5(2)),
+                                Dual(0.3, e5(3)), Dual(-0.7, e5(4))))
+        cm, t_cm = hh.CarrMadan(1.0, 32.0, hh.HestonDynamics()), []
+        for mkt in mkts:
+            bp = hh.BasketPricingProblem(quotes, mkt)
+            hh.solve(bp, cm)
+            t0 = time.perf_counter()
+            for _ in range(20):
+                hh.solve(bp, cm)
+            t_cm.append((time.perf_counter() - t0) / 20 * 1e3)
+
         out["widened_rows"] = {
+            "carr_madan_basket_100_heston_quotes": {
+                "wall_ms_prices": t_cm[0], "wall_ms_prices_and_5_parameter_gradient": t_cm[1],
+                "what": "hh.solve(BasketPricingProblem, CarrMadan): one kernel launch per call, host "
+                        "wall time including the result copy"},
             "lsm_american_put_2e6_paths_x_100_dates": {
                 "kernel_ms": t_lsm, "price": r_l.price, "std_error": r_l.std_error,
                 # the spot grid written once by the path kernel and read once by the backward
