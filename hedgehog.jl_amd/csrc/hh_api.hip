@@ -58,6 +58,7 @@ struct hh_ctx {
   } shard;
   int lsm_form = hh::kLsmFormAuto;  // hh_ctx_set_option(HH_OPT_LSM_FORM)
   int bk_term_cache = 0;            // hh_ctx_set_option(HH_OPT_BK_TERM_CACHE); 0 = the default
+  int grid_form = HH_GRID_FORM_BATCHED;  // hh_ctx_set_option(HH_OPT_GRID_FORM)
   uint64_t lsm_persistent_fallbacks = 0;  // persistent launches that gave up and were redone per date
   double* accum = nullptr;       // device, HH_ACC_LEN
   double* accum_host = nullptr;  // pinned, HH_ACC_LEN
@@ -300,6 +301,11 @@ int hh_ctx_set_option(hh_ctx* ctx, int32_t option, int64_t value) {
       if (value < 8 || value > 1024)
         return fail(ctx, HH_ERR_INVALID, "HH_OPT_BK_TERM_CACHE: 8 .. 1024 series terms per trajectory");
       ctx->bk_term_cache = (int)value;
+      return HH_OK;
+    case HH_OPT_GRID_FORM:
+      if (value != HH_GRID_FORM_PER_DATE && value != HH_GRID_FORM_BATCHED)
+        return fail(ctx, HH_ERR_INVALID, "HH_OPT_GRID_FORM: 0 (one chain per date) or 1 (dates batched)");
+      ctx->grid_form = (int)value;
       return HH_OK;
     default:
       return fail(ctx, HH_ERR_INVALID, "unknown option %d", option);
@@ -861,12 +867,18 @@ static int run_heston_grid(hh_ctx* ctx, const hh_model* m, const hh_config* c) {
                 "exact Heston grid: S0, T, V0 > 0, |rho| <= 1, 1e-8 <= 4 kappa theta / sigma^2 <= 1e6, all finite");
   const uint64_t n = c->n_paths;
   const size_t grid_elems = (size_t)(c->n_steps + 1) * n;
+  // dates per kernel chain: given the variance rows, the CF inversions of different dates are
+  // independent, so a batch of dates runs as ONE chain over its (date, trajectory) pairs
+  const uint32_t per_chain = ctx->grid_form == HH_GRID_FORM_BATCHED
+                                 ? hh::bk_grid_dates_per_chain(n, c->n_steps, ctx->bk_term_cache)
+                                 : 1u;
+  const uint64_t n_chain = n * per_chain;
   int rc;
   if ((rc = ensure(ctx, ctx->lsm_grid, ctx->lsm_grid_cap, grid_elems))) return rc;
   if ((rc = ensure(ctx, ctx->heston_var, ctx->heston_var_cap, grid_elems))) return rc;
-  if ((rc = ensure(ctx, ctx->records, ctx->records_cap, (size_t)hh::bk_record_count(n) * hh::kRecStride)))
+  if ((rc = ensure(ctx, ctx->records, ctx->records_cap, (size_t)hh::bk_record_count(n_chain) * hh::kRecStride)))
     return rc;
-  if ((rc = ensure(ctx, ctx->bk_scratch, ctx->bk_scratch_cap, hh::bk_scratch_bytes(n, ctx->bk_term_cache)))) return rc;
+  if ((rc = ensure(ctx, ctx->bk_scratch, ctx->bk_scratch_cap, hh::bk_scratch_bytes(n_chain, ctx->bk_term_cache)))) return rc;
   if ((rc = ensure(ctx, ctx->basket_accum, ctx->basket_accum_cap, (size_t)c->n_steps * HH_ACC_LEN)))
     return rc;
   hh::DevicePtrs p{};
@@ -881,6 +893,20 @@ static int run_heston_grid(hh_ctx* ctx, const hh_model* m, const hh_config* c) {
   step_model.cp = 1.0;
   hh_config step_cfg = *c;
   step_cfg.path_offset = 0;
+  if (per_chain > 1) {
+    HH_HIP(ctx, hipMemsetAsync(ctx->basket_accum, 0, (size_t)c->n_steps * HH_ACC_LEN * sizeof(double),
+                               ctx->stream));
+    for (uint32_t k = 0; k < c->n_steps; k += per_chain) {
+      const uint32_t nd = std::min(per_chain, c->n_steps - k);
+      HH_HIP(ctx, hh::launch_bk_grid(step_model, step_cfg, p, ctx->stream, ctx->lsm_grid + (size_t)k * n,
+                                     ctx->heston_var + (size_t)k * n, k, nd, /*upload_tables=*/k == 0));
+      // the counters of the batch's pairs, kept in the slot of its first date
+      HH_HIP(ctx, hh::launch_reduce_records(ctx->records, hh::bk_record_count(n * nd), (double)(n * nd),
+                                            ctx->basket_accum + (size_t)k * HH_ACC_LEN, ctx->stream, 1,
+                                            &step_model, &step_cfg));
+    }
+    return HH_OK;
+  }
   for (uint32_t k = 0; k < c->n_steps; ++k) {
     const hh::BkTransition tr{ctx->lsm_grid + (size_t)k * n, ctx->heston_var + (size_t)k * n,
                               ctx->lsm_grid + (size_t)(k + 1) * n,

@@ -74,6 +74,10 @@ struct BkArgs {
   double* out_spot;
   double* out_var;
   uint32_t step;
+  // several dates of a grid in ONE chain (launch_bk_grid): the chain's "trajectories" are the (date, trajectory)
+  // pairs of the batch, in_var = the variance rows of the batch (row-major, so pair i starts at in_var[i]),
+  // in_spot = NULL, and the chain leaves the sampled ∫V of pair i in iv_out[i] instead of a spot
+  double* iv_out;
   double* records;                 // [2·n_tiles][kRecStride]: phase 1, then phase 2
   double* draws;                   // [4][draw_stride]: Z, u, normal quantile of u, V_T per trajectory
   size_t draw_stride;
@@ -284,51 +288,76 @@ __device__ int poisson(double mu, const PathDraws& dr, int& it) {
 // inside sample_from_cf, then Z inside sample_log_S_T) and the normal quantile of u, left in
 // draws[4][stride] for the CF kernels.  REPLAY: V_T, u, Z are the caller's (replay[3][n_paths]) —
 // the seam through which the reference's own draws reach sample_from_cf / inverse_cdf per trajectory.
-template <bool REPLAY>
-__global__ __launch_bounds__(kTile) void bk_draw_kernel(const BkArgs p) {
-  const uint64_t path = (uint64_t)blockIdx.x * kTile + threadIdx.x;
-  if (path >= p.n_paths) return;
-  double Z, u, VT;
-  if constexpr (REPLAY) {
-    VT = p.replay[path];
-    u = p.replay[p.n_paths + path];
-    Z = p.replay[2 * p.n_paths + path];
+// the draws of one transition from start variance V0: stream `key`, indexed by G
+__device__ __forceinline__ void draw_transition(const BkArgs& p, uint64_t key, uint64_t G, double V0, double& Z,
+                                                double& u, double& VT) {
+  const double lam = p.lam_num * V0 / p.lam_den;  // heston.jl:129
+  const PathDraws dr{(uint32_t)key, (uint32_t)(key >> 32), (uint32_t)G, (uint32_t)(G >> 32)};
+  double zshift, u_boost;
+  dr.normals(0u, Z, zshift);
+  dr.uniforms(1u, u, u_boost);
+  // V_T (heston.jl:131)
+  int it = 0;
+  double chi;
+  if (p.d > 1.0) {
+    const double g = gamma_any(0.5 * (p.d - 1.0), dr, it, u_boost);
+    const double sh = zshift + sqrt(lam);
+    chi = sh * sh + 2.0 * g;
   } else {
-    // terminal law: ONE stream, seeds[1], indexed by trajectory (montecarlo.jl:456); grid: the
-    // trajectory's own seed (montecarlo.jl:331), indexed by the transition
-    const bool grid = p.in_var != nullptr;
-    const uint64_t key = grid ? p.seeds[path] : p.seeds[0];
-    const uint64_t G = grid ? (uint64_t)p.step : p.path_offset + path;
-    const double V0 = grid ? p.in_var[path] : p.V0;
-    const double lam = p.lam_num * V0 / p.lam_den;  // heston.jl:129
-    const PathDraws dr{(uint32_t)key, (uint32_t)(key >> 32), (uint32_t)G, (uint32_t)(G >> 32)};
-    double zshift, u_boost;
-    dr.normals(0u, Z, zshift);
-    dr.uniforms(1u, u, u_boost);
-    // V_T (heston.jl:131)
-    int it = 0;
-    double chi;
-    if (p.d > 1.0) {
-      const double g = gamma_any(0.5 * (p.d - 1.0), dr, it, u_boost);
-      const double sh = zshift + sqrt(lam);
-      chi = sh * sh + 2.0 * g;
-    } else {
-      const int n = poisson(0.5 * lam, dr, it);
-      chi = 2.0 * gamma_any(0.5 * p.d + (double)n, dr, it, u_boost);
-    }
-    VT = p.cscale * chi;
+    const int n = poisson(0.5 * lam, dr, it);
+    chi = 2.0 * gamma_any(0.5 * p.d + (double)n, dr, it, u_boost);
   }
   // With d = 4κθ/σ² far below 1 the variance is absorbed at zero with real probability and the gamma
   // draw u^(1/shape) underflows to an exact 0 (d = 0.012: 1.4 % of the trajectories).  The CF of ∫V has
   // a finite limit for V_T -> 0 (the Bessel ratio tends to (ν_γ/ν_κ)^ν), but at V_T = 0 itself
   // log I_ν(0) is ±inf and the ratio NaN — in the reference too (heston.jl:193,207), whose series loop
   // then never ends.  The smallest variance kept is 2^-1000: the limit, to every digit.
-  VT = fmax(VT, 0x1p-1000);
-  double* d = p.draws + path;  // trajectory index == lane index of the CF kernels' tiles
+  VT = fmax(p.cscale * chi, 0x1p-1000);
+}
+
+__device__ __forceinline__ void store_draws(const BkArgs& p, uint64_t i, double Z, double u, double VT) {
+  double* d = p.draws + i;  // trajectory index == lane index of the CF kernels' tiles
   d[0] = Z;
   d[p.draw_stride] = u;
   d[2 * p.draw_stride] = normcdfinv(u);  // quantile(Normal(), u) (sample_from_cf.jl:33)
   d[3 * p.draw_stride] = VT;
+}
+
+template <bool REPLAY>
+__global__ __launch_bounds__(kTile) void bk_draw_kernel(const BkArgs p) {
+  const uint64_t path = (uint64_t)blockIdx.x * kTile + threadIdx.x;
+  if (path >= p.n_paths) return;
+  double Z, u, VT;
+  if constexpr (REPLAY) {
+    VT = fmax(p.replay[path], 0x1p-1000);
+    u = p.replay[p.n_paths + path];
+    Z = p.replay[2 * p.n_paths + path];
+  } else {
+    // terminal law: ONE stream, seeds[1], indexed by trajectory (montecarlo.jl:456); grid: the
+    // trajectory's own seed (montecarlo.jl:331), indexed by the transition
+    const bool grid = p.in_var != nullptr;
+    draw_transition(p, grid ? p.seeds[path] : p.seeds[0], grid ? (uint64_t)p.step : p.path_offset + path,
+                    grid ? p.in_var[path] : p.V0, Z, u, VT);
+  }
+  store_draws(p, path, Z, u, VT);
+}
+
+// The variance chain of dates k0 … k0 + n_dates of a grid, one trajectory per thread: V of each date from the
+// one before (cheap: one non-central χ² draw), its draws left where the chain's pair (date, trajectory) =
+// b·n_row + trajectory finds them, the variance rows written on the way.
+__global__ __launch_bounds__(kTile) void bk_draw_grid_kernel(const BkArgs p, uint64_t n_row, uint32_t k0,
+                                                             uint32_t n_dates, double* __restrict__ var_rows) {
+  const uint64_t path = (uint64_t)blockIdx.x * kTile + threadIdx.x;
+  if (path >= n_row) return;
+  const uint64_t key = p.seeds[path];
+  double V = var_rows[path];  // row k0
+  for (uint32_t b = 0; b < n_dates; ++b) {
+    double Z, u, VT;
+    draw_transition(p, key, (uint64_t)(k0 + b), V, Z, u, VT);
+    store_draws(p, (uint64_t)b * n_row + path, Z, u, VT);
+    var_rows[(uint64_t)(b + 1) * n_row + path] = VT;
+    V = VT;
+  }
 }
 
 // HestonCFIterator (heston.jl:165-176) and the moment heuristics (sample_from_cf.jl:31-37) of one
@@ -378,7 +407,7 @@ __device__ void bk_setup(const BkArgs& p, const BesselTable* bt, uint64_t path, 
   s.cache.theta_cap = __builtin_nan("");
   const bool grid = p.in_var != nullptr;
   s.V0 = grid ? p.in_var[path] : p.V0;
-  s.logS0 = grid ? fm::log(p.in_spot[path]) : p.logS0;  // heston.jl:84: S = exp(W[1]), then log(S0) :289
+  s.logS0 = p.in_spot ? fm::log(p.in_spot[path]) : p.logS0;  // heston.jl:84: S = exp(W[1]), then log(S0) :289
   const double* d = p.draws + path;
   s.Z = d[0];
   s.u = d[p.draw_stride];
@@ -387,12 +416,20 @@ __device__ void bk_setup(const BkArgs& p, const BesselTable* bt, uint64_t path, 
 }
 
 // 3. log S_T (heston.jl:288-297), S_T = exp(.) (montecarlo.jl:384), payoff
-__device__ __forceinline__ double bk_finish(const BkArgs& p, double logS0, double V0, double VT,
-                                            double Z, double IV, uint64_t path) {
+__device__ __forceinline__ double bk_spot(const BkArgs& p, double logS0, double V0, double VT, double Z,
+                                          double IV) {
   const double mu = logS0 + p.r * p.T - 0.5 * IV +
                     (p.rho / p.sigma) * (VT - V0 - p.kappa * p.theta * p.T + p.kappa * IV);
   const double sigma2 = (1.0 - p.rho * p.rho) * IV;
-  const double S = fm::exp(mu + sqrt(sigma2) * Z);
+  return fm::exp(mu + sqrt(sigma2) * Z);
+}
+__device__ __forceinline__ double bk_finish(const BkArgs& p, double logS0, double V0, double VT,
+                                            double Z, double IV, uint64_t path) {
+  if (p.iv_out) {  // a batch of dates: the spot rows are chained afterwards (bk_grid_spots_kernel)
+    p.iv_out[path] = IV;
+    return 0.0;
+  }
+  const double S = bk_spot(p, logS0, V0, VT, Z, IV);
   if (p.terminal) p.terminal[path] = S;
   if (p.out_spot) {
     p.out_spot[path] = S;
@@ -400,6 +437,23 @@ __device__ __forceinline__ double bk_finish(const BkArgs& p, double logS0, doubl
   }
   const double m = p.cp * (S - p.strike);
   return m > 0.0 ? m : 0.0;
+}
+
+// … and the spot rows of the same dates once the chain has left ∫V of every pair in iv_out: log S chained date by
+// date, the arithmetic of bk_finish on the same operands (bit-identical with the launch-per-date form)
+__global__ __launch_bounds__(kTile) void bk_grid_spots_kernel(const BkArgs p, uint64_t n_row, uint32_t n_dates,
+                                                              const double* __restrict__ var_rows,
+                                                              double* __restrict__ spot_rows) {
+  const uint64_t path = (uint64_t)blockIdx.x * kTile + threadIdx.x;
+  if (path >= n_row) return;
+  double S = spot_rows[path], V0 = var_rows[path];
+  for (uint32_t b = 0; b < n_dates; ++b) {
+    const uint64_t i = (uint64_t)b * n_row + path;
+    const double VT = p.draws[3 * p.draw_stride + i];
+    S = bk_spot(p, fm::log(S), V0, VT, p.draws[i], p.iv_out[i]);
+    spot_rows[(uint64_t)(b + 1) * n_row + path] = S;
+    V0 = VT;
+  }
 }
 
 // (tile_count, when given, receives the tile's number of failed | too-long trajectories: the sums of
@@ -583,7 +637,7 @@ __device__ __forceinline__ void invert_phase(const BkArgs& p, uint32_t tile, uin
       if (ok) {
         const bool grid = p.in_var != nullptr;
         const double V0 = grid ? p.in_var[path] : p.V0;
-        const double logS0 = grid ? fm::log(p.in_spot[path]) : p.logS0;  // heston.jl:84, :289
+        const double logS0 = p.in_spot ? fm::log(p.in_spot[path]) : p.logS0;  // heston.jl:84, :289
         const double pay = bk_finish(p, logS0, V0, p.draws[3 * p.draw_stride + path], p.draws[path],
                                      IV, path);
         acc[0] = pay;
@@ -783,7 +837,7 @@ __global__ __launch_bounds__(kTile) void bk_ladder_kernel(const BkArgs p, uint32
     acc[5] += n_terms;
     const bool grid = p.in_var != nullptr;
     const double V0 = grid ? p.in_var[path] : p.V0;
-    const double logS0 = grid ? fm::log(p.in_spot[path]) : p.logS0;
+    const double logS0 = p.in_spot ? fm::log(p.in_spot[path]) : p.logS0;
     const double pay = bk_finish(p, logS0, V0, p.draws[3 * p.draw_stride + path], p.draws[path], IV, path);
     acc[0] += pay;
     acc[1] = fma(pay, pay, acc[1]);
@@ -870,7 +924,7 @@ __global__ __launch_bounds__(256) void fill_rows_kernel(double* __restrict__ spo
 
 }  // namespace
 
-constexpr size_t kPhiBudget = (size_t)4 << 30;   // at most 4 GiB of device scratch for the cache
+constexpr size_t kPhiBudget = (size_t)8 << 30;   // at most 8 GiB of device scratch for the cache
 
 // series terms cached per trajectory: term_cache (HH_OPT_BK_TERM_CACHE; 0 = kBkTermCacheDefault) unless
 // the ensemble is so large that the cache would pass kPhiBudget
@@ -910,18 +964,22 @@ uint32_t bk_record_count(uint64_t n_paths) {
 
 size_t bk_scratch_bytes(uint64_t n_paths, int term_cache) {
   const size_t n_tiles = tiles_for(n_paths);
-  // ballots + prefix | cached series terms [cap][lanes] | draws [4][lanes] | rec [4][lanes]
-  return bk_flags_bytes(n_tiles) + n_tiles * kTile * sizeof(double) * ((size_t)phi_cache_cap(n_tiles, term_cache) + 8);
+  // ballots + prefix | cached series terms [cap][lanes] | draws [4][lanes] | rec [4][lanes] | ∫V [lanes]
+  return bk_flags_bytes(n_tiles) + n_tiles * kTile * sizeof(double) * ((size_t)phi_cache_cap(n_tiles, term_cache) + 9);
 }
 
-int launch_bk(const hh_model& m, const hh_config& c, const DevicePtrs& ptr, hipStream_t s,
-              const BkTransition* tr, bool upload_tables) {
-  BkArgs a{};
-  if (tr) {
-    a.in_spot = tr->in_spot; a.in_var = tr->in_var;
-    a.out_spot = tr->out_spot; a.out_var = tr->out_var;
-    a.step = tr->step;
-  }
+namespace {
+
+struct BkLayout {
+  uint32_t n_tiles;
+  uint32_t *prefix, *prefix_long;
+  BkTables* tabs_dev;
+};
+
+// the argument block of a chain over n_chain trajectories (or (date, trajectory) pairs) and where its pieces
+// of the scratch buffer are
+int bk_prepare(const hh_model& m, const hh_config& c, const DevicePtrs& ptr, uint64_t n_chain, BkArgs& a,
+               BkLayout& L) {
   a.kappa = m.kappa; a.theta = m.theta; a.sigma = m.sigma; a.sigma2 = m.sigma * m.sigma; a.inv_sigma2 = 1.0 / a.sigma2;
   a.rho = m.rho; a.V0 = m.V0; a.T = m.T; a.logS0 = log(m.S0); a.r = m.r_drift;
   a.strike = m.strike; a.cp = m.cp;
@@ -943,56 +1001,115 @@ int launch_bk(const hh_model& m, const hh_config& c, const DevicePtrs& ptr, hipS
   a.moment_h = c.bk_moment_h > 0.0 ? c.bk_moment_h : 1e-2;
   a.newton_maxiter = c.bk_newton_maxiter > 0 ? c.bk_newton_maxiter : 10;
   a.bisect_maxiter = c.bk_bisect_maxiter > 0 ? c.bk_bisect_maxiter : 100;
-  a.n_paths = c.n_paths;
+  a.n_paths = n_chain;
   a.path_offset = c.path_offset;
   a.seeds = ptr.seeds;
   a.terminal = ptr.terminal;
   a.records = ptr.records;
-  const uint32_t n_tiles = tiles_for(c.n_paths);
-  // scratch: ballots (fail, long) + prefix | cached series terms [cap][lanes] | draws [4][lanes] | rec [4][lanes]
+  const uint32_t n_tiles = tiles_for(n_chain);
+  // scratch: ballots (fail, long) + prefix | cached series terms [cap][lanes] | draws [4][lanes] | rec [4][lanes] | ∫V [lanes]
   const size_t lanes = (size_t)n_tiles * kTile;
   unsigned char* base = reinterpret_cast<unsigned char*>(ptr.bk_scratch);
   a.fail_mask = reinterpret_cast<unsigned long long*>(base);
   a.long_mask = a.fail_mask + (size_t)n_tiles * (kTile / 64);
-  uint32_t* prefix = reinterpret_cast<uint32_t*>(a.long_mask + (size_t)n_tiles * (kTile / 64));
-  uint32_t* prefix_long = prefix + n_tiles + 1;
-  a.tile_counts = prefix_long + n_tiles + 1;
+  L.n_tiles = n_tiles;
+  L.prefix = reinterpret_cast<uint32_t*>(a.long_mask + (size_t)n_tiles * (kTile / 64));
+  L.prefix_long = L.prefix + n_tiles + 1;
+  a.tile_counts = L.prefix_long + n_tiles + 1;
   a.args_dev = base + bk_args_offset(n_tiles);
-  BkTables* tabs_dev = reinterpret_cast<BkTables*>(base + bk_tables_offset(n_tiles));
-  a.tabs_dev = tabs_dev;
+  L.tabs_dev = reinterpret_cast<BkTables*>(base + bk_tables_offset(n_tiles));
+  a.tabs_dev = L.tabs_dev;
   a.phi_cache = reinterpret_cast<double*>(base + bk_flags_bytes(n_tiles));
   a.cache_stride = lanes;
   a.cache_cap = phi_cache_cap(n_tiles, ptr.bk_term_cache);
   a.draws = a.phi_cache + lanes * (size_t)a.cache_cap;
   a.rec = a.draws + 4 * lanes;
   a.draw_stride = lanes;
-  a.replay = c.noise_mode == HH_NOISE_REPLAY ? ptr.replay : nullptr;
-  const dim3 g(n_tiles), b(kTile);
-  // the tables depend on ν alone: repeated solves of one model (and the dates of a grid) find them in place
-  if (ptr.bk_table_key && ptr.bk_table_key->where == tabs_dev && ptr.bk_table_key->nu == a.nu)
-    upload_tables = false;
+  return 0;
+}
+
+// the Bessel tables depend on ν alone: repeated solves of one model (and the dates of a grid) find them in place
+int bk_tables(const BkArgs& a, const BkLayout& L, const DevicePtrs& ptr, hipStream_t s, bool upload_tables) {
+  // (where they lie depends on the chain's size: a grid's last, shorter batch of dates has its own place)
+  if (ptr.bk_table_key)
+    upload_tables = !(ptr.bk_table_key->where == L.tabs_dev && ptr.bk_table_key->nu == a.nu);
   if (upload_tables) {
     BkTables tabs;
     if (!bessel_table(a.nu, tabs.t[0]) || !bessel_table(a.nu - a.n_int, tabs.t[1]))
       return (int)hipErrorInvalidValue;  // the series table of hh_bessel.h does not reach |z| = 13: not for ν > -1
-    hipLaunchKernelGGL(bk_tables_kernel, dim3(1), dim3(64), 0, s, tabs, tabs_dev);
-    if (ptr.bk_table_key) *ptr.bk_table_key = BkTableKey{tabs_dev, a.nu};
+    hipLaunchKernelGGL(bk_tables_kernel, dim3(1), dim3(64), 0, s, tabs, L.tabs_dev);
+    if (ptr.bk_table_key) *ptr.bk_table_key = BkTableKey{L.tabs_dev, a.nu};
   }
+  return 0;
+}
+
+// CF work, prefix sums, ladder, fall-back — everything behind the draws
+void bk_chain(const BkArgs& a, const BkLayout& L, hipStream_t s) {
+  const dim3 g(L.n_tiles), b(kTile);
+#if HH_BK_FUSED
+  hipLaunchKernelGGL(bk_cf_kernel, g, b, 0, s, a, static_cast<const BkTables*>(L.tabs_dev));
+#else
+  hipLaunchKernelGGL(bk_series_kernel, g, b, 0, s, a, static_cast<const BkTables*>(L.tabs_dev));
+  hipLaunchKernelGGL(bk_invert_kernel, g, b, 0, s, a);
+#endif
+  hipLaunchKernelGGL(bk_scan_kernel, dim3(1), dim3(kScanThreads), 0, s, a, L.n_tiles, L.prefix, L.prefix_long);
+  hipLaunchKernelGGL(bk_ladder_kernel, dim3(kPackedGrid), b, 0, s, a, L.n_tiles, L.prefix);
+  hipLaunchKernelGGL(bk_fallback_kernel, dim3(kHeavyGrid), b, 0, s,
+                     static_cast<const BkArgs*>(a.args_dev), static_cast<const BkTables*>(L.tabs_dev), L.n_tiles,
+                     L.prefix_long);
+}
+
+}  // namespace
+
+int launch_bk(const hh_model& m, const hh_config& c, const DevicePtrs& ptr, hipStream_t s,
+              const BkTransition* tr, bool upload_tables) {
+  BkArgs a{};
+  BkLayout L{};
+  if (tr) {
+    a.in_spot = tr->in_spot; a.in_var = tr->in_var;
+    a.out_spot = tr->out_spot; a.out_var = tr->out_var;
+    a.step = tr->step;
+  }
+  int rc = bk_prepare(m, c, ptr, c.n_paths, a, L);
+  if (rc) return rc;
+  a.replay = c.noise_mode == HH_NOISE_REPLAY ? ptr.replay : nullptr;
+  if ((rc = bk_tables(a, L, ptr, s, upload_tables))) return rc;
+  const dim3 g(L.n_tiles), b(kTile);
   if (a.replay)
     hipLaunchKernelGGL(bk_draw_kernel<true>, g, b, 0, s, a);
   else
     hipLaunchKernelGGL(bk_draw_kernel<false>, g, b, 0, s, a);
-#if HH_BK_FUSED
-  hipLaunchKernelGGL(bk_cf_kernel, g, b, 0, s, a, static_cast<const BkTables*>(tabs_dev));
-#else
-  hipLaunchKernelGGL(bk_series_kernel, g, b, 0, s, a, static_cast<const BkTables*>(tabs_dev));
-  hipLaunchKernelGGL(bk_invert_kernel, g, b, 0, s, a);
-#endif
-  hipLaunchKernelGGL(bk_scan_kernel, dim3(1), dim3(kScanThreads), 0, s, a, n_tiles, prefix, prefix_long);
-  hipLaunchKernelGGL(bk_ladder_kernel, dim3(kPackedGrid), b, 0, s, a, n_tiles, prefix);
-  hipLaunchKernelGGL(bk_fallback_kernel, dim3(kHeavyGrid), b, 0, s,
-                     static_cast<const BkArgs*>(a.args_dev), static_cast<const BkTables*>(tabs_dev), n_tiles,
-                     prefix_long);
+  bk_chain(a, L, s);
+  return (int)hipGetLastError();
+}
+
+uint32_t bk_grid_dates_per_chain(uint64_t n_paths, uint32_t n_steps, int term_cache) {
+  // as many (date, trajectory) pairs per chain as keep the full term cache inside kPhiBudget, the dates spread
+  // evenly over the chains
+  const size_t want = term_cache > 0 ? (size_t)term_cache : (size_t)kBkTermCacheDefault;
+  const uint64_t pairs_max = kPhiBudget / (want * sizeof(double));
+  const uint64_t per = n_paths ? pairs_max / n_paths : 1;
+  if (per <= 1) return 1;
+  const uint64_t chains = (n_steps + per - 1) / per;
+  return (uint32_t)((n_steps + chains - 1) / chains);
+}
+
+int launch_bk_grid(const hh_model& m, const hh_config& c, const DevicePtrs& ptr, hipStream_t s,
+                   double* spot_rows, double* var_rows, uint32_t k0, uint32_t n_dates, bool upload_tables) {
+  BkArgs a{};
+  BkLayout L{};
+  const uint64_t n_row = c.n_paths, n_chain = n_row * n_dates;
+  int rc = bk_prepare(m, c, ptr, n_chain, a, L);
+  if (rc) return rc;
+  a.in_var = var_rows;  // pair i = b·n_row + trajectory starts from var_rows[i]
+  a.step = k0;
+  a.iv_out = a.rec + 4 * a.draw_stride;
+  if ((rc = bk_tables(a, L, ptr, s, upload_tables))) return rc;
+  const dim3 rows(tiles_for(n_row)), b(kTile);
+  hipLaunchKernelGGL(bk_draw_grid_kernel, rows, b, 0, s, a, n_row, k0, n_dates, var_rows);
+  bk_chain(a, L, s);
+  hipLaunchKernelGGL(bk_grid_spots_kernel, rows, b, 0, s, a, n_row, n_dates,
+                     static_cast<const double*>(var_rows), spot_rows);
   return (int)hipGetLastError();
 }
 

@@ -102,6 +102,16 @@ struct BkTransition {
 // launch_bk on the SAME scratch buffer and trajectory count (the dates of one exact grid)
 int launch_bk(const hh_model& m, const hh_config& c, const DevicePtrs& p, hipStream_t s,
               const BkTransition* tr = nullptr, bool upload_tables = true);
+// Dates k0 … k0 + n_dates of an exact grid in ONE chain: the variance rows first (sequential in the date, cheap),
+// then the CF inversions of all (date, trajectory) pairs at once — they are independent given the variances —
+// then the spot rows chained date by date.  spot_rows / var_rows = row k0 of the grids ([date][c.n_paths]);
+// rows k0+1 … k0+n_dates are written.  Scratch: bk_scratch_bytes(c.n_paths · n_dates); records:
+// bk_record_count(c.n_paths · n_dates) (payoff sums zero, the counters of all pairs).  Same draws, same
+// arithmetic per pair as n_dates launch_bk transitions: bit-identical rows.
+int launch_bk_grid(const hh_model& m, const hh_config& c, const DevicePtrs& p, hipStream_t s,
+                   double* spot_rows, double* var_rows, uint32_t k0, uint32_t n_dates, bool upload_tables);
+// dates per chain for a grid of n_steps dates: all of them unless the pairs' term cache would pass its budget
+uint32_t bk_grid_dates_per_chain(uint64_t n_paths, uint32_t n_steps, int term_cache);
 constexpr int kBkTermCacheDefault = 256;
 size_t bk_scratch_bytes(uint64_t n_paths, int term_cache = 0);
 uint32_t bk_record_count(uint64_t n_paths);  // records the Broadie–Kaya chain writes (inversion tiles + packed kernels)

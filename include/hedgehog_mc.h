@@ -166,12 +166,21 @@ const char* hh_last_error(const hh_ctx* ctx); /* NUL-terminated, owned by ctx (o
  * All forms give bit-identical prices and stopping decisions.
  *
  * HH_OPT_BK_TERM_CACHE: how many CDF-series terms Re ϕ(h·j) per trajectory the Broadie–Kaya kernels
- * keep (8 … 1024, default 256; 8 bytes x trajectories each, capped at 4 GiB in all).  Series that fit
+ * keep (8 … 1024, default 256; 8 bytes x trajectories each, capped at 8 GiB in all).  Series that fit
  * are evaluated once and inverted on the cached terms; a trajectory whose series is longer re-evaluates
  * the whole series in every CDF call (as the reference does with all of them), in a separate, much
  * slower kernel.  With the reference's controls the series has 10–15 terms (60 at short maturities,
- * 100–250 for d = 4κθ/σ² ≪ 1 or cf_tol ≪ 1e-3). */
-enum hh_option { HH_OPT_LSM_FORM = 1, HH_OPT_BK_TERM_CACHE = 2 };
+ * 100–250 for d = 4κθ/σ² ≪ 1 or cf_tol ≪ 1e-3).
+ *
+ * HH_OPT_GRID_FORM: how hh_heston_exact_grid (and LSM on those paths) runs the dates of a grid:
+ *   HH_GRID_FORM_BATCHED   (default) the variances of all dates first, then ONE kernel chain over every
+ *                          (date, trajectory) pair — given the variances the CF inversions of different
+ *                          dates are independent — then the spot rows; several chains only when the pairs'
+ *                          term cache would pass its 8 GiB;
+ *   HH_GRID_FORM_PER_DATE  one kernel chain per date.
+ * Both forms give bit-identical grids. */
+enum hh_option { HH_OPT_LSM_FORM = 1, HH_OPT_BK_TERM_CACHE = 2, HH_OPT_GRID_FORM = 3 };
+enum hh_grid_form { HH_GRID_FORM_PER_DATE = 0, HH_GRID_FORM_BATCHED = 1 };
 enum hh_lsm_form { HH_LSM_FORM_PER_DATE = 0, HH_LSM_FORM_PERSISTENT = 1, HH_LSM_FORM_AUTO = 2 };
 int hh_ctx_set_option(hh_ctx* ctx, int32_t option, int64_t value);
 

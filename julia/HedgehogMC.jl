@@ -84,6 +84,7 @@ last_error(ctx) = unsafe_string(ccall((:hh_last_error, LIB[]), Cstring, (Ptr{Cvo
 # build options of a context (include/hedgehog_mc.h, enum hh_option; none changes a result)
 const HH_OPT_LSM_FORM = Int32(1)        # 0 launch per date, 1 one persistent launch, 2 auto (default)
 const HH_OPT_BK_TERM_CACHE = Int32(2)   # cached CDF-series terms per trajectory, 8 … 1024 (default 256)
+const HH_OPT_GRID_FORM = Int32(3)       # exact Heston grid: 0 one kernel chain per date, 1 dates batched (default)
 function set_option!(ctx::Context, option::Integer, value::Integer)
     rc = ccall((:hh_ctx_set_option, LIB[]), Cint, (Ptr{Cvoid}, Int32, Int64), ctx.handle, option, value)
     rc == 0 || error("hh_ctx_set_option failed ($rc): " * last_error(ctx))

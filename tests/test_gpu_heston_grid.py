@@ -74,6 +74,43 @@ def test_chain_matches_oracle_chain(hhlib):
     assert np.mean(rel > 1e-5) <= 0.03, np.sort(rel.ravel())[-8:]
 
 
+@pytest.mark.parametrize("name,prm,steps,n,bk", [
+    ("h252", H252, 12, 3001, {}), ("q2", Q2, 5, 700, {}), ("nu_one", NU_ONE, 7, 513, {}),
+    ("h252_tight_tol", H252, 4, 300, {"bk_cf_tol": 1e-6}),   # series beyond the cache: the fall-back kernel
+    ("one_date", H252, 1, 400, {})])
+def test_batched_dates_and_a_chain_per_date_agree_bit_for_bit(name, prm, steps, n, bk):
+    """HH_OPT_GRID_FORM: all (date, trajectory) pairs in one kernel chain vs one chain per date — same
+    draws, same arithmetic per pair, so the same bits in every row; the counters are sums over pairs."""
+    seeds = np.random.default_rng(steps).integers(1, 2**63, n).astype(np.uint64)
+    out = []
+    for form in (_ffi.HH_GRID_FORM_PER_DATE, _ffi.HH_GRID_FORM_BATCHED):
+        ctx = hh.Context(0)
+        ctx.check(ctx.lib.hh_ctx_set_option(ctx.handle, _ffi.HH_OPT_GRID_FORM, form))
+        if "bk_cf_tol" in bk:
+            ctx.check(ctx.lib.hh_ctx_set_option(ctx.handle, _ffi.HH_OPT_BK_TERM_CACHE, 16))
+        out.append(gpu_grid(ctx, prm, seeds, steps, **bk))
+    (s0, v0, r0), (s1, v1, r1) = out
+    np.testing.assert_array_equal(s0, s1)
+    np.testing.assert_array_equal(v0, v1)
+    for f in ("bk_newton_fail", "bk_bisect_fallback", "bk_maxguess_fallback", "bk_cf_terms"):
+        assert getattr(r0, f) == getattr(r1, f), f
+    assert r0.bk_cf_terms > 0 and np.all(np.isfinite(s1)) and np.all(s1 > 0)
+
+
+def test_batched_grid_splits_into_several_chains_when_the_pairs_pass_the_cache_budget():
+    """1024 cached terms per pair: 8 GiB hold 2^20 pairs, so 300 000 trajectories x 7 dates run as
+    3 + 3 + 1 dates; rows identical with a smaller ensemble's (trajectories depend on their seed only)."""
+    n, steps = 300_000, 7
+    seeds = np.arange(1, n + 1, dtype=np.uint64)
+    ctx = hh.Context(0)
+    ctx.check(ctx.lib.hh_ctx_set_option(ctx.handle, _ffi.HH_OPT_BK_TERM_CACHE, 1024))
+    big, bv, res = gpu_grid(ctx, H252, seeds, steps)
+    small, sv, _ = gpu_grid(hh.Context(0), H252, seeds[:2000], steps)
+    np.testing.assert_array_equal(big[:, :2000], small)
+    np.testing.assert_array_equal(bv[:, :2000], sv)
+    assert np.all(np.isfinite(big)) and res.bk_cf_terms > 0
+
+
 def test_trajectories_depend_on_their_seed_only(hhlib):
     """montecarlo.jl:331: one seed per trajectory — position in the ensemble, ensemble size and
     tile placement are invisible."""
