@@ -621,7 +621,7 @@ def main():
             "heston_exact_grid_2e5_paths_x_12_dates": {
                 "kernel_ms": r_g.kernel_ms, "transitions_per_s": n_g * st_g / (r_g.kernel_ms * 1e-3),
                 "cf_terms_per_transition": r_g.bk_cf_terms / (n_g * st_g),
-                "roofline": valu_roofline("bk_kernel chain, one transition per date",
+                "roofline": valu_roofline("bk_draw_grid + ONE bk chain over all (date, trajectory) pairs + bk_grid_spots",
                                           "heston_exact_grid", float(n_g) * st_g, r_g.kernel_ms, vt)},
         }
 

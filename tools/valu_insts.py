@@ -40,13 +40,14 @@ def main():
     gen = mean_of(a, "generate", lambda n: "euler_kernel<hh::HestonModel<0, true>, 0, false, false" in n)
     exact = mean_of(a, "exact", lambda n: "exact_gbm_kernel<0, false, false>" in n)
     bk = mean_of(a, "bk", lambda n: "::bk_" in n)          # the five kernels of one chain, per launch each
-    grid = mean_of(b, "grid", lambda n: "::bk_" in n)      # per transition: the same chain
+    grid = mean_of(b, "grid", lambda n: "::bk_" in n)      # one chain over the 2e5 x 12 (date, trajectory) pairs
     out = {
         "heston_euler_generate": {"valu_insts_per_unit": gen / (N * M), "unit": "path-step", "source": src},
         "lognormal_exact": {"valu_insts_per_unit": exact / N, "unit": "path", "source": src},
         "broadie_kaya": {"valu_insts_per_unit": bk / N, "unit": "path (draw + cf (series, inversion) + scan + ladder + fall-back kernels)",
                          "source": src},
-        "heston_exact_grid": {"valu_insts_per_unit": grid / 200_000, "unit": "transition (the same chain per date)",
+        "heston_exact_grid": {"valu_insts_per_unit": grid / (200_000 * 12),
+                              "unit": "transition (variance rows + the chain over all (date, trajectory) pairs + spot rows)",
                               "source": src},
         "_what": "VALU wave-instructions (64 lanes each) per unit, SQ_INSTS_VALU averaged over the dispatches of a kernel",
     }
