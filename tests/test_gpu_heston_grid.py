@@ -297,3 +297,18 @@ if given is not None:
         ST = spot[-1]
         se = ST.std(ddof=1) / math.sqrt(n)
         assert abs(ST.mean() - 100.0 * math.exp(0.02 * T)) < 5 * se + 0.05
+        # … and the same bits from a kernel chain per date (hhlib's default is the batched form)
+        per_date = _per_date_ctx()
+        spot1, var1, res1 = gpu_grid(per_date, prm, seeds, steps)
+        np.testing.assert_array_equal(spot, spot1)
+        np.testing.assert_array_equal(var, var1)
+        assert res.bk_cf_terms == res1.bk_cf_terms and res.bk_bisect_fallback == res1.bk_bisect_fallback
+
+    _PER_DATE = []
+
+    def _per_date_ctx():
+        if not _PER_DATE:
+            ctx = hh.Context(0)
+            ctx.check(ctx.lib.hh_ctx_set_option(ctx.handle, _ffi.HH_OPT_GRID_FORM, _ffi.HH_GRID_FORM_PER_DATE))
+            _PER_DATE.append(ctx)
+        return _PER_DATE[0]
