@@ -23,6 +23,7 @@
 // backward ratio recurrence), NCχ² (normal shift for d > 1, else Poisson mixture; Marsaglia–Tsang
 // gamma; inversion / PTRS Poisson), secant and bisection root finding.  Compute-bound (fp64 VALU);
 // loop lengths are data dependent, so lanes of a wave diverge — see DESIGN.md for the measured cost.
+#include <algorithm>
 #include <cmath>
 
 #include "hh_bessel.h"
@@ -1087,7 +1088,8 @@ uint32_t bk_grid_dates_per_chain(uint64_t n_paths, uint32_t n_steps, int term_ca
   // as many (date, trajectory) pairs per chain as keep the full term cache inside kPhiBudget, the dates spread
   // evenly over the chains
   const size_t want = term_cache > 0 ? (size_t)term_cache : (size_t)kBkTermCacheDefault;
-  const uint64_t pairs_max = kPhiBudget / (want * sizeof(double));
+  // (and at most 2^24 pairs per chain: past that a chain fills the chip many times over anyway)
+  const uint64_t pairs_max = std::min<uint64_t>(kPhiBudget / (want * sizeof(double)), (uint64_t)1 << 24);
   const uint64_t per = n_paths ? pairs_max / n_paths : 1;
   if (per <= 1) return 1;
   const uint64_t chains = (n_steps + per - 1) / per;
