@@ -116,9 +116,18 @@ constexpr uint32_t kMaxGridSteps = 65534u;        // LSM / exact grid: one grid.
 
 // degrees of freedom of the noncentral chi-squared law of V_T (heston.jl:128): the Bessel order is
 // d/2 - 1, which must stay strictly above -1 in fp64 and within what the tables of hh_bessel.h cover
-static bool bk_law_ok(const hh_model* m) {
-  const double d = 4.0 * m->kappa * m->theta / (m->sigma * m->sigma);
-  return d >= 1e-8 && d <= 1e6;
+// … and the constants of a transition of length dt (heston.jl:129-130, :170-172) must come out finite:
+// kappa·dt beyond ±700 overflows e^{∓κ dt}
+static bool bk_law_ok(const hh_model* m, double dt) {
+  const double s2 = m->sigma * m->sigma;
+  const double d = 4.0 * m->kappa * m->theta / s2;
+  if (!(d >= 1e-8 && d <= 1e6)) return false;
+  const double em1 = -std::expm1(-m->kappa * dt);
+  const double lam_per_v = 4.0 * m->kappa * std::exp(-m->kappa * dt) / (s2 * em1);  // λ / V0
+  const double cscale = s2 * em1 / (4.0 * m->kappa);
+  const double nuk = 4.0 * m->kappa * std::exp(-0.5 * m->kappa * dt) / s2 / em1;
+  return std::isfinite(lam_per_v) && lam_per_v >= 0.0 && std::isfinite(cscale) && cscale > 0.0 &&
+         std::isfinite(nuk) && nuk > 0.0 && std::isfinite(m->kappa * (1.0 + std::exp(-m->kappa * dt)) / em1);
 }
 
 int validate(hh_ctx* ctx, const hh_model* m, const hh_config* c) {
@@ -163,9 +172,10 @@ int validate(hh_ctx* ctx, const hh_model* m, const hh_config* c) {
     if (m->sigma == 0.0 || m->kappa == 0.0 || !(m->V0 > 0.0))
       return fail(ctx, HH_ERR_INVALID, "HestonBroadieKaya needs sigma != 0, kappa != 0, V0 > 0");
     // d = 4κθ/σ² degrees of freedom of the noncentral chi-squared law (heston.jl:128), λ >= 0 (:129)
-    if (!bk_law_ok(m))
+    if (!bk_law_ok(m, m->T))
       return fail(ctx, HH_ERR_INVALID, "HestonBroadieKaya needs 1e-8 <= d = 4 kappa theta / sigma^2 <= 1e6 "
-                                       "(Bessel order d/2 - 1 strictly above -1, tables up to order 5e5)");
+                                       "(Bessel order d/2 - 1 strictly above -1, tables up to order 5e5) and "
+                                       "finite transition constants (|kappa T| < 700)");
   }
   const bool euler = c->strategy == HH_EULER_MARUYAMA;
   if (c->noise_mode == HH_NOISE_REPLAY) {
@@ -862,9 +872,9 @@ static int run_heston_grid(hh_ctx* ctx, const hh_model* m, const hh_config* c) {
       !(std::fabs(m->rho) <= 1.0) || m->sigma == 0.0 || m->kappa == 0.0 || !(m->V0 > 0.0) ||
       !std::isfinite(m->sigma) || !std::isfinite(m->kappa) || !std::isfinite(m->theta) ||
       !std::isfinite(m->V0) || !std::isfinite(m->r_drift) ||
-      !bk_law_ok(m))
+      !bk_law_ok(m, m->T / (double)c->n_steps))
     return fail(ctx, HH_ERR_INVALID,
-                "exact Heston grid: S0, T, V0 > 0, |rho| <= 1, 1e-8 <= 4 kappa theta / sigma^2 <= 1e6, all finite");
+                "exact Heston grid: S0, T, V0 > 0, |rho| <= 1, 1e-8 <= 4 kappa theta / sigma^2 <= 1e6, all finite (|kappa dt| < 700)");
   const uint64_t n = c->n_paths;
   const size_t grid_elems = (size_t)(c->n_steps + 1) * n;
   // dates per kernel chain: given the variance rows, the CF inversions of different dates are
