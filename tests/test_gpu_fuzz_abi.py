@@ -31,7 +31,7 @@ weird = st.one_of(st.floats(allow_nan=True, allow_infinity=True, width=64),
 sane = dict(S0=100.0, V0=0.04, kappa=2.0, theta=0.04, sigma=0.3, rho=-0.7, r=0.03, T=1.0, strike=100.0, cp=1.0)
 
 
-@settings(max_examples=int(os.environ.get("HH_FUZZ_EXAMPLES", "200")), deadline=None, derandomize=True, database=None, phases=[Phase.explicit, Phase.generate],
+@settings(max_examples=int(os.environ.get("HH_FUZZ_EXAMPLES", "800")), deadline=None, derandomize=True, database=None, phases=[Phase.explicit, Phase.generate],
           suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
 @given(which=st.lists(st.sampled_from(sorted(sane)), min_size=1, max_size=3, unique=True), vals=st.lists(weird, min_size=3, max_size=3),
        dynamics=st.sampled_from([0, 1, 1, 7]), strategy=st.sampled_from([0, 1, 2, 2, 9]), anti=st.sampled_from([0, 1]),
@@ -56,7 +56,7 @@ def test_hostile_scalars_return_a_status(hhlib, which, vals, dynamics, strategy,
         assert res.n_paths_done == n_paths
 
 
-@settings(max_examples=int(os.environ.get("HH_FUZZ_EXAMPLES", "60")), deadline=None, derandomize=True, database=None, phases=[Phase.explicit, Phase.generate],
+@settings(max_examples=int(os.environ.get("HH_FUZZ_EXAMPLES", "500")), deadline=None, derandomize=True, database=None, phases=[Phase.explicit, Phase.generate],
           suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
 @given(which=st.lists(st.sampled_from(["S0", "sigma", "r", "T", "strike"]), min_size=1, max_size=2, unique=True),
        vals=st.lists(weird, min_size=2, max_size=2), degree=st.sampled_from([0, 1, 5, 8, 9, -1]),
@@ -74,7 +74,7 @@ def test_hostile_scalars_lsm(hhlib, which, vals, degree, n_paths, n_steps, disc)
     assert rc in (_ffi.HH_OK, _ffi.HH_ERR_INVALID, _ffi.HH_ERR_UNSUPPORTED), (rc, prm)
 
 
-@settings(max_examples=int(os.environ.get("HH_FUZZ_EXAMPLES", "80")), deadline=None, derandomize=True, database=None, phases=[Phase.explicit, Phase.generate],
+@settings(max_examples=int(os.environ.get("HH_FUZZ_EXAMPLES", "500")), deadline=None, derandomize=True, database=None, phases=[Phase.explicit, Phase.generate],
           suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
 @given(which=st.lists(st.sampled_from(["S0", "V0", "kappa", "theta", "sigma", "rho"]), min_size=1, max_size=2, unique=True),
        vals=st.lists(weird, min_size=2, max_size=2), dyn=st.sampled_from([0, 1, 5]),
@@ -96,7 +96,7 @@ def test_hostile_scalars_carr_madan_basket(hhlib, which, vals, dyn, strike, T, r
     assert rc in (_ffi.HH_OK, _ffi.HH_ERR_INVALID, _ffi.HH_ERR_UNSUPPORTED), rc
 
 
-@settings(max_examples=int(os.environ.get("HH_FUZZ_EXAMPLES", "60")), deadline=None, derandomize=True, database=None, phases=[Phase.explicit, Phase.generate],
+@settings(max_examples=int(os.environ.get("HH_FUZZ_EXAMPLES", "500")), deadline=None, derandomize=True, database=None, phases=[Phase.explicit, Phase.generate],
           suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
 @given(which=st.lists(st.sampled_from(sorted(sane)), min_size=1, max_size=3, unique=True), vals=st.lists(weird, min_size=3, max_size=3),
        n_paths=st.sampled_from([0, 1, 200]), n_steps=st.sampled_from([0, 1, 5]))
@@ -117,7 +117,7 @@ def test_hostile_scalars_exact_grid(hhlib, which, vals, n_paths, n_steps):
         assert np.all(np.isfinite(spot)) and np.all(spot > 0)  # moderate inputs: moderate outputs
 
 
-@settings(max_examples=int(os.environ.get("HH_FUZZ_EXAMPLES", "80")), deadline=None, derandomize=True, database=None,
+@settings(max_examples=int(os.environ.get("HH_FUZZ_EXAMPLES", "500")), deadline=None, derandomize=True, database=None,
           phases=[Phase.explicit, Phase.generate],
           suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
 @given(strikes=st.lists(weird, min_size=1, max_size=6), cps=st.lists(st.sampled_from([1.0, -1.0, 0.0, 2.0]), min_size=6, max_size=6),
@@ -136,7 +136,7 @@ def test_hostile_scalars_basket(hhlib, strikes, cps, dynamics, strategy, anti, n
     assert rc in (_ffi.HH_OK, _ffi.HH_ERR_INVALID, _ffi.HH_ERR_UNSUPPORTED), rc
 
 
-@settings(max_examples=int(os.environ.get("HH_FUZZ_EXAMPLES", "80")), deadline=None, derandomize=True, database=None,
+@settings(max_examples=int(os.environ.get("HH_FUZZ_EXAMPLES", "500")), deadline=None, derandomize=True, database=None,
           phases=[Phase.explicit, Phase.generate],
           suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
 @given(dynamics=st.sampled_from([0, 1]), strategy=st.sampled_from([0, 1, 2]), layout=st.sampled_from([0, 1, 4]),
