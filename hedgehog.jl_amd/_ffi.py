@@ -19,7 +19,9 @@ HH_EULER_MARUYAMA, HH_EXACT_LAW, HH_BROADIE_KAYA = 0, 1, 2
 HH_NOISE_GENERATE, HH_NOISE_REPLAY = 0, 1
 HH_REPLAY_TILE_MAJOR, HH_REPLAY_PATH_MAJOR = 0, 1
 
-HH_OK, HH_ERR_INVALID, HH_ERR_UNSUPPORTED, HH_ERR_HIP, HH_ERR_NOMEM = 0, -1, -2, -3, -4
+HH_OK, HH_ERR_INVALID, HH_ERR_UNSUPPORTED, HH_ERR_HIP, HH_ERR_NOMEM, HH_ERR_RCCL = 0, -1, -2, -3, -4, -5
+HH_MGPU_AUTO, HH_MGPU_HOST_SUM, HH_MGPU_RCCL = 0, 1, 2
+HH_MGPU_REDUCE_HOST, HH_MGPU_REDUCE_RCCL = 0, 1
 
 _dp = C.POINTER(C.c_double)
 
@@ -124,6 +126,16 @@ SYMBOLS = [
     ("hh_ctx_synchronize", C.c_int, [_vp]),
     ("hh_ctx_enable_timing", C.c_int, [_vp, C.c_int32]),
     ("hh_ctx_read_timings", C.c_int, [_vp, _vp, C.c_int32, C.POINTER(C.c_int32)]),
+    ("hh_mgpu_create", C.c_int, [C.POINTER(_vp), C.POINTER(C.c_int), C.c_int, C.c_int]),
+    ("hh_mgpu_destroy", None, [_vp]),
+    ("hh_mgpu_last_error", C.c_char_p, [_vp]),
+    ("hh_mgpu_n_devices", C.c_int, [_vp]),
+    ("hh_mgpu_reduce_mode", C.c_int, [_vp]),
+    ("hh_mgpu_ctx", _vp, [_vp, C.c_int]),
+    ("hh_mgpu_shard_range", None, [C.c_uint64, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    ("hh_mgpu_solve", C.c_int, [_vp, C.POINTER(hh_model), C.POINTER(hh_config), C.POINTER(hh_result), _vp]),
+    ("hh_mgpu_solve_shards", C.c_int, [_vp, C.POINTER(hh_model), C.POINTER(hh_config), C.POINTER(hh_result), _vp]),
+    ("hh_mgpu_solve_basket", C.c_int, [_vp, C.POINTER(hh_model), C.POINTER(hh_config), _vp, _vp, C.c_uint32, _vp]),
 ]
 
 _lib = None
@@ -269,7 +281,99 @@ class DeviceBuffer:
             pass
 
 
+class BorrowedContext(Context):
+    """The hh_ctx of one device of a MultiGpu (hh_mgpu_ctx): same methods, never destroyed here."""
+
+    def __init__(self, lib, handle, device):
+        self.lib, self.handle, self.device = lib, handle, int(device)
+
+    def close(self):
+        for p, _ in self.__dict__.get("_pool", []):
+            self.lib.hh_device_free(self.handle, _vp(p))
+        self.__dict__["_pool"] = []
+        self.handle = None
+
+
+class MultiGpu:
+    """Owns one hh_mgpu: one hh_ctx per listed device, driven from this host thread; the accumulator
+    vectors are combined inside the library (RCCL all-reduce, or the host's ordered sum)."""
+
+    def __init__(self, devices, flags: int = HH_MGPU_AUTO):
+        self.lib = load_library()
+        self.devices = [int(d) for d in devices]
+        arr = (C.c_int * len(self.devices))(*self.devices)
+        h = _vp()
+        rc = self.lib.hh_mgpu_create(C.byref(h), arr, len(self.devices), int(flags))
+        if rc != HH_OK:
+            raise HedgehogMCError(rc, f"hh_mgpu_create(devices={self.devices}, flags={flags}) failed "
+                                  "(no HIP device, a bad ordinal, or RCCL required but unavailable)")
+        self.handle = h
+        self._ctxs = [BorrowedContext(self.lib, _vp(self.lib.hh_mgpu_ctx(h, i)), d)
+                      for i, d in enumerate(self.devices)]
+
+    @property
+    def n_devices(self) -> int:
+        return self.lib.hh_mgpu_n_devices(self.handle)
+
+    @property
+    def reduce_mode(self) -> int:
+        return self.lib.hh_mgpu_reduce_mode(self.handle)
+
+    def last_error(self) -> str:
+        return self.lib.hh_mgpu_last_error(self.handle).decode(errors="replace")
+
+    def ctx(self, i: int) -> Context:
+        return self._ctxs[i]
+
+    def check(self, rc: int):
+        if rc != HH_OK:
+            raise HedgehogMCError(rc, self.last_error())
+
+    def shard_range(self, n_paths: int, g: int, tile_aligned: bool = False):
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        self.lib.hh_mgpu_shard_range(int(n_paths), len(self.devices), int(g), int(tile_aligned),
+                                     C.byref(a), C.byref(b))
+        return a.value, b.value
+
+    def solve(self, model, cfg, terminal=None) -> hh_result:
+        res = hh_result()
+        self.check(self.lib.hh_mgpu_solve(self.handle, C.byref(model), C.byref(cfg), C.byref(res),
+                                          terminal.ctypes.data if terminal is not None else None))
+        return res
+
+    def solve_shards(self, model, cfgs, terminals=None) -> hh_result:
+        arr = (hh_config * len(cfgs))(*cfgs)
+        tp = None
+        if terminals is not None:
+            tp = (_vp * len(cfgs))(*[(t if isinstance(t, int) or t is None else t.ctypes.data) for t in terminals])
+        res = hh_result()
+        self.check(self.lib.hh_mgpu_solve_shards(self.handle, C.byref(model), arr, C.byref(res), tp))
+        return res
+
+    def close(self):
+        if getattr(self, "handle", None):
+            for c in self._ctxs:
+                c.close()
+            self.lib.hh_mgpu_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 _contexts: dict[int, Context] = {}
+_mgpus: dict[tuple, MultiGpu] = {}
+
+
+def get_multi_gpu(devices, flags: int = HH_MGPU_AUTO) -> MultiGpu:
+    key = (tuple(int(d) for d in devices), int(flags))
+    mg = _mgpus.get(key)
+    if mg is None:
+        mg = _mgpus[key] = MultiGpu(key[0], flags)
+    return mg
 
 
 def get_context(device: int = 0) -> Context:

@@ -11,101 +11,11 @@
 
 #include "hh_kernels.h"
 
-struct hh_ctx {
-  int device = 0;
-  hipStream_t own_stream = nullptr;
-  hipStream_t stream = nullptr;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_switch = nullptr;
-  double* records = nullptr;
-  size_t records_cap = 0;  // in records
-  uint64_t* seeds = nullptr;
-  size_t seeds_cap = 0;  // in elements
-  double* replay = nullptr;  // tile-major staging
-  size_t replay_cap = 0;
-  double* replay_src = nullptr;  // path-major staging
-  size_t replay_src_cap = 0;
-  double* terminal = nullptr;
-  size_t terminal_cap = 0;
-  double* terminal_d = nullptr;  // [P][n_total] terminal partials (basket Greeks)
-  size_t terminal_d_cap = 0;
-  double* payoffs = nullptr;  // [2][n_payoffs]: strikes, cps
-  size_t payoffs_cap = 0;
-  double* basket_records = nullptr;
-  size_t basket_records_cap = 0;
-  double* basket_accum = nullptr;
-  size_t basket_accum_cap = 0;
-  unsigned char* bk_scratch = nullptr;
-  size_t bk_scratch_cap = 0;
-  hh::BkTableKey bk_table_key{};  // Bessel tables resident in bk_scratch (a new allocation has a new address)
-  double* lsm_grid = nullptr;  // [n_steps+1][ntot]
-  size_t lsm_grid_cap = 0;
-  double* heston_var = nullptr;  // [n_steps+1][n_paths] variance rows of the exact Heston grid
-  size_t heston_var_cap = 0;
-  double* lsm_val = nullptr;
-  size_t lsm_val_cap = 0;
-  int32_t* lsm_tau = nullptr;
-  size_t lsm_tau_cap = 0;
-  double* lsm_scratch = nullptr;
-  size_t lsm_scratch_cap = 0;
-  // sharded LSM in progress (hh_lsm_shard_begin .. hh_lsm_shard_finish)
-  struct {
-    bool active = false;
-    hh_model m{};
-    uint64_t ntot = 0;
-    uint32_t n_steps = 0;
-    int32_t degree = 0;
-    double step_discount = 1.0;
-  } shard;
-  int lsm_form = hh::kLsmFormAuto;  // hh_ctx_set_option(HH_OPT_LSM_FORM)
-  int bk_term_cache = 0;            // hh_ctx_set_option(HH_OPT_BK_TERM_CACHE); 0 = the default
-  int grid_form = HH_GRID_FORM_BATCHED;  // hh_ctx_set_option(HH_OPT_GRID_FORM)
-  uint64_t lsm_persistent_fallbacks = 0;  // persistent launches that gave up and were redone per date
-  double* accum = nullptr;       // device, HH_ACC_LEN
-  double* accum_host = nullptr;  // pinned, HH_ACC_LEN
-  // optional per-launch timing of the simulation kernel (hh_ctx_enable_timing)
-  static constexpr int kTimingSlots = 256;
-  bool timing = false;
-  hipEvent_t tev[kTimingSlots][2] = {};
-  int t_count = 0;  // pairs recorded since the last read (capped at kTimingSlots)
-  char err[512] = {0};
-  std::recursive_mutex mu;  // entry points serialise on it: a ctx may be shared between threads
-};
+#include "hh_ctx.h"
 
 namespace {
 
-const char* kNoCtx = "hedgehog_mc: no context";
-
-int fail(hh_ctx* ctx, int code, const char* fmt, ...) {
-  if (ctx) {
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(ctx->err, sizeof(ctx->err), fmt, ap);
-    va_end(ap);
-  }
-  return code;
-}
-
-#define HH_HIP(ctx, expr)                                                                   \
-  do {                                                                                      \
-    hipError_t e__ = (hipError_t)(expr);                                                    \
-    if (e__ != hipSuccess)                                                                  \
-      return fail(ctx, HH_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__),  \
-                  __FILE__, __LINE__);                                                      \
-  } while (0)
-
-template <class T>
-int ensure(hh_ctx* ctx, T*& buf, size_t& cap, size_t need) {
-  if (need <= cap) return HH_OK;
-  if (buf) HH_HIP(ctx, hipFree(buf));
-  buf = nullptr;
-  cap = 0;
-  hipError_t e = hipMalloc((void**)&buf, need * sizeof(T));
-  if (e != hipSuccess)
-    return fail(ctx, HH_ERR_NOMEM, "hipMalloc(%zu bytes) failed: %s", need * sizeof(T),
-                hipGetErrorString(e));
-  cap = need;
-  return HH_OK;
-}
+const char* const kNoCtx = "hedgehog_mc: no context";
 
 int ncomp_of(int dynamics) { return dynamics == HH_HESTON ? 2 : 1; }
 
@@ -392,7 +302,7 @@ static int run_simulation(hh_ctx* ctx, const hh_model* m, const hh_config* c, do
   hh::DevicePtrs p{};
   p.records = ctx->records;
   if (bk) {
-    rc = ensure(ctx, ctx->bk_scratch, ctx->bk_scratch_cap, hh::bk_scratch_bytes(c->n_paths, ctx->bk_term_cache));
+    rc = ensure_bk_scratch(ctx, hh::bk_scratch_bytes(c->n_paths, ctx->bk_term_cache));
     if (rc) return rc;
     p.bk_scratch = ctx->bk_scratch;
     p.bk_table_key = &ctx->bk_table_key;
@@ -888,7 +798,7 @@ static int run_heston_grid(hh_ctx* ctx, const hh_model* m, const hh_config* c) {
   if ((rc = ensure(ctx, ctx->heston_var, ctx->heston_var_cap, grid_elems))) return rc;
   if ((rc = ensure(ctx, ctx->records, ctx->records_cap, (size_t)hh::bk_record_count(n_chain) * hh::kRecStride)))
     return rc;
-  if ((rc = ensure(ctx, ctx->bk_scratch, ctx->bk_scratch_cap, hh::bk_scratch_bytes(n_chain, ctx->bk_term_cache)))) return rc;
+  if ((rc = ensure_bk_scratch(ctx, hh::bk_scratch_bytes(n_chain, ctx->bk_term_cache)))) return rc;
   if ((rc = ensure(ctx, ctx->basket_accum, ctx->basket_accum_cap, (size_t)c->n_steps * HH_ACC_LEN)))
     return rc;
   hh::DevicePtrs p{};

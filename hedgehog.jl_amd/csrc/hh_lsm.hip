@@ -718,7 +718,7 @@ __device__ __forceinline__ bool gather_records(const LsmPersistArgs& a, uint32_t
         const unsigned tag = mine ? __hip_atomic_load((gu32*)(a.tags + slot), __ATOMIC_RELAXED,
                                                       __HIP_MEMORY_SCOPE_AGENT)
                                   : e;
-        if (__all(tag == e) || (HH_LSM_DEBUG & 1)) break;
+        if (__all(tag == e) || ((HH_LSM_DEBUG & 1) != 0)) break;
         __builtin_amdgcn_s_sleep(1);
         if ((++spins & 63u) == 0) {  // bounded: every wave reaches an exit
           const unsigned gave_up = __hip_atomic_load((gu32*)a.status, __ATOMIC_RELAXED,

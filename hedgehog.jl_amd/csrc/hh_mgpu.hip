@@ -1,0 +1,462 @@
+// hh_mgpu_*: the path-sharded multi-GPU solve driven from ONE host thread inside the library
+// (include/hedgehog_mc.h).  What it stands in for is still ONE call of
+// solve(prob, method) (montecarlo.jl:478-493) on one EnsembleProblem (:329-333,351): the trajectories
+// are cut into contiguous ranges, every device runs the single-GPU kernel sequence of hh_mc_accumulate
+// on its range and on its own stream, and the HH_ACC_LEN-double accumulator vectors are combined by
+// one RCCL all-reduce over xGMI — or, when RCCL is not there or refuses, by an ordered sum on the
+// host.  No arithmetic of the pricing path happens here except that ordered sum.
+//
+// RCCL is bound with dlopen at run time: the product library has no link-time dependency on it (a
+// Julia host that never shards does not need librccl at all), and inside a PyTorch process the
+// already-loaded librccl.so.1 — built against the HIP runtime the process uses — is what the soname
+// resolves to.
+#include <dlfcn.h>
+
+#include <chrono>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "hh_ctx.h"
+
+namespace {
+
+// the few RCCL declarations used (rccl.h: ncclComm_t, ncclResult_t, ncclSum = 0, ncclDouble = 8)
+typedef struct ncclComm* rccl_comm_t;
+constexpr int kNcclSuccess = 0, kNcclSum = 0, kNcclDouble = 8;
+
+struct RcclApi {
+  void* lib = nullptr;
+  int (*CommInitAll)(rccl_comm_t*, int, const int*) = nullptr;
+  int (*CommDestroy)(rccl_comm_t) = nullptr;
+  int (*AllReduce)(const void*, void*, size_t, int, int, rccl_comm_t, hipStream_t) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+  char why[256] = {0};  // why it is not available
+  bool ok = false;
+};
+
+RcclApi& rccl() {
+  static RcclApi api;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    const char* env = std::getenv("HEDGEHOG_MC_RCCL");
+    const char* names[] = {env, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* n : names) {
+      if (!n || !*n) continue;
+      api.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+      if (api.lib) break;
+    }
+    if (!api.lib) {
+      snprintf(api.why, sizeof(api.why), "librccl not found (%s)", dlerror());
+      return;
+    }
+    api.CommInitAll = (decltype(api.CommInitAll))dlsym(api.lib, "ncclCommInitAll");
+    api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.lib, "ncclCommDestroy");
+    api.AllReduce = (decltype(api.AllReduce))dlsym(api.lib, "ncclAllReduce");
+    api.GroupStart = (decltype(api.GroupStart))dlsym(api.lib, "ncclGroupStart");
+    api.GroupEnd = (decltype(api.GroupEnd))dlsym(api.lib, "ncclGroupEnd");
+    api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.lib, "ncclGetErrorString");
+    api.ok = api.CommInitAll && api.CommDestroy && api.AllReduce && api.GroupStart && api.GroupEnd &&
+             api.GetErrorString;
+    if (!api.ok) snprintf(api.why, sizeof(api.why), "librccl lacks an expected symbol");
+  });
+  return api;
+}
+
+}  // namespace
+
+struct hh_mgpu {
+  int n = 0;
+  int flags = HH_MGPU_AUTO;
+  int mode = HH_MGPU_REDUCE_HOST;
+  std::vector<int> devices;
+  std::vector<hh_ctx*> ctx;
+  std::vector<double*> acc, red;  // per device: local sums, all-reduced sums (RCCL writes out of place)
+  std::vector<size_t> acc_cap;    // doubles
+  std::vector<rccl_comm_t> comms;
+  double* host = nullptr;  // pinned, n x acc_cap
+  size_t host_cap = 0;
+  char err[512] = {0};
+  std::mutex mu;
+};
+
+namespace {
+
+int mfail(hh_mgpu* mg, int code, const char* fmt, ...) {
+  if (mg) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(mg->err, sizeof(mg->err), fmt, ap);
+    va_end(ap);
+  }
+  return code;
+}
+
+#define HH_MHIP(mg, expr)                                                                     \
+  do {                                                                                        \
+    hipError_t e__ = (hipError_t)(expr);                                                      \
+    if (e__ != hipSuccess)                                                                    \
+      return mfail(mg, HH_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__),    \
+                   __FILE__, __LINE__);                                                       \
+  } while (0)
+
+void shard_range(uint64_t n_paths, int n_dev, int g, bool tile_aligned, uint64_t* start, uint64_t* stop) {
+  uint64_t per = (n_paths + (uint64_t)n_dev - 1) / (uint64_t)n_dev;
+  if (tile_aligned) per = (per + hh::kTile - 1) / hh::kTile * hh::kTile;
+  const uint64_t a = std::min(n_paths, (uint64_t)g * per);
+  *start = a;
+  *stop = std::min(n_paths, a + per);
+}
+
+// the staging / accumulator buffers of an accumulator vector of n_acc doubles per device
+int ensure_acc(hh_mgpu* mg, size_t n_acc) {
+  for (int g = 0; g < mg->n; ++g) {
+    if (mg->acc_cap[g] >= n_acc) continue;
+    HH_MHIP(mg, hipSetDevice(mg->devices[g]));
+    if (mg->acc[g]) HH_MHIP(mg, hipFree(mg->acc[g]));
+    if (mg->red[g]) HH_MHIP(mg, hipFree(mg->red[g]));
+    mg->acc[g] = mg->red[g] = nullptr;
+    mg->acc_cap[g] = 0;
+    if (hipMalloc((void**)&mg->acc[g], n_acc * sizeof(double)) != hipSuccess ||
+        hipMalloc((void**)&mg->red[g], n_acc * sizeof(double)) != hipSuccess)
+      return mfail(mg, HH_ERR_NOMEM, "hipMalloc of the accumulator vectors failed");
+    mg->acc_cap[g] = n_acc;
+  }
+  if (mg->host_cap < n_acc * (size_t)mg->n) {
+    if (mg->host) HH_MHIP(mg, hipHostFree(mg->host));
+    mg->host = nullptr;
+    mg->host_cap = 0;
+    HH_MHIP(mg, hipHostMalloc((void**)&mg->host, n_acc * (size_t)mg->n * sizeof(double), hipHostMallocDefault));
+    mg->host_cap = n_acc * (size_t)mg->n;
+  }
+  return HH_OK;
+}
+
+void sync_all(hh_mgpu* mg) {
+  for (int g = 0; g < mg->n; ++g) {
+    (void)hipSetDevice(mg->devices[g]);
+    (void)hipStreamSynchronize(mg->ctx[g]->stream);
+  }
+}
+
+struct Basket {
+  const double *strikes, *cps;
+  uint32_t n_payoffs;
+};
+
+// Enqueue every shard, combine the accumulator vectors, leave the combined vector in mg->host[0 .. n_acc).
+// cfgs[g].n_paths == 0 leaves device g idle (it contributes zeros).  term_dev[g] (nullable): device
+// buffer for the shard's terminal samples, already part of cfgs[g] — nothing to do with it here.
+int run_shards(hh_mgpu* mg, const hh_model* m, const hh_config* cfgs, const Basket* basket,
+               double* const* terminals, double* kernel_ms) {
+  const size_t n_acc = (size_t)HH_ACC_LEN * (basket ? basket->n_payoffs : 1u);
+  int rc = ensure_acc(mg, n_acc);
+  if (rc) return rc;
+  // 1. every shard's kernel sequence, back to back, nobody waits
+  for (int g = 0; g < mg->n; ++g) {
+    hh_ctx* c = mg->ctx[g];
+    HH_MHIP(mg, hipSetDevice(mg->devices[g]));
+    HH_MHIP(mg, hipEventRecord(c->ev0, c->stream));
+    if (cfgs[g].n_paths == 0) {
+      HH_MHIP(mg, hipMemsetAsync(mg->acc[g], 0, n_acc * sizeof(double), c->stream));
+    } else {
+      double* term = terminals ? terminals[g] : nullptr;
+      rc = basket ? hh_mc_accumulate_basket(c, m, &cfgs[g], basket->strikes, basket->cps, basket->n_payoffs,
+                                            mg->acc[g], term)
+                  : hh_mc_accumulate(c, m, &cfgs[g], mg->acc[g], term);
+      if (rc) {
+        mfail(mg, rc, "shard %d (device %d): %s", g, mg->devices[g], hh_last_error(c));
+        sync_all(mg);  // earlier shards still read the caller's buffers
+        return rc;
+      }
+    }
+    HH_MHIP(mg, hipEventRecord(c->ev1, c->stream));
+  }
+  // 2. the path's one exchange
+  bool reduced = false;
+  if (mg->mode == HH_MGPU_REDUCE_RCCL) {
+    RcclApi& api = rccl();
+    int e = api.GroupStart();
+    for (int g = 0; g < mg->n && e == kNcclSuccess; ++g)
+      e = api.AllReduce(mg->acc[g], mg->red[g], n_acc, kNcclDouble, kNcclSum, mg->comms[g], mg->ctx[g]->stream);
+    const int e2 = api.GroupEnd();
+    if (e == kNcclSuccess) e = e2;
+    if (e == kNcclSuccess) {
+      HH_MHIP(mg, hipSetDevice(mg->devices[0]));
+      HH_MHIP(mg, hipMemcpyAsync(mg->host, mg->red[0], n_acc * sizeof(double), hipMemcpyDeviceToHost,
+                                 mg->ctx[0]->stream));
+      reduced = true;
+    } else {
+      mfail(mg, HH_ERR_RCCL, "ncclAllReduce failed: %s", api.GetErrorString(e));
+      if (mg->flags == HH_MGPU_RCCL) {
+        sync_all(mg);
+        return HH_ERR_RCCL;
+      }  // else: the local sums are untouched (out-of-place reduce) — finish on the host
+    }
+  }
+  if (!reduced) {
+    for (int g = 0; g < mg->n; ++g) {
+      HH_MHIP(mg, hipSetDevice(mg->devices[g]));
+      HH_MHIP(mg, hipMemcpyAsync(mg->host + (size_t)g * n_acc, mg->acc[g], n_acc * sizeof(double),
+                                 hipMemcpyDeviceToHost, mg->ctx[g]->stream));
+    }
+  }
+  // 3. wait for every device (the caller's buffers are free again after this), then the ordered sum
+  for (int g = 0; g < mg->n; ++g) {
+    HH_MHIP(mg, hipSetDevice(mg->devices[g]));
+    HH_MHIP(mg, hipStreamSynchronize(mg->ctx[g]->stream));
+  }
+  if (!reduced) {
+    for (int g = 1; g < mg->n; ++g)  // fixed order g = 0 … G-1: deterministic for a given sharding
+      for (size_t i = 0; i < n_acc; ++i) mg->host[i] += mg->host[(size_t)g * n_acc + i];
+  }
+  double worst = 0.0;
+  for (int g = 0; g < mg->n; ++g) {
+    float ms = 0.f;
+    HH_MHIP(mg, hipSetDevice(mg->devices[g]));
+    HH_MHIP(mg, hipEventElapsedTime(&ms, mg->ctx[g]->ev0, mg->ctx[g]->ev1));
+    if (ms > worst) worst = ms;
+  }
+  *kernel_ms = worst;
+  return HH_OK;
+}
+
+int ncomp(int dynamics) { return dynamics == HH_HESTON ? 2 : 1; }
+
+}  // namespace
+
+extern "C" {
+
+void hh_mgpu_shard_range(uint64_t n_paths, int n_devices, int g, int tile_aligned, uint64_t* start,
+                         uint64_t* stop) {
+  uint64_t a = 0, b = 0;
+  if (n_devices > 0 && g >= 0 && g < n_devices) shard_range(n_paths, n_devices, g, tile_aligned != 0, &a, &b);
+  if (start) *start = a;
+  if (stop) *stop = b;
+}
+
+int hh_mgpu_create(hh_mgpu** out, const int* device_ids, int n_devices, int flags) {
+  if (!out) return HH_ERR_INVALID;
+  *out = nullptr;
+  if (!device_ids || n_devices < 1 || n_devices > 64) return HH_ERR_INVALID;
+  if (flags != HH_MGPU_AUTO && flags != HH_MGPU_HOST_SUM && flags != HH_MGPU_RCCL) return HH_ERR_INVALID;
+  hh_mgpu* mg = new (std::nothrow) hh_mgpu();
+  if (!mg) return HH_ERR_NOMEM;
+  mg->n = n_devices;
+  mg->flags = flags;
+  mg->devices.assign(device_ids, device_ids + n_devices);
+  mg->ctx.assign(n_devices, nullptr);
+  mg->acc.assign(n_devices, nullptr);
+  mg->red.assign(n_devices, nullptr);
+  mg->acc_cap.assign(n_devices, 0);
+  for (int g = 0; g < n_devices; ++g) {
+    const int rc = hh_ctx_create(&mg->ctx[g], device_ids[g]);
+    if (rc) {
+      hh_mgpu_destroy(mg);
+      return rc;
+    }
+  }
+  const bool want = flags == HH_MGPU_RCCL || (flags == HH_MGPU_AUTO && n_devices > 1);
+  if (want) {
+    RcclApi& api = rccl();
+    int e = -1;
+    if (api.ok) {
+      mg->comms.assign(n_devices, nullptr);
+      e = api.CommInitAll(mg->comms.data(), n_devices, device_ids);  // refuses a device listed twice
+      if (e != kNcclSuccess) {
+        mg->comms.clear();
+        mfail(mg, HH_ERR_RCCL, "ncclCommInitAll failed: %s — accumulators are summed on the host",
+              api.GetErrorString(e));
+      }
+    } else {
+      mfail(mg, HH_ERR_RCCL, "RCCL unavailable: %s — accumulators are summed on the host", api.why);
+    }
+    if (e == kNcclSuccess) {
+      mg->mode = HH_MGPU_REDUCE_RCCL;
+    } else if (flags == HH_MGPU_RCCL) {
+      hh_mgpu_destroy(mg);
+      return HH_ERR_RCCL;
+    }
+  }
+  *out = mg;
+  return HH_OK;
+}
+
+void hh_mgpu_destroy(hh_mgpu* mg) {
+  if (!mg) return;
+  for (int g = 0; g < mg->n; ++g) {
+    if (!mg->ctx[g]) continue;
+    (void)hipSetDevice(mg->devices[g]);
+    (void)hipStreamSynchronize(mg->ctx[g]->stream);
+  }
+  for (rccl_comm_t c : mg->comms)
+    if (c) (void)rccl().CommDestroy(c);
+  for (int g = 0; g < mg->n; ++g) {
+    (void)hipSetDevice(mg->devices[g]);
+    if (mg->acc[g]) (void)hipFree(mg->acc[g]);
+    if (mg->red[g]) (void)hipFree(mg->red[g]);
+    if (mg->ctx[g]) hh_ctx_destroy(mg->ctx[g]);
+  }
+  if (mg->host) (void)hipHostFree(mg->host);
+  delete mg;
+}
+
+const char* hh_mgpu_last_error(const hh_mgpu* mg) { return mg ? mg->err : "hedgehog_mc: no multi-GPU context"; }
+int hh_mgpu_n_devices(const hh_mgpu* mg) { return mg ? mg->n : 0; }
+int hh_mgpu_reduce_mode(const hh_mgpu* mg) { return mg ? mg->mode : HH_MGPU_REDUCE_HOST; }
+hh_ctx* hh_mgpu_ctx(hh_mgpu* mg, int i) { return (mg && i >= 0 && i < mg->n) ? mg->ctx[i] : nullptr; }
+
+int hh_mgpu_solve_shards(hh_mgpu* mg, const hh_model* m, const hh_config* cfgs, hh_result* out,
+                         double* const* terminals) {
+  if (!mg) return HH_ERR_INVALID;
+  std::lock_guard<std::mutex> lock__(mg->mu);
+  if (!m || !cfgs || !out) return mfail(mg, HH_ERR_INVALID, "hh_mgpu_solve_shards: NULL argument");
+  const auto t0 = std::chrono::steady_clock::now();
+  int first = -1;
+  for (int g = 0; g < mg->n && first < 0; ++g)
+    if (cfgs[g].n_paths) first = g;
+  if (first < 0) return mfail(mg, HH_ERR_INVALID, "every shard is empty");
+  std::memset(out, 0, sizeof(*out));
+  double kernel_ms = 0.0;
+  int rc = run_shards(mg, m, cfgs, nullptr, terminals, &kernel_ms);
+  if (rc) return rc;
+  rc = hh_mc_finalize(m, &cfgs[first], mg->host, out);  // reads n_partials and the discount seeds only
+  if (rc) return mfail(mg, rc, "finalize failed");
+  out->kernel_ms = kernel_ms;
+  out->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  return HH_OK;
+}
+
+// Shards of a whole-ensemble config with host buffers; BK REPLAY draws [V_T | u | Z] are three slices
+// per shard, staged into the shard ctx's own replay buffer.
+static int cut_config(hh_mgpu* mg, const hh_config* cfg, bool want_terminal, std::vector<hh_config>& cs,
+                      std::vector<double*>& term_dev, std::vector<uint64_t>& starts) {
+  if (cfg->n_paths == 0) return mfail(mg, HH_ERR_INVALID, "n_paths must be >= 1");
+  if (cfg->seeds_on_device || cfg->replay_on_device || cfg->terminal_on_device)
+    return mfail(mg, HH_ERR_INVALID,
+                 "hh_mgpu_solve takes host buffers; device-resident shards go through hh_mgpu_solve_shards");
+  const bool euler = cfg->strategy == HH_EULER_MARUYAMA;
+  const bool replay = cfg->noise_mode == HH_NOISE_REPLAY;
+  const bool bk = cfg->strategy == HH_BROADIE_KAYA;
+  const bool tile = replay && euler && cfg->replay_layout == HH_REPLAY_TILE_MAJOR;
+  if (replay && !cfg->replay) return mfail(mg, HH_ERR_INVALID, "REPLAY needs a replay buffer");
+  if (!replay && !cfg->seeds) return mfail(mg, HH_ERR_INVALID, "GENERATE needs seeds");
+  const uint64_t N = cfg->n_paths;
+  const size_t per_path = euler ? (size_t)cfg->n_steps * ncomp(cfg->dynamics) : 1;
+  if (replay && cfg->replay_len) {  // whole-ensemble operand shape, as hh_mc_solve would check it
+    const uint64_t need = bk ? 3 * N : tile ? (uint64_t)hh::tiles_for(N) * hh::kTile * per_path : N * per_path;
+    if (cfg->replay_len < need)
+      return mfail(mg, HH_ERR_INVALID, "replay buffer holds %llu elements, %llu needed",
+                   (unsigned long long)cfg->replay_len, (unsigned long long)need);
+  }
+  if (!replay && cfg->seeds_len && cfg->seeds_len < (euler ? N : 1))
+    return mfail(mg, HH_ERR_INVALID, "Number of seeds (%llu) must be >= number of trajectories (%llu)",
+                 (unsigned long long)cfg->seeds_len, (unsigned long long)(euler ? N : 1));
+  cs.assign(mg->n, *cfg);
+  term_dev.assign(mg->n, nullptr);
+  starts.assign(mg->n, 0);
+  for (int g = 0; g < mg->n; ++g) {
+    uint64_t a, b;
+    shard_range(N, mg->n, g, tile, &a, &b);
+    hh_config& c = cs[g];
+    hh_ctx* x = mg->ctx[g];
+    starts[g] = a;
+    c.n_paths = b - a;
+    c.path_offset = cfg->path_offset + a;
+    c.seeds_len = c.replay_len = 0;
+    if (c.n_paths == 0) continue;
+    if (!replay && euler) c.seeds = cfg->seeds + a;
+    if (replay && !bk) c.replay = cfg->replay + a * per_path;  // a is a multiple of 256 for tile-major data
+    HH_MHIP(mg, hipSetDevice(mg->devices[g]));
+    if (replay && bk) {
+      int rc = ensure(x, x->replay, x->replay_cap, (size_t)3 * c.n_paths);
+      if (rc) return mfail(mg, rc, "%s", x->err);
+      for (int k = 0; k < 3; ++k)
+        HH_MHIP(mg, hipMemcpyAsync(x->replay + (size_t)k * c.n_paths, cfg->replay + (size_t)k * N + a,
+                                   c.n_paths * sizeof(double), hipMemcpyHostToDevice, x->stream));
+      c.replay = x->replay;
+      c.replay_on_device = 1;
+    }
+    if (want_terminal) {
+      int rc = ensure(x, x->terminal, x->terminal_cap, (size_t)c.n_paths * (c.antithetic ? 2 : 1));
+      if (rc) return mfail(mg, rc, "%s", x->err);
+      term_dev[g] = x->terminal;
+      c.terminal_on_device = 1;
+    }
+  }
+  return HH_OK;
+}
+
+int hh_mgpu_solve(hh_mgpu* mg, const hh_model* m, const hh_config* cfg, hh_result* out, double* terminal) {
+  if (!mg) return HH_ERR_INVALID;
+  std::lock_guard<std::mutex> lock__(mg->mu);
+  if (!m || !cfg || !out) return mfail(mg, HH_ERR_INVALID, "hh_mgpu_solve: NULL argument");
+  const auto t0 = std::chrono::steady_clock::now();
+  std::vector<hh_config> cs;
+  std::vector<double*> term_dev;
+  std::vector<uint64_t> starts;
+  int rc = cut_config(mg, cfg, terminal != nullptr, cs, term_dev, starts);
+  if (rc) {
+    sync_all(mg);
+    return rc;
+  }
+  std::memset(out, 0, sizeof(*out));
+  double kernel_ms = 0.0;
+  rc = run_shards(mg, m, cs.data(), nullptr, terminal ? term_dev.data() : nullptr, &kernel_ms);
+  if (rc) return rc;
+  if (terminal) {  // the shards' samples into the caller's whole-ensemble layout [N] (+ [N] mirrored)
+    for (int g = 0; g < mg->n; ++g) {
+      const uint64_t n = cs[g].n_paths;
+      if (!n) continue;
+      HH_MHIP(mg, hipSetDevice(mg->devices[g]));
+      HH_MHIP(mg, hipMemcpyAsync(terminal + starts[g], term_dev[g], n * sizeof(double), hipMemcpyDeviceToHost,
+                                 mg->ctx[g]->stream));
+      if (cfg->antithetic)
+        HH_MHIP(mg, hipMemcpyAsync(terminal + cfg->n_paths + starts[g], term_dev[g] + n, n * sizeof(double),
+                                   hipMemcpyDeviceToHost, mg->ctx[g]->stream));
+    }
+    for (int g = 0; g < mg->n; ++g) {
+      HH_MHIP(mg, hipSetDevice(mg->devices[g]));
+      HH_MHIP(mg, hipStreamSynchronize(mg->ctx[g]->stream));
+    }
+  }
+  rc = hh_mc_finalize(m, cfg, mg->host, out);
+  if (rc) return mfail(mg, rc, "finalize failed");
+  out->kernel_ms = kernel_ms;
+  out->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  return HH_OK;
+}
+
+int hh_mgpu_solve_basket(hh_mgpu* mg, const hh_model* m, const hh_config* cfg, const double* strikes,
+                         const double* cps, uint32_t n_payoffs, hh_result* out) {
+  if (!mg) return HH_ERR_INVALID;
+  std::lock_guard<std::mutex> lock__(mg->mu);
+  if (!m || !cfg || !out || !strikes || !cps || n_payoffs == 0 || n_payoffs > 65535)
+    return mfail(mg, HH_ERR_INVALID, "hh_mgpu_solve_basket: bad arguments");
+  const auto t0 = std::chrono::steady_clock::now();
+  std::vector<hh_config> cs;
+  std::vector<double*> term_dev;
+  std::vector<uint64_t> starts;
+  int rc = cut_config(mg, cfg, false, cs, term_dev, starts);
+  if (rc) {
+    sync_all(mg);
+    return rc;
+  }
+  const Basket b{strikes, cps, n_payoffs};
+  double kernel_ms = 0.0;
+  rc = run_shards(mg, m, cs.data(), &b, nullptr, &kernel_ms);
+  if (rc) return rc;
+  const double total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  for (uint32_t k = 0; k < n_payoffs; ++k) {
+    std::memset(&out[k], 0, sizeof(hh_result));
+    rc = hh_mc_finalize(m, cfg, mg->host + (size_t)k * HH_ACC_LEN, &out[k]);
+    if (rc) return mfail(mg, rc, "finalize failed");
+    out[k].kernel_ms = kernel_ms;
+    out[k].total_ms = total;
+  }
+  return HH_OK;
+}
+
+}  // extern "C"

@@ -99,6 +99,7 @@ class MonteCarlo(AbstractPricingMethod):
     em_split: bool = True
     compat_sqrt_alpha: bool = False
     device: int = 0
+    devices: Any = None  # e.g. range(8): ONE solve sharded over these GPUs inside the library (hh_mgpu_solve)
 
 
 class MethodError(TypeError):
@@ -188,6 +189,8 @@ def solve_montecarlo(prob: PricingProblem, method: MonteCarlo, ensemble: bool = 
     numpy array [path][step][comp] (or tile-major), the noise-replay parity mode of DESIGN.md."""
     model, c, keep, P, discount = _model_and_config(prob, method)
     cfg = method.config
+    if method.devices is not None:
+        return _solve_multi_gpu(prob, method, model, c, P, discount, ensemble, replay, replay_layout)
     ctx = _ffi.get_context(method.device)
     seeds_dev = cfg.device_seeds(ctx)
     c.seeds, c.seeds_on_device = seeds_dev.ptr, 1
@@ -215,3 +218,22 @@ def solve_montecarlo(prob: PricingProblem, method: MonteCarlo, ensemble: bool = 
     del keep, seeds_dev
     return MonteCarloSolution(prob, method, _price_from(res, discount, P), None,
                               std_error=res.std_error, result=res, fetch=fetch)
+
+
+def _solve_multi_gpu(prob, method, model, c, P, discount, ensemble, replay, replay_layout):
+    """solve(prob, method) with `method.devices`: the trajectories sharded over those GPUs by ONE
+    library call from this thread (hh_mgpu_solve: contiguous ranges, one RCCL all-reduce of the
+    accumulator vector or the host's ordered sum) — still one `solve`, as montecarlo.jl:478-493."""
+    cfg = method.config
+    mg = _ffi.get_multi_gpu(tuple(method.devices))
+    c.seeds, c.seeds_len = cfg.seeds.ctypes.data, cfg.seeds.size
+    if replay is not None:
+        replay = np.ascontiguousarray(replay, dtype=np.float64)
+        c.noise_mode, c.replay_layout = _ffi.HH_NOISE_REPLAY, replay_layout
+        c.replay, c.replay_len = replay.ctypes.data, replay.size
+    n, anti = int(c.n_paths), bool(c.antithetic)
+    term = np.empty(n * (2 if anti else 1), dtype=np.float64) if ensemble else None
+    res = mg.solve(model, c, term)
+    ens = None if term is None else ((term[:n], term[n:]) if anti else term)
+    return MonteCarloSolution(prob, method, _price_from(res, discount, P), ens,
+                              std_error=res.std_error, result=res)

@@ -18,8 +18,10 @@
  *     whatever it allocates inside hh_ctx and releases it in hh_ctx_destroy().
  *   - a hh_ctx is bound to ONE device and ONE HIP stream; its entry points serialise on an
  *     internal mutex, so sharing one between threads is safe but gains nothing — use one ctx per
- *     host thread / per GPU.  Multi-GPU = one process (or thread) per GPU, each
- *     with its own ctx, exchanging only the HH_ACC_LEN-double accumulator vector (one all-reduce).
+ *     host thread / per GPU.  Multi-GPU = either ONE call on a hh_mgpu (one host thread driving
+ *     one ctx per device, the all-reduce inside the library: hh_mgpu_solve), or one process (or
+ *     thread) per GPU, each with its own ctx, exchanging only the HH_ACC_LEN-double accumulator
+ *     vector (hh_mc_accumulate + the caller's all-reduce + hh_mc_finalize).
  *   - there is NO CPU fallback in this library: without a HIP device every compute entry point
  *     fails with HH_ERR_HIP.
  */
@@ -33,7 +35,7 @@
 extern "C" {
 #endif
 
-#define HH_ABI_VERSION 2
+#define HH_ABI_VERSION 3
 #define HH_MAX_PARTIALS 8   /* max. number of dual-number partials carried through one solve    */
 #define HH_TILE_PATHS 256   /* paths per tile of the tile-major REPLAY layout (see below)        */
 #define HH_ACC_LEN 16       /* doubles in the accumulator vector exchanged between GPUs          */
@@ -53,7 +55,8 @@ enum hh_status {
   HH_ERR_INVALID = -1,     /* bad argument (NULL, sizes, ranges)                                  */
   HH_ERR_UNSUPPORTED = -2, /* combination the reference itself cannot run (e.g. BK + antithetic)  */
   HH_ERR_HIP = -3,         /* HIP runtime error, or no HIP device                                 */
-  HH_ERR_NOMEM = -4
+  HH_ERR_NOMEM = -4,
+  HH_ERR_RCCL = -5         /* RCCL missing or failed where the caller REQUIRED it (HH_MGPU_RCCL)  */
 };
 
 /* montecarlo.jl:8-22 */
@@ -203,6 +206,56 @@ int hh_mc_accumulate(hh_ctx* ctx, const hh_model* model, const hh_config* cfg, d
 /* Pure host arithmetic: accumulator vector (HOST memory) -> price, std_error, dprice. */
 int hh_mc_finalize(const hh_model* model, const hh_config* cfg, const double* accum_host,
                    hh_result* out);
+
+/*
+ * Multi-GPU solve in ONE call from ONE host thread — what solve(prob, method) (montecarlo.jl:478-493,
+ * the one EnsembleProblem of :329-333,351) becomes when the trajectories are sharded over the GPUs of
+ * a node.  A hh_mgpu owns one hh_ctx (own stream, own scratch) per listed device.
+ * hh_mgpu_solve cuts the ensemble into contiguous ranges [g·per, min(N, (g+1)·per)), per = ⌈N/G⌉
+ * (rounded up to a multiple of HH_TILE_PATHS for tile-major REPLAY data, whose tiles cannot be cut),
+ * slices seeds / increments / terminal samples by the same ranges (exact laws: path_offset), enqueues
+ * every shard's kernels back to back without waiting, and combines the HH_ACC_LEN-double accumulator
+ * vectors
+ *   HH_MGPU_REDUCE_RCCL  by ONE ncclAllReduce(ncclSum, ncclDouble) inside ncclGroupStart/End on the
+ *                        shards' own streams (communicators from ncclCommInitAll at creation; RCCL is
+ *                        bound at run time — librccl.so.1, or the path in $HEDGEHOG_MC_RCCL — so the
+ *                        library itself has no link-time dependency on it), or
+ *   HH_MGPU_REDUCE_HOST  by a deterministic ordered sum on the host, g = 0 … G−1 (also what is used
+ *                        when RCCL is absent, fails to initialise — e.g. a device listed twice — or
+ *                        fails in the call: the solve is still completed, hh_mgpu_last_error() says why).
+ * Draws depend on (seed, counter) only, so a G-device result differs from the one-device result by
+ * the order of that last sum alone (≤ 1e-13 relative); with one device there is no sum and the result
+ * is hh_mc_solve's bit for bit.
+ *   flags of hh_mgpu_create: HH_MGPU_AUTO  RCCL when n_devices > 1 and it initialises, else host sum;
+ *                            HH_MGPU_HOST_SUM  never touch RCCL;
+ *                            HH_MGPU_RCCL  RCCL or fail (HH_ERR_RCCL), used even for one device.
+ * hh_mgpu_solve takes HOST buffers in cfg (seeds, replay) and for `terminal` (n_paths doubles, then the
+ * n_paths mirrored samples when antithetic — the layout of hh_mc_solve); *_on_device must be 0.
+ * hh_mgpu_solve_shards takes one hh_config per device exactly as hh_mc_accumulate would on that device
+ * (device-resident seeds / increments allowed; n_paths = 0 leaves a device idle) and optional per-shard
+ * terminal pointers — for callers that keep their inputs in HBM.  hh_mgpu_ctx(mg, i) is the i-th
+ * device's context (hh_device_malloc, hh_wiener_fill, hh_ctx_enable_timing … on that device); it stays
+ * owned by mg.  out->kernel_ms is the LONGEST shard's HIP-event time, total_ms the host wall time.
+ */
+typedef struct hh_mgpu hh_mgpu;
+enum hh_mgpu_flags { HH_MGPU_AUTO = 0, HH_MGPU_HOST_SUM = 1, HH_MGPU_RCCL = 2 };
+enum hh_mgpu_reduce { HH_MGPU_REDUCE_HOST = 0, HH_MGPU_REDUCE_RCCL = 1 };
+int hh_mgpu_create(hh_mgpu** out, const int* device_ids, int n_devices, int flags);
+void hh_mgpu_destroy(hh_mgpu* mg);
+const char* hh_mgpu_last_error(const hh_mgpu* mg);
+int hh_mgpu_n_devices(const hh_mgpu* mg);
+int hh_mgpu_reduce_mode(const hh_mgpu* mg);       /* enum hh_mgpu_reduce in use                    */
+hh_ctx* hh_mgpu_ctx(hh_mgpu* mg, int i);          /* NULL when i is out of range                   */
+/* shard g of an ensemble of n_paths over n_devices, as hh_mgpu_solve cuts it (tile_aligned = 1 for
+ * tile-major REPLAY increments) */
+void hh_mgpu_shard_range(uint64_t n_paths, int n_devices, int g, int tile_aligned, uint64_t* start,
+                         uint64_t* stop);
+int hh_mgpu_solve(hh_mgpu* mg, const hh_model* model, const hh_config* cfg, hh_result* out,
+                  double* terminal);
+int hh_mgpu_solve_shards(hh_mgpu* mg, const hh_model* model, const hh_config* shard_cfgs /* n_devices */,
+                         hh_result* out, double* const* terminals /* nullable; n_devices, each nullable */);
+int hh_mgpu_solve_basket(hh_mgpu* mg, const hh_model* model, const hh_config* cfg, const double* strikes,
+                         const double* cps, uint32_t n_payoffs, hh_result* out /* n_payoffs */);
 
 /*
  * Several payoffs on ONE simulation — solve(::BasketPricingProblem, method) for payoffs that share
