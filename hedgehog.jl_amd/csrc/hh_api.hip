@@ -337,7 +337,21 @@ static int run_simulation(hh_ctx* ctx, const hh_model* m, const hh_config* c, do
     const uint32_t steps = (c->strategy == HH_EULER_MARUYAMA) ? c->n_steps : 1;
     const int dyn = (c->strategy == HH_EULER_MARUYAMA) ? c->dynamics : HH_LOGNORMAL;
     const size_t tile_elems = replay_elems(c->n_paths, steps, dyn);
-    if (c->replay_layout == HH_REPLAY_PATH_MAJOR) {
+    if (c->replay_layout == HH_REPLAY_PATH_MAJOR && c->strategy == HH_EULER_MARUYAMA &&
+        hh::replay_direct_path_major(steps, ncomp_of(dyn))) {
+      // the reference's layout, streamed as it stands (euler_pm_kernel): no repack pass
+      if (c->replay_on_device) {
+        p.replay = c->replay;
+      } else {
+        const size_t n = (size_t)c->n_paths * steps * ncomp_of(dyn);
+        rc = ensure(ctx, ctx->replay_src, ctx->replay_src_cap, n);
+        if (rc) return rc;
+        HH_HIP(ctx, hipMemcpyAsync(ctx->replay_src, c->replay, n * sizeof(double), hipMemcpyHostToDevice,
+                                   ctx->stream));
+        p.replay = ctx->replay_src;
+      }
+      p.replay_path_major = true;
+    } else if (c->replay_layout == HH_REPLAY_PATH_MAJOR) {
       rc = ensure(ctx, ctx->replay, ctx->replay_cap, tile_elems);
       if (rc) return rc;
       rc = hh_replay_pack(ctx, dyn, c->n_paths, steps, c->replay, c->replay_on_device, ctx->replay);

@@ -57,7 +57,12 @@ struct DevicePtrs {
   // bk_scratch keeps one BkTableKey next to it, zero-initialised
   struct BkTableKey* bk_table_key;
   int bk_term_cache;  // Broadie–Kaya: cached series terms per trajectory at most (0 = default)
+  // Euler REPLAY: `replay` is the reference's own layout dW[path][step][comp] (rows of a multiple of
+  // 16 bytes: replay_direct_path_major()) and is consumed as it stands by euler_pm_kernel
+  bool replay_path_major;
 };
+// can path-major increments of this shape be streamed without the repack pass?
+inline bool replay_direct_path_major(uint32_t n_steps, int ncomp) { return ((uint64_t)n_steps * ncomp) % 2 == 0; }
 struct BkTableKey {
   const void* where;  // address of the tables inside the scratch buffer
   double nu;          // Bessel order they were made for

@@ -631,6 +631,150 @@ __attribute__((amdgpu_waves_per_eu(REPLAY ? HH_REPLAY_MINW : 1,
 }
 
 // ------------------------------------------------------------------------------------------
+// Euler–Maruyama on the REFERENCE's noise layout: path-major REPLAY
+// ------------------------------------------------------------------------------------------
+//
+// The reference keeps the noise per trajectory (W.W of each solution, montecarlo.jl:258,370), i.e.
+// dW[path][step][comp]: a trajectory's increments are one contiguous row of S = n_steps·NCOMP·8
+// bytes.  This kernel consumes that layout directly (no repack pass): the row is cut along the
+// ABSOLUTE 128-byte lines of memory, a wave owns 64 consecutive rows and moves, per chunk, one line
+// of each of them — 8 rows x 128 B per LDS-DMA instruction (global_load_lds_dwordx4: per-lane source
+// address, wave-linear destination), 8 instructions per chunk — into its private 8 KiB LDS image
+// [row][8 pieces of 16 B], from which every lane reads its own row back with 8 ds_read_b128 and steps
+// through it.  Every line of the buffer is requested exactly once, whole and aligned, by one
+// wave-instruction (HBM traffic = algorithmic bytes; nothing relies on a cache keeping a half-used
+// line); rows that do not start on a line boundary simply run with a per-lane phase o ∈ 0..7 pieces:
+// piece j of chunk k is row piece t = 8k − o + j (Heston: step t; lognormal: steps 2t, 2t+1), outside
+// 0 ≤ t < T only in the first and the last two chunks, which run a guarded copy of the loop body.
+//
+// The LDS image is XOR-swizzled — piece j of row r sits in slot j ^ ((r >> 1) & 7) — so that the 16
+// lanes ds_read_b128 serves together (MI355X_MICROARCH.md, LDS table) cover all 64 banks; LDS-DMA
+// writes lane-linearly, so the swizzle is applied to the SOURCE address (guide rule 21).  The image is
+// private to its wave: no workgroup barrier anywhere, the only ordering needed is the wave's own
+// vmcnt(0) before it reads (microarch guide, item 7) and lgkmcnt(0) before the next chunk overwrites.
+// While the wave steps through the 32 registers of chunk k, the DMA of chunk k+1 is in flight.
+//
+// Needs S to be a multiple of 16 bytes (n_steps·NCOMP even: every Heston shape); the one remaining
+// case (lognormal, odd n_steps) goes through replay_pack_kernel + the tile-major kernel.
+#ifndef HH_PM_MAXW
+#define HH_PM_MAXW 2   // waves per SIMD of the path-major kernel: 0.622 ms at 2, 0.632-0.634 at 3, 4, 5 (profiles/r03_a_path_major_ab.txt)
+#endif
+#ifndef HH_PM_NT
+#define HH_PM_NT 1
+#endif
+constexpr int kPmPieces = 8;  // 16-byte pieces per row and chunk = one 128-byte line
+
+template <class M, int P, bool ANTI>
+__global__ __launch_bounds__(kTile)
+__attribute__((amdgpu_waves_per_eu(1, HH_PM_MAXW))) void euler_pm_kernel(const SimArgs<P> a) {
+  constexpr int NC = M::NCOMP;
+  using State = typename M::State;
+  using V2 = double __attribute__((ext_vector_type(2)));
+  __shared__ __attribute__((aligned(128))) double image[kTile / 64][64 * 2 * kPmPieces];
+
+  const uint32_t tile = blockIdx.x, tid = threadIdx.x;
+  const uint32_t wave = tid >> 6, lane = tid & 63;
+  const uint64_t path = (uint64_t)tile * kTile + tid;
+  const uint64_t last = a.n_paths - 1;
+  const int64_t T = (int64_t)a.n_steps * NC / 2;  // 16-byte pieces per row
+  const uint64_t S = (uint64_t)T * 16;             // bytes per row
+  const char* base = reinterpret_cast<const char*>(a.replay);
+
+  // rows beyond the ensemble (last tile) repeat the last trajectory: loads stay unguarded and in
+  // bounds, finish_path drops the duplicates
+  const uint64_t wave_path0 = (uint64_t)tile * kTile + (uint64_t)wave * 64;
+  auto row_of = [&](uint32_t r) {
+    const uint64_t pth = wave_path0 + r;
+    return base + (pth < last ? pth : last) * S;
+  };
+
+  // ---- loader role: instruction i moves rows 8i + (lane >> 3), this lane the piece in slot lane & 7
+  const char* src[kPmPieces];   // source of the CURRENT chunk's piece (advanced by one line per chunk)
+  const char* row_r[kPmPieces]; // the row's first byte: where invalid pieces are pointed (any valid address)
+  int tb[kPmPieces];            // row piece index of that slot in chunk 0
+#pragma unroll
+  for (int i = 0; i < kPmPieces; ++i) {
+    const uint32_t r = 8u * i + (lane >> 3);
+    const char* row = row_of(r);
+    const uint32_t o_r = ((uint32_t)(uintptr_t)row & 127u) >> 4;
+    const uint32_t jg = (lane & 7u) ^ ((r >> 1) & 7u);  // swizzle on the source side
+    row_r[i] = row;
+    tb[i] = (int)jg - (int)o_r;
+    src[i] = row - ((uintptr_t)row & 127u) + jg * 16u;
+  }
+  // ---- consumer role: this lane's own row
+  const char* my_row = row_of(lane);
+  const int o = (int)(((uint32_t)(uintptr_t)my_row & 127u) >> 4);
+  const uint32_t sw = (lane >> 1) & 7u;
+  const char* my_img = reinterpret_cast<const char*>(&image[wave][0]) + lane * 128u;
+
+  const int64_t n_chunks = (T + 2 * kPmPieces - 1) / kPmPieces;  // covers every phase o <= 7
+  // chunks whose 15 possible row pieces 8k-7 .. 8k+7 are all inside the row: no guards
+  const int64_t k_full_end = T >= 2 * kPmPieces ? (T - kPmPieces) / kPmPieces : 0;  // full: 1 <= k <= k_full_end
+
+  auto issue = [&](int64_t k, bool guarded) {
+#pragma unroll
+    for (int i = 0; i < kPmPieces; ++i) {
+      const char* g = src[i];
+      if (guarded) {
+        const int64_t t = 8 * k + tb[i];
+        if (t < 0 || t >= T) g = row_r[i];
+      }
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                       (__attribute__((address_space(3))) void*)&image[wave][i * 128],
+                                       16, 0, HH_PM_NT ? 2 : 0);
+      src[i] += 128;
+    }
+  };
+
+  State st, sa;
+  M::init(st, a);
+  if constexpr (ANTI) M::init(sa, a);
+
+  auto advance = [&](const V2& d) {
+    if constexpr (NC == 2) {
+      M::step(st, a, d.x, d.y);
+      if constexpr (ANTI) M::step(sa, a, -d.x, -d.y);  // montecarlo.jl:258: -W
+    } else {
+      M::step(st, a, d.x, 0.0);
+      if constexpr (ANTI) M::step(sa, a, -d.x, 0.0);
+      M::step(st, a, d.y, 0.0);
+      if constexpr (ANTI) M::step(sa, a, -d.y, 0.0);
+    }
+  };
+
+  if (n_chunks > 0) issue(0, true);
+  for (int64_t k = 0; k < n_chunks; ++k) {
+    // the compiler orders LDS reads behind every outstanding LDS-DMA (s_waitcnt vmcnt(0))
+    V2 d[kPmPieces];
+#pragma unroll
+    for (int j = 0; j < kPmPieces; ++j)
+      d[j] = *reinterpret_cast<const V2*>(my_img + (((uint32_t)j ^ sw) << 4));
+    // WAR: the next chunk's DMA overwrites the image — not before these reads have returned
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    const bool full = k >= 1 && k <= k_full_end;
+    if (k + 1 < n_chunks) issue(k + 1, !(k + 1 >= 1 && k + 1 <= k_full_end));
+    if (full) {
+#pragma unroll
+      for (int j = 0; j < kPmPieces; ++j) advance(d[j]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < kPmPieces; ++j) {
+        const int64_t t = 8 * k - o + j;
+        if (t >= 0 && t < T) advance(d[j]);
+      }
+    }
+  }
+
+  double acc[4 + P];
+#pragma unroll
+  for (int i = 0; i < 4 + P; ++i) acc[i] = 0.0;
+  finish_path<P, ANTI>(st, sa, a, path, acc);
+  block_reduce_store<4 + P, kTile / 64, 2>(acc, a.records + (size_t)tile * kRecStride);
+}
+
+// ------------------------------------------------------------------------------------------
 // exact lognormal law (montecarlo.jl:293-303, 384-390, 412-414, 454-459)
 // ------------------------------------------------------------------------------------------
 
@@ -949,7 +1093,16 @@ static int launch_euler_t(const SimArgs<P>& a, hipStream_t s) {
 }
 
 template <class M, int P>
-static int launch_euler_m(const SimArgs<P>& a, bool replay, bool anti, hipStream_t s) {
+static int launch_euler_pm(const SimArgs<P>& a, bool anti, hipStream_t s) {
+  const dim3 g(a.n_tiles), b(kTile);
+  if (anti) hipLaunchKernelGGL((euler_pm_kernel<M, P, true>), g, b, 0, s, a);
+  else hipLaunchKernelGGL((euler_pm_kernel<M, P, false>), g, b, 0, s, a);
+  return (int)hipGetLastError();
+}
+
+template <class M, int P>
+static int launch_euler_m(const SimArgs<P>& a, bool replay, bool anti, hipStream_t s, bool path_major = false) {
+  if (replay && path_major) return launch_euler_pm<M, P>(a, anti, s);
   if (replay) return anti ? launch_euler_t<M, P, true, true>(a, s) : launch_euler_t<M, P, true, false>(a, s);
   return anti ? launch_euler_t<M, P, false, true>(a, s) : launch_euler_t<M, P, false, false>(a, s);
 }
@@ -971,9 +1124,10 @@ static int launch_sim_p(const hh_model& m, const hh_config& c, const DevicePtrs&
     }
     return (int)hipGetLastError();
   }
-  if (c.dynamics == HH_LOGNORMAL) return launch_euler_m<GbmModel<P>, P>(a, replay, anti, s);
-  if (c.em_split) return launch_euler_m<HestonModel<P, true>, P>(a, replay, anti, s);
-  return launch_euler_m<HestonModel<P, false>, P>(a, replay, anti, s);
+  const bool direct = replay && p.replay_path_major;
+  if (c.dynamics == HH_LOGNORMAL) return launch_euler_m<GbmModel<P>, P>(a, replay, anti, s, direct);
+  if (c.em_split) return launch_euler_m<HestonModel<P, true>, P>(a, replay, anti, s, direct);
+  return launch_euler_m<HestonModel<P, false>, P>(a, replay, anti, s, direct);
 }
 
 int launch_simulation(const hh_model& m, const hh_config& c, const DevicePtrs& p, hipStream_t s) {

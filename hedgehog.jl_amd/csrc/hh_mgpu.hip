@@ -242,6 +242,10 @@ int hh_mgpu_create(hh_mgpu** out, const int* device_ids, int n_devices, int flag
   *out = nullptr;
   if (!device_ids || n_devices < 1 || n_devices > 64) return HH_ERR_INVALID;
   if (flags != HH_MGPU_AUTO && flags != HH_MGPU_HOST_SUM && flags != HH_MGPU_RCCL) return HH_ERR_INVALID;
+  int n_hip = 0;
+  if (hipGetDeviceCount(&n_hip) != hipSuccess || n_hip <= 0) return HH_ERR_HIP;  // no CPU fallback
+  for (int g = 0; g < n_devices; ++g)
+    if (device_ids[g] < 0 || device_ids[g] >= n_hip) return HH_ERR_INVALID;
   hh_mgpu* mg = new (std::nothrow) hh_mgpu();
   if (!mg) return HH_ERR_NOMEM;
   mg->n = n_devices;
@@ -294,6 +298,7 @@ void hh_mgpu_destroy(hh_mgpu* mg) {
   for (rccl_comm_t c : mg->comms)
     if (c) (void)rccl().CommDestroy(c);
   for (int g = 0; g < mg->n; ++g) {
+    if (!mg->ctx[g]) continue;  // creation stopped before this device: nothing of it exists
     (void)hipSetDevice(mg->devices[g]);
     if (mg->acc[g]) (void)hipFree(mg->acc[g]);
     if (mg->red[g]) (void)hipFree(mg->red[g]);

@@ -197,6 +197,78 @@ def test_path_major_replay_equals_tile_major(hhlib, oracle):
     np.testing.assert_allclose(t1, to, rtol=1e-12)
 
 
+def _path_major(oracle, dyn, n_paths, n_steps, seeds, rho=-0.7, T=1.0):
+    """the oracle's increments in the reference's own layout dW[path][step][comp] + the tile-major form"""
+    nc = 2 if dyn == HES else 1
+    tiled = oracle.wiener_fill(dyn, rho, T, n_steps, seeds)
+    pm = tiled.reshape(-1, n_steps, nc, 256).transpose(0, 3, 1, 2).reshape(-1, n_steps, nc)[:n_paths]
+    return np.ascontiguousarray(pm), tiled
+
+
+@pytest.mark.parametrize("dyn", [GBM, HES])
+@pytest.mark.parametrize("n_paths", [1, 63, 64, 65, 255, 256, 257, 1000, 4099])
+@pytest.mark.parametrize("n_steps", [1, 2, 3, 7, 8, 9, 15, 16, 17, 31, 100, 252])
+def test_path_major_replay_ragged(hhlib, oracle, dyn, n_paths, n_steps):
+    """The reference's noise layout streamed as it stands (euler_pm_kernel): rows of every length —
+    shorter than one 128-byte line, not a multiple of it, starting at every phase of a line — and the
+    lognormal rows of an odd number of steps, which still take the repack route.  Same samples and
+    sums as the tile-major kernel, bit for bit; oracle parity at the REPLAY bar."""
+    seeds = seeds_for(n_paths, 21)
+    m = o.make_model(sigma=0.2 if dyn == GBM else 0.3)
+    pm, tiled = _path_major(oracle, dyn, n_paths, n_steps, seeds, m.rho, m.T)
+    c1 = o.make_config(dyn, EM, n_paths, n_steps, noise_mode=REP, replay=pm,
+                       replay_layout=_ffi.HH_REPLAY_PATH_MAJOR)
+    c2 = o.make_config(dyn, EM, n_paths, n_steps, noise_mode=REP, replay=tiled)
+    r1, t1 = gpu_solve(hhlib, m, c1)
+    r2, t2 = gpu_solve(hhlib, m, c2)
+    np.testing.assert_array_equal(t1, t2)
+    assert (r1.price, r1.sum_payoff, r1.sumsq_payoff) == (r2.price, r2.sum_payoff, r2.sumsq_payoff)
+    ro, to, _ = oracle.mc_solve(m, c2)
+    check(r1, t1, ro, to, 0, 1e-12, 1e-12)
+
+
+@pytest.mark.parametrize("dyn,split", [(GBM, 1), (HES, 1), (HES, 0)])
+@pytest.mark.parametrize("anti", [0, 1])
+@pytest.mark.parametrize("duals", [0, 1, 3])
+def test_path_major_replay_variants(hhlib, oracle, dyn, split, anti, duals):
+    n_paths, n_steps = 1500, 38
+    seeds = seeds_for(n_paths, 22)
+    sd = {0: None, 1: {"V0": [1.0]} if dyn == HES else {"sigma": [1.0]},
+          3: HESTON_SEEDS if dyn == HES else {"S0": [1, 0, 0], "sigma": [0, 1, 0], "r_drift": [0, 0, 1],
+                                              "discount": [0, 0, -float(np.exp(-0.03))]}}[duals]
+    m = o.make_model(sigma=0.2 if dyn == GBM else 0.3, seeds=sd, n_partials=duals)
+    pm, tiled = _path_major(oracle, dyn, n_paths, n_steps, seeds, m.rho, m.T)
+    kw = dict(antithetic=anti, em_split=split, noise_mode=REP, n_partials=duals)
+    c1 = o.make_config(dyn, EM, n_paths, n_steps, replay=pm, replay_layout=_ffi.HH_REPLAY_PATH_MAJOR, **kw)
+    c2 = o.make_config(dyn, EM, n_paths, n_steps, replay=tiled, **kw)
+    r1, t1 = gpu_solve(hhlib, m, c1)
+    r2, t2 = gpu_solve(hhlib, m, c2)
+    np.testing.assert_array_equal(t1, t2)
+    assert r1.price == r2.price and [r1.dprice[k] for k in range(duals)] == [r2.dprice[k] for k in range(duals)]
+    ro, to, _ = oracle.mc_solve(m, c2)
+    check(r1, t1, ro, to, duals, 1e-12, 1e-12)
+
+
+@pytest.mark.parametrize("shift", [1, 2, 3, 5, 7])
+def test_path_major_replay_from_any_16_byte_boundary(hhlib, oracle, shift):
+    """Device-resident rows that start `shift` pieces into a 128-byte line (a slice of a larger
+    buffer): the loader clamps what lies before the first and behind the last row."""
+    import torch
+    n_paths, n_steps = 777, 45
+    seeds = seeds_for(n_paths, 23)
+    m = o.make_model()
+    pm, tiled = _path_major(oracle, HES, n_paths, n_steps, seeds, m.rho, m.T)
+    buf = torch.full((pm.size + 2 * shift + 64,), float("nan"), dtype=torch.float64, device="cuda")
+    buf[2 * shift:2 * shift + pm.size] = torch.from_numpy(pm.ravel()).cuda()
+    c1 = o.make_config(HES, EM, n_paths, n_steps, noise_mode=REP, replay_layout=_ffi.HH_REPLAY_PATH_MAJOR)
+    c1.replay, c1.replay_on_device, c1.replay_len = buf.data_ptr() + 16 * shift, 1, pm.size
+    c2 = o.make_config(HES, EM, n_paths, n_steps, noise_mode=REP, replay=tiled)
+    r1, t1 = gpu_solve(hhlib, m, c1)
+    r2, t2 = gpu_solve(hhlib, m, c2)
+    np.testing.assert_array_equal(t1, t2)
+    assert r1.price == r2.price
+
+
 def test_device_resident_inputs(hhlib, oracle):
     """seeds / replay / terminal living in HBM (the bench configuration)."""
     import torch

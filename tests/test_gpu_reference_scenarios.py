@@ -269,6 +269,46 @@ def test_config3_full_size_properties():
     assert ES == pytest.approx(100 * np.exp(0.03), rel=1e-3)  # martingale check
 
 
+def test_config3_full_size_path_major_noise():
+    """BASELINE config 3 at full size on the REFERENCE's noise layout dW[path][step][comp]
+    (montecarlo.jl:258,370), streamed as it stands: the same price, sums and samples as the tile-major
+    stream of the same increments, bit for bit, and GENERATE's price to rounding."""
+    import ctypes as C
+
+    import torch
+
+    from hedgehog_jl_amd import _ffi
+    from tests import oracle_ffi as o
+    ctx = hh.get_context(0)
+    lib, h = ctx.lib, ctx.handle
+    n, steps = 1_000_000, 252
+    seeds = torch.arange(1, n + 1, dtype=torch.int64, device="cuda")
+    m = o.make_model()
+    n_tile = lib.hh_replay_elems(n, steps, 1)
+    dW = torch.empty(n_tile, dtype=torch.float64, device="cuda")
+    ctx.check(lib.hh_wiener_fill(h, 1, m.rho, m.T, steps, n, seeds.data_ptr(), 1, dW.data_ptr()))
+    ctx.synchronize()
+    pm = dW.view(-1, steps, 2, 256).permute(0, 3, 1, 2).reshape(-1, steps, 2)[:n].contiguous()
+    torch.cuda.synchronize()
+    t1 = torch.empty(n, dtype=torch.float64, device="cuda")
+    t2 = torch.empty(n, dtype=torch.float64, device="cuda")
+
+    def run(replay, layout, term, noise=1):
+        c = o.make_config(1, 0, n, steps, noise_mode=noise, replay_layout=layout)
+        c.seeds, c.seeds_on_device = seeds.data_ptr(), 1
+        c.replay, c.replay_on_device, c.terminal_on_device = replay.data_ptr(), 1, 1
+        r = _ffi.hh_result()
+        ctx.check(lib.hh_mc_solve(h, C.byref(m), C.byref(c), C.byref(r), term.data_ptr()))
+        return r
+
+    a = run(pm, _ffi.HH_REPLAY_PATH_MAJOR, t1)
+    b = run(dW, _ffi.HH_REPLAY_TILE_MAJOR, t2)
+    assert (a.price, a.sum_payoff, a.sumsq_payoff) == (b.price, b.sum_payoff, b.sumsq_payoff)
+    assert torch.equal(t1, t2)
+    g = run(dW, 0, t2, noise=0)
+    assert a.price == pytest.approx(g.price, rel=1e-13)
+
+
 def test_solve_sharded_hip_path_world1():
     """The sharded driver on the HIP path (device-resident accumulators, no process group) agrees
     with plain solve()."""
