@@ -18,7 +18,17 @@ all-reduces the 16-double accumulator vector over RCCL — the path's only excha
   --global-paths G   strong scaling: G trajectories split over the ranks by contiguous ranges
                      (hedgehog_jl_amd.shard_range), e.g. north_star's 10^7
 
+`--single-process` runs the same steps from ONE process and ONE host thread over all N devices
+through the library's own multi-GPU entry point (hh_mgpu_solve_shards: per-device contexts and
+streams, one ncclAllReduce of the accumulator vector inside the library, host ordered sum when RCCL
+is absent) — the form a Julia host calls.  The default line embeds that form's result as
+`single_process` (rank 0 starts it as a child process once every rank has left the process group).
+
 Rank 0 prints ONE JSON line.  Besides the contract's keys it carries
+  value_cold      the same K steps after W warm-ups with NO clock ramp before them (value has the ramp)
+  value_default_mode  = generate.value: what solve() delivers by default (in-kernel Philox)
+  path_major_replay   REPLAY on the reference's own noise layout dW[path][step][comp], streamed
+                  directly by euler_pm_kernel, with its own HBM roofline entry (N = 1 only)
   roofline        dominant kernel (euler_kernel REPLAY): algorithmic bytes / HIP-event time vs 8 TB/s
   cpu_baseline    the CPU oracle (oracle/hh_oracle.c, a port) timed on this host on a bounded sample
   generate        the same workload with the increments drawn in-kernel from Philox — what a caller
@@ -81,6 +91,11 @@ def parse(argv=None):
                          "timed region runs at the clock a pricing service sees in steady state "
                          "(the first ~15 ms of a fresh process run 3-8 %% slower); reported as "
                          "clock_ramp_ms, 0 disables")
+    ap.add_argument("--single-process", action="store_true",
+                    help="ONE process, ONE host thread drives all --gpus devices through the library's "
+                         "hh_mgpu_solve_shards (RCCL all-reduce inside the library, host ordered sum when "
+                         "RCCL is unavailable) instead of one rank per GPU")
+    ap.add_argument("--mgpu-flags", type=int, default=0, help="hh_mgpu_create flags: 0 auto, 1 host sum, 2 RCCL")
     # rehearsal knobs (tests): ranks on one GPU need gloo (RCCL refuses two ranks per device)
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl")
     ap.add_argument("--devices", default="", help="comma list: device ordinal of each local rank")
@@ -287,8 +302,120 @@ def valu_roofline(kernel, key, units, ms, table):
             "insts_source": "profiles/valu_insts.json (" + ent.get("source", "rocprofv3 --pmc") + ")"}
 
 
+def single_process(args):
+    """ONE process, ONE host thread, N devices: every step is one hh_mgpu_solve_shards call."""
+    devs = _device_list(args)
+    if not torch.cuda.is_available() or torch.cuda.device_count() <= max(devs):
+        print(f"bench.py: --single-process needs device ordinals {devs}; there is no CPU fallback",
+              file=sys.stderr)
+        return 2
+    from hedgehog_jl_amd import _ffi
+    with _StdoutToStderr():  # RCCL's banner
+        mg = _ffi.MultiGpu(devs, args.mgpu_flags)
+    n_steps, G = args.nsteps, len(devs)
+    model = _ffi.make_model(**H252)
+    strong = args.global_paths > 0
+    n_global = args.global_paths if strong else G * args.paths
+    cfgs, keep = [], []
+    for g in range(G):
+        a, b = mg.shard_range(n_global, g, tile_aligned=True) if strong else (g * args.paths, (g + 1) * args.paths)
+        ctx = mg.ctx(g)
+        n = b - a
+        seeds = np.arange(a + 1, b + 1, dtype=np.uint64)
+        dW = _ffi.DeviceBuffer(ctx, 8 * ctx.lib.hh_replay_elems(n, n_steps, _ffi.HH_HESTON))
+        ctx.check(ctx.lib.hh_wiener_fill(ctx.handle, _ffi.HH_HESTON, model.rho, model.T, n_steps, n,
+                                         seeds.ctypes.data, 0, dW.ptr))
+        ctx.synchronize()
+        c = _ffi.make_config(_ffi.HH_HESTON, _ffi.HH_EULER_MARUYAMA, n, n_steps, noise_mode=_ffi.HH_NOISE_REPLAY)
+        c.replay, c.replay_on_device = dW.ptr, 1
+        cfgs.append(c)
+        keep.append(dW)
+
+    def steps(k):
+        r = None
+        for _ in range(k):
+            r = mg.solve_shards(model, cfgs)
+        return r
+
+    def timed(k, w, ramp_ms):
+        ramp = 0.0
+        if ramp_ms > 0.0:
+            t0 = time.perf_counter()
+            while (time.perf_counter() - t0) * 1e3 < ramp_ms:
+                steps(4)
+            ramp = (time.perf_counter() - t0) * 1e3
+        steps(w)
+        mg.ctx(0).enable_timing(True)
+        for g in range(G):
+            mg.ctx(g).synchronize()
+        t0 = time.perf_counter()
+        r = steps(k)            # every call returns with all devices synchronised
+        dt = time.perf_counter() - t0
+        kern = mg.ctx(0).read_timings()
+        mg.ctx(0).enable_timing(False)
+        return dt, kern, r, ramp
+
+    dt_c, _, _, _ = timed(args.steps, args.warmup, 0.0)
+    dt, kern, res, ramp = timed(args.steps, args.warmup, args.ramp_ms)
+    tot = float(n_global) * n_steps
+    n0 = int(cfgs[0].n_paths)
+    out = {
+        "metric": "MC path-steps/sec (Heston Euler-Maruyama, 1e6 paths x 252 steps per GPU)",
+        "value": tot * args.steps / dt, "value_cold": tot * args.steps / dt_c, "unit": "path-steps/s",
+        "n_gpus": G, "single_process": True,
+        "reduce": "rccl" if mg.reduce_mode == _ffi.HH_MGPU_REDUCE_RCCL else "host ordered sum",
+        "rccl_ranks": G if mg.reduce_mode == _ffi.HH_MGPU_REDUCE_RCCL else 0,
+        "reduce_note": mg.last_error(),
+        "steps": args.steps, "warmup": args.warmup, "clock_ramp_ms": ramp,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f64",
+        "data": "synthetic (Philox-generated correlated Wiener increments, resident in each GPU's HBM)",
+        "config": {"workload": "HestonDynamics EulerMaruyama European call H252 (configs[2]): %d paths x %d "
+                               "steps %s, NoVarianceReduction, noise REPLAY in the library's tile-major "
+                               "layout (hh_wiener_fill)" % (n_global if strong else args.paths, n_steps,
+                                                            "in all" if strong else "per GPU"),
+                   "paths_per_gpu": n0, "n_steps": n_steps, "global_paths": n_global,
+                   "parallelism": "one process, one host thread, hh_mgpu_solve_shards over %d devices, one "
+                                  "16-double all-reduce inside the library" % G},
+        "price": res.price, "std_error": res.std_error, "analytic_carr_madan": H252_ANALYTIC,
+        "roofline": dict(hbm_roofline("euler_kernel<HestonModel,REPLAY> (device %d's launches)" % devs[0],
+                                      BYTES_PER_PATH_STEP * n0 * n_steps, float(np.mean(kern))),
+                         traffic=None, launches_timed=len(kern)),
+    }
+    print(json.dumps(out), flush=True)
+    mg.close()
+    return 0
+
+
+def run_single_process_child(args, world, timeout=420):
+    """The one-process form of the same run, as a child process (it owns its devices' contexts and its
+    RCCL communicators; a hang or failure there costs this block, not the line)."""
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(world), "--single-process",
+           "--steps", str(args.steps), "--warmup", str(args.warmup), "--paths", str(args.paths),
+           "--nsteps", str(args.nsteps), "--ramp-ms", str(args.ramp_ms)]
+    if args.devices:
+        cmd += ["--devices", args.devices]
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "HH_BENCH_CHILD",
+                        "GROUP_RANK", "ROLE_RANK", "LOCAL_WORLD_SIZE", "TORCHELASTIC_RUN_ID")}
+    try:
+        p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+        for line in reversed(p.stdout.splitlines()):
+            if line.startswith("{"):
+                j = json.loads(line)
+                return {k: j[k] for k in ("value", "value_cold", "unit", "n_gpus", "reduce", "reduce_note",
+                                          "ms_per_step", "price", "steps", "warmup", "roofline")}
+        return {"error": "no JSON line", "rc": p.returncode, "stderr_tail": p.stderr[-400:]}
+    except subprocess.TimeoutExpired:
+        return {"error": "timed out after %d s" % timeout}
+    except Exception as e:  # noqa: BLE001
+        return {"error": repr(e)}
+
+
 def main():
     args = parse()
+    if args.single_process:
+        sys.exit(single_process(args))
     if args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(launch(args))
     d = Dist(args)
@@ -411,6 +538,7 @@ def main():
     n_paths = sh.n
     cfg_rep, cfg_gen = sh.config(_ffi.HH_NOISE_REPLAY), sh.config(_ffi.HH_NOISE_GENERATE)
 
+    dt_cold, _, _, _ = timed(model, cfg_rep, args.steps, args.warmup, 0.0)  # no ramp: first GPU work after the fill
     dt_rep, kern_rep, acc_rep, ramp_ms = timed(model, cfg_rep, args.steps, args.warmup, args.ramp_ms)
     dt_gen, kern_gen, acc_gen, _ = timed(model, cfg_gen, args.steps, args.warmup, args.ramp_ms)
     res, res_gen = finalize(model, cfg_rep, acc_rep), finalize(model, cfg_gen, acc_gen)
@@ -433,6 +561,8 @@ def main():
     out = {
         "metric": "MC path-steps/sec (Heston Euler-Maruyama, 1e6 paths x 252 steps per GPU)",
         "value": value,
+        "value_cold": total_path_steps * args.steps / dt_cold,
+        "value_default_mode": total_path_steps * args.steps / dt_gen,
         "unit": "path-steps/s",
         "n_gpus": world,
         "rccl_ranks": rccl_ranks,
@@ -447,8 +577,10 @@ def main():
         "data": "synthetic (Philox-generated correlated Wiener increments, resident in HBM)",
         "config": {"workload": "HestonDynamics EulerMaruyama European call H252 "
                                "(configs[2]): %d paths x %d steps %s, NoVarianceReduction, "
-                               "noise REPLAY" % (n_paths if not strong else n_global, n_steps,
-                                                 "in all" if strong else "per GPU"),
+                               "noise REPLAY in the library's tile-major layout dW[tile][step][comp][256] "
+                               "(hh_wiener_fill); the reference's own layout dW[path][step][comp] is the "
+                               "path_major_replay block" % (n_paths if not strong else n_global, n_steps,
+                                                            "in all" if strong else "per GPU"),
                    "paths_per_gpu": n_paths, "n_steps": n_steps, "global_paths": n_global,
                    "backend": "rccl" if args.backend == "nccl" else args.backend,
                    "parallelism": "path-sharded x%d, one 16-double all-reduce" % world},
@@ -463,7 +595,7 @@ def main():
         "generate": {
             "value": total_path_steps * args.steps / dt_gen, "unit": "path-steps/s",
             "what": "the same workload with in-kernel Philox — the mode hh.solve() / the Julia "
-                    "solve_hip() use by default; REPLAY needs the caller's increments",
+                    "solve_hip() use by default (= value_default_mode); REPLAY needs the caller's increments",
             "ms_per_step": dt_gen / args.steps * 1e3,
             "price": res_gen.price,
             "rel_diff_vs_replay": abs(res_gen.price - res.price) / abs(res.price),
@@ -520,6 +652,11 @@ def main():
     if rank != 0:
         return
 
+    if not args.no_extra:
+        if world > 1:
+            time.sleep(2.0)  # the other ranks are leaving their GPUs
+        out["single_process"] = run_single_process_child(args, world)
+
     accum = accums[0]
     if world == 1 and not args.no_extra:
         def kernel_ms(mdl, cfg, reps=10, warm_ms=15.0):
@@ -565,6 +702,30 @@ def main():
                 "roofline": hbm_roofline("euler_kernel<HestonModel,REPLAY,ANTI>",
                                          BYTES_PER_PATH_STEP * n_paths * n_steps, ta)},
         }
+
+        # REPLAY on the reference's own noise layout (montecarlo.jl:258,370: W.W per trajectory):
+        # dW[path][step][comp], consumed as it stands by euler_pm_kernel — no repack pass
+        pm = sh.dW.view(-1, n_steps, 2, _ffi.HH_TILE_PATHS).permute(0, 3, 1, 2).reshape(-1, n_steps, 2)[:n_paths].contiguous()
+        torch.cuda.synchronize(dev)
+        cp = sh.config(_ffi.HH_NOISE_REPLAY)
+        cp.replay, cp.replay_len, cp.replay_layout = pm.data_ptr(), pm.numel(), _ffi.HH_REPLAY_PATH_MAJOR
+        tp, rp = kernel_ms(model, cp, reps=40)
+        pm_traffic = None
+        try:
+            pm_traffic = json.load(open(tpath)).get("path_major_hbm_bytes_per_launch")
+        except Exception:
+            pass
+        out["path_major_replay"] = {
+            "what": "the same increments in the reference's layout dW[path][step][comp], device-resident, "
+                    "streamed directly (128-byte lines by LDS-DMA into a swizzled wave-private LDS image)",
+            "value": float(n_paths) * n_steps / (tp * 1e-3), "unit": "path-steps/s", "kernel_ms": tp,
+            "price": rp.price, "same_price_as_tile_major": rp.price == res.price,
+            "roofline": dict(hbm_roofline("euler_pm_kernel<HestonModel>", BYTES_PER_PATH_STEP * n_paths * n_steps, tp),
+                             traffic=pm_traffic,
+                             traffic_source="profiles/pmc_traffic.json (rocprofv3 --pmc, separate passes)"
+                             if pm_traffic else None)}
+        del pm, cp
+        torch.cuda.empty_cache()
 
         # the rows widened beyond the headline path: one timing each, same C-ABI
         import math

@@ -11,7 +11,8 @@
 #     G   = Hedgehog.solve(BatchGreekProblem(prob, lenses), ForwardAD(), mc)    # ONE fused pass
 #
 # What is bound (include/hedgehog_mc.h, HH_ABI_VERSION 3): hh_mc_solve (solve_hip, with the REPLAY
-# keywords), hh_mc_accumulate + hh_mc_finalize (solve_sharded_hip), hh_mc_solve_basket, hh_carr_madan,
+# keywords), hh_mgpu_create / hh_mgpu_solve (solve_hip(...; devices = 0:7): several GPUs behind the one
+# call), hh_mc_accumulate + hh_mc_finalize (solve_sharded_hip: one process per GPU), hh_mc_solve_basket, hh_carr_madan,
 # hh_carr_madan_basket (+ _grad), hh_ctx_set_option, hh_lsm_solve, hh_heston_exact_grid, hh_replay_elems, the device-memory helpers.  The struct mirrors
 # below are checked field by field against the C header by tests/test_julia_layout.py (offsets from
 # a compiled offsetof dump), so a drift between the two shows up on the CPU, without Julia.
@@ -91,6 +92,34 @@ function set_option!(ctx::Context, option::Integer, value::Integer)
     return nothing
 end
 
+# ---- several GPUs behind ONE call (hh_mgpu_*: include/hedgehog_mc.h) -------------------------------
+# One hh_mgpu = one hh_ctx per listed device, driven from the calling Julia thread; the library shards
+# the trajectories, launches every device's kernels back to back and combines the HH_ACC_LEN-double
+# accumulator vectors by one ncclAllReduce (RCCL bound at run time) — or by an ordered sum on the host
+# when RCCL is missing or refuses.  No MPI, no extra Julia processes: `solve(prob, method)` stays ONE call.
+const HH_MGPU_AUTO, HH_MGPU_HOST_SUM, HH_MGPU_RCCL = Cint(0), Cint(1), Cint(2)
+mutable struct MultiGpu
+    handle::Ptr{Cvoid}
+    devices::Vector{Cint}
+end
+
+function MultiGpu(devices; flags::Integer = HH_MGPU_AUTO)
+    devs = collect(Cint, devices)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    rc = ccall((:hh_mgpu_create, LIB[]), Cint, (Ref{Ptr{Cvoid}}, Ptr{Cint}, Cint, Cint),
+               h, devs, length(devs), flags)
+    rc == 0 || error("hh_mgpu_create($(devs)) failed ($rc): no HIP device, a bad ordinal, or RCCL required but unavailable")
+    mg = MultiGpu(h[], devs)
+    finalizer(m -> ccall((:hh_mgpu_destroy, LIB[]), Cvoid, (Ptr{Cvoid},), m.handle), mg)
+    return mg
+end
+
+const MGPUS = Dict{Vector{Cint},MultiGpu}()
+multi_gpu(devices) = get!(() -> MultiGpu(devices), MGPUS, collect(Cint, devices))
+last_error(mg::MultiGpu) = unsafe_string(ccall((:hh_mgpu_last_error, LIB[]), Cstring, (Ptr{Cvoid},), mg.handle))
+"`:rccl` or `:host` — how this context combines the shards' accumulator vectors"
+reduce_mode(mg::MultiGpu) = ccall((:hh_mgpu_reduce_mode, LIB[]), Cint, (Ptr{Cvoid},), mg.handle) == 1 ? :rccl : :host
+
 # ---- dual-number plumbing (greeks_problem.jl:258-260) ------------------------------------------
 _val(x) = ForwardDiff.value(x)
 _npartials(x) = x isa ForwardDiff.Dual ? ForwardDiff.npartials(x) : 0
@@ -162,24 +191,33 @@ _price(r, res::HHResult) = r.DT === nothing ? res.price :
     r.DT(res.price, ForwardDiff.Partials(ntuple(k -> res.dprice[k], r.P)))   # same tag as the input Dual
 
 # ---- solve(prob, ::MonteCarlo) on the GPU (montecarlo.jl:478-493) -------------------------------
+# `devices = 0:7` shards the SAME solve over those GPUs inside the library (hh_mgpu_solve: contiguous
+# trajectory ranges, one RCCL all-reduce of the accumulator vector or the host's ordered sum) — still
+# one call from one Julia thread, the result differing from the one-GPU one by the order of the final
+# sum only (<= 1e-13 relative); `devices = nothing` (default) is the one-GPU hh_mc_solve.
 function solve_hip(prob::PricingProblem{VanillaOption{TS,TE,European,C,Spot},I},
                    method::MonteCarlo; ensemble::Bool = true,
                    em_split::Bool = true, compat_sqrt_alpha::Bool = false,
                    replay::Union{Nothing,AbstractArray{Float64}} = nothing,
-                   replay_layout::Int32 = HH_REPLAY_PATH_MAJOR) where {TS,TE,C,I}
+                   replay_layout::Int32 = HH_REPLAY_PATH_MAJOR,
+                   devices = nothing) where {TS,TE,C,I}
     r = _resolve(prob.payoff, prob.market_inputs, method)
     r === nothing && throw(MethodError(Hedgehog.solve, (prob, method)))
     terminal = ensemble ? Vector{Float64}(undef, r.anti ? 2r.n : r.n) : Float64[]
     res = Ref{HHResult}()
-    ctx = context()
+    ctx = devices === nothing ? context() : multi_gpu(devices)
     seedvecs, seeds = r.seedvecs, r.seeds
     rep = replay === nothing ? nothing : collect(Float64, vec(replay))   # noise replay (montecarlo.jl:258,370)
     GC.@preserve seedvecs seeds terminal rep begin
         model, config = _structs(r; em_split, compat_sqrt_alpha, replay = rep, replay_layout)
-        rc = ccall((:hh_mc_solve, LIB[]), Cint,
-                   (Ptr{Cvoid}, Ref{HHModel}, Ref{HHConfig}, Ref{HHResult}, Ptr{Cdouble}),
-                   ctx.handle, model, config, res,
-                   ensemble ? pointer(terminal) : Ptr{Cdouble}(C_NULL))
+        term = ensemble ? pointer(terminal) : Ptr{Cdouble}(C_NULL)
+        rc = devices === nothing ?
+            ccall((:hh_mc_solve, LIB[]), Cint,
+                  (Ptr{Cvoid}, Ref{HHModel}, Ref{HHConfig}, Ref{HHResult}, Ptr{Cdouble}),
+                  ctx.handle, model, config, res, term) :
+            ccall((:hh_mgpu_solve, LIB[]), Cint,
+                  (Ptr{Cvoid}, Ref{HHModel}, Ref{HHConfig}, Ref{HHResult}, Ptr{Cdouble}),
+                  ctx.handle, model, config, res, term)
         rc == -2 && throw(MethodError(Hedgehog.solve, (prob, method)))
         rc == 0 || error("hh_mc_solve failed ($rc): $(last_error(ctx))")
     end
@@ -500,15 +538,20 @@ end
 Overwrite `Hedgehog.solve(::PricingProblem{<:VanillaOption{…,European,…,Spot}}, ::MonteCarlo)`
 (montecarlo.jl:478-481) with the GPU implementation and add the fused
 `solve(::BatchGreekProblem, ::ForwardAD, ::MonteCarlo)`.  `GreekProblem` and `FiniteDifference`
-solvers (greeks_problem.jl:249-329) then run through the first unchanged.
+solvers (greeks_problem.jl:249-329) then run through the first unchanged.  `install!(devices = 0:7)`
+shards every routed solve over those GPUs inside the library (hh_mgpu_solve) — `solve(prob, method)`
+stays one call, as montecarlo.jl:478-493.
 """
-function install!()
+const DEVICES = Ref{Any}(nothing)   # install!(devices = 0:7): every routed solve is sharded over these GPUs
+
+function install!(; devices = nothing)
     ccall((:hh_abi_version, LIB[]), Cint, ()) == HH_ABI_VERSION ||
         error("libhedgehog_mc.so has another ABI version than this file ($HH_ABI_VERSION)")
+    DEVICES[] = devices
     @eval Hedgehog function solve(
         prob::PricingProblem{VanillaOption{TS,TE,European,C,Spot},I}, method::MonteCarlo,
     ) where {TS,TE,C,I<:AbstractMarketInputs}
-        return $(solve_hip)(prob, method)
+        return $(solve_hip)(prob, method; devices = $(DEVICES)[])
     end
     # the fused form of greeks_problem.jl:559-568 (more specific than the reference's generic method:
     # ForwardAD + MonteCarlo); FiniteDifference / analytic methods keep the reference's loop

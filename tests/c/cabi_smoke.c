@@ -146,6 +146,46 @@ int main(void) {
           hh_device_free(ctx, d_acc2) == HH_OK, "free");
   }
 
+  /* several devices behind ONE call (hh_mgpu_*), as a Julia host would drive them: no torch in this
+     process, so RCCL is whatever dlopen("librccl.so.1") finds.  One device + HH_MGPU_RCCL runs the
+     library's own communicator and ncclAllReduce; device 0 listed twice is refused by RCCL and takes
+     the host ordered sum — same sums as the single solve up to the order of the last addition. */
+  {
+    const int one[1] = {0}, twice[2] = {0, 0};
+    hh_mgpu *mg1 = NULL, *mg2 = NULL;
+    hh_result r1, r2, r3;
+    CHECK(hh_mc_solve(ctx, &m, &c, &gen, NULL) == HH_OK, hh_last_error(ctx));
+    rc = hh_mgpu_create(&mg1, one, 1, HH_MGPU_RCCL);
+    if (rc == HH_OK) {
+      CHECK(hh_mgpu_reduce_mode(mg1) == HH_MGPU_REDUCE_RCCL && hh_mgpu_n_devices(mg1) == 1, "rccl mode");
+      CHECK(hh_mgpu_solve(mg1, &m, &c, &r1, NULL) == HH_OK, hh_mgpu_last_error(mg1));
+      CHECK(r1.price == gen.price && r1.sumsq_payoff == gen.sumsq_payoff, "one device over RCCL == single solve");
+      hh_mgpu_destroy(mg1);
+    } else {
+      CHECK(rc == HH_ERR_RCCL, "RCCL required: only HH_ERR_RCCL may refuse");  /* a host without librccl */
+    }
+    CHECK(hh_mgpu_create(&mg2, twice, 2, HH_MGPU_AUTO) == HH_OK, "mgpu create");
+    CHECK(hh_mgpu_reduce_mode(mg2) == HH_MGPU_REDUCE_HOST, "duplicate device: host ordered sum");
+    CHECK(hh_mgpu_solve(mg2, &m, &c, &r2, NULL) == HH_OK, hh_mgpu_last_error(mg2));
+    CHECK(r2.n_paths_done == N && fabs(r2.price - gen.price) <= 1e-13 * gen.price &&
+          fabs(r2.sumsq_payoff - gen.sumsq_payoff) <= 1e-13 * gen.sumsq_payoff, "two shards == single solve");
+    /* device-resident shards: the REPLAY buffer of above, cut at a tile boundary */
+    uint64_t a0, b0, a1, b1;
+    hh_mgpu_shard_range(N, 2, 0, 1, &a0, &b0);
+    hh_mgpu_shard_range(N, 2, 1, 1, &a1, &b1);
+    CHECK(a0 == 0 && b0 == a1 && b1 == N && a1 % HH_TILE_PATHS == 0, "shard ranges");
+    hh_config cs[2] = {cr, cr};
+    cs[0].n_paths = b0 - a0;
+    cs[1].n_paths = b1 - a1;
+    cs[1].replay = (const double*)d_dw + (size_t)(a1 / HH_TILE_PATHS) * M * 2 * HH_TILE_PATHS;
+    CHECK(hh_mgpu_solve_shards(mg2, &m, cs, &r3, NULL) == HH_OK, hh_mgpu_last_error(mg2));
+    CHECK(fabs(r3.price - rep.price) <= 1e-13 * rep.price, "device-resident shards == single REPLAY solve");
+    CHECK(hh_mgpu_ctx(mg2, 2) == NULL && hh_mgpu_ctx(mg2, 1) != NULL, "per-device contexts");
+    hh_mgpu_destroy(mg2);
+    const int bad_ids[2] = {0, 4096};
+    CHECK(hh_mgpu_create(&mg2, bad_ids, 2, HH_MGPU_AUTO) == HH_ERR_INVALID && mg2 == NULL, "bad ordinal");
+  }
+
   CHECK(hh_device_free(ctx, d_seeds) == HH_OK && hh_device_free(ctx, d_dw) == HH_OK &&
         hh_device_free(ctx, d_acc) == HH_OK, "free");
   hh_ctx_destroy(ctx);

@@ -87,6 +87,27 @@ def test_two_ranks_on_this_gpu_price_what_one_process_prices(hhlib):
     s = out["strong_scaling"]
     assert s["global_paths"] == 10_000_000 and s["paths_this_rank"] == 5_000_000
     assert s["price"] == pytest.approx(9.2425, abs=0.05)
+    # the same run from ONE process through hh_mgpu_solve_shards (device 0 listed twice: RCCL refuses
+    # the duplicate, the library sums the two accumulator vectors on the host)
+    sp = out["single_process"]
+    assert "error" not in sp, sp
+    assert sp["n_gpus"] == 2 and sp["reduce"] == "host ordered sum"
+    assert sp["price"] == pytest.approx(r.price, rel=1e-12)
+    assert sp["value"] > 0 and sp["value_cold"] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_single_process_line_keeps_the_contract(hhlib):
+    p, out = run_bench("--gpus", "1", "--single-process", "--steps", "5", "--warmup", "2", "--paths", "200000")
+    assert p.returncode == 0, p.stderr[-3000:]
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
+                "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in out
+    assert out["single_process"] is True and out["n_gpus"] == 1 and out["steps"] == 5
+    assert out["roofline"]["launches_timed"] == 5
+    p, _ = run_bench("--gpus", "2", "--single-process", "--devices", "0,7", "--steps", "1", "--warmup", "0")
+    assert p.returncode != 0  # fewer GPUs than asked: refused, never a smaller run
 
 
 @pytest.mark.gpu
@@ -128,6 +149,9 @@ def test_two_ranks_over_rccl_price_what_one_process_prices(hhlib):
     hhlib.check(hhlib.lib.hh_mc_solve(hhlib.handle, C.byref(m), C.byref(c), C.byref(r), None))
     assert out["price"] == pytest.approx(r.price, rel=1e-12)
     assert out["strong_scaling"]["paths_this_rank"] == 5_000_000
+    sp = out["single_process"]  # one process, two devices, the library's own ncclAllReduce
+    assert "error" not in sp, sp
+    assert sp["reduce"] == "rccl" and sp["price"] == pytest.approx(r.price, rel=1e-12)
     p, out = run_bench("--gpus", "2", "--global-paths", str(2 * n), "--steps", "3", "--warmup", "1",
                        "--ramp-ms", "0", "--no-cpu-baseline", "--no-extra")
     assert p.returncode == 0 and out["scaling"] == "strong" and out["config"]["paths_per_gpu"] == n

@@ -120,10 +120,12 @@ def test_every_ccall_of_the_julia_layer_is_a_declared_entry_point():
     assert called and called <= declared, called - declared
     # what VERDICT r1 #5 asks the Julia layer to bind
     assert {"hh_mc_solve", "hh_mc_accumulate", "hh_mc_finalize", "hh_carr_madan", "hh_mc_solve_basket",
-            "hh_lsm_solve", "hh_heston_exact_grid", "hh_abi_version"} <= called
+            "hh_lsm_solve", "hh_heston_exact_grid", "hh_abi_version",
+            "hh_mgpu_create", "hh_mgpu_solve", "hh_mgpu_destroy", "hh_mgpu_reduce_mode"} <= called
     src = open(JULIA).read()
     for needle in ("function solve_batch_greeks_hip", "BatchGreekProblem{P,L}, ::ForwardAD, pricing_method::MonteCarlo",
-                   "function solve_sharded_hip", "replay_layout", "HH_NOISE_REPLAY"):
+                   "function solve_sharded_hip", "replay_layout", "HH_NOISE_REPLAY",
+                   "devices = nothing", "function install!(; devices = nothing)"):
         assert needle in src, needle
     abi = re.search(r"#define HH_ABI_VERSION (\d+)", open(HEADER).read()).group(1)
     assert "const HH_ABI_VERSION = " + abi in src

@@ -27,7 +27,35 @@ def per_kernel(path, counter):
     return {k: (sum(v) / len(v), len(v)) for k, v in agg.items()}
 
 
+PM_KERNEL = "euler_pm_kernel<hh::HestonModel<0, true>, 0, false>"  # path-major REPLAY, price-only
+
+
+def path_major(fetch_csv, write_csv, tag):
+    """usage: tools/pmc_traffic.py pm <fetch csv> <write csv> [tag] — adds the path-major kernel's
+    traffic (PMC passes of `tools/tune_pm.py run 1` with HH_VARIANTS='{"main": []}') to the JSON.
+    Its reads are 16 B per lane LDS-DMA of whole aligned 128-B lines: the x2 of the guide's gfx950 note."""
+    fetch, write = per_kernel(fetch_csv, "FETCH_SIZE"), per_kernel(write_csv, "WRITE_SIZE")
+    fk = next(k for k in fetch if PM_KERNEL in k)
+    dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles",
+                       "pmc_traffic.json")
+    out = json.load(open(dst))
+    f_kib, n = fetch[fk]
+    w_kib = write[fk][0]
+    tile = next((k for k in fetch if KERNEL in k), None)
+    out.update({
+        "path_major_kernel": fk, "path_major_launches": n,
+        "path_major_FETCH_SIZE_KiB_raw": f_kib, "path_major_WRITE_SIZE_KiB_raw": w_kib,
+        "path_major_hbm_bytes_per_launch": 2.0 * f_kib * 1024.0 + w_kib * 1024.0,
+        "path_major_same_pass_tile_major_FETCH_SIZE_KiB_raw": fetch[tile][0] if tile else None,
+        "path_major_source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 "
+                             "tools/tune_pm.py run 1 (HH_VARIANTS={\"main\": []}); round " + tag})
+    json.dump(out, open(dst, "w"), indent=1)
+    print(json.dumps({k: v for k, v in out.items() if k.startswith("path_major")}, indent=1))
+
+
 def main():
+    if sys.argv[1] == "pm":
+        return path_major(sys.argv[2], sys.argv[3], sys.argv[4] if len(sys.argv) > 4 else "r03")
     fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
     write = per_kernel(sys.argv[2], "WRITE_SIZE")
     tag = sys.argv[3] if len(sys.argv) > 3 else "r01"

@@ -51,7 +51,8 @@ def run(rounds=5):
     seeds = torch.arange(1, n + 1, dtype=torch.int64, device=dev)
     libs = {}
     for tag in VARIANTS:
-        lib = C.CDLL(os.path.join(VDIR, f"libhh_{tag}.so"))
+        # tag "main" = the shipped library itself (PMC passes: rocprofv3 ... -- python3 tools/tune_pm.py run 1)
+        lib = C.CDLL(_ffi.LIB_PATH if tag == "main" else os.path.join(VDIR, f"libhh_{tag}.so"))
         for name, res, args in _ffi.SYMBOLS:
             f = getattr(lib, name)
             f.restype, f.argtypes = res, args
