@@ -662,22 +662,30 @@ __attribute__((amdgpu_waves_per_eu(REPLAY ? HH_REPLAY_MINW : 1,
 #ifndef HH_PM_NT
 #define HH_PM_NT 1
 #endif
-constexpr int kPmPieces = 8;  // 16-byte pieces per row and chunk = one 128-byte line
+#ifndef HH_PM_PIECES
+#define HH_PM_PIECES 8  // 16-byte pieces per row and chunk: 8 = one 128-byte line, 16 = two
+#endif
+constexpr int kPmPieces = HH_PM_PIECES;
+static_assert(kPmPieces == 8 || kPmPieces == 16, "one or two 128-byte lines per row and chunk");
 
 template <class M, int P, bool ANTI>
 __global__ __launch_bounds__(kTile)
 __attribute__((amdgpu_waves_per_eu(1, HH_PM_MAXW))) void euler_pm_kernel(const SimArgs<P> a) {
   constexpr int NC = M::NCOMP;
+  constexpr int NP = kPmPieces;            // pieces per row and chunk
+  constexpr int ROWB = NP * 16;            // bytes of a row of the LDS image
+  constexpr int RPI = 64 / NP;             // rows one LDS-DMA instruction (64 lanes x 16 B) covers
+  constexpr int NI = 64 / RPI;             // instructions per chunk
   using State = typename M::State;
   using V2 = double __attribute__((ext_vector_type(2)));
-  __shared__ __attribute__((aligned(128))) double image[kTile / 64][64 * 2 * kPmPieces];
+  __shared__ __attribute__((aligned(128))) double image[kTile / 64][64 * 2 * NP];
 
   const uint32_t tile = blockIdx.x, tid = threadIdx.x;
   const uint32_t wave = tid >> 6, lane = tid & 63;
   const uint64_t path = (uint64_t)tile * kTile + tid;
   const uint64_t last = a.n_paths - 1;
-  const int64_t T = (int64_t)a.n_steps * NC / 2;  // 16-byte pieces per row
-  const uint64_t S = (uint64_t)T * 16;             // bytes per row
+  const int T = (int)((uint64_t)a.n_steps * NC / 2);  // 16-byte pieces per row (<= 262 140)
+  const uint64_t S = (uint64_t)T * 16;                  // bytes per row
   const char* base = reinterpret_cast<const char*>(a.replay);
 
   // rows beyond the ensemble (last tile) repeat the last trajectory: loads stay unguarded and in
@@ -687,17 +695,20 @@ __attribute__((amdgpu_waves_per_eu(1, HH_PM_MAXW))) void euler_pm_kernel(const S
     const uint64_t pth = wave_path0 + r;
     return base + (pth < last ? pth : last) * S;
   };
+  // slot of piece j in row r of the image: the 16 lanes one ds_read_b128 cycle serves
+  // ({0-3,12-15,20-27}, {4-11,16-19,28-31}, ...) must land on 16 different 16-byte bank groups
+  auto swz = [](uint32_t r) { return NP == 8 ? (r >> 1) & 7u : r & 15u; };
 
-  // ---- loader role: instruction i moves rows 8i + (lane >> 3), this lane the piece in slot lane & 7
-  const char* src[kPmPieces];   // source of the CURRENT chunk's piece (advanced by one line per chunk)
-  const char* row_r[kPmPieces]; // the row's first byte: where invalid pieces are pointed (any valid address)
-  int tb[kPmPieces];            // row piece index of that slot in chunk 0
+  // ---- loader role: instruction i moves rows RPI·i + lane / NP, this lane the piece in slot lane % NP
+  const char* src[NI];   // source of the CURRENT chunk's piece (advanced by ROWB per chunk)
+  const char* row_r[NI]; // the row's first byte
+  int tb[NI];            // row piece index of that slot in chunk 0
 #pragma unroll
-  for (int i = 0; i < kPmPieces; ++i) {
-    const uint32_t r = 8u * i + (lane >> 3);
+  for (int i = 0; i < NI; ++i) {
+    const uint32_t r = (uint32_t)RPI * i + lane / NP;
     const char* row = row_of(r);
     const uint32_t o_r = ((uint32_t)(uintptr_t)row & 127u) >> 4;
-    const uint32_t jg = (lane & 7u) ^ ((r >> 1) & 7u);  // swizzle on the source side
+    const uint32_t jg = (lane % NP) ^ swz(r);  // swizzle on the source side (LDS-DMA writes lane-linearly)
     row_r[i] = row;
     tb[i] = (int)jg - (int)o_r;
     src[i] = row - ((uintptr_t)row & 127u) + jg * 16u;
@@ -705,25 +716,34 @@ __attribute__((amdgpu_waves_per_eu(1, HH_PM_MAXW))) void euler_pm_kernel(const S
   // ---- consumer role: this lane's own row
   const char* my_row = row_of(lane);
   const int o = (int)(((uint32_t)(uintptr_t)my_row & 127u) >> 4);
-  const uint32_t sw = (lane >> 1) & 7u;
-  const char* my_img = reinterpret_cast<const char*>(&image[wave][0]) + lane * 128u;
+  const uint32_t sw = swz(lane);
+  const char* my_img = reinterpret_cast<const char*>(&image[wave][0]) + lane * (uint32_t)ROWB;
 
-  const int64_t n_chunks = (T + 2 * kPmPieces - 1) / kPmPieces;  // covers every phase o <= 7
-  // chunks whose 15 possible row pieces 8k-7 .. 8k+7 are all inside the row: no guards
-  const int64_t k_full_end = T >= 2 * kPmPieces ? (T - kPmPieces) / kPmPieces : 0;  // full: 1 <= k <= k_full_end
-
-  auto issue = [&](int64_t k, bool guarded) {
+  // chunks this wave runs: enough for its row with the largest phase (wave-uniform)
+  int om = o;
 #pragma unroll
-    for (int i = 0; i < kPmPieces; ++i) {
+  for (int off = 32; off > 0; off >>= 1) om = max(om, __shfl_xor(om, off, 64));
+  om = __builtin_amdgcn_readfirstlane(om);
+  const int n_chunks = (T + om + NP - 1) / NP;
+  // chunks all of whose possible row pieces NP·k − 7 … NP·k + NP − 1 lie inside the row: no guards
+  const int k_full_end = (T - NP) / NP;  // full: 1 <= k <= k_full_end (none when T < 2·NP)
+
+  auto issue = [&](int k, bool guarded) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
       const char* g = src[i];
       if (guarded) {
-        const int64_t t = 8 * k + tb[i];
-        if (t < 0 || t >= T) g = row_r[i];
+        // a piece outside the row is redirected to the row's NEAREST piece: inside the same half
+        // line as the valid pieces next to it, so a partly valid line costs no second request and a
+        // line shared by two rows is fetched by halves
+        int t = NP * k + tb[i];
+        t = t < 0 ? 0 : (t >= T ? T - 1 : t);
+        g = row_r[i] + (uint32_t)t * 16u;
       }
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                        (__attribute__((address_space(3))) void*)&image[wave][i * 128],
                                        16, 0, HH_PM_NT ? 2 : 0);
-      src[i] += 128;
+      src[i] += ROWB;
     }
   };
 
@@ -744,24 +764,24 @@ __attribute__((amdgpu_waves_per_eu(1, HH_PM_MAXW))) void euler_pm_kernel(const S
   };
 
   if (n_chunks > 0) issue(0, true);
-  for (int64_t k = 0; k < n_chunks; ++k) {
+  for (int k = 0; k < n_chunks; ++k) {
     // the compiler orders LDS reads behind every outstanding LDS-DMA (s_waitcnt vmcnt(0))
-    V2 d[kPmPieces];
+    V2 d[NP];
 #pragma unroll
-    for (int j = 0; j < kPmPieces; ++j)
+    for (int j = 0; j < NP; ++j)
       d[j] = *reinterpret_cast<const V2*>(my_img + (((uint32_t)j ^ sw) << 4));
     // WAR: the next chunk's DMA overwrites the image — not before these reads have returned
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     const bool full = k >= 1 && k <= k_full_end;
-    if (k + 1 < n_chunks) issue(k + 1, !(k + 1 >= 1 && k + 1 <= k_full_end));
+    if (k + 1 < n_chunks) issue(k + 1, !(k + 1 <= k_full_end));
     if (full) {
 #pragma unroll
-      for (int j = 0; j < kPmPieces; ++j) advance(d[j]);
+      for (int j = 0; j < NP; ++j) advance(d[j]);
     } else {
 #pragma unroll
-      for (int j = 0; j < kPmPieces; ++j) {
-        const int64_t t = 8 * k - o + j;
+      for (int j = 0; j < NP; ++j) {
+        const int t = NP * k - o + j;
         if (t >= 0 && t < T) advance(d[j]);
       }
     }
