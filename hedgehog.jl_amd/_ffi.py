@@ -66,12 +66,13 @@ class hh_lsm_result(C.Structure):
     _fields_ = [("price", C.c_double), ("std_error", C.c_double), ("n_paths_total", C.c_uint64),
                 ("rows_regressed", C.c_uint32), ("rows_skipped", C.c_uint32),
                 ("kernel_ms", C.c_double), ("total_ms", C.c_double),
-                ("form", C.c_int32), ("reserved_", C.c_int32)]
+                ("form", C.c_int32), ("persistent_fallbacks", C.c_int32)]
 
 
 HH_OPT_LSM_FORM = 1
 HH_OPT_BK_TERM_CACHE = 2
 HH_OPT_GRID_FORM = 3
+HH_OPT_LSM_SPIN_TICKS = 4
 HH_GRID_FORM_PER_DATE, HH_GRID_FORM_BATCHED = 0, 1
 HH_CM_GRAD_LEN = 8  # enum hh_cm_grad: S0, V0, kappa, theta, sigma, rho, r_drift, discount
 HH_LSM_FORM_PER_DATE, HH_LSM_FORM_PERSISTENT, HH_LSM_FORM_AUTO = 0, 1, 2

@@ -222,6 +222,10 @@ int hh_ctx_set_option(hh_ctx* ctx, int32_t option, int64_t value) {
         return fail(ctx, HH_ERR_INVALID, "HH_OPT_BK_TERM_CACHE: 8 .. 1024 series terms per trajectory");
       ctx->bk_term_cache = (int)value;
       return HH_OK;
+    case HH_OPT_LSM_SPIN_TICKS:
+      if (value < -1) return fail(ctx, HH_ERR_INVALID, "HH_OPT_LSM_SPIN_TICKS: ticks of the 100 MHz clock, 0 = give up at once, -1 = default");
+      ctx->lsm_spin_ticks = value;
+      return HH_OK;
     case HH_OPT_GRID_FORM:
       if (value != HH_GRID_FORM_PER_DATE && value != HH_GRID_FORM_BATCHED)
         return fail(ctx, HH_ERR_INVALID, "HH_OPT_GRID_FORM: 0 (one chain per date) or 1 (dates batched)");
@@ -707,11 +711,13 @@ static int lsm_on_grid(hh_ctx* ctx, const double* grid_dev, uint64_t ntot, uint3
   int form_used = hh::kLsmFormPerDate;
   double counters[2] = {0, 0};
   unsigned int gave_up = 0;
+  int32_t fallbacks = 0;
   for (int attempt = 0; attempt < 2; ++attempt) {
     const int form = attempt == 0 ? ctx->lsm_form : hh::kLsmFormPerDate;
     HH_HIP(ctx, hh::launch_lsm(grid_dev, ntot, n_steps, m->strike, m->cp, step_discount, degree,
                                ctx->lsm_tau, ctx->lsm_val, ctx->lsm_scratch, ctx->records,
-                               ctx->stream, form, &form_used));
+                               ctx->stream, form, &form_used,
+                               ctx->lsm_spin_ticks < 0 ? 100000000ull : (unsigned long long)ctx->lsm_spin_ticks));
     HH_HIP(ctx, hh::launch_reduce_records(ctx->records, ch, (double)ntot, ctx->accum, ctx->stream));
     HH_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
     gave_up = 0;
@@ -731,6 +737,7 @@ static int lsm_on_grid(hh_ctx* ctx, const double* grid_dev, uint64_t ntot, uint3
     HH_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (!gave_up) break;
     ++ctx->lsm_persistent_fallbacks;
+    ++fallbacks;
   }
   const double n = (double)ntot, mean = ctx->accum_host[HH_ACC_SUM] / n;
   double var = n > 1.0 ? (ctx->accum_host[HH_ACC_SUMSQ] - n * mean * mean) / (n - 1.0) : 0.0;
@@ -742,6 +749,7 @@ static int lsm_on_grid(hh_ctx* ctx, const double* grid_dev, uint64_t ntot, uint3
   out->rows_regressed = (uint32_t)counters[0];
   out->rows_skipped = (uint32_t)counters[1];
   out->form = form_used;
+  out->persistent_fallbacks = fallbacks;
   float ms = 0.f;
   HH_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
   out->kernel_ms = ms;

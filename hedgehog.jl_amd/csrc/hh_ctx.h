@@ -56,6 +56,7 @@ struct hh_ctx {
   int bk_term_cache = 0;            // hh_ctx_set_option(HH_OPT_BK_TERM_CACHE); 0 = the default
   int grid_form = HH_GRID_FORM_BATCHED;  // hh_ctx_set_option(HH_OPT_GRID_FORM)
   uint64_t lsm_persistent_fallbacks = 0;  // persistent launches that gave up and were redone per date
+  long long lsm_spin_ticks = -1;          // hh_ctx_set_option(HH_OPT_LSM_SPIN_TICKS); < 0 = the default (1 s)
   double* accum = nullptr;       // device, HH_ACC_LEN
   double* accum_host = nullptr;  // pinned, HH_ACC_LEN
   // optional per-launch timing of the simulation kernel (hh_ctx_enable_timing)

@@ -168,7 +168,8 @@ int launch_gbm_grid(const uint64_t* seeds_dev, uint64_t n_paths, uint32_t n_step
 enum { kLsmFormPerDate = 0, kLsmFormPersistent = 1, kLsmFormAuto = 2 };  // auto: persistent above 2^18 trajectories
 int launch_lsm(const double* grid, uint64_t ntot, uint32_t n_steps, double strike, double cp,
                double step_discount, int degree, int32_t* tau, double* val, double* scratch,
-               double* records, hipStream_t s, int form, int* form_used);
+               double* records, hipStream_t s, int form, int* form_used,
+               unsigned long long spin_ticks = 100000000ull /* 1 s of the 100 MHz constant clock */);
 const unsigned int* lsm_persistent_status(const double* scratch);
 constexpr int kLsmStampSlotsApi = 8;  // doubles behind the two row counters at the end of the scratch
 int launch_wiener_fill(int dynamics, double rho, double sqrt_dt, uint32_t n_steps, uint64_t n_paths,

@@ -661,7 +661,9 @@ struct LsmPersistArgs {
   unsigned long long* rec;  // [kLsmRing][32 values][n_chunks] (fp64 bit patterns), write-through:
                             // value-major, so that the 64 lanes of a gathering wave — one record
                             // each — read 512 contiguous bytes per value
-  unsigned int* tags;       // [kLsmRing][n_chunks] epoch of the record in that slot (0 = none yet)
+  unsigned int* tags;       // [2 groups][kLsmRing][kLsmMaxResident] epoch of the record half in that
+                            // slot (0 = none yet): group A (moment sums, statistics) and group B (power
+                            // sums) of a record are published — and polled — separately
   unsigned int* status;     // [0] != 0: a workgroup gave up waiting (the grid was not co-resident)
   unsigned long long spin_ticks;  // bound of every wait, in s_memrealtime ticks (100 MHz)
 };
@@ -674,20 +676,26 @@ struct LsmPersistArgs {
 constexpr int kRecP2 = 32, kGrp = 16, kOffStats = 12;
 constexpr int kDiscLds = 1024;
 
-// publish this workgroup's record for epoch e: write-through (sc1) stores by ONE wave, drained,
-// then the tag by one lane (Guideline 16, recipe R1)
+// publish group g (0 = A, 1 = B) of this workgroup's record for epoch e: write-through (sc1) stores
+// of its 16 values by the first 16 lanes of ONE wave (wave 0 for A, wave 4 for B), drained, then the
+// group's tag by one lane (Guideline 16, recipe R1).  `val` is the lane's value (lanes >= 16: unused).
+__device__ __forceinline__ void publish_group(const LsmPersistArgs& a, uint32_t e, int g, double val) {
+  const size_t ring = e % kLsmRing;
+  const uint32_t lane = threadIdx.x & 63u;
+  if (lane < (uint32_t)kGrp)
+    __hip_atomic_store((gu64*)(a.rec + (ring * kRecP2 + g * kGrp + lane) * a.n_chunks + blockIdx.x),
+                       (unsigned long long)__double_as_longlong(val), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (lane == 0)
+    __hip_atomic_store((gu32*)(a.tags + ((size_t)g * kLsmRing + ring) * kLsmMaxResident + blockIdx.x), e,
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// both groups from the workgroup totals tot[32] (the two prologue epochs)
 __device__ __forceinline__ void publish_record(const LsmPersistArgs& a, uint32_t e, const double* tot) {
-  if (threadIdx.x < 64) {
-    const size_t ring = e % kLsmRing;
-    if (threadIdx.x < kRecP2)
-      __hip_atomic_store((gu64*)(a.rec + (ring * kRecP2 + threadIdx.x) * a.n_chunks + blockIdx.x),
-                         (unsigned long long)__double_as_longlong(tot[threadIdx.x]), __ATOMIC_RELAXED,
-                         __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (threadIdx.x == 0)
-      __hip_atomic_store((gu32*)(a.tags + ring * a.n_chunks + blockIdx.x), e, __ATOMIC_RELAXED,
-                         __HIP_MEMORY_SCOPE_AGENT);
-  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (wave == 0) publish_group(a, e, 0, lane < kGrp ? tot[lane] : 0.0);
+  if (wave == 4) publish_group(a, e, 1, lane < kGrp ? tot[kGrp + lane] : 0.0);
 }
 
 // gather the records of epoch e from every workgroup and reduce them in the canonical order: lane
@@ -709,9 +717,9 @@ __device__ __forceinline__ bool gather_records(const LsmPersistArgs& a, uint32_t
     const uint32_t r = threadIdx.x & 255u;    // record
     const bool mine = r < a.n_chunks;
     const size_t ring = e % kLsmRing;
-    const size_t slot = ring * a.n_chunks + r;
-    bool ok = true;
-    if (__any(mine)) {
+    const size_t slot = ((size_t)g * kLsmRing + ring) * kLsmMaxResident + r;  // this group's tag of record r
+    bool ok = a.spin_ticks != 0;  // 0 (HH_OPT_LSM_SPIN_TICKS, tests): give up at once
+    if (ok && __any(mine)) {
       const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
       unsigned spins = 0;
       while (true) {
@@ -863,20 +871,27 @@ __global__ __launch_bounds__(kLsmWg, (Q * kLsmWg > 1024 ? 2 : 4)) void lsm_persi
       finish_block<kRecP2, kLsmWaves>(scratch, tot);
       publish_record(a, 2u, tot);
     }
-    // for i = nsteps:-1:2, t = i-1 (:112-113)
+    // Row t-2 of an iteration is loaded one iteration ahead (here: for t = M-1), off the critical path
+    double xin[Q];
+    auto issue_row = [&](uint32_t row) {
+      const double* S2 = row_ptr(row);
+#pragma unroll
+      for (int j = 0; j < Q; ++j) {  // clamped, not guarded: 16 loads issue back to back
+        const uint64_t p = p0 + (uint64_t)j * kLsmWg;
+        xin[j] = S2[p < a.ntot ? p : a.ntot - 1];
+      }
+    };
+    if (alive && M >= 4) issue_row(M - 3);
+    // for i = nsteps:-1:2, t = i-1 (:112-113).
+    // What a date's critical path carries — gather of group A → normal equations → decisions →
+    // moment sums of row t-1 → their workgroup total → publish A — and what it does not: the power
+    // sums of row t-1 depend on the row and its statistics alone, not on the stopping state, and are
+    // needed one date LATER (the fit of row t-1).  They are formed, totalled and published as group B
+    // behind the publication of A, i.e. while the other workgroups' A records are on their way, and the
+    // next row's loads are issued there too.  Same values, same summation tree as before.
     for (uint32_t t = M - 1; alive && t >= 1; --t) {
       const uint32_t e = M - t + 1;  // epoch whose records hold the sums of row t
       HH_STAMP(7)
-      double xin[Q];  // row t-2: issued here, in flight behind the gather, the solve and the decisions
-      if (t >= 3) {
-        const double* S2 = row_ptr(t - 2);
-#pragma unroll
-        for (int j = 0; j < Q; ++j) {  // clamped, not guarded: 16 loads issue back to back
-          const uint64_t p = p0 + (uint64_t)j * kLsmWg;
-          xin[j] = S2[p < a.ntot ? p : a.ntot - 1];
-        }
-      }
-      HH_STAMP(0)  // row t-2 issued
       alive = gather_records(a, e, scratch, tot, &ok_flag);
       HH_STAMP(1)  // all-gather: wait, loads, reduction
       if (!alive) break;
@@ -900,6 +915,7 @@ __global__ __launch_bounds__(kLsmWg, (Q * kLsmWg > 1024 ? 2 : 4)) void lsm_persi
 #pragma unroll
         for (int j = 0; j < Q; ++j) xs[j] = xl[cur][j * kLsmWg + threadIdx.x];
         if (!(HH_LSM_DEBUG & 4)) {
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
         {
           double v[kGrp];
 #pragma unroll
@@ -917,6 +933,17 @@ __global__ __launch_bounds__(kLsmWg, (Q * kLsmWg > 1024 ? 2 : 4)) void lsm_persi
           wave_part<kGrp, kRecP2>(v, scratch, 0);
         }
         HH_STAMP(4)  // moment sums + their wave butterfly
+        __syncthreads();
+        if (wave == 0) {  // group A: the waves in order (as finish_block), straight into the record
+          double tA = 0.0;
+          if (lane < kGrp) {
+            tA = scratch[lane];
+#pragma unroll
+            for (int w = 1; w < kLsmWaves; ++w) tA += scratch[w * kRecP2 + lane];
+          }
+          publish_group(a, e + 1, 0, tA);
+        }
+        HH_STAMP(6)  // workgroup total of A, publish  — the date's critical path ends here
         {
           double w[kGrp];
 #pragma unroll
@@ -926,10 +953,19 @@ __global__ __launch_bounds__(kLsmWg, (Q * kLsmWg > 1024 ? 2 : 4)) void lsm_persi
           wave_part<kGrp, kRecP2>(w, scratch, kGrp);
         }
         HH_STAMP(5)  // power sums + their wave butterfly
-        finish_block<kRecP2, kLsmWaves>(scratch, tot);
-        publish_record(a, e + 1, tot);
-        HH_STAMP(6)  // workgroup totals, publish
+        __syncthreads();
+        if (wave == 4) {
+          double tB = 0.0;
+          if (lane < kGrp) {
+            tB = scratch[kGrp + lane];
+#pragma unroll
+            for (int w = 1; w < kLsmWaves; ++w) tB += scratch[w * kRecP2 + kGrp + lane];
+          }
+          publish_group(a, e + 1, 1, tB);
         }
+        }
+        if (t >= 4) issue_row(t - 3);  // row (t-1)-2 of the next iteration
+        HH_STAMP(0)  // group B, next row issued
         cur ^= 1;
         r_cur = r_next;
       }
@@ -971,7 +1007,7 @@ struct LsmLayout {
   int q;
 };
 
-constexpr size_t kSyncWords = (size_t)kLsmRing * kLsmMaxResident + 4;       // uint32: tags, status
+constexpr size_t kSyncWords = (size_t)2 * kLsmRing * kLsmMaxResident + 4;   // uint32: tags of both groups, status
 constexpr size_t kSyncDoubles = (kSyncWords * 4 + 15) / 16 * 2;             // padded to 16 bytes
 constexpr size_t kRingDoubles = (size_t)kLsmRing * kLsmMaxResident * 32;    // records of 32 doubles
 
@@ -1045,37 +1081,58 @@ int run_lsm(const LsmLayout& L, const LsmStepArgs& a, hipStream_t s) {
   return (int)hipGetLastError();
 }
 
-// can `blocks` workgroups of this kernel be resident together?  (one per CU is what the register
-// budget of a 1024-thread workgroup allows; the occupancy query is the authority)
+// The persistent form synchronises its workgroups through memory, so ALL of them must be resident
+// at once.  It is therefore launched with hipLaunchCooperativeKernel: the runtime checks the grid
+// against what the device can hold (registers, LDS, waves — the kernel's own occupancy) and REFUSES
+// the launch (hipErrorCooperativeLaunchTooLarge) instead of starting a grid whose late workgroups
+// would never meet the early ones; and a cooperative grid is not dispatched beside other kernels that
+// would take its CUs.  On top of that one workgroup per CU is asked for (the induction's workgroups
+// are sized for a whole CU: 512 threads x 256 registers, 130 KiB of LDS).  The bounded waits inside
+// the kernel stay as the last guard (spin_ticks).
 template <class K>
 bool grid_fits(K kernel, uint32_t blocks) {
-  int dev = 0, cus = 0, per_cu = 0;
+  int dev = 0, cus = 0, per_cu = 0, coop = 0;
   if (hipGetDevice(&dev) != hipSuccess) return false;
+  if (hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, dev) != hipSuccess || !coop) return false;
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kLsmWg, 0) != hipSuccess) return false;
   return per_cu >= 1 && blocks <= (uint32_t)cus;  // counted at ONE workgroup per CU, whatever the query allows
 }
 
-// the whole induction in one launch; 1 = not applicable here (too many chunks for the chip)
+template <class K>
+int launch_cooperative(K kernel, uint32_t blocks, const LsmPersistArgs& a, hipStream_t s) {
+  LsmPersistArgs args = a;
+  void* params[] = {&args};
+  const hipError_t e = hipLaunchCooperativeKernel(reinterpret_cast<const void*>(kernel), dim3(blocks),
+                                                  dim3(kLsmWg), params, 0, s);
+  if (e == hipErrorCooperativeLaunchTooLarge || e == hipErrorLaunchOutOfResources ||
+      e == hipErrorInvalidConfiguration) {
+    (void)hipGetLastError();  // refused, nothing started: the caller runs the launch-per-date form
+    return 1;
+  }
+  return (int)e;
+}
+
+// the whole induction in one launch; 1 = not applicable here (too many chunks for the chip, or the
+// runtime cannot guarantee that the grid is resident)
 template <int D>
-int run_lsm_persistent(const LsmLayout& L, const LsmStepArgs& s_args, hipStream_t s) {
+int run_lsm_persistent(const LsmLayout& L, const LsmStepArgs& s_args, hipStream_t s, unsigned long long spin_ticks) {
   if (L.nch > (uint32_t)kLsmMaxResident) return 1;
   LsmPersistArgs a{};
   a.grid = s_args.grid; a.ntot = s_args.ntot; a.strike = s_args.strike; a.cp = s_args.cp;
   a.n_steps = s_args.n_steps; a.n_chunks = L.nch; a.tau = s_args.tau; a.val = s_args.val;
   a.disc_pow = L.disc_pow; a.counters = L.counters;
   a.tags = reinterpret_cast<unsigned int*>(L.sync);
-  a.status = a.tags + (size_t)kLsmRing * kLsmMaxResident;
+  a.status = a.tags + (size_t)2 * kLsmRing * kLsmMaxResident;
   a.rec = reinterpret_cast<unsigned long long*>(L.sync + kSyncDoubles);
-  a.spin_ticks = 100000000ull;  // 1 s of the 100 MHz constant clock
+  a.spin_ticks = spin_ticks;  // default 1 s of the 100 MHz constant clock
   const bool fits = L.q == kLsmQSmall ? grid_fits(lsm_persistent_kernel<D, kLsmQSmall>, L.nch)
                              : grid_fits(lsm_persistent_kernel<D, kLsmQLarge>, L.nch);
   if (!fits) return 1;
   hipError_t e = hipMemsetAsync(L.sync, 0, kSyncDoubles * sizeof(double), s);
   if (e != hipSuccess) return (int)e;
-  if (L.q == kLsmQSmall) hipLaunchKernelGGL((lsm_persistent_kernel<D, kLsmQSmall>), dim3(L.nch), dim3(kLsmWg), 0, s, a);
-  else hipLaunchKernelGGL((lsm_persistent_kernel<D, kLsmQLarge>), dim3(L.nch), dim3(kLsmWg), 0, s, a);
-  return (int)hipGetLastError();
+  if (L.q == kLsmQSmall) return launch_cooperative(lsm_persistent_kernel<D, kLsmQSmall>, L.nch, a, s);
+  return launch_cooperative(lsm_persistent_kernel<D, kLsmQLarge>, L.nch, a, s);
 }
 
 // one phase of the sharded induction (see hh_kernels.h); vec_in / vec_out are device vectors
@@ -1160,7 +1217,7 @@ int launch_gbm_grid(const uint64_t* seeds_dev, uint64_t n_paths, uint32_t n_step
 // the caller must then check lsm_persistent_status after synchronising) — kLsmFormPerDate never does.
 int launch_lsm(const double* grid, uint64_t ntot, uint32_t n_steps, double strike, double cp,
                double step_discount, int degree, int32_t* tau, double* val, double* scratch,
-               double* records, hipStream_t s, int form, int* form_used) {
+               double* records, hipStream_t s, int form, int* form_used, unsigned long long spin_ticks) {
   if (degree < 1 || degree > kLsmMaxDeg) return (int)hipErrorInvalidValue;
   const LsmLayout L = lsm_layout(scratch, ntot, n_steps, degree);
   hipError_t e = hipMemsetAsync(L.counters, 0, (2 + kLsmStampSlots) * sizeof(double), s);
@@ -1171,7 +1228,7 @@ int launch_lsm(const double* grid, uint64_t ntot, uint32_t n_steps, double strik
                      L.disc_pow);
   int rc = 1;
   if (form == kLsmFormPersistent || (form == kLsmFormAuto && L.q == kLsmQLarge)) {
-#define HH_CALL(D) run_lsm_persistent<D>(L, a, s)
+#define HH_CALL(D) run_lsm_persistent<D>(L, a, s, spin_ticks)
     HH_LSM_DISPATCH(degree, HH_CALL)
 #undef HH_CALL
     if (rc != 0 && rc != 1) return rc;
@@ -1190,7 +1247,7 @@ int launch_lsm(const double* grid, uint64_t ntot, uint32_t n_steps, double strik
 
 // device address of the word the persistent form sets when a workgroup gave up waiting
 const unsigned int* lsm_persistent_status(const double* scratch) {
-  return reinterpret_cast<const unsigned int*>(scratch) + (size_t)kLsmRing * kLsmMaxResident;
+  return reinterpret_cast<const unsigned int*>(scratch) + (size_t)2 * kLsmRing * kLsmMaxResident;
 }
 
 // Sharded induction, one phase per call (hh_kernels.h).  kLsmPhaseStats: local row sums

@@ -159,8 +159,8 @@ const char* hh_last_error(const hh_ctx* ctx); /* NUL-terminated, owned by ctx (o
  *   HH_LSM_FORM_PERSISTENT  ONE launch that keeps every trajectory's stopping state in registers,
  *                           reads each row of the grid once and exchanges the per-date sums between
  *                           its workgroups in the kernel; applies to ensembles of up to 2^21
- *                           trajectories (256 chunks), falls back by itself beyond that or when its
- *                           workgroups cannot all be resident;
+ *                           trajectories (256 chunks); a COOPERATIVE launch — refused by the runtime, and
+ *                           replaced by the other form, when its workgroups cannot all be resident;
  *   HH_LSM_FORM_PER_DATE    one launch per exercise date;
  *   HH_LSM_FORM_AUTO        (default) the persistent form above 2^18 trajectories — where not
  *                           re-loading the state pays (2·10^6 x 100 dates: 2.0 vs 3.1 ms) — and a
@@ -181,8 +181,14 @@ const char* hh_last_error(const hh_ctx* ctx); /* NUL-terminated, owned by ctx (o
  *                          dates are independent — then the spot rows; several chains only when the pairs'
  *                          term cache would pass its 8 GiB;
  *   HH_GRID_FORM_PER_DATE  one kernel chain per date.
- * Both forms give bit-identical grids. */
-enum hh_option { HH_OPT_LSM_FORM = 1, HH_OPT_BK_TERM_CACHE = 2, HH_OPT_GRID_FORM = 3 };
+ * Both forms give bit-identical grids.
+ *
+ * HH_OPT_LSM_SPIN_TICKS: bound of every wait inside the persistent LSM launch, in ticks of the 100 MHz
+ * constant clock (default -1 = 10^8 = one second).  The launch is cooperative (hipLaunchCooperativeKernel:
+ * a grid that cannot be resident as a whole is refused at launch and the launch-per-date form runs), so
+ * the bound is only the last guard; 0 makes every workgroup give up at once, which is how the tests
+ * force the give-up-and-redo path (hh_lsm_result.persistent_fallbacks counts it; same result). */
+enum hh_option { HH_OPT_LSM_FORM = 1, HH_OPT_BK_TERM_CACHE = 2, HH_OPT_GRID_FORM = 3, HH_OPT_LSM_SPIN_TICKS = 4 };
 enum hh_grid_form { HH_GRID_FORM_PER_DATE = 0, HH_GRID_FORM_BATCHED = 1 };
 enum hh_lsm_form { HH_LSM_FORM_PER_DATE = 0, HH_LSM_FORM_PERSISTENT = 1, HH_LSM_FORM_AUTO = 2 };
 int hh_ctx_set_option(hh_ctx* ctx, int32_t option, int64_t value);
@@ -331,7 +337,8 @@ typedef struct hh_lsm_result {
   uint32_t rows_regressed, rows_skipped; /* time rows with / without an in-the-money path */
   double kernel_ms, total_ms;
   int32_t form;      /* HH_LSM_FORM_PER_DATE / _PERSISTENT: how the backward induction ran */
-  int32_t reserved_;
+  int32_t persistent_fallbacks; /* 1: the one-launch form gave up waiting (nothing written) and the
+                                   launch-per-date form produced this result instead */
 } hh_lsm_result;
 size_t hh_lsm_grid_elems(uint64_t n_paths, uint32_t n_steps, int32_t antithetic);
 int hh_lsm_solve(hh_ctx* ctx, const hh_model* model, const hh_config* cfg, int32_t degree,

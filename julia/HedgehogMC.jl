@@ -455,7 +455,7 @@ struct HHLsmResult
     n_paths_total::UInt64
     rows_regressed::UInt32; rows_skipped::UInt32
     kernel_ms::Cdouble; total_ms::Cdouble
-    form::Int32; reserved_::Int32
+    form::Int32; persistent_fallbacks::Int32
 end
 
 """

@@ -85,6 +85,33 @@ def test_one_launch_and_launch_per_date_agree_bit_for_bit(hhlib, n, steps, anti,
     assert ta.min() >= 1 and ta.max() <= steps
 
 
+@pytest.mark.parametrize("n,steps", [(3000, 9), (300_000, 12)])
+def test_a_persistent_launch_that_gives_up_is_redone_per_date(hhlib, n, steps):
+    """The last guard of the one-launch form: a workgroup whose wait runs out raises the status word,
+    every workgroup leaves WITHOUT writing anything, and the host runs the launch-per-date form — the
+    same result bit for bit, with persistent_fallbacks = 1 in the result.  HH_OPT_LSM_SPIN_TICKS = 0
+    makes the waits run out at once (a co-resident grid, which the cooperative launch guarantees,
+    never gets there by itself)."""
+    seeds = np.random.default_rng(n + steps).integers(0, 2**63, n).astype(np.uint64)
+    args = (100.0, 105.0, 0.06, 0.3, 0.5, -1.0, seeds, steps, 1, 4)
+    try:
+        hhlib.set_option(_ffi.HH_OPT_LSM_FORM, _ffi.HH_LSM_FORM_PERSISTENT)
+        ok = gpu_lsm(hhlib, *args, want_grid=False)
+        assert ok[0].form == _ffi.HH_LSM_FORM_PERSISTENT and ok[0].persistent_fallbacks == 0
+        hhlib.set_option(_ffi.HH_OPT_LSM_SPIN_TICKS, 0)
+        redo = gpu_lsm(hhlib, *args, want_grid=False)
+        assert redo[0].form == _ffi.HH_LSM_FORM_PER_DATE and redo[0].persistent_fallbacks == 1
+    finally:
+        hhlib.set_option(_ffi.HH_OPT_LSM_SPIN_TICKS, -1)
+        hhlib.set_option(_ffi.HH_OPT_LSM_FORM, _ffi.HH_LSM_FORM_AUTO)
+    np.testing.assert_array_equal(ok[1], redo[1])
+    np.testing.assert_array_equal(ok[2], redo[2])
+    assert (ok[0].price, ok[0].std_error, ok[0].rows_regressed) == \
+           (redo[0].price, redo[0].std_error, redo[0].rows_regressed)
+    again = gpu_lsm(hhlib, *args, want_grid=False)  # and the context is as before
+    assert again[0].persistent_fallbacks == 0 and again[0].price == ok[0].price
+
+
 def test_larger_ensembles_than_the_chip_holds_fall_back_by_themselves(hhlib):
     """More than 256 chunks (> 2^21 trajectories): the persistent form does not apply and the solve
     runs per date, whatever the option says."""
