@@ -397,21 +397,34 @@ constexpr int kLsmStampSlots = 8;
 
 // coefficients of row t into LDS (coef[D+1], *have_fit) from the global sums B[0..D], P[0] = n_itm,
 // P[1..2D] = Pm1[0..]; all threads call it
+// Workgroup barrier for LDS traffic only.  __syncthreads() is a release/acquire fence on ALL memory:
+// with a global store or load outstanding the compiler puts s_waitcnt vmcnt(0) in front of s_barrier,
+// which drains the published record's write-through stores (~1.5 µs) and the NEXT row's prefetch
+// (~2 µs of HBM latency) on every barrier of the persistent induction.  What its barriers order is
+// LDS (partial sums, coefficients); the record protocol has its own vmcnt(0) in front of the tag.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// the solve alone, by the threads of wave 0 (no barrier): coef[D+1], *have_fit
 template <int D>
-__device__ __forceinline__ void fit_row(double n_itm, const double* B, const double* Pm1, double* coef,
-                                        int* have_fit) {
+__device__ __forceinline__ void fit_row_wave0(double n_itm, const double* B, const double* Pm1, double* coef,
+                                              int* have_fit) {
 #if HH_LSM_WAVE_SOLVE
-  if (threadIdx.x < 64) {
-    if (n_itm > 0.0 && !(HH_LSM_DEBUG & 2))
-      solve_normal_equations_wave<D>(B, n_itm, Pm1, coef);  // isempty(in_the_money) && continue (:120)
-    if (threadIdx.x == 0) *have_fit = n_itm > 0.0 ? 1 : 0;
-  }
+  if (n_itm > 0.0 && !(HH_LSM_DEBUG & 2))
+    solve_normal_equations_wave<D>(B, n_itm, Pm1, coef);  // isempty(in_the_money) && continue (:120)
+  if (threadIdx.x == 0) *have_fit = n_itm > 0.0 ? 1 : 0;
 #else
   if (threadIdx.x == 0) {
     if (n_itm > 0.0) solve_normal_equations<D>(B, n_itm, Pm1, coef);
     *have_fit = n_itm > 0.0 ? 1 : 0;
   }
 #endif
+}
+template <int D>
+__device__ __forceinline__ void fit_row(double n_itm, const double* B, const double* Pm1, double* coef,
+                                        int* have_fit) {
+  if (threadIdx.x < 64) fit_row_wave0<D>(n_itm, B, Pm1, coef, have_fit);
   __syncthreads();
 }
 
@@ -679,17 +692,25 @@ constexpr int kDiscLds = 1024;
 // publish group g (0 = A, 1 = B) of this workgroup's record for epoch e: write-through (sc1) stores
 // of its 16 values by the first 16 lanes of ONE wave (wave 0 for A, wave 4 for B), drained, then the
 // group's tag by one lane (Guideline 16, recipe R1).  `val` is the lane's value (lanes >= 16: unused).
-__device__ __forceinline__ void publish_group(const LsmPersistArgs& a, uint32_t e, int g, double val) {
+__device__ __forceinline__ void publish_stores(const LsmPersistArgs& a, uint32_t e, int g, double val) {
   const size_t ring = e % kLsmRing;
   const uint32_t lane = threadIdx.x & 63u;
   if (lane < (uint32_t)kGrp)
     __hip_atomic_store((gu64*)(a.rec + (ring * kRecP2 + g * kGrp + lane) * a.n_chunks + blockIdx.x),
                        (unsigned long long)__double_as_longlong(val), __ATOMIC_RELAXED,
                        __HIP_MEMORY_SCOPE_AGENT);
+}
+// the same wave, later: its stores drained, then the group's tag
+__device__ __forceinline__ void publish_tag(const LsmPersistArgs& a, uint32_t e, int g) {
+  const size_t ring = e % kLsmRing;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if (lane == 0)
+  if ((threadIdx.x & 63u) == 0)
     __hip_atomic_store((gu32*)(a.tags + ((size_t)g * kLsmRing + ring) * kLsmMaxResident + blockIdx.x), e,
                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void publish_group(const LsmPersistArgs& a, uint32_t e, int g, double val) {
+  publish_stores(a, e, g, val);
+  publish_tag(a, e, g);
 }
 // both groups from the workgroup totals tot[32] (the two prologue epochs)
 __device__ __forceinline__ void publish_record(const LsmPersistArgs& a, uint32_t e, const double* tot) {
@@ -705,11 +726,12 @@ __device__ __forceinline__ void publish_record(const LsmPersistArgs& a, uint32_t
 // caller leaves the kernel.
 __device__ __forceinline__ bool gather_records(const LsmPersistArgs& a, uint32_t e, double* scratch,
                                                double* tot, int* ok_flag) {
+  // no barrier on entry (*ok_flag is set once, at the start of the kernel, and only ever cleared): the
+  // waves that poll start at once, whatever another wave of the workgroup is still draining; `scratch`
+  // is the gather's own (gscratch), nobody else writes it
   double v[kGrp];
 #pragma unroll
   for (int i = 0; i < kGrp; ++i) v[i] = 0.0;
-  if (threadIdx.x == 0) *ok_flag = 1;
-  __syncthreads();
   const int wave = threadIdx.x >> 6;
   static_assert(kLsmWg >= 512, "the gather uses 8 waves");
   if (threadIdx.x < 512) {
@@ -753,7 +775,7 @@ __device__ __forceinline__ bool gather_records(const LsmPersistArgs& a, uint32_t
     wave_reduce_multi<kGrp>(v);
     if ((threadIdx.x & 3) == 0) scratch[wave * kGrp + ((threadIdx.x & 63) >> 2)] = v[0];
   }
-  __syncthreads();
+  lds_barrier();
   if (threadIdx.x < kRecP2) {  // the four waves of a group, in order
     const int g = threadIdx.x >> 4, i = threadIdx.x & 15;
     double t = scratch[(4 * g) * kGrp + i];
@@ -761,7 +783,7 @@ __device__ __forceinline__ bool gather_records(const LsmPersistArgs& a, uint32_t
     for (int w = 1; w < 4; ++w) t += scratch[(4 * g + w) * kGrp + i];
     tot[threadIdx.x] = t;
   }
-  __syncthreads();
+  lds_barrier();
   return *ok_flag != 0;
 }
 
@@ -775,7 +797,7 @@ __global__ __launch_bounds__(kLsmWg, (Q * kLsmWg > 1024 ? 2 : 4)) void lsm_persi
     const LsmPersistArgs a) {
   constexpr int N = D + 1;
   static_assert(N <= kOffStats && 2 * D <= kGrp, "record layout");
-  __shared__ double scratch[kLsmWaves * kRecP2], tot[kRecP2], coef[N];
+  __shared__ double scratch[kLsmWaves * kRecP2], gscratch[kLsmWaves * kGrp], tot[kRecP2], coef[N];
   __shared__ double dtab[kDiscLds];  // discount^k, k <= n_steps, when the table fits
   // rows t-1 and t-2 of this workgroup's trajectories wait here (a lane only ever touches its own
   // slots): registers hold the stopping state and row t, the partial sums need the rest
@@ -789,29 +811,53 @@ __global__ __launch_bounds__(kLsmWg, (Q * kLsmWg > 1024 ? 2 : 4)) void lsm_persi
   if (disc_lds)
     for (uint32_t k = threadIdx.x; k <= M; k += kLsmWg) dtab[k] = a.disc_pow[k];
   auto disc = [&](int k) { return disc_lds ? dtab[k] : a.disc_pow[k]; };
+  if (threadIdx.x == 0) ok_flag = 1;
+  __syncthreads();
 
   int tau[Q];
   double val[Q], xs[Q];  // xs = row t, where the next decisions are taken
+  double xin[Q];         // a row on its way from memory: issued one date before it is first used
+  // A lane's 16 slots of a row: byte offsets off0 + j·(512·8), clamped to the row's last trajectory
+  // (never guarded: the loads issue back to back).  The offsets are re-derived from ONE register at
+  // every issue — kept opaque to the compiler, which otherwise hoists the 16 clamped 64-bit addresses
+  // out of the date loop, spills them (the kernel sits at its 256-register budget) and reloads them
+  // from scratch between the loads: every reload's s_waitcnt vmcnt then also waits for the row loads
+  // issued before it, 4 x the HBM latency per date.
+  const uint32_t off_last = (uint32_t)((a.ntot - 1) * 8);
+  uint32_t off0 = (uint32_t)((p0 < a.ntot ? p0 : a.ntot - 1) * 8);
+  auto issue_row = [&](uint32_t row) {
+    const char* Sr = reinterpret_cast<const char*>(row_ptr(row));
+    asm volatile("" : "+v"(off0));
+#pragma unroll
+    for (int j = 0; j < Q; ++j) {
+      const uint32_t o = off0 + (uint32_t)j * (kLsmWg * 8u);
+      xin[j] = *reinterpret_cast<const double*>(Sr + (o < off_last ? o : off_last));
+    }
+  };
   {
     const double* SM = row_ptr(M);
     const double* S1 = row_ptr(M >= 2 ? M - 1 : M);
     const double* S2 = row_ptr(M >= 3 ? M - 2 : M);
+    const double* S3 = row_ptr(M >= 4 ? M - 3 : M);
 #pragma unroll
     for (int j = 0; j < Q; ++j) {
       const uint64_t p = p0 + (uint64_t)j * kLsmWg;
       tau[j] = (int)M;
       val[j] = xs[j] = 0.0;
-      double x2 = 0.0;
+      double x2 = 0.0, x3 = 0.0;
       if (p < a.ntot) {
         const double m = a.cp * (SM[p] - a.strike);  // stopping_info = [(nsteps, payoff(S_T))] (:109)
         val[j] = m > 0.0 ? m : 0.0;
         xs[j] = S1[p];
         x2 = S2[p];
+        x3 = S3[p];
       }
       xl[0][j * kLsmWg + threadIdx.x] = x2;  // row M-2
+      xl[1][j * kLsmWg + threadIdx.x] = x3;  // row M-3
     }
   }
-  int cur = 0;  // xl[cur] = row t-1, xl[cur ^ 1] receives row t-2
+  if (M >= 5) issue_row(M - 4);
+  int cur = 0;  // at date t: xl[cur] = row t-1, xl[cur ^ 1] = row t-2, xin = row t-3
   double regressed = 0.0, skipped = 0.0;
 #if HH_LSM_STAMPS
   unsigned long long st_acc[kLsmStampSlots] = {}, st_t0 = __builtin_amdgcn_s_memrealtime();
@@ -825,28 +871,56 @@ __global__ __launch_bounds__(kLsmWg, (Q * kLsmWg > 1024 ? 2 : 4)) void lsm_persi
 #else
 #define HH_STAMP(k)
 #endif
+  // The pipeline of a date t (epoch e = M - t + 1).  What couples the workgroups is one record per
+  // date; its two halves travel separately, because only one of them depends on the stopping state:
+  //   group A, epoch e   Σ z^k y of row t (k = 0..D; needs the decisions of date t+1)  +  (n, Σx, Σx²) of row t-2
+  //   group B, epoch e   Σ z^k of row t (k = 1..2D): the row and its statistics alone
+  // The CRITICAL path of a date is  gather A_e → normal equations of row t → decisions at row t →
+  // moment sums of row t-1 → workgroup total → publish A_{e+1}.  Everything else runs BEHIND that
+  // publication, while the other workgroups' A records are on their way: the power sums of row t-2
+  // (their statistics arrived with A_e) are published as B_{e+2}, two gathers before they are needed,
+  // and row t-4 is issued from memory.  Statistics therefore run three rows ahead of the decisions,
+  // power sums two, moment sums one.  Same per-trajectory terms and the same summation tree as the
+  // launch-per-date form (bit-identical results); only WHEN a sum is formed differs.
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  // group g of the workgroup's sums out of the waves' partial sums (the waves in order, as
+  // finish_block adds them), straight into the record, by one wave
+  auto total_and_publish = [&](uint32_t e, int g, int by_wave, bool tag_now = true) {
+    if (wave == by_wave) {
+      double t = 0.0;
+      if (lane < kGrp) {
+        t = scratch[g * kGrp + lane];
+#pragma unroll
+        for (int w = 1; w < kLsmWaves; ++w) t += scratch[w * kRecP2 + g * kGrp + lane];
+      }
+      publish_stores(a, e, g, t);
+      if (tag_now) publish_tag(a, e, g);
+    }
+  };
   bool alive = true;
   if (M >= 2) {
-    {  // epoch 1: statistics of row M-1
-      double v[kGrp];
+    {  // epoch 1: statistics of rows M-1 (A) and M-2 (B)
+      double v[kGrp], w[kGrp];
 #pragma unroll
-      for (int i = 0; i < kGrp; ++i) v[i] = 0.0;
+      for (int i = 0; i < kGrp; ++i) v[i] = w[i] = 0.0;
 #pragma unroll
-      for (int j = 0; j < Q; ++j)
+      for (int j = 0; j < Q; ++j) {
         add_stats(xs[j], a.cp, a.strike, live(j), v + kOffStats);
-      double w[kGrp];
-#pragma unroll
-      for (int i = 0; i < kGrp; ++i) w[i] = 0.0;
+        if (M >= 3) add_stats(xl[0][j * kLsmWg + threadIdx.x], a.cp, a.strike, live(j), w);
+      }
       wave_part<kGrp, kRecP2>(v, scratch, 0);
       wave_part<kGrp, kRecP2>(w, scratch, kGrp);
       finish_block<kRecP2, kLsmWaves>(scratch, tot);
       publish_record(a, 1u, tot);
-      alive = gather_records(a, 1u, scratch, tot, &ok_flag);
+      alive = gather_records(a, 1u, gscratch, tot, &ok_flag);
     }
     RowStat r_cur = rowstat_of(tot[kOffStats], tot[kOffStats + 1], tot[kOffStats + 2]);  // row M-1
-    RowStat r_next = r_cur;
+    RowStat r_next = rowstat_of(tot[kGrp], tot[kGrp + 1], tot[kGrp + 2]);                // row M-2
+    RowStat r_nn = r_next;
     __syncthreads();  // tot is rewritten below
-    if (alive) {  // epoch 2: sums of row M-1 (tau = M everywhere), statistics of row M-2
+    if (alive) {
+      // epoch 2: moment sums of row M-1 (tau = M everywhere) + statistics of row M-3 (A), power sums of
+      // row M-1 (B); and the power sums of row M-2 as B of epoch 3
       const double d1 = disc(1);
       {
         double v[kGrp];
@@ -855,7 +929,7 @@ __global__ __launch_bounds__(kLsmWg, (Q * kLsmWg > 1024 ? 2 : 4)) void lsm_persi
 #pragma unroll
         for (int j = 0; j < Q; ++j) {
           add_moments<D>(xs[j], a.cp, a.strike, live(j), r_cur, d1 * val[j], v);
-          if (M >= 3) add_stats(xl[0][j * kLsmWg + threadIdx.x], a.cp, a.strike, live(j), v + kOffStats);
+          if (M >= 4) add_stats(xl[1][j * kLsmWg + threadIdx.x], a.cp, a.strike, live(j), v + kOffStats);
         }
         wave_part<kGrp, kRecP2>(v, scratch, 0);
       }
@@ -870,33 +944,33 @@ __global__ __launch_bounds__(kLsmWg, (Q * kLsmWg > 1024 ? 2 : 4)) void lsm_persi
       }
       finish_block<kRecP2, kLsmWaves>(scratch, tot);
       publish_record(a, 2u, tot);
-    }
-    // Row t-2 of an iteration is loaded one iteration ahead (here: for t = M-1), off the critical path
-    double xin[Q];
-    auto issue_row = [&](uint32_t row) {
-      const double* S2 = row_ptr(row);
+      if (M >= 3) {
+        double w[kGrp];
 #pragma unroll
-      for (int j = 0; j < Q; ++j) {  // clamped, not guarded: 16 loads issue back to back
-        const uint64_t p = p0 + (uint64_t)j * kLsmWg;
-        xin[j] = S2[p < a.ntot ? p : a.ntot - 1];
+        for (int i = 0; i < kGrp; ++i) w[i] = 0.0;
+#pragma unroll
+        for (int j = 0; j < Q; ++j)
+          add_powers_from1<D>(xl[0][j * kLsmWg + threadIdx.x], a.cp, a.strike, live(j), r_next, w);
+        wave_part<kGrp, kRecP2>(w, scratch, kGrp);  // finish_block's last barrier is behind every read of scratch
+        __syncthreads();
+        total_and_publish(3u, 1, 4);
       }
-    };
-    if (alive && M >= 4) issue_row(M - 3);
+    }
     // for i = nsteps:-1:2, t = i-1 (:112-113).
-    // What a date's critical path carries — gather of group A → normal equations → decisions →
-    // moment sums of row t-1 → their workgroup total → publish A — and what it does not: the power
-    // sums of row t-1 depend on the row and its statistics alone, not on the stopping state, and are
-    // needed one date LATER (the fit of row t-1).  They are formed, totalled and published as group B
-    // behind the publication of A, i.e. while the other workgroups' A records are on their way, and the
-    // next row's loads are issued there too.  Same values, same summation tree as before.
+    // All workgroups run the same schedule, so a record published while the publisher still has work
+    // of its own to do is not waited for by anybody: wave 0 issues the stores of group A, forms its
+    // power sums like every other wave, and only then drains the stores and raises the tag — by the
+    // time another workgroup polls (it has the same power sums to form first) the tag is there.  Group
+    // B is drained by wave 4 beside the next gather, which has no barrier on entry.
     for (uint32_t t = M - 1; alive && t >= 1; --t) {
       const uint32_t e = M - t + 1;  // epoch whose records hold the sums of row t
       HH_STAMP(7)
-      alive = gather_records(a, e, scratch, tot, &ok_flag);
+      alive = gather_records(a, e, gscratch, tot, &ok_flag);
       HH_STAMP(1)  // all-gather: wait, loads, reduction
       if (!alive) break;
-      if (t >= 2) r_next = rowstat_of(tot[kOffStats], tot[kOffStats + 1], tot[kOffStats + 2]);  // row t-1
-      fit_row<D>(r_cur.n, tot, tot + kGrp, coef, &have_fit);  // Gram entries: P[0] = n, P[k] = group B
+      if (t >= 3) r_nn = rowstat_of(tot[kOffStats], tot[kOffStats + 1], tot[kOffStats + 2]);  // row t-2
+      if (wave == 0) fit_row_wave0<D>(r_cur.n, tot, tot + kGrp, coef, &have_fit);  // Gram: P[0] = n, P[k] = group B
+      lds_barrier();
       HH_STAMP(2)  // normal equations
       if (r_cur.n > 0.0) regressed += 1.0; else skipped += 1.0;
       if (have_fit) {
@@ -910,64 +984,64 @@ __global__ __launch_bounds__(kLsmWg, (Q * kLsmWg > 1024 ? 2 : 4)) void lsm_persi
       }
       HH_STAMP(3)  // exercise decisions
       if (t >= 2) {
-        // sums of row t-1 (xl[cur]) with the stopping state as of now; statistics of row t-2 (sv);
-        // row t-1 moves into the registers on the way: it is the next decision row
+        // row t-1 moves from LDS into the registers (the next decision row) and its moment sums are
+        // formed with the stopping state as of now; row t-3 has landed: it takes the freed LDS slots
+        // (a lane only ever touches its own) and leaves its statistics
 #pragma unroll
         for (int j = 0; j < Q; ++j) xs[j] = xl[cur][j * kLsmWg + threadIdx.x];
         if (!(HH_LSM_DEBUG & 4)) {
-        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
         {
           double v[kGrp];
 #pragma unroll
           for (int i = 0; i < kGrp; ++i) v[i] = 0.0;
-          if (t >= 3) {  // row t-2 has landed: park it in LDS (it becomes row t-1 next), its statistics
+          if (t >= 4) {
 #pragma unroll
             for (int j = 0; j < Q; ++j) {
-              xl[cur ^ 1][j * kLsmWg + threadIdx.x] = xin[j];
+              xl[cur][j * kLsmWg + threadIdx.x] = xin[j];
               add_stats(xin[j], a.cp, a.strike, live(j), v + kOffStats);
             }
           }
+          // discount^(tau - (t-1)): from the LDS table or from memory — two copies of the loop, not a
+          // select per lookup: `disc_lds ? dtab[k] : a.disc_pow[k]` compiles to FLAT loads of a selected
+          // address, each followed by s_waitcnt vmcnt(0) lgkmcnt(0) (16 serialised round trips per date,
+          // every one of them also waiting for the record stores and the row prefetch in flight)
+          auto moments = [&](auto disc_of) {
+            double y[Q];
 #pragma unroll
-          for (int j = 0; j < Q; ++j)
-            add_moments<D>(xs[j], a.cp, a.strike, live(j), r_next, disc(tau[j] - (int)(t - 1)) * val[j], v);
+            for (int j = 0; j < Q; ++j) y[j] = disc_of(tau[j] - (int)(t - 1)) * val[j];
+#pragma unroll
+            for (int j = 0; j < Q; ++j) add_moments<D>(xs[j], a.cp, a.strike, live(j), r_next, y[j], v);
+          };
+          if (disc_lds) moments([&](int k) { return dtab[k]; });
+          else moments([&](int k) { return a.disc_pow[k]; });
           wave_part<kGrp, kRecP2>(v, scratch, 0);
         }
         HH_STAMP(4)  // moment sums + their wave butterfly
-        __syncthreads();
-        if (wave == 0) {  // group A: the waves in order (as finish_block), straight into the record
-          double tA = 0.0;
-          if (lane < kGrp) {
-            tA = scratch[lane];
-#pragma unroll
-            for (int w = 1; w < kLsmWaves; ++w) tA += scratch[w * kRecP2 + lane];
-          }
-          publish_group(a, e + 1, 0, tA);
-        }
-        HH_STAMP(6)  // workgroup total of A, publish  — the date's critical path ends here
-        {
+        lds_barrier();
+        total_and_publish(e + 1, 0, 0, /*tag_now=*/t < 3);  // wave 0: the stores of A are on their way
+        HH_STAMP(6)  // workgroup total of A, stores issued
+        if (t >= 3) {  // power sums of row t-2 (xl[cur ^ 1]): B of epoch e+2, needed by the fit of date t-2
           double w[kGrp];
 #pragma unroll
           for (int i = 0; i < kGrp; ++i) w[i] = 0.0;
 #pragma unroll
-          for (int j = 0; j < Q; ++j) add_powers_from1<D>(xs[j], a.cp, a.strike, live(j), r_next, w);
+          for (int j = 0; j < Q; ++j)
+            add_powers_from1<D>(xl[cur ^ 1][j * kLsmWg + threadIdx.x], a.cp, a.strike, live(j), r_nn, w);
+          __builtin_amdgcn_sched_barrier(0);  // the tag goes out BEHIND the power sums, not before them
+          if (wave == 0) publish_tag(a, e + 1, 0);  // drained long ago: the date's critical path ends here
           wave_part<kGrp, kRecP2>(w, scratch, kGrp);
         }
-        HH_STAMP(5)  // power sums + their wave butterfly
-        __syncthreads();
-        if (wave == 4) {
-          double tB = 0.0;
-          if (lane < kGrp) {
-            tB = scratch[kGrp + lane];
-#pragma unroll
-            for (int w = 1; w < kLsmWaves; ++w) tB += scratch[w * kRecP2 + kGrp + lane];
-          }
-          publish_group(a, e + 1, 1, tB);
+        HH_STAMP(5)  // power sums + their wave butterfly, tag of A
         }
+        if (t >= 5) issue_row(t - 4);  // row (t-1)-3: lands, is parked and leaves its statistics at date t-1
+        if (t >= 3 && !(HH_LSM_DEBUG & 4)) {
+          lds_barrier();
+          total_and_publish(e + 2, 1, 4);  // wave 4; its drain runs beside the next gather
         }
-        if (t >= 4) issue_row(t - 3);  // row (t-1)-2 of the next iteration
-        HH_STAMP(0)  // group B, next row issued
+        HH_STAMP(0)  // next row issued, group B total + publish
         cur ^= 1;
         r_cur = r_next;
+        r_next = r_nn;
       }
     }
   }

@@ -18,8 +18,8 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-PHASES = ["row t-2 + stats", "all-gather", "solve", "decisions", "moment sums", "power sums",
-          "totals+publish", "loop overhead"]
+PHASES = ["B total+publish, next row issue (hidden)", "all-gather", "solve", "decisions", "moment sums + stats",
+          "power sums (hidden)", "A total+publish", "loop overhead"]
 
 
 def child(sizes):
@@ -56,8 +56,10 @@ def main():
     os.makedirs(vdir, exist_ok=True)
     for i, flags in enumerate(variants):
         lib = os.path.join(vdir, f"libhh_lsmdbg{i}.so")
-        cmd = [b._hipcc(), *b.FLAGS, *flags, *[os.path.join(b.CSRC, s) for s in b.SOURCES], "-o", lib]
-        subprocess.run(cmd, check=True, capture_output=True)
+        if not os.path.exists(lib) or os.environ.get("HH_REBUILD"):  # cross-compiled here, run on the GPU box
+            b.build_library(extra_flags=tuple(flags), out=lib)
+        if os.environ.get("HH_BUILD_ONLY"):
+            continue
         print("== " + " ".join(flags), flush=True)
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", *sizes],
                            env=dict(os.environ, HEDGEHOG_MC_LIB=lib), capture_output=True, text=True)
