@@ -127,6 +127,7 @@ SYMBOLS = [
     ("hh_ctx_synchronize", C.c_int, [_vp]),
     ("hh_ctx_enable_timing", C.c_int, [_vp, C.c_int32]),
     ("hh_ctx_read_timings", C.c_int, [_vp, _vp, C.c_int32, C.POINTER(C.c_int32)]),
+    ("hh_bk_decisions", C.c_int, [_vp, C.c_uint64, _vp, _vp]),
     ("hh_mgpu_create", C.c_int, [C.POINTER(_vp), C.POINTER(C.c_int), C.c_int, C.c_int]),
     ("hh_mgpu_destroy", None, [_vp]),
     ("hh_mgpu_last_error", C.c_char_p, [_vp]),

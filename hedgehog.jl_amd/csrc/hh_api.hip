@@ -311,6 +311,8 @@ static int run_simulation(hh_ctx* ctx, const hh_model* m, const hh_config* c, do
     p.bk_scratch = ctx->bk_scratch;
     p.bk_table_key = &ctx->bk_table_key;
     p.bk_term_cache = ctx->bk_term_cache;
+    ctx->bk_last_n = c->n_paths;
+    ctx->bk_last_cache = ctx->bk_term_cache;
   }
 
   // seeds: per-trajectory for Euler (montecarlo.jl:331), seeds[1] only for the exact laws (:456)
@@ -567,6 +569,23 @@ int hh_mc_solve(hh_ctx* ctx, const hh_model* m, const hh_config* c, hh_result* o
   out->kernel_ms = ms;
   out->total_ms =
       std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  return HH_OK;
+}
+
+int hh_bk_decisions(hh_ctx* ctx, uint64_t n_paths, uint32_t* decisions, uint32_t* series_len) {
+  if (!ctx) return HH_ERR_INVALID;
+  std::lock_guard<std::recursive_mutex> lock__(ctx->mu);
+  if (!ctx->bk_scratch || ctx->bk_last_n == 0 || n_paths != ctx->bk_last_n)
+    return fail(ctx, HH_ERR_INVALID, "hh_bk_decisions: the last Broadie-Kaya solve of this context had %llu trajectories",
+                (unsigned long long)ctx->bk_last_n);
+  HH_HIP(ctx, hipSetDevice(ctx->device));
+  const uint32_t *dec = nullptr, *len = nullptr;
+  hh::bk_diag_ptrs(ctx->bk_scratch, n_paths, ctx->bk_last_cache, &dec, &len);
+  if (decisions)
+    HH_HIP(ctx, hipMemcpyAsync(decisions, dec, n_paths * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+  if (series_len)
+    HH_HIP(ctx, hipMemcpyAsync(series_len, len, n_paths * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+  HH_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return HH_OK;
 }
 

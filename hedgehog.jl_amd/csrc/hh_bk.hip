@@ -38,9 +38,22 @@ namespace {
 constexpr double kPi = kBesselPi;
 constexpr double kTwoPi = kBesselTwoPi;
 
-constexpr int kPackedGrid = 256;  // workgroups of the packed (grid-stride) ladder kernel
-constexpr int kHeavyGrid = 512;   // … of the fall-back kernel: 2 per CU, what its 246 registers let be resident (it is empty
+#ifndef HH_BK_SLOTS
+#define HH_BK_SLOTS 1024
+#endif
+#ifndef HH_BK_HEAVY_GRID
+#define HH_BK_HEAVY_GRID 64
+#endif
+// Columns of cached series terms.  A lane's column belongs to a workgroup SLOT that a workgroup of the
+// CF kernel (or of the ladder kernel behind it) takes when it starts and gives back when it is done —
+// not to the trajectory: the cache is kSlots x 256 columns however many trajectories the chain has
+// (1024 slots = the 4 workgroups per CU that can be resident; 256 terms of 8 bytes: 0.54 GB for 10^4 and
+// for 10^8 trajectories alike).  A trajectory's terms are only needed again if its secant fails (2 % of
+// them): the ladder kernel re-derives those.
+constexpr int kSlots = HH_BK_SLOTS;
+constexpr int kHeavyGrid = HH_BK_HEAVY_GRID;   // workgroups of the fall-back kernel (246 registers; it is empty
                                   // with the reference's controls, and the whole job when no series fits the term cache)
+static_assert(kHeavyGrid <= kSlots, "the fall-back kernel's workgroup b uses slot b");
 
 struct BkTables {
   BesselTable t[2];  // order ν, base order ν0
@@ -83,14 +96,18 @@ struct BkArgs {
   double* draws;                   // [4][draw_stride]: Z, u, normal quantile of u, V_T per trajectory
   size_t draw_stride;
   const double* replay;            // REPLAY: the caller's [3][n_paths] V_T, u, Z (device), else NULL
-  double* rec;                     // [4][draw_stride]: h, initial_guess, max_guess, series length
+  double* iv_store;                // [draw_stride]: where a grid chain keeps the sampled ∫V of its pairs (iv_out)
   unsigned long long* fail_mask;   // [n_tiles][4] ballots: secant failed, the ladder is left (bk_ladder_kernel)
   unsigned long long* long_mask;   // [n_tiles][4] ballots: series longer than the cache, not inverted yet
                                    //              (bk_fallback_kernel runs these whole)
   uint32_t* tile_counts;           // [n_tiles] set bits of a tile's ballots: fail | long << 16
-  double* phi_cache;               // [cache_cap][cache_stride] cached Re ϕ(h·j), one column per lane
-  size_t cache_stride;
+  double* phi_cache;               // [cache_cap][cache_stride] cached Re ϕ(h·j), one column per lane of a
+  size_t cache_stride;             //   workgroup SLOT (kSlots·256 columns), not per trajectory
   int cache_cap;
+  uint32_t* slot_busy;             // slot bitmaps, one 128-byte line per XCD: 0 free / 1 taken (zeroed per launch)
+  uint32_t static_slots;           // 1: the chain has at most kSlots tiles, slot = tile (no bitmap)
+  uint32_t n_tiles;
+  uint32_t* diag;                  // [2][draw_stride] per trajectory: decision word (BkDecision), series length
   void* args_dev;                  // a copy of this struct in device memory (written by bk_scan_kernel)
                                    // for bk_fallback_kernel, whose code is too large to inline: passing
                                    // a by-value kernel argument by reference to its functions would put
@@ -399,8 +416,8 @@ struct PathSetup {
 };
 
 __device__ void bk_setup(const BkArgs& p, const BesselTable* bt, uint64_t path, PathSetup& s) {
-  s.cache.col = p.phi_cache + path;  // the trajectory's own column, filled again from the start
-  s.cache.stride = p.cache_stride;
+  s.cache.col = p.phi_cache + (size_t)blockIdx.x * kTile + threadIdx.x;  // slot b of workgroup b: this kernel
+  s.cache.stride = p.cache_stride;                                        // runs alone, behind the other two
   s.cache.cap = p.cache_cap;
   s.cache.filled = 0;
   s.cache.j_stop = 0;
@@ -502,9 +519,22 @@ __device__ __forceinline__ void bk_store_record(double (&acc)[6], double* rec, u
 
 // secant of inverse_cdf (sample_from_cf.jl:116-122) on a CDF given as a callable: Order2 restated as
 // the secant iteration from (x0 + dx, x0), dx = h + |x0| h², h = eps^(1/3)
+// A trajectory's decision word (BkArgs::diag, hh_bk_decisions): what the root search of inverse_cdf
+// DID — the number of CDF evaluations of the secant, which branch finished it, the bisection's
+// iterations.  Two implementations that agree on this word (and on the series length) have run the
+// same sequence of floating-point operations up to rounding; where they differ, a stopping test sat
+// within rounding of its threshold.
+enum BkDecision : uint32_t {
+  kDecEvalsMask = 0xffu,        // CDF evaluations of the secant iteration (2 … newton_maxiter)
+  kDecBisect = 1u << 8,         // secant failed, bisection finished it (sample_from_cf.jl:127-133)
+  kDecMaxGuess = 2u << 8,       // secant failed, no sign change: max_guess (:124-126)
+  kDecItersShift = 16,          // bits 16-23: bisection iterations
+  kDecLongSeries = 1u << 31     // series longer than the term cache: ran whole in bk_fallback_kernel
+};
+
 template <class Cdf>
 __device__ __forceinline__ bool secant_inverse(Cdf&& cdf, double u, double guess, double atol,
-                                               int maxiter, double& root) {
+                                               int maxiter, double& root, uint32_t& evals_out) {
   const double hs = 6.0554544523933395e-06;
   double x1 = guess;
   double x0 = x1 + hs + fabs(x1) * hs * hs;
@@ -527,6 +557,7 @@ __device__ __forceinline__ bool secant_inverse(Cdf&& cdf, double u, double guess
     ++evals;
   }
   root = x1;
+  evals_out = (uint32_t)evals;
   return ok && !(x1 < 0.0);
 }
 
@@ -538,23 +569,22 @@ __device__ __forceinline__ bool secant_inverse(Cdf&& cdf, double u, double guess
 // is what fits 128 registers (4 waves per SIMD).  Returns h, the secant's first guess and the series
 // length (0: longer than the cache — the fall-back kernel runs this trajectory whole); leaves them
 // with max_guess in rec[] for the ladder kernel.
-__device__ __forceinline__ void series_phase(const BkArgs& p, const BesselTable* bt, uint64_t path, double& h, double& initial_guess,
-                                             int& j_stop) {
+__device__ __forceinline__ void series_phase(const BkArgs& p, const BesselTable* bt, uint64_t path, double* col,
+                                             size_t col_stride, double& h, double& initial_guess,
+                                             double& max_guess, int& j_stop) {
   const bool grid = p.in_var != nullptr;
   const double V0 = grid ? p.in_var[path] : p.V0;
   const double* d = p.draws + path;
   const double q_u = d[2 * p.draw_stride];
   const double VT = d[3 * p.draw_stride];
   CfIter cf;
-  double max_guess;
   cf_setup(p, bt, V0, VT, q_u, cf, initial_guess, max_guess, h);
-  double* col = p.phi_cache + path;
   const double stop = kPi * p.cf_tol / 2.0;
   double theta = __builtin_nan("");
   j_stop = 0;
   for (int j = 1; j <= p.cache_cap; ++j) {
     const cx phi = evaluate_chf(p, bt, cf, h * (double)j, theta);
-    col[(size_t)(j - 1) * p.cache_stride] = phi.re;
+    col[(size_t)(j - 1) * col_stride] = phi.re;
     const double sj = stop * (double)j;
     const double mag2 = fma(phi.re, phi.re, phi.im * phi.im);
     if (!(mag2 >= sj * sj && mag2 <= 0x1p200)) {  // |ϕ|/j < π·tol/2, squared; also leaves on NaN / overflow
@@ -562,11 +592,6 @@ __device__ __forceinline__ void series_phase(const BkArgs& p, const BesselTable*
       break;
     }
   }
-  double* r = p.rec + path;
-  r[0] = h;
-  r[p.draw_stride] = initial_guess;
-  r[2 * p.draw_stride] = max_guess;
-  r[3 * p.draw_stride] = (double)j_stop;
 }
 
 // The first kRegTerms series terms of a trajectory, held in registers for all the CDF evaluations of
@@ -619,21 +644,24 @@ __device__ __forceinline__ double cdf_cached(const double (&t)[kRegTerms], const
 // so is a trajectory whose series did not fit the cache (bk_fallback_kernel).  Flags are ballots in
 // trajectory order, so the result is bit-reproducible.  Called by every thread of the workgroup.
 __device__ __forceinline__ void invert_phase(const BkArgs& p, uint32_t tile, uint32_t tid, uint64_t path,
-                                             bool live, double h, double guess, int j_stop) {
+                                             bool live, const double* col, double h, double guess, int j_stop) {
   double acc[6] = {0, 0, 0, 0, 0, 0};  // Σp, Σp², newton_fail, bisect, maxguess, cf_terms
   bool failed = false, too_long = false;
   if (live) {
     const double u = p.draws[p.draw_stride + path];
+    p.diag[p.draw_stride + path] = (uint32_t)j_stop;
     if (j_stop == 0) {
       too_long = true;
+      p.diag[path] = kDecLongSeries;
     } else {
-      const double* col = p.phi_cache + path;
       double t[kRegTerms];
       load_terms(col, p.cache_stride, j_stop, t);
       double n_terms = 0.0, IV;
+      uint32_t evals = 0;
       const bool ok = secant_inverse(
           [&](double x) { return cdf_cached(t, col, p.cache_stride, j_stop, h, x, n_terms); }, u, guess,
-          p.atol, p.newton_maxiter, IV);
+          p.atol, p.newton_maxiter, IV, evals);
+      p.diag[path] = evals;
       acc[5] = n_terms;
       if (ok) {
         const bool grid = p.in_var != nullptr;
@@ -657,53 +685,91 @@ __device__ __forceinline__ void invert_phase(const BkArgs& p, uint32_t tile, uin
   bk_store_record(acc, p.records + (size_t)tile * kRecStride, p.tile_counts + tile, too_long ? 1.0 : 0.0);
 }
 
-// Two forms of the CF work (HH_BK_FUSED):
-//  1  ONE kernel, series phase then inversion phase per trajectory.  The inversion re-reads the terms
-//     the lane has just written (L2 hits) while other waves of the CU are still in their series phase,
-//     so its memory latency — 2/3 of a stand-alone inversion kernel's time — hides behind their
-//     arithmetic; the series state is dead by then, so the register count is the series phase's.
-//  0  two kernels, bk_series_kernel then bk_invert_kernel.
-#ifndef HH_BK_FUSED
-#define HH_BK_FUSED 1
-#endif
+// A workgroup's slot of the term cache.
+//  * Chains of at most kSlots tiles: slot = tile, nothing shared, nothing to take.
+//  * Longer chains: the slots are REUSED, and a reused column must stay inside one XCD — the L2s of the
+//    eight XCDs are write-back and not coherent with each other, so a dirty line of a column's previous
+//    owner on another XCD could be written back over the new owner's terms (seen: 1 trajectory in 10^6
+//    moved when it was allowed).  Each XCD therefore owns kSlots / 8 slots (its 32 CUs hold 4 workgroups
+//    each = 128), as a bitmap of two 64-bit words in a 128-byte line of its own.  Wave 0 reads the XCD's
+//    words, lane 0 claims a free bit with an atomic OR (which returns the word's current state when
+//    somebody else was faster), the slot goes to the other waves through LDS and is given back (atomic
+//    AND) at the end.  A slot's holder never waits for anything, so a workgroup that finds every slot
+//    taken only waits for another one to finish: no deadlock however the hardware places workgroups.
+constexpr int kXcds = 8, kSlotsPerXcd = kSlots / kXcds, kSlotLineWords = 16;  // 128-byte line per XCD
+static_assert(kSlotsPerXcd % 64 == 0 && kSlotsPerXcd / 64 <= kSlotLineWords, "whole bitmap words, one line per XCD");
+__device__ __forceinline__ uint32_t take_slot(const BkArgs& p, uint32_t own) {
+  if (p.static_slots) return own;  // uniform
+  __shared__ uint32_t slot_sh;
+  if (threadIdx.x == 0) {
+    // HW_REG_XCC_ID (hwreg 20), bits 3:0: the XCD this workgroup runs on
+    const uint32_t xcc = (uint32_t)__builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20) % (uint32_t)kXcds;
+    unsigned long long* bm = reinterpret_cast<unsigned long long*>(p.slot_busy) + (size_t)xcc * kSlotLineWords;
+    constexpr uint32_t kWords = kSlotsPerXcd / 64;
+    // Start at the bit this workgroup would own if the slots were dealt out in order (workgroups go to the
+    // XCDs round-robin by their index): the first kSlotsPerXcd workgroups of an XCD then start on
+    // kSlotsPerXcd different bits — picking the LOWEST free bit instead makes them all claim bit 0, then
+    // bit 1, …: O(n²) serialised atomics on one line when the grid starts (0.1 ms at 128 per XCD).
+    const uint32_t h = (own / (uint32_t)kXcds) % (uint32_t)kSlotsPerXcd;
+    uint32_t wi = h >> 6, rot = h & 63u, slot = 0;
+    unsigned long long wv = __hip_atomic_load(bm + wi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (true) {
+      if (~wv == 0ull) {  // this word is full: look at the next one
+        wi = wi + 1 == kWords ? 0u : wi + 1;
+        rot = 0;
+        __builtin_amdgcn_s_sleep(2);
+        wv = __hip_atomic_load(bm + wi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        continue;
+      }
+      const unsigned long long fr = ~wv;                                   // free bits
+      const unsigned long long rr = rot ? (fr >> rot) | (fr << (64u - rot)) : fr;  // … seen from bit `rot`
+      const uint32_t bit = (rot + (uint32_t)__ffsll((long long)rr) - 1u) & 63u;
+      const unsigned long long old = atomicOr(bm + wi, 1ull << bit);
+      if (((old >> bit) & 1ull) == 0ull) {
+        slot = xcc * (uint32_t)kSlotsPerXcd + wi * 64u + bit;
+        break;
+      }
+      wv = old | (1ull << bit);
+    }
+    slot_sh = slot;
+  }
+  __syncthreads();
+  return slot_sh;
+}
+__device__ __forceinline__ void give_slot(const BkArgs& p, uint32_t slot) {
+  if (p.static_slots) return;
+  __syncthreads();  // every lane is done with its column
+  if (threadIdx.x == 0) {
+    const uint32_t xcc = slot / (uint32_t)kSlotsPerXcd, r = slot % (uint32_t)kSlotsPerXcd;
+    atomicAnd(reinterpret_cast<unsigned long long*>(p.slot_busy) + (size_t)xcc * kSlotLineWords + (r >> 6),
+              ~(1ull << (r & 63u)));
+  }
+}
+
+// The CF kernel: series phase then inversion phase per trajectory, one tile per workgroup.
+// The inversion re-reads the terms the lane has just written (L2 hits) while other waves of the CU are
+// still in their series phase, so its memory latency — 2/3 of a stand-alone inversion kernel's time —
+// hides behind their arithmetic; the series state is dead by then, so the register count is the series
+// phase's.
 // (tabs: the Bessel tables, a `const __restrict__` kernel argument of its own so that the compiler
 // knows them read-only and un-aliased: their uniform-index reads are then scalar loads, as they were
 // from the argument block; staged in LDS instead, the per-order scalars and the coefficients in
 // flight sit in VGPRs and the kernel needs 192)
+// (one tile per workgroup, NOT a grid-stride loop over the tiles: with a loop around this body the compiler
+// hoists loop-invariant table values into 215-247 registers — measured — and halves the occupancy)
 __global__ __launch_bounds__(kTile) void bk_cf_kernel(const BkArgs p, const BkTables* __restrict__ tabs) {
   const uint32_t tile = blockIdx.x, tid = threadIdx.x;
   const uint64_t path = (uint64_t)tile * kTile + tid;
   const bool live = path < p.n_paths;
   const BesselTable* bt = tabs->t;
-  double h = 0.0, guess = 0.0;
+  const uint32_t slot = take_slot(p, tile);
+  double* col = p.phi_cache + (size_t)slot * kTile + tid;
+  double h = 0.0, guess = 0.0, max_guess = 0.0;
   int j_stop = 0;
-  if (live) series_phase(p, bt, path, h, guess, j_stop);
-  invert_phase(p, tile, tid, path, live, h, guess, j_stop);
+  if (live) series_phase(p, bt, path, col, p.cache_stride, h, guess, max_guess, j_stop);
+  invert_phase(p, tile, tid, path, live, col, h, guess, j_stop);
+  give_slot(p, slot);
 }
-#if !HH_BK_FUSED
-__global__ __launch_bounds__(kTile) void bk_series_kernel(const BkArgs p, const BkTables* __restrict__ tabs) {
-  const uint64_t path = (uint64_t)blockIdx.x * kTile + threadIdx.x;
-  const BesselTable* bt = tabs->t;
-  if (path >= p.n_paths) return;
-  double h, guess;
-  int j_stop;
-  series_phase(p, bt, path, h, guess, j_stop);
-}
-__global__ __launch_bounds__(kTile) void bk_invert_kernel(const BkArgs p) {
-  const uint32_t tile = blockIdx.x, tid = threadIdx.x;
-  const uint64_t path = (uint64_t)tile * kTile + tid;
-  const bool live = path < p.n_paths;
-  double h = 0.0, guess = 0.0;
-  int j_stop = 0;
-  if (live) {
-    const double* r = p.rec + path;
-    h = r[0];
-    guess = r[p.draw_stride];
-    j_stop = (int)r[3 * p.draw_stride];
-  }
-  invert_phase(p, tile, tid, path, live, h, guess, j_stop);
-}
-#endif
 
 // exclusive prefix sums of the per-tile counts of both ballot arrays (the inversion phase leaves the counts,
 // 4 bytes per tile: a single workgroup reading the 64 bytes of ballots per tile instead is bound by
@@ -792,35 +858,52 @@ __device__ __forceinline__ uint64_t packed_path(const unsigned long long* mask, 
 }
 
 // Ladder kernel: the fall-back of inverse_cdf (sample_from_cf.jl:123-133) for the trajectories whose
-// secant failed, densely packed (one per lane, in trajectory order), on the cached series terms —
-// no characteristic-function arithmetic, so it is as light as the inversion kernel.  Work items are
-// taken with a grid stride: the grid does not depend on how many there are.
-__global__ __launch_bounds__(kTile) void bk_ladder_kernel(const BkArgs p, uint32_t n_tiles,
+// secant failed, densely packed (one per lane, in trajectory order).  The CF kernel's column of such a
+// trajectory has long been reused, so its series is evaluated again here — same operations, same
+// terms — into the column of the slot THIS workgroup takes, and the ladder then runs on the cached
+// terms.  2 % of the trajectories x the series' share of the CF work: ~7 µs of the chip.  One work item
+// per lane, no loop (see bk_cf_kernel): the grid covers the worst case (every trajectory failed) and the
+// workgroups beyond the packed list leave at once with an empty record.
+__global__ __launch_bounds__(kTile) void bk_ladder_kernel(const BkArgs p, const BkTables* __restrict__ tabs,
+                                                          uint32_t n_tiles,
                                                           const uint32_t* __restrict__ prefix) {
   const uint32_t total = prefix[n_tiles];
+  double* rec = p.records + (size_t)(n_tiles + blockIdx.x) * kRecStride;
+  if (blockIdx.x * (uint32_t)kTile >= total) {  // uniform
+    if (threadIdx.x < (uint32_t)kRecStride) rec[threadIdx.x] = 0.0;
+    return;
+  }
+  const BesselTable* bt = tabs->t;
+  const uint32_t slot = take_slot(p, blockIdx.x);
+  double* col = p.phi_cache + (size_t)slot * kTile + threadIdx.x;
+  const size_t stride = p.cache_stride;
   double acc[6] = {0, 0, 0, 0, 0, 0};
-  for (uint32_t g = blockIdx.x * kTile + threadIdx.x; g < total; g += gridDim.x * kTile) {
+  const uint32_t g = blockIdx.x * kTile + threadIdx.x;
+  if (g < total) {
     const uint64_t path = packed_path(p.fail_mask, prefix, n_tiles, g);
-    const double* r = p.rec + path;
-    const double h = r[0], max_guess = r[2 * p.draw_stride];
-    const int j_stop = (int)r[3 * p.draw_stride];
+    double h, guess, max_guess;
+    int j_stop;
+    series_phase(p, bt, path, col, stride, h, guess, max_guess, j_stop);
     const double u = p.draws[p.draw_stride + path];
-    const double* col = p.phi_cache + path;
     double t[kRegTerms];
-    load_terms(col, p.cache_stride, j_stop, t);
+    load_terms(col, stride, j_stop, t);
     double n_terms = 0.0, IV;
-    auto cdf = [&](double x) { return cdf_cached(t, col, p.cache_stride, j_stop, h, x, n_terms); };
+    auto cdf = [&](double x) { return cdf_cached(t, col, stride, j_stop, h, x, n_terms); };
     double fa = cdf(0.0) - u;
     const double fb = cdf(max_guess) - u;
+    uint32_t dec = p.diag[path];
     if (fa * fb > 0.0) {
       acc[4] += 1.0;
       IV = max_guess;  // sample_from_cf.jl:124-126
+      dec |= kDecMaxGuess;
     } else {
       acc[3] += 1.0;
       double lo_x = 0.0, hi_x = max_guess;
+      uint32_t iters = 0;
       for (int i = 0; i < p.bisect_maxiter; ++i) {
         const double mid = 0.5 * (lo_x + hi_x);
         const double fm = cdf(mid) - u;
+        ++iters;
         if (fm == 0.0) {
           lo_x = hi_x = mid;
           break;
@@ -834,7 +917,9 @@ __global__ __launch_bounds__(kTile) void bk_ladder_kernel(const BkArgs p, uint32
         if (hi_x - lo_x <= p.atol) break;
       }
       IV = 0.5 * (lo_x + hi_x);
+      dec |= kDecBisect | ((iters & 0xffu) << kDecItersShift);
     }
+    p.diag[path] = dec;
     acc[5] += n_terms;
     const bool grid = p.in_var != nullptr;
     const double V0 = grid ? p.in_var[path] : p.V0;
@@ -843,7 +928,8 @@ __global__ __launch_bounds__(kTile) void bk_ladder_kernel(const BkArgs p, uint32
     acc[0] += pay;
     acc[1] = fma(pay, pay, acc[1]);
   }
-  bk_store_record(acc, p.records + (size_t)(n_tiles + blockIdx.x) * kRecStride);
+  bk_store_record(acc, rec);
+  give_slot(p, slot);
 }
 
 // Fall-back kernel: trajectories whose series did not fit the cache (cf_tol far below the reference's
@@ -864,9 +950,11 @@ __global__ __launch_bounds__(kTile) void bk_fallback_kernel(const BkArgs* __rest
     bk_setup(p, bt, path, s);
     double n_terms = 0.0;
     double IV;
+    uint32_t dec = 0, iters = 0;
     const bool done =
         secant_inverse([&](double x) { return cdf_from_cf(p, bt, s.cf, x, s.h, s.cache, n_terms); }, s.u,
-                       s.initial_guess, p.atol, p.newton_maxiter, IV);
+                       s.initial_guess, p.atol, p.newton_maxiter, IV, dec);
+    dec |= kDecLongSeries;
     if (!done) {  // the fall-back ladder (sample_from_cf.jl:123-133)
       acc[2] += 1.0;
       double fa = cdf_from_cf(p, bt, s.cf, 0.0, s.h, s.cache, n_terms) - s.u;
@@ -874,12 +962,15 @@ __global__ __launch_bounds__(kTile) void bk_fallback_kernel(const BkArgs* __rest
       if (fa * fb > 0.0) {
         acc[4] += 1.0;
         IV = s.max_guess;  // sample_from_cf.jl:124-126
+        dec |= kDecMaxGuess;
       } else {
         acc[3] += 1.0;
+        dec |= kDecBisect;
         double lo_x = 0.0, hi_x = s.max_guess;
         for (int i = 0; i < p.bisect_maxiter; ++i) {
           const double mid = 0.5 * (lo_x + hi_x);
           const double fm = cdf_from_cf(p, bt, s.cf, mid, s.h, s.cache, n_terms) - s.u;
+          ++iters;
           if (fm == 0.0) {
             lo_x = hi_x = mid;
             break;
@@ -893,14 +984,17 @@ __global__ __launch_bounds__(kTile) void bk_fallback_kernel(const BkArgs* __rest
           if (hi_x - lo_x <= p.atol) break;
         }
         IV = 0.5 * (lo_x + hi_x);
+        dec |= (iters & 0xffu) << kDecItersShift;
       }
     }
+    p.diag[path] = dec;
+    p.diag[p.draw_stride + path] = (uint32_t)s.cache.j_stop;
     acc[5] += n_terms;
     const double pay = bk_finish(p, s.logS0, s.V0, s.VT, s.Z, IV, path);
     acc[0] += pay;
     acc[1] = fma(pay, pay, acc[1]);
   }
-  bk_store_record(acc, p.records + (size_t)(n_tiles + kPackedGrid + blockIdx.x) * kRecStride);
+  bk_store_record(acc, p.records + (size_t)(2 * n_tiles + blockIdx.x) * kRecStride);
 }
 
 // The host-made tables into device memory: ONE lane, constant indices (a lane-indexed read of the
@@ -925,25 +1019,18 @@ __global__ __launch_bounds__(256) void fill_rows_kernel(double* __restrict__ spo
 
 }  // namespace
 
-constexpr size_t kPhiBudget = (size_t)8 << 30;   // at most 8 GiB of device scratch for the cache
+constexpr size_t kSlotBitmapBytes = 8 * 128;  // one 128-byte line per XCD (kXcds = 8)
 
-// series terms cached per trajectory: term_cache (HH_OPT_BK_TERM_CACHE; 0 = kBkTermCacheDefault) unless
-// the ensemble is so large that the cache would pass kPhiBudget
-static int phi_cache_cap(size_t n_tiles, int term_cache) {
-  const size_t lanes = n_tiles * kTile;
-  size_t cap = kPhiBudget / (lanes * sizeof(double));
-  const size_t want = term_cache > 0 ? (size_t)term_cache : (size_t)kBkTermCacheDefault;
-  if (cap > want) cap = want;
-  if (cap < 8) cap = 8;
-  return (int)cap;
-}
+// series terms cached per column: term_cache (HH_OPT_BK_TERM_CACHE; 0 = kBkTermCacheDefault).  The columns
+// belong to workgroup slots, so the cache does not grow with the ensemble.
+static int phi_cache_cap(int term_cache) { return term_cache > 0 ? term_cache : kBkTermCacheDefault; }
 
-// ballots (fail, long) | prefix sums (fail, long) | tile counts | device copy of the argument block | Bessel tables
+// ballots (fail, long) | prefix sums (fail, long) | tile counts | slot flags | device copy of the argument block | Bessel tables
 static size_t bk_masks_bytes(size_t n_tiles) {
   return 2 * n_tiles * (kTile / 64) * sizeof(unsigned long long);
 }
 static size_t bk_args_offset(size_t n_tiles) {  // … + prefix sums [2][n_tiles+1] + tile counts [n_tiles]
-  const size_t b = bk_masks_bytes(n_tiles) + (2 * (n_tiles + 1) + n_tiles) * sizeof(uint32_t);
+  const size_t b = bk_masks_bytes(n_tiles) + (2 * (n_tiles + 1) + n_tiles) * sizeof(uint32_t) + 128 + kSlotBitmapBytes;
   return (b + 255) & ~(size_t)255;
 }
 static size_t bk_tables_offset(size_t n_tiles) {
@@ -951,6 +1038,11 @@ static size_t bk_tables_offset(size_t n_tiles) {
 }
 static size_t bk_flags_bytes(size_t n_tiles) {
   return bk_tables_offset(n_tiles) + ((sizeof(BkTables) + 255) & ~(size_t)255);
+}
+// columns of cached terms: one per lane of a workgroup slot (fewer slots than tiles are never needed)
+static size_t bk_cache_columns(size_t n_tiles) {
+  const size_t slots = n_tiles < (size_t)kHeavyGrid ? (size_t)kHeavyGrid : n_tiles < (size_t)kSlots ? n_tiles : (size_t)kSlots;
+  return slots * kTile;
 }
 
 int launch_fill_rows(double* spot0, double* var0, uint64_t n, double S0, double V0, hipStream_t s) {
@@ -960,13 +1052,15 @@ int launch_fill_rows(double* spot0, double* var0, uint64_t n, double S0, double 
 }
 
 uint32_t bk_record_count(uint64_t n_paths) {
-  return tiles_for(n_paths) + (uint32_t)kPackedGrid + (uint32_t)kHeavyGrid;
+  return 2 * tiles_for(n_paths) + (uint32_t)kHeavyGrid;  // CF tiles | ladder workgroups (worst case) | fall-back
 }
 
 size_t bk_scratch_bytes(uint64_t n_paths, int term_cache) {
   const size_t n_tiles = tiles_for(n_paths);
-  // ballots + prefix | cached series terms [cap][lanes] | draws [4][lanes] | rec [4][lanes] | ∫V [lanes]
-  return bk_flags_bytes(n_tiles) + n_tiles * kTile * sizeof(double) * ((size_t)phi_cache_cap(n_tiles, term_cache) + 9);
+  // flags + prefix | cached series terms [cap][columns] (per workgroup SLOT: independent of n_paths) |
+  // per trajectory: draws [4] | ∫V [1] | decision word + series length (2 x uint32)
+  return bk_flags_bytes(n_tiles) + bk_cache_columns(n_tiles) * (size_t)phi_cache_cap(term_cache) * sizeof(double) +
+         n_tiles * kTile * sizeof(double) * 6;
 }
 
 namespace {
@@ -1017,14 +1111,19 @@ int bk_prepare(const hh_model& m, const hh_config& c, const DevicePtrs& ptr, uin
   L.prefix = reinterpret_cast<uint32_t*>(a.long_mask + (size_t)n_tiles * (kTile / 64));
   L.prefix_long = L.prefix + n_tiles + 1;
   a.tile_counts = L.prefix_long + n_tiles + 1;
+  a.slot_busy = reinterpret_cast<uint32_t*>(
+      (reinterpret_cast<uintptr_t>(a.tile_counts + n_tiles) + 127) & ~(uintptr_t)127);  // 128-byte lines
   a.args_dev = base + bk_args_offset(n_tiles);
   L.tabs_dev = reinterpret_cast<BkTables*>(base + bk_tables_offset(n_tiles));
   a.tabs_dev = L.tabs_dev;
+  a.n_tiles = n_tiles;
+  a.cache_cap = phi_cache_cap(ptr.bk_term_cache);
   a.phi_cache = reinterpret_cast<double*>(base + bk_flags_bytes(n_tiles));
-  a.cache_stride = lanes;
-  a.cache_cap = phi_cache_cap(n_tiles, ptr.bk_term_cache);
-  a.draws = a.phi_cache + lanes * (size_t)a.cache_cap;
-  a.rec = a.draws + 4 * lanes;
+  a.cache_stride = bk_cache_columns(n_tiles);
+  a.static_slots = n_tiles <= (uint32_t)kSlots ? 1u : 0u;
+  a.draws = a.phi_cache + a.cache_stride * (size_t)a.cache_cap;
+  a.iv_store = a.draws + 4 * lanes;  // ∫V per pair of a grid chain
+  a.diag = reinterpret_cast<uint32_t*>(a.iv_store + lanes);
   a.draw_stride = lanes;
   return 0;
 }
@@ -1046,18 +1145,14 @@ int bk_tables(const BkArgs& a, const BkLayout& L, const DevicePtrs& ptr, hipStre
 
 // CF work, prefix sums, ladder, fall-back — everything behind the draws
 void bk_chain(const BkArgs& a, const BkLayout& L, hipStream_t s) {
-  const dim3 g(L.n_tiles), b(kTile);
-#if HH_BK_FUSED
-  hipLaunchKernelGGL(bk_cf_kernel, g, b, 0, s, a, static_cast<const BkTables*>(L.tabs_dev));
-#else
-  hipLaunchKernelGGL(bk_series_kernel, g, b, 0, s, a, static_cast<const BkTables*>(L.tabs_dev));
-  hipLaunchKernelGGL(bk_invert_kernel, g, b, 0, s, a);
-#endif
+  const dim3 b(kTile), g(L.n_tiles);
+  const BkTables* tabs = static_cast<const BkTables*>(L.tabs_dev);
+  if (!a.static_slots) (void)hipMemsetAsync(a.slot_busy, 0, kSlotBitmapBytes, s);
+  hipLaunchKernelGGL(bk_cf_kernel, g, b, 0, s, a, tabs);
   hipLaunchKernelGGL(bk_scan_kernel, dim3(1), dim3(kScanThreads), 0, s, a, L.n_tiles, L.prefix, L.prefix_long);
-  hipLaunchKernelGGL(bk_ladder_kernel, dim3(kPackedGrid), b, 0, s, a, L.n_tiles, L.prefix);
+  hipLaunchKernelGGL(bk_ladder_kernel, g, b, 0, s, a, tabs, L.n_tiles, L.prefix);
   hipLaunchKernelGGL(bk_fallback_kernel, dim3(kHeavyGrid), b, 0, s,
-                     static_cast<const BkArgs*>(a.args_dev), static_cast<const BkTables*>(L.tabs_dev), L.n_tiles,
-                     L.prefix_long);
+                     static_cast<const BkArgs*>(a.args_dev), tabs, L.n_tiles, L.prefix_long);
 }
 
 }  // namespace
@@ -1085,15 +1180,27 @@ int launch_bk(const hh_model& m, const hh_config& c, const DevicePtrs& ptr, hipS
 }
 
 uint32_t bk_grid_dates_per_chain(uint64_t n_paths, uint32_t n_steps, int term_cache) {
-  // as many (date, trajectory) pairs per chain as keep the full term cache inside kPhiBudget, the dates spread
-  // evenly over the chains
-  const size_t want = term_cache > 0 ? (size_t)term_cache : (size_t)kBkTermCacheDefault;
-  // (and at most 2^24 pairs per chain: past that a chain fills the chip many times over anyway)
-  const uint64_t pairs_max = std::min<uint64_t>(kPhiBudget / (want * sizeof(double)), (uint64_t)1 << 24);
+  // The term cache no longer grows with the pairs of a chain; what does is 48 bytes per pair (draws, ∫V,
+  // decision words).  2^22 pairs fill the chip more than twenty times over and keep that at 0.2 GB: a
+  // longer grid is cut into several chains, the dates spread evenly over them.
+  (void)term_cache;
+  const uint64_t pairs_max = (uint64_t)1 << 22;
   const uint64_t per = n_paths ? pairs_max / n_paths : 1;
   if (per <= 1) return 1;
   const uint64_t chains = (n_steps + per - 1) / per;
   return (uint32_t)((n_steps + chains - 1) / chains);
+}
+
+// where a chain over n_paths trajectories left its decision words / series lengths inside `scratch`
+void bk_diag_ptrs(const void* scratch, uint64_t n_paths, int term_cache, const uint32_t** decisions,
+                  const uint32_t** series_len) {
+  const size_t n_tiles = tiles_for(n_paths), lanes = n_tiles * kTile;
+  const unsigned char* base = reinterpret_cast<const unsigned char*>(scratch);
+  const double* cache = reinterpret_cast<const double*>(base + bk_flags_bytes(n_tiles));
+  const double* draws = cache + bk_cache_columns(n_tiles) * (size_t)phi_cache_cap(term_cache);
+  const uint32_t* diag = reinterpret_cast<const uint32_t*>(draws + 5 * lanes);
+  *decisions = diag;
+  *series_len = diag + lanes;
 }
 
 int launch_bk_grid(const hh_model& m, const hh_config& c, const DevicePtrs& ptr, hipStream_t s,
@@ -1105,7 +1212,7 @@ int launch_bk_grid(const hh_model& m, const hh_config& c, const DevicePtrs& ptr,
   if (rc) return rc;
   a.in_var = var_rows;  // pair i = b·n_row + trajectory starts from var_rows[i]
   a.step = k0;
-  a.iv_out = a.rec + 4 * a.draw_stride;
+  a.iv_out = a.iv_store;
   if ((rc = bk_tables(a, L, ptr, s, upload_tables))) return rc;
   const dim3 rows(tiles_for(n_row)), b(kTile);
   hipLaunchKernelGGL(bk_draw_grid_kernel, rows, b, 0, s, a, n_row, k0, n_dates, var_rows);

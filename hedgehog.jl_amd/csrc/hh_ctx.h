@@ -54,6 +54,8 @@ struct hh_ctx {
   } shard;
   int lsm_form = hh::kLsmFormAuto;  // hh_ctx_set_option(HH_OPT_LSM_FORM)
   int bk_term_cache = 0;            // hh_ctx_set_option(HH_OPT_BK_TERM_CACHE); 0 = the default
+  uint64_t bk_last_n = 0;           // trajectories of the last Broadie–Kaya solve (hh_bk_decisions)
+  int bk_last_cache = 0;            // … and the term cache it ran with
   int grid_form = HH_GRID_FORM_BATCHED;  // hh_ctx_set_option(HH_OPT_GRID_FORM)
   uint64_t lsm_persistent_fallbacks = 0;  // persistent launches that gave up and were redone per date
   long long lsm_spin_ticks = -1;          // hh_ctx_set_option(HH_OPT_LSM_SPIN_TICKS); < 0 = the default (1 s)

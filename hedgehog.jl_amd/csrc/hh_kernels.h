@@ -119,6 +119,10 @@ int launch_bk_grid(const hh_model& m, const hh_config& c, const DevicePtrs& p, h
 uint32_t bk_grid_dates_per_chain(uint64_t n_paths, uint32_t n_steps, int term_cache);
 constexpr int kBkTermCacheDefault = 256;
 size_t bk_scratch_bytes(uint64_t n_paths, int term_cache = 0);
+// where the last chain over n_paths trajectories left, per trajectory, its decision word (BkDecision bits:
+// secant evaluations | branch << 8 | bisection iterations << 16 | long-series bit 31) and its series length
+void bk_diag_ptrs(const void* scratch, uint64_t n_paths, int term_cache, const uint32_t** decisions,
+                  const uint32_t** series_len);
 uint32_t bk_record_count(uint64_t n_paths);  // records the Broadie–Kaya chain writes (inversion tiles + packed kernels)
 // the four Broadie–Kaya counter slots of `src` (HH_ACC_LEN doubles) into each of n_groups accumulators
 int launch_copy_bk_counters(const double* src, double* accum, uint32_t n_groups, hipStream_t s);

@@ -15,6 +15,8 @@ from __future__ import annotations
 from dataclasses import dataclass, field
 from typing import Any
 
+import numpy as np
+
 from .dates import to_ticks, yearfrac
 from .dual import dexp
 
@@ -233,29 +235,53 @@ class PricingProblem:
     market_inputs: Any
 
 
-class MonteCarloSolution:
-    """pricing_solutions.jl:22-27; `ensemble` holds the samples at expiry (a pair when antithetic).
+class _DeviceSamples:
+    """Samples at expiry still in device memory: downloaded on the first read, then kept as plain
+    arrays.  Reading after the owning Context was closed is a clear error, not a HIP fault."""
+    __slots__ = ("_fetch", "_value", "_ctx")
 
-    `std_error`, `result` are build extensions (the reference computes no standard error).  The
-    samples stay in device memory until `ensemble` is first read (most callers only read `price`;
-    the download is 8 MB per 10^6 trajectories): `fetch` is the callable that brings them over."""
-    __slots__ = ("problem", "method", "price", "std_error", "result", "_ensemble", "_fetch")
+    def __init__(self, fetch, ctx=None):
+        self._fetch, self._value, self._ctx = fetch, None, ctx
 
-    def __init__(self, problem, method, price, ensemble=None, std_error=float("nan"), result=None,
-                 fetch=None):
-        self.problem, self.method, self.price = problem, method, price
-        self.std_error, self.result = std_error, result
-        self._ensemble, self._fetch = ensemble, fetch
-
-    @property
-    def ensemble(self):
+    def get(self):
         if self._fetch is not None:
-            self._ensemble, self._fetch = self._fetch(), None
-        return self._ensemble
+            if self._ctx is not None and getattr(self._ctx, "handle", None) is None:
+                raise RuntimeError("MonteCarloSolution.ensemble was left on the device and its Context has "
+                                   "been closed: read .ensemble before closing the context")
+            self._value, self._fetch = self._fetch(), None
+        return self._value
+
+
+@dataclass(frozen=True, eq=False)
+class MonteCarloSolution:
+    """pricing_solutions.jl:22-27: (problem, method, price, ensemble); `ensemble` holds the samples at
+    expiry (a pair when antithetic).  A plain frozen dataclass (`dataclasses.replace` / `asdict` /
+    `fields` work) whose `ensemble` may be a device-side handle that is downloaded on the first read —
+    most callers only read `price`, the download is 8 MB per 10^6 trajectories.  `std_error`, `result`
+    are build extensions (the reference computes no standard error)."""
+    problem: Any
+    method: Any
+    price: Any
+    ensemble: Any = None
+    std_error: float = float("nan")
+    result: Any = field(default=None, repr=False, compare=False)
+
+    def __getattribute__(self, name):
+        v = object.__getattribute__(self, name)
+        if name == "ensemble" and isinstance(v, _DeviceSamples):
+            v = v.get()
+        return v
 
     def __eq__(self, other):
-        return isinstance(other, MonteCarloSolution) and \
-            (self.problem, self.method, self.price) == (other.problem, other.method, other.price)
+        if not isinstance(other, MonteCarloSolution):
+            return NotImplemented
+        if (self.problem, self.method, self.price) != (other.problem, other.method, other.price):
+            return False
+        a, b = self.ensemble, other.ensemble
+        if a is None or b is None:
+            return a is None and b is None
+        a, b = (a if isinstance(a, tuple) else (a,)), (b if isinstance(b, tuple) else (b,))
+        return len(a) == len(b) and all(np.array_equal(x, y) for x, y in zip(a, b))
 
     __hash__ = None
 

@@ -15,7 +15,7 @@ from . import _ffi
 from .dates import yearfrac
 from .dual import Dual, n_partials, partials_of, value_of
 from .domain import (BlackScholesInputs, European, HestonInputs, MonteCarloSolution, PricingProblem,
-                    Spot, VanillaOption, df, get_vol, zero_rate)
+                    Spot, VanillaOption, _DeviceSamples, df, get_vol, zero_rate)
 
 
 # ---- montecarlo.jl:8-43 ----
@@ -216,8 +216,9 @@ def solve_montecarlo(prob: PricingProblem, method: MonteCarlo, ensemble: bool = 
     ctx.check(ctx.lib.hh_mc_solve(ctx.handle, C.byref(model), C.byref(c), C.byref(res),
                                   term_dev.ptr if term_dev else None))
     del keep, seeds_dev
-    return MonteCarloSolution(prob, method, _price_from(res, discount, P), None,
-                              std_error=res.std_error, result=res, fetch=fetch)
+    ens = _DeviceSamples(fetch, ctx) if fetch is not None else None
+    return MonteCarloSolution(prob, method, _price_from(res, discount, P), ens,
+                              std_error=res.std_error, result=res)
 
 
 def _solve_multi_gpu(prob, method, model, c, P, discount, ensemble, replay, replay_layout):

@@ -168,18 +168,20 @@ const char* hh_last_error(const hh_ctx* ctx); /* NUL-terminated, owned by ctx (o
  *                           synchronisation (10^5 x 100: 0.66 vs 0.79 ms).
  * All forms give bit-identical prices and stopping decisions.
  *
- * HH_OPT_BK_TERM_CACHE: how many CDF-series terms Re ϕ(h·j) per trajectory the Broadie–Kaya kernels
- * keep (8 … 1024, default 256; 8 bytes x trajectories each, capped at 8 GiB in all).  Series that fit
- * are evaluated once and inverted on the cached terms; a trajectory whose series is longer re-evaluates
- * the whole series in every CDF call (as the reference does with all of them), in a separate, much
- * slower kernel.  With the reference's controls the series has 10–15 terms (60 at short maturities,
- * 100–250 for d = 4κθ/σ² ≪ 1 or cf_tol ≪ 1e-3).
+ * HH_OPT_BK_TERM_CACHE: how many CDF-series terms Re ϕ(h·j) the Broadie–Kaya kernels keep per column
+ * (8 … 1024, default 256).  A column belongs to a resident workgroup slot of the kernel, not to a
+ * trajectory, so the cache is 8 bytes x terms x 262 144 columns (0.54 GB at 256 terms) whatever the
+ * ensemble size; beside it a solve keeps 48 bytes per trajectory.  Series that fit are evaluated once
+ * and inverted on the cached terms; a trajectory whose series is longer re-evaluates the terms beyond
+ * the cache in every CDF call (as the reference does with all of them), in a separate, slower kernel.
+ * With the reference's controls the series has 10–15 terms (60 at short maturities, 100–250 for
+ * d = 4κθ/σ² ≪ 1 or cf_tol ≪ 1e-3).
  *
  * HH_OPT_GRID_FORM: how hh_heston_exact_grid (and LSM on those paths) runs the dates of a grid:
  *   HH_GRID_FORM_BATCHED   (default) the variances of all dates first, then ONE kernel chain over every
  *                          (date, trajectory) pair — given the variances the CF inversions of different
- *                          dates are independent — then the spot rows; several chains only when the pairs'
- *                          term cache would pass its 8 GiB;
+ *                          dates are independent — then the spot rows; a chain takes at most 2^22 pairs
+ *                          (48 bytes each; longer grids run as several chains);
  *   HH_GRID_FORM_PER_DATE  one kernel chain per date.
  * Both forms give bit-identical grids.
  *
@@ -212,6 +214,21 @@ int hh_mc_accumulate(hh_ctx* ctx, const hh_model* model, const hh_config* cfg, d
 /* Pure host arithmetic: accumulator vector (HOST memory) -> price, std_error, dprice. */
 int hh_mc_finalize(const hh_model* model, const hh_config* cfg, const double* accum_host,
                    hh_result* out);
+
+/*
+ * Diagnostics of the last HH_BROADIE_KAYA solve of this context (hh_mc_solve / _accumulate with the same
+ * n_paths; the scratch it reads is overwritten by the next Broadie–Kaya call): per trajectory, WHAT the
+ * root search of inverse_cdf (sample_from_cf.jl:105-135) did —
+ *   decisions[i]   bits 0-7   CDF evaluations of the secant iteration (find_zero(…, Order2(); maxevals))
+ *                  bits 8-9   0 the secant's root was accepted, 1 bisection finished it (:127-133),
+ *                             2 no sign change: max_guess (:124-126)
+ *                  bits 16-23 bisection iterations;   bit 31  series longer than the term cache
+ *   series_len[i]  terms of the CDF series, set by |ϕ(h j)|/j < π·cf_tol/2 (sample_from_cf.jl:88)
+ * Two implementations that agree on both have run the same sequence of operations on that trajectory;
+ * the parity tests compare samples per trajectory where they agree and count where they do not.
+ * Either output may be NULL.
+ */
+int hh_bk_decisions(hh_ctx* ctx, uint64_t n_paths, uint32_t* decisions, uint32_t* series_len);
 
 /*
  * Multi-GPU solve in ONE call from ONE host thread — what solve(prob, method) (montecarlo.jl:478-493,

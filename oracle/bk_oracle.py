@@ -252,6 +252,7 @@ def moments_from_cf(it: HestonCFIterator, h=1e-2):
 
 class CdfCounter:
     terms = 0
+    last_len = 0   # series length of the last CDF evaluation (the same for every x of a trajectory)
 
 
 def cdf_from_cf(it: HestonCFIterator, x, h, cf_tol=1e-3, block=32, counter=None):
@@ -271,6 +272,7 @@ def cdf_from_cf(it: HestonCFIterator, x, h, cf_tol=1e-3, block=32, counter=None)
         result += float(np.sum((pref * np.sin(a[:n] * x) / j[:n] * phi[:n].real)))
         if counter is not None:
             counter.terms += n
+            counter.last_len = j0 - 1 + n
         if stop.any():
             break
         prev = prev_new
@@ -298,9 +300,13 @@ def _cdf_seq(it, x, h, cf_tol, counter):
 SECANT_H = np.finfo(np.float64).eps ** (1.0 / 3.0)
 
 
+DEC_BISECT, DEC_MAXGUESS, DEC_ITERS_SHIFT = 1 << 8, 2 << 8, 16  # decision word: hh_bk_decisions (hedgehog_mc.h)
+
+
 def inverse_cdf(cdf, u, initial_guess, max_guess, atol=1e-4, maxiter_newton=10,
-                maxiter_bisection=100, stats=None):
-    """sample_from_cf.jl:105-135."""
+                maxiter_bisection=100, stats=None, trace=None):
+    """sample_from_cf.jl:105-135.  trace (a list): receives the trajectory's decision word —
+    secant evaluations | branch << 8 | bisection iterations << 16 — what the search DID."""
     func = lambda y: cdf(y) - u
     # --- find_zero(func, initial_guess, Order2(); atol, maxeval) restated as a secant iteration
     ok, sol, fsol = False, float("nan"), float("nan")
@@ -321,6 +327,8 @@ def inverse_cdf(cdf, u, initial_guess, max_guess, atol=1e-4, maxiter_newton=10,
         x1, f1 = x2, func(x2)
         evals += 1
     if ok and not (sol < 0 or abs(fsol) > atol):
+        if trace is not None:
+            trace.append(evals)
         return sol
     if stats is not None:
         stats["newton_fail"] += 1
@@ -329,27 +337,34 @@ def inverse_cdf(cdf, u, initial_guess, max_guess, atol=1e-4, maxiter_newton=10,
     if fa * fb > 0:
         if stats is not None:
             stats["maxguess"] += 1
+        if trace is not None:
+            trace.append(evals | DEC_MAXGUESS)
         return max_guess
     if stats is not None:
         stats["bisect"] += 1
     a, b = 0.0, max_guess
+    iters, out = 0, None
     for _ in range(maxiter_bisection):
         mid = 0.5 * (a + b)
         fm = func(mid)
+        iters += 1
         if fm == 0.0:
-            return mid
+            out = mid
+            break
         if (fm < 0) == (fa < 0):
             a, fa = mid, fm
         else:
             b = mid
         if b - a <= atol:
             break
-    return 0.5 * (a + b)
+    if trace is not None:
+        trace.append(evals | DEC_BISECT | ((iters & 0xff) << DEC_ITERS_SHIFT))
+    return 0.5 * (a + b) if out is None else out
 
 
 def sample_from_cf(u, it: HestonCFIterator, n=5, cf_tol=1e-3, atol=1e-4, moment_h=1e-2,
                    maxiter_newton=10, maxiter_bisection=100, stats=None, counter=None,
-                   sequential=False):
+                   sequential=False, trace=None):
     """sample_from_cf.jl:27-41 (the uniform u is supplied by the caller)."""
     mean, variance = moments_from_cf(it, moment_h)
     s2 = max(variance, 1e-12)
@@ -362,7 +377,7 @@ def sample_from_cf(u, it: HestonCFIterator, n=5, cf_tol=1e-3, atol=1e-4, moment_
     else:
         cdf = lambda x: cdf_from_cf(it, x, h, cf_tol, counter=counter)
     return inverse_cdf(cdf, u, initial_guess, max_guess, atol, maxiter_newton, maxiter_bisection,
-                       stats)
+                       stats, trace)
 
 
 def sample_log_S_T(V_T, integral_V, Z, d):
@@ -373,7 +388,8 @@ def sample_log_S_T(V_T, integral_V, Z, d):
     return mu + math.sqrt(sigma2) * Z
 
 
-def rand_path(dist, key: int, G: int, stats=None, counter=None, sequential=False, draws=None, **kw):
+def rand_path(dist, key: int, G: int, stats=None, counter=None, sequential=False, draws=None, trace=None,
+              **kw):
     """heston.jl:246-259 for trajectory G -> (log S_T, V_T, ∫V).  draws = (V_T, u, Z): the
     trajectory's three draws supplied by the caller (HH_NOISE_REPLAY) instead of drawn here."""
     if draws is not None:
@@ -384,14 +400,15 @@ def rand_path(dist, key: int, G: int, stats=None, counter=None, sequential=False
         u, _ = dr.uniforms(1)
         Z, _ = dr.normals(0)
     it = HestonCFIterator(V_T, dist)
-    I = sample_from_cf(u, it, stats=stats, counter=counter, sequential=sequential, **kw)
+    I = sample_from_cf(u, it, stats=stats, counter=counter, sequential=sequential, trace=trace, **kw)
     return sample_log_S_T(V_T, I, Z, dist), V_T, I
 
 
 def mc_solve(S0, V0, kappa, theta, sigma, rho, r, T, strike, cp, discount, n_paths, seed0,
              path_offset=0, replay=None, **kw):
     """solve(prob, MonteCarlo(HestonDynamics(), HestonBroadieKaya(), cfg)), montecarlo.jl:454-493.
-    Returns dict(price, std_error, terminal, V_T, integral_V, stats, cf_terms)."""
+    Returns dict(price, std_error, terminal, V_T, integral_V, stats, cf_terms, decisions, series_len) —
+    decisions / series_len: what each trajectory's root search did (the words of hh_bk_decisions)."""
     dist = LogHestonDistribution(S0, V0, kappa, theta, sigma, rho, r, T)
     stats = {"newton_fail": 0, "bisect": 0, "maxguess": 0}
     counter = CdfCounter()
@@ -399,16 +416,18 @@ def mc_solve(S0, V0, kappa, theta, sigma, rho, r, T, strike, cp, discount, n_pat
     logS = np.empty(n_paths)
     VT = np.empty(n_paths)
     IV = np.empty(n_paths)
+    decisions, series_len = [], np.zeros(n_paths, dtype=np.uint32)
     for i in range(n_paths):
         dr = None if replay is None else (replay[0][i], replay[1][i], replay[2][i])  # [V_T | u | Z]
         logS[i], VT[i], IV[i] = rand_path(dist, int(seed0), path_offset + i, stats, counter,
-                                          draws=dr, **kw)
+                                          draws=dr, trace=decisions, **kw)
+        series_len[i] = counter.last_len
     S = np.exp(logS)  # final_sample(law, sample, NoVR) = exp.(sample)  montecarlo.jl:384
     pay = np.maximum(cp * (S - strike), 0.0)
     price = discount * pay.mean()
     se = discount * pay.std(ddof=1) / math.sqrt(n_paths) if n_paths > 1 else 0.0
     return dict(price=price, std_error=se, terminal=S, V_T=VT, integral_V=IV, stats=stats,
-                cf_terms=counter.terms)
+                cf_terms=counter.terms, decisions=np.array(decisions, dtype=np.uint32), series_len=series_len)
 
 
 def exact_grid(S0, V0, kappa, theta, sigma, rho, r, T, n_steps, seeds, stats=None, counter=None,

@@ -121,6 +121,21 @@ def test_solution_is_consistent_with_its_ensemble():
         assert sol.ensemble is sol.ensemble  # downloaded once, on the first read
 
 
+def test_samples_left_on_the_device_survive_further_solves():
+    """`ensemble` is read AFTER other solves on the same context have come and gone (their sample
+    buffers recycled through the pool): still this solve's samples."""
+    import dataclasses
+    prob = heston_problem()
+    cfgs = [hh.SimulationConfig(7_000, steps=12, seeds=np.arange(1, 7_001) + 1000 * k) for k in range(4)]
+    sols = [hh.solve(prob, hh.MonteCarlo(hh.HestonDynamics(), hh.EulerMaruyama(), c)) for c in cfgs]
+    for _ in range(6):  # same size: the pool hands the same buffers around
+        hh.solve(prob, hh.MonteCarlo(hh.HestonDynamics(), hh.EulerMaruyama(), cfgs[0])).ensemble
+    D = hh.df(prob.market_inputs.rate, prob.payoff.expiry)
+    for sol in sols:
+        assert sol.price == pytest.approx(D * prob.payoff(sol.ensemble).mean(), rel=1e-12)
+    assert dataclasses.replace(sols[0]) == sols[0] and sols[0] != sols[1]
+
+
 def test_repeated_solves_reuse_the_device_seeds_and_sample_buffers():
     """The host mirror keeps a config's seeds on the device and recycles the sample buffer: a second
     solve gives the same price and samples, and solves whose samples are never read leave nothing

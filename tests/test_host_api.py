@@ -123,6 +123,40 @@ def test_dual_arithmetic():
     assert x > 1 and x < y
 
 
+def test_monte_carlo_solution_is_a_plain_frozen_dataclass():
+    """pricing_solutions.jl:22-27: a value type.  `dataclasses.replace` / `asdict` / `fields` work, equality
+    covers the samples, and samples that were left on the device are downloaded ONCE on the first read."""
+    import dataclasses
+
+    from hedgehog_jl_amd.domain import MonteCarloSolution, _DeviceSamples
+    calls = []
+
+    def fetch():
+        calls.append(1)
+        return np.arange(4.0)
+
+    sol = MonteCarloSolution("prob", "method", 1.5, _DeviceSamples(fetch), std_error=0.1)
+    assert [f.name for f in dataclasses.fields(sol)][:4] == ["problem", "method", "price", "ensemble"]
+    assert not calls                                  # nothing moved yet
+    np.testing.assert_array_equal(sol.ensemble, np.arange(4.0))
+    assert sol.ensemble is sol.ensemble and calls == [1]
+    other = dataclasses.replace(sol, price=2.0)
+    assert other.price == 2.0 and other.ensemble is sol.ensemble and other != sol
+    assert dataclasses.replace(sol) == sol
+    assert dataclasses.asdict(sol)["price"] == 1.5
+    with pytest.raises(dataclasses.FrozenInstanceError):
+        sol.price = 3.0
+    pair = MonteCarloSolution("p", "m", 1.0, (np.ones(2), np.zeros(2)))
+    assert pair == MonteCarloSolution("p", "m", 1.0, (np.ones(2), np.zeros(2)))
+    assert pair != MonteCarloSolution("p", "m", 1.0, (np.ones(2), np.ones(2)))
+
+    class Closed:
+        handle = None
+    gone = MonteCarloSolution("p", "m", 1.0, _DeviceSamples(fetch, Closed()))
+    with pytest.raises(RuntimeError, match="Context has been closed"):
+        gone.ensemble
+
+
 def test_cabi_header_and_library_agree():
     """Every function include/hedgehog_mc.h declares is bound in _ffi.SYMBOLS and exported by the
     built library (no compute call is made here)."""

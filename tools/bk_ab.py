@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Interleaved A/B of Broadie–Kaya build variants (hedgehog.jl_amd/lib/variants/libhh_bk_*.so) against the
+shipped library in ONE process: config 4 (10^6 trajectories) chain time by HIP events.  GPU box only."""
+import ctypes as C
+import glob
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+
+from hedgehog_jl_amd import _ffi
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
+libs = {"shipped": _ffi.LIB_PATH}
+for f in sorted(glob.glob(os.path.join(ROOT, "hedgehog.jl_amd", "lib", "variants", "libhh_bk_*.so"))):
+    libs[os.path.basename(f)[9:-3]] = f
+seed0 = torch.tensor([99], dtype=torch.int64, device="cuda")
+acc = torch.zeros(16, dtype=torch.float64, device="cuda")
+m = _ffi.make_model()
+c = _ffi.make_config(_ffi.HH_HESTON, _ffi.HH_BROADIE_KAYA, n)
+c.seeds, c.seeds_on_device = seed0.data_ptr(), 1
+ctxs = {}
+for tag, path in libs.items():
+    lib = C.CDLL(path)
+    for name, res, args in _ffi.SYMBOLS:
+        f = getattr(lib, name)
+        f.restype, f.argtypes = res, args
+    h = C.c_void_p()
+    assert lib.hh_ctx_create(C.byref(h), 0) == 0
+    lib.hh_ctx_enable_timing(h, 1)
+    ctxs[tag] = (lib, h)
+times = {t: [] for t in ctxs}
+sums = {}
+for r in range(6):
+    for tag, (lib, h) in ctxs.items():
+        for _ in range(6):
+            assert lib.hh_mc_accumulate(h, C.byref(m), C.byref(c), acc.data_ptr(), None) == 0
+        buf = (C.c_double * 256)()
+        k = C.c_int32()
+        lib.hh_ctx_read_timings(h, buf, 256, C.byref(k))
+        if r:
+            times[tag] += [buf[i] for i in range(k.value)]
+        sums[tag] = float(acc[0].item())
+for tag, t in times.items():
+    print(f"{tag:10s} n={n}: median {np.median(t):.4f} ms  min {min(t):.4f}  same_sum={sums[tag] == sums['shipped']}")
