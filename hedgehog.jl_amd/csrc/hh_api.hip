@@ -830,16 +830,24 @@ static int run_heston_grid(hh_ctx* ctx, const hh_model* m, const hh_config* c) {
   const size_t grid_elems = (size_t)(c->n_steps + 1) * n;
   // dates per kernel chain: given the variance rows, the CF inversions of different dates are
   // independent, so a batch of dates runs as ONE chain over its (date, trajectory) pairs
-  const uint32_t per_chain = ctx->grid_form == HH_GRID_FORM_BATCHED
-                                 ? hh::bk_grid_dates_per_chain(n, c->n_steps, ctx->bk_term_cache)
-                                 : 1u;
-  const uint64_t n_chain = n * per_chain;
+  uint32_t per_chain = ctx->grid_form == HH_GRID_FORM_BATCHED
+                           ? hh::bk_grid_dates_per_chain(n, c->n_steps, ctx->bk_term_cache)
+                           : 1u;
   int rc;
   if ((rc = ensure(ctx, ctx->lsm_grid, ctx->lsm_grid_cap, grid_elems))) return rc;
   if ((rc = ensure(ctx, ctx->heston_var, ctx->heston_var_cap, grid_elems))) return rc;
+  // a chain's scratch is 48 bytes per (date, trajectory) pair beside the fixed term cache: on a device
+  // that cannot spare it (shared with another allocator) the dates go into shorter chains, down to one
+  // chain per date — same bits either way
+  uint64_t n_chain = n * per_chain;
+  while ((rc = ensure_bk_scratch(ctx, hh::bk_scratch_bytes(n_chain, ctx->bk_term_cache))) == HH_ERR_NOMEM &&
+         per_chain > 1) {
+    per_chain = (per_chain + 1) / 2;
+    n_chain = n * per_chain;
+  }
+  if (rc) return rc;
   if ((rc = ensure(ctx, ctx->records, ctx->records_cap, (size_t)hh::bk_record_count(n_chain) * hh::kRecStride)))
     return rc;
-  if ((rc = ensure_bk_scratch(ctx, hh::bk_scratch_bytes(n_chain, ctx->bk_term_cache)))) return rc;
   if ((rc = ensure(ctx, ctx->basket_accum, ctx->basket_accum_cap, (size_t)c->n_steps * HH_ACC_LEN)))
     return rc;
   hh::DevicePtrs p{};
