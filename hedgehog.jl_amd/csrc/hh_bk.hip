@@ -51,6 +51,8 @@ constexpr double kTwoPi = kBesselTwoPi;
 // for 10^8 trajectories alike).  A trajectory's terms are only needed again if its secant fails (2 % of
 // them): the ladder kernel re-derives those.
 constexpr int kSlots = HH_BK_SLOTS;
+constexpr int kSideTerms = 64, kSideEntry = kSideTerms + 2;  // doubles per side-store entry: h, max_guess, terms
+constexpr uint32_t kNoSide = 0xffffffffu;
 constexpr int kHeavyGrid = HH_BK_HEAVY_GRID;   // workgroups of the fall-back kernel (246 registers; it is empty
                                   // with the reference's controls, and the whole job when no series fits the term cache)
 static_assert(kHeavyGrid <= kSlots, "the fall-back kernel's workgroup b uses slot b");
@@ -107,7 +109,16 @@ struct BkArgs {
   uint32_t* slot_busy;             // slot bitmaps, one 128-byte line per XCD: 0 free / 1 taken (zeroed per launch)
   uint32_t static_slots;           // 1: the chain has at most kSlots tiles, slot = tile (no bitmap)
   uint32_t n_tiles;
-  uint32_t* diag;                  // [2][draw_stride] per trajectory: decision word (BkDecision), series length
+  uint32_t* diag;                  // [3][draw_stride] per trajectory: decision word (BkDecision), series length,
+                                   //   index of its side-store entry (kNoSide: none)
+  // Side store: the series of a trajectory whose secant FAILED (2 % of them) is copied here by the CF
+  // kernel — h, max_guess, then its terms — so that the ladder kernel finds it without evaluating the
+  // characteristic function again.  Entries are handed out by an atomic counter (their order does not
+  // matter: a trajectory finds its own through diag[2]); a series longer than kSideTerms, or one that
+  // comes when the store is full, is re-derived by the ladder kernel instead.
+  double* side;                    // [side_cap][kSideEntry]
+  uint32_t* side_count;            // entries handed out (zeroed per launch, beside the slot bitmaps)
+  uint32_t side_cap;
   void* args_dev;                  // a copy of this struct in device memory (written by bk_scan_kernel)
                                    // for bk_fallback_kernel, whose code is too large to inline: passing
                                    // a by-value kernel argument by reference to its functions would put
@@ -644,7 +655,8 @@ __device__ __forceinline__ double cdf_cached(const double (&t)[kRegTerms], const
 // so is a trajectory whose series did not fit the cache (bk_fallback_kernel).  Flags are ballots in
 // trajectory order, so the result is bit-reproducible.  Called by every thread of the workgroup.
 __device__ __forceinline__ void invert_phase(const BkArgs& p, uint32_t tile, uint32_t tid, uint64_t path,
-                                             bool live, const double* col, double h, double guess, int j_stop) {
+                                             bool live, const double* col, double h, double guess,
+                                             double max_guess, int j_stop) {
   double acc[6] = {0, 0, 0, 0, 0, 0};  // Σp, Σp², newton_fail, bisect, maxguess, cf_terms
   bool failed = false, too_long = false;
   if (live) {
@@ -678,6 +690,23 @@ __device__ __forceinline__ void invert_phase(const BkArgs& p, uint32_t tile, uin
     }
   }
   const unsigned long long m_fail = __ballot(failed), m_long = __ballot(too_long);
+  if (m_fail != 0ull) {  // the failed trajectories' series into the side store, for the ladder kernel
+    const uint32_t lane = tid & 63u;
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(p.side_count, (uint32_t)__popcll(m_fail));
+    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+    if (failed) {
+      const uint32_t k = base + (uint32_t)__popcll(m_fail & ((1ull << lane) - 1ull));
+      const bool fits = k < p.side_cap && j_stop <= kSideTerms;
+      p.diag[2 * p.draw_stride + path] = fits ? k : kNoSide;
+      if (fits) {
+        double* e = p.side + (size_t)k * kSideEntry;
+        e[0] = h;
+        e[1] = max_guess;
+        for (int j = 0; j < j_stop; ++j) e[2 + j] = col[(size_t)j * p.cache_stride];
+      }
+    }
+  }
   if ((tid & 63) == 0) {
     p.fail_mask[(size_t)tile * (kTile / 64) + (tid >> 6)] = m_fail;
     p.long_mask[(size_t)tile * (kTile / 64) + (tid >> 6)] = m_long;
@@ -767,7 +796,7 @@ __global__ __launch_bounds__(kTile) void bk_cf_kernel(const BkArgs p, const BkTa
   double h = 0.0, guess = 0.0, max_guess = 0.0;
   int j_stop = 0;
   if (live) series_phase(p, bt, path, col, p.cache_stride, h, guess, max_guess, j_stop);
-  invert_phase(p, tile, tid, path, live, col, h, guess, j_stop);
+  invert_phase(p, tile, tid, path, live, col, h, guess, max_guess, j_stop);
   give_slot(p, slot);
 }
 
@@ -859,9 +888,9 @@ __device__ __forceinline__ uint64_t packed_path(const unsigned long long* mask, 
 
 // Ladder kernel: the fall-back of inverse_cdf (sample_from_cf.jl:123-133) for the trajectories whose
 // secant failed, densely packed (one per lane, in trajectory order).  The CF kernel's column of such a
-// trajectory has long been reused, so its series is evaluated again here — same operations, same
-// terms — into the column of the slot THIS workgroup takes, and the ladder then runs on the cached
-// terms.  2 % of the trajectories x the series' share of the CF work: ~7 µs of the chip.  One work item
+// trajectory has long been reused; its series waits in the side store (BkArgs::side), and the ladder
+// runs on those terms.  Only a series that found no room there is evaluated again — same operations,
+// same terms — into the column of the slot THIS workgroup takes.  One work item
 // per lane, no loop (see bk_cf_kernel): the grid covers the worst case (every trajectory failed) and the
 // workgroups beyond the packed list leave at once with an empty record.
 __global__ __launch_bounds__(kTile) void bk_ladder_kernel(const BkArgs p, const BkTables* __restrict__ tabs,
@@ -883,12 +912,24 @@ __global__ __launch_bounds__(kTile) void bk_ladder_kernel(const BkArgs p, const 
     const uint64_t path = packed_path(p.fail_mask, prefix, n_tiles, g);
     double h, guess, max_guess;
     int j_stop;
-    series_phase(p, bt, path, col, stride, h, guess, max_guess, j_stop);
+    const double* terms = col;
+    size_t tstride = stride;
+    const uint32_t k = p.diag[2 * p.draw_stride + path];
+    if (k != kNoSide) {  // its series waits in the side store
+      const double* e = p.side + (size_t)k * kSideEntry;
+      h = e[0];
+      max_guess = e[1];
+      j_stop = (int)p.diag[p.draw_stride + path];
+      terms = e + 2;
+      tstride = 1;
+    } else {  // too long for an entry, or the store was full: evaluate it again
+      series_phase(p, bt, path, col, stride, h, guess, max_guess, j_stop);
+    }
     const double u = p.draws[p.draw_stride + path];
     double t[kRegTerms];
-    load_terms(col, stride, j_stop, t);
+    load_terms(terms, tstride, j_stop, t);
     double n_terms = 0.0, IV;
-    auto cdf = [&](double x) { return cdf_cached(t, col, stride, j_stop, h, x, n_terms); };
+    auto cdf = [&](double x) { return cdf_cached(t, terms, tstride, j_stop, h, x, n_terms); };
     double fa = cdf(0.0) - u;
     const double fb = cdf(max_guess) - u;
     uint32_t dec = p.diag[path];
@@ -1019,7 +1060,7 @@ __global__ __launch_bounds__(256) void fill_rows_kernel(double* __restrict__ spo
 
 }  // namespace
 
-constexpr size_t kSlotBitmapBytes = 8 * 128;  // one 128-byte line per XCD (kXcds = 8)
+constexpr size_t kSlotBitmapBytes = 8 * 128 + 128;  // one 128-byte line per XCD (kXcds = 8) + the side-store counter's
 
 // series terms cached per column: term_cache (HH_OPT_BK_TERM_CACHE; 0 = kBkTermCacheDefault).  The columns
 // belong to workgroup slots, so the cache does not grow with the ensemble.
@@ -1038,6 +1079,11 @@ static size_t bk_tables_offset(size_t n_tiles) {
 }
 static size_t bk_flags_bytes(size_t n_tiles) {
   return bk_tables_offset(n_tiles) + ((sizeof(BkTables) + 255) & ~(size_t)255);
+}
+// side-store entries: one trajectory in sixteen (2 % fail with the reference's controls), at least 4096
+static size_t bk_side_cap(size_t n_tiles) {
+  const size_t c = n_tiles * kTile / 16;
+  return c < 4096 ? 4096 : c;
 }
 // columns of cached terms: one per lane of a workgroup slot (fewer slots than tiles are never needed)
 static size_t bk_cache_columns(size_t n_tiles) {
@@ -1058,9 +1104,10 @@ uint32_t bk_record_count(uint64_t n_paths) {
 size_t bk_scratch_bytes(uint64_t n_paths, int term_cache) {
   const size_t n_tiles = tiles_for(n_paths);
   // flags + prefix | cached series terms [cap][columns] (per workgroup SLOT: independent of n_paths) |
-  // per trajectory: draws [4] | ∫V [1] | decision word + series length (2 x uint32)
+  // per trajectory: draws [4] | ∫V [1] | decision word, series length, side index (3 x uint32 in 2 doubles) |
+  // side store: kSideEntry doubles for one trajectory in sixteen
   return bk_flags_bytes(n_tiles) + bk_cache_columns(n_tiles) * (size_t)phi_cache_cap(term_cache) * sizeof(double) +
-         n_tiles * kTile * sizeof(double) * 6;
+         n_tiles * kTile * sizeof(double) * 7 + bk_side_cap(n_tiles) * (size_t)kSideEntry * sizeof(double);
 }
 
 namespace {
@@ -1123,7 +1170,10 @@ int bk_prepare(const hh_model& m, const hh_config& c, const DevicePtrs& ptr, uin
   a.static_slots = n_tiles <= (uint32_t)kSlots ? 1u : 0u;
   a.draws = a.phi_cache + a.cache_stride * (size_t)a.cache_cap;
   a.iv_store = a.draws + 4 * lanes;  // ∫V per pair of a grid chain
-  a.diag = reinterpret_cast<uint32_t*>(a.iv_store + lanes);
+  a.diag = reinterpret_cast<uint32_t*>(a.iv_store + lanes);  // 3 x uint32 per lane in 2 doubles per lane
+  a.side = a.iv_store + 3 * lanes;
+  a.side_cap = (uint32_t)bk_side_cap(n_tiles);
+  a.side_count = a.slot_busy + 8 * 32;  // the 128-byte line behind the eight slot bitmaps
   a.draw_stride = lanes;
   return 0;
 }
@@ -1147,7 +1197,7 @@ int bk_tables(const BkArgs& a, const BkLayout& L, const DevicePtrs& ptr, hipStre
 void bk_chain(const BkArgs& a, const BkLayout& L, hipStream_t s) {
   const dim3 b(kTile), g(L.n_tiles);
   const BkTables* tabs = static_cast<const BkTables*>(L.tabs_dev);
-  if (!a.static_slots) (void)hipMemsetAsync(a.slot_busy, 0, kSlotBitmapBytes, s);
+  (void)hipMemsetAsync(a.slot_busy, 0, kSlotBitmapBytes, s);  // slot bitmaps + the side-store counter
   hipLaunchKernelGGL(bk_cf_kernel, g, b, 0, s, a, tabs);
   hipLaunchKernelGGL(bk_scan_kernel, dim3(1), dim3(kScanThreads), 0, s, a, L.n_tiles, L.prefix, L.prefix_long);
   hipLaunchKernelGGL(bk_ladder_kernel, g, b, 0, s, a, tabs, L.n_tiles, L.prefix);
