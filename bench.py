@@ -96,6 +96,8 @@ def parse(argv=None):
                          "hh_mgpu_solve_shards (RCCL all-reduce inside the library, host ordered sum when "
                          "RCCL is unavailable) instead of one rank per GPU")
     ap.add_argument("--mgpu-flags", type=int, default=0, help="hh_mgpu_create flags: 0 auto, 1 host sum, 2 RCCL")
+    ap.add_argument("--no-single-process-child", action="store_true",
+                    help="do not run the one-process form as a child (profilers that preload into children)")
     # rehearsal knobs (tests): ranks on one GPU need gloo (RCCL refuses two ranks per device)
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl")
     ap.add_argument("--devices", default="", help="comma list: device ordinal of each local rank")
@@ -652,7 +654,7 @@ def main():
     if rank != 0:
         return
 
-    if not args.no_extra:
+    if not args.no_extra and not args.no_single_process_child:
         if world > 1:
             time.sleep(2.0)  # the other ranks are leaving their GPUs
         out["single_process"] = run_single_process_child(args, world)

@@ -62,9 +62,10 @@ def test_heston_euler_replay_ragged(hhlib, oracle, n_paths, n_steps):
 @pytest.mark.parametrize("dyn", [GBM, HES])
 @pytest.mark.parametrize("n_steps", [1, 2, 5, 9])
 def test_replay_ragged_above_the_small_grid_threshold(hhlib, oracle, dyn, n_steps):
-    """More than 512 workgroups: the launch takes the drain form of the LDS ring (ragged last
-    tile, odd step counts, fewer chunks than ring slots); below that the pipelined deep ring runs
-    (test_heston_euler_replay_ragged)."""
+    """A grid of more than 512 workgroups (beyond the chip's resident set: workgroups start and leave
+    while others run) with a ragged last tile, odd step counts and runs shorter than one pipeline
+    chunk: the register pipeline's guarded head and tail (test_heston_euler_replay_ragged covers the
+    small grids)."""
     n_paths = 512 * 256 + 4099
     seeds = seeds_for(n_paths, 9)
     m = o.make_model(sigma=0.2 if dyn == GBM else 0.3)
