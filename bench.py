@@ -389,7 +389,7 @@ def single_process(args):
     return 0
 
 
-def run_single_process_child(args, world, timeout=420):
+def run_single_process_child(args, world, timeout=240):
     """The one-process form of the same run, as a child process (it owns its devices' contexts and its
     RCCL communicators; a hang or failure there costs this block, not the line)."""
     cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(world), "--single-process",

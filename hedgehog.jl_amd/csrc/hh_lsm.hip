@@ -45,6 +45,7 @@
 // are dealt to 256 lanes (r, r+256, …, added in order) which are summed by the same butterfly and,
 // over their 4 waves, in order.
 #include <cmath>
+#include <type_traits>
 
 #include "hh_kernels.h"
 #include "hh_math.h"
@@ -117,12 +118,48 @@ constexpr int log2_of(int p) { return p <= 1 ? 0 : 1 + log2_of(p / 2); }
 // moves half as many values as the one before (P2 + log2(64/P2) exchanges instead of 6·P2).  The
 // tree — and so every bit of the totals — is the same for every P2.  On return the total of value i
 // is a[0] of the lanes with (lane >> (6 - log2 P2)) == i.
+// x of lane (l ^ OFF), without the LDS round trip of __shfl_xor (ds_bpermute_b32, ~100 cycles each, and
+// three 16-value butterflies per date sit on the induction's critical path): DPP moves inside a row of
+// 16 lanes (xor 1, 2: quad_perm; xor 4: row_shl / row_shr by 4 into alternate banks; xor 8: row_ror:8),
+// gfx950's v_permlane16_swap / v_permlane32_swap across rows.  Same partner, same value: the sums do
+// not change by a bit.
+#ifndef HH_LSM_DPP
+#define HH_LSM_DPP 1
+#endif
+template <int OFF>
+__device__ __forceinline__ unsigned xor_lane_u32(unsigned x, int lane) {
+  if constexpr (OFF == 1) return (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, 0xB1, 0xF, 0xF, false);
+  else if constexpr (OFF == 2) return (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x4E, 0xF, 0xF, false);
+  else if constexpr (OFF == 4) {
+    int t = __builtin_amdgcn_update_dpp((int)x, (int)x, 0x104, 0xF, 0x5, false);  // lanes 0-3, 8-11 of a row: l + 4
+    return (unsigned)__builtin_amdgcn_update_dpp(t, (int)x, 0x114, 0xF, 0xA, false);  // lanes 4-7, 12-15: l - 4
+  } else if constexpr (OFF == 8) return (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x128, 0xF, 0xF, false);
+  else if constexpr (OFF == 16) {
+    const auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false);  // odd rows of [0] <-> even rows of [1]
+    return (lane & 16) ? r[0] : r[1];
+  } else {
+    static_assert(OFF == 32, "xor offsets of a wave64 butterfly");
+    const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);  // upper half of [0] <-> lower half of [1]
+    return (lane & 32) ? r[0] : r[1];
+  }
+}
+template <int OFF>
+__device__ __forceinline__ double xor_lane(double x, int lane) {
+#if HH_LSM_DPP
+  const unsigned long long b = (unsigned long long)__double_as_longlong(x);
+  const unsigned lo = xor_lane_u32<OFF>((unsigned)b, lane), hi = xor_lane_u32<OFF>((unsigned)(b >> 32), lane);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+#else
+  return __shfl_xor(x, OFF, 64);
+#endif
+}
+
 template <int P2>
 __device__ __forceinline__ void wave_reduce_multi(double (&a)[P2]) {
   const int lane = threadIdx.x & 63;
   int cnt = P2;
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) {
+  auto step = [&](auto off_c) {
+    constexpr int off = decltype(off_c)::value;
     if (cnt > 1) {
       const int h = cnt / 2;
       const bool upper = (lane & off) != 0;
@@ -134,14 +171,20 @@ __device__ __forceinline__ void wave_reduce_multi(double (&a)[P2]) {
           const double lo = a[i], hi = a[i + h];
           const double send = upper ? lo : hi;
           const double keep = upper ? hi : lo;
-          a[i] = keep + __shfl_xor(send, off, 64);
+          a[i] = keep + xor_lane<off>(send, lane);
         }
       }
       cnt = h;
     } else {
-      a[0] += __shfl_xor(a[0], off, 64);
+      a[0] += xor_lane<off>(a[0], lane);
     }
-  }
+  };
+  step(std::integral_constant<int, 32>{});
+  step(std::integral_constant<int, 16>{});
+  step(std::integral_constant<int, 8>{});
+  step(std::integral_constant<int, 4>{});
+  step(std::integral_constant<int, 2>{});
+  step(std::integral_constant<int, 1>{});
 }
 
 // NW waves x 64 lanes x P2 values -> tot[P2] in LDS (valid for every thread after the call):

@@ -42,12 +42,15 @@ RcclApi& rccl() {
   static std::once_flag once;
   std::call_once(once, [] {
     const char* env = std::getenv("HEDGEHOG_MC_RCCL");
-    const char* names[] = {env, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-    for (const char* n : names) {
-      if (!n || !*n) continue;
-      api.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
-      if (api.lib) break;
-    }
+    if (env && *env) api.lib = dlopen(env, RTLD_NOW | RTLD_LOCAL);
+    // a copy the process has ALREADY loaded first (PyTorch ships its own librccl.so, built against the HIP
+    // runtime the process runs on): the communicators then live on the same runtime as the streams
+    const char* loaded[] = {"librccl.so", "librccl.so.1"};
+    for (const char* n : loaded)
+      if (!api.lib) api.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* n : names)
+      if (!api.lib) api.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
     if (!api.lib) {
       snprintf(api.why, sizeof(api.why), "librccl not found (%s)", dlerror());
       return;

@@ -177,11 +177,12 @@ function _structs(r; em_split::Bool = true, compat_sqrt_alpha::Bool = false,
     model = HHModel(v[1], v[2], v[3], v[4], v[5], r.rho, v[6], v[7], r.T, v[8], r.cp,
                     ptr(1), ptr(2), ptr(3), ptr(4), ptr(5), ptr(6), ptr(7), ptr(8))
     noise = replay === nothing ? HH_NOISE_GENERATE : HH_NOISE_REPLAY
-    config = HHConfig(r.dynamics, r.strategy, r.anti, em_split, compat_sqrt_alpha,
-                      noise, replay_layout, 0, 0, 0, UInt32(r.steps), UInt32(r.P), UInt64(n_paths),
+    config = HHConfig(Int32(r.dynamics), Int32(r.strategy), Int32(r.anti), Int32(em_split),
+                      Int32(compat_sqrt_alpha), noise, replay_layout, Int32(0), Int32(0), Int32(0),
+                      UInt32(r.steps), UInt32(r.P), UInt64(n_paths),
                       UInt64(path_offset), pointer(r.seeds) + 8 * seed_offset,
                       replay === nothing ? Ptr{Cdouble}(C_NULL) : pointer(replay),
-                      0.0, 0.0, 0.0, 0.0, 0, 0,
+                      0.0, 0.0, 0.0, 0.0, Int32(0), Int32(0),
                       UInt64(length(r.seeds) - seed_offset),
                       UInt64(replay === nothing ? 0 : length(replay)))
     return model, config
