@@ -138,6 +138,8 @@ SYMBOLS = [
     ("hh_mgpu_solve", C.c_int, [_vp, C.POINTER(hh_model), C.POINTER(hh_config), C.POINTER(hh_result), _vp]),
     ("hh_mgpu_solve_shards", C.c_int, [_vp, C.POINTER(hh_model), C.POINTER(hh_config), C.POINTER(hh_result), _vp]),
     ("hh_mgpu_solve_basket", C.c_int, [_vp, C.POINTER(hh_model), C.POINTER(hh_config), _vp, _vp, C.c_uint32, _vp]),
+    ("hh_mgpu_lsm_solve", C.c_int, [_vp, C.POINTER(hh_model), C.POINTER(hh_config), C.c_int32, C.c_double,
+                                    C.POINTER(hh_lsm_result), _vp, _vp]),
 ]
 
 _lib = None

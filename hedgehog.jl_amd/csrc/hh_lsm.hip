@@ -1061,6 +1061,9 @@ __global__ __launch_bounds__(kLsmWg, (Q * kLsmWg > 1024 ? 2 : 4)) void lsm_persi
         }
         HH_STAMP(4)  // moment sums + their wave butterfly
         lds_barrier();
+#if HH_LSM_STAMPS > 1
+        HH_STAMP(7)  // (diagnostic: the barrier's wait goes to "loop overhead")
+#endif
         total_and_publish(e + 1, 0, 0, /*tag_now=*/t < 3);  // wave 0: the stores of A are on their way
         HH_STAMP(6)  // workgroup total of A, stores issued
         if (t >= 3) {  // power sums of row t-2 (xl[cur ^ 1]): B of epoch e+2, needed by the fit of date t-2

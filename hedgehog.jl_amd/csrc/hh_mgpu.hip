@@ -81,6 +81,8 @@ struct hh_mgpu {
   std::vector<rccl_comm_t> comms;
   double* host = nullptr;  // pinned, n x acc_cap
   size_t host_cap = 0;
+  std::vector<double*> xchg;  // per device: the exchange vector of a sharded LSM solve
+  std::vector<size_t> xchg_cap;
   char err[512] = {0};
   std::mutex mu;
 };
@@ -258,6 +260,8 @@ int hh_mgpu_create(hh_mgpu** out, const int* device_ids, int n_devices, int flag
   mg->acc.assign(n_devices, nullptr);
   mg->red.assign(n_devices, nullptr);
   mg->acc_cap.assign(n_devices, 0);
+  mg->xchg.assign(n_devices, nullptr);
+  mg->xchg_cap.assign(n_devices, 0);
   for (int g = 0; g < n_devices; ++g) {
     const int rc = hh_ctx_create(&mg->ctx[g], device_ids[g]);
     if (rc) {
@@ -305,6 +309,7 @@ void hh_mgpu_destroy(hh_mgpu* mg) {
     (void)hipSetDevice(mg->devices[g]);
     if (mg->acc[g]) (void)hipFree(mg->acc[g]);
     if (mg->red[g]) (void)hipFree(mg->red[g]);
+    if (mg->xchg[g]) (void)hipFree(mg->xchg[g]);
     if (mg->ctx[g]) hh_ctx_destroy(mg->ctx[g]);
   }
   if (mg->host) (void)hipHostFree(mg->host);
@@ -464,6 +469,155 @@ int hh_mgpu_solve_basket(hh_mgpu* mg, const hh_model* m, const hh_config* cfg, c
     out[k].kernel_ms = kernel_ms;
     out[k].total_ms = total;
   }
+  return HH_OK;
+}
+
+// SUM all-reduce of the first n doubles of every device's exchange vector, in place
+static int lsm_exchange(hh_mgpu* mg, size_t n) {
+  if (mg->n == 1) return HH_OK;
+  if (mg->mode == HH_MGPU_REDUCE_RCCL) {
+    RcclApi& api = rccl();
+    int e = api.GroupStart();
+    for (int g = 0; g < mg->n && e == kNcclSuccess; ++g)
+      e = api.AllReduce(mg->xchg[g], mg->xchg[g], n, kNcclDouble, kNcclSum, mg->comms[g], mg->ctx[g]->stream);
+    const int e2 = api.GroupEnd();
+    if (e == kNcclSuccess) e = e2;
+    if (e != kNcclSuccess) return mfail(mg, HH_ERR_RCCL, "ncclAllReduce failed inside the LSM induction: %s", api.GetErrorString(e));
+    return HH_OK;
+  }
+  // host ordered sum: local vectors back, added in the order g = 0 … G-1, the total out again
+  int rc = ensure_acc(mg, n > (size_t)HH_ACC_LEN ? n : (size_t)HH_ACC_LEN);
+  if (rc) return rc;
+  for (int g = 0; g < mg->n; ++g) {
+    HH_MHIP(mg, hipSetDevice(mg->devices[g]));
+    HH_MHIP(mg, hipMemcpyAsync(mg->host + (size_t)g * n, mg->xchg[g], n * sizeof(double), hipMemcpyDeviceToHost,
+                               mg->ctx[g]->stream));
+  }
+  for (int g = 0; g < mg->n; ++g) {
+    HH_MHIP(mg, hipSetDevice(mg->devices[g]));
+    HH_MHIP(mg, hipStreamSynchronize(mg->ctx[g]->stream));
+  }
+  for (int g = 1; g < mg->n; ++g)
+    for (size_t i = 0; i < n; ++i) mg->host[i] += mg->host[(size_t)g * n + i];
+  for (int g = 0; g < mg->n; ++g) {
+    HH_MHIP(mg, hipSetDevice(mg->devices[g]));
+    HH_MHIP(mg, hipMemcpyAsync(mg->xchg[g], mg->host, n * sizeof(double), hipMemcpyHostToDevice, mg->ctx[g]->stream));
+  }
+  for (int g = 0; g < mg->n; ++g) {  // mg->host is reused by the next exchange
+    HH_MHIP(mg, hipSetDevice(mg->devices[g]));
+    HH_MHIP(mg, hipStreamSynchronize(mg->ctx[g]->stream));
+  }
+  return HH_OK;
+}
+
+int hh_mgpu_lsm_solve(hh_mgpu* mg, const hh_model* m, const hh_config* cfg, int32_t degree, double step_discount,
+                      hh_lsm_result* out, int32_t* stop_time, double* stop_value) {
+  if (!mg) return HH_ERR_INVALID;
+  std::lock_guard<std::mutex> lock__(mg->mu);
+  if (!m || !cfg || !out) return mfail(mg, HH_ERR_INVALID, "hh_mgpu_lsm_solve: NULL argument");
+  if (cfg->seeds_on_device || !cfg->seeds || cfg->noise_mode != HH_NOISE_GENERATE)
+    return mfail(mg, HH_ERR_INVALID, "hh_mgpu_lsm_solve: GENERATE noise with host seeds");
+  if (cfg->n_paths < (uint64_t)mg->n) return mfail(mg, HH_ERR_INVALID, "every device needs at least one trajectory");
+  if (cfg->seeds_len && cfg->seeds_len < cfg->n_paths)
+    return mfail(mg, HH_ERR_INVALID, "Number of seeds (%llu) must be >= number of trajectories (%llu)",
+                 (unsigned long long)cfg->seeds_len, (unsigned long long)cfg->n_paths);
+  if (degree < 1 || degree > 8 || cfg->n_steps == 0) return mfail(mg, HH_ERR_INVALID, "LSM: 1 <= degree <= 8, n_steps >= 1");
+  const auto t0 = std::chrono::steady_clock::now();
+  const uint64_t N = cfg->n_paths;
+  const uint32_t steps = cfg->n_steps;
+  const size_t rows = (size_t)steps + 1, nv = 2 * (size_t)degree + 1, nb = (size_t)degree + 1;
+  size_t n_x = hh_lsm_shard_xchg_elems(steps, degree);
+  if (n_x < (size_t)HH_ACC_LEN) n_x = HH_ACC_LEN;  // the same vector carries the final accumulator
+  std::vector<hh_config> cs(mg->n, *cfg);
+  std::vector<uint64_t> starts(mg->n, 0);
+  auto fail_shard = [&](int g, int rc) {
+    mfail(mg, rc, "shard %d (device %d): %s", g, mg->devices[g], hh_last_error(mg->ctx[g]));
+    sync_all(mg);
+    return rc;
+  };
+  for (int g = 0; g < mg->n; ++g) {
+    uint64_t a, b;
+    shard_range(N, mg->n, g, false, &a, &b);
+    if (b <= a) return mfail(mg, HH_ERR_INVALID, "every device needs at least one trajectory");
+    starts[g] = a;
+    cs[g].n_paths = b - a;
+    cs[g].seeds = cfg->seeds + a;  // trajectory i keyed by seeds[i] (montecarlo.jl:331), both path sources
+    cs[g].seeds_len = 0;
+    if (mg->xchg_cap[g] < n_x) {
+      HH_MHIP(mg, hipSetDevice(mg->devices[g]));
+      if (mg->xchg[g]) HH_MHIP(mg, hipFree(mg->xchg[g]));
+      mg->xchg[g] = nullptr;
+      mg->xchg_cap[g] = 0;
+      if (hipMalloc((void**)&mg->xchg[g], n_x * sizeof(double)) != hipSuccess)
+        return mfail(mg, HH_ERR_NOMEM, "hipMalloc of the LSM exchange vector failed");
+      mg->xchg_cap[g] = n_x;
+    }
+  }
+  int rc = ensure_acc(mg, (size_t)HH_ACC_LEN);
+  if (rc) return rc;
+  for (int g = 0; g < mg->n; ++g) {
+    HH_MHIP(mg, hipSetDevice(mg->devices[g]));
+    HH_MHIP(mg, hipEventRecord(mg->ctx[g]->ev0, mg->ctx[g]->stream));
+    if ((rc = hh_lsm_shard_begin(mg->ctx[g], m, &cs[g], degree, step_discount, mg->xchg[g]))) return fail_shard(g, rc);
+  }
+  auto phase = [&](int32_t ph, uint32_t t, size_t n_in) -> int {
+    int e = lsm_exchange(mg, n_in);
+    if (e) {
+      sync_all(mg);
+      return e;
+    }
+    for (int g = 0; g < mg->n; ++g)
+      if ((e = hh_lsm_shard_phase(mg->ctx[g], ph, t, mg->xchg[g], mg->xchg[g]))) return fail_shard(g, e);
+    return HH_OK;
+  };
+  if ((rc = phase(HH_LSM_PHASE_POW, 0, rows * 3))) return rc;
+  if ((rc = phase(HH_LSM_PHASE_INIT, 0, rows * nv))) return rc;
+  for (uint32_t t = steps - 1; t >= 1; --t)  // for i = nsteps:-1:2, t = i-1 (:112-113)
+    if ((rc = phase(HH_LSM_PHASE_STEP, t, nb))) return rc;
+  // the shards' Σ, Σ² of the discounted stopped values; their stopping_info into the caller's order
+  uint32_t regressed = 0, skipped = 0;
+  std::vector<int32_t> tau;
+  std::vector<double> val;
+  for (int g = 0; g < mg->n; ++g) {
+    const uint64_t n = cs[g].n_paths, ntot = n * (cfg->antithetic ? 2 : 1);
+    if (stop_time) tau.resize(ntot);
+    if (stop_value) val.resize(ntot);
+    HH_MHIP(mg, hipSetDevice(mg->devices[g]));
+    HH_MHIP(mg, hipEventRecord(mg->ctx[g]->ev1, mg->ctx[g]->stream));
+    uint32_t rg = 0, sk = 0;
+    if ((rc = hh_lsm_shard_finish(mg->ctx[g], mg->xchg[g], stop_time ? tau.data() : nullptr,
+                                  stop_value ? val.data() : nullptr, nullptr, &rg, &sk)))
+      return fail_shard(g, rc);
+    if (g == 0) {
+      regressed = rg;
+      skipped = sk;
+    }
+    for (int h = 0; h < (cfg->antithetic ? 2 : 1); ++h) {
+      if (stop_time) std::memcpy(stop_time + (size_t)h * N + starts[g], tau.data() + (size_t)h * n, n * sizeof(int32_t));
+      if (stop_value) std::memcpy(stop_value + (size_t)h * N + starts[g], val.data() + (size_t)h * n, n * sizeof(double));
+    }
+  }
+  if ((rc = lsm_exchange(mg, (size_t)HH_ACC_LEN))) {
+    sync_all(mg);
+    return rc;
+  }
+  HH_MHIP(mg, hipSetDevice(mg->devices[0]));
+  HH_MHIP(mg, hipMemcpyAsync(mg->host, mg->xchg[0], HH_ACC_LEN * sizeof(double), hipMemcpyDeviceToHost,
+                             mg->ctx[0]->stream));
+  double worst = 0.0;
+  for (int g = 0; g < mg->n; ++g) {
+    HH_MHIP(mg, hipSetDevice(mg->devices[g]));
+    HH_MHIP(mg, hipStreamSynchronize(mg->ctx[g]->stream));
+    float ms = 0.f;
+    HH_MHIP(mg, hipEventElapsedTime(&ms, mg->ctx[g]->ev0, mg->ctx[g]->ev1));
+    if (ms > worst) worst = ms;
+  }
+  if ((rc = hh_lsm_finalize(mg->host, out))) return mfail(mg, rc, "finalize failed");
+  out->rows_regressed = regressed;
+  out->rows_skipped = skipped;
+  out->form = HH_LSM_FORM_PER_DATE;
+  out->kernel_ms = worst;
+  out->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   return HH_OK;
 }
 

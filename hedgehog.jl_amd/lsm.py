@@ -109,6 +109,15 @@ def solve_lsm(prob: PricingProblem, method: LSM, spot_paths: bool = False,
     val = np.empty(ntot) if stopping_info else None
     grid = np.empty((nsteps + 1, ntot)) if spot_paths else None
     res = _ffi.hh_lsm_result()
+    if mc.devices is not None:  # ONE call, the trajectories sharded over these GPUs inside the library
+        if spot_paths:
+            raise ValueError("spot_paths is not returned by the multi-GPU form")
+        mg = _ffi.get_multi_gpu(tuple(mc.devices))
+        mg.check(mg.lib.hh_mgpu_lsm_solve(mg.handle, C.byref(model), C.byref(c), method.degree, step_discount,
+                                          C.byref(res), tau.ctypes.data if stopping_info else None,
+                                          val.ctypes.data if stopping_info else None))
+        return LSMSolution(prob, method, res.price, (tau, val) if stopping_info else None, None,
+                           std_error=res.std_error, result=res)
     ctx = _ffi.get_context(mc.device)
     ctx.check(ctx.lib.hh_lsm_solve(ctx.handle, C.byref(model), C.byref(c), method.degree,
                                    step_discount, C.byref(res),

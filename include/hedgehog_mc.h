@@ -280,6 +280,7 @@ int hh_mgpu_solve_shards(hh_mgpu* mg, const hh_model* model, const hh_config* sh
 int hh_mgpu_solve_basket(hh_mgpu* mg, const hh_model* model, const hh_config* cfg, const double* strikes,
                          const double* cps, uint32_t n_payoffs, hh_result* out /* n_payoffs */);
 
+
 /*
  * Several payoffs on ONE simulation — solve(::BasketPricingProblem, method) for payoffs that share
  * an expiry (src/calibration/basket.jl:35-38 prices them as independent solves; with the fixed
@@ -404,6 +405,22 @@ int hh_lsm_finalize(const double* accum_host, hh_lsm_result* out);
  * -DHH_LSM_STAMPS=1 leaves behind a persistent LSM solve of that shape; zeros from the shipped build. */
 int hh_lsm_debug_read(hh_ctx* ctx, uint64_t n_paths_total, uint32_t n_steps, int32_t degree,
                       double* out8);
+
+/*
+ * hh_lsm_solve (least_squares_montecarlo.jl:99-136) with the trajectories sharded over the devices of
+ * mg, in ONE call: the phased induction of hh_lsm_shard_* on every device, the vectors of local sums
+ * all-reduced INSIDE the library between consecutive phases (2 + (n_steps − 1) + 1 exchanges of at most
+ * (n_steps + 1)·(2·degree + 1) doubles: ncclAllReduce in place on the shards' streams, or — host-sum
+ * contexts — copied back, added in the order g = 0 … G−1 and handed out again).  Unlike the European
+ * solve this path has real exchange steps, so an RCCL failure in the middle is an error (HH_ERR_RCCL),
+ * not a fall-back.  cfg: the whole ensemble with HOST seeds, as for hh_lsm_solve; every device must get
+ * at least one trajectory.  stop_time / stop_value (nullable, host): the reference's stopping_info in
+ * the whole-ensemble order of hh_lsm_solve (n_paths entries, then the n_paths mirrored ones).  Same
+ * regression sums up to their summation order: identical stopping decisions except where a payoff
+ * equals its fitted continuation value to rounding.
+ */
+int hh_mgpu_lsm_solve(hh_mgpu* mg, const hh_model* model, const hh_config* cfg, int32_t degree,
+                      double step_discount, hh_lsm_result* out, int32_t* stop_time, double* stop_value);
 
 /*
  * Per-date EXACT Heston paths: the NoiseProblem that sde_problem(::PricingProblem, ::HestonDynamics,

@@ -466,8 +466,11 @@ end
 polynomial regression of degree `method.degree`.  Returns an `LSMSolution` whose `stopping_info` is
 rebuilt from the (time, value) arrays and whose `spot_paths` is the (nsteps+1) x npaths matrix.
 """
+# `devices = 0:7`: the same solve with the trajectories sharded over those GPUs inside the library
+# (hh_mgpu_lsm_solve: the phased induction on every device, its per-date sums all-reduced in the library);
+# the spot grid is then not returned (`spot_paths` of the solution is an empty matrix).
 function solve_lsm_hip(prob::PricingProblem{VanillaOption{TS,TE,Hedgehog.American,C,S},I},
-                       method::Hedgehog.LSM) where {TS,TE,C,S,I<:BlackScholesInputs}
+                       method::Hedgehog.LSM; devices = nothing) where {TS,TE,C,S,I<:BlackScholesInputs}
     mc, m, payoff = method.mc_method, prob.market_inputs, prob.payoff
     (mc.dynamics isa LognormalDynamics && mc.strategy isa BlackScholesExact) ||
         throw(MethodError(Hedgehog.solve, (prob, method)))
@@ -486,9 +489,21 @@ function solve_lsm_hip(prob::PricingProblem{VanillaOption{TS,TE,Hedgehog.America
         model = HHModel(Float64(m.spot), 0.0, 0.0, 0.0, Float64(get_vol(m.sigma, nothing, nothing)), 0.0,
                         Float64(zero_rate(m.rate, 0.0)), 1.0, Float64(T), Float64(payoff.strike),
                         payoff.call_put(), ntuple(_ -> Ptr{Cdouble}(C_NULL), 8)...)
-        config = HHConfig(0, 1, anti, 1, 0, 0, 0, 0, 0, 0, UInt32(nsteps), UInt32(0), UInt64(n),
-                          UInt64(0), pointer(seeds), Ptr{Cdouble}(C_NULL), 0.0, 0.0, 0.0, 0.0, 0, 0,
+        config = HHConfig(Int32(0), Int32(1), Int32(anti), Int32(1), Int32(0), Int32(0), Int32(0), Int32(0),
+                          Int32(0), Int32(0), UInt32(nsteps), UInt32(0), UInt64(n),
+                          UInt64(0), pointer(seeds), Ptr{Cdouble}(C_NULL), 0.0, 0.0, 0.0, 0.0, Int32(0), Int32(0),
                           UInt64(length(seeds)), UInt64(0))
+        if devices !== nothing
+            mg = multi_gpu(devices)
+            rc = ccall((:hh_mgpu_lsm_solve, LIB[]), Cint,
+                       (Ptr{Cvoid}, Ref{HHModel}, Ref{HHConfig}, Int32, Cdouble, Ref{HHLsmResult},
+                        Ptr{Int32}, Ptr{Cdouble}),
+                       mg.handle, model, config, Int32(method.degree), Float64(step_discount), res,
+                       pointer(tau), pointer(val))
+            rc == 0 || error("hh_mgpu_lsm_solve failed ($rc): $(last_error(mg))")
+            return Hedgehog.LSMSolution(prob, method, res[].price,
+                                        [(Int(tau[p]), val[p]) for p in 1:ntot], Matrix{Float64}(undef, 0, 0))
+        end
         rc = ccall((:hh_lsm_solve, LIB[]), Cint,
                    (Ptr{Cvoid}, Ref{HHModel}, Ref{HHConfig}, Int32, Cdouble, Ref{HHLsmResult},
                     Ptr{Int32}, Ptr{Cdouble}, Ptr{Cdouble}),

@@ -250,3 +250,36 @@ def test_host_mirror_devices_keyword(hhlib):
     assert two.price == pytest.approx(one.price, rel=1e-13)
     np.testing.assert_array_equal(one.ensemble[0], two.ensemble[0])
     np.testing.assert_array_equal(one.ensemble[1], two.ensemble[1])
+
+
+@pytest.mark.parametrize("case", [dict(model="gbm", n=6000, steps=20, degree=4, anti=1, cp=-1.0, strike=100.0, seed=7),
+                                  dict(model="gbm", n=3001, steps=7, degree=2, anti=0, cp=-1.0, strike=110.0, seed=8),
+                                  dict(model="heston", n=2500, steps=6, degree=3, anti=0, cp=-1.0, strike=100.0, seed=9)],
+                         ids=lambda c: f"{c['model']}-{c['n']}x{c['steps']}")
+@pytest.mark.parametrize("devices", [(0,), (0, 0), (0, 0, 0)])
+def test_lsm_sharded_inside_the_library(hhlib, case, devices):
+    """hh_mgpu_lsm_solve: the phased induction on every shard with the exchanges INSIDE the library (here
+    the host ordered sum: device 0 listed several times).  One device: the fused solve bit for bit;
+    several: the same stopping decisions except where a payoff equals its fitted continuation to
+    rounding, as for the two-process form (tests/test_gpu_sharded.py)."""
+    import dataclasses
+
+    import hedgehog_jl_amd as hh
+    from tests.shard_worker import problem
+    prob, method = problem(case)
+    single = hh.solve(prob, method)
+    mc = dataclasses.replace(method.mc_method, devices=devices)
+    many = hh.solve(prob, hh.LSM(mc, method.degree))
+    n_tot = case["n"] * (2 if case["anti"] else 1)
+    assert many.result.n_paths_total == n_tot
+    tau1, val1 = single.stopping_info
+    tau2, val2 = many.stopping_info
+    same = tau1 == tau2
+    if len(devices) == 1:
+        assert many.price == single.price and same.all()
+        np.testing.assert_array_equal(val1, val2)
+        return
+    assert same.mean() >= 0.998
+    np.testing.assert_allclose(val2[same], val1[same], rtol=1e-12)
+    assert many.price == pytest.approx(single.price, rel=2e-4 if not same.all() else 1e-11)
+    assert many.std_error == pytest.approx(single.std_error, rel=1e-3)
