@@ -631,6 +631,95 @@ __attribute__((amdgpu_waves_per_eu(REPLAY ? HH_REPLAY_MINW : 1,
 }
 
 // ------------------------------------------------------------------------------------------
+// Experiment (review r2, item 7): an antithetic pair split over TWO lanes
+// ------------------------------------------------------------------------------------------
+//
+// 512 threads per tile: thread t < 256 integrates trajectory t with +dW, thread t + 256 its mirror with
+// −dW; both halves load the same 2 KiB rows (the second read is an L1 / L2 hit, HBM traffic unchanged),
+// the pair average is formed through LDS at the end.  Per LANE the arithmetic per loaded byte halves —
+// per SIMD it does not (the two waves issue 2 x 33 instructions where one issued 61), which is why this
+// form is not faster than the one-lane pair (profiles/r03_e_anti_split_ab.txt).  Built only with
+// -DHH_ANTI_SPLIT=1 (tools/tune_replay.py); price-only, tile-major REPLAY.
+#ifndef HH_ANTI_SPLIT
+#define HH_ANTI_SPLIT 0
+#endif
+#ifndef HH_ANTI_SPLIT_MAXW
+#define HH_ANTI_SPLIT_MAXW 4
+#endif
+#if HH_ANTI_SPLIT
+template <class M>
+__global__ __launch_bounds__(2 * kTile)
+__attribute__((amdgpu_waves_per_eu(1, HH_ANTI_SPLIT_MAXW))) void euler_pair_split_kernel(const SimArgs<0> a) {
+  constexpr int NC = M::NCOMP, CH = HH_REPLAY_CHUNK_PRICE;
+  using State = typename M::State;
+  const uint32_t tile = blockIdx.x, tid = threadIdx.x & (kTile - 1);
+  const bool mirror = threadIdx.x >= (uint32_t)kTile;
+  const double sgn = mirror ? -1.0 : 1.0;
+  const uint64_t path = (uint64_t)tile * kTile + tid;
+  const uint32_t n_steps = a.n_steps;
+  State st;
+  M::init(st, a);
+  const double* __restrict__ base = a.replay + (size_t)tile * n_steps * NC * kTile + tid;
+  double X[CH][NC], Y[CH][NC];
+  auto ld = [&](double(&buf)[CH][NC], uint32_t s0, bool guard) {
+#pragma unroll
+    for (int u = 0; u < CH; ++u)
+      if (!guard || s0 + u < n_steps)
+#pragma unroll
+        for (int c = 0; c < NC; ++c) buf[u][c] = stream_load<double>(base + ((size_t)(s0 + u) * NC + c) * kTile);
+  };
+  auto go = [&](const double(&buf)[CH][NC], uint32_t s0, bool guard) {
+#pragma unroll
+    for (int u = 0; u < CH; ++u)
+      if (!guard || s0 + u < n_steps) M::step(st, a, sgn * buf[u][0], NC > 1 ? sgn * buf[u][NC - 1] : 0.0);
+  };
+  uint32_t s = 0;
+  if (n_steps >= 2u * CH) {
+    ld(X, 0, false);
+    while (s + 3u * CH <= n_steps) {
+      ld(Y, s + CH, false);
+      go(X, s, false);
+      ld(X, s + 2u * CH, false);
+      go(Y, s + CH, false);
+      s += 2u * CH;
+    }
+    ld(Y, s + CH, true);
+    go(X, s, false);
+    s += CH;
+    ld(X, s + CH, true);
+    go(Y, s, true);
+    go(X, s + CH, true);
+  } else {
+    for (; s < n_steps; s += CH) {
+      ld(X, s, true);
+      go(X, s, true);
+    }
+  }
+  // pair average through LDS (montecarlo.jl:431), then the tile's record as the one-lane form leaves it
+  __shared__ double pm[4][kTile];
+  double S, p, pd[1], wS, wN;
+  payoff_of<0>(st.x, a, S, p, pd, wS, wN);
+  const bool livep = path < a.n_paths;
+  if (mirror) {
+    pm[0][tid] = p; pm[1][tid] = wS; pm[2][tid] = wN;
+    if (a.terminal && livep) a.terminal[a.n_paths + path] = S;
+  } else if (a.terminal && livep) {
+    a.terminal[path] = S;
+  }
+  __syncthreads();
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  if (!mirror && livep) {
+    p = (p + pm[0][tid]) / 2;
+    acc[0] = p;
+    acc[1] = p * p;
+    acc[2] = (wS + pm[1][tid]) / 2;
+    acc[3] = (wN + pm[2][tid]) / 2;
+  }
+  block_reduce_store<4, 2 * kTile / 64, 2>(acc, a.records + (size_t)tile * kRecStride);
+}
+#endif
+
+// ------------------------------------------------------------------------------------------
 // Euler–Maruyama on the REFERENCE's noise layout: path-major REPLAY
 // ------------------------------------------------------------------------------------------
 //
@@ -1123,6 +1212,14 @@ static int launch_euler_pm(const SimArgs<P>& a, bool anti, hipStream_t s) {
 template <class M, int P>
 static int launch_euler_m(const SimArgs<P>& a, bool replay, bool anti, hipStream_t s, bool path_major = false) {
   if (replay && path_major) return launch_euler_pm<M, P>(a, anti, s);
+#if HH_ANTI_SPLIT
+  if constexpr (P == 0) {
+    if (replay && anti) {
+      hipLaunchKernelGGL((euler_pair_split_kernel<M>), dim3(a.n_tiles), dim3(2 * kTile), 0, s, a);
+      return (int)hipGetLastError();
+    }
+  }
+#endif
   if (replay) return anti ? launch_euler_t<M, P, true, true>(a, s) : launch_euler_t<M, P, true, false>(a, s);
   return anti ? launch_euler_t<M, P, false, true>(a, s) : launch_euler_t<M, P, false, false>(a, s);
 }

@@ -13,15 +13,20 @@ import torch
 
 from hedgehog_jl_amd import _ffi
 
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
+GRID = len(sys.argv) > 1 and sys.argv[1] == "grid"  # the exact Heston grid 2e5 x 12 instead of config 4
+n = 200_000 if GRID else int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 libs = {"shipped": _ffi.LIB_PATH}
 for f in sorted(glob.glob(os.path.join(ROOT, "hedgehog.jl_amd", "lib", "variants", "libhh_bk_*.so"))):
     libs[os.path.basename(f)[9:-3]] = f
 seed0 = torch.tensor([99], dtype=torch.int64, device="cuda")
 acc = torch.zeros(16, dtype=torch.float64, device="cuda")
 m = _ffi.make_model()
-c = _ffi.make_config(_ffi.HH_HESTON, _ffi.HH_BROADIE_KAYA, n)
-c.seeds, c.seeds_on_device = seed0.data_ptr(), 1
+c = _ffi.make_config(_ffi.HH_HESTON, _ffi.HH_BROADIE_KAYA, n, 12 if GRID else 1)
+if GRID:
+    seeds = torch.arange(1, n + 1, dtype=torch.int64, device="cuda")
+    c.seeds, c.seeds_on_device = seeds.data_ptr(), 1
+else:
+    c.seeds, c.seeds_on_device = seed0.data_ptr(), 1
 ctxs = {}
 for tag, path in libs.items():
     lib = C.CDLL(path)
@@ -36,6 +41,14 @@ times = {t: [] for t in ctxs}
 sums = {}
 for r in range(6):
     for tag, (lib, h) in ctxs.items():
+        if GRID:
+            res = _ffi.hh_result()
+            for _ in range(3):
+                assert lib.hh_heston_exact_grid(h, C.byref(m), C.byref(c), None, None, 0, C.byref(res)) == 0
+                if r:
+                    times[tag].append(res.kernel_ms)
+            sums[tag] = float(res.bk_cf_terms)
+            continue
         for _ in range(6):
             assert lib.hh_mc_accumulate(h, C.byref(m), C.byref(c), acc.data_ptr(), None) == 0
         buf = (C.c_double * 256)()
