@@ -904,7 +904,10 @@ __global__ __launch_bounds__(kLsmWg, (Q * kLsmWg > 1024 ? 2 : 4)) void lsm_persi
   double regressed = 0.0, skipped = 0.0;
 #if HH_LSM_STAMPS
   unsigned long long st_acc[kLsmStampSlots] = {}, st_t0 = __builtin_amdgcn_s_memrealtime();
-  const bool st_me = blockIdx.x == gridDim.x / 2 && threadIdx.x == 0;
+#ifndef HH_LSM_STAMP_THREAD
+#define HH_LSM_STAMP_THREAD 0  // which thread of the middle workgroup stamps (waves 0-3 and 4-7 differ, below)
+#endif
+  const bool st_me = blockIdx.x == gridDim.x / 2 && threadIdx.x == HH_LSM_STAMP_THREAD;
 #define HH_STAMP(k)                                                  \
   if (st_me) {                                                       \
     const unsigned long long now = __builtin_amdgcn_s_memrealtime(); \
