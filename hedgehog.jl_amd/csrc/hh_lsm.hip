@@ -126,6 +126,13 @@ constexpr int log2_of(int p) { return p <= 1 ? 0 : 1 + log2_of(p / 2); }
 #ifndef HH_LSM_DPP
 #define HH_LSM_DPP 1
 #endif
+#ifndef HH_LSM_SWAP_PAIRS  // A/B switches of round 3's later cuts (tools/lsm_breakdown.py; both bit-identical)
+#define HH_LSM_SWAP_PAIRS 1
+#endif
+#ifndef HH_LSM_GATHER_USED
+#define HH_LSM_GATHER_USED 1
+#endif
+
 template <int OFF>
 __device__ __forceinline__ unsigned xor_lane_u32(unsigned x, int lane) {
   if constexpr (OFF == 1) return (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, 0xB1, 0xF, 0xF, false);
@@ -166,6 +173,29 @@ __device__ __forceinline__ void wave_reduce_multi(double (&a)[P2]) {
 #pragma unroll
       for (int i = 0; i < P2 / 2; ++i) {
         if (i < h) {
+#if HH_LSM_DPP && HH_LSM_SWAP_PAIRS
+          if constexpr (off == 32 || off == 16) {
+            // v_permlane{32,16}_swap IS the exchange of this step: it swaps a[i] of the upper lanes with
+            // a[i + h] of their partners, after which every lane holds {what it keeps, what it was sent}
+            // in the two registers — no select on either side.  (Upper lanes add recv + keep instead of
+            // keep + recv: the same sum.)
+            const unsigned long long x = (unsigned long long)__double_as_longlong(a[i]);
+            const unsigned long long y = (unsigned long long)__double_as_longlong(a[i + h]);
+            unsigned xl, yl, xh, yh;
+            if constexpr (off == 32) {
+              const auto rl = __builtin_amdgcn_permlane32_swap((unsigned)x, (unsigned)y, false, false);
+              const auto rh = __builtin_amdgcn_permlane32_swap((unsigned)(x >> 32), (unsigned)(y >> 32), false, false);
+              xl = rl[0], yl = rl[1], xh = rh[0], yh = rh[1];
+            } else {
+              const auto rl = __builtin_amdgcn_permlane16_swap((unsigned)x, (unsigned)y, false, false);
+              const auto rh = __builtin_amdgcn_permlane16_swap((unsigned)(x >> 32), (unsigned)(y >> 32), false, false);
+              xl = rl[0], yl = rl[1], xh = rh[0], yh = rh[1];
+            }
+            a[i] = __longlong_as_double((long long)(((unsigned long long)xh << 32) | xl)) +
+                   __longlong_as_double((long long)(((unsigned long long)yh << 32) | yl));
+            continue;
+          }
+#endif
           // both elements into registers first: written as `upper ? a[i] : a[i + h]` the compiler
           // selects the ADDRESS, which makes `a` a dynamically indexed array in scratch memory
           const double lo = a[i], hi = a[i + h];
@@ -767,6 +797,7 @@ __device__ __forceinline__ void publish_record(const LsmPersistArgs& a, uint32_t
 // its record and then (and only then) loads its half with sc1 loads.  tot[32] on return.  Returns
 // false — for every thread of the workgroup — when a wait ran out or another workgroup gave up; the
 // caller leaves the kernel.
+template <int D>
 __device__ __forceinline__ bool gather_records(const LsmPersistArgs& a, uint32_t e, double* scratch,
                                                double* tot, int* ok_flag) {
   // no barrier on entry (*ok_flag is set once, at the start of the kernel, and only ever cleared): the
@@ -805,11 +836,25 @@ __device__ __forceinline__ bool gather_records(const LsmPersistArgs& a, uint32_t
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // no instruction: keeps the loads below the poll
     if (ok && mine) {
-#pragma unroll
-      for (int i = 0; i < kGrp; ++i)
+      // only the values a record of degree D carries (the others are zero on both sides): 9 + 10 of the
+      // 32 for D = 5 — every workgroup reads every record, so this is most of the induction's traffic
+      auto take = [&](int i) {
         v[i] = __longlong_as_double((long long)__hip_atomic_load(
             (gu64*)(a.rec + (ring * kRecP2 + g * kGrp + i) * a.n_chunks + r), __ATOMIC_RELAXED,
             __HIP_MEMORY_SCOPE_AGENT));
+      };
+      if (!HH_LSM_GATHER_USED) {
+#pragma unroll
+        for (int i = 0; i < kGrp; ++i) take(i);
+      } else if (g == 0) {
+#pragma unroll
+        for (int i = 0; i <= D; ++i) take(i);
+#pragma unroll
+        for (int i = kOffStats; i < kOffStats + 3; ++i) take(i);
+      } else {
+#pragma unroll
+        for (int i = 0; i < (2 * D > 3 ? 2 * D : 3); ++i) take(i);  // epoch 1: three statistics
+      }
     }
     if (!ok && (threadIdx.x & 63) == 0) {
       __hip_atomic_store((gu32*)a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -958,7 +1003,7 @@ __global__ __launch_bounds__(kLsmWg, (Q * kLsmWg > 1024 ? 2 : 4)) void lsm_persi
       wave_part<kGrp, kRecP2>(w, scratch, kGrp);
       finish_block<kRecP2, kLsmWaves>(scratch, tot);
       publish_record(a, 1u, tot);
-      alive = gather_records(a, 1u, gscratch, tot, &ok_flag);
+      alive = gather_records<D>(a, 1u, gscratch, tot, &ok_flag);
     }
     RowStat r_cur = rowstat_of(tot[kOffStats], tot[kOffStats + 1], tot[kOffStats + 2]);  // row M-1
     RowStat r_next = rowstat_of(tot[kGrp], tot[kGrp + 1], tot[kGrp + 2]);                // row M-2
@@ -1011,7 +1056,7 @@ __global__ __launch_bounds__(kLsmWg, (Q * kLsmWg > 1024 ? 2 : 4)) void lsm_persi
     for (uint32_t t = M - 1; alive && t >= 1; --t) {
       const uint32_t e = M - t + 1;  // epoch whose records hold the sums of row t
       HH_STAMP(7)
-      alive = gather_records(a, e, gscratch, tot, &ok_flag);
+      alive = gather_records<D>(a, e, gscratch, tot, &ok_flag);
       HH_STAMP(1)  // all-gather: wait, loads, reduction
       if (!alive) break;
       if (t >= 3) r_nn = rowstat_of(tot[kOffStats], tot[kOffStats + 1], tot[kOffStats + 2]);  // row t-2
