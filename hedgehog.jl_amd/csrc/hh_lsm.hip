@@ -65,9 +65,29 @@ constexpr int kLsmWaves = kLsmWg / 64;
 constexpr int kLsmMaxDeg = 8;
 constexpr uint64_t kLsmQ1Max = 1ull << 18;  // up to here chunks of 1024 trajectories, beyond it 8192
 constexpr int kLsmMaxResident = 256;        // chunks the persistent form handles (one per workgroup)
-constexpr int kLsmRing = 4;                 // record slots of the persistent all-gather (2 suffice)
+constexpr int kLsmRing = 16;                // record slots of the persistent all-gather (2 suffice for
+                                            // correctness; 16 dates between two uses of a slot make it all
+                                            // but certain that no L2 still holds the slot's previous lines)
 
-inline int lsm_q(uint64_t ntot) { return ntot <= kLsmQ1Max ? kLsmQSmall : kLsmQLarge; }
+// Trajectories per lane: the smallest of 2, 4, 8, 16 (x 512 lanes = chunks of 1024 … 8192) with which
+// the ensemble fits 256 chunks — one workgroup per CU in the persistent form, whose date is bounded by
+// what ONE workgroup has to do (a 10^6-trajectory induction in chunks of 8192 would keep half the chip
+// idle and every busy CU twice as long).  The chunk size is part of the summation tree: both forms of
+// the induction (and every phase of the sharded one) use lsm_q() of the same ensemble.
+inline int lsm_q(uint64_t ntot) {
+  int q = kLsmQSmall;
+  for (uint64_t cap = kLsmQ1Max; q < kLsmQLarge && ntot > cap; cap <<= 1) q <<= 1;
+  return q;
+}
+// f(std::integral_constant<int, Q>) for the Q that lsm_q() returned
+template <class F>
+inline auto with_q(int q, F&& f) {
+  static_assert(kLsmQLarge == 8 * kLsmQSmall, "four chunk sizes");
+  if (q == kLsmQSmall) return f(std::integral_constant<int, kLsmQSmall>{});
+  if (q == 2 * kLsmQSmall) return f(std::integral_constant<int, 2 * kLsmQSmall>{});
+  if (q == 4 * kLsmQSmall) return f(std::integral_constant<int, 4 * kLsmQSmall>{});
+  return f(std::integral_constant<int, kLsmQLarge>{});
+}
 inline uint32_t lsm_nch(uint64_t ntot) {
   const uint64_t per = (uint64_t)kLsmWg * lsm_q(ntot);
   return (uint32_t)((ntot + per - 1) / per);
@@ -744,12 +764,9 @@ struct LsmPersistArgs {
   const double* disc_pow;
   double* counters;
   // all-gather state, zeroed by a memset node ahead of every launch
-  unsigned long long* rec;  // [kLsmRing][32 values][n_chunks] (fp64 bit patterns), write-through:
-                            // value-major, so that the 64 lanes of a gathering wave — one record
-                            // each — read 512 contiguous bytes per value
-  unsigned int* tags;       // [2 groups][kLsmRing][kLsmMaxResident] epoch of the record half in that
-                            // slot (0 = none yet): group A (moment sums, statistics) and group B (power
-                            // sums) of a record are published — and polled — separately
+  unsigned long long* rec;  // [kLsmRing][32 values][n_chunks] GRANULES of 16 bytes {bits, bits ^ epoch}
+                            // (fp64 bit patterns), write-through: value-major, so that the 64 lanes of a
+                            // gathering wave — one record each — read 1 KiB of contiguous bytes per value
   unsigned int* status;     // [0] != 0: a workgroup gave up waiting (the grid was not co-resident)
   unsigned long long spin_ticks;  // bound of every wait, in s_memrealtime ticks (100 MHz)
 };
@@ -762,28 +779,36 @@ struct LsmPersistArgs {
 constexpr int kRecP2 = 32, kGrp = 16, kOffStats = 12;
 constexpr int kDiscLds = 1024;
 
-// publish group g (0 = A, 1 = B) of this workgroup's record for epoch e: write-through (sc1) stores
-// of its 16 values by the first 16 lanes of ONE wave (wave 0 for A, wave 4 for B), drained, then the
-// group's tag by one lane (Guideline 16, recipe R1).  `val` is the lane's value (lanes >= 16: unused).
-__device__ __forceinline__ void publish_stores(const LsmPersistArgs& a, uint32_t e, int g, double val) {
-  const size_t ring = e % kLsmRing;
-  const uint32_t lane = threadIdx.x & 63u;
-  if (lane < (uint32_t)kGrp)
-    __hip_atomic_store((gu64*)(a.rec + (ring * kRecP2 + g * kGrp + lane) * a.n_chunks + blockIdx.x),
-                       (unsigned long long)__double_as_longlong(val), __ATOMIC_RELAXED,
-                       __HIP_MEMORY_SCOPE_AGENT);
+// Every value travels as a self-validating 16-byte granule {v, v ^ e} (v the fp64 bit pattern, e the
+// epoch, never 0): no tag word, hence no "drain the stores, then raise the tag" on the publisher's side
+// and no "poll the tag, then load" on the reader's — one store instruction to publish, one round trip to
+// gather.  A granule that reads back as anything but {v, v ^ e} (zeros from the per-launch memset, the
+// slot's previous epoch, two halves of different ages) is simply not there yet.  That also makes it
+// safe to read through the caches: the FIRST sweep of a gather uses plain loads, which the XCD's L2
+// serves to all but the first of its ~31 workgroups (every workgroup reads every record: through sc1
+// loads that was 245² x 19 x 8 B = 9 MB of fabric traffic per date, and two dependent round trips); a
+// stale or partly written line in L1 / L2 fails the validation and only then is re-read with sc1 loads,
+// which see the other XCDs' write-through stores.
+using u32x4 = unsigned __attribute__((ext_vector_type(4)));
+constexpr int kAuxSc1 = 16, kAuxVolatile = (int)0x80000000u;  // cache-policy bits of the raw buffer intrinsics (gfx94x/95x)
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t record_ring(const LsmPersistArgs& a) {
+  return __builtin_amdgcn_make_buffer_rsrc(a.rec, 0, (int)((size_t)kLsmRing * kRecP2 * a.n_chunks * 16), 0x00020000);
 }
-// the same wave, later: its stores drained, then the group's tag
-__device__ __forceinline__ void publish_tag(const LsmPersistArgs& a, uint32_t e, int g) {
-  const size_t ring = e % kLsmRing;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if ((threadIdx.x & 63u) == 0)
-    __hip_atomic_store((gu32*)(a.tags + ((size_t)g * kLsmRing + ring) * kLsmMaxResident + blockIdx.x), e,
-                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+__device__ __forceinline__ uint32_t granule_offset(const LsmPersistArgs& a, uint32_t e, int value, uint32_t r) {
+  return (((e % kLsmRing) * kRecP2 + (uint32_t)value) * a.n_chunks + r) * 16u;
 }
+
+// publish group g (0 = A, 1 = B) of this workgroup's record for epoch e: one write-through (sc1) store
+// of 16 granules by the first 16 lanes of a wave.  `val` is the lane's value (lanes >= 16: unused).
 __device__ __forceinline__ void publish_group(const LsmPersistArgs& a, uint32_t e, int g, double val) {
-  publish_stores(a, e, g, val);
-  publish_tag(a, e, g);
+  const uint32_t lane = threadIdx.x & 63u;
+  if (lane < (uint32_t)kGrp) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(val);
+    const u32x4 gr = {(unsigned)b, (unsigned)(b >> 32), (unsigned)b ^ e, (unsigned)(b >> 32)};
+    __builtin_amdgcn_raw_buffer_store_b128(gr, record_ring(a), granule_offset(a, e, g * kGrp + (int)lane, blockIdx.x),
+                                           0, kAuxSc1);
+  }
 }
 // both groups from the workgroup totals tot[32] (the two prologue epochs)
 __device__ __forceinline__ void publish_record(const LsmPersistArgs& a, uint32_t e, const double* tot) {
@@ -793,69 +818,69 @@ __device__ __forceinline__ void publish_record(const LsmPersistArgs& a, uint32_t
 }
 
 // gather the records of epoch e from every workgroup and reduce them in the canonical order: lane
-// r < 256 of waves 0-3 takes group A of record r, lane r of waves 4-7 group B; each polls the tag of
-// its record and then (and only then) loads its half with sc1 loads.  tot[32] on return.  Returns
-// false — for every thread of the workgroup — when a wait ran out or another workgroup gave up; the
-// caller leaves the kernel.
+// r < 256 of waves 0-3 takes group A of record r, lane r of waves 4-7 group B, and loads the granules of
+// the values a record of degree D carries (9 + 10 of the 32 for D = 5; the others are zero on both
+// sides) until all of them validate.  tot[32] on return.  Returns false — for every thread of the
+// workgroup — when a wait ran out or another workgroup gave up; the caller leaves the kernel.
 template <int D>
 __device__ __forceinline__ bool gather_records(const LsmPersistArgs& a, uint32_t e, double* scratch,
                                                double* tot, int* ok_flag) {
   // no barrier on entry (*ok_flag is set once, at the start of the kernel, and only ever cleared): the
-  // waves that poll start at once, whatever another wave of the workgroup is still draining; `scratch`
-  // is the gather's own (gscratch), nobody else writes it
+  // waves start loading at once, whatever another wave of the workgroup is still doing; `scratch` is
+  // the gather's own (gscratch), nobody else writes it
   double v[kGrp];
 #pragma unroll
   for (int i = 0; i < kGrp; ++i) v[i] = 0.0;
   const int wave = threadIdx.x >> 6;
   static_assert(kLsmWg >= 512, "the gather uses 8 waves");
   if (threadIdx.x < 512) {
-    const int g = threadIdx.x >> 8;           // group A or B
+    const int g = threadIdx.x >> 8;           // group A or B (wave-uniform)
     const uint32_t r = threadIdx.x & 255u;    // record
     const bool mine = r < a.n_chunks;
-    const size_t ring = e % kLsmRing;
-    const size_t slot = ((size_t)g * kLsmRing + ring) * kLsmMaxResident + r;  // this group's tag of record r
+    const __amdgpu_buffer_rsrc_t ring = record_ring(a);
     bool ok = a.spin_ticks != 0;  // 0 (HH_OPT_LSM_SPIN_TICKS, tests): give up at once
-    if (ok && __any(mine)) {
-      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-      unsigned spins = 0;
-      while (true) {
-        const unsigned tag = mine ? __hip_atomic_load((gu32*)(a.tags + slot), __ATOMIC_RELAXED,
-                                                      __HIP_MEMORY_SCOPE_AGENT)
-                                  : e;
-        if (__all(tag == e) || ((HH_LSM_DEBUG & 1) != 0)) break;
-        __builtin_amdgcn_s_sleep(1);
-        if ((++spins & 63u) == 0) {  // bounded: every wave reaches an exit
-          const unsigned gave_up = __hip_atomic_load((gu32*)a.status, __ATOMIC_RELAXED,
-                                                     __HIP_MEMORY_SCOPE_AGENT);
-          if (gave_up != 0 || __builtin_amdgcn_s_memrealtime() - t0 > a.spin_ticks) {
-            ok = false;
-            break;
+    // NV values of group G, value i of them at index IDX(i) of the group
+    auto take = [&](auto nv_c, auto idx) {
+      constexpr int NV = decltype(nv_c)::value;
+      u32x4 gr[NV];
+      auto sweep = [&](auto aux_c) {
+        constexpr int aux = decltype(aux_c)::value;
+        bool bad = false;
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+          gr[i] = __builtin_amdgcn_raw_buffer_load_b128(ring, granule_offset(a, e, g * kGrp + idx(i), mine ? r : 0u), 0, aux);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) bad |= ((gr[i].x ^ gr[i].z) != e) | (gr[i].y != gr[i].w);
+        return bad && mine;
+      };
+      if (ok) {
+        bool bad = sweep(std::integral_constant<int, 0>{});  // through the caches (a volatile access is made sc0 sc1)
+        if (__any(bad) && !(HH_LSM_DEBUG & 1)) {
+          const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+          unsigned spins = 0;
+          while (true) {
+            bad = sweep(std::integral_constant<int, kAuxVolatile | kAuxSc1>{});
+            if (!__any(bad)) break;
+            __builtin_amdgcn_s_sleep(1);
+            if ((++spins & 63u) == 0) {  // bounded: every wave reaches an exit
+              const unsigned gave_up = __hip_atomic_load((gu32*)a.status, __ATOMIC_RELAXED,
+                                                         __HIP_MEMORY_SCOPE_AGENT);
+              if (gave_up != 0 || __builtin_amdgcn_s_memrealtime() - t0 > a.spin_ticks) {
+                ok = false;
+                break;
+              }
+            }
           }
         }
       }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // no instruction: keeps the loads below the poll
-    if (ok && mine) {
-      // only the values a record of degree D carries (the others are zero on both sides): 9 + 10 of the
-      // 32 for D = 5 — every workgroup reads every record, so this is most of the induction's traffic
-      auto take = [&](int i) {
-        v[i] = __longlong_as_double((long long)__hip_atomic_load(
-            (gu64*)(a.rec + (ring * kRecP2 + g * kGrp + i) * a.n_chunks + r), __ATOMIC_RELAXED,
-            __HIP_MEMORY_SCOPE_AGENT));
-      };
-      if (!HH_LSM_GATHER_USED) {
+      if (ok && mine) {
 #pragma unroll
-        for (int i = 0; i < kGrp; ++i) take(i);
-      } else if (g == 0) {
-#pragma unroll
-        for (int i = 0; i <= D; ++i) take(i);
-#pragma unroll
-        for (int i = kOffStats; i < kOffStats + 3; ++i) take(i);
-      } else {
-#pragma unroll
-        for (int i = 0; i < (2 * D > 3 ? 2 * D : 3); ++i) take(i);  // epoch 1: three statistics
+        for (int i = 0; i < NV; ++i)
+          v[idx(i)] = __longlong_as_double((long long)(((unsigned long long)gr[i].y << 32) | gr[i].x));
       }
-    }
+    };
+    if (g == 0) take(std::integral_constant<int, D + 4>{}, [](int i) { return i <= D ? i : kOffStats + (i - D - 1); });
+    else take(std::integral_constant<int, (2 * D > 3 ? 2 * D : 3)>{}, [](int i) { return i; });  // epoch 1: three statistics
     if (!ok && (threadIdx.x & 63) == 0) {
       __hip_atomic_store((gu32*)a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       *ok_flag = 0;
@@ -976,7 +1001,7 @@ __global__ __launch_bounds__(kLsmWg, (Q * kLsmWg > 1024 ? 2 : 4)) void lsm_persi
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   // group g of the workgroup's sums out of the waves' partial sums (the waves in order, as
   // finish_block adds them), straight into the record, by one wave
-  auto total_and_publish = [&](uint32_t e, int g, int by_wave, bool tag_now = true) {
+  auto total_and_publish = [&](uint32_t e, int g, int by_wave) {
     if (wave == by_wave) {
       double t = 0.0;
       if (lane < kGrp) {
@@ -984,8 +1009,7 @@ __global__ __launch_bounds__(kLsmWg, (Q * kLsmWg > 1024 ? 2 : 4)) void lsm_persi
 #pragma unroll
         for (int w = 1; w < kLsmWaves; ++w) t += scratch[w * kRecP2 + g * kGrp + lane];
       }
-      publish_stores(a, e, g, t);
-      if (tag_now) publish_tag(a, e, g);
+      publish_group(a, e, g, t);
     }
   };
   bool alive = true;
@@ -1049,18 +1073,23 @@ __global__ __launch_bounds__(kLsmWg, (Q * kLsmWg > 1024 ? 2 : 4)) void lsm_persi
     }
     // for i = nsteps:-1:2, t = i-1 (:112-113).
     // All workgroups run the same schedule, so a record published while the publisher still has work
-    // of its own to do is not waited for by anybody: wave 0 issues the stores of group A, forms its
-    // power sums like every other wave, and only then drains the stores and raises the tag — by the
-    // time another workgroup polls (it has the same power sums to form first) the tag is there.  Group
-    // B is drained by wave 4 beside the next gather, which has no barrier on entry.
+    // of its own to do is not waited for by anybody: wave 0 stores group A, issues the next row and
+    // forms its power sums like every other wave — by the time anybody gathers (it has the same power
+    // sums to form first) the granules have long landed.  VMEM operations retire in order: a wave that
+    // waits for the granules it loads also waits for everything it issued before them, so nothing slow
+    // may be issued just ahead of a gather — the row prefetch goes out BEFORE the power sums, and the
+    // stores of group B (write-through, ~1.5 µs to retire) are issued by wave 4 in the NEXT date's solve
+    // window, a full date before anybody needs them.
     for (uint32_t t = M - 1; alive && t >= 1; --t) {
       const uint32_t e = M - t + 1;  // epoch whose records hold the sums of row t
       HH_STAMP(7)
       alive = gather_records<D>(a, e, gscratch, tot, &ok_flag);
-      HH_STAMP(1)  // all-gather: wait, loads, reduction
+      HH_STAMP(1)  // all-gather: loads, validation, reduction
       if (!alive) break;
       if (t >= 3) r_nn = rowstat_of(tot[kOffStats], tot[kOffStats + 1], tot[kOffStats + 2]);  // row t-2
       if (wave == 0) fit_row_wave0<D>(r_cur.n, tot, tot + kGrp, coef, &have_fit);  // Gram: P[0] = n, P[k] = group B
+      // the power sums date t+1 left in scratch (row t-1): group B of the epoch of date t-1
+      if (t + 2 <= M && t >= 2 && !(HH_LSM_DEBUG & 4)) total_and_publish(e + 1, 1, 4);
       lds_barrier();
       HH_STAMP(2)  // normal equations
       if (r_cur.n > 0.0) regressed += 1.0; else skipped += 1.0;
@@ -1112,27 +1141,21 @@ __global__ __launch_bounds__(kLsmWg, (Q * kLsmWg > 1024 ? 2 : 4)) void lsm_persi
 #if HH_LSM_STAMPS > 1
         HH_STAMP(7)  // (diagnostic: the barrier's wait goes to "loop overhead")
 #endif
-        total_and_publish(e + 1, 0, 0, /*tag_now=*/t < 3);  // wave 0: the stores of A are on their way
-        HH_STAMP(6)  // workgroup total of A, stores issued
-        if (t >= 3) {  // power sums of row t-2 (xl[cur ^ 1]): B of epoch e+2, needed by the fit of date t-2
+        total_and_publish(e + 1, 0, 0);  // wave 0: group A is on its way — the date's critical path ends here
+        HH_STAMP(6)  // workgroup total of A, store issued
+        }
+        if (t >= 5) issue_row(t - 4);  // row (t-1)-3: lands, is parked and leaves its statistics at date t-1
+        HH_STAMP(0)  // next row issued
+        if (t >= 3 && !(HH_LSM_DEBUG & 4)) {  // power sums of row t-2 (xl[cur ^ 1]): published from the next window
           double w[kGrp];
 #pragma unroll
           for (int i = 0; i < kGrp; ++i) w[i] = 0.0;
 #pragma unroll
           for (int j = 0; j < Q; ++j)
             add_powers_from1<D>(xl[cur ^ 1][j * kLsmWg + threadIdx.x], a.cp, a.strike, live(j), r_nn, w);
-          __builtin_amdgcn_sched_barrier(0);  // the tag goes out BEHIND the power sums, not before them
-          if (wave == 0) publish_tag(a, e + 1, 0);  // drained long ago: the date's critical path ends here
           wave_part<kGrp, kRecP2>(w, scratch, kGrp);
         }
-        HH_STAMP(5)  // power sums + their wave butterfly, tag of A
-        }
-        if (t >= 5) issue_row(t - 4);  // row (t-1)-3: lands, is parked and leaves its statistics at date t-1
-        if (t >= 3 && !(HH_LSM_DEBUG & 4)) {
-          lds_barrier();
-          total_and_publish(e + 2, 1, 4);  // wave 4; its drain runs beside the next gather
-        }
-        HH_STAMP(0)  // next row issued, group B total + publish
+        HH_STAMP(5)  // power sums + their wave butterfly
         cur ^= 1;
         r_cur = r_next;
         r_next = r_nn;
@@ -1175,9 +1198,8 @@ struct LsmLayout {
   int q;
 };
 
-constexpr size_t kSyncWords = (size_t)2 * kLsmRing * kLsmMaxResident + 4;   // uint32: tags of both groups, status
-constexpr size_t kSyncDoubles = (kSyncWords * 4 + 15) / 16 * 2;             // padded to 16 bytes
-constexpr size_t kRingDoubles = (size_t)kLsmRing * kLsmMaxResident * 32;    // records of 32 doubles
+constexpr size_t kSyncDoubles = 2;                                           // uint32 status word, padded to 16 bytes
+constexpr size_t kRingDoubles = (size_t)kLsmRing * kLsmMaxResident * 32 * 2; // records of 32 granules of 16 bytes
 
 LsmLayout lsm_layout(double* scratch, uint64_t ntot, uint32_t n_steps, int degree) {
   const size_t rows = (size_t)n_steps + 1, ch = lsm_nch(ntot), nv = 2 * (size_t)degree + 1;
@@ -1208,31 +1230,31 @@ LsmStepArgs lsm_step_args(const LsmLayout& L, const double* grid, uint64_t ntot,
 
 void launch_stats(const LsmLayout& L, const LsmStepArgs& a, hipStream_t s) {
   const dim3 g(L.nch, L.rows), b(kLsmWg);
-  if (L.q == kLsmQSmall)
-    hipLaunchKernelGGL(lsm_stats_kernel<kLsmQSmall>, g, b, 0, s, a.grid, a.ntot, a.strike, a.cp, L.nch, L.rec_stats);
-  else
-    hipLaunchKernelGGL(lsm_stats_kernel<kLsmQLarge>, g, b, 0, s, a.grid, a.ntot, a.strike, a.cp, L.nch, L.rec_stats);
+  with_q(L.q, [&](auto qc) {
+    hipLaunchKernelGGL(lsm_stats_kernel<decltype(qc)::value>, g, b, 0, s, a.grid, a.ntot, a.strike, a.cp, L.nch, L.rec_stats);
+  });
 }
 
 template <int D>
 void launch_pow(const LsmLayout& L, const LsmStepArgs& a, hipStream_t s) {
   const dim3 g(L.nch, L.rows), b(kLsmWg);
-  if (L.q == kLsmQSmall)
-    hipLaunchKernelGGL((lsm_pow_kernel<D, kLsmQSmall>), g, b, 0, s, a.grid, a.ntot, a.strike, a.cp, L.nch, a.rs, L.rec_pow);
-  else
-    hipLaunchKernelGGL((lsm_pow_kernel<D, kLsmQLarge>), g, b, 0, s, a.grid, a.ntot, a.strike, a.cp, L.nch, a.rs, L.rec_pow);
+  with_q(L.q, [&](auto qc) {
+    hipLaunchKernelGGL((lsm_pow_kernel<D, decltype(qc)::value>), g, b, 0, s, a.grid, a.ntot, a.strike, a.cp, L.nch, a.rs, L.rec_pow);
+  });
 }
 
 template <int D>
 void launch_init(const LsmLayout& L, const LsmStepArgs& a, hipStream_t s) {
-  if (L.q == kLsmQSmall) hipLaunchKernelGGL((lsm_init_kernel<D, kLsmQSmall>), dim3(a.n_chunks), dim3(kLsmWg), 0, s, a);
-  else hipLaunchKernelGGL((lsm_init_kernel<D, kLsmQLarge>), dim3(a.n_chunks), dim3(kLsmWg), 0, s, a);
+  with_q(L.q, [&](auto qc) {
+    hipLaunchKernelGGL((lsm_init_kernel<D, decltype(qc)::value>), dim3(a.n_chunks), dim3(kLsmWg), 0, s, a);
+  });
 }
 
 template <int D>
 void launch_step(const LsmLayout& L, const LsmStepArgs& a, uint32_t t, hipStream_t s) {
-  if (L.q == kLsmQSmall) hipLaunchKernelGGL((lsm_step_kernel<D, kLsmQSmall>), dim3(a.n_chunks), dim3(kLsmWg), 0, s, a, t);
-  else hipLaunchKernelGGL((lsm_step_kernel<D, kLsmQLarge>), dim3(a.n_chunks), dim3(kLsmWg), 0, s, a, t);
+  with_q(L.q, [&](auto qc) {
+    hipLaunchKernelGGL((lsm_step_kernel<D, decltype(qc)::value>), dim3(a.n_chunks), dim3(kLsmWg), 0, s, a, t);
+  });
 }
 
 // the whole induction on one device, one launch per date
@@ -1290,17 +1312,15 @@ int run_lsm_persistent(const LsmLayout& L, const LsmStepArgs& s_args, hipStream_
   a.grid = s_args.grid; a.ntot = s_args.ntot; a.strike = s_args.strike; a.cp = s_args.cp;
   a.n_steps = s_args.n_steps; a.n_chunks = L.nch; a.tau = s_args.tau; a.val = s_args.val;
   a.disc_pow = L.disc_pow; a.counters = L.counters;
-  a.tags = reinterpret_cast<unsigned int*>(L.sync);
-  a.status = a.tags + (size_t)2 * kLsmRing * kLsmMaxResident;
+  a.status = reinterpret_cast<unsigned int*>(L.sync);
   a.rec = reinterpret_cast<unsigned long long*>(L.sync + kSyncDoubles);
   a.spin_ticks = spin_ticks;  // default 1 s of the 100 MHz constant clock
-  const bool fits = L.q == kLsmQSmall ? grid_fits(lsm_persistent_kernel<D, kLsmQSmall>, L.nch)
-                             : grid_fits(lsm_persistent_kernel<D, kLsmQLarge>, L.nch);
+  const bool fits = with_q(L.q, [&](auto qc) { return grid_fits(lsm_persistent_kernel<D, decltype(qc)::value>, L.nch); });
   if (!fits) return 1;
-  hipError_t e = hipMemsetAsync(L.sync, 0, kSyncDoubles * sizeof(double), s);
+  // status word and the whole record ring (2 MiB): a granule of an earlier launch must not validate
+  hipError_t e = hipMemsetAsync(L.sync, 0, (kSyncDoubles + kRingDoubles) * sizeof(double), s);
   if (e != hipSuccess) return (int)e;
-  if (L.q == kLsmQSmall) return launch_cooperative(lsm_persistent_kernel<D, kLsmQSmall>, L.nch, a, s);
-  return launch_cooperative(lsm_persistent_kernel<D, kLsmQLarge>, L.nch, a, s);
+  return with_q(L.q, [&](auto qc) { return launch_cooperative(lsm_persistent_kernel<D, decltype(qc)::value>, L.nch, a, s); });
 }
 
 // one phase of the sharded induction (see hh_kernels.h); vec_in / vec_out are device vectors
@@ -1395,7 +1415,7 @@ int launch_lsm(const double* grid, uint64_t ntot, uint32_t n_steps, double strik
   hipLaunchKernelGGL(lsm_disc_kernel, dim3((L.rows + 255) / 256), b, 0, s, a.ln_disc, n_steps,
                      L.disc_pow);
   int rc = 1;
-  if (form == kLsmFormPersistent || (form == kLsmFormAuto && L.q == kLsmQLarge)) {
+  if (form == kLsmFormPersistent || form == kLsmFormAuto) {  // one launch whenever the chip can hold the grid
 #define HH_CALL(D) run_lsm_persistent<D>(L, a, s, spin_ticks)
     HH_LSM_DISPATCH(degree, HH_CALL)
 #undef HH_CALL
@@ -1415,7 +1435,7 @@ int launch_lsm(const double* grid, uint64_t ntot, uint32_t n_steps, double strik
 
 // device address of the word the persistent form sets when a workgroup gave up waiting
 const unsigned int* lsm_persistent_status(const double* scratch) {
-  return reinterpret_cast<const unsigned int*>(scratch) + (size_t)2 * kLsmRing * kLsmMaxResident;
+  return reinterpret_cast<const unsigned int*>(scratch);
 }
 
 // Sharded induction, one phase per call (hh_kernels.h).  kLsmPhaseStats: local row sums

@@ -162,10 +162,10 @@ const char* hh_last_error(const hh_ctx* ctx); /* NUL-terminated, owned by ctx (o
  *                           trajectories (256 chunks); a COOPERATIVE launch — refused by the runtime, and
  *                           replaced by the other form, when its workgroups cannot all be resident;
  *   HH_LSM_FORM_PER_DATE    one launch per exercise date;
- *   HH_LSM_FORM_AUTO        (default) the persistent form above 2^18 trajectories — where not
- *                           re-loading the state pays (2·10^6 x 100 dates: 2.0 vs 3.1 ms) — and a
- *                           launch per date below, where a kernel boundary is the cheaper
- *                           synchronisation (10^5 x 100: 0.66 vs 0.79 ms).
+ *   HH_LSM_FORM_AUTO        (default) the persistent form whenever it applies (since round 3 it is the
+ *                           faster one at every size: 2·10^6 x 100 dates 1.6 vs 2.9 ms, 2.6·10^5 x 100
+ *                           0.59 vs 0.71 ms, 4·10^3 x 100 0.45 vs 0.50 ms), a launch per date beyond
+ *                           2^21 trajectories.
  * All forms give bit-identical prices and stopping decisions.
  *
  * HH_OPT_BK_TERM_CACHE: how many CDF-series terms Re ϕ(h·j) the Broadie–Kaya kernels keep per column

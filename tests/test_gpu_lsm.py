@@ -53,13 +53,14 @@ def test_lsm_matches_oracle(hhlib, anti, cp, K, degree, n, steps):
 
 
 @pytest.mark.parametrize("n,steps,anti,degree,cp", [
-    (3000, 30, 1, 5, -1.0),        # 6 chunks of one trajectory per lane
+    (3000, 30, 1, 5, -1.0),        # 6 chunks of two trajectories per lane
     (1025, 7, 0, 3, -1.0),
     (700, 2, 0, 2, 1.0), (700, 3, 1, 8, -1.0),   # the shortest inductions: 1 and 2 regression rows
-    (140_000, 12, 1, 4, -1.0),     # 280 000 trajectories: 35 chunks of eight per lane
-    (262_144, 5, 0, 1, 1.0),       # exactly the last size with one trajectory per lane (256 chunks)
-    (300_000, 25, 0, 5, -1.0),     # 37 chunks, the last one ragged
-    (1_048_576, 4, 1, 2, -1.0),    # 2^21 trajectories: 256 chunks, one workgroup on EVERY CU of the chip
+    (262_144, 5, 0, 1, 1.0),       # 2^18: the last size with two trajectories per lane (256 chunks of 1024)
+    (140_000, 12, 1, 4, -1.0),     # 280 000 trajectories: four per lane, 137 chunks of 2048, the last one ragged
+    (300_000, 25, 0, 5, -1.0),     # four per lane, 147 chunks
+    (700_000, 6, 0, 3, -1.0),      # eight per lane, 171 chunks of 4096
+    (1_048_576, 4, 1, 2, -1.0),    # 2^21 trajectories, sixteen per lane: 256 chunks, one workgroup on EVERY CU
 ])
 def test_one_launch_and_launch_per_date_agree_bit_for_bit(hhlib, n, steps, anti, degree, cp):
     """The persistent form (one launch, stopping state in registers, an in-kernel all-gather per
