@@ -149,6 +149,9 @@ constexpr int log2_of(int p) { return p <= 1 ? 0 : 1 + log2_of(p / 2); }
 #ifndef HH_LSM_SWAP_PAIRS  // A/B switches of round 3's later cuts (tools/lsm_breakdown.py; both bit-identical)
 #define HH_LSM_SWAP_PAIRS 1
 #endif
+#ifndef HH_LSM_EARLY_STATS
+#define HH_LSM_EARLY_STATS 1
+#endif
 #ifndef HH_LSM_GATHER_USED
 #define HH_LSM_GATHER_USED 1
 #endif
@@ -1087,7 +1090,16 @@ __global__ __launch_bounds__(kLsmWg, (Q * kLsmWg > 1024 ? 2 : 4)) void lsm_persi
       HH_STAMP(1)  // all-gather: loads, validation, reduction
       if (!alive) break;
       if (t >= 3) r_nn = rowstat_of(tot[kOffStats], tot[kOffStats + 1], tot[kOffStats + 2]);  // row t-2
-      if (wave == 0) fit_row_wave0<D>(r_cur.n, tot, tot + kGrp, coef, &have_fit);  // Gram: P[0] = n, P[k] = group B
+      // The solve is one wave's; the other seven use the window for the one piece of the date's arithmetic
+      // that needs neither the coefficients nor the stopping state: the statistics of the row that has
+      // just landed (xin = row t-3; wave 0 forms its own beside the moment sums, as before).
+      double st[3] = {0.0, 0.0, 0.0};
+      if (wave == 0) {
+        fit_row_wave0<D>(r_cur.n, tot, tot + kGrp, coef, &have_fit);  // Gram: P[0] = n, P[k] = group B
+      } else if (HH_LSM_EARLY_STATS && t >= 4) {
+#pragma unroll
+        for (int j = 0; j < Q; ++j) add_stats(xin[j], a.cp, a.strike, live(j), st);
+      }
       // the power sums date t+1 left in scratch (row t-1): group B of the epoch of date t-1
       if (t + 2 <= M && t >= 2 && !(HH_LSM_DEBUG & 4)) total_and_publish(e + 1, 1, 4);
       lds_barrier();
@@ -1115,10 +1127,17 @@ __global__ __launch_bounds__(kLsmWg, (Q * kLsmWg > 1024 ? 2 : 4)) void lsm_persi
 #pragma unroll
           for (int i = 0; i < kGrp; ++i) v[i] = 0.0;
           if (t >= 4) {
+            if (HH_LSM_EARLY_STATS && wave != 0) {
 #pragma unroll
-            for (int j = 0; j < Q; ++j) {
-              xl[cur][j * kLsmWg + threadIdx.x] = xin[j];
-              add_stats(xin[j], a.cp, a.strike, live(j), v + kOffStats);
+              for (int j = 0; j < Q; ++j) xl[cur][j * kLsmWg + threadIdx.x] = xin[j];
+#pragma unroll
+              for (int i = 0; i < 3; ++i) v[kOffStats + i] = st[i];
+            } else {
+#pragma unroll
+              for (int j = 0; j < Q; ++j) {
+                xl[cur][j * kLsmWg + threadIdx.x] = xin[j];
+                add_stats(xin[j], a.cp, a.strike, live(j), v + kOffStats);
+              }
             }
           }
           // discount^(tau - (t-1)): from the LDS table or from memory — two copies of the loop, not a
