@@ -522,6 +522,10 @@ int hh_mgpu_lsm_solve(hh_mgpu* mg, const hh_model* m, const hh_config* cfg, int3
     return mfail(mg, HH_ERR_INVALID, "Number of seeds (%llu) must be >= number of trajectories (%llu)",
                  (unsigned long long)cfg->seeds_len, (unsigned long long)cfg->n_paths);
   if (degree < 1 || degree > 8 || cfg->n_steps == 0) return mfail(mg, HH_ERR_INVALID, "LSM: 1 <= degree <= 8, n_steps >= 1");
+  if (mg->n == 1) {  // nothing to exchange: the fused induction (one persistent launch where it fits); same bits
+    const int rc1 = hh_lsm_solve(mg->ctx[0], m, cfg, degree, step_discount, out, stop_time, stop_value, nullptr);
+    return rc1 ? mfail(mg, rc1, "device %d: %s", mg->devices[0], hh_last_error(mg->ctx[0])) : HH_OK;
+  }
   const auto t0 = std::chrono::steady_clock::now();
   const uint64_t N = cfg->n_paths;
   const uint32_t steps = cfg->n_steps;
