@@ -1089,7 +1089,6 @@ __global__ __launch_bounds__(kLsmWg, (Q * kLsmWg > 1024 ? 2 : 4)) void lsm_persi
       alive = gather_records<D>(a, e, gscratch, tot, &ok_flag);
       HH_STAMP(1)  // all-gather: loads, validation, reduction
       if (!alive) break;
-      if (t >= 3) r_nn = rowstat_of(tot[kOffStats], tot[kOffStats + 1], tot[kOffStats + 2]);  // row t-2
       // The solve is one wave's; the other seven use the window for the one piece of the date's arithmetic
       // that needs neither the coefficients nor the stopping state: the statistics of the row that has
       // just landed (xin = row t-3; wave 0 forms its own beside the moment sums, as before).
@@ -1104,6 +1103,10 @@ __global__ __launch_bounds__(kLsmWg, (Q * kLsmWg > 1024 ? 2 : 4)) void lsm_persi
       if (t + 2 <= M && t >= 2 && !(HH_LSM_DEBUG & 4)) total_and_publish(e + 1, 1, 4);
       lds_barrier();
       HH_STAMP(2)  // normal equations
+      // statistics of row t-2 (two divisions and a square root: a 0.3 µs chain for a wave with nothing
+      // else to issue): needed by the power sums at the end of the date, so formed beside the decisions,
+      // not in front of the solve
+      if (t >= 3) r_nn = rowstat_of(tot[kOffStats], tot[kOffStats + 1], tot[kOffStats + 2]);
       if (r_cur.n > 0.0) regressed += 1.0; else skipped += 1.0;
       if (have_fit) {
 #pragma unroll
