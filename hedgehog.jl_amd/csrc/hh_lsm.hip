@@ -50,6 +50,7 @@
 #include "hh_kernels.h"
 #include "hh_math.h"
 #include "hh_rng.h"
+#include <atomic>
 
 namespace hh {
 
@@ -772,6 +773,7 @@ struct LsmPersistArgs {
                             // gathering wave — one record each — read 1 KiB of contiguous bytes per value
   unsigned int* status;     // [0] != 0: a workgroup gave up waiting (the grid was not co-resident)
   unsigned long long spin_ticks;  // bound of every wait, in s_memrealtime ticks (100 MHz)
+  unsigned int nonce;       // of this launch (never 0, process-wide counter): part of every granule's check
 };
 
 // Record of an epoch e (row t = M - e + 1), 32 doubles in two groups of 16 — the groups are formed,
@@ -782,8 +784,9 @@ struct LsmPersistArgs {
 constexpr int kRecP2 = 32, kGrp = 16, kOffStats = 12;
 constexpr int kDiscLds = 1024;
 
-// Every value travels as a self-validating 16-byte granule {v, v ^ e} (v the fp64 bit pattern, e the
-// epoch, never 0): no tag word, hence no "drain the stores, then raise the tag" on the publisher's side
+// Every value travels as a self-validating 16-byte granule {v, v ^ (nonce:e)} (v the fp64 bit pattern,
+// e the epoch, never 0, nonce the launch's number: a granule of an earlier launch — same epochs, same
+// addresses — cannot validate even if some cache still held it): no tag word, hence no "drain the stores, then raise the tag" on the publisher's side
 // and no "poll the tag, then load" on the reader's — one store instruction to publish, one round trip to
 // gather.  A granule that reads back as anything but {v, v ^ e} (zeros from the per-launch memset, the
 // slot's previous epoch, two halves of different ages) is simply not there yet.  That also makes it
@@ -808,7 +811,7 @@ __device__ __forceinline__ void publish_group(const LsmPersistArgs& a, uint32_t 
   const uint32_t lane = threadIdx.x & 63u;
   if (lane < (uint32_t)kGrp) {
     const unsigned long long b = (unsigned long long)__double_as_longlong(val);
-    const u32x4 gr = {(unsigned)b, (unsigned)(b >> 32), (unsigned)b ^ e, (unsigned)(b >> 32)};
+    const u32x4 gr = {(unsigned)b, (unsigned)(b >> 32), (unsigned)b ^ e, (unsigned)(b >> 32) ^ a.nonce};
     __builtin_amdgcn_raw_buffer_store_b128(gr, record_ring(a), granule_offset(a, e, g * kGrp + (int)lane, blockIdx.x),
                                            0, kAuxSc1);
   }
@@ -853,7 +856,7 @@ __device__ __forceinline__ bool gather_records(const LsmPersistArgs& a, uint32_t
         for (int i = 0; i < NV; ++i)
           gr[i] = __builtin_amdgcn_raw_buffer_load_b128(ring, granule_offset(a, e, g * kGrp + idx(i), mine ? r : 0u), 0, aux);
 #pragma unroll
-        for (int i = 0; i < NV; ++i) bad |= ((gr[i].x ^ gr[i].z) != e) | (gr[i].y != gr[i].w);
+        for (int i = 0; i < NV; ++i) bad |= ((gr[i].x ^ gr[i].z) != e) | ((gr[i].y ^ gr[i].w) != a.nonce);
         return bad && mine;
       };
       if (ok) {
@@ -1325,6 +1328,8 @@ int launch_cooperative(K kernel, uint32_t blocks, const LsmPersistArgs& a, hipSt
   return (int)e;
 }
 
+std::atomic<unsigned int> g_lsm_launches{0};  // numbers the persistent launches of the process (granule nonce)
+
 // the whole induction in one launch; 1 = not applicable here (too many chunks for the chip, or the
 // runtime cannot guarantee that the grid is resident)
 template <int D>
@@ -1337,6 +1342,7 @@ int run_lsm_persistent(const LsmLayout& L, const LsmStepArgs& s_args, hipStream_
   a.status = reinterpret_cast<unsigned int*>(L.sync);
   a.rec = reinterpret_cast<unsigned long long*>(L.sync + kSyncDoubles);
   a.spin_ticks = spin_ticks;  // default 1 s of the 100 MHz constant clock
+  do a.nonce = ++g_lsm_launches; while (a.nonce == 0);
   const bool fits = with_q(L.q, [&](auto qc) { return grid_fits(lsm_persistent_kernel<D, decltype(qc)::value>, L.nch); });
   if (!fits) return 1;
   // status word and the whole record ring (2 MiB): a granule of an earlier launch must not validate
