@@ -60,6 +60,9 @@ def test_lsm_matches_oracle(hhlib, anti, cp, K, degree, n, steps):
     (140_000, 12, 1, 4, -1.0),     # 280 000 trajectories: four per lane, 137 chunks of 2048, the last one ragged
     (300_000, 25, 0, 5, -1.0),     # four per lane, 147 chunks
     (700_000, 6, 0, 3, -1.0),      # eight per lane, 171 chunks of 4096
+    (262_145, 3, 0, 2, -1.0),      # one past 2^18: 129 chunks of 2048, the last one holds ONE trajectory
+    (524_289, 3, 0, 2, 1.0),       # one past 2^19: 129 chunks of 4096
+    (1_048_577, 3, 0, 2, -1.0),    # one past 2^20: 129 chunks of 8192
     (1_048_576, 4, 1, 2, -1.0),    # 2^21 trajectories, sixteen per lane: 256 chunks, one workgroup on EVERY CU
 ])
 def test_one_launch_and_launch_per_date_agree_bit_for_bit(hhlib, n, steps, anti, degree, cp):
