@@ -885,8 +885,24 @@ __device__ __forceinline__ bool gather_records(const LsmPersistArgs& a, uint32_t
           v[idx(i)] = __longlong_as_double((long long)(((unsigned long long)gr[i].y << 32) | gr[i].x));
       }
     };
-    if (g == 0) take(std::integral_constant<int, D + 4>{}, [](int i) { return i <= D ? i : kOffStats + (i - D - 1); });
-    else take(std::integral_constant<int, (2 * D > 3 ? 2 * D : 3)>{}, [](int i) { return i; });  // epoch 1: three statistics
+    // (degrees 7 and 8 in two batches of at most 8 granules — 4 registers each — or they spill)
+    constexpr int NA = D + 4, NB = 2 * D > 3 ? 2 * D : 3;  // epoch 1: three statistics in group B
+    auto idx_a = [](int i) { return i <= D ? i : kOffStats + (i - D - 1); };
+    if (g == 0) {
+      if constexpr (NA > 10) {
+        take(std::integral_constant<int, 8>{}, idx_a);
+        take(std::integral_constant<int, NA - 8>{}, [idx_a](int i) { return idx_a(i + 8); });
+      } else {
+        take(std::integral_constant<int, NA>{}, idx_a);
+      }
+    } else {
+      if constexpr (NB > 12) {
+        take(std::integral_constant<int, 8>{}, [](int i) { return i; });
+        take(std::integral_constant<int, NB - 8>{}, [](int i) { return i + 8; });
+      } else {
+        take(std::integral_constant<int, NB>{}, [](int i) { return i; });
+      }
+    }
     if (!ok && (threadIdx.x & 63) == 0) {
       __hip_atomic_store((gu32*)a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       *ok_flag = 0;
