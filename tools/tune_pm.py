@@ -4,7 +4,8 @@ process, against the tile-major kernel and the repack route, on H252 10^6 x 252.
 
     python tools/tune_pm.py build            # here (cross-compile the variants)
     python tools/tune_pm.py run [rounds]     # on the GPU box
-    HH_TUNE_MODE = price | anti | greeks1 | greeks3 ;  HH_VARIANTS = json {tag: [flags]}
+    HH_TUNE_MODE = price | anti | greeks1 | greeks3 ;  HH_VARIANTS = json {tag: [flags]} ;
+    HH_TUNE_LAYOUT = tile: the variants run the tile-major kernel (A/B of euler_kernel builds)
 """
 import ctypes as C
 import importlib.util
@@ -81,7 +82,8 @@ def run(rounds=5):
         return c
 
     c_pm, c_tile = cfg(1, pm), cfg(0, dW)
-    cases = [(tag, lib, h, c_pm) for tag, (lib, h) in libs.items()] + [("tile-major", lib0, h0, c_tile)]
+    c_var = c_tile if os.environ.get("HH_TUNE_LAYOUT") == "tile" else c_pm  # which kernel the variants differ in
+    cases = [(tag, lib, h, c_var) for tag, (lib, h) in libs.items()] + [("tile-major", lib0, h0, c_tile)]
     times = {t: [] for t, *_ in cases}
     sums = {}
     for r in range(rounds + 1):
