@@ -96,6 +96,15 @@ inline uint32_t lsm_nch(uint64_t ntot) {
 
 // ---- full path grid -----------------------------------------------------------------------
 
+#ifndef HH_LSM_GRID_NT
+#define HH_LSM_GRID_NT 1  // the grid is written once and read once, 1.6 GB: nontemporal stores (-2 % of the LSM chain)
+#endif
+
+#if HH_LSM_GRID_NT
+#define HH_GRID_STORE(p, v) __builtin_nontemporal_store((v), (p))
+#else
+#define HH_GRID_STORE(p, v) (*(p) = (v))
+#endif
 template <bool ANTI>
 __global__ __launch_bounds__(256) void gbm_grid_kernel(const uint64_t* __restrict__ seeds,
                                                        uint64_t n_paths, uint32_t n_steps,
@@ -117,11 +126,11 @@ __global__ __launch_bounds__(256) void gbm_grid_kernel(const uint64_t* __restric
         // GBM process increment dW = W (exp((μ-σ²/2) dt + σ √dt z) - 1)
         const double e = fm::exp(fma(b, z[h], a));  // hh_math.h: <= 1.5 ulp, a third of the library's instructions
         S = S + S * (e - 1.0);
-        grid[(size_t)(s + h + 1) * ntot + i] = S;
+        HH_GRID_STORE(&grid[(size_t)(s + h + 1) * ntot + i], S);
         if (ANTI) {  // flipped σ, same draws (montecarlo.jl:276): exp(a - b z) = exp(2a) / exp(a + b z),
                      // a reciprocal (6 instructions, <= 3.5 ulp) instead of a second exponential (25)
           Sa = Sa + Sa * (e2a * fm::rcp(e) - 1.0);
-          grid[(size_t)(s + h + 1) * ntot + n_paths + i] = Sa;
+          HH_GRID_STORE(&grid[(size_t)(s + h + 1) * ntot + n_paths + i], Sa);
         }
       }
     }
