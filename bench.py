@@ -270,6 +270,18 @@ def rehearse(args, d):
                           "shard_rank0": [a, b], "value": None}), flush=True)
 
 
+def lsm_traffic(n_traj, n_dates):
+    """HBM bytes of the LSM chain from the PMC passes on file (same workload only), like the headline's."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        if abs(t["lsm_chain_algorithmic_bytes"] - 16.0 * n_traj * (n_dates + 1)) > 1.0:
+            return {"traffic": None}
+        return {"traffic": t["lsm_chain_hbm_bytes_per_solve"],
+                "traffic_source": "profiles/pmc_traffic.json (" + t["lsm_source"] + "; not collected in this run)"}
+    except Exception:
+        return {"traffic": None}
+
+
 def valu_insts():
     """VALU wave-instructions per launch of the VALU-bound kernels (rocprofv3 --pmc SQ_INSTS_VALU,
     tools/valu_insts.py) — file-sourced, the time beside it is measured live."""
@@ -780,7 +792,7 @@ def main():
                 # the spot grid written once by the path kernel and read once by the backward
                 # induction: 2 x 8 B per (trajectory, date)
                 "roofline": hbm_roofline("gbm_grid_kernel + LSM backward induction (whole chain)",
-                                         16.0 * 2 * n_l * (st_l + 1), t_lsm)},
+                                         16.0 * 2 * n_l * (st_l + 1), t_lsm, **lsm_traffic(2 * n_l, st_l))},
             "heston_exact_grid_2e5_paths_x_12_dates": {
                 "kernel_ms": r_g.kernel_ms, "transitions_per_s": n_g * st_g / (r_g.kernel_ms * 1e-3),
                 "cf_terms_per_transition": r_g.bk_cf_terms / (n_g * st_g),
