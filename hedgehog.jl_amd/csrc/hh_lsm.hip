@@ -782,6 +782,7 @@ struct LsmPersistArgs {
                             // gathering wave — one record each — read 1 KiB of contiguous bytes per value
   unsigned int* status;     // [0] != 0: a workgroup gave up waiting (the grid was not co-resident)
   unsigned long long spin_ticks;  // bound of every wait, in s_memrealtime ticks (100 MHz)
+  double ln_disc;           // log of the per-step discount: the table discount^k is formed in the kernel
   unsigned int nonce;       // of this launch (never 0, process-wide counter): part of every granule's check
 };
 
@@ -952,8 +953,8 @@ __global__ __launch_bounds__(kLsmWg, (Q * kLsmWg > 1024 ? 2 : 4)) void lsm_persi
   auto row_ptr = [&](uint32_t row) { return a.grid + (size_t)row * a.ntot; };
   auto live = [&](int j) { return p0 + (uint64_t)j * kLsmWg < a.ntot; };
   const bool disc_lds = M < (uint32_t)kDiscLds;
-  if (disc_lds)
-    for (uint32_t k = threadIdx.x; k <= M; k += kLsmWg) dtab[k] = a.disc_pow[k];
+  if (disc_lds)  // lsm_disc_kernel's expression: the same table, without its launch
+    for (uint32_t k = threadIdx.x; k <= M; k += kLsmWg) dtab[k] = exp(a.ln_disc * (double)k);
   auto disc = [&](int k) { return disc_lds ? dtab[k] : a.disc_pow[k]; };
   if (threadIdx.x == 0) ok_flag = 1;
   __syncthreads();
@@ -1363,7 +1364,7 @@ int run_lsm_persistent(const LsmLayout& L, const LsmStepArgs& s_args, hipStream_
   LsmPersistArgs a{};
   a.grid = s_args.grid; a.ntot = s_args.ntot; a.strike = s_args.strike; a.cp = s_args.cp;
   a.n_steps = s_args.n_steps; a.n_chunks = L.nch; a.tau = s_args.tau; a.val = s_args.val;
-  a.disc_pow = L.disc_pow; a.counters = L.counters;
+  a.disc_pow = L.disc_pow; a.counters = L.counters; a.ln_disc = s_args.ln_disc;
   a.status = reinterpret_cast<unsigned int*>(L.sync);
   a.rec = reinterpret_cast<unsigned long long*>(L.sync + kSyncDoubles);
   a.spin_ticks = spin_ticks;  // default 1 s of the 100 MHz constant clock
@@ -1461,14 +1462,23 @@ int launch_lsm(const double* grid, uint64_t ntot, uint32_t n_steps, double strik
                double* records, hipStream_t s, int form, int* form_used, unsigned long long spin_ticks) {
   if (degree < 1 || degree > kLsmMaxDeg) return (int)hipErrorInvalidValue;
   const LsmLayout L = lsm_layout(scratch, ntot, n_steps, degree);
-  hipError_t e = hipMemsetAsync(L.counters, 0, (2 + kLsmStampSlots) * sizeof(double), s);
-  if (e != hipSuccess) return (int)e;
   const dim3 b(256);
   const LsmStepArgs a = lsm_step_args(L, grid, ntot, n_steps, strike, cp, step_discount, tau, val);
-  hipLaunchKernelGGL(lsm_disc_kernel, dim3((L.rows + 255) / 256), b, 0, s, a.ln_disc, n_steps,
-                     L.disc_pow);
+  // the discount table in memory: the launch-per-date form reads it, the one-launch form only when it
+  // does not fit its LDS copy (which it forms itself)
+  bool table_out = false;
+  auto table = [&]() {
+    if (!table_out)
+      hipLaunchKernelGGL(lsm_disc_kernel, dim3((L.rows + 255) / 256), b, 0, s, a.ln_disc, n_steps, L.disc_pow);
+    table_out = true;
+  };
   int rc = 1;
   if (form == kLsmFormPersistent || form == kLsmFormAuto) {  // one launch whenever the chip can hold the grid
+    if (n_steps >= (uint32_t)kDiscLds) table();
+    if (HH_LSM_STAMPS) {  // (the shipped kernel writes both counters itself; the stamps accumulate)
+      const hipError_t e = hipMemsetAsync(L.counters, 0, (2 + kLsmStampSlots) * sizeof(double), s);
+      if (e != hipSuccess) return (int)e;
+    }
 #define HH_CALL(D) run_lsm_persistent<D>(L, a, s, spin_ticks)
     HH_LSM_DISPATCH(degree, HH_CALL)
 #undef HH_CALL
@@ -1476,6 +1486,9 @@ int launch_lsm(const double* grid, uint64_t ntot, uint32_t n_steps, double strik
   }
   if (form_used) *form_used = rc == 0 ? kLsmFormPersistent : kLsmFormPerDate;
   if (rc == 1) {
+    const hipError_t e = hipMemsetAsync(L.counters, 0, (2 + kLsmStampSlots) * sizeof(double), s);
+    if (e != hipSuccess) return (int)e;
+    table();
 #define HH_CALL(D) run_lsm<D>(L, a, s)
     HH_LSM_DISPATCH(degree, HH_CALL)
 #undef HH_CALL
