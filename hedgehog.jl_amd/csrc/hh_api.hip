@@ -140,7 +140,7 @@ int hh_ctx_create(hh_ctx** out, int device_id) {
       hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->ev_switch, hipEventDisableTiming) != hipSuccess ||
       hipMalloc((void**)&ctx->accum, HH_ACC_LEN * sizeof(double)) != hipSuccess ||
-      hipHostMalloc((void**)&ctx->accum_host, HH_ACC_LEN * sizeof(double), hipHostMallocDefault) !=
+      hipHostMalloc((void**)&ctx->accum_host, (HH_ACC_LEN + 8) * sizeof(double), hipHostMallocDefault) !=
           hipSuccess) {
     hh_ctx_destroy(ctx);
     return HH_ERR_HIP;
@@ -728,8 +728,11 @@ static int lsm_on_grid(hh_ctx* ctx, const double* grid_dev, uint64_t ntot, uint3
   // one-launch form leaves a word behind when its workgroups could not all be resident together
   // (another kernel held CUs): nothing was written then, and the launch-per-date form runs instead
   int form_used = hh::kLsmFormPerDate;
-  double counters[2] = {0, 0};
-  unsigned int gave_up = 0;
+  // the small results land in PINNED memory behind the accumulator (a copy to the stack is staged
+  // through the runtime's own buffer and costs ~10 µs apiece)
+  double* counters = ctx->accum_host + HH_ACC_LEN;
+  unsigned int& gave_up = *reinterpret_cast<unsigned int*>(ctx->accum_host + HH_ACC_LEN + 2);
+  counters[0] = counters[1] = 0.0;
   int32_t fallbacks = 0;
   for (int attempt = 0; attempt < 2; ++attempt) {
     const int form = attempt == 0 ? ctx->lsm_form : hh::kLsmFormPerDate;

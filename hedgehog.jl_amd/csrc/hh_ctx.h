@@ -60,7 +60,7 @@ struct hh_ctx {
   uint64_t lsm_persistent_fallbacks = 0;  // persistent launches that gave up and were redone per date
   long long lsm_spin_ticks = -1;          // hh_ctx_set_option(HH_OPT_LSM_SPIN_TICKS); < 0 = the default (1 s)
   double* accum = nullptr;       // device, HH_ACC_LEN
-  double* accum_host = nullptr;  // pinned, HH_ACC_LEN
+  double* accum_host = nullptr;  // pinned, HH_ACC_LEN + 8 (LSM: row counters and the give-up word behind the accumulator)
   // optional per-launch timing of the simulation kernel (hh_ctx_enable_timing)
   static constexpr int kTimingSlots = 256;
   bool timing = false;
