@@ -792,7 +792,11 @@ def main():
                 # the spot grid written once by the path kernel and read once by the backward
                 # induction: 2 x 8 B per (trajectory, date)
                 "roofline": hbm_roofline("gbm_grid_kernel + LSM backward induction (whole chain)",
-                                         16.0 * 2 * n_l * (st_l + 1), t_lsm, **lsm_traffic(2 * n_l, st_l))},
+                                         16.0 * 2 * n_l * (st_l + 1), t_lsm, **lsm_traffic(2 * n_l, st_l)),
+                # what actually bounds a date of the induction is the SIMDs' issue rate (and ~2.5 µs of
+                # synchronisation): the same chain against the fp64-VALU issue roofline
+                "roofline_valu": valu_roofline("gbm_grid_kernel + lsm_persistent_kernel + lsm_final_kernel",
+                                               "lsm_chain", 2.0 * n_l * st_l, t_lsm, vt)},
             "heston_exact_grid_2e5_paths_x_12_dates": {
                 "kernel_ms": r_g.kernel_ms, "transitions_per_s": n_g * st_g / (r_g.kernel_ms * 1e-3),
                 "cf_terms_per_transition": r_g.bk_cf_terms / (n_g * st_g),

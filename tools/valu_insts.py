@@ -6,7 +6,8 @@ time and by 1024 SIMDs x 2.4 GHz: the fp64-VALU issue fraction of its roofline e
 
     rocprofv3 --pmc SQ_INSTS_VALU --kernel-trace --output-format csv -d A -- python3 tools/bench_configs.py
     rocprofv3 --pmc SQ_INSTS_VALU --kernel-trace --output-format csv -d B -- python3 tools/bk_only.py grid
-    python tools/valu_insts.py A/*/*_counter_collection.csv B/*/*_counter_collection.csv [tag]
+    rocprofv3 --pmc SQ_INSTS_VALU --kernel-trace --output-format csv -d L -- python3 tools/lsm_latency.py 1000000
+    python tools/valu_insts.py A/*/*_counter_collection.csv B/*/*_counter_collection.csv [L/*/*_counter_collection.csv] [tag]
 """
 import collections
 import csv
@@ -34,7 +35,8 @@ def mean_of(k, names, pick):
 
 def main():
     a, b = per_kernel(sys.argv[1]), per_kernel(sys.argv[2])
-    tag = sys.argv[3] if len(sys.argv) > 3 else "r02"
+    lsm_csv = sys.argv[3] if len(sys.argv) > 3 and sys.argv[3].endswith(".csv") else None
+    tag = sys.argv[-1] if not sys.argv[-1].endswith(".csv") else "r02"
     src = f"rocprofv3 --pmc SQ_INSTS_VALU, round {tag}"
     N, M = 1_000_000, 252
     gen = mean_of(a, "generate", lambda n: "euler_kernel<hh::HestonModel<0, true>, 0, false, false" in n)
@@ -51,6 +53,14 @@ def main():
                               "source": src},
         "_what": "VALU wave-instructions (64 lanes each) per unit, SQ_INSTS_VALU averaged over the dispatches of a kernel",
     }
+    if lsm_csv:  # tools/lsm_latency.py 1000000: 2*10^6 trajectories x 100 dates, both forms; the one-launch chain
+        l = per_kernel(lsm_csv)
+        ind = mean_of(l, "lsm", lambda n: "lsm_persistent_kernel<5, 16>" in n)
+        grid = mean_of(l, "grid", lambda n: "gbm_grid_kernel<true>" in n)
+        fin = mean_of(l, "final", lambda n: "lsm_final_kernel" in n)
+        out["lsm_chain"] = {"valu_insts_per_unit": (ind + grid + fin) / (2_000_000 * 100),
+                            "unit": "(trajectory, date): gbm_grid_kernel + lsm_persistent_kernel + lsm_final_kernel",
+                            "induction_share": ind / (ind + grid + fin), "source": src}
     json.dump(out, open(os.path.join(ROOT, "profiles", "valu_insts.json"), "w"), indent=1)
     print(json.dumps(out, indent=1))
 
