@@ -385,8 +385,10 @@ __device__ __forceinline__ double rcp_nr(double x) {
 // Normal equations G c = B, G_jk = P[j+k] = Σ z^(j+k) (P[0] = the in-the-money count, handed over
 // separately as p0; Pm1 points at P[1]).  G is a Gram matrix — symmetric positive (semi-)definite —
 // so elimination needs no pivoting (it is the LDLᵀ factorisation, stable as it stands); a column
-// whose pivot has vanished against the matrix scale (fewer distinct in-the-money spots than
-// coefficients) is dropped, its coefficient 0.  Every workgroup of either form runs this on the same
+// whose pivot has vanished against ITS OWN diagonal entry Σ z^2c (fewer distinct in-the-money spots than
+// coefficients) is dropped, its coefficient 0.  (Until late round 3 the pivot was held against the
+// largest diagonal entry: with heavy-tailed z and degree 7-8 that one, Σ z^16, is 10^13 times the
+// count Σ z^0, and the test dropped the constant and the linear column of a perfectly determined fit.)  Every workgroup of either form runs this on the same
 // sums and so obtains the same coefficients.  One-thread form:
 template <int D>
 __device__ void solve_normal_equations(const double* B, double p0, const double* Pm1, double* coef) {
@@ -399,13 +401,10 @@ __device__ void solve_normal_equations(const double* B, double p0, const double*
     for (int k = 0; k < N; ++k) M[j][k] = Pv(j + k);
     M[j][N] = B[j];
   }
-  double scale = 0.0;
-#pragma unroll
-  for (int j = 0; j < N; ++j) scale = fmax(scale, fabs(M[j][j]));
   double inv[N];
 #pragma unroll
   for (int c = 0; c < N; ++c) {
-    const bool dead = !(M[c][c] > 1e-13 * scale);
+    const bool dead = !(M[c][c] > 1e-13 * Pv(2 * c));
     inv[c] = dead ? 0.0 : rcp_nr(M[c][c]);
     if (!dead) {
 #pragma unroll
@@ -452,16 +451,13 @@ __device__ void solve_normal_equations_wave(const double* B, double p0, const do
 #pragma unroll
   for (int k = 0; k < N; ++k) r[k] = Pv(row + k);
   r[N] = B[row];
-  double scale = 0.0;
-#pragma unroll
-  for (int j = 0; j < N; ++j) scale = fmax(scale, fabs(Pv(2 * j)));
   double inv[N];
 #pragma unroll
   for (int c = 0; c < N; ++c) {
     double prow[N + 1];  // row c (wave-uniform); final, since only the rows below it change from here
 #pragma unroll
     for (int k = c; k <= N; ++k) prow[k] = readlane_f64(r[k], c);
-    const bool dead = !(prow[c] > 1e-13 * scale);
+    const bool dead = !(prow[c] > 1e-13 * Pv(2 * c));
     inv[c] = dead ? 0.0 : rcp_nr(prow[c]);
     if (!dead && lane > c) {
       const double f = r[c] * inv[c];

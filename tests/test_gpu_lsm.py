@@ -218,7 +218,10 @@ if given is not None:
         # degrees 6-8 on a few hundred in-the-money trajectories: the normal equations lose ~10 digits, and
         # a flipped decision changes the cash flows every earlier regression sees (95 % was seen: degree 7,
         # 514 trajectories, 34 dates)
-        assert same.mean() >= (0.97 if degree <= 5 else 0.90), (same.mean(), degree, n, steps)
+        # (and 88 % with 9 coefficients on the 26-37 in-the-money ones of 128 trajectories, where the two
+        # solvers regularise a rank-deficient fit differently: 80 % asked below 1000 trajectories)
+        floor = 0.97 if degree <= 5 else 0.90 if grid.shape[1] >= 1000 else 0.80
+        assert same.mean() >= floor, (same.mean(), degree, n, steps)
         np.testing.assert_allclose(val[same], ref["stop_value"][same], rtol=1e-12, atol=1e-13 * S0)
         # a flipped trajectory changes its discounted value by at most its largest payoff along the path
         pay_max = np.maximum(cp * (grid - K), 0.0).max(axis=0)
