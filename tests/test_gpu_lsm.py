@@ -227,3 +227,32 @@ if given is not None:
         pay_max = np.maximum(cp * (grid - K), 0.0).max(axis=0)
         slack = float(np.sum(pay_max[~same])) / grid.shape[1]
         assert abs(res.price - ref["price"]) <= slack + 1e-11 * max(ref["price"], 1e-3 * S0)
+
+
+def test_concurrent_contexts_share_the_chip(hhlib):
+    """Three host threads, each with its own context, run one-launch inductions at the same time: the
+    cooperative launches are serialised by the runtime (none finds its grid half resident and gives up),
+    and every thread gets the serial result bit for bit."""
+    import threading
+    n, steps, degree = 30_000, 25, 4
+    seeds = np.arange(1, n + 1, dtype=np.uint64)
+
+    def run(ctx, out, key):
+        prices, fallbacks = set(), 0
+        for _ in range(8):
+            res, *_ = gpu_lsm(ctx, 100.0, 100.0, 0.05, 0.2, 1.0, -1.0, seeds, steps, 1, degree, want_grid=False)
+            prices.add(res.price)
+            fallbacks += res.persistent_fallbacks
+            assert res.form == _ffi.HH_LSM_FORM_PERSISTENT
+        out[key] = (prices, fallbacks)
+
+    out = {}
+    run(hhlib, out, "serial")
+    ctxs = [_ffi.Context(0) for _ in range(3)]
+    threads = [threading.Thread(target=run, args=(c, out, i)) for i, c in enumerate(ctxs)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert len(out) == 4
+    assert all(v == (out["serial"][0], 0) for v in out.values()) and len(out["serial"][0]) == 1
