@@ -22,6 +22,13 @@
  *     one ctx per device, the all-reduce inside the library: hh_mgpu_solve), or one process (or
  *     thread) per GPU, each with its own ctx, exchanging only the HH_ACC_LEN-double accumulator
  *     vector (hh_mc_accumulate + the caller's all-reduce + hh_mc_finalize).
+ *   - DEVICE buffers the caller passes (seeds / replay / terminal `_on_device`, grids) are read and
+ *     written on the ctx's stream, which does not wait for any other stream: data produced on another
+ *     stream (PyTorch's, say) must be complete before the call — synchronize it, or lend that stream
+ *     to the ctx with hh_ctx_set_stream — and results of the ASYNCHRONOUS entry points
+ *     (hh_mc_accumulate, hh_wiener_fill, hh_replay_pack, the hh_lsm_shard_* phases) are ready only after
+ *     hh_ctx_synchronize.  The synchronous ones (hh_mc_solve, hh_lsm_solve, …) return with their
+ *     device outputs complete.
  *   - there is NO CPU fallback in this library: without a HIP device every compute entry point
  *     fails with HH_ERR_HIP.
  */
