@@ -256,3 +256,23 @@ def test_concurrent_contexts_share_the_chip(hhlib):
         t.join()
     assert len(out) == 4
     assert all(v == (out["serial"][0], 0) for v in out.values()) and len(out["serial"][0]) == 1
+
+
+def test_the_one_launch_form_on_a_borrowed_stream():
+    """hh_ctx_set_stream: the cooperative launch goes out on the caller's stream (the null stream,
+    a PyTorch side stream) like every other kernel; same bits as on the context's own."""
+    import torch
+    ctx = _ffi.Context(0)
+    seeds = np.arange(1, 150_001, dtype=np.uint64)
+    args = (100.0, 100.0, 0.05, 0.2, 1.0, -1.0, seeds, 20, 1, 4)
+    own = gpu_lsm(ctx, *args, want_grid=False)[0]
+    side = torch.cuda.Stream()
+    for stream in (0, side.cuda_stream):  # 0 = the null stream
+        ctx.set_stream(stream)
+        try:
+            res = gpu_lsm(ctx, *args, want_grid=False)[0]
+        finally:
+            ctx.check(ctx.lib.hh_ctx_reset_stream(ctx.handle))
+        assert (res.price, res.std_error) == (own.price, own.std_error)
+        assert res.form == _ffi.HH_LSM_FORM_PERSISTENT and res.persistent_fallbacks == 0
+    ctx.close()
