@@ -13,33 +13,31 @@
 // conditioned in fp64) and the moment sums Σ z^k y.  Two forms compute them, with the SAME
 // summation tree (so their coefficients, stopping decisions and prices are bit-identical):
 //
-//  * ONE PERSISTENT LAUNCH (lsm_persistent_kernel; ensembles of up to 256 chunks = 2^21
-//    trajectories): every workgroup keeps the stopping state and the current row of its
-//    trajectories in registers for the whole induction (512 threads x 16 trajectories, 256
-//    registers per lane; rows t-1 and t-2 wait in 128 KiB of LDS) and reads every row of the grid
-//    exactly once.  Per date the workgroups publish one 32-double record {Σ z^k y and Σ z^k of row
-//    t-1, statistics of row t-2} and gather everybody's — an all-gather by write-through (sc1)
-//    stores + per-record epoch tags polled with sc1 loads (the hand-off of
-//    cdna_hip_programming.md §6 Guideline 16, row 1 of its table; records value-major so that a
-//    gathering wave reads contiguous lines) — then each of them reduces the records in the fixed
-//    order, solves the normal equations redundantly (one wave, rows spread over its lanes) and
-//    takes the exercise decisions of its own trajectories.  No launch, no re-load of tau / val /
-//    spots, no separate passes for the statistics and the power sums.  Every wait is bounded
-//    (s_memrealtime): if the grid is not co-resident the kernel gives up, the host sees a status
-//    word and runs the other form.
+//  * ONE PERSISTENT (cooperative) LAUNCH (lsm_persistent_kernel; every ensemble of up to 256 chunks =
+//    2^21 trajectories): every workgroup keeps the stopping state and the current row of its
+//    trajectories in registers for the whole induction (512 threads x 2 … 16 trajectories, up to 256
+//    registers per lane; rows t-1 and t-2 wait in LDS) and reads every row of the grid exactly once.
+//    Per date the workgroups publish one record in two halves — A: Σ z^k y of row t-1 and the
+//    statistics of row t-3, B: Σ z^k of row t-2 (the pipeline runs statistics three rows, power sums
+//    two, moment sums one row ahead of the decisions) — and gather everybody's: every value travels as
+//    a self-validating 16-byte granule {v, v ^ (launch nonce : epoch)} written through (sc1), read
+//    first through the caches and again with sc0 sc1 loads only if it does not validate (records
+//    value-major so that a gathering wave reads contiguous lines).  Each workgroup then reduces the
+//    records in the fixed order, solves the normal equations redundantly (one wave, rows spread over
+//    its lanes) and takes the exercise decisions of its own trajectories.  No launch, no re-load of
+//    tau / val / spots, no separate passes for the statistics and the power sums.  Every wait is
+//    bounded (s_memrealtime): should the grid not be co-resident after all the kernel gives up, the
+//    host sees a status word and runs the other form.
 //  * ONE LAUNCH PER DATE (lsm_step_kernel & co.): statistics and power sums of every row in one-off
-//    launches, then a launch per exercise date.  Used for larger ensembles, for small ones (up to
-//    2^18 trajectories a kernel boundary, ~1.5 µs, is a cheaper synchronisation than the in-kernel
-//    all-gather, ~3.5 µs), when the persistent grid cannot be resident, and — cut at the global
-//    sums — for ensembles sharded over several GPUs (launch_lsm_phase), where the host all-reduces
-//    between launches.
-//  Measured, 2·10^6 trajectories x 100 dates, degree 5 (profiles/r02_lsm_*): 2.05 ms in one launch
-//  (13.9 µs per date: all-gather 3.5, workgroup totals + publish 3.2, moment sums 2.6, power sums
-//  1.3, row issue 1.2, solve 1.2, decisions 0.8) against 3.1 ms with a launch per date and 4.3 ms
-//  for round 1's launch-per-date form.
+//    launches, then a launch per exercise date.  Used beyond 2^21 trajectories, when the runtime
+//    refuses the cooperative grid, and — cut at the global sums — for ensembles sharded over several
+//    GPUs (launch_lsm_phase), where the sums are all-reduced between launches.
+//  Measured, 2·10^6 trajectories x 100 dates, degree 5 (profiles/r03_g_lsm_*, r03_m_*): 1.44-1.60 ms
+//  in one launch by box (10.3 µs per date: arithmetic of both waves of a SIMD 7.4, solve window 1.35,
+//  gather 1.1) against 2.9 ms with a launch per date; round 2 2.05 ms, round 1 4.3 ms.
 //
 // Summation tree (independent of the form and of the GPU): chunk = 512 lanes x Q trajectories
-// (trajectory = chunk·512·Q + j·512 + lane; Q = 2 up to 2^18 trajectories, else 16); a lane adds
+// (trajectory = chunk·512·Q + j·512 + lane; Q = the smallest of 2, 4, 8, 16 that fits 256 chunks: lsm_q); a lane adds
 // its Q terms in order j (out-of-the-money terms are exact zeros); a wave adds its 64 lanes by the
 // butterfly (l, l^32), (l, l^16), …; the chunk adds its 8 waves in order; the records of the chunks
 // are dealt to 256 lanes (r, r+256, …, added in order) which are summed by the same butterfly and,
@@ -485,7 +483,7 @@ __device__ void solve_normal_equations_wave(const double* B, double p0, const do
 #define HH_LSM_WAVE_SOLVE 1
 #endif
 // timing diagnostics only (results are WRONG with any bit set; tools/lsm_breakdown.py builds variants):
-// 1 = the gather does not wait for the tags, 2 = no solve, 4 = no partial sums / reductions / publish
+// 1 = the gather does not wait for granules that fail their check, 2 = no solve, 4 = no partial sums / reductions / publish
 #ifndef HH_LSM_DEBUG
 #define HH_LSM_DEBUG 0
 #endif
@@ -503,7 +501,7 @@ constexpr int kLsmStampSlots = 8;
 // with a global store or load outstanding the compiler puts s_waitcnt vmcnt(0) in front of s_barrier,
 // which drains the published record's write-through stores (~1.5 µs) and the NEXT row's prefetch
 // (~2 µs of HBM latency) on every barrier of the persistent induction.  What its barriers order is
-// LDS (partial sums, coefficients); the record protocol has its own vmcnt(0) in front of the tag.
+// LDS (partial sums, coefficients); the record protocol needs no fence at all (self-validating granules).
 __device__ __forceinline__ void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
@@ -1239,7 +1237,7 @@ struct LsmLayout {
   double* P;          // [rows][2D+1]
   double* recB;       // [rows][nch][D+1]
   double* disc_pow;   // [rows]
-  double* sync;       // persistent form: tags + status (memset per launch), then the record ring
+  double* sync;       // persistent form: status word, then the record ring (both zeroed per launch)
   double* counters;   // [2]
   uint32_t rows, nch;
   int q;
