@@ -22,6 +22,8 @@ HH_REPLAY_TILE_MAJOR, HH_REPLAY_PATH_MAJOR = 0, 1
 HH_OK, HH_ERR_INVALID, HH_ERR_UNSUPPORTED, HH_ERR_HIP, HH_ERR_NOMEM, HH_ERR_RCCL = 0, -1, -2, -3, -4, -5
 HH_MGPU_AUTO, HH_MGPU_HOST_SUM, HH_MGPU_RCCL = 0, 1, 2
 HH_MGPU_REDUCE_HOST, HH_MGPU_REDUCE_RCCL = 0, 1
+HH_MGPU_OPT_ENQUEUE = 1
+HH_MGPU_ENQUEUE_SERIAL, HH_MGPU_ENQUEUE_THREADS = 0, 1
 
 _dp = C.POINTER(C.c_double)
 
@@ -134,6 +136,8 @@ SYMBOLS = [
     ("hh_mgpu_n_devices", C.c_int, [_vp]),
     ("hh_mgpu_reduce_mode", C.c_int, [_vp]),
     ("hh_mgpu_ctx", _vp, [_vp, C.c_int]),
+    ("hh_mgpu_set_option", C.c_int, [_vp, C.c_int32, C.c_int64]),
+    ("hh_mgpu_enqueue_stats", C.c_int, [_vp, _vp, C.POINTER(C.c_double)]),
     ("hh_mgpu_shard_range", None, [C.c_uint64, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     ("hh_mgpu_solve", C.c_int, [_vp, C.POINTER(hh_model), C.POINTER(hh_config), C.POINTER(hh_result), _vp]),
     ("hh_mgpu_solve_shards", C.c_int, [_vp, C.POINTER(hh_model), C.POINTER(hh_config), C.POINTER(hh_result), _vp]),
@@ -155,10 +159,11 @@ def load_library(path: str | None = None):
         raise HedgehogMCError(HH_ERR_HIP, f"{path} not found — build it with "
                               "`python -c 'import __graft_entry__ as g; g.build()'`; "
                               "there is no CPU fallback")
-    try:  # share PyTorch's HIP runtime (same libamdhip64 soname) when torch is the allocator
-        import torch  # noqa: F401
-    except Exception:  # pragma: no cover - torch is optional for the C-ABI itself
-        pass
+    if not os.environ.get("HEDGEHOG_MC_NO_TORCH"):
+        try:  # share PyTorch's HIP runtime (same libamdhip64 soname) when torch is the allocator
+            import torch  # noqa: F401
+        except Exception:  # pragma: no cover - torch is optional for the C-ABI itself
+            pass
     lib = C.CDLL(path, mode=C.RTLD_GLOBAL)
     for name, res, args in SYMBOLS:
         fn = getattr(lib, name)
@@ -325,6 +330,16 @@ class MultiGpu:
 
     def last_error(self) -> str:
         return self.lib.hh_mgpu_last_error(self.handle).decode(errors="replace")
+
+    def set_option(self, option: int, value: int):
+        self.check(self.lib.hh_mgpu_set_option(self.handle, int(option), int(value)))
+
+    def enqueue_stats(self):
+        """(per-shard host µs, whole-phase host µs) of the last solve's enqueue phase."""
+        per = (C.c_double * len(self.devices))()
+        whole = C.c_double(0.0)
+        self.check(self.lib.hh_mgpu_enqueue_stats(self.handle, per, C.byref(whole)))
+        return list(per), whole.value
 
     def ctx(self, i: int) -> Context:
         return self._ctxs[i]

@@ -1,4 +1,4 @@
-// hh_mgpu_*: the path-sharded multi-GPU solve driven from ONE host thread inside the library
+// hh_mgpu_*: the path-sharded multi-GPU solve behind ONE call of the caller's host thread
 // (include/hedgehog_mc.h).  What it stands in for is still ONE call of
 // solve(prob, method) (montecarlo.jl:478-493) on one EnsembleProblem (:329-333,351): the trajectories
 // are cut into contiguous ranges, every device runs the single-GPU kernel sequence of hh_mc_accumulate
@@ -6,15 +6,33 @@
 // one RCCL all-reduce over xGMI — or, when RCCL is not there or refuses, by an ordered sum on the
 // host.  No arithmetic of the pricing path happens here except that ordered sum.
 //
+// Enqueueing a shard costs the host tens of microseconds (argument checks, two event records, two or
+// three launches: profiles/r04_a_mgpu_enqueue.txt), which over eight devices in a row is a fifth of the
+// 0.57 ms the kernels take.  So the shards are enqueued CONCURRENTLY: device 0 by the calling thread,
+// device g > 0 by a library-owned worker thread bound to that device, which spins for a short window
+// after each job (back-to-back solves find it awake) and parks on a condition variable otherwise.
+// The exchange itself is issued by the calling thread once every shard is enqueued.
+//
+// A collective that fails for rank g after ranks < g were enqueued leaves kernels on those ranks'
+// streams that wait for peers which never come.  Such a stream is never synchronised: the
+// communicators are aborted, every shard stream is retired (replaced by a fresh one that waits for the
+// event recorded BEFORE the collective), and the sums are finished on the host (rccl_give_up).
+//
 // RCCL is bound with dlopen at run time: the product library has no link-time dependency on it (a
 // Julia host that never shards does not need librccl at all), and inside a PyTorch process the
 // already-loaded librccl.so.1 — built against the HIP runtime the process uses — is what the soname
 // resolves to.
 #include <dlfcn.h>
 
+#include <array>
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
+#include <memory>
+#include <thread>
 #include <vector>
 
 #include "hh_ctx.h"
@@ -29,6 +47,7 @@ struct RcclApi {
   void* lib = nullptr;
   int (*CommInitAll)(rccl_comm_t*, int, const int*) = nullptr;
   int (*CommDestroy)(rccl_comm_t) = nullptr;
+  int (*CommAbort)(rccl_comm_t) = nullptr;  // optional: without it a lost communicator is leaked
   int (*AllReduce)(const void*, void*, size_t, int, int, rccl_comm_t, hipStream_t) = nullptr;
   int (*GroupStart)() = nullptr;
   int (*GroupEnd)() = nullptr;
@@ -57,6 +76,7 @@ RcclApi& rccl() {
     }
     api.CommInitAll = (decltype(api.CommInitAll))dlsym(api.lib, "ncclCommInitAll");
     api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.lib, "ncclCommDestroy");
+    api.CommAbort = (decltype(api.CommAbort))dlsym(api.lib, "ncclCommAbort");
     api.AllReduce = (decltype(api.AllReduce))dlsym(api.lib, "ncclAllReduce");
     api.GroupStart = (decltype(api.GroupStart))dlsym(api.lib, "ncclGroupStart");
     api.GroupEnd = (decltype(api.GroupEnd))dlsym(api.lib, "ncclGroupEnd");
@@ -70,10 +90,21 @@ RcclApi& rccl() {
 
 }  // namespace
 
+// One per device g >= 1 (device 0 is driven by the calling thread).
+struct hh_worker {
+  std::thread th;
+  std::mutex m;
+  std::condition_variable cv;
+  std::atomic<uint64_t> posted{0}, finished{0};
+  std::atomic<int> parked{0}, stop{0};
+  int rc = 0;
+};
+
 struct hh_mgpu {
   int n = 0;
   int flags = HH_MGPU_AUTO;
   int mode = HH_MGPU_REDUCE_HOST;
+  bool rccl_lost = false;  // the communicators were aborted after a failed collective
   std::vector<int> devices;
   std::vector<hh_ctx*> ctx;
   std::vector<double*> acc, red;  // per device: local sums, all-reduced sums (RCCL writes out of place)
@@ -83,11 +114,37 @@ struct hh_mgpu {
   size_t host_cap = 0;
   std::vector<double*> xchg;  // per device: the exchange vector of a sharded LSM solve
   std::vector<size_t> xchg_cap;
+  // concurrent enqueue
+  int enqueue = HH_MGPU_ENQUEUE_THREADS;
+  std::vector<std::unique_ptr<hh_worker>> workers;  // [g - 1], made on first use
+  const std::function<int(int)>* job = nullptr;
+  std::vector<int> rcs;
+  std::vector<std::array<char, 320>> derr;  // per device: what failed inside a job (jobs never write err)
+  std::vector<double> enq_us;               // host time of each shard's enqueue in the last solve
+  double enq_phase_us = 0.0;                // … and of the whole enqueue phase (wall)
+  // retiring streams that may hold an orphaned collective
+  std::vector<hipEvent_t> pre;    // per device: recorded before a collective is enqueued
+  std::vector<hipEvent_t> fence;  // per device: the event a retired stream's successor waits for
+  struct Retired {
+    int device;
+    hipStream_t s;
+  };
+  std::vector<Retired> retired;
   char err[512] = {0};
   std::mutex mu;
 };
 
 namespace {
+
+using clk = std::chrono::steady_clock;
+inline double us_since(clk::time_point t0) {
+  return std::chrono::duration<double, std::micro>(clk::now() - t0).count();
+}
+inline void cpu_relax() {
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+  __builtin_ia32_pause();
+#endif
+}
 
 int mfail(hh_mgpu* mg, int code, const char* fmt, ...) {
   if (mg) {
@@ -107,6 +164,17 @@ int mfail(hh_mgpu* mg, int code, const char* fmt, ...) {
                    __FILE__, __LINE__);                                                       \
   } while (0)
 
+// inside a per-device job (possibly on a worker thread): the text goes to the device's own slot
+#define HH_DHIP(mg, g, expr)                                                                       \
+  do {                                                                                             \
+    hipError_t e__ = (hipError_t)(expr);                                                           \
+    if (e__ != hipSuccess) {                                                                       \
+      snprintf(mg->derr[g].data(), mg->derr[g].size(), "%s failed: %s (%s:%d)", #expr,             \
+               hipGetErrorString(e__), __FILE__, __LINE__);                                        \
+      return HH_ERR_HIP;                                                                           \
+    }                                                                                              \
+  } while (0)
+
 void shard_range(uint64_t n_paths, int n_dev, int g, bool tile_aligned, uint64_t* start, uint64_t* stop) {
   uint64_t per = (n_paths + (uint64_t)n_dev - 1) / (uint64_t)n_dev;
   if (tile_aligned) per = (per + hh::kTile - 1) / hh::kTile * hh::kTile;
@@ -114,6 +182,101 @@ void shard_range(uint64_t n_paths, int n_dev, int g, bool tile_aligned, uint64_t
   *start = a;
   *stop = std::min(n_paths, a + per);
 }
+
+// ---- the workers ------------------------------------------------------------------------------------
+
+constexpr double kSpinWindowUs = 150.0;  // how long an idle worker polls before it parks
+
+void worker_main(hh_mgpu* mg, int g) {
+  hh_worker& w = *mg->workers[g - 1];
+  (void)hipSetDevice(mg->devices[g]);
+  uint64_t seen = 0;
+  for (;;) {
+    const auto idle0 = clk::now();
+    while (w.posted.load() == seen && !w.stop.load()) {
+      if (us_since(idle0) < kSpinWindowUs) {
+        cpu_relax();
+        continue;
+      }
+      std::unique_lock<std::mutex> lk(w.m);
+      w.parked.store(1);
+      w.cv.wait(lk, [&] { return w.posted.load() != seen || w.stop.load(); });
+      w.parked.store(0);
+    }
+    if (w.stop.load()) return;
+    ++seen;
+    w.rc = (*mg->job)(g);
+    w.finished.store(seen);
+  }
+}
+
+void stop_workers(hh_mgpu* mg) {
+  for (auto& w : mg->workers) {
+    if (!w) continue;
+    w->stop.store(1);
+    {
+      std::lock_guard<std::mutex> lk(w->m);
+      w->cv.notify_one();
+    }
+    if (w->th.joinable()) w->th.join();
+  }
+  mg->workers.clear();
+}
+
+// fn(g) for every device — concurrently when the context enqueues with threads — and the first failure
+// in device order (every job has returned by then).  A job reports through mg->derr[g] only.
+int for_each_device(hh_mgpu* mg, const std::function<int(int)>& fn) {
+  for (int g = 0; g < mg->n; ++g) mg->derr[g][0] = 0;
+  bool threads = mg->enqueue == HH_MGPU_ENQUEUE_THREADS && mg->n > 1;
+  if (threads && mg->workers.empty()) {
+    mg->workers.resize(mg->n - 1);
+    for (int g = 1; g < mg->n && threads; ++g) {
+      mg->workers[g - 1].reset(new (std::nothrow) hh_worker());
+      if (!mg->workers[g - 1]) {
+        threads = false;
+        break;
+      }
+      try {
+        mg->workers[g - 1]->th = std::thread(worker_main, mg, g);
+      } catch (...) {
+        threads = false;
+      }
+    }
+    if (!threads) {  // no threads to be had: the shards are enqueued in a row from here on
+      stop_workers(mg);
+      mg->enqueue = HH_MGPU_ENQUEUE_SERIAL;
+    }
+  }
+  if (!threads) {
+    for (int g = 0; g < mg->n; ++g) mg->rcs[g] = fn(g);
+  } else {
+    mg->job = &fn;
+    for (int g = 1; g < mg->n; ++g) {
+      hh_worker& w = *mg->workers[g - 1];
+      w.posted.fetch_add(1);
+      if (w.parked.load()) {
+        std::lock_guard<std::mutex> lk(w.m);
+        w.cv.notify_one();
+      }
+    }
+    mg->rcs[0] = fn(0);
+    for (int g = 1; g < mg->n; ++g) {
+      hh_worker& w = *mg->workers[g - 1];
+      const uint64_t want = w.posted.load();
+      const auto t0 = clk::now();
+      while (w.finished.load() != want) {
+        if (us_since(t0) < 2000.0) cpu_relax(); else std::this_thread::yield();
+      }
+      mg->rcs[g] = w.rc;
+    }
+    mg->job = nullptr;
+  }
+  for (int g = 0; g < mg->n; ++g)
+    if (mg->rcs[g]) return mfail(mg, mg->rcs[g], "shard %d (device %d): %s", g, mg->devices[g], mg->derr[g].data());
+  return HH_OK;
+}
+
+// ---- buffers ----------------------------------------------------------------------------------------
 
 // the staging / accumulator buffers of an accumulator vector of n_acc doubles per device
 int ensure_acc(hh_mgpu* mg, size_t n_acc) {
@@ -139,11 +302,70 @@ int ensure_acc(hh_mgpu* mg, size_t n_acc) {
   return HH_OK;
 }
 
-void sync_all(hh_mgpu* mg) {
+// Every failure AFTER something was enqueued leaves through here: earlier shards' kernels may still
+// read the caller's buffers, and a sharded LSM must not stay half open.  Only ever called on streams
+// that hold no collective (after rccl_give_up these are the fresh ones).
+int drain(hh_mgpu* mg, int rc) {
   for (int g = 0; g < mg->n; ++g) {
     (void)hipSetDevice(mg->devices[g]);
     (void)hipStreamSynchronize(mg->ctx[g]->stream);
+    mg->ctx[g]->shard.active = false;
   }
+  return rc;
+}
+#define HH_MHIP_DRAIN(mg, expr)                                                                       \
+  do {                                                                                                \
+    hipError_t e__ = (hipError_t)(expr);                                                              \
+    if (e__ != hipSuccess)                                                                            \
+      return drain(mg, mfail(mg, HH_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), \
+                             __FILE__, __LINE__));                                                    \
+  } while (0)
+
+// ---- the exchange -----------------------------------------------------------------------------------
+
+// ONE grouped all-reduce over the shards' streams.  fence[g] must already name an event recorded on
+// stream g behind the kernels that produced send[g] (and before anything of the collective).
+int all_reduce_group(hh_mgpu* mg, double* const* send, double* const* recv, size_t n) {
+  RcclApi& api = rccl();
+  int e = api.GroupStart();
+  for (int g = 0; g < mg->n && e == kNcclSuccess; ++g)
+    e = api.AllReduce(send[g], recv[g], n, kNcclDouble, kNcclSum, mg->comms[g], mg->ctx[g]->stream);
+  const int e2 = api.GroupEnd();  // launches what WAS enqueued, also after a failure in the middle
+  return e == kNcclSuccess ? e2 : e;
+}
+
+// After a failed collective.  Ranks enqueued before the failure may sit in their streams waiting for
+// peers that never arrive, so no shard stream is waited for again: the communicators are aborted (which
+// lets such kernels leave), every stream is retired in favour of a fresh one that continues behind
+// fence[g], and from here on this context sums on the host.  Returns with nothing synchronised.
+void rccl_give_up(hh_mgpu* mg) {
+  RcclApi& api = rccl();
+  for (rccl_comm_t c : mg->comms)
+    if (c && api.CommAbort) (void)api.CommAbort(c);  // no ncclCommAbort: leaked (CommDestroy could wait for the orphan)
+  mg->comms.clear();
+  mg->mode = HH_MGPU_REDUCE_HOST;
+  mg->rccl_lost = true;
+  for (int g = 0; g < mg->n; ++g) {
+    hh_ctx* c = mg->ctx[g];
+    std::lock_guard<std::recursive_mutex> lock__(c->mu);
+    c->shard.active = false;
+    if (c->stream != c->own_stream) continue;  // a stream lent by the caller is the caller's to retire
+    (void)hipSetDevice(mg->devices[g]);
+    hipStream_t fresh = nullptr;
+    if (hipStreamCreateWithFlags(&fresh, hipStreamNonBlocking) != hipSuccess) continue;
+    if (mg->fence[g]) (void)hipStreamWaitEvent(fresh, mg->fence[g], 0);
+    mg->retired.push_back({mg->devices[g], c->own_stream});
+    c->own_stream = c->stream = fresh;
+  }
+}
+
+// the caller's buffers are free once the kernels in front of the fences have run
+void wait_fences(hh_mgpu* mg) {
+  for (int g = 0; g < mg->n; ++g)
+    if (mg->fence[g]) {
+      (void)hipSetDevice(mg->devices[g]);
+      (void)hipEventSynchronize(mg->fence[g]);
+    }
 }
 
 struct Basket {
@@ -152,66 +374,72 @@ struct Basket {
 };
 
 // Enqueue every shard, combine the accumulator vectors, leave the combined vector in mg->host[0 .. n_acc).
-// cfgs[g].n_paths == 0 leaves device g idle (it contributes zeros).  term_dev[g] (nullable): device
+// cfgs[g].n_paths == 0 leaves device g idle (it contributes zeros).  terminals[g] (nullable): device
 // buffer for the shard's terminal samples, already part of cfgs[g] — nothing to do with it here.
 int run_shards(hh_mgpu* mg, const hh_model* m, const hh_config* cfgs, const Basket* basket,
                double* const* terminals, double* kernel_ms) {
   const size_t n_acc = (size_t)HH_ACC_LEN * (basket ? basket->n_payoffs : 1u);
+  if (mg->flags == HH_MGPU_RCCL && mg->rccl_lost)
+    return drain(mg, mfail(mg, HH_ERR_RCCL, "the RCCL communicators of this context were aborted after a failed "
+                                            "collective (HH_MGPU_RCCL does not fall back): create a new one"));
   int rc = ensure_acc(mg, n_acc);
-  if (rc) return rc;
-  // 1. every shard's kernel sequence, back to back, nobody waits
-  for (int g = 0; g < mg->n; ++g) {
+  if (rc) return drain(mg, rc);  // cut_config may have queued staging copies
+  // 1. every shard's kernel sequence: nobody waits, the devices are served concurrently
+  const auto t_enq = clk::now();
+  rc = for_each_device(mg, [&](int g) -> int {
+    const auto t0 = clk::now();
     hh_ctx* c = mg->ctx[g];
-    HH_MHIP(mg, hipSetDevice(mg->devices[g]));
-    HH_MHIP(mg, hipEventRecord(c->ev0, c->stream));
+    HH_DHIP(mg, g, hipSetDevice(mg->devices[g]));
+    HH_DHIP(mg, g, hipEventRecord(c->ev0, c->stream));
     if (cfgs[g].n_paths == 0) {
-      HH_MHIP(mg, hipMemsetAsync(mg->acc[g], 0, n_acc * sizeof(double), c->stream));
+      HH_DHIP(mg, g, hipMemsetAsync(mg->acc[g], 0, n_acc * sizeof(double), c->stream));
     } else {
       double* term = terminals ? terminals[g] : nullptr;
-      rc = basket ? hh_mc_accumulate_basket(c, m, &cfgs[g], basket->strikes, basket->cps, basket->n_payoffs,
-                                            mg->acc[g], term)
-                  : hh_mc_accumulate(c, m, &cfgs[g], mg->acc[g], term);
-      if (rc) {
-        mfail(mg, rc, "shard %d (device %d): %s", g, mg->devices[g], hh_last_error(c));
-        sync_all(mg);  // earlier shards still read the caller's buffers
-        return rc;
+      const int r = basket ? hh_mc_accumulate_basket(c, m, &cfgs[g], basket->strikes, basket->cps,
+                                                     basket->n_payoffs, mg->acc[g], term)
+                           : hh_mc_accumulate(c, m, &cfgs[g], mg->acc[g], term);
+      if (r) {
+        snprintf(mg->derr[g].data(), mg->derr[g].size(), "%s", hh_last_error(c));
+        return r;
       }
     }
-    HH_MHIP(mg, hipEventRecord(c->ev1, c->stream));
-  }
+    HH_DHIP(mg, g, hipEventRecord(c->ev1, c->stream));
+    mg->fence[g] = c->ev1;
+    mg->enq_us[g] = us_since(t0);
+    return HH_OK;
+  });
+  mg->enq_phase_us = us_since(t_enq);
+  if (rc) return drain(mg, rc);  // earlier shards still read the caller's buffers
   // 2. the path's one exchange
   bool reduced = false;
   if (mg->mode == HH_MGPU_REDUCE_RCCL) {
-    RcclApi& api = rccl();
-    int e = api.GroupStart();
-    for (int g = 0; g < mg->n && e == kNcclSuccess; ++g)
-      e = api.AllReduce(mg->acc[g], mg->red[g], n_acc, kNcclDouble, kNcclSum, mg->comms[g], mg->ctx[g]->stream);
-    const int e2 = api.GroupEnd();
-    if (e == kNcclSuccess) e = e2;
+    const int e = all_reduce_group(mg, mg->acc.data(), mg->red.data(), n_acc);
     if (e == kNcclSuccess) {
-      HH_MHIP(mg, hipSetDevice(mg->devices[0]));
-      HH_MHIP(mg, hipMemcpyAsync(mg->host, mg->red[0], n_acc * sizeof(double), hipMemcpyDeviceToHost,
-                                 mg->ctx[0]->stream));
+      HH_MHIP_DRAIN(mg, hipSetDevice(mg->devices[0]));
+      HH_MHIP_DRAIN(mg, hipMemcpyAsync(mg->host, mg->red[0], n_acc * sizeof(double), hipMemcpyDeviceToHost,
+                                       mg->ctx[0]->stream));
       reduced = true;
     } else {
-      mfail(mg, HH_ERR_RCCL, "ncclAllReduce failed: %s", api.GetErrorString(e));
+      mfail(mg, HH_ERR_RCCL, "ncclAllReduce failed: %s — communicators aborted, accumulators are summed on the host",
+            rccl().GetErrorString(e));
+      rccl_give_up(mg);
       if (mg->flags == HH_MGPU_RCCL) {
-        sync_all(mg);
+        wait_fences(mg);
         return HH_ERR_RCCL;
-      }  // else: the local sums are untouched (out-of-place reduce) — finish on the host
+      }  // else: the local sums are untouched (out-of-place reduce) — finish on the host, on the fresh streams
     }
   }
   if (!reduced) {
     for (int g = 0; g < mg->n; ++g) {
-      HH_MHIP(mg, hipSetDevice(mg->devices[g]));
-      HH_MHIP(mg, hipMemcpyAsync(mg->host + (size_t)g * n_acc, mg->acc[g], n_acc * sizeof(double),
-                                 hipMemcpyDeviceToHost, mg->ctx[g]->stream));
+      HH_MHIP_DRAIN(mg, hipSetDevice(mg->devices[g]));
+      HH_MHIP_DRAIN(mg, hipMemcpyAsync(mg->host + (size_t)g * n_acc, mg->acc[g], n_acc * sizeof(double),
+                                       hipMemcpyDeviceToHost, mg->ctx[g]->stream));
     }
   }
   // 3. wait for every device (the caller's buffers are free again after this), then the ordered sum
   for (int g = 0; g < mg->n; ++g) {
-    HH_MHIP(mg, hipSetDevice(mg->devices[g]));
-    HH_MHIP(mg, hipStreamSynchronize(mg->ctx[g]->stream));
+    HH_MHIP_DRAIN(mg, hipSetDevice(mg->devices[g]));
+    HH_MHIP_DRAIN(mg, hipStreamSynchronize(mg->ctx[g]->stream));
   }
   if (!reduced) {
     for (int g = 1; g < mg->n; ++g)  // fixed order g = 0 … G-1: deterministic for a given sharding
@@ -262,8 +490,14 @@ int hh_mgpu_create(hh_mgpu** out, const int* device_ids, int n_devices, int flag
   mg->acc_cap.assign(n_devices, 0);
   mg->xchg.assign(n_devices, nullptr);
   mg->xchg_cap.assign(n_devices, 0);
+  mg->rcs.assign(n_devices, 0);
+  mg->derr.resize(n_devices);
+  mg->enq_us.assign(n_devices, 0.0);
+  mg->pre.assign(n_devices, nullptr);
+  mg->fence.assign(n_devices, nullptr);
   for (int g = 0; g < n_devices; ++g) {
-    const int rc = hh_ctx_create(&mg->ctx[g], device_ids[g]);
+    int rc = hh_ctx_create(&mg->ctx[g], device_ids[g]);
+    if (!rc && hipEventCreateWithFlags(&mg->pre[g], hipEventDisableTiming) != hipSuccess) rc = HH_ERR_HIP;
     if (rc) {
       hh_mgpu_destroy(mg);
       return rc;
@@ -297,6 +531,7 @@ int hh_mgpu_create(hh_mgpu** out, const int* device_ids, int n_devices, int flag
 
 void hh_mgpu_destroy(hh_mgpu* mg) {
   if (!mg) return;
+  stop_workers(mg);
   for (int g = 0; g < mg->n; ++g) {
     if (!mg->ctx[g]) continue;
     (void)hipSetDevice(mg->devices[g]);
@@ -304,7 +539,12 @@ void hh_mgpu_destroy(hh_mgpu* mg) {
   }
   for (rccl_comm_t c : mg->comms)
     if (c) (void)rccl().CommDestroy(c);
+  for (const auto& r : mg->retired) {  // a retired stream is destroyed only once it is known to have drained
+    (void)hipSetDevice(r.device);
+    if (hipStreamQuery(r.s) == hipSuccess) (void)hipStreamDestroy(r.s);
+  }
   for (int g = 0; g < mg->n; ++g) {
+    if (mg->pre[g]) (void)hipEventDestroy(mg->pre[g]);
     if (!mg->ctx[g]) continue;  // creation stopped before this device: nothing of it exists
     (void)hipSetDevice(mg->devices[g]);
     if (mg->acc[g]) (void)hipFree(mg->acc[g]);
@@ -320,6 +560,30 @@ const char* hh_mgpu_last_error(const hh_mgpu* mg) { return mg ? mg->err : "hedge
 int hh_mgpu_n_devices(const hh_mgpu* mg) { return mg ? mg->n : 0; }
 int hh_mgpu_reduce_mode(const hh_mgpu* mg) { return mg ? mg->mode : HH_MGPU_REDUCE_HOST; }
 hh_ctx* hh_mgpu_ctx(hh_mgpu* mg, int i) { return (mg && i >= 0 && i < mg->n) ? mg->ctx[i] : nullptr; }
+
+int hh_mgpu_set_option(hh_mgpu* mg, int32_t option, int64_t value) {
+  if (!mg) return HH_ERR_INVALID;
+  std::lock_guard<std::mutex> lock__(mg->mu);
+  switch (option) {
+    case HH_MGPU_OPT_ENQUEUE:
+      if (value != HH_MGPU_ENQUEUE_SERIAL && value != HH_MGPU_ENQUEUE_THREADS)
+        return mfail(mg, HH_ERR_INVALID, "HH_MGPU_OPT_ENQUEUE: 0 (one shard after the other) or 1 (a thread per device)");
+      if (value == HH_MGPU_ENQUEUE_SERIAL) stop_workers(mg);
+      mg->enqueue = (int)value;
+      return HH_OK;
+    default:
+      return mfail(mg, HH_ERR_INVALID, "unknown option %d", option);
+  }
+}
+
+int hh_mgpu_enqueue_stats(hh_mgpu* mg, double* shard_us, double* phase_us) {
+  if (!mg) return HH_ERR_INVALID;
+  std::lock_guard<std::mutex> lock__(mg->mu);
+  if (shard_us)
+    for (int g = 0; g < mg->n; ++g) shard_us[g] = mg->enq_us[g];
+  if (phase_us) *phase_us = mg->enq_phase_us;
+  return HH_OK;
+}
 
 int hh_mgpu_solve_shards(hh_mgpu* mg, const hh_model* m, const hh_config* cfgs, hh_result* out,
                          double* const* terminals) {
@@ -342,8 +606,11 @@ int hh_mgpu_solve_shards(hh_mgpu* mg, const hh_model* m, const hh_config* cfgs, 
   return HH_OK;
 }
 
-// Shards of a whole-ensemble config with host buffers; BK REPLAY draws [V_T | u | Z] are three slices
-// per shard, staged into the shard ctx's own replay buffer.
+// Shards of a whole-ensemble config with host buffers.  Host slices go to hh_mc_accumulate as they are
+// (it stages them on the shard's stream, from the shard's thread) unless the kernels' operand rules say
+// otherwise: BK REPLAY draws [V_T | u | Z] are three slices per shard, and a slice that does not start on
+// a 16-byte boundary (one double per trajectory — the exact law, lognormal Euler with one step — or an
+// odd row length, cut at an odd trajectory) is staged here into the shard ctx's own buffer.
 static int cut_config(hh_mgpu* mg, const hh_config* cfg, bool want_terminal, std::vector<hh_config>& cs,
                       std::vector<double*>& term_dev, std::vector<uint64_t>& starts) {
   if (cfg->n_paths == 0) return mfail(mg, HH_ERR_INVALID, "n_paths must be >= 1");
@@ -355,6 +622,8 @@ static int cut_config(hh_mgpu* mg, const hh_config* cfg, bool want_terminal, std
   const bool bk = cfg->strategy == HH_BROADIE_KAYA;
   const bool tile = replay && euler && cfg->replay_layout == HH_REPLAY_TILE_MAJOR;
   if (replay && !cfg->replay) return mfail(mg, HH_ERR_INVALID, "REPLAY needs a replay buffer");
+  if (replay && ((uintptr_t)cfg->replay & 15u) != 0)
+    return mfail(mg, HH_ERR_INVALID, "replay buffer must be 16-byte aligned");
   if (!replay && !cfg->seeds) return mfail(mg, HH_ERR_INVALID, "GENERATE needs seeds");
   const uint64_t N = cfg->n_paths;
   const size_t per_path = euler ? (size_t)cfg->n_steps * ncomp(cfg->dynamics) : 1;
@@ -391,6 +660,18 @@ static int cut_config(hh_mgpu* mg, const hh_config* cfg, bool want_terminal, std
                                    c.n_paths * sizeof(double), hipMemcpyHostToDevice, x->stream));
       c.replay = x->replay;
       c.replay_on_device = 1;
+    } else if (replay && ((uintptr_t)c.replay & 15u) != 0) {
+      // path-major rows go where hh_mc_accumulate would stage them itself (replay_src: both the direct
+      // kernel and the repack read from there); one normal per trajectory of the exact law likewise
+      const bool pm = cfg->replay_layout == HH_REPLAY_PATH_MAJOR;
+      const size_t n_el = (size_t)c.n_paths * per_path;
+      int rc = pm ? ensure(x, x->replay_src, x->replay_src_cap, n_el)
+                  : ensure(x, x->replay, x->replay_cap, (size_t)hh::tiles_for(c.n_paths) * hh::kTile);
+      if (rc) return mfail(mg, rc, "%s", x->err);
+      double* dst = pm ? x->replay_src : x->replay;
+      HH_MHIP(mg, hipMemcpyAsync(dst, c.replay, n_el * sizeof(double), hipMemcpyHostToDevice, x->stream));
+      c.replay = dst;
+      c.replay_on_device = 1;
     }
     if (want_terminal) {
       int rc = ensure(x, x->terminal, x->terminal_cap, (size_t)c.n_paths * (c.antithetic ? 2 : 1));
@@ -411,10 +692,7 @@ int hh_mgpu_solve(hh_mgpu* mg, const hh_model* m, const hh_config* cfg, hh_resul
   std::vector<double*> term_dev;
   std::vector<uint64_t> starts;
   int rc = cut_config(mg, cfg, terminal != nullptr, cs, term_dev, starts);
-  if (rc) {
-    sync_all(mg);
-    return rc;
-  }
+  if (rc) return drain(mg, rc);
   std::memset(out, 0, sizeof(*out));
   double kernel_ms = 0.0;
   rc = run_shards(mg, m, cs.data(), nullptr, terminal ? term_dev.data() : nullptr, &kernel_ms);
@@ -423,16 +701,16 @@ int hh_mgpu_solve(hh_mgpu* mg, const hh_model* m, const hh_config* cfg, hh_resul
     for (int g = 0; g < mg->n; ++g) {
       const uint64_t n = cs[g].n_paths;
       if (!n) continue;
-      HH_MHIP(mg, hipSetDevice(mg->devices[g]));
-      HH_MHIP(mg, hipMemcpyAsync(terminal + starts[g], term_dev[g], n * sizeof(double), hipMemcpyDeviceToHost,
-                                 mg->ctx[g]->stream));
+      HH_MHIP_DRAIN(mg, hipSetDevice(mg->devices[g]));
+      HH_MHIP_DRAIN(mg, hipMemcpyAsync(terminal + starts[g], term_dev[g], n * sizeof(double), hipMemcpyDeviceToHost,
+                                       mg->ctx[g]->stream));
       if (cfg->antithetic)
-        HH_MHIP(mg, hipMemcpyAsync(terminal + cfg->n_paths + starts[g], term_dev[g] + n, n * sizeof(double),
-                                   hipMemcpyDeviceToHost, mg->ctx[g]->stream));
+        HH_MHIP_DRAIN(mg, hipMemcpyAsync(terminal + cfg->n_paths + starts[g], term_dev[g] + n, n * sizeof(double),
+                                         hipMemcpyDeviceToHost, mg->ctx[g]->stream));
     }
     for (int g = 0; g < mg->n; ++g) {
-      HH_MHIP(mg, hipSetDevice(mg->devices[g]));
-      HH_MHIP(mg, hipStreamSynchronize(mg->ctx[g]->stream));
+      HH_MHIP_DRAIN(mg, hipSetDevice(mg->devices[g]));
+      HH_MHIP_DRAIN(mg, hipStreamSynchronize(mg->ctx[g]->stream));
     }
   }
   rc = hh_mc_finalize(m, cfg, mg->host, out);
@@ -453,10 +731,7 @@ int hh_mgpu_solve_basket(hh_mgpu* mg, const hh_model* m, const hh_config* cfg, c
   std::vector<double*> term_dev;
   std::vector<uint64_t> starts;
   int rc = cut_config(mg, cfg, false, cs, term_dev, starts);
-  if (rc) {
-    sync_all(mg);
-    return rc;
-  }
+  if (rc) return drain(mg, rc);
   const Basket b{strikes, cps, n_payoffs};
   double kernel_ms = 0.0;
   rc = run_shards(mg, m, cs.data(), &b, nullptr, &kernel_ms);
@@ -472,60 +747,51 @@ int hh_mgpu_solve_basket(hh_mgpu* mg, const hh_model* m, const hh_config* cfg, c
   return HH_OK;
 }
 
-// SUM all-reduce of the first n doubles of every device's exchange vector, in place
+// SUM all-reduce of the first n doubles of every device's exchange vector, in place.  HH_ERR_RCCL: the
+// collective failed, rccl_give_up has run (nothing may be synchronised; the vectors are lost).
 static int lsm_exchange(hh_mgpu* mg, size_t n) {
   if (mg->n == 1) return HH_OK;
   if (mg->mode == HH_MGPU_REDUCE_RCCL) {
-    RcclApi& api = rccl();
-    int e = api.GroupStart();
-    for (int g = 0; g < mg->n && e == kNcclSuccess; ++g)
-      e = api.AllReduce(mg->xchg[g], mg->xchg[g], n, kNcclDouble, kNcclSum, mg->comms[g], mg->ctx[g]->stream);
-    const int e2 = api.GroupEnd();
-    if (e == kNcclSuccess) e = e2;
-    if (e != kNcclSuccess) return mfail(mg, HH_ERR_RCCL, "ncclAllReduce failed inside the LSM induction: %s", api.GetErrorString(e));
-    return HH_OK;
+    for (int g = 0; g < mg->n; ++g) {  // what a retired stream's successor would wait for
+      HH_MHIP_DRAIN(mg, hipSetDevice(mg->devices[g]));
+      HH_MHIP_DRAIN(mg, hipEventRecord(mg->pre[g], mg->ctx[g]->stream));
+      mg->fence[g] = mg->pre[g];
+    }
+    const int e = all_reduce_group(mg, mg->xchg.data(), mg->xchg.data(), n);
+    if (e == kNcclSuccess) return HH_OK;
+    mfail(mg, HH_ERR_RCCL, "ncclAllReduce failed inside the LSM induction: %s — communicators aborted",
+          rccl().GetErrorString(e));
+    rccl_give_up(mg);
+    return HH_ERR_RCCL;
   }
   // host ordered sum: local vectors back, added in the order g = 0 … G-1, the total out again
   int rc = ensure_acc(mg, n > (size_t)HH_ACC_LEN ? n : (size_t)HH_ACC_LEN);
-  if (rc) return rc;
+  if (rc) return drain(mg, rc);
   for (int g = 0; g < mg->n; ++g) {
-    HH_MHIP(mg, hipSetDevice(mg->devices[g]));
-    HH_MHIP(mg, hipMemcpyAsync(mg->host + (size_t)g * n, mg->xchg[g], n * sizeof(double), hipMemcpyDeviceToHost,
-                               mg->ctx[g]->stream));
+    HH_MHIP_DRAIN(mg, hipSetDevice(mg->devices[g]));
+    HH_MHIP_DRAIN(mg, hipMemcpyAsync(mg->host + (size_t)g * n, mg->xchg[g], n * sizeof(double), hipMemcpyDeviceToHost,
+                                     mg->ctx[g]->stream));
   }
   for (int g = 0; g < mg->n; ++g) {
-    HH_MHIP(mg, hipSetDevice(mg->devices[g]));
-    HH_MHIP(mg, hipStreamSynchronize(mg->ctx[g]->stream));
+    HH_MHIP_DRAIN(mg, hipSetDevice(mg->devices[g]));
+    HH_MHIP_DRAIN(mg, hipStreamSynchronize(mg->ctx[g]->stream));
   }
   for (int g = 1; g < mg->n; ++g)
     for (size_t i = 0; i < n; ++i) mg->host[i] += mg->host[(size_t)g * n + i];
   for (int g = 0; g < mg->n; ++g) {
-    HH_MHIP(mg, hipSetDevice(mg->devices[g]));
-    HH_MHIP(mg, hipMemcpyAsync(mg->xchg[g], mg->host, n * sizeof(double), hipMemcpyHostToDevice, mg->ctx[g]->stream));
+    HH_MHIP_DRAIN(mg, hipSetDevice(mg->devices[g]));
+    HH_MHIP_DRAIN(mg, hipMemcpyAsync(mg->xchg[g], mg->host, n * sizeof(double), hipMemcpyHostToDevice, mg->ctx[g]->stream));
   }
   for (int g = 0; g < mg->n; ++g) {  // mg->host is reused by the next exchange
-    HH_MHIP(mg, hipSetDevice(mg->devices[g]));
-    HH_MHIP(mg, hipStreamSynchronize(mg->ctx[g]->stream));
+    HH_MHIP_DRAIN(mg, hipSetDevice(mg->devices[g]));
+    HH_MHIP_DRAIN(mg, hipStreamSynchronize(mg->ctx[g]->stream));
   }
   return HH_OK;
 }
 
-int hh_mgpu_lsm_solve(hh_mgpu* mg, const hh_model* m, const hh_config* cfg, int32_t degree, double step_discount,
-                      hh_lsm_result* out, int32_t* stop_time, double* stop_value) {
-  if (!mg) return HH_ERR_INVALID;
-  std::lock_guard<std::mutex> lock__(mg->mu);
-  if (!m || !cfg || !out) return mfail(mg, HH_ERR_INVALID, "hh_mgpu_lsm_solve: NULL argument");
-  if (cfg->seeds_on_device || !cfg->seeds || cfg->noise_mode != HH_NOISE_GENERATE)
-    return mfail(mg, HH_ERR_INVALID, "hh_mgpu_lsm_solve: GENERATE noise with host seeds");
-  if (cfg->n_paths < (uint64_t)mg->n) return mfail(mg, HH_ERR_INVALID, "every device needs at least one trajectory");
-  if (cfg->seeds_len && cfg->seeds_len < cfg->n_paths)
-    return mfail(mg, HH_ERR_INVALID, "Number of seeds (%llu) must be >= number of trajectories (%llu)",
-                 (unsigned long long)cfg->seeds_len, (unsigned long long)cfg->n_paths);
-  if (degree < 1 || degree > 8 || cfg->n_steps == 0) return mfail(mg, HH_ERR_INVALID, "LSM: 1 <= degree <= 8, n_steps >= 1");
-  if (mg->n == 1) {  // nothing to exchange: the fused induction (one persistent launch where it fits); same bits
-    const int rc1 = hh_lsm_solve(mg->ctx[0], m, cfg, degree, step_discount, out, stop_time, stop_value, nullptr);
-    return rc1 ? mfail(mg, rc1, "device %d: %s", mg->devices[0], hh_last_error(mg->ctx[0])) : HH_OK;
-  }
+// One pass of the sharded induction in the context's current reduce mode.  HH_ERR_RCCL: see lsm_exchange.
+static int lsm_attempt(hh_mgpu* mg, const hh_model* m, const hh_config* cfg, int32_t degree, double step_discount,
+                       hh_lsm_result* out, int32_t* stop_time, double* stop_value) {
   const auto t0 = std::chrono::steady_clock::now();
   const uint64_t N = cfg->n_paths;
   const uint32_t steps = cfg->n_steps;
@@ -534,11 +800,6 @@ int hh_mgpu_lsm_solve(hh_mgpu* mg, const hh_model* m, const hh_config* cfg, int3
   if (n_x < (size_t)HH_ACC_LEN) n_x = HH_ACC_LEN;  // the same vector carries the final accumulator
   std::vector<hh_config> cs(mg->n, *cfg);
   std::vector<uint64_t> starts(mg->n, 0);
-  auto fail_shard = [&](int g, int rc) {
-    mfail(mg, rc, "shard %d (device %d): %s", g, mg->devices[g], hh_last_error(mg->ctx[g]));
-    sync_all(mg);
-    return rc;
-  };
   for (int g = 0; g < mg->n; ++g) {
     uint64_t a, b;
     shard_range(N, mg->n, g, false, &a, &b);
@@ -559,70 +820,99 @@ int hh_mgpu_lsm_solve(hh_mgpu* mg, const hh_model* m, const hh_config* cfg, int3
   }
   int rc = ensure_acc(mg, (size_t)HH_ACC_LEN);
   if (rc) return rc;
-  for (int g = 0; g < mg->n; ++g) {
-    HH_MHIP(mg, hipSetDevice(mg->devices[g]));
-    HH_MHIP(mg, hipEventRecord(mg->ctx[g]->ev0, mg->ctx[g]->stream));
-    if ((rc = hh_lsm_shard_begin(mg->ctx[g], m, &cs[g], degree, step_discount, mg->xchg[g]))) return fail_shard(g, rc);
-  }
+  auto shard_call = [&](int g, int r) -> int {  // a shard entry point's status, with its text
+    if (r) snprintf(mg->derr[g].data(), mg->derr[g].size(), "%s", hh_last_error(mg->ctx[g]));
+    return r;
+  };
+  rc = for_each_device(mg, [&](int g) -> int {
+    HH_DHIP(mg, g, hipSetDevice(mg->devices[g]));
+    HH_DHIP(mg, g, hipEventRecord(mg->ctx[g]->ev0, mg->ctx[g]->stream));
+    return shard_call(g, hh_lsm_shard_begin(mg->ctx[g], m, &cs[g], degree, step_discount, mg->xchg[g]));
+  });
+  if (rc) return drain(mg, rc);
   auto phase = [&](int32_t ph, uint32_t t, size_t n_in) -> int {
     int e = lsm_exchange(mg, n_in);
-    if (e) {
-      sync_all(mg);
-      return e;
-    }
-    for (int g = 0; g < mg->n; ++g)
-      if ((e = hh_lsm_shard_phase(mg->ctx[g], ph, t, mg->xchg[g], mg->xchg[g]))) return fail_shard(g, e);
-    return HH_OK;
+    if (e) return e;  // already drained, or (HH_ERR_RCCL) given up without a wait
+    e = for_each_device(mg, [&](int g) -> int {
+      return shard_call(g, hh_lsm_shard_phase(mg->ctx[g], ph, t, mg->xchg[g], mg->xchg[g]));
+    });
+    return e ? drain(mg, e) : HH_OK;
   };
   if ((rc = phase(HH_LSM_PHASE_POW, 0, rows * 3))) return rc;
   if ((rc = phase(HH_LSM_PHASE_INIT, 0, rows * nv))) return rc;
   for (uint32_t t = steps - 1; t >= 1; --t)  // for i = nsteps:-1:2, t = i-1 (:112-113)
     if ((rc = phase(HH_LSM_PHASE_STEP, t, nb))) return rc;
   // the shards' Σ, Σ² of the discounted stopped values; their stopping_info into the caller's order
-  uint32_t regressed = 0, skipped = 0;
-  std::vector<int32_t> tau;
-  std::vector<double> val;
+  const int halves = cfg->antithetic ? 2 : 1;
+  std::vector<std::vector<int32_t>> tau(mg->n);
+  std::vector<std::vector<double>> val(mg->n);
+  std::vector<uint32_t> rg(mg->n, 0), sk(mg->n, 0);
+  rc = for_each_device(mg, [&](int g) -> int {
+    const uint64_t ntot = cs[g].n_paths * (uint64_t)halves;
+    if (stop_time) tau[g].resize(ntot);
+    if (stop_value) val[g].resize(ntot);
+    HH_DHIP(mg, g, hipSetDevice(mg->devices[g]));
+    HH_DHIP(mg, g, hipEventRecord(mg->ctx[g]->ev1, mg->ctx[g]->stream));
+    return shard_call(g, hh_lsm_shard_finish(mg->ctx[g], mg->xchg[g], stop_time ? tau[g].data() : nullptr,
+                                             stop_value ? val[g].data() : nullptr, nullptr, &rg[g], &sk[g]));
+  });
+  if (rc) return drain(mg, rc);
   for (int g = 0; g < mg->n; ++g) {
-    const uint64_t n = cs[g].n_paths, ntot = n * (cfg->antithetic ? 2 : 1);
-    if (stop_time) tau.resize(ntot);
-    if (stop_value) val.resize(ntot);
-    HH_MHIP(mg, hipSetDevice(mg->devices[g]));
-    HH_MHIP(mg, hipEventRecord(mg->ctx[g]->ev1, mg->ctx[g]->stream));
-    uint32_t rg = 0, sk = 0;
-    if ((rc = hh_lsm_shard_finish(mg->ctx[g], mg->xchg[g], stop_time ? tau.data() : nullptr,
-                                  stop_value ? val.data() : nullptr, nullptr, &rg, &sk)))
-      return fail_shard(g, rc);
-    if (g == 0) {
-      regressed = rg;
-      skipped = sk;
-    }
-    for (int h = 0; h < (cfg->antithetic ? 2 : 1); ++h) {
-      if (stop_time) std::memcpy(stop_time + (size_t)h * N + starts[g], tau.data() + (size_t)h * n, n * sizeof(int32_t));
-      if (stop_value) std::memcpy(stop_value + (size_t)h * N + starts[g], val.data() + (size_t)h * n, n * sizeof(double));
+    const uint64_t n = cs[g].n_paths;
+    for (int h = 0; h < halves; ++h) {
+      if (stop_time) std::memcpy(stop_time + (size_t)h * N + starts[g], tau[g].data() + (size_t)h * n, n * sizeof(int32_t));
+      if (stop_value) std::memcpy(stop_value + (size_t)h * N + starts[g], val[g].data() + (size_t)h * n, n * sizeof(double));
     }
   }
-  if ((rc = lsm_exchange(mg, (size_t)HH_ACC_LEN))) {
-    sync_all(mg);
-    return rc;
-  }
-  HH_MHIP(mg, hipSetDevice(mg->devices[0]));
-  HH_MHIP(mg, hipMemcpyAsync(mg->host, mg->xchg[0], HH_ACC_LEN * sizeof(double), hipMemcpyDeviceToHost,
-                             mg->ctx[0]->stream));
+  if ((rc = lsm_exchange(mg, (size_t)HH_ACC_LEN))) return rc;
+  HH_MHIP_DRAIN(mg, hipSetDevice(mg->devices[0]));
+  HH_MHIP_DRAIN(mg, hipMemcpyAsync(mg->host, mg->xchg[0], HH_ACC_LEN * sizeof(double), hipMemcpyDeviceToHost,
+                                   mg->ctx[0]->stream));
   double worst = 0.0;
   for (int g = 0; g < mg->n; ++g) {
-    HH_MHIP(mg, hipSetDevice(mg->devices[g]));
-    HH_MHIP(mg, hipStreamSynchronize(mg->ctx[g]->stream));
+    HH_MHIP_DRAIN(mg, hipSetDevice(mg->devices[g]));
+    HH_MHIP_DRAIN(mg, hipStreamSynchronize(mg->ctx[g]->stream));
     float ms = 0.f;
     HH_MHIP(mg, hipEventElapsedTime(&ms, mg->ctx[g]->ev0, mg->ctx[g]->ev1));
     if (ms > worst) worst = ms;
   }
   if ((rc = hh_lsm_finalize(mg->host, out))) return mfail(mg, rc, "finalize failed");
-  out->rows_regressed = regressed;
-  out->rows_skipped = skipped;
+  out->rows_regressed = rg[0];
+  out->rows_skipped = sk[0];
   out->form = HH_LSM_FORM_PER_DATE;
   out->kernel_ms = worst;
   out->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   return HH_OK;
+}
+
+int hh_mgpu_lsm_solve(hh_mgpu* mg, const hh_model* m, const hh_config* cfg, int32_t degree, double step_discount,
+                      hh_lsm_result* out, int32_t* stop_time, double* stop_value) {
+  if (!mg) return HH_ERR_INVALID;
+  std::lock_guard<std::mutex> lock__(mg->mu);
+  if (!m || !cfg || !out) return mfail(mg, HH_ERR_INVALID, "hh_mgpu_lsm_solve: NULL argument");
+  if (cfg->seeds_on_device || !cfg->seeds || cfg->noise_mode != HH_NOISE_GENERATE)
+    return mfail(mg, HH_ERR_INVALID, "hh_mgpu_lsm_solve: GENERATE noise with host seeds");
+  if (cfg->n_paths < (uint64_t)mg->n) return mfail(mg, HH_ERR_INVALID, "every device needs at least one trajectory");
+  if (cfg->seeds_len && cfg->seeds_len < cfg->n_paths)
+    return mfail(mg, HH_ERR_INVALID, "Number of seeds (%llu) must be >= number of trajectories (%llu)",
+                 (unsigned long long)cfg->seeds_len, (unsigned long long)cfg->n_paths);
+  if (degree < 1 || degree > 8 || cfg->n_steps == 0) return mfail(mg, HH_ERR_INVALID, "LSM: 1 <= degree <= 8, n_steps >= 1");
+  if (mg->n == 1) {  // nothing to exchange: the fused induction (one persistent launch where it fits); same bits
+    const int rc1 = hh_lsm_solve(mg->ctx[0], m, cfg, degree, step_discount, out, stop_time, stop_value, nullptr);
+    return rc1 ? mfail(mg, rc1, "device %d: %s", mg->devices[0], hh_last_error(mg->ctx[0])) : HH_OK;
+  }
+  if (mg->flags == HH_MGPU_RCCL && mg->rccl_lost)
+    return mfail(mg, HH_ERR_RCCL, "the RCCL communicators of this context were aborted after a failed collective "
+                                  "(HH_MGPU_RCCL does not fall back): create a new one");
+  const bool was_rccl = mg->mode == HH_MGPU_REDUCE_RCCL;
+  int rc = lsm_attempt(mg, m, cfg, degree, step_discount, out, stop_time, stop_value);
+  if (rc == HH_ERR_RCCL && was_rccl) {
+    // the exchange is in place, so the local sums went with the failed collective: nothing to finish
+    wait_fences(mg);  // the kernels in front of the collective have read the caller's seeds
+    if (mg->flags == HH_MGPU_AUTO)  // … the whole induction again, on the fresh streams, summed on the host
+      rc = lsm_attempt(mg, m, cfg, degree, step_discount, out, stop_time, stop_value);
+  }
+  return rc;
 }
 
 }  // extern "C"

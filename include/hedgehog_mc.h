@@ -18,8 +18,8 @@
  *     whatever it allocates inside hh_ctx and releases it in hh_ctx_destroy().
  *   - a hh_ctx is bound to ONE device and ONE HIP stream; its entry points serialise on an
  *     internal mutex, so sharing one between threads is safe but gains nothing — use one ctx per
- *     host thread / per GPU.  Multi-GPU = either ONE call on a hh_mgpu (one host thread driving
- *     one ctx per device, the all-reduce inside the library: hh_mgpu_solve), or one process (or
+ *     host thread / per GPU.  Multi-GPU = either ONE call on a hh_mgpu (one ctx per device, the
+ *     shards enqueued concurrently and the all-reduce inside the library: hh_mgpu_solve), or one process (or
  *     thread) per GPU, each with its own ctx, exchanging only the HH_ACC_LEN-double accumulator
  *     vector (hh_mc_accumulate + the caller's all-reduce + hh_mc_finalize).
  *   - DEVICE buffers the caller passes (seeds / replay / terminal `_on_device`, grids) are read and
@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define HH_ABI_VERSION 3
+#define HH_ABI_VERSION 4
 #define HH_MAX_PARTIALS 8   /* max. number of dual-number partials carried through one solve    */
 #define HH_TILE_PATHS 256   /* paths per tile of the tile-major REPLAY layout (see below)        */
 #define HH_ACC_LEN 16       /* doubles in the accumulator vector exchanged between GPUs          */
@@ -244,8 +244,7 @@ int hh_bk_decisions(hh_ctx* ctx, uint64_t n_paths, uint32_t* decisions, uint32_t
  * hh_mgpu_solve cuts the ensemble into contiguous ranges [g·per, min(N, (g+1)·per)), per = ⌈N/G⌉
  * (rounded up to a multiple of HH_TILE_PATHS for tile-major REPLAY data, whose tiles cannot be cut),
  * slices seeds / increments / terminal samples by the same ranges (exact laws: path_offset), enqueues
- * every shard's kernels back to back without waiting, and combines the HH_ACC_LEN-double accumulator
- * vectors
+ * every shard's kernels without waiting, and combines the HH_ACC_LEN-double accumulator vectors
  *   HH_MGPU_REDUCE_RCCL  by ONE ncclAllReduce(ncclSum, ncclDouble) inside ncclGroupStart/End on the
  *                        shards' own streams (communicators from ncclCommInitAll at creation; RCCL is
  *                        bound at run time — librccl.so.1, or the path in $HEDGEHOG_MC_RCCL — so the
@@ -259,13 +258,31 @@ int hh_bk_decisions(hh_ctx* ctx, uint64_t n_paths, uint32_t* decisions, uint32_t
  *   flags of hh_mgpu_create: HH_MGPU_AUTO  RCCL when n_devices > 1 and it initialises, else host sum;
  *                            HH_MGPU_HOST_SUM  never touch RCCL;
  *                            HH_MGPU_RCCL  RCCL or fail (HH_ERR_RCCL), used even for one device.
+ * Enqueueing: the host-side cost of one shard (checks, events, launches) is tens of microseconds, so
+ * the devices are served CONCURRENTLY — device 0 by the calling thread, every other device by a
+ * library-owned thread bound to it (created on first use, joined in hh_mgpu_destroy; it polls for
+ * ~150 µs after a job and sleeps otherwise, and never calls back into the host language).
+ * hh_mgpu_set_option(HH_MGPU_OPT_ENQUEUE, HH_MGPU_ENQUEUE_SERIAL) enqueues one shard after the other
+ * from the calling thread instead; results are identical.  hh_mgpu_enqueue_stats reports what the last
+ * solve's enqueue phase cost on the host: per shard (measured in the thread that enqueued it) and as a
+ * whole (wall time until every shard was enqueued).
+ * A collective that FAILS in the call (ncclAllReduce refusing rank g after ranks < g were enqueued) may
+ * leave kernels on the earlier ranks' streams that wait for peers which never come.  The library never
+ * synchronises such a stream: it aborts the communicators (ncclCommAbort), retires every shard stream
+ * for a fresh one that continues behind the shard's last kernel, and — HH_MGPU_AUTO — completes this
+ * and every later solve with the host's ordered sum (hh_mgpu_reduce_mode() then says HOST); with
+ * HH_MGPU_RCCL the call returns HH_ERR_RCCL once the caller's buffers are no longer read, and so does
+ * every later call on that context.
  * hh_mgpu_solve takes HOST buffers in cfg (seeds, replay) and for `terminal` (n_paths doubles, then the
- * n_paths mirrored samples when antithetic — the layout of hh_mc_solve); *_on_device must be 0.
+ * n_paths mirrored samples when antithetic — the layout of hh_mc_solve); *_on_device must be 0.  The
+ * REPLAY buffer as a whole must be 16-byte aligned, as for hh_mc_solve; a shard's slice need not be
+ * (odd row lengths cut at odd trajectories are staged by the library).
  * hh_mgpu_solve_shards takes one hh_config per device exactly as hh_mc_accumulate would on that device
  * (device-resident seeds / increments allowed; n_paths = 0 leaves a device idle) and optional per-shard
  * terminal pointers — for callers that keep their inputs in HBM.  hh_mgpu_ctx(mg, i) is the i-th
  * device's context (hh_device_malloc, hh_wiener_fill, hh_ctx_enable_timing … on that device); it stays
  * owned by mg.  out->kernel_ms is the LONGEST shard's HIP-event time, total_ms the host wall time.
+ * After any error return nothing the call enqueued is still running.
  */
 typedef struct hh_mgpu hh_mgpu;
 enum hh_mgpu_flags { HH_MGPU_AUTO = 0, HH_MGPU_HOST_SUM = 1, HH_MGPU_RCCL = 2 };
@@ -275,6 +292,11 @@ void hh_mgpu_destroy(hh_mgpu* mg);
 const char* hh_mgpu_last_error(const hh_mgpu* mg);
 int hh_mgpu_n_devices(const hh_mgpu* mg);
 int hh_mgpu_reduce_mode(const hh_mgpu* mg);       /* enum hh_mgpu_reduce in use                    */
+enum hh_mgpu_option { HH_MGPU_OPT_ENQUEUE = 1 };
+enum hh_mgpu_enqueue { HH_MGPU_ENQUEUE_SERIAL = 0, HH_MGPU_ENQUEUE_THREADS = 1 /* default */ };
+int hh_mgpu_set_option(hh_mgpu* mg, int32_t option, int64_t value);
+/* host microseconds of the last solve's enqueue phase: shard_us[n_devices] (nullable), *phase_us (nullable) */
+int hh_mgpu_enqueue_stats(hh_mgpu* mg, double* shard_us, double* phase_us);
 hh_ctx* hh_mgpu_ctx(hh_mgpu* mg, int i);          /* NULL when i is out of range                   */
 /* shard g of an ensemble of n_paths over n_devices, as hh_mgpu_solve cuts it (tile_aligned = 1 for
  * tile-major REPLAY increments) */
@@ -419,8 +441,10 @@ int hh_lsm_debug_read(hh_ctx* ctx, uint64_t n_paths_total, uint32_t n_steps, int
  * all-reduced INSIDE the library between consecutive phases (2 + (n_steps − 1) + 1 exchanges of at most
  * (n_steps + 1)·(2·degree + 1) doubles: ncclAllReduce in place on the shards' streams, or — host-sum
  * contexts — copied back, added in the order g = 0 … G−1 and handed out again).  Unlike the European
- * solve this path has real exchange steps, so an RCCL failure in the middle is an error (HH_ERR_RCCL),
- * not a fall-back.  cfg: the whole ensemble with HOST seeds, as for hh_lsm_solve; every device must get
+ * solve this path exchanges IN PLACE between its phases, so the local sums go with a collective that
+ * fails in the middle: the communicators are aborted and the streams retired as described above, and
+ * the whole induction is run again with the host's ordered sum (HH_MGPU_AUTO) or the call returns
+ * HH_ERR_RCCL (HH_MGPU_RCCL).  cfg: the whole ensemble with HOST seeds, as for hh_lsm_solve; every device must get
  * at least one trajectory.  stop_time / stop_value (nullable, host): the reference's stopping_info in
  * the whole-ensemble order of hh_lsm_solve (n_paths entries, then the n_paths mirrored ones).  Same
  * regression sums up to their summation order: identical stopping decisions except where a payoff

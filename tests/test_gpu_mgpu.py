@@ -111,6 +111,67 @@ def test_replay_buffers_are_sliced_by_the_shard_ranges(hhlib, oracle, layout):
     mg.close()
 
 
+@pytest.mark.parametrize("devices", [[0, 0], [0, 0, 0]])
+def test_replay_slices_that_do_not_start_on_a_16_byte_boundary(hhlib, devices):
+    """One double per trajectory (the exact law; lognormal Euler with an odd row length) cut at an odd
+    trajectory: the shard's slice starts 8 bytes off a 16-byte boundary, which the kernels' operand
+    rules refuse — the library stages it (the single solve accepts the whole buffer)."""
+    n = 10_001  # 2 devices: a = 5001; 3 devices: a = 3334, 6668
+    rng = np.random.default_rng(11)
+    m = o.make_model(sigma=0.2)
+    z = rng.standard_normal(n)
+    for layout in (_ffi.HH_REPLAY_TILE_MAJOR, _ffi.HH_REPLAY_PATH_MAJOR):
+        c = o.make_config(GBM, EXACT, n, 1, antithetic=1, noise_mode=REP, replay=z, replay_layout=layout)
+        r1, t1 = gpu_solve(hhlib, m, c)
+        mg = _ffi.MultiGpu(devices, _ffi.HH_MGPU_HOST_SUM)
+        t2 = np.zeros(2 * n)
+        r2 = mg.solve(m, c, t2)
+        same_result(r2, r1)
+        np.testing.assert_array_equal(t1, t2)
+        mg.close()
+    for steps in (1, 7):  # odd rows of the reference's own layout: the repack path
+        dW = rng.standard_normal((n, steps)) * np.sqrt(1.0 / steps)
+        c = o.make_config(GBM, EM, n, steps, noise_mode=REP, replay=dW.ravel(),
+                          replay_layout=_ffi.HH_REPLAY_PATH_MAJOR)
+        r1, t1 = gpu_solve(hhlib, m, c)
+        mg = _ffi.MultiGpu(devices, _ffi.HH_MGPU_HOST_SUM)
+        t2 = np.zeros(n)
+        r2 = mg.solve(m, c, t2)
+        same_result(r2, r1)
+        np.testing.assert_array_equal(t1, t2)
+        mg.close()
+    with pytest.raises(_ffi.HedgehogMCError, match="16-byte aligned"):  # the WHOLE buffer, as for hh_mc_solve
+        buf = np.zeros(n + 1)
+        c = o.make_config(GBM, EXACT, n, 1, noise_mode=REP, replay=buf[1:])
+        mg = _ffi.MultiGpu(devices, _ffi.HH_MGPU_HOST_SUM)
+        try:
+            mg.solve(m, c)
+        finally:
+            mg.close()
+
+
+@pytest.mark.parametrize("mode", [_ffi.HH_MGPU_ENQUEUE_SERIAL, _ffi.HH_MGPU_ENQUEUE_THREADS])
+def test_enqueue_modes_and_their_statistics(hhlib, mode):
+    n, steps = 30_000, 25
+    m = o.make_model(seeds=HESTON_SEEDS, n_partials=3)
+    c = o.make_config(HES, EM, n, steps, seeds=seeds_for(n, 3), n_partials=3)
+    r1, t1 = gpu_solve(hhlib, m, c)
+    mg = _ffi.MultiGpu([0, 0, 0, 0], _ffi.HH_MGPU_HOST_SUM)
+    mg.set_option(_ffi.HH_MGPU_OPT_ENQUEUE, mode)
+    for _ in range(3):  # workers found awake, then parked (the sleep), then woken again
+        t2 = np.zeros(n)
+        r2 = mg.solve(m, c, t2)
+        same_result(r2, r1, P=3)
+        np.testing.assert_array_equal(t1, t2)
+        import time
+        time.sleep(0.01)
+    per, whole = mg.enqueue_stats()
+    assert len(per) == 4 and all(0.0 < p < 1e6 for p in per) and whole >= max(per)
+    with pytest.raises(_ffi.HedgehogMCError, match="HH_MGPU_OPT_ENQUEUE"):
+        mg.set_option(_ffi.HH_MGPU_OPT_ENQUEUE, 7)
+    mg.close()
+
+
 def test_broadie_kaya_shards_and_its_replay_slices(hhlib):
     n = 3_001
     m = o.make_model()

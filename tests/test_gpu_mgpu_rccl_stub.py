@@ -1,0 +1,78 @@
+"""hh_mgpu's RCCL branch with G = 3 ranks, its AUTO-mode fall-back after a collective that fails for
+one rank, and the status HH_MGPU_RCCL returns instead — on ONE GPU, through a test-only stand-in for
+librccl (tests/c/stub_rccl.hip; see tests/rccl_stub_worker.py for the scenarios).  What the driver's
+8-GPU node runs with the real RCCL (montecarlo.jl:478-493 stays one call)."""
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+STUB_SRC = os.path.join(ROOT, "tests", "c", "stub_rccl.hip")
+STUB = os.path.join(ROOT, "tests", "c", "libstub_rccl.so")
+
+
+def build_stub():
+    if os.path.exists(STUB) and os.path.getmtime(STUB) >= os.path.getmtime(STUB_SRC):
+        return
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    subprocess.run([hipcc, "-shared", "-fPIC", "-O2", "-std=c++17", "--offload-arch=gfx950", STUB_SRC, "-o", STUB],
+                   check=True)
+
+
+@pytest.fixture(scope="module")
+def run(tmp_path_factory):
+    build_stub()
+    out = str(tmp_path_factory.mktemp("rccl_stub") / "out.json")
+    env = dict(os.environ, HEDGEHOG_MC_RCCL=STUB)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "rccl_stub_worker.py"), out], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    return json.load(open(out))
+
+
+def test_three_ranks_through_the_rccl_branch_equal_the_host_ordered_sum(run):
+    assert run["auto_mode_is_rccl"]
+    assert run["european_bit_equal"]  # Σ, Σ², three partials, every terminal sample
+    assert run["basket_bit_equal"]
+    assert run["lsm_bit_equal"] and run["lsm_heston_bit_equal"]  # price, std error, stopping times and values
+    assert run["groups"] == run["groups_expected"]  # ONE all-reduce per solve; 2 + (steps - 1) + 1 per LSM solve
+    assert run["calls"] == 3 * run["groups"]
+
+
+def test_serial_and_threaded_enqueue_agree(run):
+    assert run["serial_enqueue_bit_equal"] and run["enqueue_stats_ok"]
+
+
+def test_auto_mode_finishes_on_the_host_after_a_rank_failure_without_waiting_for_the_orphan(run):
+    assert run["auto_failure_result_bit_equal"]
+    assert run["auto_failure_orphans"] == 1  # rank 0 was enqueued before rank 1 refused
+    assert run["auto_failure_aborts"] == 3
+    # the orphan leaves after 3 s by itself: a library that synchronised its stream first would take that long
+    assert run["auto_failure_seconds"] < 1.5
+    assert run["auto_failure_mode_is_host"]
+    assert "aborted" in run["auto_failure_text"]
+    assert run["auto_after_failure_bit_equal"]  # the context keeps working (fresh streams, host sum)
+    assert run["basket_auto_failure_bit_equal"]
+
+
+def test_required_rccl_returns_a_status_not_a_hang(run):
+    assert run["strict_first_solve_bit_equal"]
+    assert run["strict_failure_code"] == run["HH_ERR_RCCL"]
+    assert run["strict_failure_seconds"] < 1.5
+    assert run["strict_second_code"] == run["HH_ERR_RCCL"]  # HH_MGPU_RCCL does not fall back, ever
+    assert run["strict_lsm_code"] == run["HH_ERR_RCCL"]
+
+
+def test_lsm_induction_through_a_failing_exchange(run):
+    assert run["lsm_auto_failure_bit_equal"]  # run again on the host's ordered sum
+    assert run["lsm_auto_failure_orphans"] == 2
+    assert run["lsm_auto_failure_seconds"] < 2.0
+    assert run["lsm_auto_failure_mode_is_host"]
+    assert run["lsm_strict_failure_code"] == run["HH_ERR_RCCL"]
+    assert run["lsm_strict_failure_seconds"] < 1.5
