@@ -14,6 +14,11 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib", "libhedgehog_mc.so")
 OBJ = os.path.join(HERE, "lib", "obj")
 SOURCES = ["hh_api.hip", "hh_mgpu.hip", "hh_kernels.hip", "hh_bk.hip", "hh_lsm.hip", "hh_fourier.hip"]
+# (source, object, extra flags): hh_bk.hip makes two objects — see the head of that file
+UNITS = [(s, s.replace(".hip", ".o"), []) for s in SOURCES if s != "hh_bk.hip"] + [
+    ("hh_bk.hip", "hh_bk.o", ["-DHH_BK_PART=1"]),
+    ("hh_bk.hip", "hh_bk_cold.o", ["-DHH_BK_PART=2", "-mllvm", "-disable-machine-licm"]),
+]
 CFLAGS = ["-fPIC", "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-Wall",
           "-Wno-unused-function"]
 LDFLAGS = ["-shared", "-fPIC", "--offload-arch=gfx950", "-ldl"]  # RCCL is bound with dlopen (hh_mgpu.hip)
@@ -57,12 +62,12 @@ def build_library(force: bool = False, extra_flags=(), out: str | None = None) -
     os.makedirs(os.path.dirname(lib), exist_ok=True)
     hdr_t = max(os.path.getmtime(h) for h in _headers())
     jobs, objs = [], []
-    for s in SOURCES:
+    for s, o, unit_flags in UNITS:
         src = os.path.join(CSRC, s)
-        obj = os.path.join(objdir, s.replace(".hip", ".o"))
+        obj = os.path.join(objdir, o)
         objs.append(obj)
         if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_t):
-            jobs.append([_hipcc(), "-c", *CFLAGS, *extra_flags, src, "-o", obj])
+            jobs.append([_hipcc(), "-c", *CFLAGS, *unit_flags, *extra_flags, src, "-o", obj])
     warnings = ""
     if jobs:
         with ThreadPoolExecutor(max_workers=min(len(jobs), 6)) as ex:

@@ -23,6 +23,16 @@
 // backward ratio recurrence), NCχ² (normal shift for d > 1, else Poisson mixture; Marsaglia–Tsang
 // gamma; inversion / PTRS Poisson), secant and bisection root finding.  Compute-bound (fp64 VALU);
 // loop lengths are data dependent, so lanes of a wave diverge — see DESIGN.md for the measured cost.
+//
+// This file is compiled TWICE (hedgehog.jl_amd/_build.py): HH_BK_PART = 1 holds the kernels of the chain
+// that carry the time (CF series + inversion, scan, ladder, spot rows) and the host side; HH_BK_PART = 2
+// holds the two programs made of library calls inside rejection / root-search loops — the NCχ² draws and
+// the whole-trajectory fall-back — and is built with -mllvm -disable-machine-licm.  There the machine-code
+// LICM pass lifts every fp64 literal of log / exp / lgamma / sincos / Philox out of those loops into a
+// register of its own (544 of them in the draw kernel of a grid: 512 registers, 156 spilled); without it
+// the literals stay where they are used and the same kernels take 92-128 registers with nothing in
+// scratch.  The hot kernels keep the pass (it removes instructions from their VALU-bound loops).
+// HH_BK_PART = 0 (default, single-object A/B builds): everything in one object.
 #include <algorithm>
 #include <cmath>
 
@@ -30,6 +40,12 @@
 #include "hh_kernels.h"
 #include "hh_math.h"
 #include "hh_rng.h"
+
+#ifndef HH_BK_PART
+#define HH_BK_PART 0
+#endif
+#define HH_BK_HOT (HH_BK_PART == 0 || HH_BK_PART == 1)
+#define HH_BK_COLD (HH_BK_PART == 0 || HH_BK_PART == 2)
 
 namespace hh {
 
@@ -352,8 +368,9 @@ __device__ __forceinline__ void store_draws(const BkArgs& p, uint64_t i, double 
   d[3 * p.draw_stride] = VT;
 }
 
+#if HH_BK_COLD
 template <bool REPLAY>
-__global__ __launch_bounds__(kTile) void bk_draw_kernel(const BkArgs p) {
+__global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(4, 8))) void bk_draw_kernel(const BkArgs p) {
   const uint64_t path = (uint64_t)blockIdx.x * kTile + threadIdx.x;
   if (path >= p.n_paths) return;
   double Z, u, VT;
@@ -370,11 +387,13 @@ __global__ __launch_bounds__(kTile) void bk_draw_kernel(const BkArgs p) {
   }
   store_draws(p, path, Z, u, VT);
 }
+#endif
 
 // The variance chain of dates k0 … k0 + n_dates of a grid, one trajectory per thread: V of each date from the
 // one before (cheap: one non-central χ² draw), its draws left where the chain's pair (date, trajectory) =
 // b·n_row + trajectory finds them, the variance rows written on the way.
-__global__ __launch_bounds__(kTile) void bk_draw_grid_kernel(const BkArgs p, uint64_t n_row, uint32_t k0,
+#if HH_BK_COLD
+__global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(4, 8))) void bk_draw_grid_kernel(const BkArgs p, uint64_t n_row, uint32_t k0,
                                                              uint32_t n_dates, double* __restrict__ var_rows) {
   const uint64_t path = (uint64_t)blockIdx.x * kTile + threadIdx.x;
   if (path >= n_row) return;
@@ -388,6 +407,7 @@ __global__ __launch_bounds__(kTile) void bk_draw_grid_kernel(const BkArgs p, uin
     V = VT;
   }
 }
+#endif
 
 // HestonCFIterator (heston.jl:165-176) and the moment heuristics (sample_from_cf.jl:31-37) of one
 // trajectory, from its start variance, its V_T and the normal quantile of its uniform
@@ -418,15 +438,16 @@ __device__ __forceinline__ void cf_setup(const BkArgs& p, const BesselTable* bt,
   h = kPi / (mean + p.n_sigma * sd);
 }
 
-// everything a trajectory of the fall-back kernel needs before the CDF inversion
+// everything a trajectory of the fall-back kernel keeps THROUGH the CDF inversion (what only the finish
+// needs — Z, V_T, the start state — is read again there: registers, not bandwidth, are short here)
 struct PathSetup {
-  double Z, u, VT, V0, logS0;
+  double u;
   CfIter cf;
   PhiCache cache;
   double initial_guess, max_guess, h;
 };
 
-__device__ void bk_setup(const BkArgs& p, const BesselTable* bt, uint64_t path, PathSetup& s) {
+__device__ __forceinline__ void bk_setup(const BkArgs& p, const BesselTable* bt, uint64_t path, PathSetup& s) {
   s.cache.col = p.phi_cache + (size_t)blockIdx.x * kTile + threadIdx.x;  // slot b of workgroup b: this kernel
   s.cache.stride = p.cache_stride;                                        // runs alone, behind the other two
   s.cache.cap = p.cache_cap;
@@ -434,14 +455,10 @@ __device__ void bk_setup(const BkArgs& p, const BesselTable* bt, uint64_t path, 
   s.cache.j_stop = 0;
   s.cache.theta_run = __builtin_nan("");
   s.cache.theta_cap = __builtin_nan("");
-  const bool grid = p.in_var != nullptr;
-  s.V0 = grid ? p.in_var[path] : p.V0;
-  s.logS0 = p.in_spot ? fm::log(p.in_spot[path]) : p.logS0;  // heston.jl:84: S = exp(W[1]), then log(S0) :289
+  const double V0 = p.in_var ? p.in_var[path] : p.V0;
   const double* d = p.draws + path;
-  s.Z = d[0];
   s.u = d[p.draw_stride];
-  s.VT = d[3 * p.draw_stride];
-  cf_setup(p, bt, s.V0, s.VT, d[2 * p.draw_stride], s.cf, s.initial_guess, s.max_guess, s.h);
+  cf_setup(p, bt, V0, d[3 * p.draw_stride], d[2 * p.draw_stride], s.cf, s.initial_guess, s.max_guess, s.h);
 }
 
 // 3. log S_T (heston.jl:288-297), S_T = exp(.) (montecarlo.jl:384), payoff
@@ -467,9 +484,17 @@ __device__ __forceinline__ double bk_finish(const BkArgs& p, double logS0, doubl
   const double m = p.cp * (S - p.strike);
   return m > 0.0 ? m : 0.0;
 }
+// … and the finish of that trajectory from its sampled ∫V
+__device__ __forceinline__ double bk_finish_path(const BkArgs& p, uint64_t path, double IV) {
+  const double V0 = p.in_var ? p.in_var[path] : p.V0;
+  const double logS0 = p.in_spot ? fm::log(p.in_spot[path]) : p.logS0;  // heston.jl:84: S = exp(W[1]), then log(S0) :289
+  const double* d = p.draws + path;
+  return bk_finish(p, logS0, V0, d[3 * p.draw_stride], d[0], IV, path);
+}
 
 // … and the spot rows of the same dates once the chain has left ∫V of every pair in iv_out: log S chained date by
 // date, the arithmetic of bk_finish on the same operands (bit-identical with the launch-per-date form)
+#if HH_BK_HOT
 __global__ __launch_bounds__(kTile) void bk_grid_spots_kernel(const BkArgs p, uint64_t n_row, uint32_t n_dates,
                                                               const double* __restrict__ var_rows,
                                                               double* __restrict__ spot_rows) {
@@ -484,6 +509,7 @@ __global__ __launch_bounds__(kTile) void bk_grid_spots_kernel(const BkArgs p, ui
     V0 = VT;
   }
 }
+#endif
 
 // (tile_count, when given, receives the tile's number of failed | too-long trajectories: the sums of
 // the 0/1 flags in acc[2] and `n_long` — what bk_scan_kernel needs, without re-reading the ballots)
@@ -786,6 +812,7 @@ __device__ __forceinline__ void give_slot(const BkArgs& p, uint32_t slot) {
 // flight sit in VGPRs and the kernel needs 192)
 // (one tile per workgroup, NOT a grid-stride loop over the tiles: with a loop around this body the compiler
 // hoists loop-invariant table values into 215-247 registers — measured — and halves the occupancy)
+#if HH_BK_HOT
 __global__ __launch_bounds__(kTile) void bk_cf_kernel(const BkArgs p, const BkTables* __restrict__ tabs) {
   const uint32_t tile = blockIdx.x, tid = threadIdx.x;
   const uint64_t path = (uint64_t)tile * kTile + tid;
@@ -799,6 +826,7 @@ __global__ __launch_bounds__(kTile) void bk_cf_kernel(const BkArgs p, const BkTa
   invert_phase(p, tile, tid, path, live, col, h, guess, max_guess, j_stop);
   give_slot(p, slot);
 }
+#endif
 
 // exclusive prefix sums of the per-tile counts of both ballot arrays (the inversion phase leaves the counts,
 // 4 bytes per tile: a single workgroup reading the 64 bytes of ballots per tile instead is bound by
@@ -806,7 +834,8 @@ __global__ __launch_bounds__(kTile) void bk_cf_kernel(const BkArgs p, const BkTa
 // up a run of consecutive tiles, the run totals are scanned (shuffles inside a wave, then the 16 wave
 // totals), then the runs are expanded.  Its last thread also leaves the copy of the argument block
 // bk_fallback_kernel reads (BkArgs::args_dev).
-constexpr int kScanThreads = 1024;
+[[maybe_unused]] constexpr int kScanThreads = 1024;
+#if HH_BK_HOT
 __global__ __launch_bounds__(kScanThreads) void bk_scan_kernel(const BkArgs p, uint32_t n_tiles,
                                                                uint32_t* __restrict__ prefix_a,
                                                                uint32_t* __restrict__ prefix_b) {
@@ -861,6 +890,7 @@ __global__ __launch_bounds__(kScanThreads) void bk_scan_kernel(const BkArgs p, u
     prefix_b[n_tiles] = tb;
   }
 }
+#endif
 
 // trajectory of packed work item g: the last tile t with prefix[t] <= g, then the (g - prefix[t])-th
 // set bit of its 4 ballots
@@ -893,6 +923,7 @@ __device__ __forceinline__ uint64_t packed_path(const unsigned long long* mask, 
 // same terms — into the column of the slot THIS workgroup takes.  One work item
 // per lane, no loop (see bk_cf_kernel): the grid covers the worst case (every trajectory failed) and the
 // workgroups beyond the packed list leave at once with an empty record.
+#if HH_BK_HOT
 __global__ __launch_bounds__(kTile) void bk_ladder_kernel(const BkArgs p, const BkTables* __restrict__ tabs,
                                                           uint32_t n_tiles,
                                                           const uint32_t* __restrict__ prefix) {
@@ -972,15 +1003,25 @@ __global__ __launch_bounds__(kTile) void bk_ladder_kernel(const BkArgs p, const 
   bk_store_record(acc, rec);
   give_slot(p, slot);
 }
+#endif
 
 // Fall-back kernel: trajectories whose series did not fit the cache (cf_tol far below the reference's
 // default) run whole here — secant, then the ladder if it fails — evaluating the terms beyond the
 // cache on every use, as the reference does with all of them.  Densely packed, grid stride; with
 // the default controls there are none and the launch returns at once.
-__global__ __launch_bounds__(kTile) void bk_fallback_kernel(const BkArgs* __restrict__ args,
-                                                            const BkTables* __restrict__ tabs,
-                                                            uint32_t n_tiles,
-                                                            const uint32_t* __restrict__ prefix) {
+#if HH_BK_COLD
+// Every CDF evaluation of the root search — the two starting points of the secant, its iterates, the two
+// ends of the ladder, the bisection's midpoints — goes through ONE call of cdf_from_cf below, the search
+// itself being a small state machine around it (the same statements, in the same order, as
+// secant_inverse and the ladder of bk_ladder_kernel).  With the CDF inlined at four places the kernel took
+// 248 registers and kept the trajectory's state in scratch (the calls that did not inline took it by
+// reference); with one place it is 154 registers and nothing in scratch.  (Capped at 128 the allocator
+// spills 8-30 registers whatever part of the search state is parked in LDS: the pressure is inside the one
+// CF evaluation, which this kernel runs with its full series every time.  Three waves per SIMD, then, for
+// a kernel that is empty with the reference's controls.)
+__global__ __launch_bounds__(kTile) void bk_fallback_kernel(
+    const BkArgs* __restrict__ args, const BkTables* __restrict__ tabs, uint32_t n_tiles,
+    const uint32_t* __restrict__ prefix) {
   const uint32_t total = prefix[n_tiles];
   const BkArgs& p = *args;
   const BesselTable* bt = tabs->t;
@@ -990,56 +1031,96 @@ __global__ __launch_bounds__(kTile) void bk_fallback_kernel(const BkArgs* __rest
     PathSetup s;
     bk_setup(p, bt, path, s);
     double n_terms = 0.0;
-    double IV;
-    uint32_t dec = 0, iters = 0;
-    const bool done =
-        secant_inverse([&](double x) { return cdf_from_cf(p, bt, s.cf, x, s.h, s.cache, n_terms); }, s.u,
-                       s.initial_guess, p.atol, p.newton_maxiter, IV, dec);
-    dec |= kDecLongSeries;
-    if (!done) {  // the fall-back ladder (sample_from_cf.jl:123-133)
-      acc[2] += 1.0;
-      double fa = cdf_from_cf(p, bt, s.cf, 0.0, s.h, s.cache, n_terms) - s.u;
-      const double fb = cdf_from_cf(p, bt, s.cf, s.max_guess, s.h, s.cache, n_terms) - s.u;
-      if (fa * fb > 0.0) {
-        acc[4] += 1.0;
-        IV = s.max_guess;  // sample_from_cf.jl:124-126
-        dec |= kDecMaxGuess;
-      } else {
+    enum Stage { kSecantFirst, kSecant, kLadderLo, kLadderHi, kBisect };
+    // secant_inverse: Order2 restated as the secant iteration from (x0 + dx, x0), dx = h + |x0| h², h = eps^(1/3).
+    // The secant's (x0, f0), (x1, f1) and the ladder's (lo, f(lo)), hi share their registers: xa, fa, xb, fb
+    const double hs = 6.0554544523933395e-06;
+    double xb = s.initial_guess;                   // secant: x1            ladder: hi
+    double xa = xb + hs + fabs(xb) * hs * hs;      // secant: x0            ladder: lo
+    double fa = 0.0;                               // secant: f0            ladder: f(lo)
+    uint32_t dec = kDecLongSeries, evals = 1, iters = 0;
+    int stage = kSecantFirst;
+    double x = xa;
+    for (;;) {
+      const double f = cdf_from_cf(p, bt, s.cf, x, s.h, s.cache, n_terms) - s.u;
+      if (stage == kSecantFirst) {
+        fa = f;
+        x = xb;
+        stage = kSecant;
+        continue;
+      }
+      if (stage == kSecant) {
+        const double fb = f, f0 = fa;
+        ++evals;
+        const bool ok = fabs(fb) <= p.atol;
+        if (!ok && !((int)evals >= p.newton_maxiter || fb == f0)) {
+          const double x2 = xb - fb * (xb - xa) / (fb - f0);
+          if (isfinite(x2)) {
+            xa = xb;
+            fa = fb;
+            x = xb = x2;
+            continue;
+          }
+        }
+        dec |= evals;
+        x = xb;                            // the secant's answer, should it stand
+        if (ok && !(xb < 0.0)) break;
+        acc[2] += 1.0;  // the fall-back ladder (sample_from_cf.jl:123-133)
+        x = xa = 0.0;
+        xb = s.max_guess;
+        stage = kLadderLo;
+        continue;
+      }
+      if (stage == kLadderLo) {
+        fa = f;
+        x = xb;
+        stage = kLadderHi;
+        continue;
+      }
+      if (stage == kLadderHi) {
+        if (fa * f > 0.0) {
+          acc[4] += 1.0;
+          dec |= kDecMaxGuess;  // x = max_guess (sample_from_cf.jl:124-126)
+          break;
+        }
         acc[3] += 1.0;
         dec |= kDecBisect;
-        double lo_x = 0.0, hi_x = s.max_guess;
-        for (int i = 0; i < p.bisect_maxiter; ++i) {
-          const double mid = 0.5 * (lo_x + hi_x);
-          const double fm = cdf_from_cf(p, bt, s.cf, mid, s.h, s.cache, n_terms) - s.u;
-          ++iters;
-          if (fm == 0.0) {
-            lo_x = hi_x = mid;
-            break;
-          }
-          if ((fm < 0.0) == (fa < 0.0)) {
-            lo_x = mid;
-            fa = fm;
-          } else {
-            hi_x = mid;
-          }
-          if (hi_x - lo_x <= p.atol) break;
-        }
-        IV = 0.5 * (lo_x + hi_x);
+        x = 0.5 * (xa + xb);
+        if (p.bisect_maxiter <= 0) break;
+        stage = kBisect;
+        continue;
+      }
+      // kBisect: f is the CDF residual at the midpoint x
+      ++iters;
+      if (f == 0.0) {
+        xa = xb = x;
+      } else if ((f < 0.0) == (fa < 0.0)) {
+        xa = x;
+        fa = f;
+      } else {
+        xb = x;
+      }
+      x = 0.5 * (xa + xb);
+      if (f == 0.0 || xb - xa <= p.atol || (int)iters >= p.bisect_maxiter) {
         dec |= (iters & 0xffu) << kDecItersShift;
+        break;
       }
     }
+    const double IV = x;
     p.diag[path] = dec;
     p.diag[p.draw_stride + path] = (uint32_t)s.cache.j_stop;
     acc[5] += n_terms;
-    const double pay = bk_finish(p, s.logS0, s.V0, s.VT, s.Z, IV, path);
+    const double pay = bk_finish_path(p, path, IV);
     acc[0] += pay;
     acc[1] = fma(pay, pay, acc[1]);
   }
   bk_store_record(acc, p.records + (size_t)(2 * n_tiles + blockIdx.x) * kRecStride);
 }
+#endif
 
 // The host-made tables into device memory: ONE lane, constant indices (a lane-indexed read of the
 // by-value argument would again send the block through scratch), the compiler batches the scalar loads.
+#if HH_BK_HOT
 __global__ __launch_bounds__(64) void bk_tables_kernel(const BkTables t, BkTables* __restrict__ dst) {
   if (threadIdx.x != 0) return;
   const double* src = reinterpret_cast<const double*>(&t);
@@ -1047,7 +1128,9 @@ __global__ __launch_bounds__(64) void bk_tables_kernel(const BkTables t, BkTable
 #pragma unroll
   for (size_t i = 0; i < sizeof(BkTables) / sizeof(double); ++i) out[i] = src[i];
 }
+#endif
 
+#if HH_BK_HOT
 __global__ __launch_bounds__(256) void fill_rows_kernel(double* __restrict__ spot0,
                                                         double* __restrict__ var0, uint64_t n,
                                                         double S0, double V0) {
@@ -1057,9 +1140,38 @@ __global__ __launch_bounds__(256) void fill_rows_kernel(double* __restrict__ spo
     var0[i] = V0;
   }
 }
+#endif
 
 }  // namespace
 
+// The launches of the part-2 kernels, callable from the part-1 object: the argument block travels as bytes
+// (BkArgs is a type of this file's anonymous namespace in either object; one source, one layout).
+void bk_cold_draw(const void* args, uint32_t n_tiles, bool replay, hipStream_t s);
+void bk_cold_draw_grid(const void* args, uint32_t row_tiles, uint64_t n_row, uint32_t k0, uint32_t n_dates,
+                       double* var_rows, hipStream_t s);
+void bk_cold_fallback(const void* args_dev, const void* tabs_dev, uint32_t n_tiles, const uint32_t* prefix_long,
+                      hipStream_t s);
+#if HH_BK_COLD
+void bk_cold_draw(const void* args, uint32_t n_tiles, bool replay, hipStream_t s) {
+  const BkArgs& a = *static_cast<const BkArgs*>(args);
+  if (replay)
+    hipLaunchKernelGGL(bk_draw_kernel<true>, dim3(n_tiles), dim3(kTile), 0, s, a);
+  else
+    hipLaunchKernelGGL(bk_draw_kernel<false>, dim3(n_tiles), dim3(kTile), 0, s, a);
+}
+void bk_cold_draw_grid(const void* args, uint32_t row_tiles, uint64_t n_row, uint32_t k0, uint32_t n_dates,
+                       double* var_rows, hipStream_t s) {
+  hipLaunchKernelGGL(bk_draw_grid_kernel, dim3(row_tiles), dim3(kTile), 0, s, *static_cast<const BkArgs*>(args), n_row,
+                     k0, n_dates, var_rows);
+}
+void bk_cold_fallback(const void* args_dev, const void* tabs_dev, uint32_t n_tiles, const uint32_t* prefix_long,
+                      hipStream_t s) {
+  hipLaunchKernelGGL(bk_fallback_kernel, dim3(kHeavyGrid), dim3(kTile), 0, s, static_cast<const BkArgs*>(args_dev),
+                     static_cast<const BkTables*>(tabs_dev), n_tiles, prefix_long);
+}
+#endif
+
+#if HH_BK_HOT
 constexpr size_t kSlotBitmapBytes = 8 * 128 + 128;  // one 128-byte line per XCD (kXcds = 8) + the side-store counter's
 
 // series terms cached per column: term_cache (HH_OPT_BK_TERM_CACHE; 0 = kBkTermCacheDefault).  The columns
@@ -1201,8 +1313,7 @@ void bk_chain(const BkArgs& a, const BkLayout& L, hipStream_t s) {
   hipLaunchKernelGGL(bk_cf_kernel, g, b, 0, s, a, tabs);
   hipLaunchKernelGGL(bk_scan_kernel, dim3(1), dim3(kScanThreads), 0, s, a, L.n_tiles, L.prefix, L.prefix_long);
   hipLaunchKernelGGL(bk_ladder_kernel, g, b, 0, s, a, tabs, L.n_tiles, L.prefix);
-  hipLaunchKernelGGL(bk_fallback_kernel, dim3(kHeavyGrid), b, 0, s,
-                     static_cast<const BkArgs*>(a.args_dev), tabs, L.n_tiles, L.prefix_long);
+  bk_cold_fallback(a.args_dev, tabs, L.n_tiles, L.prefix_long, s);
 }
 
 }  // namespace
@@ -1220,11 +1331,7 @@ int launch_bk(const hh_model& m, const hh_config& c, const DevicePtrs& ptr, hipS
   if (rc) return rc;
   a.replay = c.noise_mode == HH_NOISE_REPLAY ? ptr.replay : nullptr;
   if ((rc = bk_tables(a, L, ptr, s, upload_tables))) return rc;
-  const dim3 g(L.n_tiles), b(kTile);
-  if (a.replay)
-    hipLaunchKernelGGL(bk_draw_kernel<true>, g, b, 0, s, a);
-  else
-    hipLaunchKernelGGL(bk_draw_kernel<false>, g, b, 0, s, a);
+  bk_cold_draw(&a, L.n_tiles, a.replay != nullptr, s);
   bk_chain(a, L, s);
   return (int)hipGetLastError();
 }
@@ -1265,11 +1372,13 @@ int launch_bk_grid(const hh_model& m, const hh_config& c, const DevicePtrs& ptr,
   a.iv_out = a.iv_store;
   if ((rc = bk_tables(a, L, ptr, s, upload_tables))) return rc;
   const dim3 rows(tiles_for(n_row)), b(kTile);
-  hipLaunchKernelGGL(bk_draw_grid_kernel, rows, b, 0, s, a, n_row, k0, n_dates, var_rows);
+  bk_cold_draw_grid(&a, rows.x, n_row, k0, n_dates, var_rows, s);
   bk_chain(a, L, s);
   hipLaunchKernelGGL(bk_grid_spots_kernel, rows, b, 0, s, a, n_row, n_dates,
                      static_cast<const double*>(var_rows), spot_rows);
   return (int)hipGetLastError();
 }
+
+#endif  // HH_BK_HOT
 
 }  // namespace hh
