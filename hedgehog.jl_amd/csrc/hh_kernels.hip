@@ -242,81 +242,51 @@ struct VecOf<2> {
   __device__ static __forceinline__ double get(const type& v, int j) { return j ? v.y : v.x; }
 };
 
-// tuning knobs of the REPLAY pipeline (tools/tune_replay.py builds variants with -D)
-#ifndef HH_REPLAY_CHUNK
-#define HH_REPLAY_CHUNK 2
+// The shape of the REPLAY pipeline, as measured (profiles/r02_a_replay_occupancy_ab.txt,
+// r02_b_replay_shape_ab.txt, r02_d_replay_counted_waits_ab.txt).  The A/B builds of tools/tune_replay.py
+// (-DHH_REPLAY_VARIANTS -Itools/variants) override these with -D and add the experiment paths that did not
+// ship — two trajectories per lane, the per-wave LDS-DMA ring, the occupancy pad, the antithetic pair
+// split over two lanes — from tools/variants/; this translation unit holds what ships.
+#ifdef HH_REPLAY_VARIANTS
+#include "replay_knobs.h"
 #endif
 #ifndef HH_REPLAY_NT
-#define HH_REPLAY_NT 1
-#endif
-#ifndef HH_REPLAY_MINW
-#define HH_REPLAY_MINW 1
-#endif
-#ifndef HH_REPLAY_LDS
-#define HH_REPLAY_LDS 0  // > 0: the price-only kernel streams through a per-wave LDS ring of that
-                          // many chunks filled by LDS-DMA (needs HH_REPLAY_PPT = 2); measured, kept
-                          // for A/B (tools/tune_replay.py), not shipped — see DESIGN.md §5
-#endif
-#ifndef HH_REPLAY_PPT
-#define HH_REPLAY_PPT 1  // trajectories per lane of the price-only REPLAY kernel: 256-thread workgroups
-#endif
-// one trajectory per lane (256-thread workgroups, 8-byte loads) for the antithetic and dual-partial
-// kernels too: 0.608 against 0.627 ms (antithetic) and 0.597 against 0.611 ms (one carried
-// derivative) with two per lane (round 2 A/B, profiles/r02_b_replay_shape_ab.txt)
-#ifndef HH_REPLAY_PPT_ANTI
-#define HH_REPLAY_PPT_ANTI 1
-#endif
-#ifndef HH_REPLAY_PPT_DUAL
-#define HH_REPLAY_PPT_DUAL 1
-#endif
-#ifndef HH_REPLAY_CHUNK_PPT1
-#define HH_REPLAY_CHUNK_PPT1 4
+#define HH_REPLAY_NT 1            // the increments are a read-once stream: nontemporal loads
 #endif
 #ifndef HH_REPLAY_CHUNK_PRICE
-#define HH_REPLAY_CHUNK_PRICE 4
+#define HH_REPLAY_CHUNK_PRICE 4   // steps per register chunk, price-only kernel …
+#endif
+#ifndef HH_REPLAY_CHUNK_PPT1
+#define HH_REPLAY_CHUNK_PPT1 4    // … antithetic and dual-partial kernels (one trajectory per lane: 0.608 vs 0.627 ms
+#endif                            //   antithetic, 0.597 vs 0.611 ms one carried derivative, against two per lane)
+#ifndef HH_REPLAY_CHUNK_TAIL
+#define HH_REPLAY_CHUNK_TAIL 4    // … and of the price-only kernel's last HH_REPLAY_TAIL_TILES workgroups
+#endif
+#ifndef HH_REPLAY_TAIL_TILES
+#define HH_REPLAY_TAIL_TILES 512
+#endif
+#ifndef HH_REPLAY_COUNTED
+#define HH_REPLAY_COUNTED 1       // steady-state loads unguarded, so that the compiler can COUNT its waits
 #endif
 // Occupancy of the REPLAY kernels.  HBM delivers most when a CU runs few concurrent 1 MB streams
 // (tools/ubench/hbm_read_sweep.hip), so the REPLAY variants are held BELOW what their register count
 // would allow — by the compiler's own occupancy control, amdgpu_waves_per_eu(1, max): the kernel
 // descriptor then reserves ⌊512 / max⌋ registers per lane and the hardware admits at most `max`
-// waves per SIMD, whatever else the kernel declares.  (Round 1 obtained the same caps as a side
-// effect of an untouched LDS allocation — HH_REPLAY_PAD_*_KIB, still here for A/B, default off.)
+// waves per SIMD, whatever else the kernel declares.
+#ifndef HH_REPLAY_MINW
+#define HH_REPLAY_MINW 1
+#endif
 #ifndef HH_REPLAY_MAXW
-#define HH_REPLAY_MAXW 2       // price-only: 2 waves per SIMD = 2 workgroups of 256 threads = 8 waves per CU
+#define HH_REPLAY_MAXW 2          // price-only: 2 waves per SIMD = 2 workgroups of 256 threads = 8 waves per CU
 #endif
 #ifndef HH_REPLAY_MAXW_DUAL
-#define HH_REPLAY_MAXW_DUAL 3  // dual-partial kernels (one trajectory per lane): 3 waves per SIMD, 0.597 ms with one carried
-                               // derivative against 0.646 at 2; with two trajectories per lane it was 0.609 at 2, 0.623 at 3, 0.663 uncapped
+#define HH_REPLAY_MAXW_DUAL 3     // one carried derivative: 0.597 ms at 3 waves per SIMD against 0.646 at 2
+#endif
+#ifndef HH_REPLAY_MAXW_DUAL_WIDE
+#define HH_REPLAY_MAXW_DUAL_WIDE HH_REPLAY_MAXW_DUAL  // two or more carried derivatives
 #endif
 #ifndef HH_REPLAY_MAXW_ANTI
-#define HH_REPLAY_MAXW_ANTI 8  // antithetic: indifferent (0.629 vs 0.625 ms), left at the register limit
-#endif
-#ifndef HH_REPLAY_CHUNK_TAIL
-#define HH_REPLAY_CHUNK_TAIL 4   // steps per chunk of the price-only kernel's last HH_REPLAY_TAIL_TILES workgroups
-#endif
-#ifndef HH_REPLAY_TAIL_TILES
-#define HH_REPLAY_TAIL_TILES 512
-#endif
-#ifndef HH_REPLAY_PAD_KIB
-#define HH_REPLAY_PAD_KIB 0
-#endif
-#ifndef HH_REPLAY_PAD_ANTI_KIB
-#define HH_REPLAY_PAD_ANTI_KIB 0
-#endif
-#ifndef HH_REPLAY_PAD_DUAL_KIB
-#define HH_REPLAY_PAD_DUAL_KIB 0
-#endif
-#ifndef HH_REPLAY_PIPE
-#define HH_REPLAY_PIPE 0  // standard ring: 0 = drain all LDS-DMA before each chunk is read
-#endif
-#ifndef HH_REPLAY_LDS_DEEP
-#define HH_REPLAY_LDS_DEEP 8  // ring depth when the grid cannot fill the chip (<= kDeepRingTiles)
-#endif
-#ifndef HH_REPLAY_LDS_ANTI
-#define HH_REPLAY_LDS_ANTI 0  // the same for the antithetic kernels
-#endif
-#ifndef HH_REPLAY_LDS_DUAL
-#define HH_REPLAY_LDS_DUAL 0  // ... and for the kernels carrying dual partials
+#define HH_REPLAY_MAXW_ANTI 8     // antithetic: indifferent (0.629 vs 0.625 ms), left at the register limit
 #endif
 
 template <class Vec>
@@ -328,10 +298,6 @@ __device__ __forceinline__ Vec stream_load(const double* p) {
 #endif
 }
 
-// RING: chunks in each wave's LDS ring of the REPLAY stream (0 = register pipeline), see below
-#ifndef HH_REPLAY_MAXW_DUAL_WIDE
-#define HH_REPLAY_MAXW_DUAL_WIDE HH_REPLAY_MAXW_DUAL  // two or more carried derivatives
-#endif
 constexpr int replay_max_waves(bool replay, bool anti, int p) {
   return !replay ? 8 : anti ? HH_REPLAY_MAXW_ANTI : p > 1 ? HH_REPLAY_MAXW_DUAL_WIDE : p > 0 ? HH_REPLAY_MAXW_DUAL : HH_REPLAY_MAXW;
 }
@@ -362,7 +328,11 @@ __attribute__((amdgpu_waves_per_eu(REPLAY ? HH_REPLAY_MINW : 1,
     const double* __restrict__ base =
         a.replay + (size_t)tile * n_steps * NC * kTile + (size_t)tid * PPT;
     // steps per chunk: the price-only kernel (one trajectory per lane) moves 4 steps at a time
+#ifdef HH_REPLAY_VARIANTS
     constexpr int kChunk = (P == 0 && !ANTI && RING == 0) ? HH_REPLAY_CHUNK_PRICE : (PPT == 1 ? HH_REPLAY_CHUNK_PPT1 : HH_REPLAY_CHUNK);
+#else
+    constexpr int kChunk = (P == 0 && !ANTI) ? HH_REPLAY_CHUNK_PRICE : HH_REPLAY_CHUNK_PPT1;
+#endif
     [[maybe_unused]] Vec A[kChunk][NC], B[kChunk][NC];
 
     auto load = [&](Vec(&buf)[kChunk][NC], uint32_t s0) {
@@ -390,109 +360,17 @@ __attribute__((amdgpu_waves_per_eu(REPLAY ? HH_REPLAY_MINW : 1,
       }
     };
 
-    // Which REPLAY pipeline (measurements: DESIGN.md §5, tools/tune_replay.py, tools/replay_sizes.py,
-    // tools/ubench/hbm_read_sweep.hip).
-    // RING = 0, what ships: two register chunks, load(B) || compute(A), with the occupancy capped by
-    // amdgpu_waves_per_eu (see HH_REPLAY_MAXW above): 8 waves per CU for the price-only kernel, 12
-    // for the dual-partial kernels, uncapped for the antithetic one.
-    // RING > 0 (-DHH_REPLAY_LDS, price-only kernel with PPT = 2): each wave moves its half-tile
-    // through a PRIVATE ring of RING chunks in LDS filled by LDS-DMA (global_load_lds_dwordx4: 16 B
-    // per lane straight into LDS, no VGPR staging, no workgroup barrier).  It ties with the shipped
-    // form at 10^6 trajectories — because its LDS footprint happens to cap the occupancy the same
-    // way — and loses at every smaller size; kept for A/B.
-    //  * PIPE = false: the wave DRAINS its LDS-DMA (vmcnt(0)) before reading a chunk, so its own
-    //    loads never overlap its own arithmetic (4 slots x 2 steps = 32 KiB per workgroup).
-    //  * PIPE = true, used for grids of <= kDeepRingTiles workgroups: counted waits keep the RING-1
-    //    younger chunks in flight.  The read-back then has to be invisible to the compiler (inline
-    //    ds_read_b128): it treats any LDS read it knows about as aliasing ALL outstanding LDS-DMA
-    //    and puts s_waitcnt vmcnt(0) in front of it.
-    constexpr int R = RING;
-    constexpr bool kUseLds = R > 0 && PPT == 2;
-    if constexpr (kUseLds) {
-    constexpr int PER_CHUNK = kChunk * NC;  // LDS-DMA instructions per chunk and wave
-    static_assert((R - 1) * PER_CHUNK <= 63, "vmcnt is a 6-bit counter");
-    __shared__ __attribute__((aligned(16))) double ring[kTile / PPT / 64][R][kChunk][NC][128];
-    const int wave = tid >> 6, lane = tid & 63;
-    const double* gbase = a.replay + (size_t)tile * n_steps * NC * kTile + wave * 128 + lane * 2;
-    const uint32_t n_chunks = n_steps / kChunk;
-    // LDS byte address of this lane's 16 B in slot 0, step 0, component 0 of the wave's ring
-    const uint32_t ring_lds =
-        (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)&ring[wave][0][0][0][lane * 2];
-    auto issue = [&](uint32_t k) {
-#pragma unroll
-      for (int u = 0; u < kChunk; ++u)
-#pragma unroll
-        for (int c = 0; c < NC; ++c)
-          __builtin_amdgcn_global_load_lds(
-              (const __attribute__((address_space(1))) void*)(gbase +
-                                                              ((size_t)(k * kChunk + u) * NC + c) * kTile),
-              (__attribute__((address_space(3))) void*)&ring[wave][k % R][u][c][0], 16, 0,
-              HH_REPLAY_NT ? 2 : 0);
-    };
-    for (uint32_t k = 0; k + 1 < (uint32_t)R && k < n_chunks; ++k) issue(k);
-    for (uint32_t k = 0; k < n_chunks; ++k) {
-      if (k + R - 1 < n_chunks) issue(k + R - 1);
-      Vec v[kChunk][NC];
-      if constexpr (PIPE) {
-        // chunk k has landed once at most `after` younger chunks are still in flight
-        const uint32_t after =
-            n_chunks - 1 - k < (uint32_t)(R - 1) ? n_chunks - 1 - k : (uint32_t)(R - 1);
-#define HH_WAIT_CHUNKS(n) \
-  case n: asm volatile("s_waitcnt vmcnt(%0)" ::"n"((n) * PER_CHUNK < 63 ? (n) * PER_CHUNK : 63) : "memory"); break;
-        switch (after) {
-          HH_WAIT_CHUNKS(0) HH_WAIT_CHUNKS(1) HH_WAIT_CHUNKS(2) HH_WAIT_CHUNKS(3) HH_WAIT_CHUNKS(4)
-          HH_WAIT_CHUNKS(5) HH_WAIT_CHUNKS(6) HH_WAIT_CHUNKS(7)
-          default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-        }
-#undef HH_WAIT_CHUNKS
-        __builtin_amdgcn_sched_barrier(0);
-        const uint32_t slot = ring_lds + (k % R) * (uint32_t)(kChunk * NC * 1024);
-#pragma unroll
-        for (int u = 0; u < kChunk; ++u)
-#pragma unroll
-          for (int c = 0; c < NC; ++c)
-            asm volatile("ds_read_b128 %0, %1 offset:%2"
-                         : "=v"(v[u][c])
-                         : "v"(slot), "n"((u * NC + c) * 1024)
-                         : "memory");
-      } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-      }
-#pragma unroll
-      for (int u = 0; u < kChunk; ++u) {
-        if constexpr (PIPE) {
-          // LDS returns in order: step u is there once (kChunk-1-u)·NC reads are still pending.  The
-          // "+v" operands are a data dependence: no use of v[u][] may be scheduled above its wait.
-#pragma unroll
-          for (int c = 0; c < NC; ++c)
-            asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(v[u][c]) : "n"((kChunk - 1 - u) * NC) : "memory");
-        } else {  // read step by step: the next step's LDS reads overlap this step's flops
-#pragma unroll
-          for (int c = 0; c < NC; ++c)
-            v[u][c] = *reinterpret_cast<const Vec*>(&ring[wave][k % R][u][c][lane * 2]);
-        }
-#pragma unroll
-        for (int j = 0; j < PPT; ++j) {
-          const double d1 = VecOf<PPT>::get(v[u][0], j);
-          const double d2 = NC > 1 ? VecOf<PPT>::get(v[u][NC - 1], j) : 0.0;
-          M::step(st[j], a, d1, d2);
-          if constexpr (ANTI) M::step(sa[j], a, -d1, -d2);  // montecarlo.jl:258: -W
-        }
-      }
-    }
-    // the n_steps % kChunk last steps: plain register loads
-    if (n_chunks * kChunk < n_steps) {
-      load(A, n_chunks * kChunk);
-      compute(A, n_chunks * kChunk);
-    }
-    } else {
-    // A/B only (HH_REPLAY_PAD_*_KIB > 0): LDS allocated to cap the occupancy, never touched
-    constexpr int kPadKib = ANTI ? HH_REPLAY_PAD_ANTI_KIB : P > 0 ? HH_REPLAY_PAD_DUAL_KIB : HH_REPLAY_PAD_KIB;
-    if constexpr (kPadKib > 0) {
-      __shared__ double occupancy_pad[kPadKib > 0 ? kPadKib * 128 : 1];
-      if (a.n_steps == 0xFFFFFFFFu) occupancy_pad[tid] = 0.0;
-    }
+    // Two register chunks, load(B) || compute(A), with the occupancy capped by amdgpu_waves_per_eu (see
+    // HH_REPLAY_MAXW above): 8 waves per CU for the price-only kernel, 12 for the dual-partial kernels,
+    // uncapped for the antithetic one (measurements: DESIGN.md §5, tools/tune_replay.py,
+    // tools/replay_sizes.py, tools/ubench/hbm_read_sweep.hip).
+#ifdef HH_REPLAY_VARIANTS
+#include "replay_lds_ring.inc"  // if constexpr (RING > 0 && PPT == 2) { the per-wave LDS-DMA ring } else
+#endif
+    {
+#ifdef HH_REPLAY_VARIANTS
+#include "replay_occupancy_pad.inc"
+#endif
     // The last workgroups of a grid run while the chip empties: fewer streams are open, so each has
     // to keep more bytes in flight to hold the bandwidth up — they pipeline HH_REPLAY_CHUNK_TAIL steps
     // per chunk instead of kChunk (registers are there: the occupancy cap leaves a wave 256).
@@ -548,9 +426,6 @@ __attribute__((amdgpu_waves_per_eu(REPLAY ? HH_REPLAY_MINW : 1,
         }
       };
       uint32_t s = 0;
-#ifndef HH_REPLAY_COUNTED
-#define HH_REPLAY_COUNTED 1
-#endif
       if (HH_REPLAY_COUNTED && n_steps >= 2u * CH) {
         ldf(X, 0);
         while (s + 3u * CH <= n_steps) {  // chunks s, s+CH and s+2CH are full
@@ -630,93 +505,8 @@ __attribute__((amdgpu_waves_per_eu(REPLAY ? HH_REPLAY_MINW : 1,
   block_reduce_store<4 + P, kTile / PPT / 64, 2>(acc, a.records + (size_t)tile * kRecStride);
 }
 
-// ------------------------------------------------------------------------------------------
-// Experiment (review r2, item 7): an antithetic pair split over TWO lanes
-// ------------------------------------------------------------------------------------------
-//
-// 512 threads per tile: thread t < 256 integrates trajectory t with +dW, thread t + 256 its mirror with
-// −dW; both halves load the same 2 KiB rows (the second read is an L1 / L2 hit, HBM traffic unchanged),
-// the pair average is formed through LDS at the end.  Per LANE the arithmetic per loaded byte halves —
-// per SIMD it does not (the two waves issue 2 x 33 instructions where one issued 61), which is why this
-// form is not faster than the one-lane pair (profiles/r03_e_anti_split_ab.txt).  Built only with
-// -DHH_ANTI_SPLIT=1 (tools/tune_replay.py); price-only, tile-major REPLAY.
-#ifndef HH_ANTI_SPLIT
-#define HH_ANTI_SPLIT 0
-#endif
-#ifndef HH_ANTI_SPLIT_MAXW
-#define HH_ANTI_SPLIT_MAXW 4
-#endif
-#if HH_ANTI_SPLIT
-template <class M>
-__global__ __launch_bounds__(2 * kTile)
-__attribute__((amdgpu_waves_per_eu(1, HH_ANTI_SPLIT_MAXW))) void euler_pair_split_kernel(const SimArgs<0> a) {
-  constexpr int NC = M::NCOMP, CH = HH_REPLAY_CHUNK_PRICE;
-  using State = typename M::State;
-  const uint32_t tile = blockIdx.x, tid = threadIdx.x & (kTile - 1);
-  const bool mirror = threadIdx.x >= (uint32_t)kTile;
-  const double sgn = mirror ? -1.0 : 1.0;
-  const uint64_t path = (uint64_t)tile * kTile + tid;
-  const uint32_t n_steps = a.n_steps;
-  State st;
-  M::init(st, a);
-  const double* __restrict__ base = a.replay + (size_t)tile * n_steps * NC * kTile + tid;
-  double X[CH][NC], Y[CH][NC];
-  auto ld = [&](double(&buf)[CH][NC], uint32_t s0, bool guard) {
-#pragma unroll
-    for (int u = 0; u < CH; ++u)
-      if (!guard || s0 + u < n_steps)
-#pragma unroll
-        for (int c = 0; c < NC; ++c) buf[u][c] = stream_load<double>(base + ((size_t)(s0 + u) * NC + c) * kTile);
-  };
-  auto go = [&](const double(&buf)[CH][NC], uint32_t s0, bool guard) {
-#pragma unroll
-    for (int u = 0; u < CH; ++u)
-      if (!guard || s0 + u < n_steps) M::step(st, a, sgn * buf[u][0], NC > 1 ? sgn * buf[u][NC - 1] : 0.0);
-  };
-  uint32_t s = 0;
-  if (n_steps >= 2u * CH) {
-    ld(X, 0, false);
-    while (s + 3u * CH <= n_steps) {
-      ld(Y, s + CH, false);
-      go(X, s, false);
-      ld(X, s + 2u * CH, false);
-      go(Y, s + CH, false);
-      s += 2u * CH;
-    }
-    ld(Y, s + CH, true);
-    go(X, s, false);
-    s += CH;
-    ld(X, s + CH, true);
-    go(Y, s, true);
-    go(X, s + CH, true);
-  } else {
-    for (; s < n_steps; s += CH) {
-      ld(X, s, true);
-      go(X, s, true);
-    }
-  }
-  // pair average through LDS (montecarlo.jl:431), then the tile's record as the one-lane form leaves it
-  __shared__ double pm[4][kTile];
-  double S, p, pd[1], wS, wN;
-  payoff_of<0>(st.x, a, S, p, pd, wS, wN);
-  const bool livep = path < a.n_paths;
-  if (mirror) {
-    pm[0][tid] = p; pm[1][tid] = wS; pm[2][tid] = wN;
-    if (a.terminal && livep) a.terminal[a.n_paths + path] = S;
-  } else if (a.terminal && livep) {
-    a.terminal[path] = S;
-  }
-  __syncthreads();
-  double acc[4] = {0.0, 0.0, 0.0, 0.0};
-  if (!mirror && livep) {
-    p = (p + pm[0][tid]) / 2;
-    acc[0] = p;
-    acc[1] = p * p;
-    acc[2] = (wS + pm[1][tid]) / 2;
-    acc[3] = (wN + pm[2][tid]) / 2;
-  }
-  block_reduce_store<4, 2 * kTile / 64, 2>(acc, a.records + (size_t)tile * kRecStride);
-}
+#ifdef HH_REPLAY_VARIANTS
+#include "anti_pair_split.inc"  // euler_pair_split_kernel (-DHH_ANTI_SPLIT=1)
 #endif
 
 // ------------------------------------------------------------------------------------------
@@ -1179,25 +969,26 @@ static SimArgs<P> make_args(const hh_model& m, const hh_config& c, const DeviceP
   return a;
 }
 
-// With the standard ring (32 KiB of LDS per Heston workgroup) a CU holds 4 workgroups, the chip
-// 1024; a grid of at most half that cannot fill it, so each wave gets a deeper, pipelined ring
-// (more bytes in flight per wave) instead: 2 workgroups per CU still hold the whole grid.
-constexpr uint32_t kDeepRingTiles = 512;
-
 template <class M, int P, bool REPLAY, bool ANTI>
 static int launch_euler_t(const SimArgs<P>& a, hipStream_t s) {
+#ifdef HH_REPLAY_VARIANTS
   constexpr int PPT = !REPLAY ? 1 : (P == 0 && !ANTI) ? HH_REPLAY_PPT : (P == 0 ? HH_REPLAY_PPT_ANTI : HH_REPLAY_PPT_DUAL);
-  constexpr int RING = !REPLAY ? 0 : ANTI ? HH_REPLAY_LDS_ANTI : P > 0 ? HH_REPLAY_LDS_DUAL
-                                                                     : HH_REPLAY_LDS;
-  const dim3 g(a.n_tiles), b(kTile / PPT);
+  constexpr int RING = !REPLAY ? 0 : ANTI ? HH_REPLAY_LDS_ANTI : P > 0 ? HH_REPLAY_LDS_DUAL : HH_REPLAY_LDS;
+  constexpr bool PIPE = HH_REPLAY_PIPE != 0;
+  // With the standard ring (32 KiB of LDS per Heston workgroup) a CU holds 4 workgroups, the chip 1024; a
+  // grid of at most half that cannot fill it, so each wave gets a deeper, pipelined ring instead
   if constexpr (RING > 0 && HH_REPLAY_LDS_DEEP > 0) {
-    if (a.n_tiles <= kDeepRingTiles) {
-      hipLaunchKernelGGL((euler_kernel<M, P, REPLAY, ANTI, PPT, HH_REPLAY_LDS_DEEP, true>), g, b, 0,
-                         s, a);
+    if (a.n_tiles <= 512u) {
+      hipLaunchKernelGGL((euler_kernel<M, P, REPLAY, ANTI, PPT, HH_REPLAY_LDS_DEEP, true>), dim3(a.n_tiles),
+                         dim3(kTile / PPT), 0, s, a);
       return (int)hipGetLastError();
     }
   }
-  hipLaunchKernelGGL((euler_kernel<M, P, REPLAY, ANTI, PPT, RING, HH_REPLAY_PIPE != 0>), g, b, 0, s, a);
+#else
+  constexpr int PPT = 1, RING = 0;  // one trajectory per lane, the register pipeline
+  constexpr bool PIPE = false;
+#endif
+  hipLaunchKernelGGL((euler_kernel<M, P, REPLAY, ANTI, PPT, RING, PIPE>), dim3(a.n_tiles), dim3(kTile / PPT), 0, s, a);
   return (int)hipGetLastError();
 }
 
@@ -1212,7 +1003,7 @@ static int launch_euler_pm(const SimArgs<P>& a, bool anti, hipStream_t s) {
 template <class M, int P>
 static int launch_euler_m(const SimArgs<P>& a, bool replay, bool anti, hipStream_t s, bool path_major = false) {
   if (replay && path_major) return launch_euler_pm<M, P>(a, anti, s);
-#if HH_ANTI_SPLIT
+#if defined(HH_REPLAY_VARIANTS) && HH_ANTI_SPLIT
   if constexpr (P == 0) {
     if (replay && anti) {
       hipLaunchKernelGGL((euler_pair_split_kernel<M>), dim3(a.n_tiles), dim3(2 * kTile), 0, s, a);

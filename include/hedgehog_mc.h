@@ -476,8 +476,16 @@ int hh_heston_exact_grid(hh_ctx* ctx, const hh_model* model, const hh_config* cf
  *     dW[tile][step][comp][HH_TILE_PATHS],  tile = path / 256, comp < ncomp (1 lognormal, 2 Heston),
  * the last tile zero-padded.  hh_replay_elems() = ceil(n_paths/256)·n_steps·ncomp·256 doubles.
  * Path-major layout (what the reference's saved noise gives per trajectory, montecarlo.jl:258,370):
- *     dW[path][step][comp]  (n_paths·n_steps·ncomp doubles); repacked on the device by
- * hh_replay_pack() (hh_mc_solve does this itself when replay_layout = HH_REPLAY_PATH_MAJOR).
+ *     dW[path][step][comp]  (n_paths·n_steps·ncomp doubles), replay_layout = HH_REPLAY_PATH_MAJOR.
+ * hh_mc_solve / hh_mc_accumulate STREAM such a buffer directly (no repacked copy) whenever a
+ * trajectory's row is a multiple of 16 bytes — n_steps·ncomp even: every Heston shape, lognormal with an
+ * even step count; the rows may start on any 16-byte boundary.  A device-resident buffer
+ * (replay_on_device) is then read in place WHILE THE KERNEL RUNS: it must stay untouched until the
+ * call's stream has completed (hh_mc_solve returns after that; after hh_mc_accumulate, synchronize) and
+ * must not alias `terminal`.  A host buffer is copied to the ctx's staging buffer first, as always.  Only
+ * the remaining case (lognormal Euler with an odd n_steps, and the one-normal-per-trajectory buffer of the
+ * exact law when it is declared path-major) is repacked into the tile-major layout first, by the kernel
+ * behind hh_replay_pack(), which callers may also use themselves.
  * For Heston the increments are the CORRELATED ones, cov = dt·[1 ρ; ρ 1] (heston.jl:18-20).
  * Exact lognormal law (HH_EXACT_LAW) in REPLAY mode: `replay` holds ONE standard normal per
  * trajectory, n_paths doubles (x = μ + σ̃·z, montecarlo.jl:302,413); no padding required.

@@ -235,6 +235,39 @@ def test_bk_long_series_beyond_the_term_cache(hhlib, term_cache):
     assert res.price == pytest.approx(ref["price"], rel=1e-5)
 
 
+@pytest.mark.parametrize("name", ["h252", "q2", "intended"])
+def test_bk_whole_trajectory_kernel_against_the_cached_chain(name):
+    """With the smallest term cache (8) every series outgrows it, so EVERY trajectory runs whole in
+    bk_fallback_kernel — a state machine around one CDF call site: secant, then the max_guess / bisection
+    ladder — while the default cache sends the same trajectories through bk_cf_kernel's secant on cached
+    terms and bk_ladder_kernel.  Two codings of inverse_cdf (sample_from_cf.jl:105-135) on the same draws:
+    the same decisions (evaluations, finishing branch, bisection iterations), the same counters, and samples
+    that differ only by where the series terms were rounded."""
+    prm = PARAMS[name]
+    n = 20_000  # ~2 % of H252's secants fail: some hundred ladders, bisections and max_guess exits
+    ctx = _ffi.Context(0)
+    try:
+        out = {}
+        for cache in (256, 8):
+            ctx.set_option(_ffi.HH_OPT_BK_TERM_CACHE, cache)
+            res, term, _ = gpu_bk(ctx, prm, n, seed=4242)
+            dec, ln = gpu_decisions(ctx, n)
+            out[cache] = (res, term, dec, ln)
+    finally:
+        ctx.close()
+    (r1, t1, d1, l1), (r2, t2, d2, l2) = out[256], out[8]
+    assert (d1 >> 31).sum() == 0 and ((d2 >> 31) == (l2 > 8)).all() and (l2 > 8).mean() > 0.99
+    np.testing.assert_array_equal(l1, l2)
+    same = (d1 & 0x7fffffff) == (d2 & 0x7fffffff)
+    assert same.mean() > 0.999, (~same).sum()  # a stopping test within rounding of its threshold may flip
+    np.testing.assert_allclose(t2[same], t1[same], rtol=1e-9)
+    n_flip = int((~same).sum())
+    for f in ("bk_newton_fail", "bk_bisect_fallback", "bk_maxguess_fallback"):
+        assert abs(int(getattr(r1, f)) - int(getattr(r2, f))) <= n_flip, f
+    assert r1.bk_newton_fail > 0 and r1.bk_bisect_fallback > 0
+    assert r2.price == pytest.approx(r1.price, rel=1e-9 if n_flip == 0 else 1e-5)
+
+
 def _bk_random_settings():
     from hypothesis import HealthCheck, settings
     # no shrinking phase: a failing example would re-run the (slow, pure-Python) oracle hundreds of times

@@ -34,26 +34,18 @@ if os.environ.get("HH_VARIANTS"):
 
 
 def build():
+    """Every variant = the product sources with -DHH_REPLAY_VARIANTS -Itools/variants (the experiment paths
+    that did not ship live there) and the variant's -D knobs, built by the product's own recipe."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_hh_build", os.path.join(ROOT, "hedgehog.jl_amd", "_build.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
     os.makedirs(VDIR, exist_ok=True)
-    procs = []
     for tag, flags in VARIANTS.items():
         out = os.path.join(VDIR, f"libhh_{tag}.so")
-        cmd = ["hipcc", "-shared", "-fPIC", "-O3", "-std=c++17", "--offload-arch=gfx950",
-               "-ffp-contract=off", *flags, *[os.path.join(CSRC, f) for f in
-                                             ("hh_api.hip", "hh_kernels.hip", "hh_bk.hip", "hh_lsm.hip", "hh_fourier.hip")],
-               "-o", out, "-Rpass-analysis=kernel-resource-usage"]
-        procs.append((tag, subprocess.Popen(cmd, stderr=subprocess.PIPE, text=True)))
-    for tag, p in procs:
-        err = p.communicate()[1]
-        if p.returncode:
-            print(err)
-            raise SystemExit(f"{tag} failed")
-        lines = err.splitlines()
-        for i, ln in enumerate(lines):
-            if os.environ.get("HH_TUNE_KERNEL", "HestonModelILi0ELb1EEELi0ELb1ELb0ELi2") in ln \
-                    and "Function Name" in ln:
-                vg = [x for x in lines[i:i + 12] if "VGPRs:" in x or "Occupancy" in x or "LDS Size" in x]
-                print(tag, " ".join(x.split("remark:")[1].strip().split("[")[0] for x in vg))
+        mod.build_library(force=True, out=out,
+                          extra_flags=["-DHH_REPLAY_VARIANTS", "-I" + os.path.join(ROOT, "tools", "variants"), *flags])
+        print(tag, "->", out)
 
 
 def run(rounds=7):
