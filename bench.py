@@ -292,6 +292,16 @@ def valu_insts():
         return {}
 
 
+def floor_insts():
+    """Operations the shipped algorithm needs per unit, one VALU instruction each (tools/floor_insts.py;
+    DESIGN.md §8) — what `frac` of a VALU row would have to be multiplied by to grade the kernel against its
+    algorithm instead of against itself."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "floor_insts.json")))
+    except Exception:
+        return {}
+
+
 def hbm_roofline(kernel, bytes_per_launch, ms, **extra):
     ach = bytes_per_launch / (ms * 1e-3) / 1e9
     r = {"bound": "hbm", "kernel": kernel, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -310,10 +320,17 @@ def valu_roofline(kernel, key, units, ms, table):
                 "note": "no instruction count for this kernel in profiles/valu_insts.json"}
     insts = ent["valu_insts_per_unit"] * units
     ach = insts * VALU_CYCLES_PER_INST / (ms * 1e-3)
-    return {"bound": "valu", "kernel": kernel, "achieved": ach / 1e9, "peak": SIMD_CYCLES_PEAK / 1e9,
-            "unit": "G SIMD-cycles/s", "frac": ach / SIMD_CYCLES_PEAK, "kernel_ms": ms,
-            "valu_insts_per_unit": ent["valu_insts_per_unit"], "unit_of_work": ent.get("unit"),
-            "insts_source": "profiles/valu_insts.json (" + ent.get("source", "rocprofv3 --pmc") + ")"}
+    r = {"bound": "valu", "kernel": kernel, "achieved": ach / 1e9, "peak": SIMD_CYCLES_PEAK / 1e9,
+         "unit": "G SIMD-cycles/s", "frac": ach / SIMD_CYCLES_PEAK, "kernel_ms": ms,
+         "valu_insts_per_unit": ent["valu_insts_per_unit"], "unit_of_work": ent.get("unit"),
+         "insts_source": "profiles/valu_insts.json (" + ent.get("source", "rocprofv3 --pmc") + ")"}
+    fl = floor_insts().get(key)
+    if fl:  # `frac` grades the kernel against its OWN instruction count; these two against its algorithm's
+        r["floor_insts_per_unit"] = fl["floor_insts_per_unit"]
+        r["frac_of_floor"] = fl["floor_insts_per_unit"] / ent["valu_insts_per_unit"]
+        r["frac_vs_floor"] = r["frac"] * r["frac_of_floor"]
+        r["floor_source"] = "profiles/floor_insts.json (tools/floor_insts.py: essential operations of the shipped algorithm, DESIGN.md §8)"
+    return r
 
 
 def single_process(args):
@@ -796,7 +813,21 @@ def main():
                 # what actually bounds a date of the induction is the SIMDs' issue rate (and ~2.5 µs of
                 # synchronisation): the same chain against the fp64-VALU issue roofline
                 "roofline_valu": valu_roofline("gbm_grid_kernel + lsm_persistent_kernel + lsm_final_kernel",
-                                               "lsm_chain", 2.0 * n_l * st_l, t_lsm, vt)},
+                                               "lsm_chain", 2.0 * n_l * st_l, t_lsm, vt),
+                # why 0.28 of the HBM floor is not wasted traffic (PMC: 1.035 x algorithmic): the induction is
+                # a chain of 100 dates, each waiting for the one before
+                "per_date_us": {
+                    "dates": st_l, "grid_kernel_ms_under_profiler": 0.405,
+                    "induction_us_per_date": (t_lsm - 0.405) * 1e3 / st_l,
+                    "budget_us": {"moment sums, statistics, power sums, decisions, totals of both record halves "
+                                  "(arithmetic of the two waves a SIMD holds)": 7.4,
+                                  "normal equations, one wave (LDL^T, rows over its lanes)": 1.35,
+                                  "all-gather of the 256 workgroups' records (from the last wave's arrival)": 1.1,
+                                  "loop overhead": 0.3},
+                    "budget_source": "in-kernel s_memrealtime stamps of a -DHH_LSM_STAMPS build, profiles/r03_g_lsm_cuts.txt "
+                                     "(box 4), r03_b_lsm_phase_stamps.txt; not collected in this run",
+                    "reading": "a date costs ~10 µs whatever the row's 16 MB cost to stream (2 µs at 8 TB/s): the row is "
+                               "read at 1.6 TB/s because the next date cannot start before this one's regression is solved"}},
             "heston_exact_grid_2e5_paths_x_12_dates": {
                 "kernel_ms": r_g.kernel_ms, "transitions_per_s": n_g * st_g / (r_g.kernel_ms * 1e-3),
                 "cf_terms_per_transition": r_g.bk_cf_terms / (n_g * st_g),
@@ -822,18 +853,33 @@ def main():
             "sample_paths": ns, "gpu": r_gpu.price, "cpu_ref": r_cpu.price,
             "rel_err": abs(r_gpu.price - r_cpu.price) / abs(r_cpu.price),
             "what": "same Wiener increments through the HIP kernel and the CPU oracle"}
+        # the CPU baseline on the metric's OWN configuration: 10^6 x 252, increments drawn per trajectory from
+        # its seed (GENERATE, what solve() runs by default) — the REPLAY sample above stays the price check
+        seeds_h = np.arange(sh.g0 + 1, sh.g0 + n_paths + 1, dtype=np.uint64) if hasattr(sh, "g0") else \
+            np.arange(1, n_paths + 1, dtype=np.uint64)
+        c_f = _ffi.make_config(_ffi.HH_HESTON, _ffi.HH_EULER_MARUYAMA, n_paths, n_steps,
+                               noise_mode=_ffi.HH_NOISE_GENERATE, seeds=seeds_h)
+        r_full, _, _ = orc.mc_solve(model, c_f, want_terminal=False)
         reps, t0 = 0, time.perf_counter()
         while True:
-            orc.mc_solve(model, c_s, want_terminal=False)
+            r_full, _, _ = orc.mc_solve(model, c_f, want_terminal=False)
             reps += 1
             el = time.perf_counter() - t0
-            if el >= args.cpu_seconds and reps >= 2:
+            if el >= args.cpu_seconds or reps >= 50:
                 break
+        r_gen = _ffi.hh_result()
+        ctx.check(lib.hh_mc_solve(h, C.byref(model), C.byref(c_f), C.byref(r_gen), None))
+        out["price_check"]["full_config_generate"] = {
+            "paths": n_paths, "gpu": r_gen.price, "cpu_ref": r_full.price,
+            "rel_err": abs(r_gen.price - r_full.price) / abs(r_full.price),
+            "what": "the whole 10^6 x 252 configuration, same seeds through both Philox / Box-Muller implementations"}
         out["cpu_baseline"] = {
-            "value": reps * ns * n_steps / el, "unit": "path-steps/s", "cores": threads,
+            "value": reps * float(n_paths) * n_steps / el, "unit": "path-steps/s", "cores": threads,
             "kind": "port",
-            "sample": "%d x (%d paths x %d steps, REPLAY of the same increments), %.1f s, "
-                      "oracle/hh_oracle.c with OpenMP over paths" % (reps, ns, n_steps, el)}
+            "sample": "%d x (the full configuration: %d paths x %d steps, GENERATE from per-trajectory seeds), %.1f s, "
+                      "oracle/hh_oracle.c with OpenMP over paths" % (reps, n_paths, n_steps, el)}
+    for c_ in list(_ffi._contexts.values()):  # nothing of the library is left for the interpreter's exit to find
+        c_.synchronize()
     print(json.dumps(out), flush=True)
 
 

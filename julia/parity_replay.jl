@@ -6,6 +6,7 @@
 # Julia + Hedgehog.jl (+ its dependencies; nothing else):
 #
 #     julia --project julia/parity_replay.jl out_dir                  # writes out_dir/manifest.json + *.bin
+#     julia --project julia/parity_replay.jl out_dir probe            # the first case only (em_split, seconds)
 #     python tools/check_reference_replay.py out_dir/manifest.json    # on the MI355X box
 #
 # Mechanism: every case simulates with the reference's OWN functions and records what its RNGs
@@ -77,6 +78,12 @@ function export_euler(name, prob, params, dynamics, N, M; antithetic = false, le
               greeks = greeks)
 end
 
+# FIRST, and alone when called as `parity_replay.jl out_dir probe` (seconds, 64 trajectories): the case that
+# settles the largest unpinned choice of the build — whether StochasticDiffEq's EM() evaluates the diffusion at
+# u or at K = u + dt·f(u) (`em_split`, SURVEY §8a-4).  8 steps of dt = 1/8 make the two forms differ by percents
+# per trajectory; tools/check_reference_replay.py prints `VERDICT em_split = 0|1 matches the reference`.
+export_euler("em_split_probe", hprob, heston, HestonDynamics(), 64, 8)
+if !(length(ARGS) >= 2 && ARGS[2] == "probe")
 export_euler("heston_euler", hprob, heston, HestonDynamics(), 20_000, 252)
 export_euler("heston_euler_antithetic", hprob, heston, HestonDynamics(), 5_000, 100; antithetic = true)
 export_euler("heston_euler_greeks", hprob, heston, HestonDynamics(), 5_000, 100;
@@ -139,6 +146,8 @@ let N = 20_000, M = 50, degree = 3
               val = wbin("lsm_put.val.bin", Float64[v for (_, v) in sol.stopping_info]),
               layout = "grid: [n_steps+1][n_paths]; tau Int32, val Float64: stopping_info")
 end
+
+end  # probe only
 
 open(joinpath(outdir, "manifest.json"), "w") do io
     print(io, "{\"generated_by\": \"julia/parity_replay.jl on Hedgehog.jl (REFERENCE output)\",\n \"cases\": [\n  ",

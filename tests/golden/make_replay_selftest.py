@@ -53,6 +53,7 @@ def euler(name, prm, dyn, n, steps, anti=0, greeks=()):
                       layout="dW: path-major [path][step][comp]; ST: [n_paths] (+ [n_paths] mirrored)"))
 
 
+euler("em_split_probe", H, 1, 64, 8)  # the manifest's first case (julia/parity_replay.jl)
 euler("heston_euler", H, 1, 500, 10)
 euler("heston_euler_antithetic", H, 1, 300, 8, anti=1)
 euler("heston_euler_greeks", H, 1, 300, 8, greeks=("S0", "V0"))

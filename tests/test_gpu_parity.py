@@ -447,8 +447,12 @@ def test_reference_replay_exchange_format(capsys):
     out = capsys.readouterr().out
     lines = {ln.split()[1]: ln for ln in out.splitlines() if ln.startswith("case ")}
     assert bad == 0, out
-    assert set(lines) == {"heston_euler", "heston_euler_antithetic", "heston_euler_greeks",
+    assert set(lines) == {"em_split_probe", "heston_euler", "heston_euler_antithetic", "heston_euler_greeks",
                           "lognormal_euler", "exact_lognormal", "broadie_kaya", "lsm_put"}
+    assert out.index("case em_split_probe") < out.index("case heston_euler ")  # the probe comes first …
+    # … and decides in one line (the fixtures were written with em_split = 1)
+    assert [ln for ln in out.splitlines() if ln.startswith("VERDICT")] and \
+        "VERDICT em_split = 1 matches the reference (em_split_probe" in out
     assert all(" OK: " in ln for ln in lines.values()), out
     h = lines["heston_euler"]
     e1 = float(h.split("em_split=1=max_rel_S=")[1].split(",")[0])
