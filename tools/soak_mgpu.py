@@ -13,9 +13,13 @@ EM, EXACT, BK = _ffi.HH_EULER_MARUYAMA, _ffi.HH_EXACT_LAW, _ffi.HH_BROADIE_KAYA
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 mgs = {g: _ffi.MultiGpu([0] * g) for g in (1, 2, 3, 5)}
+if os.environ.get("HH_SOAK_SERIAL"):
+    for mg_ in mgs.values():
+        mg_.set_option(_ffi.HH_MGPU_OPT_ENQUEUE, _ffi.HH_MGPU_ENQUEUE_SERIAL)
 bad = 0
 for it in range(N):
-    kind = rng.choice(["heston_em", "gbm_em", "gbm_exact", "heston_bk", "heston_replay_pm", "heston_replay_tile"])
+    kind = rng.choice(["heston_em", "gbm_em", "gbm_exact", "heston_bk", "heston_replay_pm", "heston_replay_tile",
+                       "gbm_exact_replay", "gbm_em_replay_pm"])
     n = int(rng.choice([rng.integers(1, 40), rng.integers(1, 3000), rng.integers(1, 40000)]))
     steps = int(rng.integers(1, 60)); anti = int(rng.random() < 0.4); g = int(rng.choice([1, 2, 3, 5]))
     duals = 0; sd = None
@@ -28,6 +32,14 @@ for it in range(N):
         m = o.make_model(sigma=0.2); c = o.make_config(GBM, EM, n, steps, antithetic=anti, seeds=seeds)
     elif kind == "gbm_exact":
         m = o.make_model(sigma=0.2); c = o.make_config(GBM, EXACT, n, 1, antithetic=anti, seeds=seeds[:1])
+    elif kind == "gbm_exact_replay":  # one normal per trajectory: shard slices start on odd elements
+        m = o.make_model(sigma=0.2)
+        c = o.make_config(GBM, EXACT, n, 1, antithetic=anti, noise_mode=_ffi.HH_NOISE_REPLAY, replay=rng.standard_normal(n),
+                          replay_layout=int(rng.integers(0, 2)))
+    elif kind == "gbm_em_replay_pm":  # odd and even rows of the reference's layout
+        m = o.make_model(sigma=0.2)
+        c = o.make_config(GBM, EM, n, steps, antithetic=anti, noise_mode=_ffi.HH_NOISE_REPLAY,
+                          replay=rng.standard_normal((n, steps)) / np.sqrt(steps), replay_layout=_ffi.HH_REPLAY_PATH_MAJOR)
     elif kind == "heston_bk":
         m = o.make_model(); c = o.make_config(HES, BK, n, 1, antithetic=0, seeds=seeds[:1])
     else:
