@@ -86,6 +86,41 @@ def main():
             print(f"  {label:8s} {mlabel:8s} first solve after 50 ms idle: phase_us {whole:.1f} total_ms {r.total_ms:.3f}")
         assert prices["serial"] == prices["threads"], prices
     mg.close()
+    lsm(a, devs)
+
+
+def lsm(a, devs):
+    """The sharded LSM induction inside the library: 2 + (dates - 1) + 1 exchanges, each followed by one launch
+    per device — the per-date host path (host ordered sum here; an RCCL all-reduce on a node)."""
+    import ctypes as C
+    import math
+    G = min(len(devs), 4)
+    n, steps, degree = 200_000, 100, 5
+    m = _ffi.make_model(S0=100.0, sigma=0.2, r=0.05, T=1.0, strike=100.0, cp=-1.0)
+    c = _ffi.make_config(_ffi.HH_LOGNORMAL, _ffi.HH_EXACT_LAW, n, steps, antithetic=1,
+                         seeds=np.arange(1, n + 1, dtype=np.uint64))
+    print(f"# hh_mgpu_lsm_solve: {2 * n} trajectories x {steps} dates, degree {degree}, {G} shards on devices {devs[:G]}, host ordered sum")
+    mg = _ffi.MultiGpu(devs[:G], _ffi.HH_MGPU_HOST_SUM)
+    prices = []
+    for mode, label in ((_ffi.HH_MGPU_ENQUEUE_SERIAL, "serial"), (_ffi.HH_MGPU_ENQUEUE_THREADS, "threads")):
+        mg.set_option(_ffi.HH_MGPU_OPT_ENQUEUE, mode)
+        res = _ffi.hh_lsm_result()
+        t = []
+        for _ in range(6):
+            mg.check(mg.lib.hh_mgpu_lsm_solve(mg.handle, C.byref(m), C.byref(c), degree, math.exp(-0.05 / steps),
+                                              C.byref(res), None, None))
+            t.append(res.total_ms)
+        prices.append(res.price)
+        print(f"  enqueue {label:8s} total_ms median {np.median(t[1:]):8.3f}  ({np.median(t[1:]) * 1e3 / (steps + 2):6.1f} us per exchange + phase)  price {res.price:.6f}")
+    assert prices[0] == prices[1]
+    one = _ffi.MultiGpu(devs[:1], _ffi.HH_MGPU_HOST_SUM)
+    res = _ffi.hh_lsm_result()
+    for _ in range(3):
+        one.check(one.lib.hh_mgpu_lsm_solve(one.handle, C.byref(m), C.byref(c), degree, math.exp(-0.05 / steps),
+                                            C.byref(res), None, None))
+    print(f"  one device (the fused persistent induction): total_ms {res.total_ms:.3f}")
+    mg.close()
+    one.close()
 
 
 if __name__ == "__main__":
