@@ -176,6 +176,31 @@ def test_cabi_header_and_library_agree():
     assert C.sizeof(_ffi.hh_config) == 10 * 4 + 2 * 4 + 2 * 8 + 2 * 8 + 4 * 8 + 2 * 4 + 2 * 8
 
 
+def test_library_shard_ranges_partition_the_ensemble():
+    """hh_mgpu_shard_range (pure host arithmetic, callable without a GPU): the ranges hh_mgpu_solve cuts —
+    [g·per, min(N, (g+1)·per)), per = ⌈N/G⌉, whole tiles for tile-major REPLAY data — cover
+    the ensemble exactly once, in order, for every G the context accepts."""
+    lib = hh.load_library()
+    a, b = C.c_uint64(), C.c_uint64()
+    for n in (1, 2, 255, 256, 257, 1000, 10_001, 1_000_000, 2**32 - 256):
+        for G in (1, 2, 3, 5, 8, 64):
+            for tile in (0, 1):
+                at, prev_len = 0, None
+                for g in range(G):
+                    lib.hh_mgpu_shard_range(n, G, g, tile, C.byref(a), C.byref(b))
+                    assert a.value == at and a.value <= b.value <= n
+                    if tile and b.value < n:
+                        assert b.value % 256 == 0
+                    if prev_len is not None:
+                        assert b.value - a.value <= prev_len  # the remainder shard is the last non-empty one
+                    prev_len, at = b.value - a.value, b.value
+                assert at == n
+    lib.hh_mgpu_shard_range(10, 0, 0, 0, C.byref(a), C.byref(b))  # bad arguments give the empty range
+    assert (a.value, b.value) == (0, 0)
+    lib.hh_mgpu_shard_range(10, 2, 5, 0, C.byref(a), C.byref(b))
+    assert (a.value, b.value) == (0, 0)
+
+
 def test_finalize_is_pure_host_arithmetic():
     lib = hh.load_library()
     from tests import oracle_ffi as o
@@ -197,6 +222,8 @@ def test_product_fails_loudly_without_gpu():
     """No CPU fallback: without a HIP device the product path raises, it does not compute."""
     with pytest.raises(hh.HedgehogMCError):
         hh.Context(0)
+    with pytest.raises(hh.HedgehogMCError):  # the several-GPU entry point likewise (HH_ERR_HIP from hh_mgpu_create)
+        _ffi.MultiGpu([0, 1])
     prob = heston_problem()
     with pytest.raises(hh.HedgehogMCError):
         hh.solve(prob, hh.MonteCarlo(hh.HestonDynamics(), hh.EulerMaruyama(),
