@@ -183,7 +183,23 @@ def main(out_path):
     out["lsm_strict_failure_seconds"] = time.perf_counter() - t0
     mg.close()
 
-    # 5. the basket through a failing collective
+    # 5. eight ranks, as on the node the driver benches (seven worker threads + the caller's)
+    host8 = _ffi.MultiGpu([0] * 8, _ffi.HH_MGPU_HOST_SUM)
+    mg8 = _ffi.MultiGpu([0] * 8)
+    out["eight_ranks_mode_is_rccl"] = mg8.reduce_mode == _ffi.HH_MGPU_REDUCE_RCCL
+    ok8 = True
+    for n8 in (7, 8, 2049, 100_003):  # fewer trajectories than ranks (idle shards), one each, ragged
+        ok8 &= european(mg8, n=n8)[:2] == european(host8, n=n8)[:2]
+    out["eight_ranks_bit_equal"] = bool(ok8)
+    out["eight_ranks_lsm_bit_equal"] = lsm(mg8, LSM_CASE)[:3] == lsm(host8, LSM_CASE)[:3]
+    stub.stub_rccl_fail_at(5, 1)
+    eu8 = european(mg8, n=100_003)
+    out["eight_ranks_failure_bit_equal"] = eu8[:2] == european(host8, n=100_003)[:2]
+    out["eight_ranks_failure_seconds"] = eu8[2]
+    mg8.close()
+    host8.close()
+
+    # 6. the basket through a failing collective
     mg = _ffi.MultiGpu(DEV)
     stub.stub_rccl_fail_at(1, 1)
     out["basket_auto_failure_bit_equal"] = basket(mg) == ref_bk

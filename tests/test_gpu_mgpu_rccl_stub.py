@@ -69,6 +69,13 @@ def test_required_rccl_returns_a_status_not_a_hang(run):
     assert run["strict_lsm_code"] == run["HH_ERR_RCCL"]
 
 
+def test_eight_ranks(run):
+    """The node's shape: eight communicators, seven worker threads; idle shards (7 trajectories over 8 ranks)."""
+    assert run["eight_ranks_mode_is_rccl"]
+    assert run["eight_ranks_bit_equal"] and run["eight_ranks_lsm_bit_equal"]
+    assert run["eight_ranks_failure_bit_equal"] and run["eight_ranks_failure_seconds"] < 1.5
+
+
 def test_lsm_induction_through_a_failing_exchange(run):
     assert run["lsm_auto_failure_bit_equal"]  # run again on the host's ordered sum
     assert run["lsm_auto_failure_orphans"] == 2
