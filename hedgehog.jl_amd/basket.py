@@ -51,8 +51,9 @@ def solve_basket(prob: BasketPricingProblem, method, ensemble: bool = False):
             sols[i] = solve_montecarlo(PricingProblem(p, prob.market_inputs), method, ensemble)
         else:
             groups.setdefault(getattr(p, "expiry", None), []).append(i)
-    ctx = _ffi.get_context(method.device)
     cfg = method.config
+    mg = _ffi.get_multi_gpu(tuple(method.devices)) if method.devices is not None else None
+    ctx = None if mg is not None else _ffi.get_context(method.device)
     for idx in groups.values():
         first = PricingProblem(payoffs[idx[0]], prob.market_inputs)
         model, c, keep, P, discount = _model_and_config(first, method)  # raises MethodError as solve
@@ -61,10 +62,22 @@ def solve_basket(prob: BasketPricingProblem, method, ensemble: bool = False):
         K = len(idx)
         strikes = (C.c_double * K)(*[float(payoffs[i].strike) for i in idx])
         cps = (C.c_double * K)(*[payoffs[i].call_put() for i in idx])
+        anti = bool(c.antithetic)
+        if mg is not None:  # ONE call, the group's simulation sharded over method.devices (hh_mgpu_solve_basket)
+            if ensemble:
+                raise ValueError("ensemble=True is not returned by the multi-GPU basket")
+            c.seeds, c.seeds_len = cfg.seeds.ctypes.data, cfg.seeds.size
+            res = (_ffi.hh_result * K)()
+            mg.check(mg.lib.hh_mgpu_solve_basket(mg.handle, C.byref(model), C.byref(c), strikes, cps, K, res))
+            for k, i in enumerate(idx):
+                sols[i] = MonteCarloSolution(PricingProblem(payoffs[i], prob.market_inputs), method,
+                                             _price_from(res[k], discount, P), None,
+                                             std_error=res[k].std_error, result=res[k])
+            del keep
+            continue
         seeds_dev = cfg.device_seeds(ctx)  # uploaded once per config, not once per objective evaluation
         c.seeds, c.seeds_on_device = seeds_dev.ptr, 1
         c.seeds_len = cfg.seeds.size
-        anti = bool(c.antithetic)
         term = np.empty(c.n_paths * (2 if anti else 1)) if ensemble else None
         res = (_ffi.hh_result * K)()
         ctx.check(ctx.lib.hh_mc_solve_basket(ctx.handle, C.byref(model), C.byref(c), strikes, cps, K,

@@ -313,6 +313,33 @@ def test_host_mirror_devices_keyword(hhlib):
     np.testing.assert_array_equal(one.ensemble[1], two.ensemble[1])
 
 
+def test_host_mirror_devices_keyword_reaches_baskets_and_batched_greeks(hhlib):
+    """solve(::BasketPricingProblem, MonteCarlo(…, devices=…)) and the fused BatchGreekProblem pass through the
+    same sharding: hh_mgpu_solve_basket / hh_mgpu_solve with dual seeds."""
+    import dataclasses
+    from datetime import date
+
+    import hedgehog_jl_amd as hh
+    ref, exp1, exp2 = date(2021, 1, 1), date(2022, 1, 1), date(2021, 7, 1)
+    mkt = hh.HestonInputs(ref, 0.03, 100.0, 0.04, 2.0, 0.04, 0.3, -0.7)
+    cfg = hh.SimulationConfig(20_000, steps=16, seeds=np.arange(1, 20_001))
+    mc = hh.MonteCarlo(hh.HestonDynamics(), hh.EulerMaruyama(), cfg)
+    mc3 = dataclasses.replace(mc, devices=(0, 0, 0))
+    payoffs = [hh.VanillaOption(k, e, hh.European(), cp, hh.Spot())
+               for e in (exp1, exp2) for k, cp in ((90.0, hh.Put()), (100.0, hh.Call()), (115.0, hh.Call()))]
+    one = hh.solve(hh.BasketPricingProblem(payoffs, mkt), mc)
+    many = hh.solve(hh.BasketPricingProblem(payoffs, mkt), mc3)
+    for a, b in zip(one.solutions, many.solutions):
+        assert b.price == pytest.approx(a.price, rel=1e-13)
+        assert b.std_error == pytest.approx(a.std_error, rel=1e-12)
+    prob = hh.PricingProblem(payoffs[1], mkt)
+    lenses = (hh.SpotLens(), hh.optic("market_inputs.V0"))
+    g1 = hh.solve(hh.BatchGreekProblem(prob, lenses), hh.ForwardAD(), mc)
+    g3 = hh.solve(hh.BatchGreekProblem(prob, lenses), hh.ForwardAD(), mc3)
+    for ln in lenses:
+        assert g3[ln] == pytest.approx(g1[ln], rel=1e-12)
+
+
 @pytest.mark.parametrize("case", [dict(model="gbm", n=6000, steps=20, degree=4, anti=1, cp=-1.0, strike=100.0, seed=7),
                                   dict(model="gbm", n=3001, steps=7, degree=2, anti=0, cp=-1.0, strike=110.0, seed=8),
                                   dict(model="heston", n=2500, steps=6, degree=3, anti=0, cp=-1.0, strike=100.0, seed=9)],
