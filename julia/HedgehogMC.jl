@@ -418,13 +418,13 @@ One simulation per expiry group, every (strike, call/put) of the group reduced o
 samples (`hh_mc_solve_basket`).  Equal to the reference's independent per-payoff solves because the
 seeds in `method.config` are fixed.  Strike partials are not carried through a basket.
 """
-function solve_basket_hip(prob::Hedgehog.BasketPricingProblem, method::MonteCarlo)
+function solve_basket_hip(prob::Hedgehog.BasketPricingProblem, method::MonteCarlo; devices = nothing)
     sols = Vector{Any}(undef, length(prob.payoffs))
     groups = Dict{Any,Vector{Int}}()
     for (i, p) in enumerate(prob.payoffs)
         push!(get!(groups, p.expiry, Int[]), i)
     end
-    ctx = context()
+    ctx = devices === nothing ? context() : multi_gpu(devices)   # devices = 0:7: hh_mgpu_solve_basket, one call
     for idx in values(groups)
         first_payoff = prob.payoffs[idx[1]]
         r = _resolve(first_payoff, prob.market_inputs, method)
@@ -435,11 +435,15 @@ function solve_basket_hip(prob::Hedgehog.BasketPricingProblem, method::MonteCarl
         seedvecs, seeds = r.seedvecs, r.seeds
         GC.@preserve seedvecs seeds strikes cps res begin
             model, config = _structs(r)
-            rc = ccall((:hh_mc_solve_basket, LIB[]), Cint,
-                       (Ptr{Cvoid}, Ref{HHModel}, Ref{HHConfig}, Ptr{Cdouble}, Ptr{Cdouble}, UInt32,
-                        Ptr{HHResult}, Ptr{Cdouble}),
-                       ctx.handle, model, config, pointer(strikes), pointer(cps), UInt32(length(idx)),
-                       pointer(res), Ptr{Cdouble}(C_NULL))
+            rc = devices === nothing ?
+                ccall((:hh_mc_solve_basket, LIB[]), Cint,
+                      (Ptr{Cvoid}, Ref{HHModel}, Ref{HHConfig}, Ptr{Cdouble}, Ptr{Cdouble}, UInt32,
+                       Ptr{HHResult}, Ptr{Cdouble}),
+                      ctx.handle, model, config, pointer(strikes), pointer(cps), UInt32(length(idx)),
+                      pointer(res), Ptr{Cdouble}(C_NULL)) :
+                ccall((:hh_mgpu_solve_basket, LIB[]), Cint,
+                      (Ptr{Cvoid}, Ref{HHModel}, Ref{HHConfig}, Ptr{Cdouble}, Ptr{Cdouble}, UInt32, Ptr{HHResult}),
+                      ctx.handle, model, config, pointer(strikes), pointer(cps), UInt32(length(idx)), pointer(res))
             rc == 0 || error("hh_mc_solve_basket failed ($rc): $(last_error(ctx))")
         end
         for (k, i) in enumerate(idx)
