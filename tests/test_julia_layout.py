@@ -129,3 +129,58 @@ def test_every_ccall_of_the_julia_layer_is_a_declared_entry_point():
         assert needle in src, needle
     abi = re.search(r"#define HH_ABI_VERSION (\d+)", open(HEADER).read()).group(1)
     assert "const HH_ABI_VERSION = " + abi in src
+
+
+def _split_top(args):
+    """'Ref{HHModel}, Ptr{Cdouble}, UInt32' -> the comma-separated items at brace depth 0"""
+    out, depth, cur = [], 0, ""
+    for ch in args:
+        if ch in "{(":
+            depth += 1
+        elif ch in "})":
+            depth -= 1
+        if ch == "," and depth == 0:
+            out.append(cur.strip())
+            cur = ""
+        else:
+            cur += ch
+    if cur.strip():
+        out.append(cur.strip())
+    return out
+
+
+def test_every_ccall_signature_matches_the_header_prototype():
+    """The Julia layer has never run (no toolchain): a ccall whose argument tuple does not match the C
+    prototype — one argument short, a Cint where the header takes a uint64_t, a value where it takes a
+    pointer — would corrupt the call silently.  Every `ccall((:hh_x, LIB[]), Ret, (T1, T2, …), …)` of
+    julia/HedgehogMC.jl is held against `Ret hh_x(T1, T2, …)` of include/hedgehog_mc.h by arity and by
+    the width / kind of each argument."""
+    hdr = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    protos = {n: (r, a) for r, n, a in
+              re.findall(r"^\s*((?:const\s+)?[\w\*]+(?:\s*\*)?)\s+(hh_\w+)\s*\(([^;{]*?)\)\s*;", hdr, re.M | re.S)}
+
+    def c_kind(t):
+        t = re.sub(r"\s+", " ", t.strip())
+        if "*" in t:
+            return "ptr"
+        base = re.sub(r"\b(const|enum|struct)\b", "", t).split()
+        base = base[0] if base else "void"   # the parameter name follows the type
+        return {"int": "i32", "int32_t": "i32", "uint32_t": "u32", "int64_t": "i64", "uint64_t": "u64",
+                "size_t": "u64", "double": "f64", "void": "void"}[base]
+
+    def jl_kind(t):
+        t = t.strip()
+        if t.startswith(("Ptr{", "Ref{")) or t in ("Cstring",):
+            return "ptr"
+        return {"Cint": "i32", "Int32": "i32", "UInt32": "u32", "Cuint": "u32", "Int64": "i64", "UInt64": "u64",
+                "Csize_t": "u64", "Cdouble": "f64", "Float64": "f64", "Cvoid": "void"}[t]
+
+    src = open(JULIA).read()
+    calls = re.findall(r"ccall\(\(:(hh_\w+),\s*LIB\[\]\),\s*([\w\{\}]+),\s*\((.*?)\),\s*\n?\s*[\w\.\(]", src, re.S)
+    assert len(calls) >= 20
+    for name, ret, args in calls:
+        c_ret, c_args = protos[name]
+        want = [] if c_args.strip() in ("", "void") else [c_kind(a) for a in _split_top(c_args)]
+        got = [jl_kind(a) for a in _split_top(args)]
+        assert got == want, (name, got, want)
+        assert jl_kind(ret) == c_kind(c_ret + " x"), (name, ret, c_ret)
