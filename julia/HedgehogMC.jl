@@ -227,6 +227,8 @@ function solve_hip(prob::PricingProblem{VanillaOption{TS,TE,European,C,Spot},I},
 end
 
 # ---- BatchGreekProblem + ForwardAD in ONE pass (greeks_problem.jl:559-568) ------------------------
+struct HipBatchTag end   # the ForwardDiff tag of the fused pass's dual numbers
+
 """
     solve_batch_greeks_hip(gprob::BatchGreekProblem, mc::MonteCarlo) -> Dict(lens => greek)
 
@@ -237,8 +239,6 @@ partial of the same `Dual{Tag,Float64,L}` — `set(prob, lens, Dual(lens(prob), 
 directions that reach the diffusion, the rest is finished in closed form (include/hedgehog_mc.h,
 `hh_model`).  Result and key type are the reference's: `Dict(lens => greek)`.
 """
-struct HipBatchTag end
-
 function solve_batch_greeks_hip(gprob::Hedgehog.BatchGreekProblem, mc::MonteCarlo)
     prob = gprob.pricing_problem
     lenses = collect(gprob.lenses)
@@ -253,7 +253,7 @@ function solve_batch_greeks_hip(gprob::Hedgehog.BatchGreekProblem, mc::MonteCarl
                                       DT(Float64(x), e)
         p = Hedgehog.set(p, lens, xd)
     end
-    price = solve_hip(p, mc; ensemble = false).price           # a Dual carrying all L partials
+    price = solve_hip(p, mc; ensemble = false, devices = DEVICES[]).price   # a Dual carrying all L partials
     parts = ForwardDiff.partials(price)
     return Dict(lens => parts[k] for (k, lens) in enumerate(lenses))
 end
@@ -463,16 +463,18 @@ struct HHLsmResult
     form::Int32; persistent_fallbacks::Int32
 end
 
+# (a docstring must sit DIRECTLY above its function: nothing between the closing quotes and `function`)
 """
-    solve_lsm_hip(prob, method::LSM)
+    solve_lsm_hip(prob, method::LSM; devices = nothing)
 
 `hh_lsm_solve`: GBM-process paths of (LognormalDynamics, BlackScholesExact), backward induction with
 polynomial regression of degree `method.degree`.  Returns an `LSMSolution` whose `stopping_info` is
 rebuilt from the (time, value) arrays and whose `spot_paths` is the (nsteps+1) x npaths matrix.
+
+`devices = 0:7`: the same solve with the trajectories sharded over those GPUs inside the library
+(`hh_mgpu_lsm_solve`: the phased induction on every device, its per-date sums all-reduced in the library);
+the spot grid is then not returned (`spot_paths` of the solution is an empty matrix).
 """
-# `devices = 0:7`: the same solve with the trajectories sharded over those GPUs inside the library
-# (hh_mgpu_lsm_solve: the phased induction on every device, its per-date sums all-reduced in the library);
-# the spot grid is then not returned (`spot_paths` of the solution is an empty matrix).
 function solve_lsm_hip(prob::PricingProblem{VanillaOption{TS,TE,Hedgehog.American,C,S},I},
                        method::Hedgehog.LSM; devices = nothing) where {TS,TE,C,S,I<:BlackScholesInputs}
     mc, m, payoff = method.mc_method, prob.market_inputs, prob.payoff
@@ -552,8 +554,10 @@ function heston_exact_paths_hip(prob::PricingProblem{P,I}, method::MonteCarlo) w
     return permutedims(spot), permutedims(var)
 end
 
+const DEVICES = Ref{Any}(nothing)   # install!(devices = 0:7): every routed solve is sharded over these GPUs
+
 """
-    install!()
+    install!(; devices = nothing)
 
 Overwrite `Hedgehog.solve(::PricingProblem{<:VanillaOption{…,European,…,Spot}}, ::MonteCarlo)`
 (montecarlo.jl:478-481) with the GPU implementation and add the fused
@@ -562,8 +566,6 @@ solvers (greeks_problem.jl:249-329) then run through the first unchanged.  `inst
 shards every routed solve over those GPUs inside the library (hh_mgpu_solve) — `solve(prob, method)`
 stays one call, as montecarlo.jl:478-493.
 """
-const DEVICES = Ref{Any}(nothing)   # install!(devices = 0:7): every routed solve is sharded over these GPUs
-
 function install!(; devices = nothing)
     ccall((:hh_abi_version, LIB[]), Cint, ()) == HH_ABI_VERSION ||
         error("libhedgehog_mc.so has another ABI version than this file ($HH_ABI_VERSION)")

@@ -184,3 +184,25 @@ def test_every_ccall_signature_matches_the_header_prototype():
         got = [jl_kind(a) for a in _split_top(args)]
         assert got == want, (name, got, want)
         assert jl_kind(ret) == c_kind(c_ret + " x"), (name, ret, c_ret)
+
+
+def test_every_docstring_sits_directly_above_a_definition():
+    """Julia attaches a top-level string literal to the NEXT expression only when nothing (no comment, no
+    blank line, no other statement) stands between them; a docstring that drifted away from its function
+    documents the wrong object or none."""
+    lines = open(JULIA).read().split("\n")
+    opened = None
+    checked = 0
+    for i, ln in enumerate(lines):
+        if ln == '"""':
+            if opened is None:
+                opened = i
+            else:
+                nxt = lines[i + 1]
+                assert re.match(r"^(function |struct |mutable struct |const |macro |abstract type |[\w!]+\()", nxt), \
+                    (i + 2, nxt)
+                opened = None
+                checked += 1
+    assert opened is None and checked >= 8
+    # the batched Greeks honour install!(devices = …) like every routed solve
+    assert "devices = DEVICES[]" in open(JULIA).read()
