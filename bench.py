@@ -775,9 +775,14 @@ def main():
         c_g = _ffi.make_config(_ffi.HH_HESTON, _ffi.HH_BROADIE_KAYA, n_g, st_g)
         c_g.seeds, c_g.seeds_on_device, c_g.seeds_len = sh.seeds.data_ptr(), 1, n_paths
         r_g = _ffi.hh_result()
-        for _ in range(2):
+        # timed like every other row (kernel_ms above): the same call for 15 ms first — this chain is VALU-bound
+        # and follows the memory-bound LSM solves — then the median of five
+        t0, t_g = time.perf_counter(), []
+        while (time.perf_counter() - t0) * 1e3 < 15.0 or len(t_g) < 5:
             ctx.check(lib.hh_heston_exact_grid(h, C.byref(model), C.byref(c_g), None, None, 0,
                                                C.byref(r_g)))
+            t_g.append(r_g.kernel_ms)
+        t_grid = float(np.median(t_g[-5:]))
         # the calibration objective's inner loop (calibration.jl:75-88): 100 Heston quotes by
         # Carr–Madan in ONE launch, plain and with the 5-parameter gradient; wall time per evaluation
         import hedgehog_jl_amd as hh
@@ -829,10 +834,10 @@ def main():
                     "reading": "a date costs ~10 µs whatever the row's 16 MB cost to stream (2 µs at 8 TB/s): the row is "
                                "read at 1.6 TB/s because the next date cannot start before this one's regression is solved"}},
             "heston_exact_grid_2e5_paths_x_12_dates": {
-                "kernel_ms": r_g.kernel_ms, "transitions_per_s": n_g * st_g / (r_g.kernel_ms * 1e-3),
+                "kernel_ms": t_grid, "transitions_per_s": n_g * st_g / (t_grid * 1e-3),
                 "cf_terms_per_transition": r_g.bk_cf_terms / (n_g * st_g),
                 "roofline": valu_roofline("bk_draw_grid + ONE bk chain over all (date, trajectory) pairs + bk_grid_spots",
-                                          "heston_exact_grid", float(n_g) * st_g, r_g.kernel_ms, vt)},
+                                          "heston_exact_grid", float(n_g) * st_g, t_grid, vt)},
         }
 
     # ---- bounded-sample checks against the CPU oracle (rank 0, N = 1 only) ------------------
