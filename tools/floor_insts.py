@@ -65,8 +65,10 @@ LSM_INDUCTION = {
     "row t-2 power sums: z = (x - mean)/std (1), z^2 .. z^2D (2D-1), masked adds (2D+1)": 1 + (2 * D - 1) + (2 * D + 1),
     "row t-1 moment sums: z (1), y = D(t) val (1), z^k y k = 1..D (D), masked adds (D+1)": 2 + D + (D + 1),
     "row t decision: z (1), Horner (D), payoff and test (3), compare (1), val / tau selects (3), discount (1)": 9 + D,
-    "wave butterflies of the 3 + 2D + (D+1) sums: 6 x (v_permlane_swap + add) each, over 64 lanes x 16 trajectories":
-        round((3 + 2 * D + D + 1) * 6 * 2 * 64 / 1024.0, 2),
+    # wave_reduce_multi (hh_lsm.hip) transposes while it reduces: P2 values cost P2/2 + P2/4 + … + 1 + log2(64/P2)
+    # exchanges, each two 32-bit swaps and one add — groups of 4, 16 and 8 values: 7 + 17 + 10 = 34 exchanges
+    "wave butterflies of the three groups (34 exchanges x 3 instructions), over 64 lanes x 16 trajectories":
+        round(34 * 3 * 64 / 1024.0, 2),
 }
 GBM_GRID = {  # gbm_grid_kernel<ANTI>: one normal and ONE exponential per antithetic PAIR and date
     "normal (half a Box–Muller pair) / 2 trajectories": round(sum(NORMAL_PAIR.values()) / 2 / 2, 2),
