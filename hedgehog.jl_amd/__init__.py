@@ -18,7 +18,8 @@ from .greeks import (BatchGreekProblem, FDBackward, FDCentral, FDForward, Finite
 from .lsm import LSM, HestonExactPaths, LSMSolution, simulate_heston_exact_paths, solve_lsm
 from .montecarlo import (AbstractPricingMethod, Antithetic, BlackScholesExact, EulerMaruyama,
                          HestonBroadieKaya, HestonDynamics, LognormalDynamics, MethodError,
-                         MonteCarlo, NoVarianceReduction, SimulationConfig, solve_montecarlo)
+                         MonteCarlo, NoVarianceReduction, NormalLaw, SimulationConfig, marginal_law,
+                         solve_montecarlo)
 from .distributed import rank_device, shard_range, solve_lsm_sharded, solve_sharded
 from .domain import (American, BlackScholesInputs, Call, European, FlatRateCurve, FlatVolSurface,
                     Forward, HestonInputs, MonteCarloSolution, PricingProblem, Put, RateCurve, Spot,

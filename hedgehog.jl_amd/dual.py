@@ -94,3 +94,10 @@ def dlog(x):
     if isinstance(x, Dual):
         return Dual(math.log(x.value), tuple(p / x.value for p in x.partials))
     return math.log(x)
+
+
+def dsqrt(x):
+    if isinstance(x, Dual):
+        r = math.sqrt(x.value)
+        return Dual(r, tuple(p / (2.0 * r) for p in x.partials))
+    return math.sqrt(x)

@@ -175,6 +175,42 @@ def _model_and_config(prob: PricingProblem, method: MonteCarlo, n_paths=None, pa
     return model, c, keep, P, discount
 
 
+@dataclass(frozen=True)
+class NormalLaw:
+    """Distributions.Normal(μ, σ) as far as the reference's callers use it (mean, std, var)."""
+    mu: Any
+    sigma: Any
+
+    def mean(self):
+        return self.mu
+
+    def std(self):
+        return self.sigma
+
+    def var(self):
+        return self.sigma * self.sigma
+
+
+def marginal_law(prob: PricingProblem, dynamics, t, compat_sqrt_alpha: bool = True):
+    """montecarlo.jl:293-303: the law of log S_t under Black–Scholes dynamics,
+    Normal(log S0 + (r − σ²/2)·√α, σ·√α) with α = yearfrac(rate.reference_date, t) — AS WRITTEN THERE (quirk
+    Q1: the mean carries √α where the lognormal law has α; identical at α = 1).  That is what a caller of
+    the reference's `marginal_law` gets, so it is this function's default; `compat_sqrt_alpha=False` gives
+    the corrected mean (r − σ²/2)·α, which is what `solve(…, MonteCarlo(…, BlackScholesExact(), …))` samples
+    from unless its method says compat_sqrt_alpha=True.  Host arithmetic only (dual numbers pass through).
+    The Heston law (:310-320, LogHestonDistribution) has no closed form to return: sample it with
+    `solve(prob, MonteCarlo(HestonDynamics(), HestonBroadieKaya(), config)).ensemble`."""
+    from .dual import dsqrt, dlog
+    m = prob.market_inputs
+    if not (isinstance(dynamics, LognormalDynamics) and isinstance(m, BlackScholesInputs)):
+        raise MethodError("marginal_law: LognormalDynamics on BlackScholesInputs (the Heston law is sampled, not returned)")
+    rate = zero_rate(m.rate, t)
+    sigma = get_vol(m.sigma, None, None)
+    alpha = yearfrac(m.rate.reference_date, t)
+    ra = dsqrt(alpha)
+    return NormalLaw(dlog(m.spot) + (rate - sigma * sigma / 2) * (ra if compat_sqrt_alpha else alpha), sigma * ra)
+
+
 def _price_from(res, discount, P):
     if P == 0:
         return res.price

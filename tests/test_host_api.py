@@ -176,6 +176,25 @@ def test_cabi_header_and_library_agree():
     assert C.sizeof(_ffi.hh_config) == 10 * 4 + 2 * 4 + 2 * 8 + 2 * 8 + 4 * 8 + 2 * 4 + 2 * 8
 
 
+def test_marginal_law_is_the_reference_formula_quirk_included():
+    """montecarlo.jl:293-303: Normal(log S0 + (r − σ²/2)·√α, σ·√α) — √α in the MEAN as written there (Q1)."""
+    import math
+    ref = hh.Date(2020, 1, 1)
+    for expiry, alpha in ((hh.Date(2021, 1, 1), 366 / 365), (hh.Date(2025, 1, 1), 1827 / 365)):
+        prob = hh.PricingProblem(hh.VanillaOption(1.0, expiry, hh.European(), hh.Put(), hh.Spot()),
+                                 hh.BlackScholesInputs(ref, 0.03, 1.0, 0.04))
+        law = hh.marginal_law(prob, hh.LognormalDynamics(), expiry)
+        assert law.std() == pytest.approx(0.04 * math.sqrt(alpha), rel=1e-15)
+        assert law.mean() == pytest.approx((0.03 - 0.04**2 / 2) * math.sqrt(alpha), rel=1e-14)
+        fixed = hh.marginal_law(prob, hh.LognormalDynamics(), expiry, compat_sqrt_alpha=False)
+        assert fixed.mean() == pytest.approx((0.03 - 0.04**2 / 2) * alpha, rel=1e-14) and fixed.var() == law.var()
+    d = hh.marginal_law(hh.PricingProblem(prob.payoff, hh.BlackScholesInputs(ref, 0.03, hh.Dual(2.0, (1.0,)), 0.04)),
+                        hh.LognormalDynamics(), expiry)
+    assert d.mean().partials == (0.5,)  # d log S0 / dS0
+    with pytest.raises(hh.MethodError):
+        hh.marginal_law(heston_problem(), hh.HestonDynamics(), expiry)
+
+
 def test_library_shard_ranges_partition_the_ensemble():
     """hh_mgpu_shard_range (pure host arithmetic, callable without a GPU): the ranges hh_mgpu_solve cuts —
     [g·per, min(N, (g+1)·per)), per = ⌈N/G⌉, whole tiles for tile-major REPLAY data — cover
