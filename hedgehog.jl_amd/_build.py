@@ -14,11 +14,8 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib", "libhedgehog_mc.so")
 OBJ = os.path.join(HERE, "lib", "obj")
 SOURCES = ["hh_api.hip", "hh_mgpu.hip", "hh_kernels.hip", "hh_bk.hip", "hh_lsm.hip", "hh_fourier.hip"]
-# (source, object, extra flags): hh_bk.hip makes two objects — see the head of that file
-UNITS = [(s, s.replace(".hip", ".o"), []) for s in SOURCES if s != "hh_bk.hip"] + [
-    ("hh_bk.hip", "hh_bk.o", ["-DHH_BK_PART=1"]),
-    ("hh_bk.hip", "hh_bk_cold.o", ["-DHH_BK_PART=2", "-mllvm", "-disable-machine-licm"]),
-]
+# (source, object, extra flags): hh_bk.hip is built without the machine-code LICM pass — see the head of that file
+UNITS = [(s, s.replace(".hip", ".o"), ["-mllvm", "-disable-machine-licm"] if s == "hh_bk.hip" else []) for s in SOURCES]
 CFLAGS = ["-fPIC", "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-Wall",
           "-Wno-unused-function"]
 LDFLAGS = ["-shared", "-fPIC", "--offload-arch=gfx950", "-ldl"]  # RCCL is bound with dlopen (hh_mgpu.hip)

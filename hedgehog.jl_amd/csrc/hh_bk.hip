@@ -24,15 +24,13 @@
 // gamma; inversion / PTRS Poisson), secant and bisection root finding.  Compute-bound (fp64 VALU);
 // loop lengths are data dependent, so lanes of a wave diverge — see DESIGN.md for the measured cost.
 //
-// This file is compiled TWICE (hedgehog.jl_amd/_build.py): HH_BK_PART = 1 holds the kernels of the chain
-// that carry the time (CF series + inversion, scan, ladder, spot rows) and the host side; HH_BK_PART = 2
-// holds the two programs made of library calls inside rejection / root-search loops — the NCχ² draws and
-// the whole-trajectory fall-back — and is built with -mllvm -disable-machine-licm.  There the machine-code
-// LICM pass lifts every fp64 literal of log / exp / lgamma / sincos / Philox out of those loops into a
-// register of its own (544 of them in the draw kernel of a grid: 512 registers, 156 spilled); without it
-// the literals stay where they are used and the same kernels take 92-128 registers with nothing in
-// scratch.  The hot kernels keep the pass (it removes instructions from their VALU-bound loops).
-// HH_BK_PART = 0 (default, single-object A/B builds): everything in one object.
+// This file is compiled with -mllvm -disable-machine-licm (hedgehog.jl_amd/_build.py).  The machine-code LICM
+// pass lifts every fp64 literal of log / exp / lgamma / sincos / Philox out of the rejection and root-search
+// loops into a register of its own: 544 of them in the draw kernel of a grid (512 registers, 156 spilled),
+// 248 registers + scratch in the fall-back kernel.  Without the pass the literals stay where they are used:
+// the draw kernels take 92-120 registers with nothing in scratch (bk_draw_grid_kernel 0.173 -> 0.111 ms), and
+// the hot CF kernel — whose Horner constants are SGPR literals already — drops from 122 to 105 registers and
+// runs 2-5 % faster (interleaved A/B, tools/bk_ab.py: config 4 0.499 -> 0.474 ms, exact grid 1.736 -> 1.706).
 #include <algorithm>
 #include <cmath>
 
@@ -40,12 +38,6 @@
 #include "hh_kernels.h"
 #include "hh_math.h"
 #include "hh_rng.h"
-
-#ifndef HH_BK_PART
-#define HH_BK_PART 0
-#endif
-#define HH_BK_HOT (HH_BK_PART == 0 || HH_BK_PART == 1)
-#define HH_BK_COLD (HH_BK_PART == 0 || HH_BK_PART == 2)
 
 namespace hh {
 
@@ -368,7 +360,6 @@ __device__ __forceinline__ void store_draws(const BkArgs& p, uint64_t i, double 
   d[3 * p.draw_stride] = VT;
 }
 
-#if HH_BK_COLD
 template <bool REPLAY>
 __global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(4, 8))) void bk_draw_kernel(const BkArgs p) {
   const uint64_t path = (uint64_t)blockIdx.x * kTile + threadIdx.x;
@@ -387,12 +378,10 @@ __global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(4, 8))) v
   }
   store_draws(p, path, Z, u, VT);
 }
-#endif
 
 // The variance chain of dates k0 … k0 + n_dates of a grid, one trajectory per thread: V of each date from the
 // one before (cheap: one non-central χ² draw), its draws left where the chain's pair (date, trajectory) =
 // b·n_row + trajectory finds them, the variance rows written on the way.
-#if HH_BK_COLD
 __global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(4, 8))) void bk_draw_grid_kernel(const BkArgs p, uint64_t n_row, uint32_t k0,
                                                              uint32_t n_dates, double* __restrict__ var_rows) {
   const uint64_t path = (uint64_t)blockIdx.x * kTile + threadIdx.x;
@@ -407,7 +396,6 @@ __global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(4, 8))) v
     V = VT;
   }
 }
-#endif
 
 // HestonCFIterator (heston.jl:165-176) and the moment heuristics (sample_from_cf.jl:31-37) of one
 // trajectory, from its start variance, its V_T and the normal quantile of its uniform
@@ -494,7 +482,6 @@ __device__ __forceinline__ double bk_finish_path(const BkArgs& p, uint64_t path,
 
 // … and the spot rows of the same dates once the chain has left ∫V of every pair in iv_out: log S chained date by
 // date, the arithmetic of bk_finish on the same operands (bit-identical with the launch-per-date form)
-#if HH_BK_HOT
 __global__ __launch_bounds__(kTile) void bk_grid_spots_kernel(const BkArgs p, uint64_t n_row, uint32_t n_dates,
                                                               const double* __restrict__ var_rows,
                                                               double* __restrict__ spot_rows) {
@@ -509,7 +496,6 @@ __global__ __launch_bounds__(kTile) void bk_grid_spots_kernel(const BkArgs p, ui
     V0 = VT;
   }
 }
-#endif
 
 // (tile_count, when given, receives the tile's number of failed | too-long trajectories: the sums of
 // the 0/1 flags in acc[2] and `n_long` — what bk_scan_kernel needs, without re-reading the ballots)
@@ -812,7 +798,6 @@ __device__ __forceinline__ void give_slot(const BkArgs& p, uint32_t slot) {
 // flight sit in VGPRs and the kernel needs 192)
 // (one tile per workgroup, NOT a grid-stride loop over the tiles: with a loop around this body the compiler
 // hoists loop-invariant table values into 215-247 registers — measured — and halves the occupancy)
-#if HH_BK_HOT
 __global__ __launch_bounds__(kTile) void bk_cf_kernel(const BkArgs p, const BkTables* __restrict__ tabs) {
   const uint32_t tile = blockIdx.x, tid = threadIdx.x;
   const uint64_t path = (uint64_t)tile * kTile + tid;
@@ -826,7 +811,6 @@ __global__ __launch_bounds__(kTile) void bk_cf_kernel(const BkArgs p, const BkTa
   invert_phase(p, tile, tid, path, live, col, h, guess, max_guess, j_stop);
   give_slot(p, slot);
 }
-#endif
 
 // exclusive prefix sums of the per-tile counts of both ballot arrays (the inversion phase leaves the counts,
 // 4 bytes per tile: a single workgroup reading the 64 bytes of ballots per tile instead is bound by
@@ -835,7 +819,6 @@ __global__ __launch_bounds__(kTile) void bk_cf_kernel(const BkArgs p, const BkTa
 // totals), then the runs are expanded.  Its last thread also leaves the copy of the argument block
 // bk_fallback_kernel reads (BkArgs::args_dev).
 [[maybe_unused]] constexpr int kScanThreads = 1024;
-#if HH_BK_HOT
 __global__ __launch_bounds__(kScanThreads) void bk_scan_kernel(const BkArgs p, uint32_t n_tiles,
                                                                uint32_t* __restrict__ prefix_a,
                                                                uint32_t* __restrict__ prefix_b) {
@@ -890,7 +873,6 @@ __global__ __launch_bounds__(kScanThreads) void bk_scan_kernel(const BkArgs p, u
     prefix_b[n_tiles] = tb;
   }
 }
-#endif
 
 // trajectory of packed work item g: the last tile t with prefix[t] <= g, then the (g - prefix[t])-th
 // set bit of its 4 ballots
@@ -923,7 +905,6 @@ __device__ __forceinline__ uint64_t packed_path(const unsigned long long* mask, 
 // same terms — into the column of the slot THIS workgroup takes.  One work item
 // per lane, no loop (see bk_cf_kernel): the grid covers the worst case (every trajectory failed) and the
 // workgroups beyond the packed list leave at once with an empty record.
-#if HH_BK_HOT
 __global__ __launch_bounds__(kTile) void bk_ladder_kernel(const BkArgs p, const BkTables* __restrict__ tabs,
                                                           uint32_t n_tiles,
                                                           const uint32_t* __restrict__ prefix) {
@@ -1003,13 +984,11 @@ __global__ __launch_bounds__(kTile) void bk_ladder_kernel(const BkArgs p, const 
   bk_store_record(acc, rec);
   give_slot(p, slot);
 }
-#endif
 
 // Fall-back kernel: trajectories whose series did not fit the cache (cf_tol far below the reference's
 // default) run whole here — secant, then the ladder if it fails — evaluating the terms beyond the
 // cache on every use, as the reference does with all of them.  Densely packed, grid stride; with
 // the default controls there are none and the launch returns at once.
-#if HH_BK_COLD
 // Every CDF evaluation of the root search — the two starting points of the secant, its iterates, the two
 // ends of the ladder, the bisection's midpoints — goes through ONE call of cdf_from_cf below, the search
 // itself being a small state machine around it (the same statements, in the same order, as
@@ -1116,11 +1095,9 @@ __global__ __launch_bounds__(kTile) void bk_fallback_kernel(
   }
   bk_store_record(acc, p.records + (size_t)(2 * n_tiles + blockIdx.x) * kRecStride);
 }
-#endif
 
 // The host-made tables into device memory: ONE lane, constant indices (a lane-indexed read of the
 // by-value argument would again send the block through scratch), the compiler batches the scalar loads.
-#if HH_BK_HOT
 __global__ __launch_bounds__(64) void bk_tables_kernel(const BkTables t, BkTables* __restrict__ dst) {
   if (threadIdx.x != 0) return;
   const double* src = reinterpret_cast<const double*>(&t);
@@ -1128,9 +1105,7 @@ __global__ __launch_bounds__(64) void bk_tables_kernel(const BkTables t, BkTable
 #pragma unroll
   for (size_t i = 0; i < sizeof(BkTables) / sizeof(double); ++i) out[i] = src[i];
 }
-#endif
 
-#if HH_BK_HOT
 __global__ __launch_bounds__(256) void fill_rows_kernel(double* __restrict__ spot0,
                                                         double* __restrict__ var0, uint64_t n,
                                                         double S0, double V0) {
@@ -1140,38 +1115,9 @@ __global__ __launch_bounds__(256) void fill_rows_kernel(double* __restrict__ spo
     var0[i] = V0;
   }
 }
-#endif
 
 }  // namespace
 
-// The launches of the part-2 kernels, callable from the part-1 object: the argument block travels as bytes
-// (BkArgs is a type of this file's anonymous namespace in either object; one source, one layout).
-void bk_cold_draw(const void* args, uint32_t n_tiles, bool replay, hipStream_t s);
-void bk_cold_draw_grid(const void* args, uint32_t row_tiles, uint64_t n_row, uint32_t k0, uint32_t n_dates,
-                       double* var_rows, hipStream_t s);
-void bk_cold_fallback(const void* args_dev, const void* tabs_dev, uint32_t n_tiles, const uint32_t* prefix_long,
-                      hipStream_t s);
-#if HH_BK_COLD
-void bk_cold_draw(const void* args, uint32_t n_tiles, bool replay, hipStream_t s) {
-  const BkArgs& a = *static_cast<const BkArgs*>(args);
-  if (replay)
-    hipLaunchKernelGGL(bk_draw_kernel<true>, dim3(n_tiles), dim3(kTile), 0, s, a);
-  else
-    hipLaunchKernelGGL(bk_draw_kernel<false>, dim3(n_tiles), dim3(kTile), 0, s, a);
-}
-void bk_cold_draw_grid(const void* args, uint32_t row_tiles, uint64_t n_row, uint32_t k0, uint32_t n_dates,
-                       double* var_rows, hipStream_t s) {
-  hipLaunchKernelGGL(bk_draw_grid_kernel, dim3(row_tiles), dim3(kTile), 0, s, *static_cast<const BkArgs*>(args), n_row,
-                     k0, n_dates, var_rows);
-}
-void bk_cold_fallback(const void* args_dev, const void* tabs_dev, uint32_t n_tiles, const uint32_t* prefix_long,
-                      hipStream_t s) {
-  hipLaunchKernelGGL(bk_fallback_kernel, dim3(kHeavyGrid), dim3(kTile), 0, s, static_cast<const BkArgs*>(args_dev),
-                     static_cast<const BkTables*>(tabs_dev), n_tiles, prefix_long);
-}
-#endif
-
-#if HH_BK_HOT
 constexpr size_t kSlotBitmapBytes = 8 * 128 + 128;  // one 128-byte line per XCD (kXcds = 8) + the side-store counter's
 
 // series terms cached per column: term_cache (HH_OPT_BK_TERM_CACHE; 0 = kBkTermCacheDefault).  The columns
@@ -1313,7 +1259,8 @@ void bk_chain(const BkArgs& a, const BkLayout& L, hipStream_t s) {
   hipLaunchKernelGGL(bk_cf_kernel, g, b, 0, s, a, tabs);
   hipLaunchKernelGGL(bk_scan_kernel, dim3(1), dim3(kScanThreads), 0, s, a, L.n_tiles, L.prefix, L.prefix_long);
   hipLaunchKernelGGL(bk_ladder_kernel, g, b, 0, s, a, tabs, L.n_tiles, L.prefix);
-  bk_cold_fallback(a.args_dev, tabs, L.n_tiles, L.prefix_long, s);
+  hipLaunchKernelGGL(bk_fallback_kernel, dim3(kHeavyGrid), b, 0, s,
+                     static_cast<const BkArgs*>(a.args_dev), tabs, L.n_tiles, L.prefix_long);
 }
 
 }  // namespace
@@ -1331,7 +1278,11 @@ int launch_bk(const hh_model& m, const hh_config& c, const DevicePtrs& ptr, hipS
   if (rc) return rc;
   a.replay = c.noise_mode == HH_NOISE_REPLAY ? ptr.replay : nullptr;
   if ((rc = bk_tables(a, L, ptr, s, upload_tables))) return rc;
-  bk_cold_draw(&a, L.n_tiles, a.replay != nullptr, s);
+  const dim3 g(L.n_tiles), b(kTile);
+  if (a.replay)
+    hipLaunchKernelGGL(bk_draw_kernel<true>, g, b, 0, s, a);
+  else
+    hipLaunchKernelGGL(bk_draw_kernel<false>, g, b, 0, s, a);
   bk_chain(a, L, s);
   return (int)hipGetLastError();
 }
@@ -1372,13 +1323,11 @@ int launch_bk_grid(const hh_model& m, const hh_config& c, const DevicePtrs& ptr,
   a.iv_out = a.iv_store;
   if ((rc = bk_tables(a, L, ptr, s, upload_tables))) return rc;
   const dim3 rows(tiles_for(n_row)), b(kTile);
-  bk_cold_draw_grid(&a, rows.x, n_row, k0, n_dates, var_rows, s);
+  hipLaunchKernelGGL(bk_draw_grid_kernel, rows, b, 0, s, a, n_row, k0, n_dates, var_rows);
   bk_chain(a, L, s);
   hipLaunchKernelGGL(bk_grid_spots_kernel, rows, b, 0, s, a, n_row, n_dates,
                      static_cast<const double*>(var_rows), spot_rows);
   return (int)hipGetLastError();
 }
-
-#endif  // HH_BK_HOT
 
 }  // namespace hh

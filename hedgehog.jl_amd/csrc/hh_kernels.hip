@@ -333,33 +333,6 @@ __attribute__((amdgpu_waves_per_eu(REPLAY ? HH_REPLAY_MINW : 1,
 #else
     constexpr int kChunk = (P == 0 && !ANTI) ? HH_REPLAY_CHUNK_PRICE : HH_REPLAY_CHUNK_PPT1;
 #endif
-    [[maybe_unused]] Vec A[kChunk][NC], B[kChunk][NC];
-
-    auto load = [&](Vec(&buf)[kChunk][NC], uint32_t s0) {
-#pragma unroll
-      for (int u = 0; u < kChunk; ++u) {
-        if (s0 + u < n_steps) {
-#pragma unroll
-          for (int c = 0; c < NC; ++c)
-            buf[u][c] = stream_load<Vec>(base + ((size_t)(s0 + u) * NC + c) * kTile);
-        }
-      }
-    };
-    auto compute = [&](const Vec(&buf)[kChunk][NC], uint32_t s0) {
-#pragma unroll
-      for (int u = 0; u < kChunk; ++u) {
-        if (s0 + u < n_steps) {
-#pragma unroll
-          for (int j = 0; j < PPT; ++j) {
-            const double d1 = VecOf<PPT>::get(buf[u][0], j);
-            const double d2 = NC > 1 ? VecOf<PPT>::get(buf[u][NC - 1], j) : 0.0;
-            M::step(st[j], a, d1, d2);
-            if constexpr (ANTI) M::step(sa[j], a, -d1, -d2);  // montecarlo.jl:258: -W
-          }
-        }
-      }
-    };
-
     // Two register chunks, load(B) || compute(A), with the occupancy capped by amdgpu_waves_per_eu (see
     // HH_REPLAY_MAXW above): 8 waves per CU for the price-only kernel, 12 for the dual-partial kernels,
     // uncapped for the antithetic one (measurements: DESIGN.md §5, tools/tune_replay.py,
