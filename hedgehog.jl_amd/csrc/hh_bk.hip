@@ -798,6 +798,8 @@ __device__ __forceinline__ void give_slot(const BkArgs& p, uint32_t slot) {
 // flight sit in VGPRs and the kernel needs 192)
 // (one tile per workgroup, NOT a grid-stride loop over the tiles: with a loop around this body the compiler
 // hoists loop-invariant table values into 215-247 registers — measured — and halves the occupancy)
+// (occupancy is not what bounds this kernel: forced to 5 waves per SIMD — 95 registers, 10 spilled — it runs as at
+// its natural 4, at 6 it spills 66 and takes 1.5 x the time: interleaved A/B of round 4)
 __global__ __launch_bounds__(kTile) void bk_cf_kernel(const BkArgs p, const BkTables* __restrict__ tabs) {
   const uint32_t tile = blockIdx.x, tid = threadIdx.x;
   const uint64_t path = (uint64_t)tile * kTile + tid;
