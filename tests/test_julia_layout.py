@@ -206,3 +206,59 @@ def test_every_docstring_sits_directly_above_a_definition():
     assert opened is None and checked >= 8
     # the batched Greeks honour install!(devices = …) like every routed solve
     assert "devices = DEVICES[]" in open(JULIA).read()
+
+
+# ---- block balance of the Julia sources (no Julia here: a missing `end` must show up on the CPU) ------------------
+_JL_OPEN = {"function","if","for","while","let","do","begin","struct","module","try","macro","quote","baremodule"}
+def _jl_strip(src):
+    # remove triple-quoted strings, then ordinary strings, then comments
+    src = re.sub(r'"""(?:.|\n)*?"""', '""', src)
+    out=[]
+    for line in src.split("\n"):
+        res=""; i=0; instr=False
+        while i < len(line):
+            ch=line[i]
+            if instr:
+                if ch=="\\": i+=2; continue
+                if ch=='"': instr=False
+                i+=1; continue
+            if ch=='"': instr=True; res+='""'; i+=1; continue
+            if ch=="'" and i+2 < len(line) and line[i+2]=="'": res+="' '"; i+=3; continue
+            if ch=="#": break
+            res+=ch; i+=1
+        out.append(res)
+    return out
+def _jl_block_balance(path):
+    lines=_jl_strip(open(path).read())
+    stack=[]; depth=0
+    for ln,line in enumerate(lines,1):
+        for tok in re.finditer(r"[A-Za-z_@!][A-Za-z_0-9!]*|[\[\]\(\)\{\}]", line):
+            t=tok.group(0)
+            if t in "[({": depth+=1; continue
+            if t in "])}": depth-=1; continue
+            if depth>0: continue                      # generators / comprehensions / a[end]
+            prev=line[:tok.start()].rstrip()
+            if t=="mutable": continue
+            if t in _JL_OPEN:
+                if prev.endswith(".") or prev.endswith(":"): continue    # x.begin / :if symbols
+                stack.append((t,ln))
+            elif t=="end":
+                if not stack: return f"{path}:{ln}: unmatched end"
+                stack.pop()
+        if depth<0: return f"{path}:{ln}: bracket underflow"
+    if stack: return f"{path}: unclosed {stack[-1]}"
+    if depth: return f"{path}: bracket depth {depth} at EOF"
+    return None
+
+
+def test_julia_sources_have_balanced_blocks(tmp_path):
+    """function / if / for / let / do / begin / struct / module … `end`, brackets and string quotes of both Julia
+    files pair up (generators, comprehensions and `a[end]` inside brackets are skipped); a copy with one `end`
+    removed is caught."""
+    root = os.path.dirname(JULIA)
+    for name in ("HedgehogMC.jl", "parity_replay.jl"):
+        assert _jl_block_balance(os.path.join(root, name)) is None
+    src = open(os.path.join(root, "parity_replay.jl")).read()
+    bad = tmp_path / "bad.jl"
+    bad.write_text(src.replace("end  # probe only", "", 1))
+    assert src != bad.read_text() and _jl_block_balance(str(bad)) is not None
