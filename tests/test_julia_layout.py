@@ -262,3 +262,23 @@ def test_julia_sources_have_balanced_blocks(tmp_path):
     bad = tmp_path / "bad.jl"
     bad.write_text(src.replace("end  # probe only", "", 1))
     assert src != bad.read_text() and _jl_block_balance(str(bad)) is not None
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/src"), reason="the reference sources are only in the build container")
+def test_every_hedgehog_name_the_julia_layer_uses_exists_in_the_reference():
+    """`Hedgehog.X` and the names of `import Hedgehog: …` in julia/*.jl against the definitions in the reference's
+    source text (struct / function / abstract type / const / assignment / re-imported names)."""
+    import glob
+    root = os.path.dirname(JULIA)
+    src = open(JULIA).read() + open(os.path.join(root, "parity_replay.jl")).read()
+    names = set(re.findall(r"Hedgehog\.([A-Za-z_]\w*!?)", src)) - {"jl"}
+    imp = re.search(r"import Hedgehog: (.*?)\n\n", src, re.S).group(1)
+    names |= {n.strip() for n in re.sub(r"\s+", " ", imp).split(",")}
+    ref = "\n".join(open(f).read() for f in glob.glob("/root/reference/src/**/*.jl", recursive=True))
+    missing = []
+    for n in sorted(names):
+        e = re.escape(n)
+        if not re.search(rf"(struct\s+{e}\b|function\s+{e}\b|^\s*{e}\s*\(|abstract type\s+{e}\b|const\s+{e}\b|"
+                         rf"^\s*{e}\s*=|import \w+: .*\b{e}\b)", ref, re.M):
+            missing.append(n)
+    assert len(names) >= 25 and not missing, missing
