@@ -324,6 +324,14 @@ def valu_roofline(kernel, key, units, ms, table):
          "unit": "G SIMD-cycles/s", "frac": ach / SIMD_CYCLES_PEAK, "kernel_ms": ms,
          "valu_insts_per_unit": ent["valu_insts_per_unit"], "unit_of_work": ent.get("unit"),
          "insts_source": "profiles/valu_insts.json (" + ent.get("source", "rocprofv3 --pmc") + ")"}
+    try:  # the clock the chip sustains under this kernel (a PMC pass on file): `frac` is against the 2.4 GHz maximum
+        clk = json.load(open(os.path.join(ROOT, "profiles", "sustained_clock.json"))).get(key)
+    except Exception:
+        clk = None
+    if clk:
+        r["sustained_clock_mhz"] = clk["clock_mhz"]
+        r["frac_at_sustained_clock"] = r["frac"] * 2400.0 / clk["clock_mhz"]
+        r["clock_source"] = "profiles/sustained_clock.json (rocprofv3 --pmc GRBM_GUI_ACTIVE / 8 XCDs / kernel duration; not collected in this run)"
     fl = floor_insts().get(key)
     if fl:  # `frac` grades the kernel against its OWN instruction count; these two against its algorithm's
         r["floor_insts_per_unit"] = fl["floor_insts_per_unit"]
