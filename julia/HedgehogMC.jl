@@ -120,6 +120,62 @@ last_error(mg::MultiGpu) = unsafe_string(ccall((:hh_mgpu_last_error, LIB[]), Cst
 "`:rccl` or `:host` — how this context combines the shards' accumulator vectors"
 reduce_mode(mg::MultiGpu) = ccall((:hh_mgpu_reduce_mode, LIB[]), Cint, (Ptr{Cvoid},), mg.handle) == 1 ? :rccl : :host
 
+# ---- a config's seeds on the device, once ---------------------------------------------------------
+# Repeated solves on one SimulationConfig (finite-difference Greeks, calibration loops) would move its
+# seed vector to the GPU again at every call: 8 MB per 10^6 trajectories, about a third of the time of a
+# GENERATE solve of that size.  The device copy is kept, keyed by the IDENTITY of `config.seeds` and
+# checked against its length and a fingerprint of 64 strided elements (+ the last): a vector mutated in
+# place between two solves in a way that leaves all of those unchanged is not noticed — `forget_seeds!()`
+# drops every copy.  At most 8 vectors are kept.
+mutable struct DeviceSeeds
+    ptr::Ptr{Cvoid}
+    n::Int
+    print::UInt64
+    ctx::Context
+end
+const SEED_CACHE = IdDict{Any,DeviceSeeds}()
+
+function _fingerprint(v::Vector{UInt64})
+    h = hash(length(v))
+    isempty(v) && return h
+    for i in 1:max(1, length(v) ÷ 64):length(v)
+        h = hash(v[i], h)
+    end
+    return hash(v[end], h)
+end
+
+function forget_seeds!()
+    for e in values(SEED_CACHE)
+        ccall((:hh_device_free, LIB[]), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), e.ctx.handle, e.ptr)
+    end
+    empty!(SEED_CACHE)
+    return nothing
+end
+
+function _device_seeds(ctx::Context, host::Vector{UInt64}, key)
+    fp = _fingerprint(host)
+    e = get(SEED_CACHE, key, nothing)
+    if e !== nothing && e.n == length(host) && e.print == fp && e.ctx === ctx
+        return e.ptr
+    end
+    length(SEED_CACHE) >= 8 && forget_seeds!()
+    if e !== nothing && haskey(SEED_CACHE, key)      # a stale copy of this very vector
+        ccall((:hh_device_free, LIB[]), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), e.ctx.handle, e.ptr)
+        delete!(SEED_CACHE, key)
+    end
+    p = Ref{Ptr{Cvoid}}(C_NULL)
+    rc = ccall((:hh_device_malloc, LIB[]), Cint, (Ptr{Cvoid}, Csize_t, Ref{Ptr{Cvoid}}),
+               ctx.handle, 8 * length(host), p)
+    rc == 0 || error("hh_device_malloc failed ($rc): $(last_error(ctx))")
+    GC.@preserve host begin
+        rc = ccall((:hh_memcpy_h2d, LIB[]), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Csize_t),
+                   ctx.handle, p[], pointer(host), 8 * length(host))
+    end
+    rc == 0 || error("hh_memcpy_h2d failed ($rc): $(last_error(ctx))")
+    SEED_CACHE[key] = DeviceSeeds(p[], length(host), fp, ctx)
+    return p[]
+end
+
 # ---- dual-number plumbing (greeks_problem.jl:258-260) ------------------------------------------
 _val(x) = ForwardDiff.value(x)
 _npartials(x) = x isa ForwardDiff.Dual ? ForwardDiff.npartials(x) : 0
@@ -157,9 +213,9 @@ function _resolve(payoff, m, method::MonteCarlo)
     P = maximum(_npartials, scal)
     P <= HH_MAX_PARTIALS || error("at most $HH_MAX_PARTIALS partials per solve")
     seedvecs = [_partials(x, P) for x in scal]
-    seeds = convert(Vector{UInt64}, cfg.seeds .% UInt64)
+    seeds = cfg.seeds isa Vector{UInt64} ? cfg.seeds : convert(Vector{UInt64}, cfg.seeds .% UInt64)
     anti = cfg.variance_reduction isa Antithetic
-    return (; dynamics, strategy, scal, rho = Float64(rho), T = Float64(T), P, seedvecs, seeds, anti,
+    return (; seeds_key = cfg.seeds, dynamics, strategy, scal, rho = Float64(rho), T = Float64(T), P, seedvecs, seeds, anti,
             n = Int(cfg.trajectories), steps = Int(cfg.steps), cp = payoff.call_put(),
             DT = _dualtype(scal...))
 end
@@ -171,16 +227,18 @@ end
 function _structs(r; em_split::Bool = true, compat_sqrt_alpha::Bool = false,
                   replay::Union{Nothing,Vector{Float64}} = nothing,
                   replay_layout::Int32 = HH_REPLAY_PATH_MAJOR,
-                  n_paths::Int = r.n, path_offset::Int = 0, seed_offset::Int = 0)
+                  n_paths::Int = r.n, path_offset::Int = 0, seed_offset::Int = 0,
+                  seeds_dev::Ptr{Cvoid} = C_NULL)
     ptr(i) = (r.P == 0 || all(iszero, r.seedvecs[i])) ? Ptr{Cdouble}(C_NULL) : pointer(r.seedvecs[i])
     v = map(_val, r.scal)
     model = HHModel(v[1], v[2], v[3], v[4], v[5], r.rho, v[6], v[7], r.T, v[8], r.cp,
                     ptr(1), ptr(2), ptr(3), ptr(4), ptr(5), ptr(6), ptr(7), ptr(8))
     noise = replay === nothing ? HH_NOISE_GENERATE : HH_NOISE_REPLAY
     config = HHConfig(Int32(r.dynamics), Int32(r.strategy), Int32(r.anti), Int32(em_split),
-                      Int32(compat_sqrt_alpha), noise, replay_layout, Int32(0), Int32(0), Int32(0),
+                      Int32(compat_sqrt_alpha), noise, replay_layout, Int32(seeds_dev != C_NULL), Int32(0), Int32(0),
                       UInt32(r.steps), UInt32(r.P), UInt64(n_paths),
-                      UInt64(path_offset), pointer(r.seeds) + 8 * seed_offset,
+                      UInt64(path_offset),
+                      (seeds_dev != C_NULL ? Ptr{UInt64}(seeds_dev) : pointer(r.seeds)) + 8 * seed_offset,
                       replay === nothing ? Ptr{Cdouble}(C_NULL) : pointer(replay),
                       0.0, 0.0, 0.0, 0.0, Int32(0), Int32(0),
                       UInt64(length(r.seeds) - seed_offset),
@@ -209,8 +267,10 @@ function solve_hip(prob::PricingProblem{VanillaOption{TS,TE,European,C,Spot},I},
     ctx = devices === nothing ? context() : multi_gpu(devices)
     seedvecs, seeds = r.seedvecs, r.seeds
     rep = replay === nothing ? nothing : collect(Float64, vec(replay))   # noise replay (montecarlo.jl:258,370)
+    # one GPU, increments drawn in the kernel: the seeds are read from their device copy (made on first use)
+    sdev = (devices === nothing && rep === nothing) ? _device_seeds(ctx, seeds, r.seeds_key) : Ptr{Cvoid}(C_NULL)
     GC.@preserve seedvecs seeds terminal rep begin
-        model, config = _structs(r; em_split, compat_sqrt_alpha, replay = rep, replay_layout)
+        model, config = _structs(r; em_split, compat_sqrt_alpha, replay = rep, replay_layout, seeds_dev = sdev)
         term = ensemble ? pointer(terminal) : Ptr{Cdouble}(C_NULL)
         rc = devices === nothing ?
             ccall((:hh_mc_solve, LIB[]), Cint,
