@@ -33,17 +33,20 @@ namespace hh {
 // + two residual corrections, wrapped in a 2^±256 range scaling for arguments below 2^-767 and a
 // class test for 0/inf: 18 instructions, more than half of a Heston path-step.  This is the same
 // core sequence (so the same, correctly rounded, result for every w >= 2^-767) with the zero
-// handled by one select; a clipped variance between 0 and 2^-767 cannot change any later state.
+// handled by ONE v_min_f64 on the seed: rsq(0) = +inf would make w·y = NaN; capped at 2^1000 (every
+// rsq of a positive double is below 2^540) the whole sequence is exact zeros for w = 0 — g = 0·2^1000 = 0,
+// r = 1/2, both corrections add 0 — and untouched for w > 0.  (Before round 4: compare + two v_cndmask on
+// the result; the two instructions are 4 of the antithetic kernel's 47 per pair-step.)  A clipped
+// variance between 0 and 2^-767 cannot change any later state.
 __device__ __forceinline__ double sqrt_clipped(double w) {
 #if HH_LEAN_SQRT
-  const double y = __builtin_amdgcn_rsq(w);
+  const double y = __builtin_fmin(__builtin_amdgcn_rsq(w), 0x1p1000);
   double g = w * y, h = 0.5 * y;
   const double r = fma(-h, g, 0.5);
   g = fma(g, r, g);
   h = fma(h, r, h);
   g = fma(fma(-g, g, w), h, g);
-  g = fma(fma(-g, g, w), h, g);
-  return w > 0.0 ? g : 0.0;
+  return fma(fma(-g, g, w), h, g);
 #else
   return sqrt(w);
 #endif

@@ -48,6 +48,18 @@ HH_MATH_FN double fma_c(double p, double z, double c) {
 #endif
 }
 
+// (q & 2) ? -x : x — on the device a shift and one v_bitop3_b32 on the high word (hi ^ ((q << 30) & 0x80000000))
+// instead of and / compare / two v_cndmask; flipping the sign bit is negation, bit for bit
+HH_MATH_FN double negate_if_bit1(double x, int q) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const unsigned long long b = (unsigned long long)__double_as_longlong(x);
+  const uint32_t hi = __builtin_amdgcn_bitop3_b32((uint32_t)(b >> 32), (uint32_t)q << 30, 0x80000000u, 0x78);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | (uint32_t)b));
+#else
+  return (q & 2) ? -x : x;
+#endif
+}
+
 // sin r, cos r for |r| <= π/4 (+ rounding of the reduction), rotated into quadrant q (mod 4)
 HH_MATH_FN void sincos_reduced(double r, int q, double& sn, double& cs) {
   const double z = r * r;
@@ -69,8 +81,8 @@ HH_MATH_FN void sincos_reduced(double r, int q, double& sn, double& cs) {
   const double cr = w + (((1.0 - w) - hz) + z * (z * pc));
   const bool swap = q & 1;
   const double s0 = swap ? cr : sr, c0 = swap ? sr : cr;
-  sn = (q & 2) ? -s0 : s0;
-  cs = ((q + 1) & 2) ? -c0 : c0;
+  sn = negate_if_bit1(s0, q);
+  cs = negate_if_bit1(c0, q + 1);
 }
 
 // sin and cos of x, |x| <= 2^20 (error of the two-term reduction: |n|·2e-33)
@@ -131,9 +143,13 @@ HH_MATH_FN double log(double x) {
   int e;
   double mant = frexp(x, &e);
 #endif
-  const bool low = mant < 0x1.6a09e667f3bcdp-1;  // sqrt(1/2)
+  const int low = mant < 0x1.6a09e667f3bcdp-1;  // below sqrt(1/2): mant <- 2 mant, e <- e - 1
+#if defined(__HIP_DEVICE_COMPILE__)
+  mant = __builtin_amdgcn_ldexp(mant, low);      // one select + v_ldexp_f64 (a multiply + two selects otherwise)
+#else
   mant = low ? 2.0 * mant : mant;
-  e = low ? e - 1 : e;
+#endif
+  e -= low;
   const double f = mant - 1.0, d = mant + 1.0;
   const double r = rcp(d);
   double s = f * r;

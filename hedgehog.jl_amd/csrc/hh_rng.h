@@ -59,6 +59,13 @@ __device__ __forceinline__ double u01_fast(uint32_t lo, uint32_t hi) {
   return __longlong_as_double((long long)(0x3FF0000000000000ull | (w >> 12))) -
          0x1.fffffffffffffp-1;
 }
+// 2·u01_fast(lo, hi), exactly, in the same three instructions: the mantissa under the exponent of [2, 4),
+// (2 + k 2^-51) - (2 - 2^-52) = (k + 1/2) 2^-51
+__device__ __forceinline__ double two_u01_fast(uint32_t lo, uint32_t hi) {
+  const uint64_t w = ((uint64_t)hi << 32) | lo;
+  return __longlong_as_double((long long)(0x4000000000000000ull | (w >> 12))) -
+         0x1.fffffffffffffp+0;
+}
 
 // ---- transcendentals of the Box–Muller transform, specialised to its argument ranges ------------
 // The generic library routines cost 98 (log) + 71 (sincospi) + 22 (sqrt) VALU instructions per pair
@@ -80,9 +87,9 @@ __device__ __forceinline__ double horner(double p, double z, double c) {
 __device__ __forceinline__ double neg2_log_unit(double u) {
   double m = __builtin_amdgcn_frexp_mant(u);  // [1/2, 1)
   int e = __builtin_amdgcn_frexp_exp(u);
-  const bool lowm = m < 0x1.6a09e667f3bcdp-1;  // sqrt(1/2)
-  m = lowm ? 2.0 * m : m;
-  e = lowm ? e - 1 : e;
+  const int lowm = m < 0x1.6a09e667f3bcdp-1;  // below sqrt(1/2): m <- 2m, e <- e - 1
+  m = __builtin_amdgcn_ldexp(m, lowm);        // (one select + v_ldexp_f64; `lowm ? 2m : m` is a multiply + two selects)
+  e -= lowm;
   const double f = m - 1.0, d = m + 1.0;  // f exact
   double r = __builtin_amdgcn_rcp(d);     // hardware reciprocal + two Newton steps
   r = fma(fma(-d, r, 1.0), r, r);
@@ -90,20 +97,22 @@ __device__ __forceinline__ double neg2_log_unit(double u) {
   double s = f * r;
   s = fma(fma(-s, d, f), r, s);           // residual correction: s = f/d to < 1 ulp
   const double z = s * s;
-  double p = 0x1.af286bca1af28p-4;        // 2/19
-  p = horner(p, z, 0x1.e1e1e1e1e1e1ep-4);    // 2/17
-  p = horner(p, z, 0x1.1111111111111p-3);    // 2/15
-  p = horner(p, z, 0x1.3b13b13b13b14p-3);    // 2/13
-  p = horner(p, z, 0x1.745d1745d1746p-3);    // 2/11
-  p = horner(p, z, 0x1.c71c71c71c71cp-3);    // 2/9
-  p = horner(p, z, 0x1.2492492492492p-2);    // 2/7
-  p = horner(p, z, 0x1.999999999999ap-2);    // 2/5
-  p = horner(p, z, 0x1.5555555555555p-1);    // 2/3
+  // the polynomial of ln m = 2s + s z p(z), p = 2/3 + 2/5 z + …, with every coefficient times -2: scaling by a
+  // power of two commutes with every rounding, so -2·ln u comes out of the recombination directly — the same
+  // bits as (-2.0)·(the unscaled sum), one multiply less
+  double p = -0x1.af286bca1af28p-3;        // -2 · 2/19
+  p = horner(p, z, -0x1.e1e1e1e1e1e1ep-3);    // -2 · 2/17
+  p = horner(p, z, -0x1.1111111111111p-2);    // -2 · 2/15
+  p = horner(p, z, -0x1.3b13b13b13b14p-2);    // -2 · 2/13
+  p = horner(p, z, -0x1.745d1745d1746p-2);    // -2 · 2/11
+  p = horner(p, z, -0x1.c71c71c71c71cp-2);    // -2 · 2/9
+  p = horner(p, z, -0x1.2492492492492p-1);    // -2 · 2/7
+  p = horner(p, z, -0x1.999999999999ap-1);    // -2 · 2/5
+  p = horner(p, z, -0x1.5555555555555p+0);    // -2 · 2/3
   const double de = (double)e;
-  // ln u = e ln2_hi + (2 s + (s z p + e ln2_lo)); ln2_hi has 21 trailing zero bits (exact product)
-  const double t = fma(s * z, p, de * 1.90821492927058770002e-10);
-  const double lg = fma(de, 6.93147180369123816490e-01, fma(2.0, s, t));
-  return -2.0 * lg;
+  // -2 ln u = e (-2 ln2_hi) + (-4 s + (s z p' + e (-2 ln2_lo))); ln2_hi has 21 trailing zero bits (exact product)
+  const double t = fma(s * z, p, de * -3.81642985854117540004e-10);
+  return fma(de, -1.38629436073824763298e+00, fma(-4.0, s, t));
 }
 
 // sqrt(a) for a normal, positive a: reciprocal-square-root seed + two coupled Newton steps
@@ -117,6 +126,16 @@ __device__ __forceinline__ double sqrt_pos(double a) {
   g = fma(g, rr, g);
   h = fma(h, rr, h);
   return fma(fma(-g, g, a), h, g);
+}
+
+// (q & 2) ? -x : x as a shift and ONE v_bitop3_b32 on the high word — hi ^ ((q << 30) & 0x80000000), truth
+// table 0xF0 ^ (0xCC & 0xAA) — where `and, compare, two v_cndmask` stood: the GENERATE kernel issues one VALU
+// instruction per cycle, so the four instructions saved per pair of normals are 2.6 % of it.
+// Flipping the sign bit IS negation: not a bit of any result changes.
+__device__ __forceinline__ double negate_if_bit1(double x, int q) {
+  const unsigned long long b = (unsigned long long)__double_as_longlong(x);
+  const uint32_t hi = __builtin_amdgcn_bitop3_b32((uint32_t)(b >> 32), (uint32_t)q << 30, 0x80000000u, 0x78);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | (uint32_t)b));
 }
 
 // sin(pi t), cos(pi t) for t in (0, 2): t = q/2 + r exactly, |r| <= 1/4; Taylor in r^2
@@ -145,14 +164,14 @@ __device__ __forceinline__ void sincospi_02(double t, double& sn, double& cs) {
   const int qi = (int)q;
   const bool swap = qi & 1;
   const double s0 = swap ? cr : sr, c0 = swap ? sr : cr;
-  sn = (qi & 2) ? -s0 : s0;            // quadrants 2, 3
-  cs = ((qi + 1) & 2) ? -c0 : c0;      // quadrants 1, 2
+  sn = negate_if_bit1(s0, qi);         // quadrants 2, 3
+  cs = negate_if_bit1(c0, qi + 1);     // quadrants 1, 2
 }
 
 // Two independent N(0,1) from one Philox block (Box–Muller).
 __device__ __forceinline__ void normal_pair(const Philox4& b, double& z1, double& z2) {
   const double u1 = u01_fast(b.c0, b.c1);
-  const double t = 2.0 * u01_fast(b.c2, b.c3);  // angle / pi, in (0, 2)
+  const double t = two_u01_fast(b.c2, b.c3);  // angle / pi = 2 u2, in (0, 2)
   const double r = sqrt_pos(neg2_log_unit(u1));
   double s, c;
   sincospi_02(t, s, c);
