@@ -65,7 +65,10 @@ struct HestonModel {
   __device__ static __forceinline__ void step(State& s, const SimArgs<P>& a, double dW1,
                                               double dW2) {
     const bool pos = s.v.v > 0.0;
-    const double vp = pos ? s.v.v : 0.0;
+    // v+ = max(v, 0) as ONE v_max_f64: written `pos ? v : 0` (or fmax) the compiler first canonicalises the
+    // loop-carried v with v_max_f64 v, v, v — an instruction per path-step where the kernel issues one per cycle
+    double vp;
+    asm("v_max_f64 %0, %1, 0" : "=v"(vp) : "v"(s.v.v));
     const double th_m_v = a.theta.v - vp;
     const double Kx = fma(a.dt, fma(-0.5, vp, a.r.v), s.x.v);  // r - vp/2: the product is exact
     const double Kv = fma(a.dt, a.kappa.v * th_m_v, s.v.v);

@@ -33,12 +33,12 @@ UNIFORMS = {"two uniforms: 64-bit shift, or with the exponent, one exact fp64 su
 NEG2LOG = {  # neg2_log_unit
     "frexp mantissa / exponent": 2, "m < sqrt(1/2): compare, rescale m (select + ldexp), e - 1 with borrow": 4,
     "f = m - 1, d = m + 1": 2, "1/d: v_rcp_f64 + two Newton steps": 5, "s = f/d with residual correction": 3,
-    "z = s^2": 1, "nine Horner steps": 9, "e -> fp64": 1, "s z, e ln2_lo, three fma of the recombination": 5, "x (-2)": 1,
+    "z = s^2": 1, "nine Horner steps": 9, "e -> fp64": 1, "s z, e ln2_lo, three fma of the recombination (the -2 is in the coefficients)": 5,
 }
 SQRT_POS = {"v_rsq_f64, g, h": 3, "two coupled Newton steps": 6, "final correction": 2}
 SINCOSPI = {
     "q = rint(2t), r = t - q/2, z = r^2": 3, "sine polynomial: 7 Horner steps + r p": 8, "cosine polynomial: 8 steps": 8,
-    "q -> int, swap test, four 32-bit selects": 7, "two sign fix-ups (and / add, shift, xor)": 5,
+    "q -> int, swap test, four 32-bit selects": 7, "two sign fix-ups (shift, add, two v_bitop3 on the high words)": 4,
 }
 NORMAL_PAIR = {"Philox4x32-10": sum(PHILOX.values()), "uniforms": sum(UNIFORMS.values()),
                "-2 ln u1": sum(NEG2LOG.values()), "sqrt": sum(SQRT_POS.values()),
@@ -47,7 +47,7 @@ NORMAL_PAIR = {"Philox4x32-10": sum(PHILOX.values()), "uniforms": sum(UNIFORMS.v
 # ---- Heston Euler step (HestonModel<0, true>::step, heston.jl:7-16) -------------------------------------
 HESTON_STEP = {
     "v+ = max(v, 0); theta - v+; r - v+/2; Kx; kappa (theta - v+); Kv; w = max(Kv, 0)": 7,
-    "sqrt(w) clipped at 0: v_rsq_f64 + one coupled Newton step + two corrections (10), w > 0 select (3)": 13,
+    "sqrt(w) clipped at 0: v_rsq_f64, v_min_f64 on the seed, one coupled Newton step, two corrections": 11,
     "sigma sqrt(w); x' and v' (two fma)": 3,
 }
 GENERATE = {"two normals": sum(NORMAL_PAIR.values()),
