@@ -42,7 +42,7 @@ HH_MATH_FN cx cdiv(cx a, cx b) {
 }
 // |a| without hypot's range scaling (31 instructions): the moduli taken here (γ, ν_γ, ϕ, series
 // sums) are far from the overflow / underflow thresholds of a² + b²
-HH_MATH_FN double cabs(cx a) { return sqrt(fma(a.re, a.re, a.im * a.im)); }
+HH_MATH_FN double cabs(cx a) { return fm::sqrt_lean(fma(a.re, a.re, a.im * a.im)); }
 // sin, cos: the range-specialised pair of hh_math.h; beyond |x| = 2^20 (which no parameter set of
 // the tests reaches) its three-term reduction, good to 2^45
 HH_MATH_FN void sincos_cf(double x, double& s, double& c) {

@@ -140,10 +140,10 @@ __device__ __forceinline__ cx csqrt(cx z) {
   const double r = cabs(z);
   if (r == 0.0) return {0.0, 0.0};
   if (z.re >= 0.0) {
-    const double t = sqrt(0.5 * (r + z.re));
+    const double t = fm::sqrt_lean(0.5 * (r + z.re));
     return {t, z.im * rcp_nr(2.0 * t)};
   }
-  const double t = sqrt(0.5 * (r - z.re));
+  const double t = fm::sqrt_lean(0.5 * (r - z.re));
   return {fabs(z.im) * rcp_nr(2.0 * t), copysign(t, z.im)};
 }
 

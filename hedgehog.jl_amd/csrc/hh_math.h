@@ -35,6 +35,26 @@ HH_MATH_FN double rcp(double x) {
 #endif
 }
 
+// sqrt(w) for w >= 0 that is zero or at least 2^-767 (the moduli and half-sums of the characteristic-function
+// arithmetic: |γ|, |ν_γ|, |ϕ|): the library routine's own core sequence — v_rsq_f64, one coupled Newton step,
+// two residual corrections: the same correctly rounded result — without its 2^±256 range scaling and class
+// test (18 instructions -> 11; four square roots per CF evaluation).  Zero: rsq(0) = +inf is capped at 2^1000
+// and the whole sequence is then exact zeros (hh_kernels.hip, sqrt_clipped).  Below 2^-767 the result is merely
+// less accurate, never NaN.
+HH_MATH_FN double sqrt_lean(double w) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const double y = __builtin_fmin(__builtin_amdgcn_rsq(w), 0x1p1000);
+  double g = w * y, h = 0.5 * y;
+  const double r = fma(-h, g, 0.5);
+  g = fma(g, r, g);
+  h = fma(h, r, h);
+  g = fma(fma(-g, g, w), h, g);
+  return fma(fma(-g, g, w), h, g);
+#else
+  return sqrt(w);
+#endif
+}
+
 // p·z + c with c a literal: a three-operand v_fma_f64 reading the constant from an SGPR pair.  Left
 // to itself the compiler materialises the literal in VGPRs and uses the two-address v_fmac form
 // (2-3 VALU instructions per Horner step instead of 1; the scalar moves issue beside the VALU).
