@@ -41,7 +41,15 @@ Rank 0 prints ONE JSON line.  Besides the contract's keys it carries
 Every roofline entry: {bound, achieved, peak, unit, frac}; HBM-bound kernels price algorithmic
 bytes against 8 TB/s; VALU-bound kernels price SQ_INSTS_VALU x 4 SIMD-cycles (an fp64 FMA holds a
 SIMD's vector pipe for 4 cycles) against 1024 SIMDs x 2.4 GHz, the instruction counts being read
-from profiles/valu_insts.json (a rocprofv3 --pmc pass, file-sourced and labelled so).
+from profiles/valu_insts.json (a rocprofv3 --pmc pass, file-sourced and labelled so).  A VALU entry
+also says how far the kernel is from its ALGORITHM and from the clock the chip really holds:
+  floor_insts_per_unit, frac_of_floor (= floor / issued), frac_vs_floor (= frac x frac_of_floor):
+                  the operations the shipped algorithm needs, one instruction each (profiles/floor_insts.json)
+  sustained_clock_mhz, frac_at_sustained_clock: GRBM_GUI_ACTIVE / 8 XCDs / duration of a PMC pass on
+                  file (profiles/sustained_clock.json); `frac` itself stays against the 2.4 GHz maximum
+The LSM row carries per_date_us (where the 10 us of a date go); cpu_baseline is timed on the metric's
+own configuration (10^6 x 252, GENERATE, all host cores) and price_check.full_config_generate compares
+the two prices on it.
 """
 from __future__ import annotations
 
