@@ -1,7 +1,7 @@
 #!/bin/bash
 # Runs "label|command" lines one after the other (each under its own timeout) and stops as soon as a
 # step was killed by its timeout; any other exit code (a segfault at exit included) is recorded and the
-# next step runs.  usage: tools/run_steps.sh <outdir> <seconds> < steps.txt
+# next step runs.  usage: tools/run_steps.sh <outdir> <seconds> < tools/steps/<list>.txt   (the lists of round 4 are kept there)
 out=$1; lim=$2
 while IFS='|' read -r label cmd; do
   [ -z "$label" ] && continue
