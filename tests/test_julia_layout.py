@@ -282,3 +282,49 @@ def test_every_hedgehog_name_the_julia_layer_uses_exists_in_the_reference():
                          rf"^\s*{e}\s*=|import \w+: .*\b{e}\b)", ref, re.M):
             missing.append(n)
     assert len(names) >= 25 and not missing, missing
+
+
+def _header_constants():
+    """NAME -> int for every enumerator and integer #define of include/hedgehog_mc.h"""
+    hdr = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    out = {}
+    for body in re.findall(r"enum\s+\w+\s*\{(.*?)\}", hdr, re.S):
+        nxt = 0
+        for item in body.split(","):
+            item = item.strip()
+            if not item:
+                continue
+            m = re.match(r"(\w+)\s*(?:=\s*(-?\w+))?$", item)
+            assert m, item
+            nxt = int(m.group(2), 0) if m.group(2) else nxt
+            out[m.group(1)] = nxt
+            nxt += 1
+    for name, val in re.findall(r"^#define\s+(HH_\w+)\s+(-?\d+)\s", hdr, re.M):
+        out[name] = int(val)
+    return out
+
+
+def test_enumerators_agree_between_the_header_the_ctypes_binding_and_the_julia_layer():
+    """HH_* constants are spelled out three times (C header, _ffi.py, HedgehogMC.jl): every one that appears in a
+    binding must carry the header's value."""
+    from hedgehog_jl_amd import _ffi
+    hdr = _header_constants()
+    assert hdr["HH_MGPU_RCCL"] == 2 and hdr["HH_ERR_RCCL"] == -5 and hdr["HH_ACC_LEN"] == 16
+    seen = 0
+    for name, val in vars(_ffi).items():
+        if name.startswith("HH_") and isinstance(val, int) and name in hdr:
+            assert val == hdr[name], (name, val, hdr[name])
+            seen += 1
+    assert seen >= 30
+    jl = open(JULIA).read()
+    n_jl = 0
+    for m in re.finditer(r"^const\s+((?:HH_\w+\s*,\s*)*HH_\w+)\s*=\s*(.+?)\s*(?:#.*)?$", jl, re.M):
+        names = [x.strip() for x in m.group(1).split(",")]
+        vals = re.findall(r"(?:Int32|Cint|UInt32)?\(?\s*(-?\d+)\s*\)?", m.group(2))
+        vals = [int(v) for v in vals][:len(names)]
+        assert len(vals) == len(names), m.group(0)
+        for nm, v in zip(names, vals):
+            if nm in hdr:
+                assert v == hdr[nm], (nm, v, hdr[nm])
+                n_jl += 1
+    assert n_jl >= 10
