@@ -479,6 +479,14 @@ samples (`hh_mc_solve_basket`).  Equal to the reference's independent per-payoff
 seeds in `method.config` are fixed.  Strike partials are not carried through a basket.
 """
 function solve_basket_hip(prob::Hedgehog.BasketPricingProblem, method::MonteCarlo; devices = nothing)
+    # only what solve_hip itself prices (European vanilla payoffs on the spot, no strike partials); anything
+    # else in the basket: the reference's own loop (basket.jl:36), payoff by payoff
+    fused = all(p -> p isa VanillaOption{<:Any,<:Any,European,<:Any,Spot} && !(p.strike isa ForwardDiff.Dual),
+                prob.payoffs)
+    if !fused
+        return Hedgehog.BasketPricingSolution(
+            prob, [Hedgehog.solve(PricingProblem(p, prob.market_inputs), method) for p in prob.payoffs])
+    end
     sols = Vector{Any}(undef, length(prob.payoffs))
     groups = Dict{Any,Vector{Int}}()
     for (i, p) in enumerate(prob.payoffs)
@@ -621,8 +629,9 @@ const DEVICES = Ref{Any}(nothing)   # install!(devices = 0:7): every routed solv
 
 Overwrite `Hedgehog.solve(::PricingProblem{<:VanillaOption{…,European,…,Spot}}, ::MonteCarlo)`
 (montecarlo.jl:478-481) with the GPU implementation and add the fused
-`solve(::BatchGreekProblem, ::ForwardAD, ::MonteCarlo)`.  `GreekProblem` and `FiniteDifference`
-solvers (greeks_problem.jl:249-329) then run through the first unchanged.  `install!(devices = 0:7)`
+`solve(::BatchGreekProblem, ::ForwardAD, ::MonteCarlo)`, LSM on BlackScholesExact paths, Monte Carlo and
+Carr–Madan baskets.  `GreekProblem` and `FiniteDifference` solvers (greeks_problem.jl:249-329) then run
+through the first unchanged.  `install!(devices = 0:7)`
 shards every routed solve over those GPUs inside the library (hh_mgpu_solve) — `solve(prob, method)`
 stays one call, as montecarlo.jl:478-493.
 """
@@ -641,6 +650,19 @@ function install!(; devices = nothing)
         gprob::BatchGreekProblem{P,L}, ::ForwardAD, pricing_method::MonteCarlo,
     ) where {P,L}
         return $(solve_batch_greeks_hip)(gprob, pricing_method)
+    end
+    # LSM on the path source the reference's own LSM tests use (test/agreement/american_options.jl):
+    # LognormalDynamics + BlackScholesExact on BlackScholesInputs.  More specific than the reference's method
+    # (least_squares_montecarlo.jl:99-102) in BOTH arguments, so every other LSM combination keeps running the
+    # reference's code; same-expiry Monte Carlo baskets likewise (basket.jl:35-38 stays for other methods).
+    @eval Hedgehog function solve(
+        prob::PricingProblem{VanillaOption{TS,TE,American,C,S},I},
+        method::LSM{MonteCarlo{LognormalDynamics,BlackScholesExact,CF}},
+    ) where {TS,TE,C,S,I<:BlackScholesInputs,CF}
+        return $(solve_lsm_hip)(prob, method; devices = $(DEVICES)[])
+    end
+    @eval Hedgehog function solve(prob::BasketPricingProblem, method::MonteCarlo)
+        return $(solve_basket_hip)(prob, method; devices = $(DEVICES)[])
     end
     # the calibration objective's inner loop (calibration.jl:75-88): every quote in one launch, Dual
     # inputs (AutoForwardDiff) included
