@@ -350,7 +350,8 @@ def valu_roofline(kernel, key, units, ms, table):
 
 
 def single_process(args):
-    """ONE process, ONE host thread, N devices: every step is one hh_mgpu_solve_shards call."""
+    """ONE process, N devices: every step is ONE hh_mgpu_solve_shards call of this thread (the library
+    enqueues the shards concurrently from its per-device worker threads)."""
     devs = _device_list(args)
     if not torch.cuda.is_available() or torch.cuda.device_count() <= max(devs):
         print(f"bench.py: --single-process needs device ordinals {devs}; there is no CPU fallback",
@@ -422,8 +423,9 @@ def single_process(args):
                                "layout (hh_wiener_fill)" % (n_global if strong else args.paths, n_steps,
                                                             "in all" if strong else "per GPU"),
                    "paths_per_gpu": n0, "n_steps": n_steps, "global_paths": n_global,
-                   "parallelism": "one process, one host thread, hh_mgpu_solve_shards over %d devices, one "
-                                  "16-double all-reduce inside the library" % G},
+                   "parallelism": "one process, ONE call per step (hh_mgpu_solve_shards): the %d shards enqueued "
+                                  "concurrently by the library's per-device threads, one 16-double all-reduce "
+                                  "inside the library" % G},
         "price": res.price, "std_error": res.std_error, "analytic_carr_madan": H252_ANALYTIC,
         "roofline": dict(hbm_roofline("euler_kernel<HestonModel,REPLAY> (device %d's launches)" % devs[0],
                                       BYTES_PER_PATH_STEP * n0 * n_steps, float(np.mean(kern))),
