@@ -83,3 +83,20 @@ def test_lsm_induction_through_a_failing_exchange(run):
     assert run["lsm_auto_failure_mode_is_host"]
     assert run["lsm_strict_failure_code"] == run["HH_ERR_RCCL"]
     assert run["lsm_strict_failure_seconds"] < 1.5
+
+
+def test_bench_single_process_form_through_the_rccl_branch():
+    """What rank 0 of the driver's multi-GPU bench starts as its `single_process` block, rehearsed on one GPU:
+    bench.py --single-process over three shards with the stand-in bound — the line must say RCCL carried them."""
+    build_stub()
+    env = dict(os.environ, HEDGEHOG_MC_RCCL=STUB)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--single-process",
+                        "--devices", "0,0,0", "--steps", "3", "--warmup", "1", "--paths", "30000", "--ramp-ms", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = json.loads(next(ln for ln in p.stdout.splitlines() if ln.startswith("{")))
+    assert line["single_process"] is True and line["n_gpus"] == 3
+    assert line["reduce"] == "rccl" and line["rccl_ranks"] == 3
+    assert line["config"]["global_paths"] == 90000 and line["scaling"] == "weak"
+    assert abs(line["price"] - line["analytic_carr_madan"]) < 6 * line["std_error"] + 0.05  # Euler bias at dt = 1/252
+    assert line["value"] > 0 and line["roofline"]["launches_timed"] == 3
