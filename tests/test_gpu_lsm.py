@@ -276,3 +276,26 @@ def test_the_one_launch_form_on_a_borrowed_stream():
         assert (res.price, res.std_error) == (own.price, own.std_error)
         assert res.form == _ffi.HH_LSM_FORM_PERSISTENT and res.persistent_fallbacks == 0
     ctx.close()
+
+
+def test_lsm_beyond_the_one_launch_limit(hhlib):
+    """2.2 million trajectories (more than the 2^21 the persistent induction holds in its 256 workgroups): the
+    solve runs a launch per exercise date — the same summation tree in larger chunks — and is held to the oracle
+    on its own grid like every other size (the soak tool's bar); the persistent form is refused for this size."""
+    n, steps, degree, anti = 1_100_000, 5, 3, 1
+    seeds = np.random.default_rng(77).integers(0, 2**63, n).astype(np.uint64)
+    S0, K, r, sigma, T, cp = 100.0, 104.0, 0.06, 0.3, 1.0, -1.0
+    res, tau, val, grid, D = gpu_lsm(hhlib, S0, K, r, sigma, T, cp, seeds, steps, anti, degree)
+    assert res.n_paths_total == 2 * n > 2**21 and res.form == _ffi.HH_LSM_FORM_PER_DATE
+    ref = lsm_oracle.lsm_solve(grid, K, cp, D, degree)
+    same = tau == ref["stop_time"]
+    assert same.mean() >= 0.9995
+    np.testing.assert_allclose(val[same], ref["stop_value"][same], rtol=1e-12, atol=1e-13 * S0)
+    pay_max = np.maximum(cp * (grid - K), 0.0).max(axis=0)
+    assert abs(res.price - ref["price"]) <= float(np.sum(pay_max[~same])) / grid.shape[1] + 1e-11 * ref["price"]
+    hhlib.set_option(_ffi.HH_OPT_LSM_FORM, _ffi.HH_LSM_FORM_PERSISTENT)  # asked for explicitly: still a launch per date
+    try:
+        res2, tau2, val2, _, _ = gpu_lsm(hhlib, S0, K, r, sigma, T, cp, seeds, steps, anti, degree, want_grid=False)
+    finally:
+        hhlib.set_option(_ffi.HH_OPT_LSM_FORM, _ffi.HH_LSM_FORM_AUTO)
+    assert res2.form == _ffi.HH_LSM_FORM_PER_DATE and res2.price == res.price and (tau2 == tau).all()
