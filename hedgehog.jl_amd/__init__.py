@@ -19,7 +19,7 @@ from .lsm import LSM, HestonExactPaths, LSMSolution, simulate_heston_exact_paths
 from .montecarlo import (AbstractPricingMethod, Antithetic, BlackScholesExact, EulerMaruyama,
                          HestonBroadieKaya, HestonDynamics, LognormalDynamics, MethodError,
                          MonteCarlo, NoVarianceReduction, NormalLaw, SimulationConfig, marginal_law,
-                         solve_montecarlo)
+                         solve_montecarlo, solve_montecarlo_many)
 from .distributed import rank_device, shard_range, solve_lsm_sharded, solve_sharded
 from .domain import (American, BlackScholesInputs, Call, European, FlatRateCurve, FlatVolSurface,
                     Forward, HestonInputs, MonteCarloSolution, PricingProblem, Put, RateCurve, Spot,

@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib", "libhedgehog_mc.so")
 OBJ = os.path.join(HERE, "lib", "obj")
-SOURCES = ["hh_api.hip", "hh_mgpu.hip", "hh_kernels.hip", "hh_bk.hip", "hh_lsm.hip", "hh_fourier.hip"]
+SOURCES = ["hh_api.hip", "hh_mgpu.hip", "hh_kernels.hip", "hh_multi.hip", "hh_bk.hip", "hh_lsm.hip", "hh_fourier.hip"]
 # (source, object, extra flags): hh_bk.hip is built without the machine-code LICM pass — see the head of that file
 UNITS = [(s, s.replace(".hip", ".o"), ["-mllvm", "-disable-machine-licm"] if s == "hh_bk.hip" else []) for s in SOURCES]
 CFLAGS = ["-fPIC", "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-Wall",
@@ -67,7 +67,7 @@ def build_library(force: bool = False, extra_flags=(), out: str | None = None) -
             jobs.append([_hipcc(), "-c", *CFLAGS, *unit_flags, *extra_flags, src, "-o", obj])
     warnings = ""
     if jobs:
-        with ThreadPoolExecutor(max_workers=min(len(jobs), 6)) as ex:
+        with ThreadPoolExecutor(max_workers=min(len(jobs), 7)) as ex:
             warnings = "".join(ex.map(_run, jobs))
     _run([_hipcc(), *LDFLAGS, *objs, "-o", lib])
     if warnings.strip():

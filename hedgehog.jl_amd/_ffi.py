@@ -12,6 +12,7 @@ HH_MAX_PARTIALS = 8
 HH_LSM_PHASE_POW, HH_LSM_PHASE_INIT, HH_LSM_PHASE_STEP = 1, 2, 3
 HH_TILE_PATHS = 256
 HH_ACC_LEN = 16
+HH_MAX_MODELS = 16
 HH_ACC_SUM, HH_ACC_SUMSQ, HH_ACC_DSUM, HH_ACC_NPATHS = 0, 1, 2, 10
 
 HH_LOGNORMAL, HH_HESTON = 0, 1
@@ -75,6 +76,7 @@ HH_OPT_LSM_FORM = 1
 HH_OPT_BK_TERM_CACHE = 2
 HH_OPT_GRID_FORM = 3
 HH_OPT_LSM_SPIN_TICKS = 4
+HH_OPT_FUSE_REDUCE = 5
 HH_GRID_FORM_PER_DATE, HH_GRID_FORM_BATCHED = 0, 1
 HH_CM_GRAD_LEN = 8  # enum hh_cm_grad: S0, V0, kappa, theta, sigma, rho, r_drift, discount
 HH_LSM_FORM_PER_DATE, HH_LSM_FORM_PERSISTENT, HH_LSM_FORM_AUTO = 0, 1, 2
@@ -101,6 +103,8 @@ SYMBOLS = [
     ("hh_ctx_set_option", C.c_int, [_vp, C.c_int32, C.c_int64]),
     ("hh_mc_solve", C.c_int, [_vp, C.POINTER(hh_model), C.POINTER(hh_config), C.POINTER(hh_result), _vp]),
     ("hh_mc_accumulate", C.c_int, [_vp, C.POINTER(hh_model), C.POINTER(hh_config), _vp, _vp]),
+    ("hh_mc_solve_multi", C.c_int, [_vp, C.POINTER(hh_model), C.c_uint32, C.POINTER(hh_config), C.POINTER(hh_result), _vp]),
+    ("hh_mc_accumulate_multi", C.c_int, [_vp, C.POINTER(hh_model), C.c_uint32, C.POINTER(hh_config), _vp, _vp]),
     ("hh_mc_finalize", C.c_int, [C.POINTER(hh_model), C.POINTER(hh_config), _vp, C.POINTER(hh_result)]),
     ("hh_mc_accumulate_basket", C.c_int, [_vp, C.POINTER(hh_model), C.POINTER(hh_config), _vp, _vp, C.c_uint32, _vp, _vp]),
     ("hh_mc_solve_basket", C.c_int, [_vp, C.POINTER(hh_model), C.POINTER(hh_config), _vp, _vp, C.c_uint32, _vp, _vp]),

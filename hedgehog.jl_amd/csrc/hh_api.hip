@@ -116,6 +116,18 @@ int validate(hh_ctx* ctx, const hh_model* m, const hh_config* c) {
   return HH_OK;
 }
 
+// the record buffer of the launches that reduce their own records: every word kPoison (hh_sim.h) from the
+// allocation on — each launch's reducer leaves it that way again
+int ensure_poisoned(hh_ctx* ctx, size_t need) {
+  if (need <= ctx->frecords_cap) return HH_OK;
+  int rc = ensure(ctx, ctx->frecords, ctx->frecords_cap, need);
+  if (rc) return rc;
+  static_assert((hh::kPoison >> 32) == (hh::kPoison & 0xffffffffull), "hipMemsetD32 writes the pattern");
+  HH_HIP(ctx, hipMemsetD32Async((hipDeviceptr_t)ctx->frecords, (int)(hh::kPoison & 0xffffffffull),
+                                ctx->frecords_cap * 2, ctx->stream));
+  return HH_OK;
+}
+
 size_t replay_elems(uint64_t n_paths, uint32_t n_steps, int dynamics) {
   return (size_t)hh::tiles_for(n_paths) * n_steps * ncomp_of(dynamics) * hh::kTile;
 }
@@ -172,6 +184,7 @@ void hh_ctx_destroy(hh_ctx* ctx) {
   if (ctx->lsm_tau) (void)hipFree(ctx->lsm_tau);
   if (ctx->lsm_scratch) (void)hipFree(ctx->lsm_scratch);
   if (ctx->accum) (void)hipFree(ctx->accum);
+  if (ctx->frecords) (void)hipFree(ctx->frecords);
   if (ctx->accum_host) (void)hipHostFree(ctx->accum_host);
   for (auto& pr : ctx->tev)
     for (auto& e : pr)
@@ -230,6 +243,11 @@ int hh_ctx_set_option(hh_ctx* ctx, int32_t option, int64_t value) {
       if (value != HH_GRID_FORM_PER_DATE && value != HH_GRID_FORM_BATCHED)
         return fail(ctx, HH_ERR_INVALID, "HH_OPT_GRID_FORM: 0 (one chain per date) or 1 (dates batched)");
       ctx->grid_form = (int)value;
+      return HH_OK;
+    case HH_OPT_FUSE_REDUCE:
+      if (value != 0 && value != 1)
+        return fail(ctx, HH_ERR_INVALID, "HH_OPT_FUSE_REDUCE: 1 (records reduced by the simulation kernel) or 0 (a second kernel)");
+      ctx->fuse_reduce = (int)value;
       return HH_OK;
     default:
       return fail(ctx, HH_ERR_INVALID, "unknown option %d", option);
@@ -294,27 +312,12 @@ int hh_wiener_fill(hh_ctx* ctx, int32_t dynamics, double rho, double T, uint32_t
 // Shared body of hh_mc_accumulate / hh_mc_accumulate_basket: stage caller buffers, run the
 // simulation kernel (which also reduces the payoff of m->strike / m->cp into ctx->records) and
 // leave the terminal samples in device memory when asked.
-static int run_simulation(hh_ctx* ctx, const hh_model* m, const hh_config* c, double* terminal,
-                          bool need_terminal_dev, double** terminal_dev_out) {
+// The noise a simulation reads, in device memory: p.seeds (GENERATE) or p.replay (REPLAY), staged from the
+// caller's host buffers where needed.  tile_major_only: path-major Euler increments are repacked even where the
+// one-model kernel could stream them as they are (the several-model kernel reads the tile-major layout only).
+static int stage_noise(hh_ctx* ctx, const hh_config* c, hh::DevicePtrs& p, bool tile_major_only) {
   int rc = HH_OK;
-  const uint32_t n_tiles = hh::tiles_for(c->n_paths);
   const bool bk = c->strategy == HH_BROADIE_KAYA;
-  rc = ensure(ctx, ctx->records, ctx->records_cap,
-              (size_t)(bk ? hh::bk_record_count(c->n_paths) : n_tiles) * hh::kRecStride);
-  if (rc) return rc;
-
-  hh::DevicePtrs p{};
-  p.records = ctx->records;
-  if (bk) {
-    rc = ensure_bk_scratch(ctx, hh::bk_scratch_bytes(c->n_paths, ctx->bk_term_cache));
-    if (rc) return rc;
-    p.bk_scratch = ctx->bk_scratch;
-    p.bk_table_key = &ctx->bk_table_key;
-    p.bk_term_cache = ctx->bk_term_cache;
-    ctx->bk_last_n = c->n_paths;
-    ctx->bk_last_cache = ctx->bk_term_cache;
-  }
-
   // seeds: per-trajectory for Euler (montecarlo.jl:331), seeds[1] only for the exact laws (:456)
   if (c->noise_mode == HH_NOISE_GENERATE) {
     const size_t need = (c->strategy == HH_EULER_MARUYAMA) ? (size_t)c->n_paths : 1;
@@ -343,7 +346,7 @@ static int run_simulation(hh_ctx* ctx, const hh_model* m, const hh_config* c, do
     const uint32_t steps = (c->strategy == HH_EULER_MARUYAMA) ? c->n_steps : 1;
     const int dyn = (c->strategy == HH_EULER_MARUYAMA) ? c->dynamics : HH_LOGNORMAL;
     const size_t tile_elems = replay_elems(c->n_paths, steps, dyn);
-    if (c->replay_layout == HH_REPLAY_PATH_MAJOR && c->strategy == HH_EULER_MARUYAMA &&
+    if (c->replay_layout == HH_REPLAY_PATH_MAJOR && c->strategy == HH_EULER_MARUYAMA && !tile_major_only &&
         hh::replay_direct_path_major(steps, ncomp_of(dyn))) {
       // the reference's layout, streamed as it stands (euler_pm_kernel): no repack pass
       if (c->replay_on_device) {
@@ -382,6 +385,43 @@ static int run_simulation(hh_ctx* ctx, const hh_model* m, const hh_config* c, do
     }
   }
 
+  return HH_OK;
+}
+
+// accum_dev != NULL (and the ctx's HH_OPT_FUSE_REDUCE): the simulation kernel reduces its own records into
+// accum_dev — *reduced says whether it did (Broadie–Kaya's chain does not).  The timing slot opened here is
+// closed by end_timing() once the caller has enqueued its last kernel.
+static int run_simulation(hh_ctx* ctx, const hh_model* m, const hh_config* c, double* terminal,
+                          bool need_terminal_dev, double** terminal_dev_out, double* accum_dev = nullptr,
+                          bool* reduced = nullptr) {
+  int rc = HH_OK;
+  const uint32_t n_tiles = hh::tiles_for(c->n_paths);
+  const bool bk = c->strategy == HH_BROADIE_KAYA;
+  rc = ensure(ctx, ctx->records, ctx->records_cap,
+              (size_t)(bk ? hh::bk_record_count(c->n_paths) : n_tiles) * hh::kRecStride);
+  if (rc) return rc;
+
+  hh::DevicePtrs p{};
+  p.records = ctx->records;
+  const bool fuse = accum_dev && ctx->fuse_reduce && !bk;
+  if (fuse) {  // records in the buffer that holds the poison pattern between launches (hh_sim.h)
+    if ((rc = ensure_poisoned(ctx, (size_t)n_tiles * hh::kRecStride))) return rc;
+    p.records = ctx->frecords;
+    p.accum = accum_dev;
+  }
+  if (reduced) *reduced = fuse;
+  if (bk) {
+    rc = ensure_bk_scratch(ctx, hh::bk_scratch_bytes(c->n_paths, ctx->bk_term_cache));
+    if (rc) return rc;
+    p.bk_scratch = ctx->bk_scratch;
+    p.bk_table_key = &ctx->bk_table_key;
+    p.bk_term_cache = ctx->bk_term_cache;
+    ctx->bk_last_n = c->n_paths;
+    ctx->bk_last_cache = ctx->bk_term_cache;
+  }
+
+  if ((rc = stage_noise(ctx, c, p, false))) return rc;
+
   const size_t n_term = (size_t)c->n_paths * (c->antithetic ? 2 : 1);
   if (terminal && c->terminal_on_device) {
     p.terminal = terminal;
@@ -399,14 +439,18 @@ static int run_simulation(hh_ctx* ctx, const hh_model* m, const hh_config* c, do
   }
   if (terminal_dev_out) *terminal_dev_out = p.terminal;
 
-  const int slot = ctx->t_count % hh_ctx::kTimingSlots;
-  if (ctx->timing) HH_HIP(ctx, hipEventRecord(ctx->tev[slot][0], ctx->stream));
+  if (ctx->timing) HH_HIP(ctx, hipEventRecord(ctx->tev[ctx->t_count % hh_ctx::kTimingSlots][0], ctx->stream));
   if (c->strategy == HH_BROADIE_KAYA)
     HH_HIP(ctx, hh::launch_bk(*m, *c, p, ctx->stream));
   else
     HH_HIP(ctx, hh::launch_simulation(*m, *c, p, ctx->stream));
+  return HH_OK;
+}
+
+// the call's last kernel has been enqueued: close the timing slot run_simulation opened
+static int end_timing(hh_ctx* ctx) {
   if (ctx->timing) {
-    HH_HIP(ctx, hipEventRecord(ctx->tev[slot][1], ctx->stream));
+    HH_HIP(ctx, hipEventRecord(ctx->tev[ctx->t_count % hh_ctx::kTimingSlots][1], ctx->stream));
     ++ctx->t_count;
   }
   return HH_OK;
@@ -430,13 +474,114 @@ int hh_mc_accumulate(hh_ctx* ctx, const hh_model* m, const hh_config* c, double*
   if (rc) return rc;
   if (!accum_dev) return fail(ctx, HH_ERR_INVALID, "accum_dev is NULL");
   HH_HIP(ctx, hipSetDevice(ctx->device));
-  rc = run_simulation(ctx, m, c, terminal, false, nullptr);
+  bool reduced = false;
+  rc = run_simulation(ctx, m, c, terminal, false, nullptr, accum_dev, &reduced);
   if (rc) return rc;
-  const uint32_t n_rec = c->strategy == HH_BROADIE_KAYA ? hh::bk_record_count(c->n_paths)
-                                                        : hh::tiles_for(c->n_paths);
-  HH_HIP(ctx, hh::launch_reduce_records(ctx->records, n_rec, (double)c->n_paths, accum_dev,
-                                        ctx->stream, 1, m, c));
+  if (!reduced) {
+    const uint32_t n_rec = c->strategy == HH_BROADIE_KAYA ? hh::bk_record_count(c->n_paths)
+                                                          : hh::tiles_for(c->n_paths);
+    HH_HIP(ctx, hh::launch_reduce_records(ctx->records, n_rec, (double)c->n_paths, accum_dev,
+                                          ctx->stream, 1, m, c));
+  }
+  if ((rc = end_timing(ctx))) return rc;
   return copy_back_terminal(ctx, c, terminal);
+}
+
+// sizes of the passes n_models are run in: at most kMaxModelsPerPass models per launch, never one alone
+static int next_pass(int remaining) {
+  if (remaining <= hh::kMaxModelsPerPass) return remaining;
+  return remaining == hh::kMaxModelsPerPass + 1 ? hh::kMaxModelsPerPass - 1 : hh::kMaxModelsPerPass;
+}
+
+int hh_mc_accumulate_multi(hh_ctx* ctx, const hh_model* models, uint32_t n_models, const hh_config* c,
+                           double* accum_dev, double* const* terminals) {
+  if (!ctx) return HH_ERR_INVALID;
+  std::lock_guard<std::recursive_mutex> lock__(ctx->mu);
+  if (!models || n_models == 0 || n_models > HH_MAX_MODELS)
+    return fail(ctx, HH_ERR_INVALID, "hh_mc_accumulate_multi: 1 .. %d models", HH_MAX_MODELS);
+  if (!accum_dev) return fail(ctx, HH_ERR_INVALID, "accum_dev is NULL");
+  int rc;
+  for (uint32_t k = 0; k < n_models; ++k)
+    if ((rc = validate(ctx, &models[k], c))) return rc;
+  if (c->n_partials)
+    return fail(ctx, HH_ERR_UNSUPPORTED, "several models in one pass carry no dual partials (n_partials must be 0)");
+  if (n_models == 1) return hh_mc_accumulate(ctx, models, c, accum_dev, terminals ? terminals[0] : nullptr);
+  if (c->strategy == HH_BROADIE_KAYA) {  // the CF inversion has no state to share: one chain per model
+    for (uint32_t k = 0; k < n_models; ++k)
+      if ((rc = hh_mc_accumulate(ctx, &models[k], c, accum_dev + (size_t)k * HH_ACC_LEN, terminals ? terminals[k] : nullptr)))
+        return rc;
+    return HH_OK;
+  }
+  HH_HIP(ctx, hipSetDevice(ctx->device));
+  const uint32_t n_tiles = hh::tiles_for(c->n_paths);
+  const size_t rec_elems = (size_t)n_tiles * hh::kRecStride;
+  const bool fuse = ctx->fuse_reduce != 0;
+  if (fuse) rc = ensure_poisoned(ctx, (size_t)n_models * rec_elems);
+  else rc = ensure(ctx, ctx->records, ctx->records_cap, (size_t)n_models * rec_elems);
+  if (rc) return rc;
+  hh::DevicePtrs base{};
+  if ((rc = stage_noise(ctx, c, base, /*tile_major_only=*/true))) return rc;
+  // terminal samples: a model's own device buffer, or a slice of the ctx's staging buffer for a host buffer
+  const size_t n_term = (size_t)c->n_paths * (c->antithetic ? 2 : 1);
+  bool any_host_terminal = false;
+  if (terminals && !c->terminal_on_device) {
+    for (uint32_t k = 0; k < n_models; ++k) any_host_terminal = any_host_terminal || terminals[k] != nullptr;
+    if (any_host_terminal && (rc = ensure(ctx, ctx->terminal, ctx->terminal_cap, (size_t)n_models * n_term))) return rc;
+  }
+  std::vector<hh::DevicePtrs> p(n_models, base);
+  for (uint32_t k = 0; k < n_models; ++k) {
+    p[k].records = (fuse ? ctx->frecords : ctx->records) + (size_t)k * rec_elems;
+    p[k].accum = fuse ? accum_dev + (size_t)k * HH_ACC_LEN : nullptr;
+    double* t = terminals ? terminals[k] : nullptr;
+    p[k].terminal = !t ? nullptr : c->terminal_on_device ? t : ctx->terminal + (size_t)k * n_term;
+  }
+  if (ctx->timing) HH_HIP(ctx, hipEventRecord(ctx->tev[ctx->t_count % hh_ctx::kTimingSlots][0], ctx->stream));
+  for (uint32_t k0 = 0; k0 < n_models;) {
+    const int take = next_pass((int)(n_models - k0));
+    HH_HIP(ctx, hh::launch_simulation_multi(models + k0, take, *c, p.data() + k0, ctx->stream));
+    if (!fuse)
+      for (int k = 0; k < take; ++k)
+        HH_HIP(ctx, hh::launch_reduce_records(p[k0 + k].records, n_tiles, (double)c->n_paths,
+                                              accum_dev + (size_t)(k0 + k) * HH_ACC_LEN, ctx->stream, 1, &models[k0 + k], c));
+    k0 += (uint32_t)take;
+  }
+  if ((rc = end_timing(ctx))) return rc;
+  if (any_host_terminal) {
+    for (uint32_t k = 0; k < n_models; ++k)
+      if (terminals[k])
+        HH_HIP(ctx, hipMemcpyAsync(terminals[k], p[k].terminal, n_term * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  return HH_OK;
+}
+
+int hh_mc_solve_multi(hh_ctx* ctx, const hh_model* models, uint32_t n_models, const hh_config* c, hh_result* out,
+                      double* const* terminals) {
+  if (!ctx) return HH_ERR_INVALID;
+  std::lock_guard<std::recursive_mutex> lock__(ctx->mu);
+  if (!out || !models || n_models == 0 || n_models > HH_MAX_MODELS)
+    return fail(ctx, HH_ERR_INVALID, "hh_mc_solve_multi: 1 .. %d models and their results", HH_MAX_MODELS);
+  const auto t0 = std::chrono::steady_clock::now();
+  HH_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t n_acc = (size_t)n_models * HH_ACC_LEN;
+  int rc = ensure(ctx, ctx->basket_accum, ctx->basket_accum_cap, n_acc);
+  if (rc) return rc;
+  HH_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  if ((rc = hh_mc_accumulate_multi(ctx, models, n_models, c, ctx->basket_accum, terminals))) return rc;
+  HH_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  double host[HH_MAX_MODELS * HH_ACC_LEN];
+  HH_HIP(ctx, hipMemcpyAsync(host, ctx->basket_accum, n_acc * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  HH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  float ms = 0.f;
+  HH_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+  const double total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  for (uint32_t k = 0; k < n_models; ++k) {
+    std::memset(&out[k], 0, sizeof(hh_result));
+    if ((rc = hh_mc_finalize(&models[k], c, host + (size_t)k * HH_ACC_LEN, &out[k]))) return fail(ctx, rc, "finalize failed");
+    out[k].kernel_ms = ms;
+    out[k].total_ms = total;
+  }
+  return HH_OK;
 }
 
 int hh_mc_accumulate_basket(hh_ctx* ctx, const hh_model* m, const hh_config* c,
@@ -484,6 +629,7 @@ int hh_mc_accumulate_basket(hh_ctx* ctx, const hh_model* m, const hh_config* c,
                                           (double)c->n_paths, ctx->accum, ctx->stream, 1, m, c));
     HH_HIP(ctx, hh::launch_copy_bk_counters(ctx->accum, accum_dev, n_payoffs, ctx->stream));
   }
+  if ((rc = end_timing(ctx))) return rc;
   return copy_back_terminal(ctx, c, terminal);
 }
 

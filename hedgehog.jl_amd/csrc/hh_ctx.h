@@ -59,6 +59,9 @@ struct hh_ctx {
   int grid_form = HH_GRID_FORM_BATCHED;  // hh_ctx_set_option(HH_OPT_GRID_FORM)
   uint64_t lsm_persistent_fallbacks = 0;  // persistent launches that gave up and were redone per date
   long long lsm_spin_ticks = -1;          // hh_ctx_set_option(HH_OPT_LSM_SPIN_TICKS); < 0 = the default (1 s)
+  double* frecords = nullptr;      // records of the launches that reduce them themselves: kPoison between launches (hh_sim.h)
+  size_t frecords_cap = 0;         // in doubles
+  int fuse_reduce = 1;             // hh_ctx_set_option(HH_OPT_FUSE_REDUCE): record reduction inside the simulation kernel
   double* accum = nullptr;       // device, HH_ACC_LEN
   double* accum_host = nullptr;  // pinned, HH_ACC_LEN + 8 (LSM: row counters and the give-up word behind the accumulator)
   // optional per-launch timing of the simulation kernel (hh_ctx_enable_timing)

@@ -12,6 +12,9 @@ namespace hh {
 constexpr int kTile = HH_TILE_PATHS;  // paths per tile == paths per workgroup
 constexpr int kRecStride = HH_ACC_LEN;
 // internal record slots of the simulation / basket kernels (never part of the public vector)
+// what every word of the self-reducing launches' record buffer holds between launches (hh_sim.h, finish_records):
+// a quiet NaN no arithmetic produces; both 32-bit halves alike, so that hipMemsetD32 can write it
+constexpr unsigned long long kPoison = 0x7FF8C0DE7FF8C0DEull;
 constexpr int kRecItmS = 11;  // Σ 1[itm]·cp·S   (kRecItmS + 1: Σ 1[itm]·cp)
 
 // value + P partials (forward-mode dual number; ForwardDiff.Dual{Tag,Float64,P} on the reference
@@ -22,6 +25,24 @@ struct DualT {
   double d[P > 0 ? P : 1];
 };
 
+// What is carried per path and how the requested directions are assembled from it.  Derivative
+// propagation is linear in the seeds, so a requested direction k splits into
+//  * its components along the parameters that reach the variance / diffusion — V0, κ, θ, σ for the
+//    Heston Euler scheme, σ alone otherwise.  Only these BASIS derivatives are carried per path
+//    (unit seed each, at most 4 slots whatever n_partials is): Σ∂p_k += w[k][j] · Σ(∂p/∂basis_j);
+//  * its passive part (spot, drift rate, strike): ∂x_T is one constant for all paths, finished in
+//    closed form:  Σ∂p_k += xdT_k · Σ 1[itm]·cp·S  −  dK_k · Σ 1[itm]·cp.
+constexpr int kMaxBasis = 4;
+enum { kBasisV0 = 0, kBasisKappa = 1, kBasisTheta = 2, kBasisSigma = 3 };
+struct PartialMap {
+  int sim;          // 1: records of a simulation/basket kernel (slots kRecItmS.. are internal)
+  int n;            // n_partials of the call
+  int n_active;     // carried basis derivatives
+  int basis[kMaxBasis];                  // carried slot j -> parameter
+  double w[HH_MAX_PARTIALS][kMaxBasis];  // seed of direction k on the parameter of slot j
+  double xdT[HH_MAX_PARTIALS];           // passive part: ∂ log S_T / ∂θ_k from the spot and rate seeds
+  double dK[HH_MAX_PARTIALS];            // strike seed of direction k
+};
 // Model/problem block passed BY VALUE as the kernel argument (every field is wave-uniform, so it
 // is read through scalar loads).
 template <int P>
@@ -44,6 +65,11 @@ struct SimArgs {
   double* terminal;       // device or nullptr
   double* terminal_d;     // device or nullptr: dS_T/dθ_k at [k * n_total + index]
   double* records;        // device, [n_tiles][kRecStride]
+  // the record reduction folded into this launch (hh_sim.h, finish_records): the last tile's workgroup
+  // leaves the reduced HH_ACC_LEN-double accumulator vector in `accum`.  nullptr: records only.
+  double* accum;          // device; then `records` is a buffer that holds kPoison between launches
+  double acc_n_paths;     // what goes into slot HH_ACC_NPATHS
+  PartialMap map;         // how the requested directions come out of the carried ones (map.n = n_partials)
 };
 
 struct DevicePtrs {
@@ -52,6 +78,8 @@ struct DevicePtrs {
   double* terminal;
   double* terminal_d;
   double* records;
+  double* accum;          // non-NULL: the simulation kernel also reduces its records into this vector, and
+                          // `records` is a poisoned buffer (hh_sim.h, finish_records)
   void* bk_scratch;  // Broadie–Kaya: bk_scratch_bytes() of device memory
   // Broadie–Kaya: which Bessel tables bk_scratch holds (NULL = unknown, always uploaded): the owner of
   // bk_scratch keeps one BkTableKey next to it, zero-initialised
@@ -93,6 +121,14 @@ inline int pad_partials(uint32_t p) { return p <= 4 ? (int)p : 4; }
 
 // All launchers return a hipError_t as int (0 = success) and only enqueue work on `s`.
 int launch_simulation(const hh_model& m, const hh_config& c, const DevicePtrs& p, hipStream_t s);
+// The same for n_models (2, 3 or 4) models stepped on the SAME draws in one pass (hh_multi.hip): p[k] carries
+// model k's outputs (records, accum, terminal); seeds / replay are read from p[0].  c.n_partials must be 0;
+// Euler–Maruyama and the exact lognormal law (Broadie–Kaya: one chain per model, by the caller).
+int launch_simulation_multi(const hh_model* models, int n_models, const hh_config& c, const DevicePtrs* p,
+                            hipStream_t s);
+constexpr int kMaxModelsPerPass = 4;
+// kernel argument block of a model that carries no derivatives (shared with hh_multi.hip)
+SimArgs<0> make_args0(const hh_model& m, const hh_config& c, const DevicePtrs& p);
 // One transition of the per-date exact Heston grid (HestonNoise, heston.jl:82-91): start state of
 // every trajectory read from in_*, end state written to out_* (n_paths doubles each, device);
 // m.T is the length of the transition.  NULL = the one-shot terminal law of launch_bk.

@@ -14,239 +14,14 @@
 // fixed order, so results are bit-reproducible for a given (n_paths, sharding).
 #include <type_traits>
 
-#include "hh_kernels.h"
-#include "hh_rng.h"
+#include "hh_sim.h"
 
 namespace hh {
 
-// ------------------------------------------------------------------------------------------
-// model policies: one explicit Euler–Maruyama step on the log-state
-// ------------------------------------------------------------------------------------------
-
-// heston.jl:7-31.  u = [log S, v];  f = [mu - v+/2, kappa(theta - v+)],  g = [sqrt(v+), sigma sqrt(v+)]
-// with v+ = max(v, 0).  K = u + dt f(u);  u' = K + g(.) dW, g taken at K (SPLIT, the integrator's
-// split-step form) or at u.
-#ifndef HH_LEAN_SQRT
-#define HH_LEAN_SQRT 1
-#endif
-// sqrt of the clipped variance w >= 0.  The library routine is v_rsq_f64 + one coupled Newton step
-// + two residual corrections, wrapped in a 2^±256 range scaling for arguments below 2^-767 and a
-// class test for 0/inf: 18 instructions, more than half of a Heston path-step.  This is the same
-// core sequence (so the same, correctly rounded, result for every w >= 2^-767) with the zero
-// handled by ONE v_min_f64 on the seed: rsq(0) = +inf would make w·y = NaN; capped at 2^1000 (every
-// rsq of a positive double is below 2^540) the whole sequence is exact zeros for w = 0 — g = 0·2^1000 = 0,
-// r = 1/2, both corrections add 0 — and untouched for w > 0.  (Before round 4: compare + two v_cndmask on
-// the result; the two instructions are 4 of the antithetic kernel's 47 per pair-step.)  A clipped
-// variance between 0 and 2^-767 cannot change any later state.
-__device__ __forceinline__ double sqrt_clipped(double w) {
-#if HH_LEAN_SQRT
-  const double y = __builtin_fmin(__builtin_amdgcn_rsq(w), 0x1p1000);
-  double g = w * y, h = 0.5 * y;
-  const double r = fma(-h, g, 0.5);
-  g = fma(g, r, g);
-  h = fma(h, r, h);
-  g = fma(fma(-g, g, w), h, g);
-  return fma(fma(-g, g, w), h, g);
-#else
-  return sqrt(w);
-#endif
-}
-
-template <int P, bool SPLIT>
-struct HestonModel {
-  static constexpr int NCOMP = 2;
-  struct State {
-    DualT<P> x, v;
-  };
-  __device__ static __forceinline__ void init(State& s, const SimArgs<P>& a) {
-    s.x = a.x0;
-    s.v = a.v0;
-  }
-  __device__ static __forceinline__ void step(State& s, const SimArgs<P>& a, double dW1,
-                                              double dW2) {
-    const bool pos = s.v.v > 0.0;
-    // v+ = max(v, 0) as ONE v_max_f64: written `pos ? v : 0` (or fmax) the compiler first canonicalises the
-    // loop-carried v with v_max_f64 v, v, v — an instruction per path-step where the kernel issues one per cycle
-    double vp;
-    asm("v_max_f64 %0, %1, 0" : "=v"(vp) : "v"(s.v.v));
-    const double th_m_v = a.theta.v - vp;
-    const double Kx = fma(a.dt, fma(-0.5, vp, a.r.v), s.x.v);  // r - vp/2: the product is exact
-    const double Kv = fma(a.dt, a.kappa.v * th_m_v, s.v.v);
-    const bool wpos = SPLIT ? (Kv > 0.0) : pos;
-    const double w = SPLIT ? (wpos ? Kv : 0.0) : vp;
-    const double sq = sqrt_clipped(w);
-    if constexpr (P > 0) {
-      // d sqrt(w+) = dw / (2 sqrt(w)) for w > 0, and 0 at the clip ("dual rules")
-      // 1/(2 sqrt(w)): hardware reciprocal + one Newton step (relative error ~1e-16; an IEEE
-      // division would cost ~14 instructions per path-step and the partials do not need it)
-      double inv2s = 0.0;
-      if (wpos) {
-        const double r0 = __builtin_amdgcn_rcp(sq);
-        inv2s = 0.5 * fma(r0, fma(-sq, r0, 1.0), r0);
-      }
-      // The propagation of (dx, dv) is the same linear map for every direction, plus a forcing that
-      // differs by the direction's seeds: the map's coefficients are formed ONCE per step
-      //   Kvd = m·dv + f_k,        m = 1 - dt κ [v>0],   f_k = dκ_k·dt(θ - v+) + dt κ·dθ_k
-      //   dx' = dx + dt·dr_k - h·dv + e1·Kvd,            h = dt/2 [v>0],  e1 = dW1 / (2 sqrt w) [w>0]
-      //   dv' = e2·Kvd + dσ_k·(sqrt(w) dW2),             e2 = 1 + σ dW2 / (2 sqrt w) [w>0]
-      // (diffusion taken at u instead of K: the sqrt's tangent acts on dv, not on Kvd) — 6-7 fused
-      // operations per direction instead of 12; algebraically the step-by-step dual rules above.
-      const double A = a.dt * th_m_v, B = sq * dW2;
-      const double m = pos ? 1.0 - a.dt * a.kappa.v : 1.0;
-      const double h = pos ? 0.5 * a.dt : 0.0;
-      const double e1 = inv2s * dW1;
-      const double se2 = (a.sigma.v * inv2s) * dW2;
-#pragma unroll
-      for (int k = 0; k < P; ++k) {
-        const double dv = s.v.d[k];
-        const double f = fma(a.kappa.d[k], A, (a.dt * a.kappa.v) * a.theta.d[k]);
-        const double Kvd = fma(m, dv, f);
-        const double x0 = s.x.d[k] + a.dt * a.r.d[k];
-        if constexpr (SPLIT) {
-          s.x.d[k] = fma(e1, Kvd, fma(-h, dv, x0));
-          s.v.d[k] = fma(se2, Kvd, fma(a.sigma.d[k], B, Kvd));
-        } else {
-          s.x.d[k] = fma(e1 - h, dv, x0);
-          s.v.d[k] = fma(se2, dv, fma(a.sigma.d[k], B, Kvd));
-        }
-      }
-    }
-    s.x.v = fma(sq, dW1, Kx);
-    s.v.v = fma(a.sigma.v * sq, dW2, Kv);
-  }
-};
-
-// heston.jl:33-52.  x' = x + dt (mu - sigma^2/2) + sigma dW  (g constant, so split is irrelevant)
-template <int P>
-struct GbmModel {
-  static constexpr int NCOMP = 1;
-  struct State {
-    DualT<P> x;
-  };
-  __device__ static __forceinline__ void init(State& s, const SimArgs<P>& a) { s.x = a.x0; }
-  __device__ static __forceinline__ void step(State& s, const SimArgs<P>& a, double dW, double) {
-    if constexpr (P > 0) {
-#pragma unroll
-      for (int k = 0; k < P; ++k)
-        s.x.d[k] = fma(a.sigma.d[k], dW, fma(a.dt, a.gdrift.d[k], s.x.d[k]));
-    }
-    s.x.v = fma(a.sigma.v, dW, fma(a.dt, a.gdrift.v, s.x.v));
-  }
-};
-
-// ------------------------------------------------------------------------------------------
-// payoff + reduction
-// ------------------------------------------------------------------------------------------
-
-// S = exp(x) (montecarlo.jl:398); payoff max(cp (S-K), 0) (payoffs.jl:154-156)
-// Partials: only the directions that reach the variance/diffusion ("active", see PartialMap) are
-// carried per path; pd[k] = 1[itm]·cp·S·∂x_k.  wS = 1[itm]·cp·S and wN = 1[itm]·cp feed the two sums
-// from which every PASSIVE direction (spot, drift rate, strike: ∂x_T is the same constant on every
-// path) is finished in closed form by the record reduction.
-template <int P>
-__device__ __forceinline__ void payoff_of(const DualT<P>& x, const SimArgs<P>& a, double& S,
-                                          double& p, double (&pd)[P > 0 ? P : 1], double& wS,
-                                          double& wN) {
-  S = exp(x.v);
-  const double m = a.cp * (S - a.strike.v);
-  const bool itm = m > 0.0;
-  p = itm ? m : 0.0;
-  wS = itm ? a.cp * S : 0.0;
-  wN = itm ? a.cp : 0.0;
-  if constexpr (P > 0) {
-#pragma unroll
-    for (int k = 0; k < P; ++k) pd[k] = wS * x.d[k];
-  }
-}
-
-// wave64 shuffle tree, then across the workgroup's waves through LDS; lane 0 writes the record.
-// The last TAIL entries of acc go to record slots kRecItmS, kRecItmS+1 (the in-the-money sums).
-template <int N, int NWAVES, int TAIL = 0>
-__device__ __forceinline__ void block_reduce_store(double (&acc)[N], double* __restrict__ rec) {
-#pragma unroll
-  for (int i = 0; i < N; ++i) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) acc[i] += __shfl_down(acc[i], off, 64);
-  }
-  __shared__ double sm[NWAVES][N];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (lane == 0) {
-#pragma unroll
-    for (int i = 0; i < N; ++i) sm[wave][i] = acc[i];
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-#pragma unroll
-    for (int i = 0; i < kRecStride; ++i) rec[i] = 0.0;
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-      double t = sm[0][i];
-#pragma unroll
-      for (int w = 1; w < NWAVES; ++w) t += sm[w][i];
-      rec[i < N - TAIL ? i : kRecItmS + (i - (N - TAIL))] = t;
-    }
-  }
-}
-
-template <int P, bool ANTI, class State>
-__device__ __forceinline__ void finish_path(const State& st, const State& sa, const SimArgs<P>& a,
-                                            uint64_t path, double (&acc)[4 + P]) {
-  if (path >= a.n_paths) return;
-  double S, p, pd[P > 0 ? P : 1], wS, wN;
-  payoff_of<P>(st.x, a, S, p, pd, wS, wN);
-  if (a.terminal) a.terminal[path] = S;
-  const uint64_t n_total = ANTI ? 2 * a.n_paths : a.n_paths;
-  if constexpr (P > 0) {
-    if (a.terminal_d) {
-#pragma unroll
-      for (int k = 0; k < P; ++k) a.terminal_d[(uint64_t)k * n_total + path] = S * st.x.d[k];
-    }
-  }
-  if constexpr (ANTI) {
-    double Sa, pa, pda[P > 0 ? P : 1], wSa, wNa;
-    payoff_of<P>(sa.x, a, Sa, pa, pda, wSa, wNa);
-    if (a.terminal) a.terminal[a.n_paths + path] = Sa;
-    if constexpr (P > 0) {
-      if (a.terminal_d) {
-#pragma unroll
-        for (int k = 0; k < P; ++k)
-          a.terminal_d[(uint64_t)k * n_total + a.n_paths + path] = Sa * sa.x.d[k];
-      }
-    }
-    p = (p + pa) / 2;  // montecarlo.jl:431
-    wS = (wS + wSa) / 2;
-    wN = (wN + wNa) / 2;
-    if constexpr (P > 0) {
-#pragma unroll
-      for (int k = 0; k < P; ++k) pd[k] = (pd[k] + pda[k]) / 2;
-    }
-  }
-  acc[0] += p;
-  acc[1] = fma(p, p, acc[1]);
-  if constexpr (P > 0) {
-#pragma unroll
-    for (int k = 0; k < P; ++k) acc[2 + k] += pd[k];
-  }
-  acc[2 + P] += wS;
-  acc[3 + P] += wN;
-}
 
 // ------------------------------------------------------------------------------------------
 // Euler–Maruyama kernel
 // ------------------------------------------------------------------------------------------
-
-template <int PPT>
-struct VecOf;
-template <>
-struct VecOf<1> {
-  using type = double;
-  __device__ static __forceinline__ double get(const type& v, int) { return v; }
-};
-template <>
-struct VecOf<2> {
-  using type = double __attribute__((ext_vector_type(2)));
-  __device__ static __forceinline__ double get(const type& v, int j) { return j ? v.y : v.x; }
-};
 
 // The shape of the REPLAY pipeline, as measured (profiles/r02_a_replay_occupancy_ab.txt,
 // r02_b_replay_shape_ab.txt, r02_d_replay_counted_waits_ab.txt).  The A/B builds of tools/tune_replay.py
@@ -255,9 +30,6 @@ struct VecOf<2> {
 // split over two lanes — from tools/variants/; this translation unit holds what ships.
 #ifdef HH_REPLAY_VARIANTS
 #include "replay_knobs.h"
-#endif
-#ifndef HH_REPLAY_NT
-#define HH_REPLAY_NT 1            // the increments are a read-once stream: nontemporal loads
 #endif
 #ifndef HH_REPLAY_CHUNK_PRICE
 #define HH_REPLAY_CHUNK_PRICE 4   // steps per register chunk, price-only kernel …
@@ -294,15 +66,6 @@ struct VecOf<2> {
 #ifndef HH_REPLAY_MAXW_ANTI
 #define HH_REPLAY_MAXW_ANTI 8     // antithetic: indifferent (0.629 vs 0.625 ms), left at the register limit
 #endif
-
-template <class Vec>
-__device__ __forceinline__ Vec stream_load(const double* p) {
-#if HH_REPLAY_NT
-  return __builtin_nontemporal_load(reinterpret_cast<const Vec*>(p));  // read-once stream
-#else
-  return *reinterpret_cast<const Vec*>(p);
-#endif
-}
 
 constexpr int replay_max_waves(bool replay, bool anti, int p) {
   return !replay ? 8 : anti ? HH_REPLAY_MAXW_ANTI : p > 1 ? HH_REPLAY_MAXW_DUAL_WIDE : p > 0 ? HH_REPLAY_MAXW_DUAL : HH_REPLAY_MAXW;
@@ -481,7 +244,8 @@ __attribute__((amdgpu_waves_per_eu(REPLAY ? HH_REPLAY_MINW : 1,
   for (int i = 0; i < 4 + P; ++i) acc[i] = 0.0;
 #pragma unroll
   for (int j = 0; j < PPT; ++j) finish_path<P, ANTI>(st[j], sa[ANTI ? j : 0], a, path0 + j, acc);
-  block_reduce_store<4 + P, kTile / PPT / 64, 2>(acc, a.records + (size_t)tile * kRecStride);
+  block_reduce_publish<4 + P, kTile / PPT / 64, 2>(acc, a.records + (size_t)tile * kRecStride, a.accum != nullptr, a.map.n > 0);
+  if (a.accum && reduces_records(tile, a.n_tiles)) finish_records<kTile / PPT, P>(a.records, a.n_tiles, a.acc_n_paths, a.accum, &a.map);
 }
 
 #ifdef HH_REPLAY_VARIANTS
@@ -649,7 +413,8 @@ __attribute__((amdgpu_waves_per_eu(1, HH_PM_MAXW))) void euler_pm_kernel(const S
 #pragma unroll
   for (int i = 0; i < 4 + P; ++i) acc[i] = 0.0;
   finish_path<P, ANTI>(st, sa, a, path, acc);
-  block_reduce_store<4 + P, kTile / 64, 2>(acc, a.records + (size_t)tile * kRecStride);
+  block_reduce_publish<4 + P, kTile / 64, 2>(acc, a.records + (size_t)tile * kRecStride, a.accum != nullptr, a.map.n > 0);
+  if (a.accum && reduces_records(tile, a.n_tiles)) finish_records<kTile, P>(a.records, a.n_tiles, a.acc_n_paths, a.accum, &a.map);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -706,31 +471,13 @@ __global__ __launch_bounds__(kTile / 2) void exact_gbm_kernel(const SimArgs<P> a
     }
     finish_path<P, ANTI>(st, sa, a, path0 + j, acc);
   }
-  block_reduce_store<4 + P, kTile / 2 / 64, 2>(acc, a.records + (size_t)tile * kRecStride);
+  block_reduce_publish<4 + P, kTile / 2 / 64, 2>(acc, a.records + (size_t)tile * kRecStride, a.accum != nullptr, a.map.n > 0);
+  if (a.accum && reduces_records(tile, a.n_tiles)) finish_records<kTile / 2, P>(a.records, a.n_tiles, a.acc_n_paths, a.accum, &a.map);
 }
 
 // ------------------------------------------------------------------------------------------
 // record reduction: one workgroup per accumulator slot, fixed summation order
 // ------------------------------------------------------------------------------------------
-
-// What is carried per path and how the requested directions are assembled from it.  Derivative
-// propagation is linear in the seeds, so a requested direction k splits into
-//  * its components along the parameters that reach the variance / diffusion — V0, κ, θ, σ for the
-//    Heston Euler scheme, σ alone otherwise.  Only these BASIS derivatives are carried per path
-//    (unit seed each, at most 4 slots whatever n_partials is): Σ∂p_k += w[k][j] · Σ(∂p/∂basis_j);
-//  * its passive part (spot, drift rate, strike): ∂x_T is one constant for all paths, finished in
-//    closed form:  Σ∂p_k += xdT_k · Σ 1[itm]·cp·S  −  dK_k · Σ 1[itm]·cp.
-constexpr int kMaxBasis = 4;
-enum { kBasisV0 = 0, kBasisKappa = 1, kBasisTheta = 2, kBasisSigma = 3 };
-struct PartialMap {
-  int sim;          // 1: records of a simulation/basket kernel (slots kRecItmS.. are internal)
-  int n;            // n_partials of the call
-  int n_active;     // carried basis derivatives
-  int basis[kMaxBasis];                  // carried slot j -> parameter
-  double w[HH_MAX_PARTIALS][kMaxBasis];  // seed of direction k on the parameter of slot j
-  double xdT[HH_MAX_PARTIALS];           // passive part: ∂ log S_T / ∂θ_k from the spot and rate seeds
-  double dK[HH_MAX_PARTIALS];            // strike seed of direction k
-};
 
 __device__ __forceinline__ double sum_slot(const double* __restrict__ rec, uint32_t n, int slot,
                                            double* sm) {
@@ -945,7 +692,16 @@ static SimArgs<P> make_args(const hh_model& m, const hh_config& c, const DeviceP
   a.terminal = p.terminal;
   a.terminal_d = p.terminal_d;
   a.records = p.records;
+  a.accum = p.accum;
+  a.acc_n_paths = (double)c.n_paths;
+  a.map = pm;
   return a;
+}
+
+SimArgs<0> make_args0(const hh_model& m, const hh_config& c, const DevicePtrs& p) {
+  hh_config c0 = c;
+  c0.n_partials = 0;
+  return make_args<0>(m, c0, p, classify_partials(m, c0));
 }
 
 template <class M, int P, bool REPLAY, bool ANTI>
@@ -973,9 +729,8 @@ static int launch_euler_t(const SimArgs<P>& a, hipStream_t s) {
 
 template <class M, int P>
 static int launch_euler_pm(const SimArgs<P>& a, bool anti, hipStream_t s) {
-  const dim3 g(a.n_tiles), b(kTile);
-  if (anti) hipLaunchKernelGGL((euler_pm_kernel<M, P, true>), g, b, 0, s, a);
-  else hipLaunchKernelGGL((euler_pm_kernel<M, P, false>), g, b, 0, s, a);
+  auto kernel = anti ? euler_pm_kernel<M, P, true> : euler_pm_kernel<M, P, false>;
+  hipLaunchKernelGGL(kernel, dim3(a.n_tiles), dim3(kTile), 0, s, a);
   return (int)hipGetLastError();
 }
 
@@ -1001,14 +756,9 @@ static int launch_sim_p(const hh_model& m, const hh_config& c, const DevicePtrs&
   const bool anti = c.antithetic != 0;
   const bool replay = c.noise_mode == HH_NOISE_REPLAY;
   if (c.strategy == HH_EXACT_LAW) {
-    const dim3 g(a.n_tiles), b(kTile / 2);
-    if (replay) {
-      if (anti) hipLaunchKernelGGL((exact_gbm_kernel<P, true, true>), g, b, 0, s, a);
-      else hipLaunchKernelGGL((exact_gbm_kernel<P, true, false>), g, b, 0, s, a);
-    } else {
-      if (anti) hipLaunchKernelGGL((exact_gbm_kernel<P, false, true>), g, b, 0, s, a);
-      else hipLaunchKernelGGL((exact_gbm_kernel<P, false, false>), g, b, 0, s, a);
-    }
+    auto kernel = replay ? (anti ? exact_gbm_kernel<P, true, true> : exact_gbm_kernel<P, true, false>)
+                         : (anti ? exact_gbm_kernel<P, false, true> : exact_gbm_kernel<P, false, false>);
+    hipLaunchKernelGGL(kernel, dim3(a.n_tiles), dim3(kTile / 2), 0, s, a);
     return (int)hipGetLastError();
   }
   const bool direct = replay && p.replay_path_major;

@@ -156,17 +156,33 @@ def solve_greek_ad(gprob: GreekProblem, pricing_method, solve):
     return GreekResult(price.partials[0])
 
 
+def _prices(probs, pricing_method, solve):
+    """The prices of several problems under one method.  Through MonteCarlo they are simulated TOGETHER, on
+    the same draws in one pass (solve_montecarlo_many -> hh_mc_solve_multi): the same numbers as one solve
+    after the other — which is what happens for every other method, and whenever a pass cannot be shared."""
+    from .montecarlo import MonteCarlo, solve_montecarlo_many
+    if isinstance(pricing_method, MonteCarlo):
+        sols = solve_montecarlo_many(probs, pricing_method)
+        if sols is not None:
+            return [s.price for s in sols]
+    return [solve(p, pricing_method).price for p in probs]
+
+
 def solve_greek_fd(gprob: GreekProblem, method: FiniteDifference, pricing_method, solve):
-    """greeks_problem.jl:279-329 (common random numbers come from the fixed seeds)."""
+    """greeks_problem.jl:279-329 (common random numbers come from the fixed seeds): the two solves of a
+    scheme, in the reference's order."""
     prob, lens, eps = gprob.pricing_problem, gprob.wrt, method.bump
     x0 = lens(prob)
-    price = lambda x: solve(set(prob, lens, x), pricing_method).price
     if isinstance(method.scheme, FDForward):
-        d = (price(x0 * (1 + eps)) - price(x0)) / (x0 * eps)
+        v_up, v0 = _prices([set(prob, lens, x0 * (1 + eps)), prob], pricing_method, solve)
+        d = (v_up - v0) / (x0 * eps)
     elif isinstance(method.scheme, FDBackward):
-        d = (price(x0) - price(x0 * (1 - eps))) / (x0 * eps)
+        v_down, v0 = _prices([set(prob, lens, x0 * (1 - eps)), prob], pricing_method, solve)
+        d = (v0 - v_down) / (x0 * eps)
     else:
-        d = (price(x0 * (1 + eps)) - price(x0 * (1 - eps))) / (2 * eps * x0)
+        v_up, v_down = _prices([set(prob, lens, x0 * (1 + eps)), set(prob, lens, x0 * (1 - eps))],
+                               pricing_method, solve)
+        d = (v_up - v_down) / (2 * eps * x0)
     return GreekResult(d)
 
 
@@ -186,12 +202,15 @@ def solve_second_order_fd(gprob: SecondOrderGreekProblem, method: FiniteDifferen
     Monte Carlo path is not offered (the reference flags it as unstable there)."""
     prob, l1, l2, eps = gprob.pricing_problem, gprob.wrt1, gprob.wrt2, method.bump
     x0, y0 = l1(prob), l2(prob)
-    f = lambda x, y: solve(set(set(prob, l1, x), l2, y), pricing_method).price
+    at = lambda x, y: set(set(prob, l1, x), l2, y)
     if l1 == l2:
-        d = (f(x0 + eps, y0 + eps) - 2 * f(x0, y0) + f(x0 - eps, y0 - eps)) / eps**2
+        f_plus, f_0, f_minus = _prices([at(x0 + eps, y0 + eps), at(x0, y0), at(x0 - eps, y0 - eps)],
+                                       pricing_method, solve)
+        d = (f_plus - 2 * f_0 + f_minus) / eps**2
     else:
-        d = (f(x0 + eps, y0 + eps) - f(x0 + eps, y0 - eps) - f(x0 - eps, y0 + eps)
-             + f(x0 - eps, y0 - eps)) / (4 * eps**2)
+        f_pp, f_pm, f_mp, f_mm = _prices([at(x0 + eps, y0 + eps), at(x0 + eps, y0 - eps), at(x0 - eps, y0 + eps),
+                                          at(x0 - eps, y0 - eps)], pricing_method, solve)
+        d = (f_pp - f_pm - f_mp + f_mm) / (4 * eps**2)
     return GreekResult(d)
 
 
@@ -213,4 +232,12 @@ def solve_batch(gprob: BatchGreekProblem, method, pricing_method, solve):
             p = set(p, lens, x0)
         price = solve(p, pricing_method).price
         return {lens: price.partials[k] for k, lens in enumerate(lenses)}
+    if isinstance(method, FiniteDifference) and isinstance(pricing_method, MonteCarlo) and \
+            isinstance(method.scheme, FDCentral) and 0 < 2 * len(lenses) <= 16:
+        # greeks_problem.jl:567 runs compute_fd_derivative once per lens: 2 solves each, all on the same
+        # seeds — here every bumped problem of the batch shares the draws (up to 4 per pass)
+        eps, xs = method.bump, [lens(prob) for lens in lenses]
+        probs = [set(prob, lens, x * (1 + sg * eps)) for lens, x in zip(lenses, xs) for sg in (1, -1)]
+        v = _prices(probs, pricing_method, solve)
+        return {lens: (v[2 * i] - v[2 * i + 1]) / (2 * eps * x) for i, (lens, x) in enumerate(zip(lenses, xs))}
     return {lens: solve(GreekProblem(prob, lens), method, pricing_method).greek for lens in lenses}

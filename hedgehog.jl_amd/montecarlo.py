@@ -257,6 +257,33 @@ def solve_montecarlo(prob: PricingProblem, method: MonteCarlo, ensemble: bool = 
                               std_error=res.std_error, result=res)
 
 
+def solve_montecarlo_many(probs, method: MonteCarlo, replay=None, replay_layout=_ffi.HH_REPLAY_PATH_MAJOR):
+    """Several problems under ONE method on the same draws — the solves a bumped Greek is made of
+    (compute_fd_derivative, greeks_problem.jl:279-303; the second-order stencils :396-422) — in one pass of
+    the kernels (hh_mc_solve_multi): result k is solve(probs[k], method) bit for bit, without its ensemble.
+    Returns None when the problems cannot share a pass (dual numbers in one of them, a multi-GPU method, more
+    than HH_MAX_MODELS problems): the caller then solves them one by one, as the reference does."""
+    if method.devices is not None or not 1 < len(probs) <= _ffi.HH_MAX_MODELS:
+        return None
+    packed = [_model_and_config(p, method) for p in probs]
+    if any(P for _, _, _, P, _ in packed):
+        return None
+    c = packed[0][1]
+    cfg = method.config
+    ctx = _ffi.get_context(method.device)
+    seeds_dev = cfg.device_seeds(ctx)
+    c.seeds, c.seeds_on_device, c.seeds_len = seeds_dev.ptr, 1, cfg.seeds.size
+    if replay is not None:
+        replay = np.ascontiguousarray(replay, dtype=np.float64)
+        c.noise_mode, c.replay_layout = _ffi.HH_NOISE_REPLAY, replay_layout
+        c.replay, c.replay_len = replay.ctypes.data, replay.size
+    models = (_ffi.hh_model * len(probs))(*[m for m, _, _, _, _ in packed])
+    res = (_ffi.hh_result * len(probs))()
+    ctx.check(ctx.lib.hh_mc_solve_multi(ctx.handle, models, len(probs), C.byref(c), res, None))
+    return [MonteCarloSolution(p, method, res[k].price, None, std_error=res[k].std_error, result=res[k])
+            for k, p in enumerate(probs)]
+
+
 def _solve_multi_gpu(prob, method, model, c, P, discount, ensemble, replay, replay_layout):
     """solve(prob, method) with `method.devices`: the trajectories sharded over those GPUs by ONE
     library call from this thread (hh_mgpu_solve: contiguous ranges, one RCCL all-reduce of the

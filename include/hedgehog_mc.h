@@ -42,10 +42,11 @@
 extern "C" {
 #endif
 
-#define HH_ABI_VERSION 4
+#define HH_ABI_VERSION 5
 #define HH_MAX_PARTIALS 8   /* max. number of dual-number partials carried through one solve    */
 #define HH_TILE_PATHS 256   /* paths per tile of the tile-major REPLAY layout (see below)        */
 #define HH_ACC_LEN 16       /* doubles in the accumulator vector exchanged between GPUs          */
+#define HH_MAX_MODELS 16    /* models one hh_mc_solve_multi call prices on the same draws          */
 
 /* accumulator vector slots (all are plain sums, so one SUM all-reduce combines shards) */
 #define HH_ACC_SUM 0        /* Σ payoff (undiscounted; antithetic: Σ of pair averages)           */
@@ -196,8 +197,13 @@ const char* hh_last_error(const hh_ctx* ctx); /* NUL-terminated, owned by ctx (o
  * constant clock (default -1 = 10^8 = one second).  The launch is cooperative (hipLaunchCooperativeKernel:
  * a grid that cannot be resident as a whole is refused at launch and the launch-per-date form runs), so
  * the bound is only the last guard; 0 makes every workgroup give up at once, which is how the tests
- * force the give-up-and-redo path (hh_lsm_result.persistent_fallbacks counts it; same result). */
-enum hh_option { HH_OPT_LSM_FORM = 1, HH_OPT_BK_TERM_CACHE = 2, HH_OPT_GRID_FORM = 3, HH_OPT_LSM_SPIN_TICKS = 4 };
+ * force the give-up-and-redo path (hh_lsm_result.persistent_fallbacks counts it; same result).
+ *
+ * HH_OPT_FUSE_REDUCE: 1 (default) the simulation kernel of a single-payoff solve also adds its workgroups'
+ * partial sums (the workgroup that finishes last does, in a fixed order) — one launch per solve; 0 a second
+ * kernel adds them, as before round 5.  Same order of additions either way: bit-identical results. */
+enum hh_option { HH_OPT_LSM_FORM = 1, HH_OPT_BK_TERM_CACHE = 2, HH_OPT_GRID_FORM = 3, HH_OPT_LSM_SPIN_TICKS = 4,
+                 HH_OPT_FUSE_REDUCE = 5 };
 enum hh_grid_form { HH_GRID_FORM_PER_DATE = 0, HH_GRID_FORM_BATCHED = 1 };
 enum hh_lsm_form { HH_LSM_FORM_PER_DATE = 0, HH_LSM_FORM_PERSISTENT = 1, HH_LSM_FORM_AUTO = 2 };
 int hh_ctx_set_option(hh_ctx* ctx, int32_t option, int64_t value);
@@ -221,6 +227,30 @@ int hh_mc_accumulate(hh_ctx* ctx, const hh_model* model, const hh_config* cfg, d
 /* Pure host arithmetic: accumulator vector (HOST memory) -> price, std_error, dprice. */
 int hh_mc_finalize(const hh_model* model, const hh_config* cfg, const double* accum_host,
                    hh_result* out);
+
+/*
+ * SEVERAL MODELS ON THE SAME DRAWS, in one pass — what the reference's bumped Greeks are made of:
+ * compute_fd_derivative (greeks_problem.jl:279-303) solves 2 problems that differ in one number, the
+ * second-order stencils (:396-422) 3 or 4, each a full solve(prob, method) with the seeds of the SAME
+ * SimulationConfig (common random numbers).  Here the n_models problems — same payoff type, same cfg: dynamics,
+ * strategy, trajectories, steps, seeds or increments, variance reduction — are simulated TOGETHER: a lane
+ * carries one state per model and steps them all on each draw, so the normals (GENERATE) or the 16 bytes of
+ * increments (REPLAY) are paid once per path-step, not once per model and path-step.  Result k is what
+ * hh_mc_solve(ctx, &models[k], cfg, …) returns, bit for bit (same arithmetic per model, same summation order).
+ *   models     n_models hh_model (1 .. HH_MAX_MODELS); anything may differ between them (spot, variance
+ *              parameters, ρ, rate, discount, expiry time T, strike, call/put); d* seeds are ignored
+ *   cfg        as for hh_mc_solve; n_partials must be 0 (HH_ERR_UNSUPPORTED otherwise)
+ *   out        n_models results;   accum_dev  n_models x HH_ACC_LEN doubles, model-major (all-reducible as ONE
+ *              vector over path shards, then hh_mc_finalize(&models[k], cfg, accum + k·HH_ACC_LEN, &out[k]))
+ *   terminals  NULL, or n_models pointers (each nullable): model k's samples at expiry, as `terminal` of hh_mc_solve
+ * Up to 4 models share a pass (more run as ⌈n/4⌉ passes); Euler–Maruyama and the exact lognormal law share
+ * their draws, Broadie–Kaya runs one chain per model (its sampler keeps no state a second model could reuse).
+ * Path-major REPLAY increments are repacked to the tile-major layout first.
+ */
+int hh_mc_solve_multi(hh_ctx* ctx, const hh_model* models, uint32_t n_models, const hh_config* cfg,
+                      hh_result* out, double* const* terminals);
+int hh_mc_accumulate_multi(hh_ctx* ctx, const hh_model* models, uint32_t n_models, const hh_config* cfg,
+                           double* accum_dev, double* const* terminals);
 
 /*
  * Diagnostics of the last HH_BROADIE_KAYA solve of this context (hh_mc_solve / _accumulate with the same

@@ -10,7 +10,7 @@
 #     sol = Hedgehog.solve(prob, MonteCarlo(HestonDynamics(), EulerMaruyama(), cfg))
 #     G   = Hedgehog.solve(BatchGreekProblem(prob, lenses), ForwardAD(), mc)    # ONE fused pass
 #
-# What is bound (include/hedgehog_mc.h, HH_ABI_VERSION 4): hh_mc_solve (solve_hip, with the REPLAY
+# What is bound (include/hedgehog_mc.h, HH_ABI_VERSION 5): hh_mc_solve (solve_hip, with the REPLAY
 # keywords), hh_mgpu_create / hh_mgpu_solve (solve_hip(...; devices = 0:7): several GPUs behind the one
 # call), hh_mc_accumulate + hh_mc_finalize (solve_sharded_hip: one process per GPU), hh_mc_solve_basket, hh_carr_madan,
 # hh_carr_madan_basket (+ _grad), hh_ctx_set_option, hh_lsm_solve, hh_heston_exact_grid, hh_replay_elems, the device-memory helpers.  The struct mirrors
@@ -30,7 +30,7 @@ const LIB = Ref{String}(get(ENV, "HEDGEHOG_MC_LIB",
 
 const HH_MAX_PARTIALS = 8
 const HH_ACC_LEN = 16
-const HH_ABI_VERSION = 4
+const HH_ABI_VERSION = 5
 const HH_NOISE_GENERATE, HH_NOISE_REPLAY = Int32(0), Int32(1)
 const HH_REPLAY_TILE_MAJOR, HH_REPLAY_PATH_MAJOR = Int32(0), Int32(1)
 

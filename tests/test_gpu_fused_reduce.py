@@ -1,0 +1,157 @@
+"""The record reduction folded into the simulation kernels (hh_sim.h, finish_records; mean(payoffs) of
+montecarlo.jl:490): the LAST tile's workgroup adds every workgroup's record in the order the separate
+reduce_records_kernel uses — waiting for records that are not there yet — so the accumulator vector must
+come out bit for bit the same, for every record count, with and without carried derivatives, and the record
+buffer must be ready (poisoned) again for the next launch, whatever that launch's shape."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from hedgehog_jl_amd import _ffi
+from tests import oracle_ffi as o
+
+pytestmark = pytest.mark.gpu
+
+GBM, HES = _ffi.HH_LOGNORMAL, _ffi.HH_HESTON
+EM, EXACT = _ffi.HH_EULER_MARUYAMA, _ffi.HH_EXACT_LAW
+GEN, REP = _ffi.HH_NOISE_GENERATE, _ffi.HH_NOISE_REPLAY
+
+
+def accumulate(ctx, m, c, fused):
+    ctx.set_option(_ffi.HH_OPT_FUSE_REDUCE, int(fused))
+    try:
+        acc = _ffi.DeviceBuffer(ctx, 8 * _ffi.HH_ACC_LEN)
+        acc.upload(np.full(_ffi.HH_ACC_LEN, np.nan))
+        ctx.check(ctx.lib.hh_mc_accumulate(ctx.handle, C.byref(m), C.byref(c), acc.ptr, None))
+        ctx.synchronize()
+        return acc.download(np.empty(_ffi.HH_ACC_LEN))
+    finally:
+        ctx.set_option(_ffi.HH_OPT_FUSE_REDUCE, 1)
+
+
+def seeds_for(n, salt=0):
+    return np.arange(1, n + 1, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15) + np.uint64(salt)
+
+
+def model_with(P, dyn):
+    names = ["S0", "sigma", "r_drift", "strike", "V0"] if dyn == GBM else ["S0", "V0", "r_drift", "kappa", "sigma"]
+    sd = {}
+    for k in range(P):
+        v = [0.0] * P
+        v[k] = 1.0
+        sd[names[k]] = v
+    return o.make_model(sigma=0.2 if dyn == GBM else 0.3, seeds=sd, n_partials=P)
+
+
+# 1 record, a few, one more than a virtual thread's first batch (256 x 8 = 2048), and beyond
+@pytest.mark.parametrize("n_paths", [1, 257, 256 * 255 + 3, 256 * 2049 + 17])
+@pytest.mark.parametrize("P", [0, 1, 3, 5])
+@pytest.mark.parametrize("anti", [0, 1])
+def test_fused_sum_is_the_separate_kernels_sum_bit_for_bit(hhlib, n_paths, P, anti):
+    n_steps = 6
+    m = model_with(P, HES)
+    c = o.make_config(HES, EM, n_paths, n_steps, antithetic=anti, seeds=seeds_for(n_paths, 5), n_partials=P)
+    a1 = accumulate(hhlib, m, c, True)
+    a0 = accumulate(hhlib, m, c, False)
+    assert a1.tobytes() == a0.tobytes()
+    assert a1[_ffi.HH_ACC_NPATHS] == n_paths and np.isfinite(a1).all() and a1[_ffi.HH_ACC_SUM] >= 0.0
+
+
+@pytest.mark.parametrize("dyn,strat", [(GBM, EM), (GBM, EXACT)])
+@pytest.mark.parametrize("P", [0, 2])
+def test_fused_sum_lognormal_kernels(hhlib, dyn, strat, P):
+    n_paths = 256 * 700 + 11  # the exact-law kernel runs 128 threads: two virtual threads each
+    m = model_with(P, GBM)
+    c = o.make_config(dyn, strat, n_paths, 3, seeds=seeds_for(n_paths, 6), n_partials=P)
+    a1 = accumulate(hhlib, m, c, True)
+    a0 = accumulate(hhlib, m, c, False)
+    assert a1.tobytes() == a0.tobytes()
+
+
+def test_fused_sum_path_major_replay(hhlib, oracle):
+    n_paths, n_steps = 256 * 40 + 5, 8
+    seeds = seeds_for(n_paths, 2)
+    dW = oracle.wiener_fill(HES, -0.7, 1.0, n_steps, seeds)
+    pm = dW.reshape(-1, n_steps, 2, 256).transpose(0, 3, 1, 2).reshape(-1, n_steps, 2)[:n_paths].copy()
+    m = o.make_model()
+    ct = o.make_config(HES, EM, n_paths, n_steps, noise_mode=REP, replay=dW)
+    cp = o.make_config(HES, EM, n_paths, n_steps, noise_mode=REP, replay=pm, replay_layout=_ffi.HH_REPLAY_PATH_MAJOR)
+    at = accumulate(hhlib, m, ct, True)
+    for c in (ct, cp):
+        assert accumulate(hhlib, m, c, True).tobytes() == accumulate(hhlib, m, c, False).tobytes()
+    assert accumulate(hhlib, m, cp, True).tobytes() == at.tobytes()
+
+
+def test_records_are_ready_for_the_next_launch(hhlib, oracle):
+    """Back-to-back launches of different record counts, no synchronisation in between: every one must find
+    every record word poisoned (a stale value of the launch before would be taken for this launch's)."""
+    ctx = hhlib
+    m = o.make_model()
+    shapes = [(256 * 33 + 1, 4), (5, 2), (256 * 900, 3), (256, 1), (256 * 33 + 1, 4)]
+    cfgs = [o.make_config(HES, EM, n, s, seeds=seeds_for(n, 8)) for n, s in shapes]
+    want = [accumulate(ctx, m, c, False) for c in cfgs]
+    bufs = [_ffi.DeviceBuffer(ctx, 8 * _ffi.HH_ACC_LEN) for _ in range(4 * len(cfgs))]
+    for rep in range(4):
+        for i, c in enumerate(cfgs):
+            ctx.check(ctx.lib.hh_mc_accumulate(ctx.handle, C.byref(m), C.byref(c), bufs[rep * len(cfgs) + i].ptr, None))
+    ctx.synchronize()
+    for rep in range(4):
+        for i in range(len(cfgs)):
+            got = bufs[rep * len(cfgs) + i].download(np.empty(_ffi.HH_ACC_LEN))
+            assert got.tobytes() == want[i].tobytes(), (rep, i)
+    ro, _, _ = oracle.mc_solve(m, cfgs[0], want_terminal=False)
+    r = _ffi.hh_result()
+    ctx.lib.hh_mc_finalize(C.byref(m), C.byref(cfgs[0]), want[0].ctypes.data, C.byref(r))
+    assert r.price == pytest.approx(ro.price, rel=1e-11)
+
+
+def test_fused_sum_at_the_headline_size_under_load(hhlib):
+    """10^6 x 252 REPLAY — 3907 workgroups, two per CU, finishing while others stream — repeated: the fused
+    accumulator must equal the separate kernel's every time."""
+    ctx = hhlib
+    n_paths, n_steps = 1_000_000, 252
+    seeds = _ffi.DeviceBuffer(ctx, 8 * n_paths).upload(seeds_for(n_paths, 1))
+    dW = _ffi.DeviceBuffer(ctx, 8 * ctx.lib.hh_replay_elems(n_paths, n_steps, HES))
+    m = o.make_model()
+    ctx.check(ctx.lib.hh_wiener_fill(ctx.handle, HES, m.rho, m.T, n_steps, n_paths, seeds.ptr, 1, dW.ptr))
+    c = o.make_config(HES, EM, n_paths, n_steps, noise_mode=REP)
+    c.replay, c.replay_on_device = dW.ptr, 1
+    want = accumulate(ctx, m, c, False)
+    for _ in range(20):
+        assert accumulate(ctx, m, c, True).tobytes() == want.tobytes()
+
+
+def test_live_slots_change_between_launches(hhlib):
+    """A price-only launch, then one that carries derivatives, then price-only again, on the same records:
+    slots the first launch filled with zeros must not be taken for the second launch's derivative sums."""
+    ctx = hhlib
+    n_paths = 256 * 300 + 9
+    seeds = seeds_for(n_paths, 4)
+    jobs = [(model_with(P, HES), o.make_config(HES, EM, n_paths, 5, seeds=seeds, n_partials=P)) for P in (0, 5, 1, 0, 3)]
+    want = [accumulate(ctx, m, c, False) for m, c in jobs]
+    bufs = [_ffi.DeviceBuffer(ctx, 8 * _ffi.HH_ACC_LEN) for _ in jobs]
+    for (m, c), b in zip(jobs, bufs):
+        ctx.check(ctx.lib.hh_mc_accumulate(ctx.handle, C.byref(m), C.byref(c), b.ptr, None))
+    ctx.synchronize()
+    for w, b in zip(want, bufs):
+        assert b.download(np.empty(_ffi.HH_ACC_LEN)).tobytes() == w.tobytes()
+
+
+def test_a_sum_that_equals_the_poison_pattern(hhlib):
+    """REPLAY increments are the caller's: a NaN whose payload is the record buffer's poison pattern travels
+    through the derivative arithmetic (0 x NaN keeps the payload) into a record.  The solve must end with a NaN
+    in that sum, not wait for the record forever, and leave the records usable."""
+    ctx = hhlib
+    n_paths, n_steps = 300, 2
+    dW = np.zeros(ctx.lib.hh_replay_elems(n_paths, n_steps, HES))
+    dW.view(np.uint64)[:] = 0x7FF8C0DE7FF8C0DE
+    m = o.make_model(seeds={"V0": [1.0]}, n_partials=1)
+    c = o.make_config(HES, EM, n_paths, n_steps, noise_mode=REP, replay=dW, n_partials=1)
+    a = accumulate(ctx, m, c, True)
+    assert np.isnan(a[_ffi.HH_ACC_DSUM]) and a[_ffi.HH_ACC_NPATHS] == n_paths
+    m2 = o.make_model()
+    c2 = o.make_config(HES, EM, n_paths, n_steps, seeds=seeds_for(n_paths), n_partials=0)
+    assert accumulate(ctx, m2, c2, True).tobytes() == accumulate(ctx, m2, c2, False).tobytes()
+    c3 = o.make_config(HES, EM, n_paths, n_steps, seeds=seeds_for(n_paths), n_partials=1)
+    assert accumulate(ctx, m, c3, True).tobytes() == accumulate(ctx, m, c3, False).tobytes()

@@ -1,0 +1,260 @@
+"""hh_mc_solve_multi: several models stepped on the SAME draws in one pass — the solves a FiniteDifference or
+second-order Greek is made of (greeks_problem.jl:279-303, 318-329, 396-422: 2, 3 or 4 full solves on the seeds
+of one SimulationConfig).
+
+Bars: every output of the K-model pass is BIT-IDENTICAL to K independent hh_mc_solve calls (same arithmetic per
+model, same summation order) and matches K oracle solves to the tolerances of test_gpu_parity (REPLAY 1e-12,
+GENERATE 1e-11)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import hedgehog_jl_amd as hh
+from hedgehog_jl_amd import _ffi
+from tests import oracle_ffi as o
+
+pytestmark = pytest.mark.gpu
+
+GBM, HES = _ffi.HH_LOGNORMAL, _ffi.HH_HESTON
+EM, EXACT, BK = _ffi.HH_EULER_MARUYAMA, _ffi.HH_EXACT_LAW, _ffi.HH_BROADIE_KAYA
+GEN, REP = _ffi.HH_NOISE_GENERATE, _ffi.HH_NOISE_REPLAY
+
+
+def seeds_for(n, salt=0):
+    return np.arange(1, n + 1, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15) + np.uint64(salt)
+
+
+def bumped_models(dyn, K, same_noise_law):
+    """K models around the test model, each differing in something else; same_noise_law keeps ρ and T (what a
+    REPLAY run's increments were drawn for)"""
+    base = dict(sigma=0.2) if dyn == GBM else {}
+    bumps = [dict(), dict(S0=101.0), dict(sigma=0.21 if dyn == GBM else 0.33, strike=95.0), dict(r=0.035, cp=-1.0),
+             dict(V0=0.05, kappa=1.5), dict(theta=0.05, S0=99.0), dict(strike=110.0)]
+    if not same_noise_law:
+        bumps[2] = dict(rho=-0.5, sigma=0.33)
+        bumps[3] = dict(T=1.25, r=0.035, cp=-1.0)
+    return [o.make_model(**{**base, **bumps[k % len(bumps)]}) for k in range(K)]
+
+
+def solve_each(ctx, models, c, want_terminal):
+    out = []
+    for m in models:
+        r = _ffi.hh_result()
+        t = np.zeros(c.n_paths * (2 if c.antithetic else 1)) if want_terminal else None
+        ctx.check(ctx.lib.hh_mc_solve(ctx.handle, C.byref(m), C.byref(c), C.byref(r), t.ctypes.data if want_terminal else None))
+        out.append((r, t))
+    return out
+
+
+def solve_multi(ctx, models, c, want_terminal):
+    K = len(models)
+    arr = (_ffi.hh_model * K)(*models)
+    res = (_ffi.hh_result * K)()
+    terms = [np.zeros(c.n_paths * (2 if c.antithetic else 1)) for _ in range(K)] if want_terminal else None
+    tp = (C.c_void_p * K)(*[t.ctypes.data for t in terms]) if want_terminal else None
+    ctx.check(ctx.lib.hh_mc_solve_multi(ctx.handle, arr, K, C.byref(c), res, tp))
+    return [(res[k], terms[k] if want_terminal else None) for k in range(K)]
+
+
+FIELDS = ("price", "std_error", "sum_payoff", "sumsq_payoff", "n_paths_done")
+
+
+def same_bits(a, b):
+    return all(np.float64(getattr(a, f)).tobytes() == np.float64(getattr(b, f)).tobytes() for f in FIELDS)
+
+
+@pytest.mark.parametrize("dyn,strat,split", [(HES, EM, 1), (HES, EM, 0), (GBM, EM, 1), (GBM, EXACT, 1)])
+@pytest.mark.parametrize("noise", [GEN, REP])
+@pytest.mark.parametrize("anti", [0, 1])
+@pytest.mark.parametrize("K", [2, 3, 4])
+def test_multi_is_k_independent_solves_bit_for_bit(hhlib, oracle, dyn, strat, split, noise, anti, K):
+    n_paths, n_steps = 256 * 9 + 77, (1 if strat == EXACT else 23)
+    seeds = seeds_for(n_paths, 11)
+    models = bumped_models(dyn, K, same_noise_law=(noise == REP))
+    rep = None
+    if noise == REP:
+        rep = oracle.wiener_fill(dyn, models[0].rho, models[0].T, n_steps, seeds) if strat == EM else \
+            np.random.default_rng(3).standard_normal(n_paths)
+    c = o.make_config(dyn, strat, n_paths, n_steps, antithetic=anti, em_split=split, noise_mode=noise, seeds=seeds, replay=rep)
+    each = solve_each(hhlib, models, c, True)
+    multi = solve_multi(hhlib, models, c, True)
+    for k, ((r1, t1), (rk, tk)) in enumerate(zip(each, multi)):
+        assert same_bits(r1, rk), k
+        assert t1.tobytes() == tk.tobytes(), k
+        ro, to, _ = oracle.mc_solve(models[k], c)
+        tol = 1e-12 if noise == REP and strat == EM else 1e-11
+        np.testing.assert_allclose(tk, to, rtol=tol)
+        assert rk.price == pytest.approx(ro.price, rel=tol, abs=1e-300)
+    # models that differ must have given different prices (nothing was computed once and copied)
+    assert len({np.float64(r.price).tobytes() for r, _ in multi}) == K
+
+
+@pytest.mark.parametrize("K", [5, 7, 9, 16])
+def test_more_models_than_one_pass_holds(hhlib, K):
+    n_paths, n_steps = 1500, 10
+    models = bumped_models(HES, K, same_noise_law=False)
+    for k, m in enumerate(models):
+        m.strike = 90.0 + k  # all different
+    c = o.make_config(HES, EM, n_paths, n_steps, seeds=seeds_for(n_paths, 2))
+    each = solve_each(hhlib, models, c, False)
+    multi = solve_multi(hhlib, models, c, False)
+    assert all(same_bits(a[0], b[0]) for a, b in zip(each, multi))
+
+
+def test_multi_above_the_small_grid_and_with_a_ragged_tile(hhlib, oracle):
+    n_paths, n_steps = 256 * 600 + 1, 9
+    seeds = seeds_for(n_paths, 5)
+    models = bumped_models(HES, 3, same_noise_law=True)
+    dW = oracle.wiener_fill(HES, models[0].rho, models[0].T, n_steps, seeds)
+    for c in (o.make_config(HES, EM, n_paths, n_steps, noise_mode=REP, replay=dW),
+              o.make_config(HES, EM, n_paths, n_steps, seeds=seeds, antithetic=1)):
+        assert all(same_bits(a[0], b[0]) for a, b in zip(solve_each(hhlib, models, c, False), solve_multi(hhlib, models, c, False)))
+
+
+def test_multi_path_major_replay_and_device_buffers(hhlib, oracle):
+    ctx = hhlib
+    n_paths, n_steps = 256 * 12 + 3, 8
+    seeds = seeds_for(n_paths, 4)
+    models = bumped_models(HES, 2, same_noise_law=True)
+    dW = oracle.wiener_fill(HES, models[0].rho, models[0].T, n_steps, seeds)
+    pm = dW.reshape(-1, n_steps, 2, 256).transpose(0, 3, 1, 2).reshape(-1, n_steps, 2)[:n_paths].copy()
+    ct = o.make_config(HES, EM, n_paths, n_steps, noise_mode=REP, replay=dW)
+    cp = o.make_config(HES, EM, n_paths, n_steps, noise_mode=REP, replay=pm, replay_layout=_ffi.HH_REPLAY_PATH_MAJOR)
+    want = solve_multi(ctx, models, ct, True)
+    got = solve_multi(ctx, models, cp, True)
+    assert all(same_bits(a[0], b[0]) and a[1].tobytes() == b[1].tobytes() for a, b in zip(want, got))
+    # device-resident increments and device terminal buffers
+    dev = _ffi.DeviceBuffer(ctx, dW.nbytes).upload(dW)
+    cd = o.make_config(HES, EM, n_paths, n_steps, noise_mode=REP)
+    cd.replay, cd.replay_on_device, cd.replay_len, cd.terminal_on_device = dev.ptr, 1, dW.size, 1
+    tb = [_ffi.DeviceBuffer(ctx, 8 * n_paths) for _ in models]
+    arr = (_ffi.hh_model * 2)(*models)
+    res = (_ffi.hh_result * 2)()
+    ctx.check(ctx.lib.hh_mc_solve_multi(ctx.handle, arr, 2, C.byref(cd), res, (C.c_void_p * 2)(*[b.ptr for b in tb])))
+    for k in range(2):
+        assert same_bits(res[k], want[k][0])
+        assert tb[k].download(np.empty(n_paths)).tobytes() == want[k][1].tobytes()
+
+
+def test_multi_with_the_separate_reduction_kernel(hhlib):
+    n_paths = 256 * 40 + 9
+    models = bumped_models(HES, 4, same_noise_law=False)
+    c = o.make_config(HES, EM, n_paths, 12, seeds=seeds_for(n_paths, 8), antithetic=1)
+    want = solve_multi(hhlib, models, c, False)
+    hhlib.set_option(_ffi.HH_OPT_FUSE_REDUCE, 0)
+    try:
+        got = solve_multi(hhlib, models, c, False)
+    finally:
+        hhlib.set_option(_ffi.HH_OPT_FUSE_REDUCE, 1)
+    assert all(same_bits(a[0], b[0]) for a, b in zip(want, got))
+
+
+def test_multi_broadie_kaya_is_one_chain_per_model(hhlib):
+    n_paths = 4000
+    models = bumped_models(HES, 3, same_noise_law=False)
+    c = o.make_config(HES, BK, n_paths, 1, seeds=seeds_for(n_paths, 1))
+    each = solve_each(hhlib, models, c, True)
+    multi = solve_multi(hhlib, models, c, True)
+    for (r1, t1), (rk, tk) in zip(each, multi):
+        assert same_bits(r1, rk) and t1.tobytes() == tk.tobytes() and rk.bk_cf_terms == r1.bk_cf_terms
+
+
+def test_multi_argument_errors(hhlib):
+    ctx = hhlib
+    models = bumped_models(HES, 2, same_noise_law=True)
+    arr = (_ffi.hh_model * 2)(*models)
+    res = (_ffi.hh_result * 17)()
+    c = o.make_config(HES, EM, 100, 4, seeds=seeds_for(100))
+    assert ctx.lib.hh_mc_solve_multi(ctx.handle, arr, 0, C.byref(c), res, None) == _ffi.HH_ERR_INVALID
+    assert ctx.lib.hh_mc_solve_multi(ctx.handle, arr, 17, C.byref(c), res, None) == _ffi.HH_ERR_INVALID
+    assert ctx.lib.hh_mc_solve_multi(ctx.handle, None, 2, C.byref(c), res, None) == _ffi.HH_ERR_INVALID
+    cp = o.make_config(HES, EM, 100, 4, seeds=seeds_for(100), n_partials=1)
+    assert ctx.lib.hh_mc_solve_multi(ctx.handle, arr, 2, C.byref(cp), res, None) == _ffi.HH_ERR_UNSUPPORTED
+    models[1].S0 = -1.0
+    bad = (_ffi.hh_model * 2)(*models)
+    assert ctx.lib.hh_mc_solve_multi(ctx.handle, bad, 2, C.byref(c), res, None) == _ffi.HH_ERR_INVALID
+    assert b"S0" in ctx.lib.hh_last_error(ctx.handle)
+    # one model: hh_mc_solve itself
+    r1 = _ffi.hh_result()
+    ctx.check(ctx.lib.hh_mc_solve(ctx.handle, C.byref(arr[0]), C.byref(c), C.byref(r1), None))
+    ctx.check(ctx.lib.hh_mc_solve_multi(ctx.handle, arr, 1, C.byref(c), res, None))
+    assert same_bits(r1, res[0])
+
+
+# ---- through the host API: the reference's own call forms ---------------------------------------------------
+
+def heston_problem():
+    ref = hh.Date(2021, 1, 1)
+    mkt = hh.HestonInputs(ref, 0.03, 100.0, 0.04, 2.0, 0.04, 0.3, -0.7)
+    return hh.PricingProblem(hh.VanillaOption(100.0, hh.Date(2022, 1, 1), hh.European(), hh.Call(), hh.Spot()), mkt)
+
+
+def heston_method(n=20_000, steps=50, anti=False):
+    vr = hh.Antithetic() if anti else hh.NoVarianceReduction()
+    return hh.MonteCarlo(hh.HestonDynamics(), hh.EulerMaruyama(),
+                         hh.SimulationConfig(n, steps=steps, seeds=seeds_for(n, 21), variance_reduction=vr))
+
+
+@pytest.mark.parametrize("scheme", [hh.FDCentral(), hh.FDForward(), hh.FDBackward()])
+@pytest.mark.parametrize("path", ["market_inputs.spot", "market_inputs.V0", "market_inputs.σ", "market_inputs.ρ", "payoff.strike"])
+def test_finite_difference_greek_is_the_references_two_solves(hhlib, scheme, path):
+    """solve(GreekProblem, FiniteDifference, MonteCarlo) = compute_fd_derivative's formula on two plain solves
+    (greeks_problem.jl:279-303): the shared pass must give that number exactly."""
+    prob, m, lens, eps = heston_problem(), heston_method(), hh.optic(path), 1e-3
+    x0 = lens(prob)
+    price = lambda x: hh.solve(hh.set(prob, lens, x), m, ensemble=False).price
+    if isinstance(scheme, hh.FDForward):
+        want = (price(x0 * (1 + eps)) - price(x0)) / (x0 * eps)
+    elif isinstance(scheme, hh.FDBackward):
+        want = (price(x0) - price(x0 * (1 - eps))) / (x0 * eps)
+    else:
+        want = (price(x0 * (1 + eps)) - price(x0 * (1 - eps))) / (2 * eps * x0)
+    got = hh.solve(hh.GreekProblem(prob, lens), hh.FiniteDifference(eps, scheme), m).greek
+    assert np.float64(got).tobytes() == np.float64(want).tobytes()
+
+
+def test_second_order_greeks_are_the_references_stencils(hhlib):
+    prob, m, eps = heston_problem(), heston_method(anti=True), 0.5
+    spot, v0 = hh.optic("market_inputs.spot"), hh.optic("market_inputs.V0")
+    f = lambda x, y, l1, l2: hh.solve(hh.set(hh.set(prob, l1, x), l2, y), m, ensemble=False).price
+    x0 = spot(prob)
+    gamma = (f(x0 + eps, x0 + eps, spot, spot) - 2 * f(x0, x0, spot, spot) + f(x0 - eps, x0 - eps, spot, spot)) / eps**2
+    got = hh.solve(hh.SecondOrderGreekProblem(prob, spot, spot), hh.FiniteDifference(eps), m).greek
+    assert np.float64(got).tobytes() == np.float64(gamma).tobytes()
+    e2, y0 = 0.004, v0(prob)
+    cross = (f(x0 + e2, y0 + e2, spot, v0) - f(x0 + e2, y0 - e2, spot, v0) - f(x0 - e2, y0 + e2, spot, v0)
+             + f(x0 - e2, y0 - e2, spot, v0)) / (4 * e2**2)
+    got = hh.solve(hh.SecondOrderGreekProblem(prob, spot, v0), hh.FiniteDifference(e2), m).greek
+    assert np.float64(got).tobytes() == np.float64(cross).tobytes()
+
+
+def test_batch_of_finite_differences_shares_its_passes(hhlib):
+    prob, m, eps = heston_problem(), heston_method(), 1e-3
+    lenses = (hh.optic("market_inputs.spot"), hh.optic("market_inputs.V0"), hh.optic("market_inputs.κ"))
+    got = hh.solve(hh.BatchGreekProblem(prob, lenses), hh.FiniteDifference(eps), m)
+    for lens in lenses:
+        one = hh.solve(hh.GreekProblem(prob, lens), hh.FiniteDifference(eps), m).greek
+        assert np.float64(got[lens]).tobytes() == np.float64(one).tobytes()
+    # and the bumped delta is the AD delta to the bump's order
+    ad = hh.solve(hh.GreekProblem(prob, lenses[0]), hh.ForwardAD(), m).greek
+    assert got[lenses[0]] == pytest.approx(ad, rel=2e-2)
+
+
+def test_multi_at_the_headline_size_both_modes(hhlib):
+    """10^6 x 252: the central bump of the spot, GENERATE and REPLAY, against two plain solves."""
+    ctx = hhlib
+    n_paths, n_steps = 1_000_000, 252
+    seeds = _ffi.DeviceBuffer(ctx, 8 * n_paths).upload(seeds_for(n_paths, 1))
+    dW = _ffi.DeviceBuffer(ctx, 8 * ctx.lib.hh_replay_elems(n_paths, n_steps, HES))
+    models = [o.make_model(S0=100.1), o.make_model(S0=99.9)]
+    ctx.check(ctx.lib.hh_wiener_fill(ctx.handle, HES, models[0].rho, models[0].T, n_steps, n_paths, seeds.ptr, 1, dW.ptr))
+    for noise in (GEN, REP):
+        c = o.make_config(HES, EM, n_paths, n_steps, noise_mode=noise)
+        c.seeds, c.seeds_on_device, c.seeds_len = seeds.ptr, 1, n_paths
+        c.replay, c.replay_on_device = dW.ptr, 1
+        each = solve_each(ctx, models, c, False)
+        multi = solve_multi(ctx, models, c, False)
+        assert all(same_bits(a[0], b[0]) for a, b in zip(each, multi))
+        delta = (multi[0][0].price - multi[1][0].price) / 0.2
+        assert delta == pytest.approx(0.6557, abs=5e-3)  # Carr–Madan ∂/∂S0 of H252, Euler bias within
