@@ -104,6 +104,10 @@ def parse(argv=None):
                          "hh_mgpu_solve_shards (RCCL all-reduce inside the library, host ordered sum when "
                          "RCCL is unavailable) instead of one rank per GPU")
     ap.add_argument("--mgpu-flags", type=int, default=0, help="hh_mgpu_create flags: 0 auto, 1 host sum, 2 RCCL")
+    ap.add_argument("--allow-rccl-override", action="store_true",
+                    help="accept $HEDGEHOG_MC_RCCL (another library bound in place of librccl by hh_mgpu — the "
+                         "tests' stand-in); without this flag a set variable is an error, so that no line of a "
+                         "real run can come from a substitute unnoticed")
     ap.add_argument("--no-single-process-child", action="store_true",
                     help="do not run the one-process form as a child (profilers that preload into children)")
     # rehearsal knobs (tests): ranks on one GPU need gloo (RCCL refuses two ranks per device)
@@ -235,6 +239,15 @@ class Dist:
         t = torch.tensor([x], dtype=torch.float64, device="cpu" if self.backend == "gloo" else dev)
         self.pg.all_reduce(t, op=self.pg.ReduceOp.MAX)
         return float(t.item())
+
+    def gather_floats(self, x, dev):
+        """one float of every rank, in rank order (an all-reduce of a one-hot vector: the same collective path)"""
+        if self.pg is None:
+            return [x]
+        t = torch.zeros(self.world, dtype=torch.float64, device="cpu" if self.backend == "gloo" else dev)
+        t[self.rank] = x
+        self.pg.all_reduce(t)
+        return [float(v) for v in t.cpu()]
 
     def count_ranks(self, dev):
         """ranks that really take part in the collective: an all-reduce of ones"""
@@ -393,26 +406,37 @@ def single_process(args):
                 steps(4)
             ramp = (time.perf_counter() - t0) * 1e3
         steps(w)
-        mg.ctx(0).enable_timing(True)
         for g in range(G):
+            mg.ctx(g).enable_timing(True)
             mg.ctx(g).synchronize()
         t0 = time.perf_counter()
         r = steps(k)            # every call returns with all devices synchronised
         dt = time.perf_counter() - t0
-        kern = mg.ctx(0).read_timings()
-        mg.ctx(0).enable_timing(False)
+        kern = [mg.ctx(g).read_timings() for g in range(G)]
+        for g in range(G):
+            mg.ctx(g).enable_timing(False)
         return dt, kern, r, ramp
 
+    # who really carries the exchange: counted by a collective of the library's own path, and named
+    ranks_counted, mode_tested = mg.selftest()
+    info = mg.rccl_info()
     dt_c, _, _, _ = timed(args.steps, args.warmup, 0.0)
     dt, kern, res, ramp = timed(args.steps, args.warmup, args.ramp_ms)
+    per_shard_us, phase_us = mg.enqueue_stats()
     tot = float(n_global) * n_steps
     n0 = int(cfgs[0].n_paths)
+    rccl_used = mg.reduce_mode == _ffi.HH_MGPU_REDUCE_RCCL  # AFTER the run: a collective that failed fell back
     out = {
         "metric": "MC path-steps/sec (Heston Euler-Maruyama, 1e6 paths x 252 steps per GPU)",
         "value": tot * args.steps / dt, "value_cold": tot * args.steps / dt_c, "unit": "path-steps/s",
         "n_gpus": G, "single_process": True,
-        "reduce": "rccl" if mg.reduce_mode == _ffi.HH_MGPU_REDUCE_RCCL else "host ordered sum",
-        "rccl_ranks": G if mg.reduce_mode == _ffi.HH_MGPU_REDUCE_RCCL else 0,
+        "reduce": "rccl" if rccl_used else "host ordered sum",
+        "reduce_mode_in_selftest": "rccl" if mode_tested == _ffi.HH_MGPU_REDUCE_RCCL else "host ordered sum",
+        # ranks counted by an all-reduce of ones through the solve's own exchange (hh_mgpu_selftest); 0 = no collective ran
+        "rccl_ranks": ranks_counted if (rccl_used and mode_tested == _ffi.HH_MGPU_REDUCE_RCCL) else 0,
+        "ranks_counted_by_the_exchange": ranks_counted,
+        "rccl_library": info["library"], "rccl_version": info["version"],
+        "rccl_library_from_env": info["from_env"],
         "reduce_note": mg.last_error(),
         "steps": args.steps, "warmup": args.warmup, "clock_ramp_ms": ramp,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
@@ -427,9 +451,11 @@ def single_process(args):
                                   "concurrently by the library's per-device threads, one 16-double all-reduce "
                                   "inside the library" % G},
         "price": res.price, "std_error": res.std_error, "analytic_carr_madan": H252_ANALYTIC,
+        "per_rank_kernel_ms": [float(np.mean(k)) if len(k) else None for k in kern],
+        "enqueue_host_us": {"per_shard": per_shard_us, "phase": phase_us},
         "roofline": dict(hbm_roofline("euler_kernel<HestonModel,REPLAY> (device %d's launches)" % devs[0],
-                                      BYTES_PER_PATH_STEP * n0 * n_steps, float(np.mean(kern))),
-                         traffic=None, launches_timed=len(kern)),
+                                      BYTES_PER_PATH_STEP * n0 * n_steps, float(np.mean(kern[0]))),
+                         traffic=None, launches_timed=len(kern[0])),
     }
     print(json.dumps(out), flush=True)
     mg.close()
@@ -444,6 +470,8 @@ def run_single_process_child(args, world, timeout=240):
            "--nsteps", str(args.nsteps), "--ramp-ms", str(args.ramp_ms)]
     if args.devices:
         cmd += ["--devices", args.devices]
+    if args.allow_rccl_override:
+        cmd += ["--allow-rccl-override"]
     env = {k: v for k, v in os.environ.items()
            if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "HH_BENCH_CHILD",
                         "GROUP_RANK", "ROLE_RANK", "LOCAL_WORLD_SIZE", "TORCHELASTIC_RUN_ID")}
@@ -452,8 +480,10 @@ def run_single_process_child(args, world, timeout=240):
         for line in reversed(p.stdout.splitlines()):
             if line.startswith("{"):
                 j = json.loads(line)
-                return {k: j[k] for k in ("value", "value_cold", "unit", "n_gpus", "reduce", "reduce_note",
-                                          "ms_per_step", "price", "steps", "warmup", "roofline")}
+                return {k: j.get(k) for k in ("value", "value_cold", "unit", "n_gpus", "reduce", "reduce_note",
+                                              "rccl_ranks", "ranks_counted_by_the_exchange", "rccl_library",
+                                              "rccl_version", "rccl_library_from_env", "per_rank_kernel_ms",
+                                              "enqueue_host_us", "ms_per_step", "price", "steps", "warmup", "roofline")}
         return {"error": "no JSON line", "rc": p.returncode, "stderr_tail": p.stderr[-400:]}
     except subprocess.TimeoutExpired:
         return {"error": "timed out after %d s" % timeout}
@@ -463,6 +493,11 @@ def run_single_process_child(args, world, timeout=240):
 
 def main():
     args = parse()
+    if os.environ.get("HEDGEHOG_MC_RCCL") and not args.allow_rccl_override:
+        print("bench.py: $HEDGEHOG_MC_RCCL is set (%s): hh_mgpu would bind that library in place of librccl. "
+              "Unset it, or pass --allow-rccl-override to run with it knowingly (the line then names it)."
+              % os.environ["HEDGEHOG_MC_RCCL"], file=sys.stderr)
+        sys.exit(2)
     if args.single_process:
         sys.exit(single_process(args))
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -596,6 +631,20 @@ def main():
     vt = valu_insts() if rank == 0 else {}
 
     kern_ms = float(np.mean(kern_rep))
+    per_rank_kernel_ms = d.gather_floats(kern_ms, dev)
+    per_rank_step_ms = d.gather_floats(dt_rep / args.steps * 1e3, dev)
+    # which collective library carried the run's all-reduces (torch.distributed's backend "nccl" IS RCCL on ROCm)
+    coll = {"backend": args.backend, "ranks_counted_by_all_reduce_of_ones": rccl_ranks}
+    if args.backend == "nccl" and d.on:
+        try:
+            coll["rccl_version"] = ".".join(str(x) for x in torch.cuda.nccl.version())
+        except Exception as e:  # noqa: BLE001
+            coll["rccl_version"] = repr(e)
+        try:  # the file the process mapped it from
+            libs = sorted({ln.split()[-1] for ln in open("/proc/self/maps") if "librccl" in ln or "libnccl" in ln})
+            coll["rccl_library"] = libs
+        except Exception:  # noqa: BLE001
+            coll["rccl_library"] = None
     traffic, traffic_source = None, None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(tpath) and n_paths == 1_000_000 and n_steps == 252:
@@ -615,6 +664,9 @@ def main():
         "unit": "path-steps/s",
         "n_gpus": world,
         "rccl_ranks": rccl_ranks,
+        "collective": coll,
+        "per_rank_kernel_ms": per_rank_kernel_ms,
+        "per_rank_ms_per_step": per_rank_step_ms,
         "steps": args.steps,
         "warmup": args.warmup,
         "clock_ramp_ms": ramp_ms,
@@ -724,6 +776,54 @@ def main():
             ctx.enable_timing(False)
             return t, finalize(mdl, cfg, accum.cpu().numpy().copy())
 
+        # `solve_ms` of the rows below is the HIP-event time of EVERYTHING one hh_mc_accumulate enqueues (since
+        # round 5 the timing hook brackets the call's last kernel too: a record reduction that is a kernel of its
+        # own — Broadie–Kaya, baskets — is inside)
+        def multi_ms(models, cfg, reps=10, warm_ms=15.0):
+            K = len(models)
+            arr = (_ffi.hh_model * K)(*models)
+            acc_k = torch.zeros(K * _ffi.HH_ACC_LEN, dtype=torch.float64, device=dev)
+            call = lambda: ctx.check(lib.hh_mc_accumulate_multi(h, arr, K, C.byref(cfg), acc_k.data_ptr(), None))  # noqa: E731
+            t0 = time.perf_counter()
+            while (time.perf_counter() - t0) * 1e3 < warm_ms:
+                for _ in range(4):
+                    call()
+                torch.cuda.synchronize(dev)
+            ctx.enable_timing(True)
+            for _ in range(reps):
+                call()
+            t = float(np.median(ctx.read_timings()))
+            ctx.enable_timing(False)
+            a = acc_k.cpu().numpy().copy()
+            return t, [finalize(models[k], cfg, a[k * _ffi.HH_ACC_LEN:(k + 1) * _ffi.HH_ACC_LEN].copy()) for k in range(K)]
+
+        # ---- FiniteDifference(1e-3, FDCentral) delta: the two bumped solves of greeks_problem.jl:296-303 on
+        #      the same draws in ONE pass (hh_mc_accumulate_multi), both noise modes
+        eps = 1e-3
+        up, dn = dict(H252, S0=H252["S0"] * (1 + eps)), dict(H252, S0=H252["S0"] * (1 - eps))
+        fd_models = [_ffi.make_model(**up), _ffi.make_model(**dn)]
+        fd = {"what": "solve(GreekProblem(prob, spot), FiniteDifference(1e-3), MonteCarlo): the reference runs two full "
+                      "solves on the same seeds (greeks_problem.jl:296-303); here both models are stepped on each draw "
+                      "in one pass — bit-identical prices (tests/test_gpu_multi.py)", "bump": eps}
+        for key, cfg_n in (("generate", sh.config(_ffi.HH_NOISE_GENERATE)), ("replay", sh.config(_ffi.HH_NOISE_REPLAY))):
+            t_one, _ = kernel_ms(fd_models[0], cfg_n)
+            t_two, rr = multi_ms(fd_models, cfg_n)
+            delta = (rr[0].price - rr[1].price) / (2 * eps * H252["S0"])
+            ent = {"solve_ms": t_two, "two_separate_solves_ms": 2 * t_one, "ratio": t_two / (2 * t_one),
+                   "delta": delta, "delta_fourier": H252_GREEKS_FOURIER[0],
+                   "model_path_steps_per_s": 2.0 * n_paths * n_steps / (t_two * 1e-3)}
+            if key == "replay":  # the 16 bytes of a pair of increments now serve TWO path-steps
+                ent["roofline"] = hbm_roofline("euler_multi_kernel<HestonModel,REPLAY,K=2>",
+                                               BYTES_PER_PATH_STEP * n_paths * n_steps, t_two,
+                                               bytes_per_model_path_step=BYTES_PER_PATH_STEP / 2)
+                ent["roofline_valu"] = valu_roofline("euler_multi_kernel<HestonModel,REPLAY,K=2>", "heston_euler_replay_multi2",
+                                                     float(n_paths) * n_steps, t_two, vt)
+            else:
+                ent["roofline"] = valu_roofline("euler_multi_kernel<HestonModel,GENERATE,K=2>", "heston_euler_generate_multi2",
+                                                float(n_paths) * n_steps, t_two, vt)
+            fd[key] = ent
+        out["fd_central_delta_H252"] = fd
+
         c4 = _ffi.make_config(_ffi.HH_HESTON, _ffi.HH_BROADIE_KAYA, n_paths)
         c4.seeds, c4.seeds_on_device = sh.seeds.data_ptr(), 1
         t4, r4 = kernel_ms(model, c4, reps=5)
@@ -731,23 +831,33 @@ def main():
         c2 = _ffi.make_config(_ffi.HH_LOGNORMAL, _ffi.HH_EXACT_LAW, n_paths)
         c2.seeds, c2.seeds_on_device = sh.seeds.data_ptr(), 1
         t2, r2 = kernel_ms(m2, c2)
+        n2b = 100_000_000  # the same law at a size where the kernel, not its launch, is what is timed
+        c2b = _ffi.make_config(_ffi.HH_LOGNORMAL, _ffi.HH_EXACT_LAW, n2b)
+        c2b.seeds, c2b.seeds_on_device = sh.seeds.data_ptr(), 1
+        t2b, r2b = kernel_ms(m2, c2b, reps=10)
         ca = sh.config(_ffi.HH_NOISE_REPLAY)
         ca.antithetic = 1
         ta, ra = kernel_ms(model, ca)
         out["other_configs"] = {
             "config2_lognormal_exact": {
-                "paths_per_s": n_paths / (t2 * 1e-3), "kernel_ms": t2, "price": r2.price,
+                "paths_per_s": n_paths / (t2 * 1e-3), "solve_ms": t2, "kernel_ms": t2, "price": r2.price,
                 "analytic": 10.450583572185565,
-                "roofline": valu_roofline("exact_gbm_kernel", "lognormal_exact", float(n_paths), t2, vt)},
+                "note": "BASELINE's size (10^6): ONE launch of ~15 us — launch-bound, its fraction says little; "
+                        "the 10^8 row beside it is the kernel",
+                "roofline": valu_roofline("exact_gbm_kernel<1 pair per lane>", "lognormal_exact", float(n_paths), t2, vt)},
+            "config2_lognormal_exact_1e8": {
+                "paths": n2b, "paths_per_s": n2b / (t2b * 1e-3), "solve_ms": t2b, "price": r2b.price,
+                "std_error": r2b.std_error, "analytic": 10.450583572185565,
+                "roofline": valu_roofline("exact_gbm_kernel<64 pairs per lane>", "lognormal_exact_1e8", float(n2b), t2b, vt)},
             "config4_broadie_kaya": {
-                "paths_per_s": n_paths / (t4 * 1e-3), "kernel_ms": t4, "price": r4.price,
+                "paths_per_s": n_paths / (t4 * 1e-3), "solve_ms": t4, "kernel_ms": t4, "price": r4.price,
                 "std_error": r4.std_error, "cf_terms_per_path": r4.bk_cf_terms / n_paths,
                 "bisect_fallbacks": int(r4.bk_bisect_fallback),
                 "roofline": valu_roofline("bk_kernel + bk_scan_kernel + bk_fallback_kernel",
                                           "broadie_kaya", float(n_paths), t4, vt)},
             "config3_antithetic_replay": {
                 "integrated_path_steps_per_s": 2.0 * n_paths * n_steps / (ta * 1e-3),
-                "kernel_ms": ta, "price": ra.price, "std_error": ra.std_error,
+                "solve_ms": ta, "kernel_ms": ta, "price": ra.price, "std_error": ra.std_error,
                 "roofline": hbm_roofline("euler_kernel<HestonModel,REPLAY,ANTI>",
                                          BYTES_PER_PATH_STEP * n_paths * n_steps, ta)},
         }

@@ -126,6 +126,9 @@ SYMBOLS = [
     ("hh_replay_elems", C.c_size_t, [C.c_uint64, C.c_uint32, C.c_int32]),
     ("hh_replay_pack", C.c_int, [_vp, C.c_int32, C.c_uint64, C.c_uint32, _vp, C.c_int32, _vp]),
     ("hh_wiener_fill", C.c_int, [_vp, C.c_int32, C.c_double, C.c_double, C.c_uint32, C.c_uint64, _vp, C.c_int32, _vp]),
+    ("hh_seeds_fingerprint", C.c_uint64, [_vp, C.c_uint64]),
+    ("hh_seeds_cache", C.c_int, [_vp, _vp, C.c_uint64, C.c_uint64, C.POINTER(_vp)]),
+    ("hh_seeds_cache_stats", C.c_int, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     ("hh_device_malloc", C.c_int, [_vp, C.c_size_t, C.POINTER(_vp)]),
     ("hh_device_free", C.c_int, [_vp, _vp]),
     ("hh_memcpy_h2d", C.c_int, [_vp, _vp, _vp, C.c_size_t]),
@@ -140,12 +143,15 @@ SYMBOLS = [
     ("hh_mgpu_n_devices", C.c_int, [_vp]),
     ("hh_mgpu_reduce_mode", C.c_int, [_vp]),
     ("hh_mgpu_ctx", _vp, [_vp, C.c_int]),
+    ("hh_mgpu_selftest", C.c_int, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    ("hh_mgpu_rccl_info", C.c_int, [_vp, C.c_char_p, C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     ("hh_mgpu_set_option", C.c_int, [_vp, C.c_int32, C.c_int64]),
     ("hh_mgpu_enqueue_stats", C.c_int, [_vp, _vp, C.POINTER(C.c_double)]),
     ("hh_mgpu_shard_range", None, [C.c_uint64, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     ("hh_mgpu_solve", C.c_int, [_vp, C.POINTER(hh_model), C.POINTER(hh_config), C.POINTER(hh_result), _vp]),
     ("hh_mgpu_solve_shards", C.c_int, [_vp, C.POINTER(hh_model), C.POINTER(hh_config), C.POINTER(hh_result), _vp]),
     ("hh_mgpu_solve_basket", C.c_int, [_vp, C.POINTER(hh_model), C.POINTER(hh_config), _vp, _vp, C.c_uint32, _vp]),
+    ("hh_mgpu_solve_multi", C.c_int, [_vp, C.POINTER(hh_model), C.c_uint32, C.POINTER(hh_config), C.POINTER(hh_result)]),
     ("hh_mgpu_lsm_solve", C.c_int, [_vp, C.POINTER(hh_model), C.POINTER(hh_config), C.c_int32, C.c_double,
                                     C.POINTER(hh_lsm_result), _vp, _vp]),
 ]
@@ -208,6 +214,18 @@ class Context:
 
     def synchronize(self):
         self.check(self.lib.hh_ctx_synchronize(self.handle))
+
+    def seeds_on_device(self, seeds, fingerprint: int = 0) -> int:
+        """Device address of this seed vector in the context's content-addressed cache (hh_seeds_cache): valid
+        until a later call misses — ask right before every solve."""
+        p = _vp()
+        self.check(self.lib.hh_seeds_cache(self.handle, _vp(seeds.ctypes.data), seeds.size, int(fingerprint), C.byref(p)))
+        return p.value
+
+    def seeds_cache_stats(self):
+        h, u, e = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        self.check(self.lib.hh_seeds_cache_stats(self.handle, C.byref(h), C.byref(u), C.byref(e)))
+        return {"hits": h.value, "uploads": u.value, "evictions": e.value}
 
     def enable_timing(self, on: bool = True):
         self.check(self.lib.hh_ctx_enable_timing(self.handle, int(on)))
@@ -335,6 +353,20 @@ class MultiGpu:
     def last_error(self) -> str:
         return self.lib.hh_mgpu_last_error(self.handle).decode(errors="replace")
 
+    def selftest(self):
+        """(ranks counted by an all-reduce of ones through the solve's own exchange, reduce mode it ran in)"""
+        n, mode = C.c_int32(0), C.c_int32(0)
+        self.check(self.lib.hh_mgpu_selftest(self.handle, C.byref(n), C.byref(mode)))
+        return n.value, mode.value
+
+    def rccl_info(self):
+        """{"library": path the collective entry points were bound from ("" = none), "version", "from_env", "usable"}"""
+        buf = C.create_string_buffer(512)
+        ver, env = C.c_int32(0), C.c_int32(0)
+        rc = self.lib.hh_mgpu_rccl_info(self.handle, buf, 512, C.byref(ver), C.byref(env))
+        return {"library": buf.value.decode(errors="replace"), "version": ver.value, "from_env": bool(env.value),
+                "usable": rc == HH_OK}
+
     def set_option(self, option: int, value: int):
         self.check(self.lib.hh_mgpu_set_option(self.handle, int(option), int(value)))
 
@@ -363,6 +395,12 @@ class MultiGpu:
         self.check(self.lib.hh_mgpu_solve(self.handle, C.byref(model), C.byref(cfg), C.byref(res),
                                           terminal.ctypes.data if terminal is not None else None))
         return res
+
+    def solve_multi(self, models, cfg):
+        arr = (hh_model * len(models))(*models)
+        res = (hh_result * len(models))()
+        self.check(self.lib.hh_mgpu_solve_multi(self.handle, arr, len(models), C.byref(cfg), res))
+        return list(res)
 
     def solve_shards(self, model, cfgs, terminals=None) -> hh_result:
         arr = (hh_config * len(cfgs))(*cfgs)

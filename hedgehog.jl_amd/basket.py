@@ -75,8 +75,8 @@ def solve_basket(prob: BasketPricingProblem, method, ensemble: bool = False):
                                              std_error=res[k].std_error, result=res[k])
             del keep
             continue
-        seeds_dev = cfg.device_seeds(ctx)  # uploaded once per config, not once per objective evaluation
-        c.seeds, c.seeds_on_device = seeds_dev.ptr, 1
+        # the context's seed cache: uploaded once per config, not once per objective evaluation
+        c.seeds, c.seeds_on_device = cfg.device_seeds(ctx), 1
         c.seeds_len = cfg.seeds.size
         term = np.empty(c.n_paths * (2 if anti else 1)) if ensemble else None
         res = (_ffi.hh_result * K)()

@@ -151,6 +151,7 @@ int hh_ctx_create(hh_ctx** out, int device_id) {
       hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->ev_switch, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->ev_stage, hipEventDisableTiming) != hipSuccess ||
       hipMalloc((void**)&ctx->accum, HH_ACC_LEN * sizeof(double)) != hipSuccess ||
       hipHostMalloc((void**)&ctx->accum_host, (HH_ACC_LEN + 8) * sizeof(double), hipHostMallocDefault) !=
           hipSuccess) {
@@ -183,6 +184,8 @@ void hh_ctx_destroy(hh_ctx* ctx) {
   if (ctx->lsm_val) (void)hipFree(ctx->lsm_val);
   if (ctx->lsm_tau) (void)hipFree(ctx->lsm_tau);
   if (ctx->lsm_scratch) (void)hipFree(ctx->lsm_scratch);
+  for (auto& e : ctx->seed_cache)
+    if (e.dev) (void)hipFree(e.dev);
   if (ctx->accum) (void)hipFree(ctx->accum);
   if (ctx->frecords) (void)hipFree(ctx->frecords);
   if (ctx->accum_host) (void)hipHostFree(ctx->accum_host);
@@ -190,6 +193,7 @@ void hh_ctx_destroy(hh_ctx* ctx) {
     for (auto& e : pr)
       if (e) (void)hipEventDestroy(e);
   if (ctx->ev_switch) (void)hipEventDestroy(ctx->ev_switch);
+  if (ctx->ev_stage) (void)hipEventDestroy(ctx->ev_stage);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -281,10 +285,11 @@ int hh_replay_pack(hh_ctx* ctx, int32_t dynamics, uint64_t n_paths, uint32_t n_s
     if (rc) return rc;
     HH_HIP(ctx, hipMemcpyAsync(ctx->replay_src, src, n * sizeof(double), hipMemcpyHostToDevice,
                                ctx->stream));
+    if ((rc = note_host_copy(ctx))) return rc;
     src_dev = ctx->replay_src;
   }
   HH_HIP(ctx, hh::launch_replay_pack(nc, n_paths, n_steps, src_dev, dst, ctx->stream));
-  return HH_OK;
+  return release_host_operands(ctx);
 }
 
 int hh_wiener_fill(hh_ctx* ctx, int32_t dynamics, double rho, double T, uint32_t n_steps,
@@ -301,12 +306,13 @@ int hh_wiener_fill(hh_ctx* ctx, int32_t dynamics, double rho, double T, uint32_t
     if (rc) return rc;
     HH_HIP(ctx, hipMemcpyAsync(ctx->seeds, seeds, n_paths * sizeof(uint64_t),
                                hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = note_host_copy(ctx))) return rc;
     seeds_dev = ctx->seeds;
   }
   const double dt = T / (double)n_steps;
   HH_HIP(ctx, hh::launch_wiener_fill(dynamics, rho, std::sqrt(dt), n_steps, n_paths, seeds_dev, dst,
                                      ctx->stream));
-  return HH_OK;
+  return release_host_operands(ctx);
 }
 
 // Shared body of hh_mc_accumulate / hh_mc_accumulate_basket: stage caller buffers, run the
@@ -328,6 +334,7 @@ static int stage_noise(hh_ctx* ctx, const hh_config* c, hh::DevicePtrs& p, bool 
       if (rc) return rc;
       HH_HIP(ctx, hipMemcpyAsync(ctx->seeds, c->seeds, need * sizeof(uint64_t),
                                  hipMemcpyHostToDevice, ctx->stream));
+      if ((rc = note_host_copy(ctx))) return rc;
       p.seeds = ctx->seeds;
     }
   } else if (bk) {
@@ -340,6 +347,7 @@ static int stage_noise(hh_ctx* ctx, const hh_config* c, hh::DevicePtrs& p, bool 
       if (rc) return rc;
       HH_HIP(ctx, hipMemcpyAsync(ctx->replay, c->replay, n3 * sizeof(double), hipMemcpyHostToDevice,
                                  ctx->stream));
+      if ((rc = note_host_copy(ctx))) return rc;
       p.replay = ctx->replay;
     }
   } else {
@@ -357,6 +365,7 @@ static int stage_noise(hh_ctx* ctx, const hh_config* c, hh::DevicePtrs& p, bool 
         if (rc) return rc;
         HH_HIP(ctx, hipMemcpyAsync(ctx->replay_src, c->replay, n * sizeof(double), hipMemcpyHostToDevice,
                                    ctx->stream));
+        if ((rc = note_host_copy(ctx))) return rc;
         p.replay = ctx->replay_src;
       }
       p.replay_path_major = true;
@@ -378,6 +387,7 @@ static int stage_noise(hh_ctx* ctx, const hh_config* c, hh::DevicePtrs& p, bool 
         if (rc) return rc;
         HH_HIP(ctx, hipMemcpyAsync(ctx->replay, c->replay, host_elems * sizeof(double),
                                    hipMemcpyHostToDevice, ctx->stream));
+        if ((rc = note_host_copy(ctx))) return rc;
         p.replay = ctx->replay;
       }
     } else {
@@ -478,12 +488,12 @@ int hh_mc_accumulate(hh_ctx* ctx, const hh_model* m, const hh_config* c, double*
   rc = run_simulation(ctx, m, c, terminal, false, nullptr, accum_dev, &reduced);
   if (rc) return rc;
   if (!reduced) {
-    const uint32_t n_rec = c->strategy == HH_BROADIE_KAYA ? hh::bk_record_count(c->n_paths)
-                                                          : hh::tiles_for(c->n_paths);
+    const uint32_t n_rec = c->strategy == HH_BROADIE_KAYA ? hh::bk_record_count(c->n_paths) : hh::sim_records(*c);
     HH_HIP(ctx, hh::launch_reduce_records(ctx->records, n_rec, (double)c->n_paths, accum_dev,
                                           ctx->stream, 1, m, c));
   }
   if ((rc = end_timing(ctx))) return rc;
+  if ((rc = release_host_operands(ctx))) return rc;
   return copy_back_terminal(ctx, c, terminal);
 }
 
@@ -541,11 +551,12 @@ int hh_mc_accumulate_multi(hh_ctx* ctx, const hh_model* models, uint32_t n_model
     HH_HIP(ctx, hh::launch_simulation_multi(models + k0, take, *c, p.data() + k0, ctx->stream));
     if (!fuse)
       for (int k = 0; k < take; ++k)
-        HH_HIP(ctx, hh::launch_reduce_records(p[k0 + k].records, n_tiles, (double)c->n_paths,
+        HH_HIP(ctx, hh::launch_reduce_records(p[k0 + k].records, hh::sim_records(*c), (double)c->n_paths,
                                               accum_dev + (size_t)(k0 + k) * HH_ACC_LEN, ctx->stream, 1, &models[k0 + k], c));
     k0 += (uint32_t)take;
   }
   if ((rc = end_timing(ctx))) return rc;
+  if ((rc = release_host_operands(ctx))) return rc;
   if (any_host_terminal) {
     for (uint32_t k = 0; k < n_models; ++k)
       if (terminals[k])
@@ -612,6 +623,7 @@ int hh_mc_accumulate_basket(hh_ctx* ctx, const hh_model* m, const hh_config* c,
                              hipMemcpyHostToDevice, ctx->stream));
   HH_HIP(ctx, hipMemcpyAsync(ctx->payoffs + n_payoffs, cps, n_payoffs * sizeof(double),
                              hipMemcpyHostToDevice, ctx->stream));
+  if ((rc = note_host_copy(ctx))) return rc;
   rc = ensure(ctx, ctx->basket_records, ctx->basket_records_cap,
               (size_t)n_payoffs * b.n_chunks * hh::kRecStride);
   if (rc) return rc;
@@ -630,6 +642,7 @@ int hh_mc_accumulate_basket(hh_ctx* ctx, const hh_model* m, const hh_config* c,
     HH_HIP(ctx, hh::launch_copy_bk_counters(ctx->accum, accum_dev, n_payoffs, ctx->stream));
   }
   if ((rc = end_timing(ctx))) return rc;
+  if ((rc = release_host_operands(ctx))) return rc;
   return copy_back_terminal(ctx, c, terminal);
 }
 
@@ -951,6 +964,7 @@ static int stage_path_seeds(hh_ctx* ctx, const hh_config* c, const uint64_t** ou
     if (rc) return rc;
     HH_HIP(ctx, hipMemcpyAsync(ctx->seeds, c->seeds, c->n_paths * sizeof(uint64_t),
                                hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = note_host_copy(ctx))) return rc;
     *out = ctx->seeds;
   }
   return HH_OK;
@@ -1187,7 +1201,7 @@ int hh_lsm_shard_begin(hh_ctx* ctx, const hh_model* m, const hh_config* c, int32
   ctx->shard.step_discount = step_discount;
   if ((rc = shard_phase(ctx, hh::kLsmPhaseStats, 0, nullptr, xchg_dev))) return rc;
   ctx->shard.active = true;
-  return HH_OK;
+  return release_host_operands(ctx);
 }
 
 int hh_lsm_shard_phase(hh_ctx* ctx, int32_t phase, uint32_t t, const double* in_dev, double* out_dev) {
@@ -1313,6 +1327,79 @@ int hh_ctx_read_timings(hh_ctx* ctx, double* ms, int32_t cap, int32_t* n_out) {
   }
   *n_out = n;
   ctx->t_count = 0;
+  return HH_OK;
+}
+
+uint64_t hh_seeds_fingerprint(const uint64_t* seeds, uint64_t n) {
+  // four independent multiply-xorshift lanes over the whole vector (about a millisecond per 10^6 seeds on one
+  // core), folded with the length: every element and its position enter
+  uint64_t h[4] = {0x9E3779B97F4A7C15ull ^ n, 0xC2B2AE3D27D4EB4Full, 0x165667B19E3779F9ull, 0x27D4EB2F165667C5ull};
+  uint64_t i = 0;
+  for (; i + 4 <= n; i += 4)
+    for (int l = 0; l < 4; ++l) {
+      uint64_t x = (seeds[i + l] + h[l]) * 0xFF51AFD7ED558CCDull;
+      h[l] = (x ^ (x >> 29)) + 0x9E3779B97F4A7C15ull;
+    }
+  for (; i < n; ++i) {
+    uint64_t x = (seeds[i] + h[i & 3]) * 0xFF51AFD7ED558CCDull;
+    h[i & 3] = (x ^ (x >> 29)) + 0x9E3779B97F4A7C15ull;
+  }
+  uint64_t f = n;
+  for (int l = 0; l < 4; ++l) {
+    f = (f ^ h[l]) * 0xC4CEB9FE1A85EC53ull;
+    f ^= f >> 32;
+  }
+  return f ? f : 1;  // 0 is "not given" in hh_seeds_cache
+}
+
+int hh_seeds_cache(hh_ctx* ctx, const uint64_t* seeds, uint64_t n, uint64_t fingerprint, const uint64_t** dev_out) {
+  if (!ctx) return HH_ERR_INVALID;
+  std::lock_guard<std::recursive_mutex> lock__(ctx->mu);
+  if (!seeds || n == 0 || !dev_out) return fail(ctx, HH_ERR_INVALID, "hh_seeds_cache: seeds, n >= 1 and dev_out");
+  *dev_out = nullptr;
+  if (fingerprint == 0) fingerprint = hh_seeds_fingerprint(seeds, n);
+  const uint64_t head = seeds[0], tail = seeds[n - 1];
+  hh_ctx::SeedEntry* victim = &ctx->seed_cache[0];
+  for (auto& e : ctx->seed_cache) {
+    if (e.dev && e.n == n && e.fingerprint == fingerprint && e.head == head && e.tail == tail) {
+      e.stamp = ++ctx->seed_clock;
+      ++ctx->seed_hits;
+      *dev_out = e.dev;
+      return HH_OK;
+    }
+    if (!e.dev ? victim->dev != nullptr : (victim->dev && e.stamp < victim->stamp)) victim = &e;
+  }
+  HH_HIP(ctx, hipSetDevice(ctx->device));
+  if (victim->dev) {  // hipFree waits for the device: nothing in flight reads the copy any more
+    HH_HIP(ctx, hipFree(victim->dev));
+    *victim = hh_ctx::SeedEntry{};
+    ++ctx->seed_evictions;
+  }
+  uint64_t* d = nullptr;
+  hipError_t e = hipMalloc((void**)&d, n * sizeof(uint64_t));
+  if (e != hipSuccess) return fail(ctx, HH_ERR_NOMEM, "hipMalloc(%llu bytes) failed: %s", (unsigned long long)(n * 8), hipGetErrorString(e));
+  // synchronous: the caller's vector may change, or go, as soon as this returns
+  if ((e = hipMemcpy(d, seeds, n * sizeof(uint64_t), hipMemcpyHostToDevice)) != hipSuccess) {
+    (void)hipFree(d);
+    return fail(ctx, HH_ERR_HIP, "hipMemcpy of the seeds failed: %s", hipGetErrorString(e));
+  }
+  victim->dev = d;
+  victim->n = n;
+  victim->fingerprint = fingerprint;
+  victim->head = head;
+  victim->tail = tail;
+  victim->stamp = ++ctx->seed_clock;
+  ++ctx->seed_uploads;
+  *dev_out = d;
+  return HH_OK;
+}
+
+int hh_seeds_cache_stats(hh_ctx* ctx, uint64_t* hits, uint64_t* uploads, uint64_t* evictions) {
+  if (!ctx) return HH_ERR_INVALID;
+  std::lock_guard<std::recursive_mutex> lock__(ctx->mu);
+  if (hits) *hits = ctx->seed_hits;
+  if (uploads) *uploads = ctx->seed_uploads;
+  if (evictions) *evictions = ctx->seed_evictions;
   return HH_OK;
 }
 

@@ -12,6 +12,10 @@ struct hh_ctx {
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_switch = nullptr;
+  // recorded behind the last copy FROM a caller's host buffer; staged_host: such a copy is queued and the entry
+  // point has to wait for it (release_host_operands) before it returns — the caller owns its buffers again then
+  hipEvent_t ev_stage = nullptr;
+  bool staged_host = false;
   double* records = nullptr;
   size_t records_cap = 0;  // in records
   uint64_t* seeds = nullptr;
@@ -62,6 +66,14 @@ struct hh_ctx {
   double* frecords = nullptr;      // records of the launches that reduce them themselves: kPoison between launches (hh_sim.h)
   size_t frecords_cap = 0;         // in doubles
   int fuse_reduce = 1;             // hh_ctx_set_option(HH_OPT_FUSE_REDUCE): record reduction inside the simulation kernel
+  // seed vectors kept in device memory (hh_seeds_cache): content-addressed, least recently used one out
+  struct SeedEntry {
+    uint64_t* dev = nullptr;
+    uint64_t n = 0, fingerprint = 0, head = 0, tail = 0, stamp = 0;
+  };
+  static constexpr int kSeedEntries = HH_SEED_CACHE_ENTRIES;
+  SeedEntry seed_cache[kSeedEntries];
+  uint64_t seed_clock = 0, seed_hits = 0, seed_uploads = 0, seed_evictions = 0;
   double* accum = nullptr;       // device, HH_ACC_LEN
   double* accum_host = nullptr;  // pinned, HH_ACC_LEN + 8 (LSM: row counters and the give-up word behind the accumulator)
   // optional per-launch timing of the simulation kernel (hh_ctx_enable_timing)
@@ -104,6 +116,22 @@ int ensure(hh_ctx* ctx, T*& buf, size_t& cap, size_t need) {
     return fail(ctx, HH_ERR_NOMEM, "hipMalloc(%zu bytes) failed: %s", need * sizeof(T),
                 hipGetErrorString(e));
   cap = need;
+  return HH_OK;
+}
+
+// a copy from a caller's host buffer has just been queued on the ctx stream
+[[maybe_unused]] inline int note_host_copy(hh_ctx* ctx) {
+  HH_HIP(ctx, hipEventRecord(ctx->ev_stage, ctx->stream));
+  ctx->staged_host = true;
+  return HH_OK;
+}
+// Before an ASYNCHRONOUS entry point returns: every copy it queued from the caller's host memory has read its
+// source (pageable memory is staged by the runtime before hipMemcpyAsync returns, PINNED memory is read by the
+// DMA engine whenever the stream gets there) — only the copies are waited for, the kernels behind them run on.
+[[maybe_unused]] inline int release_host_operands(hh_ctx* ctx) {
+  if (!ctx->staged_host) return HH_OK;
+  ctx->staged_host = false;
+  HH_HIP(ctx, hipEventSynchronize(ctx->ev_stage));
   return HH_OK;
 }
 

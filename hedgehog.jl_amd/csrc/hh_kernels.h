@@ -58,7 +58,7 @@ struct SimArgs {
   uint64_t n_paths;
   uint64_t path_offset;
   uint32_t n_steps;
-  uint32_t n_tiles;
+  uint32_t n_tiles;       // workgroups of the launch = records it leaves (sim_records)
   uint32_t tail_from;     // REPLAY: tiles from here on pipeline deeper (the grid's tail)
   const uint64_t* seeds;  // device
   const double* replay;   // device, tile-major
@@ -116,6 +116,26 @@ inline uint32_t basket_chunks(uint64_t n_paths) {
 }
 
 inline uint32_t tiles_for(uint64_t n_paths) { return (uint32_t)((n_paths + kTile - 1) / kTile); }
+// The exact-law kernels (one normal, one exp per trajectory — no time loop to amortise a workgroup's reduction
+// over) give a lane ONE pair of trajectories in a small ensemble and kExactPairs / kExactPairsHuge pairs in a
+// large / huge one: a workgroup of 256 lanes then leaves ONE record per 512 / 4096 / 32768 trajectories, the
+// chip always has >= 2048 workgroups to run and the reducer at most a few thousand records to add.  The form is
+// a function of the shard's n_paths alone, so a result is reproducible for a given (n_paths, sharding) as
+// everywhere else.
+constexpr int kExactPairs = 8, kExactPairsHuge = 64;
+inline int exact_pairs_per_lane(uint64_t n_paths) {
+  return n_paths >= (uint64_t)2048 * 512 * kExactPairsHuge ? kExactPairsHuge
+         : n_paths >= (uint64_t)2048 * 512 * kExactPairs   ? kExactPairs
+                                                           : 1;
+}
+inline uint32_t exact_records(uint64_t n_paths) {
+  const uint64_t per = 512ull * (uint64_t)exact_pairs_per_lane(n_paths);
+  return (uint32_t)((n_paths + per - 1) / per);
+}
+// records a simulation launch of this shape leaves (what its in-kernel reducer, or reduce_records_kernel, adds)
+inline uint32_t sim_records(const hh_config& c) {
+  return c.strategy == HH_EXACT_LAW ? exact_records(c.n_paths) : tiles_for(c.n_paths);
+}
 // carried basis derivatives (at most 4: V0, κ, θ, σ) -> instantiated kernel width
 inline int pad_partials(uint32_t p) { return p <= 4 ? (int)p : 4; }
 

@@ -426,53 +426,38 @@ struct ExactState {
   DualT<P> x;
 };
 
-template <int P, bool REPLAY, bool ANTI>
-__global__ __launch_bounds__(kTile / 2) void exact_gbm_kernel(const SimArgs<P> a) {
-  const uint32_t tile = blockIdx.x;
+template <int P, bool REPLAY, bool ANTI, int PAIRS>
+__global__ __launch_bounds__(kTile) void exact_gbm_kernel(const SimArgs<P> a) {
+  const uint32_t chunk = blockIdx.x;
   const uint32_t tid = threadIdx.x;
-  const uint64_t path0 = (uint64_t)tile * kTile + (uint64_t)tid * 2;
 
   double acc[4 + P];
 #pragma unroll
   for (int i = 0; i < 4 + P; ++i) acc[i] = 0.0;
 
-  // trajectory G (global index) takes component G&1 of Philox block G>>1
-  const uint64_t g0 = a.path_offset + path0;
-  double z[2];
-  if constexpr (REPLAY) {
-    // standard normals supplied by the caller, one per trajectory (tile-major with 1 step, 1 comp)
-    z[0] = path0 < a.n_paths ? a.replay[path0] : 0.0;
-    z[1] = path0 + 1 < a.n_paths ? a.replay[path0 + 1] : 0.0;
-  } else {
-    const uint64_t key = a.seeds[0];  // ONE key for the whole sample (montecarlo.jl:456)
-    double z1, z2;
-    normal_pair(key, (uint32_t)(g0 >> 1), (uint32_t)(g0 >> 33), 0u, kDomExactGbm, z1, z2);
-    if ((g0 & 1ull) == 0) {
-      z[0] = z1;
-      z[1] = z2;
-    } else {
-      z[0] = z2;
-      const uint64_t g1 = g0 + 1;
-      normal_pair(key, (uint32_t)(g1 >> 1), (uint32_t)(g1 >> 33), 0u, kDomExactGbm, z1, z2);
-      z[1] = z1;
-    }
-  }
+  // pair j of this lane: trajectories chunk·512·PAIRS + j·512 + 2·tid, + 1 (a wave's samples are contiguous)
+#pragma unroll 2
+  for (int jp = 0; jp < PAIRS; ++jp) {
+    const uint64_t path0 = ((uint64_t)chunk * PAIRS + jp) * (2 * kTile) + (uint64_t)tid * 2;
+    double z[2];
+    exact_pair_normals<REPLAY>(a, path0, z);
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    ExactState<P> st, sa;
-    st.x.v = fma(a.law_sd.v, z[j], a.law_mu.v);
-    if constexpr (ANTI) sa.x.v = 2 * a.law_mu.v - st.x.v;  // montecarlo.jl:387
-    if constexpr (P > 0) {
+    for (int j = 0; j < 2; ++j) {
+      ExactState<P> st, sa;
+      st.x.v = fma(a.law_sd.v, z[j], a.law_mu.v);
+      if constexpr (ANTI) sa.x.v = 2 * a.law_mu.v - st.x.v;  // montecarlo.jl:387
+      if constexpr (P > 0) {
 #pragma unroll
-      for (int k = 0; k < P; ++k) {
-        st.x.d[k] = fma(a.law_sd.d[k], z[j], a.law_mu.d[k]);
-        if constexpr (ANTI) sa.x.d[k] = 2 * a.law_mu.d[k] - st.x.d[k];
+        for (int k = 0; k < P; ++k) {
+          st.x.d[k] = fma(a.law_sd.d[k], z[j], a.law_mu.d[k]);
+          if constexpr (ANTI) sa.x.d[k] = 2 * a.law_mu.d[k] - st.x.d[k];
+        }
       }
+      finish_path<P, ANTI>(st, sa, a, path0 + j, acc);
     }
-    finish_path<P, ANTI>(st, sa, a, path0 + j, acc);
   }
-  block_reduce_publish<4 + P, kTile / 2 / 64, 2>(acc, a.records + (size_t)tile * kRecStride, a.accum != nullptr, a.map.n > 0);
-  if (a.accum && reduces_records(tile, a.n_tiles)) finish_records<kTile / 2, P>(a.records, a.n_tiles, a.acc_n_paths, a.accum, &a.map);
+  block_reduce_publish<4 + P, kTile / 64, 2>(acc, a.records + (size_t)chunk * kRecStride, a.accum != nullptr, a.map.n > 0);
+  if (a.accum && reduces_records(chunk, a.n_tiles)) finish_records<kTile, P>(a.records, a.n_tiles, a.acc_n_paths, a.accum, &a.map);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -685,7 +670,7 @@ static SimArgs<P> make_args(const hh_model& m, const hh_config& c, const DeviceP
   a.n_paths = c.n_paths;
   a.path_offset = c.path_offset;
   a.n_steps = c.n_steps;
-  a.n_tiles = tiles_for(c.n_paths);
+  a.n_tiles = sim_records(c);
   a.tail_from = a.n_tiles > (uint32_t)HH_REPLAY_TAIL_TILES ? a.n_tiles - (uint32_t)HH_REPLAY_TAIL_TILES : 0u;
   a.seeds = p.seeds;
   a.replay = p.replay;
@@ -756,9 +741,17 @@ static int launch_sim_p(const hh_model& m, const hh_config& c, const DevicePtrs&
   const bool anti = c.antithetic != 0;
   const bool replay = c.noise_mode == HH_NOISE_REPLAY;
   if (c.strategy == HH_EXACT_LAW) {
-    auto kernel = replay ? (anti ? exact_gbm_kernel<P, true, true> : exact_gbm_kernel<P, true, false>)
-                         : (anti ? exact_gbm_kernel<P, false, true> : exact_gbm_kernel<P, false, false>);
-    hipLaunchKernelGGL(kernel, dim3(a.n_tiles), dim3(kTile / 2), 0, s, a);
+    auto pick = [&](auto replay_c, auto anti_c) {
+      constexpr bool R = decltype(replay_c)::value, A = decltype(anti_c)::value;
+      const int pairs = exact_pairs_per_lane(c.n_paths);
+      return pairs == kExactPairsHuge ? exact_gbm_kernel<P, R, A, kExactPairsHuge>
+             : pairs == kExactPairs   ? exact_gbm_kernel<P, R, A, kExactPairs>
+                                      : exact_gbm_kernel<P, R, A, 1>;
+    };
+    using T = std::true_type;
+    using F = std::false_type;
+    auto kernel = replay ? (anti ? pick(T{}, T{}) : pick(T{}, F{})) : (anti ? pick(F{}, T{}) : pick(F{}, F{}));
+    hipLaunchKernelGGL(kernel, dim3(a.n_tiles), dim3(kTile), 0, s, a);
     return (int)hipGetLastError();
   }
   const bool direct = replay && p.replay_path_major;

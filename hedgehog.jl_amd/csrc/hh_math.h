@@ -41,6 +41,11 @@ HH_MATH_FN double rcp(double x) {
 // test (18 instructions -> 11; four square roots per CF evaluation).  Zero: rsq(0) = +inf is capped at 2^1000
 // and the whole sequence is then exact zeros (hh_kernels.hip, sqrt_clipped).  Below 2^-767 the result is merely
 // less accurate, never NaN.
+// CONTRACT: w finite and >= 0 — what the callers pass (cabs: a sum of squares; csqrt: r + |re| of non-negative
+// terms).  Outside it the IEEE edge behaviour of sqrt() is NOT kept: w = +inf (an overflowed sum of squares)
+// gives NaN (rsq = 0, 0·inf), where sqrt gives inf — the Broadie–Kaya stopping test leaves on NaN as it leaves on
+// inf; w = NaN gives NaN; w = -0.0 gives NaN (sqrt: -0.0; a sum of squares is never -0.0); w < 0 gives -inf or NaN
+// (the seed NaN is replaced by the cap), never a finite positive number.  Pinned on the device by tests/test_gpu_math_device.py.
 HH_MATH_FN double sqrt_lean(double w) {
 #if defined(__HIP_DEVICE_COMPILE__)
   const double y = __builtin_fmin(__builtin_amdgcn_rsq(w), 0x1p1000);

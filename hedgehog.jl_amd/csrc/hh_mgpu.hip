@@ -47,7 +47,10 @@ struct RcclApi {
   void* lib = nullptr;
   int (*CommInitAll)(rccl_comm_t*, int, const int*) = nullptr;
   int (*CommDestroy)(rccl_comm_t) = nullptr;
-  int (*CommAbort)(rccl_comm_t) = nullptr;  // optional: without it a lost communicator is leaked
+  int (*CommAbort)(rccl_comm_t) = nullptr;  // required: what lets a collective that lost its peers leave its stream
+  int (*GetVersion)(int*) = nullptr;        // optional (reported by hh_mgpu_rccl_info)
+  char path[512] = {0};                     // the file ncclAllReduce was bound from (dladdr)
+  int from_env = 0;                         // 1: $HEDGEHOG_MC_RCCL named it
   int (*AllReduce)(const void*, void*, size_t, int, int, rccl_comm_t, hipStream_t) = nullptr;
   int (*GroupStart)() = nullptr;
   int (*GroupEnd)() = nullptr;
@@ -61,7 +64,10 @@ RcclApi& rccl() {
   static std::once_flag once;
   std::call_once(once, [] {
     const char* env = std::getenv("HEDGEHOG_MC_RCCL");
-    if (env && *env) api.lib = dlopen(env, RTLD_NOW | RTLD_LOCAL);
+    if (env && *env) {
+      api.lib = dlopen(env, RTLD_NOW | RTLD_LOCAL);
+      api.from_env = api.lib != nullptr;
+    }
     // a copy the process has ALREADY loaded first (PyTorch ships its own librccl.so, built against the HIP
     // runtime the process runs on): the communicators then live on the same runtime as the streams
     const char* loaded[] = {"librccl.so", "librccl.so.1"};
@@ -81,8 +87,14 @@ RcclApi& rccl() {
     api.GroupStart = (decltype(api.GroupStart))dlsym(api.lib, "ncclGroupStart");
     api.GroupEnd = (decltype(api.GroupEnd))dlsym(api.lib, "ncclGroupEnd");
     api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.lib, "ncclGetErrorString");
-    api.ok = api.CommInitAll && api.CommDestroy && api.AllReduce && api.GroupStart && api.GroupEnd &&
-             api.GetErrorString;
+    api.GetVersion = (decltype(api.GetVersion))dlsym(api.lib, "ncclGetVersion");
+    Dl_info info{};
+    if (api.AllReduce && dladdr((void*)api.AllReduce, &info) && info.dli_fname)
+      snprintf(api.path, sizeof(api.path), "%s", info.dli_fname);
+    // ncclCommAbort is part of the contract: after a collective that fails in the middle it is the only way
+    // the ranks already enqueued leave their streams (rccl_give_up); a library without it is not used
+    api.ok = api.CommInitAll && api.CommDestroy && api.CommAbort && api.AllReduce && api.GroupStart &&
+             api.GroupEnd && api.GetErrorString;
     if (!api.ok) snprintf(api.why, sizeof(api.why), "librccl lacks an expected symbol");
   });
   return api;
@@ -105,6 +117,7 @@ struct hh_mgpu {
   int flags = HH_MGPU_AUTO;
   int mode = HH_MGPU_REDUCE_HOST;
   bool rccl_lost = false;  // the communicators were aborted after a failed collective
+  bool stuck = false;      // … and a shard is still on a stream that may hold the orphaned collective
   std::vector<int> devices;
   std::vector<hh_ctx*> ctx;
   std::vector<double*> acc, red;  // per device: local sums, all-reduced sums (RCCL writes out of place)
@@ -337,26 +350,35 @@ int all_reduce_group(hh_mgpu* mg, double* const* send, double* const* recv, size
 // After a failed collective.  Ranks enqueued before the failure may sit in their streams waiting for
 // peers that never arrive, so no shard stream is waited for again: the communicators are aborted (which
 // lets such kernels leave), every stream is retired in favour of a fresh one that continues behind
-// fence[g], and from here on this context sums on the host.  Returns with nothing synchronised.
-void rccl_give_up(hh_mgpu* mg) {
+// fence[g], and from here on this context sums on the host.  Returns with nothing synchronised; false when a
+// shard could NOT be moved (a stream lent by the caller, or no fresh stream to be had): the context is then
+// `stuck` — nothing may be finished on it, every call returns HH_ERR_RCCL once the caller's buffers are free.
+bool rccl_give_up(hh_mgpu* mg) {
   RcclApi& api = rccl();
   for (rccl_comm_t c : mg->comms)
-    if (c && api.CommAbort) (void)api.CommAbort(c);  // no ncclCommAbort: leaked (CommDestroy could wait for the orphan)
+    if (c) (void)api.CommAbort(c);
   mg->comms.clear();
   mg->mode = HH_MGPU_REDUCE_HOST;
   mg->rccl_lost = true;
+  bool all_moved = true;
   for (int g = 0; g < mg->n; ++g) {
     hh_ctx* c = mg->ctx[g];
     std::lock_guard<std::recursive_mutex> lock__(c->mu);
     c->shard.active = false;
-    if (c->stream != c->own_stream) continue;  // a stream lent by the caller is the caller's to retire
-    (void)hipSetDevice(mg->devices[g]);
+    // a stream lent by the caller is the caller's to retire, and a fresh stream may be refused: such a shard
+    // stays on the stream that may hold the orphan — the caller of this function must not finish on it
     hipStream_t fresh = nullptr;
-    if (hipStreamCreateWithFlags(&fresh, hipStreamNonBlocking) != hipSuccess) continue;
+    (void)hipSetDevice(mg->devices[g]);
+    if (c->stream != c->own_stream || hipStreamCreateWithFlags(&fresh, hipStreamNonBlocking) != hipSuccess) {
+      all_moved = false;
+      continue;
+    }
     if (mg->fence[g]) (void)hipStreamWaitEvent(fresh, mg->fence[g], 0);
     mg->retired.push_back({mg->devices[g], c->own_stream});
     c->own_stream = c->stream = fresh;
   }
+  mg->stuck = mg->stuck || !all_moved;
+  return all_moved;
 }
 
 // the caller's buffers are free once the kernels in front of the fences have run
@@ -371,14 +393,19 @@ void wait_fences(hh_mgpu* mg) {
 struct Basket {
   const double *strikes, *cps;
   uint32_t n_payoffs;
-};
+  uint32_t n_models = 0;  // > 0: not a basket but n_models models on the same draws (hh_mc_accumulate_multi);
+};                        //      `m` of run_shards then points to the first of them
 
 // Enqueue every shard, combine the accumulator vectors, leave the combined vector in mg->host[0 .. n_acc).
 // cfgs[g].n_paths == 0 leaves device g idle (it contributes zeros).  terminals[g] (nullable): device
 // buffer for the shard's terminal samples, already part of cfgs[g] — nothing to do with it here.
 int run_shards(hh_mgpu* mg, const hh_model* m, const hh_config* cfgs, const Basket* basket,
                double* const* terminals, double* kernel_ms) {
-  const size_t n_acc = (size_t)HH_ACC_LEN * (basket ? basket->n_payoffs : 1u);
+  const bool multi = basket && basket->n_models > 0;
+  const size_t n_acc = (size_t)HH_ACC_LEN * (multi ? basket->n_models : basket ? basket->n_payoffs : 1u);
+  if (mg->stuck)  // no drain: a shard's stream may hold a collective that never ends
+    return mfail(mg, HH_ERR_RCCL, "a collective failed and a shard could not be moved off the stream it was enqueued on "
+                                  "(a stream lent with hh_ctx_set_stream, or no new stream): create a new context");
   if (mg->flags == HH_MGPU_RCCL && mg->rccl_lost)
     return drain(mg, mfail(mg, HH_ERR_RCCL, "the RCCL communicators of this context were aborted after a failed "
                                             "collective (HH_MGPU_RCCL does not fall back): create a new one"));
@@ -395,9 +422,10 @@ int run_shards(hh_mgpu* mg, const hh_model* m, const hh_config* cfgs, const Bask
       HH_DHIP(mg, g, hipMemsetAsync(mg->acc[g], 0, n_acc * sizeof(double), c->stream));
     } else {
       double* term = terminals ? terminals[g] : nullptr;
-      const int r = basket ? hh_mc_accumulate_basket(c, m, &cfgs[g], basket->strikes, basket->cps,
-                                                     basket->n_payoffs, mg->acc[g], term)
-                           : hh_mc_accumulate(c, m, &cfgs[g], mg->acc[g], term);
+      const int r = multi    ? hh_mc_accumulate_multi(c, m, basket->n_models, &cfgs[g], mg->acc[g], nullptr)
+                    : basket ? hh_mc_accumulate_basket(c, m, &cfgs[g], basket->strikes, basket->cps,
+                                                       basket->n_payoffs, mg->acc[g], term)
+                             : hh_mc_accumulate(c, m, &cfgs[g], mg->acc[g], term);
       if (r) {
         snprintf(mg->derr[g].data(), mg->derr[g].size(), "%s", hh_last_error(c));
         return r;
@@ -422,8 +450,8 @@ int run_shards(hh_mgpu* mg, const hh_model* m, const hh_config* cfgs, const Bask
     } else {
       mfail(mg, HH_ERR_RCCL, "ncclAllReduce failed: %s — communicators aborted, accumulators are summed on the host",
             rccl().GetErrorString(e));
-      rccl_give_up(mg);
-      if (mg->flags == HH_MGPU_RCCL) {
+      const bool moved = rccl_give_up(mg);
+      if (mg->flags == HH_MGPU_RCCL || !moved) {
         wait_fences(mg);
         return HH_ERR_RCCL;
       }  // else: the local sums are untouched (out-of-place reduce) — finish on the host, on the fresh streams
@@ -532,18 +560,29 @@ int hh_mgpu_create(hh_mgpu** out, const int* device_ids, int n_devices, int flag
 void hh_mgpu_destroy(hh_mgpu* mg) {
   if (!mg) return;
   stop_workers(mg);
+  // A retired stream that has not drained may hold a collective whose peers never came (ncclCommAbort is
+  // supposed to release it; until it has, it has not).  hipDeviceSynchronize and hipFree wait for EVERY stream
+  // of the device, that one included: a device with such a stream — and a stuck context altogether — is left
+  // alone (its streams, buffers and hh_ctx are leaked) rather than waited for.
+  std::vector<char> busy(mg->n, mg->stuck ? 1 : 0);
+  for (const auto& r : mg->retired) {
+    (void)hipSetDevice(r.device);
+    if (hipStreamQuery(r.s) == hipSuccess) {
+      (void)hipStreamDestroy(r.s);
+    } else {
+      for (int g = 0; g < mg->n; ++g)
+        if (mg->devices[g] == r.device) busy[g] = 1;
+    }
+  }
   for (int g = 0; g < mg->n; ++g) {
-    if (!mg->ctx[g]) continue;
+    if (!mg->ctx[g] || busy[g]) continue;
     (void)hipSetDevice(mg->devices[g]);
     (void)hipStreamSynchronize(mg->ctx[g]->stream);
   }
   for (rccl_comm_t c : mg->comms)
     if (c) (void)rccl().CommDestroy(c);
-  for (const auto& r : mg->retired) {  // a retired stream is destroyed only once it is known to have drained
-    (void)hipSetDevice(r.device);
-    if (hipStreamQuery(r.s) == hipSuccess) (void)hipStreamDestroy(r.s);
-  }
   for (int g = 0; g < mg->n; ++g) {
+    if (busy[g]) continue;
     if (mg->pre[g]) (void)hipEventDestroy(mg->pre[g]);
     if (!mg->ctx[g]) continue;  // creation stopped before this device: nothing of it exists
     (void)hipSetDevice(mg->devices[g]);
@@ -552,7 +591,9 @@ void hh_mgpu_destroy(hh_mgpu* mg) {
     if (mg->xchg[g]) (void)hipFree(mg->xchg[g]);
     if (mg->ctx[g]) hh_ctx_destroy(mg->ctx[g]);
   }
-  if (mg->host) (void)hipHostFree(mg->host);
+  bool any_busy = false;
+  for (char b : busy) any_busy = any_busy || b;
+  if (mg->host && !any_busy) (void)hipHostFree(mg->host);
   delete mg;
 }
 
@@ -560,6 +601,78 @@ const char* hh_mgpu_last_error(const hh_mgpu* mg) { return mg ? mg->err : "hedge
 int hh_mgpu_n_devices(const hh_mgpu* mg) { return mg ? mg->n : 0; }
 int hh_mgpu_reduce_mode(const hh_mgpu* mg) { return mg ? mg->mode : HH_MGPU_REDUCE_HOST; }
 hh_ctx* hh_mgpu_ctx(hh_mgpu* mg, int i) { return (mg && i >= 0 && i < mg->n) ? mg->ctx[i] : nullptr; }
+
+int hh_mgpu_selftest(hh_mgpu* mg, int32_t* ranks_out, int32_t* reduce_mode_out) {
+  if (!mg) return HH_ERR_INVALID;
+  std::lock_guard<std::mutex> lock__(mg->mu);
+  if (!ranks_out) return mfail(mg, HH_ERR_INVALID, "hh_mgpu_selftest: ranks_out is NULL");
+  if (mg->stuck) return mfail(mg, HH_ERR_RCCL, "stuck context (see hh_mgpu_last_error of the failed call)");
+  int rc = ensure_acc(mg, HH_ACC_LEN);
+  if (rc) return rc;
+  // every device contributes a vector of ones through the exchange a solve uses: what comes back counts the
+  // ranks that took part — the number a caller may print next to "reduce: rccl"
+  std::vector<double> ones(HH_ACC_LEN, 1.0);
+  for (int g = 0; g < mg->n; ++g) {
+    HH_MHIP_DRAIN(mg, hipSetDevice(mg->devices[g]));
+    HH_MHIP_DRAIN(mg, hipMemcpyAsync(mg->acc[g], ones.data(), HH_ACC_LEN * sizeof(double), hipMemcpyHostToDevice,
+                                     mg->ctx[g]->stream));
+    HH_MHIP_DRAIN(mg, hipMemsetAsync(mg->red[g], 0, HH_ACC_LEN * sizeof(double), mg->ctx[g]->stream));
+    HH_MHIP_DRAIN(mg, hipEventRecord(mg->pre[g], mg->ctx[g]->stream));
+    mg->fence[g] = mg->pre[g];
+  }
+  for (int g = 0; g < mg->n; ++g) {  // `ones` is pageable: the copies have read it once the streams are idle
+    HH_MHIP_DRAIN(mg, hipSetDevice(mg->devices[g]));
+    HH_MHIP_DRAIN(mg, hipStreamSynchronize(mg->ctx[g]->stream));
+  }
+  double total = 0.0;
+  if (mg->mode == HH_MGPU_REDUCE_RCCL) {
+    const int e = all_reduce_group(mg, mg->acc.data(), mg->red.data(), HH_ACC_LEN);
+    if (e != kNcclSuccess) {
+      mfail(mg, HH_ERR_RCCL, "ncclAllReduce failed in the self-test: %s — communicators aborted", rccl().GetErrorString(e));
+      (void)rccl_give_up(mg);
+      wait_fences(mg);
+      return HH_ERR_RCCL;
+    }
+    for (int g = 0; g < mg->n; ++g) {  // every rank must hold the same count in every slot
+      HH_MHIP_DRAIN(mg, hipSetDevice(mg->devices[g]));
+      HH_MHIP_DRAIN(mg, hipMemcpyAsync(mg->host + (size_t)g * HH_ACC_LEN, mg->red[g], HH_ACC_LEN * sizeof(double),
+                                       hipMemcpyDeviceToHost, mg->ctx[g]->stream));
+    }
+    for (int g = 0; g < mg->n; ++g) {
+      HH_MHIP_DRAIN(mg, hipSetDevice(mg->devices[g]));
+      HH_MHIP_DRAIN(mg, hipStreamSynchronize(mg->ctx[g]->stream));
+    }
+    total = mg->host[0];
+    for (size_t i = 0; i < (size_t)mg->n * HH_ACC_LEN; ++i)
+      if (mg->host[i] != total)
+        return mfail(mg, HH_ERR_RCCL, "self-test: the ranks disagree on the all-reduced count (%g vs %g)", mg->host[i], total);
+  } else {
+    for (int g = 0; g < mg->n; ++g) {
+      HH_MHIP_DRAIN(mg, hipSetDevice(mg->devices[g]));
+      HH_MHIP_DRAIN(mg, hipMemcpyAsync(mg->host + (size_t)g * HH_ACC_LEN, mg->acc[g], HH_ACC_LEN * sizeof(double),
+                                       hipMemcpyDeviceToHost, mg->ctx[g]->stream));
+    }
+    for (int g = 0; g < mg->n; ++g) {
+      HH_MHIP_DRAIN(mg, hipSetDevice(mg->devices[g]));
+      HH_MHIP_DRAIN(mg, hipStreamSynchronize(mg->ctx[g]->stream));
+    }
+    for (int g = 0; g < mg->n; ++g) total += mg->host[(size_t)g * HH_ACC_LEN];
+  }
+  *ranks_out = (int32_t)(total + 0.5);
+  if (reduce_mode_out) *reduce_mode_out = mg->mode;
+  return HH_OK;
+}
+
+int hh_mgpu_rccl_info(const hh_mgpu* mg, char* path_out, size_t cap, int32_t* version_out, int32_t* from_env_out) {
+  (void)mg;
+  RcclApi& api = rccl();
+  if (path_out && cap) snprintf(path_out, cap, "%s", api.lib ? api.path : "");
+  int v = 0;
+  if (api.lib && api.GetVersion && api.GetVersion(&v) != kNcclSuccess) v = 0;
+  if (version_out) *version_out = v;
+  if (from_env_out) *from_env_out = api.from_env;
+  return api.ok ? HH_OK : HH_ERR_RCCL;
+}
 
 int hh_mgpu_set_option(hh_mgpu* mg, int32_t option, int64_t value) {
   if (!mg) return HH_ERR_INVALID;
@@ -717,6 +830,33 @@ int hh_mgpu_solve(hh_mgpu* mg, const hh_model* m, const hh_config* cfg, hh_resul
   if (rc) return mfail(mg, rc, "finalize failed");
   out->kernel_ms = kernel_ms;
   out->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  return HH_OK;
+}
+
+int hh_mgpu_solve_multi(hh_mgpu* mg, const hh_model* models, uint32_t n_models, const hh_config* cfg,
+                        hh_result* out) {
+  if (!mg) return HH_ERR_INVALID;
+  std::lock_guard<std::mutex> lock__(mg->mu);
+  if (!models || !cfg || !out || n_models == 0 || n_models > HH_MAX_MODELS)
+    return mfail(mg, HH_ERR_INVALID, "hh_mgpu_solve_multi: 1 .. %d models and their results", HH_MAX_MODELS);
+  const auto t0 = std::chrono::steady_clock::now();
+  std::vector<hh_config> cs;
+  std::vector<double*> term_dev;
+  std::vector<uint64_t> starts;
+  int rc = cut_config(mg, cfg, false, cs, term_dev, starts);
+  if (rc) return drain(mg, rc);
+  Basket b{nullptr, nullptr, 0, n_models};
+  double kernel_ms = 0.0;
+  rc = run_shards(mg, models, cs.data(), &b, nullptr, &kernel_ms);
+  if (rc) return rc;
+  const double total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  for (uint32_t k = 0; k < n_models; ++k) {
+    std::memset(&out[k], 0, sizeof(hh_result));
+    rc = hh_mc_finalize(&models[k], cfg, mg->host + (size_t)k * HH_ACC_LEN, &out[k]);
+    if (rc) return mfail(mg, rc, "finalize failed");
+    out[k].kernel_ms = kernel_ms;
+    out[k].total_ms = total;
+  }
   return HH_OK;
 }
 
@@ -903,15 +1043,15 @@ int hh_mgpu_lsm_solve(hh_mgpu* mg, const hh_model* m, const hh_config* cfg, int3
     const int rc1 = hh_lsm_solve(mg->ctx[0], m, cfg, degree, step_discount, out, stop_time, stop_value, nullptr);
     return rc1 ? mfail(mg, rc1, "device %d: %s", mg->devices[0], hh_last_error(mg->ctx[0])) : HH_OK;
   }
-  if (mg->flags == HH_MGPU_RCCL && mg->rccl_lost)
+  if (mg->stuck || (mg->flags == HH_MGPU_RCCL && mg->rccl_lost))
     return mfail(mg, HH_ERR_RCCL, "the RCCL communicators of this context were aborted after a failed collective "
-                                  "(HH_MGPU_RCCL does not fall back): create a new one");
+                                  "(HH_MGPU_RCCL does not fall back; a stuck context cannot): create a new one");
   const bool was_rccl = mg->mode == HH_MGPU_REDUCE_RCCL;
   int rc = lsm_attempt(mg, m, cfg, degree, step_discount, out, stop_time, stop_value);
   if (rc == HH_ERR_RCCL && was_rccl) {
     // the exchange is in place, so the local sums went with the failed collective: nothing to finish
     wait_fences(mg);  // the kernels in front of the collective have read the caller's seeds
-    if (mg->flags == HH_MGPU_AUTO)  // … the whole induction again, on the fresh streams, summed on the host
+    if (mg->flags == HH_MGPU_AUTO && !mg->stuck)  // … the whole induction again, on the fresh streams, summed on the host
       rc = lsm_attempt(mg, m, cfg, degree, step_discount, out, stop_time, stop_value);
   }
   return rc;

@@ -169,51 +169,44 @@ __attribute__((amdgpu_waves_per_eu(1, REPLAY ? HH_MULTI_MAXW : 8))) void euler_m
 }
 
 // the exact lognormal law (exact_gbm_kernel) for K models on the same normals
-template <bool REPLAY, bool ANTI, int K>
-__global__ __launch_bounds__(kTile / 2) void exact_multi_kernel(const MultiArgs<K> a) {
+template <bool REPLAY, bool ANTI, int K, int PAIRS>
+__global__ __launch_bounds__(kTile) void exact_multi_kernel(const MultiArgs<K> a) {
   const SimArgs<0>& a0 = a.m[0];
-  const uint32_t tile = blockIdx.x, tid = threadIdx.x;
-  const uint64_t path0 = (uint64_t)tile * kTile + (uint64_t)tid * 2;
-  const uint64_t g0 = a0.path_offset + path0;
-  double z[2];
-  if constexpr (REPLAY) {
-    z[0] = path0 < a0.n_paths ? a0.replay[path0] : 0.0;
-    z[1] = path0 + 1 < a0.n_paths ? a0.replay[path0 + 1] : 0.0;
-  } else {
-    const uint64_t key = a0.seeds[0];  // ONE key for the whole sample (montecarlo.jl:456)
-    double z1, z2;
-    normal_pair(key, (uint32_t)(g0 >> 1), (uint32_t)(g0 >> 33), 0u, kDomExactGbm, z1, z2);
-    if ((g0 & 1ull) == 0) {
-      z[0] = z1;
-      z[1] = z2;
-    } else {
-      z[0] = z2;
-      const uint64_t g1 = g0 + 1;
-      normal_pair(key, (uint32_t)(g1 >> 1), (uint32_t)(g1 >> 33), 0u, kDomExactGbm, z1, z2);
-      z[1] = z1;
-    }
-  }
+  const uint32_t chunk = blockIdx.x, tid = threadIdx.x;
   struct S {
     DualT<0> x;
   };
+  double acc[K][4];
+#pragma unroll
+  for (int k = 0; k < K; ++k)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[k][i] = 0.0;
+#pragma unroll 2
+  for (int jp = 0; jp < PAIRS; ++jp) {
+    const uint64_t path0 = ((uint64_t)chunk * PAIRS + jp) * (2 * kTile) + (uint64_t)tid * 2;
+    double z[2];
+    exact_pair_normals<REPLAY>(a0, path0, z);
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        S st, sa;
+        st.x.v = fma(a.m[k].law_sd.v, z[j], a.m[k].law_mu.v);
+        if constexpr (ANTI) sa.x.v = 2 * a.m[k].law_mu.v - st.x.v;  // montecarlo.jl:387
+        finish_path<0, ANTI>(st, sa, a.m[k], path0 + j, acc[k]);
+      }
+    }
+  }
 #pragma unroll
   for (int k = 0; k < K; ++k) {
-    double acc[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      S st, sa;
-      st.x.v = fma(a.m[k].law_sd.v, z[j], a.m[k].law_mu.v);
-      if constexpr (ANTI) sa.x.v = 2 * a.m[k].law_mu.v - st.x.v;  // montecarlo.jl:387
-      finish_path<0, ANTI>(st, sa, a.m[k], path0 + j, acc);
-    }
-    if (k) __syncthreads();
-    block_reduce_publish<4, kTile / 2 / 64, 2>(acc, a.m[k].records + (size_t)tile * kRecStride, a.m[k].accum != nullptr, false);
+    if (k) __syncthreads();  // the reduction's LDS staging is reused
+    block_reduce_publish<4, kTile / 64, 2>(acc[k], a.m[k].records + (size_t)chunk * kRecStride, a.m[k].accum != nullptr, false);
   }
-  if (a0.accum && reduces_records(tile, a0.n_tiles)) {
+  if (a0.accum && reduces_records(chunk, a0.n_tiles)) {
 #pragma unroll
     for (int k = 0; k < K; ++k) {
       if (k) __syncthreads();
-      finish_records<kTile / 2, 0>(a.m[k].records, a0.n_tiles, a.m[k].acc_n_paths, a.m[k].accum, &a.m[k].map);
+      finish_records<kTile, 0>(a.m[k].records, a0.n_tiles, a.m[k].acc_n_paths, a.m[k].accum, &a.m[k].map);
     }
   }
 }
@@ -253,14 +246,18 @@ static int launch_multi(const hh_model* models, const hh_config& c, const Device
   }
   const bool anti = c.antithetic != 0, replay = c.noise_mode == HH_NOISE_REPLAY;
   if (c.strategy == HH_EXACT_LAW) {
-    const dim3 g(a.m[0].n_tiles), b(kTile / 2);
-    if (replay) {
-      if (anti) hipLaunchKernelGGL((exact_multi_kernel<true, true, K>), g, b, 0, s, a);
-      else hipLaunchKernelGGL((exact_multi_kernel<true, false, K>), g, b, 0, s, a);
-    } else {
-      if (anti) hipLaunchKernelGGL((exact_multi_kernel<false, true, K>), g, b, 0, s, a);
-      else hipLaunchKernelGGL((exact_multi_kernel<false, false, K>), g, b, 0, s, a);
-    }
+    const dim3 g(a.m[0].n_tiles), b(kTile);
+    auto pick = [&](auto replay_c, auto anti_c) {
+      constexpr bool R = decltype(replay_c)::value, A = decltype(anti_c)::value;
+      const int pairs = exact_pairs_per_lane(c.n_paths);
+      return pairs == kExactPairsHuge ? exact_multi_kernel<R, A, K, kExactPairsHuge>
+             : pairs == kExactPairs   ? exact_multi_kernel<R, A, K, kExactPairs>
+                                      : exact_multi_kernel<R, A, K, 1>;
+    };
+    using T = std::true_type;
+    using F = std::false_type;
+    auto kernel = replay ? (anti ? pick(T{}, T{}) : pick(T{}, F{})) : (anti ? pick(F{}, T{}) : pick(F{}, F{}));
+    hipLaunchKernelGGL(kernel, g, b, 0, s, a);
     return (int)hipGetLastError();
   }
   if (c.dynamics == HH_LOGNORMAL) return launch_multi_m<GbmModel<0>, K>(a, replay, anti, shared, s);

@@ -223,6 +223,33 @@ __device__ __forceinline__ void finish_path(const State& st, const State& sa, co
 }
 
 // ------------------------------------------------------------------------------------------
+// exact lognormal law: the two standard normals of the trajectories path0, path0 + 1
+// ------------------------------------------------------------------------------------------
+// GENERATE: ONE key for the whole sample (montecarlo.jl:456); trajectory G (global index) takes component G&1
+// of Philox block G>>1, so a lane's pair is one block when path_offset is even.  REPLAY: the caller's normals.
+template <bool REPLAY, int P>
+__device__ __forceinline__ void exact_pair_normals(const SimArgs<P>& a, uint64_t path0, double (&z)[2]) {
+  if constexpr (REPLAY) {
+    z[0] = path0 < a.n_paths ? a.replay[path0] : 0.0;
+    z[1] = path0 + 1 < a.n_paths ? a.replay[path0 + 1] : 0.0;
+  } else {
+    const uint64_t g0 = a.path_offset + path0;
+    const uint64_t key = a.seeds[0];
+    double z1, z2;
+    normal_pair(key, (uint32_t)(g0 >> 1), (uint32_t)(g0 >> 33), 0u, kDomExactGbm, z1, z2);
+    if ((g0 & 1ull) == 0) {
+      z[0] = z1;
+      z[1] = z2;
+    } else {
+      z[0] = z2;
+      const uint64_t g1 = g0 + 1;
+      normal_pair(key, (uint32_t)(g1 >> 1), (uint32_t)(g1 >> 33), 0u, kDomExactGbm, z1, z2);
+      z[1] = z1;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // the record reduction, folded into the kernel that wrote the records  (mean(payoffs), montecarlo.jl:490)
 // ------------------------------------------------------------------------------------------
 //

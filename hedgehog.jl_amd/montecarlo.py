@@ -66,16 +66,16 @@ class SimulationConfig:
         self.steps = int(steps)
         self.variance_reduction = variance_reduction
         self.seeds = seeds
-        self._seeds_dev = {}
+        self._fingerprint = 0
 
     def device_seeds(self, ctx):
-        """The seed vector in the memory of ctx's device, uploaded on first use and kept with the
-        config: repeated solves (Greeks by finite differences, calibration loops) do not move the
-        8 MB per 10^6 trajectories again.  `seeds` is read-only, so the copy cannot go stale."""
-        buf = self._seeds_dev.get(id(ctx))
-        if buf is None or buf.ptr is None or buf.ctx is not ctx:
-            buf = self._seeds_dev[id(ctx)] = _ffi.DeviceBuffer(ctx, self.seeds.nbytes).upload(self.seeds)
-        return buf
+        """Device address of the seed vector in ctx's cache (hh_seeds_cache: content-addressed, bounded, freed
+        with the context), asked for right before every solve: repeated solves (Greeks by finite differences,
+        calibration loops) do not move the 8 MB per 10^6 trajectories again.  `seeds` is this config's own
+        read-only copy, so its fingerprint is computed once."""
+        if not self._fingerprint:
+            self._fingerprint = ctx.lib.hh_seeds_fingerprint(self.seeds.ctypes.data, self.seeds.size)
+        return ctx.seeds_on_device(self.seeds, self._fingerprint)
 
     def replace(self, **kw):
         """Accessors' `@set config.seeds = …` (test/agreement/montecarlo_heston.jl:87)."""
@@ -228,8 +228,7 @@ def solve_montecarlo(prob: PricingProblem, method: MonteCarlo, ensemble: bool = 
     if method.devices is not None:
         return _solve_multi_gpu(prob, method, model, c, P, discount, ensemble, replay, replay_layout)
     ctx = _ffi.get_context(method.device)
-    seeds_dev = cfg.device_seeds(ctx)
-    c.seeds, c.seeds_on_device = seeds_dev.ptr, 1
+    c.seeds, c.seeds_on_device = cfg.device_seeds(ctx), 1
     c.seeds_len = cfg.seeds.size
     if replay is not None:
         replay = np.ascontiguousarray(replay, dtype=np.float64)
@@ -251,7 +250,7 @@ def solve_montecarlo(prob: PricingProblem, method: MonteCarlo, ensemble: bool = 
     res = _ffi.hh_result()
     ctx.check(ctx.lib.hh_mc_solve(ctx.handle, C.byref(model), C.byref(c), C.byref(res),
                                   term_dev.ptr if term_dev else None))
-    del keep, seeds_dev
+    del keep
     ens = _DeviceSamples(fetch, ctx) if fetch is not None else None
     return MonteCarloSolution(prob, method, _price_from(res, discount, P), ens,
                               std_error=res.std_error, result=res)
@@ -261,18 +260,25 @@ def solve_montecarlo_many(probs, method: MonteCarlo, replay=None, replay_layout=
     """Several problems under ONE method on the same draws — the solves a bumped Greek is made of
     (compute_fd_derivative, greeks_problem.jl:279-303; the second-order stencils :396-422) — in one pass of
     the kernels (hh_mc_solve_multi): result k is solve(probs[k], method) bit for bit, without its ensemble.
-    Returns None when the problems cannot share a pass (dual numbers in one of them, a multi-GPU method, more
-    than HH_MAX_MODELS problems): the caller then solves them one by one, as the reference does."""
-    if method.devices is not None or not 1 < len(probs) <= _ffi.HH_MAX_MODELS:
+    Returns None when the problems cannot share a pass (dual numbers in one of them, more than HH_MAX_MODELS
+    problems): the caller then solves them one by one, as the reference does."""
+    if not 1 < len(probs) <= _ffi.HH_MAX_MODELS:
         return None
     packed = [_model_and_config(p, method) for p in probs]
     if any(P for _, _, _, P, _ in packed):
         return None
     c = packed[0][1]
     cfg = method.config
+    if method.devices is not None:  # the trajectories sharded over several GPUs by the library (hh_mgpu_solve_multi)
+        if replay is not None:
+            return None
+        mg = _ffi.get_multi_gpu(tuple(method.devices))
+        c.seeds, c.seeds_len = cfg.seeds.ctypes.data, cfg.seeds.size
+        res = mg.solve_multi([m for m, _, _, _, _ in packed], c)
+        return [MonteCarloSolution(p, method, res[k].price, None, std_error=res[k].std_error, result=res[k])
+                for k, p in enumerate(probs)]
     ctx = _ffi.get_context(method.device)
-    seeds_dev = cfg.device_seeds(ctx)
-    c.seeds, c.seeds_on_device, c.seeds_len = seeds_dev.ptr, 1, cfg.seeds.size
+    c.seeds, c.seeds_on_device, c.seeds_len = cfg.device_seeds(ctx), 1, cfg.seeds.size
     if replay is not None:
         replay = np.ascontiguousarray(replay, dtype=np.float64)
         c.noise_mode, c.replay_layout = _ffi.HH_NOISE_REPLAY, replay_layout

@@ -14,8 +14,11 @@
  *   - plain C types only; every function returns an int status (0 = HH_OK, negative = error) and
  *     never throws or aborts across the boundary; text via hh_last_error().
  *   - all arithmetic is IEEE fp64 (the reference computes in Float64 throughout).
- *   - the caller owns every buffer it passes, for the duration of the call only; the library owns
- *     whatever it allocates inside hh_ctx and releases it in hh_ctx_destroy().
+ *   - the caller owns every buffer it passes, for the duration of the call only — also with the
+ *     ASYNCHRONOUS entry points: whatever they read from HOST memory (seeds, increments, strikes) has
+ *     been read when they return (the call waits for its staging copies, not for its kernels; pinned
+ *     host memory included); DEVICE operands of an asynchronous call are the exception, see below.
+ *     The library owns whatever it allocates inside hh_ctx and releases it in hh_ctx_destroy().
  *   - a hh_ctx is bound to ONE device and ONE HIP stream; its entry points serialise on an
  *     internal mutex, so sharing one between threads is safe but gains nothing — use one ctx per
  *     host thread / per GPU.  Multi-GPU = either ONE call on a hh_mgpu (one ctx per device, the
@@ -219,8 +222,9 @@ int hh_mc_solve(hh_ctx* ctx, const hh_model* model, const hh_config* cfg, hh_res
 
 /*
  * Split form for path-sharded multi-GPU runs: enqueue simulation + reduction on the ctx stream and
- * leave the HH_ACC_LEN accumulator doubles in DEVICE memory `accum_dev` (no host sync), so the
- * caller can all-reduce them (RCCL) and then finalize on the host.
+ * leave the HH_ACC_LEN accumulator doubles in DEVICE memory `accum_dev`, so the caller can all-reduce
+ * them (RCCL) and then finalize on the host.  No wait for the kernels; host seeds / increments in cfg
+ * have been read when the call returns (it waits for their staging copies only).
  */
 int hh_mc_accumulate(hh_ctx* ctx, const hh_model* model, const hh_config* cfg, double* accum_dev,
                      double* terminal);
@@ -298,7 +302,7 @@ int hh_bk_decisions(hh_ctx* ctx, uint64_t n_paths, uint32_t* decisions, uint32_t
  * whole (wall time until every shard was enqueued).
  * A collective that FAILS in the call (ncclAllReduce refusing rank g after ranks < g were enqueued) may
  * leave kernels on the earlier ranks' streams that wait for peers which never come.  The library never
- * synchronises such a stream: it aborts the communicators (ncclCommAbort), retires every shard stream
+ * synchronises such a stream: it aborts the communicators (ncclCommAbort — a library without it is not used), retires every shard stream
  * for a fresh one that continues behind the shard's last kernel, and — HH_MGPU_AUTO — completes this
  * and every later solve with the host's ordered sum (hh_mgpu_reduce_mode() then says HOST); with
  * HH_MGPU_RCCL the call returns HH_ERR_RCCL once the caller's buffers are no longer read, and so does
@@ -312,7 +316,11 @@ int hh_bk_decisions(hh_ctx* ctx, uint64_t n_paths, uint32_t* decisions, uint32_t
  * terminal pointers — for callers that keep their inputs in HBM.  hh_mgpu_ctx(mg, i) is the i-th
  * device's context (hh_device_malloc, hh_wiener_fill, hh_ctx_enable_timing … on that device); it stays
  * owned by mg.  out->kernel_ms is the LONGEST shard's HIP-event time, total_ms the host wall time.
- * After any error return nothing the call enqueued is still running.
+ * After any error return nothing that reads the caller's buffers is still running (a collective that lost its
+ * peers may still sit on a retired stream until ncclCommAbort has released it: hh_mgpu_destroy then leaves that
+ * device's streams and buffers alone rather than wait for it).  Should a shard be impossible to move off the
+ * stream the failed collective was enqueued on — a stream lent with hh_ctx_set_stream, or no new stream to be
+ * had — the context is stuck: the call and every later one return HH_ERR_RCCL, whatever the flags.
  */
 typedef struct hh_mgpu hh_mgpu;
 enum hh_mgpu_flags { HH_MGPU_AUTO = 0, HH_MGPU_HOST_SUM = 1, HH_MGPU_RCCL = 2 };
@@ -322,6 +330,14 @@ void hh_mgpu_destroy(hh_mgpu* mg);
 const char* hh_mgpu_last_error(const hh_mgpu* mg);
 int hh_mgpu_n_devices(const hh_mgpu* mg);
 int hh_mgpu_reduce_mode(const hh_mgpu* mg);       /* enum hh_mgpu_reduce in use                    */
+/* What a caller may print next to "reduce: rccl".  hh_mgpu_selftest sends a vector of ones from every device
+ * through the exchange a solve uses (the grouped ncclAllReduce on the shards' streams, or the host's ordered
+ * sum) and returns the count that came back — the ranks that really took part — and the mode it ran in.
+ * hh_mgpu_rccl_info names the library the collective entry points were bound from (dladdr of ncclAllReduce;
+ * empty when none), its ncclGetVersion (0 when unknown) and whether $HEDGEHOG_MC_RCCL chose it; HH_ERR_RCCL
+ * when no usable RCCL is bound (ncclCommAbort is required: see above). */
+int hh_mgpu_selftest(hh_mgpu* mg, int32_t* ranks_out, int32_t* reduce_mode_out /* nullable */);
+int hh_mgpu_rccl_info(const hh_mgpu* mg, char* path_out, size_t cap, int32_t* version_out, int32_t* from_env_out);
 enum hh_mgpu_option { HH_MGPU_OPT_ENQUEUE = 1 };
 enum hh_mgpu_enqueue { HH_MGPU_ENQUEUE_SERIAL = 0, HH_MGPU_ENQUEUE_THREADS = 1 /* default */ };
 int hh_mgpu_set_option(hh_mgpu* mg, int32_t option, int64_t value);
@@ -338,6 +354,11 @@ int hh_mgpu_solve_shards(hh_mgpu* mg, const hh_model* model, const hh_config* sh
                          hh_result* out, double* const* terminals /* nullable; n_devices, each nullable */);
 int hh_mgpu_solve_basket(hh_mgpu* mg, const hh_model* model, const hh_config* cfg, const double* strikes,
                          const double* cps, uint32_t n_payoffs, hh_result* out /* n_payoffs */);
+/* hh_mc_solve_multi with the trajectories sharded over the devices of mg: every device steps all n_models
+ * models on its range's draws, ONE all-reduce of the n_models x HH_ACC_LEN accumulator block.  Host buffers
+ * in cfg, as for hh_mgpu_solve; no terminal samples. */
+int hh_mgpu_solve_multi(hh_mgpu* mg, const hh_model* models, uint32_t n_models, const hh_config* cfg,
+                        hh_result* out /* n_models */);
 
 
 /*
@@ -347,8 +368,7 @@ int hh_mgpu_solve_basket(hh_mgpu* mg, const hh_model* model, const hh_config* cf
  * max(cps[k]·(S_T − strikes[k]), 0); model->strike / model->cp are ignored.  The accumulator block
  * is n_payoffs × HH_ACC_LEN doubles, payoff-major (all-reducible as one vector); dual partials of
  * the model parameters are carried for every payoff (strike partials are not).  Works for every
- * simulation strategy, Broadie–Kaya included.  Host arrays passed to an *_accumulate entry point
- * must stay valid until the ctx stream has been synchronized.
+ * simulation strategy, Broadie–Kaya included.
  */
 int hh_mc_accumulate_basket(hh_ctx* ctx, const hh_model* model, const hh_config* cfg,
                             const double* strikes, const double* cps, uint32_t n_payoffs,
@@ -545,6 +565,26 @@ int hh_wiener_fill(hh_ctx* ctx, int32_t dynamics, double rho, double T, uint32_t
  */
 int hh_ctx_enable_timing(hh_ctx* ctx, int32_t on);
 int hh_ctx_read_timings(hh_ctx* ctx, double* ms, int32_t cap, int32_t* n_out);
+
+/*
+ * A SimulationConfig's seed vector in the device memory of ctx, uploaded once and kept — repeated solves on one
+ * config (finite-difference Greeks, calibration loops) would otherwise move 8 MB per 10^6 trajectories at
+ * every call, about a third of a GENERATE solve of that size.  The reference reads seeds[i] at every solve
+ * (montecarlo.jl:331), so the cache is CONTENT-addressed: an entry is found by the vector's length and a
+ * fingerprint of ALL its elements (hh_seeds_fingerprint, ~1 ms per 10^6 seeds) — a vector changed in place, or
+ * another vector at the same address, is simply another key and is uploaded; the same numbers at another
+ * address hit.  `fingerprint` = 0 lets the call compute it; a host whose vector cannot change (the Python
+ * mirror freezes its copy) computes it once and passes it.  At most HH_SEED_CACHE_ENTRIES vectors are kept per
+ * context, the least recently used one goes first, all go with the context.  *dev_out stays valid until a
+ * later hh_seeds_cache call of this context MISSES (an eviction frees it): ask right before every solve,
+ * pass the pointer as cfg->seeds with seeds_on_device = 1, do not keep it.  The upload is synchronous — the
+ * host vector is free to change when the call returns.
+ */
+#define HH_SEED_CACHE_ENTRIES 8
+uint64_t hh_seeds_fingerprint(const uint64_t* seeds, uint64_t n);  /* pure host arithmetic; never 0 */
+int hh_seeds_cache(hh_ctx* ctx, const uint64_t* seeds_host, uint64_t n, uint64_t fingerprint,
+                   const uint64_t** dev_out);
+int hh_seeds_cache_stats(hh_ctx* ctx, uint64_t* hits, uint64_t* uploads, uint64_t* evictions); /* each nullable */
 
 /* Device memory helpers for hosts without another allocator (the Julia wrapper). */
 int hh_device_malloc(hh_ctx* ctx, size_t bytes, void** out_dev);

@@ -11,7 +11,8 @@
 #     G   = Hedgehog.solve(BatchGreekProblem(prob, lenses), ForwardAD(), mc)    # ONE fused pass
 #
 # What is bound (include/hedgehog_mc.h, HH_ABI_VERSION 5): hh_mc_solve (solve_hip, with the REPLAY
-# keywords), hh_mgpu_create / hh_mgpu_solve (solve_hip(...; devices = 0:7): several GPUs behind the one
+# keywords), hh_mc_solve_multi / hh_mgpu_solve_multi (prices_hip: the solves of a bumped Greek on shared draws),
+# hh_seeds_cache (the library's own seed cache), hh_mgpu_create / hh_mgpu_solve (solve_hip(...; devices = 0:7): several GPUs behind the one
 # call), hh_mc_accumulate + hh_mc_finalize (solve_sharded_hip: one process per GPU), hh_mc_solve_basket, hh_carr_madan,
 # hh_carr_madan_basket (+ _grad), hh_ctx_set_option, hh_lsm_solve, hh_heston_exact_grid, hh_replay_elems, the device-memory helpers.  The struct mirrors
 # below are checked field by field against the C header by tests/test_julia_layout.py (offsets from
@@ -121,58 +122,18 @@ last_error(mg::MultiGpu) = unsafe_string(ccall((:hh_mgpu_last_error, LIB[]), Cst
 reduce_mode(mg::MultiGpu) = ccall((:hh_mgpu_reduce_mode, LIB[]), Cint, (Ptr{Cvoid},), mg.handle) == 1 ? :rccl : :host
 
 # ---- a config's seeds on the device, once ---------------------------------------------------------
-# Repeated solves on one SimulationConfig (finite-difference Greeks, calibration loops) would move its
-# seed vector to the GPU again at every call: 8 MB per 10^6 trajectories, about a third of the time of a
-# GENERATE solve of that size.  The device copy is kept, keyed by the IDENTITY of `config.seeds` and
-# checked against its length and a fingerprint of 64 strided elements (+ the last): a vector mutated in
-# place between two solves in a way that leaves all of those unchanged is not noticed — `forget_seeds!()`
-# drops every copy.  At most 8 vectors are kept.
-mutable struct DeviceSeeds
-    ptr::Ptr{Cvoid}
-    n::Int
-    print::UInt64
-    ctx::Context
-end
-const SEED_CACHE = IdDict{Any,DeviceSeeds}()
-
-function _fingerprint(v::Vector{UInt64})
-    h = hash(length(v))
-    isempty(v) && return h
-    for i in 1:max(1, length(v) ÷ 64):length(v)
-        h = hash(v[i], h)
-    end
-    return hash(v[end], h)
-end
-
-function forget_seeds!()
-    for e in values(SEED_CACHE)
-        ccall((:hh_device_free, LIB[]), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), e.ctx.handle, e.ptr)
-    end
-    empty!(SEED_CACHE)
-    return nothing
-end
-
-function _device_seeds(ctx::Context, host::Vector{UInt64}, key)
-    fp = _fingerprint(host)
-    e = get(SEED_CACHE, key, nothing)
-    if e !== nothing && e.n == length(host) && e.print == fp && e.ctx === ctx
-        return e.ptr
-    end
-    length(SEED_CACHE) >= 8 && forget_seeds!()
-    if e !== nothing && haskey(SEED_CACHE, key)      # a stale copy of this very vector
-        ccall((:hh_device_free, LIB[]), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), e.ctx.handle, e.ptr)
-        delete!(SEED_CACHE, key)
-    end
+# Repeated solves on one SimulationConfig (finite-difference Greeks, calibration loops) would move its seed
+# vector to the GPU again at every call.  The LIBRARY keeps device copies (hh_seeds_cache: found by length + a
+# fingerprint of every element, so a vector mutated in place is simply another key; at most 8 per context,
+# freed with it) — nothing is cached, hashed or freed on this side.  The pointer is valid until the next call
+# that misses: ask right before each solve.
+function _device_seeds(ctx::Context, host::Vector{UInt64})
     p = Ref{Ptr{Cvoid}}(C_NULL)
-    rc = ccall((:hh_device_malloc, LIB[]), Cint, (Ptr{Cvoid}, Csize_t, Ref{Ptr{Cvoid}}),
-               ctx.handle, 8 * length(host), p)
-    rc == 0 || error("hh_device_malloc failed ($rc): $(last_error(ctx))")
     GC.@preserve host begin
-        rc = ccall((:hh_memcpy_h2d, LIB[]), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Csize_t),
-                   ctx.handle, p[], pointer(host), 8 * length(host))
+        rc = ccall((:hh_seeds_cache, LIB[]), Cint, (Ptr{Cvoid}, Ptr{UInt64}, UInt64, UInt64, Ref{Ptr{Cvoid}}),
+                   ctx.handle, pointer(host), UInt64(length(host)), UInt64(0), p)
     end
-    rc == 0 || error("hh_memcpy_h2d failed ($rc): $(last_error(ctx))")
-    SEED_CACHE[key] = DeviceSeeds(p[], length(host), fp, ctx)
+    rc == 0 || error("hh_seeds_cache failed ($rc): $(last_error(ctx))")
     return p[]
 end
 
@@ -215,7 +176,7 @@ function _resolve(payoff, m, method::MonteCarlo)
     seedvecs = [_partials(x, P) for x in scal]
     seeds = cfg.seeds isa Vector{UInt64} ? cfg.seeds : convert(Vector{UInt64}, cfg.seeds .% UInt64)
     anti = cfg.variance_reduction isa Antithetic
-    return (; seeds_key = cfg.seeds, dynamics, strategy, scal, rho = Float64(rho), T = Float64(T), P, seedvecs, seeds, anti,
+    return (; dynamics, strategy, scal, rho = Float64(rho), T = Float64(T), P, seedvecs, seeds, anti,
             n = Int(cfg.trajectories), steps = Int(cfg.steps), cp = payoff.call_put(),
             DT = _dualtype(scal...))
 end
@@ -268,7 +229,7 @@ function solve_hip(prob::PricingProblem{VanillaOption{TS,TE,European,C,Spot},I},
     seedvecs, seeds = r.seedvecs, r.seeds
     rep = replay === nothing ? nothing : collect(Float64, vec(replay))   # noise replay (montecarlo.jl:258,370)
     # one GPU, increments drawn in the kernel: the seeds are read from their device copy (made on first use)
-    sdev = (devices === nothing && rep === nothing) ? _device_seeds(ctx, seeds, r.seeds_key) : Ptr{Cvoid}(C_NULL)
+    sdev = (devices === nothing && rep === nothing) ? _device_seeds(ctx, seeds) : Ptr{Cvoid}(C_NULL)
     GC.@preserve seedvecs seeds terminal rep begin
         model, config = _structs(r; em_split, compat_sqrt_alpha, replay = rep, replay_layout, seeds_dev = sdev)
         term = ensemble ? pointer(terminal) : Ptr{Cdouble}(C_NULL)
@@ -284,6 +245,41 @@ function solve_hip(prob::PricingProblem{VanillaOption{TS,TE,European,C,Spot},I},
     end
     ens = !ensemble ? nothing : r.anti ? (terminal[1:r.n], terminal[r.n+1:2r.n]) : terminal
     return MonteCarloSolution(prob, method, _price(r, res[]), ens)       # pricing_solutions.jl:22-27
+end
+
+# ---- several problems on the SAME draws in one pass (hh_mc_solve_multi) ------------------------------
+"""
+    prices_hip(probs, method::MonteCarlo) -> Vector of prices
+
+The solves a bumped Greek is made of — `compute_fd_derivative` (greeks_problem.jl:279-303) runs 2, the
+second-order stencils (:396-422) 3 or 4, all on the seeds of one SimulationConfig — simulated together:
+`hh_mc_solve_multi` steps every model on each draw.  Price k is `solve(probs[k], method).price` bit for bit.
+Plain numbers only (a Dual input falls back to one solve per problem).
+"""
+function prices_hip(probs::AbstractVector, method::MonteCarlo; devices = DEVICES[])
+    rs = [_resolve(p.payoff, p.market_inputs, method) for p in probs]
+    any(r -> r === nothing, rs) && throw(MethodError(Hedgehog.solve, (probs[1], method)))
+    if length(probs) < 2 || length(probs) > 16 || any(r -> r.P != 0, rs)
+        return [solve_hip(p, method; ensemble = false, devices).price for p in probs]
+    end
+    seeds = rs[1].seeds
+    ctx = devices === nothing ? context() : multi_gpu(devices)
+    sdev = devices === nothing ? _device_seeds(ctx, seeds) : Ptr{Cvoid}(C_NULL)
+    res = Vector{HHResult}(undef, length(probs))
+    GC.@preserve seeds res begin
+        models = [_structs(r)[1] for r in rs]
+        _, config = _structs(rs[1]; seeds_dev = sdev)
+        rc = devices === nothing ?
+            ccall((:hh_mc_solve_multi, LIB[]), Cint,
+                  (Ptr{Cvoid}, Ptr{HHModel}, UInt32, Ref{HHConfig}, Ptr{HHResult}, Ptr{Ptr{Cdouble}}),
+                  ctx.handle, models, UInt32(length(models)), config, res, C_NULL) :
+            ccall((:hh_mgpu_solve_multi, LIB[]), Cint,
+                  (Ptr{Cvoid}, Ptr{HHModel}, UInt32, Ref{HHConfig}, Ptr{HHResult}),
+                  ctx.handle, models, UInt32(length(models)), config, res)
+        rc == -2 && throw(MethodError(Hedgehog.solve, (probs[1], method)))
+        rc == 0 || error("hh_mc_solve_multi failed ($rc): $(last_error(ctx))")
+    end
+    return [x.price for x in res]
 end
 
 # ---- BatchGreekProblem + ForwardAD in ONE pass (greeks_problem.jl:559-568) ------------------------
@@ -630,26 +626,64 @@ const DEVICES = Ref{Any}(nothing)   # install!(devices = 0:7): every routed solv
 Overwrite `Hedgehog.solve(::PricingProblem{<:VanillaOption{…,European,…,Spot}}, ::MonteCarlo)`
 (montecarlo.jl:478-481) with the GPU implementation and add the fused
 `solve(::BatchGreekProblem, ::ForwardAD, ::MonteCarlo)`, LSM on BlackScholesExact paths, Monte Carlo and
-Carr–Madan baskets.  `GreekProblem` and `FiniteDifference` solvers (greeks_problem.jl:249-329) then run
-through the first unchanged.  `install!(devices = 0:7)`
+Carr–Madan baskets.  `GreekProblem` + `ForwardAD` (greeks_problem.jl:249-262) then runs through the first
+unchanged; `FiniteDifference` through MonteCarlo gets its 2-4 prices from ONE pass on shared draws
+(`prices_hip`).  Idempotent: a second call only changes `devices`.  Must not run during precompilation (call it
+from `__init__` or from the session).  `install!(devices = 0:7)`
 shards every routed solve over those GPUs inside the library (hh_mgpu_solve) — `solve(prob, method)`
 stays one call, as montecarlo.jl:478-493.
 """
+const INSTALLED = Ref(false)
+
 function install!(; devices = nothing)
     ccall((:hh_abi_version, LIB[]), Cint, ()) == HH_ABI_VERSION ||
         error("libhedgehog_mc.so has another ABI version than this file ($HH_ABI_VERSION)")
-    DEVICES[] = devices
+    DEVICES[] = devices                   # read at every routed call: a second install! only changes this
+    INSTALLED[] && return nothing         # the methods are defined ONCE (no "method overwritten" on later calls)
+    # NOT during precompilation: `@eval Hedgehog …` adds methods to another module, which a precompiling
+    # package may not do (INTEGRATION.md) — call install!() from __init__ or from the session
+    ccall(:jl_generating_output, Cint, ()) == 1 &&
+        error("HedgehogMC.install!() must not run while a package is being precompiled: call it from __init__()")
     @eval Hedgehog function solve(
         prob::PricingProblem{VanillaOption{TS,TE,European,C,Spot},I}, method::MonteCarlo,
     ) where {TS,TE,C,I<:AbstractMarketInputs}
         return $(solve_hip)(prob, method; devices = $(DEVICES)[])
     end
     # the fused form of greeks_problem.jl:559-568 (more specific than the reference's generic method:
-    # ForwardAD + MonteCarlo); FiniteDifference / analytic methods keep the reference's loop
+    # ForwardAD + MonteCarlo); analytic methods keep the reference's loop
     @eval Hedgehog function solve(
         gprob::BatchGreekProblem{P,L}, ::ForwardAD, pricing_method::MonteCarlo,
     ) where {P,L}
         return $(solve_batch_greeks_hip)(gprob, pricing_method)
+    end
+    # FiniteDifference through MonteCarlo: the reference's formulas (greeks_problem.jl:279-303, 396-422) on
+    # prices that come out of ONE pass on shared draws instead of 2-4 solves — the same numbers
+    @eval Hedgehog function compute_fd_derivative(::FDForward, prob, lens, ε, pricing_method::MonteCarlo)
+        x₀ = lens(prob)
+        v_up, v₀ = $(prices_hip)([set(prob, lens, x₀ * (1 + ε)), prob], pricing_method)
+        return (v_up - v₀) / (x₀ * ε)
+    end
+    @eval Hedgehog function compute_fd_derivative(::FDBackward, prob, lens, ε, pricing_method::MonteCarlo)
+        x₀ = lens(prob)
+        v_down, v₀ = $(prices_hip)([set(prob, lens, x₀ * (1 - ε)), prob], pricing_method)
+        return (v₀ - v_down) / (x₀ * ε)
+    end
+    @eval Hedgehog function compute_fd_derivative(::FDCentral, prob, lens, ε, pricing_method::MonteCarlo)
+        x₀ = lens(prob)
+        v_up, v_down = $(prices_hip)([set(prob, lens, x₀ * (1 + ε)), set(prob, lens, x₀ * (1 - ε))], pricing_method)
+        return (v_up - v_down) / (2ε * x₀)
+    end
+    @eval Hedgehog function solve(gprob::SecondOrderGreekProblem, method::FiniteDifference, pricing_method::MonteCarlo)
+        prob, lens1, lens2, ε = gprob.pricing_problem, gprob.wrt1, gprob.wrt2, method.bump
+        x₀, y₀ = lens1(prob), lens2(prob)
+        at(x, y) = set(set(prob, lens1, x), lens2, y)
+        if lens1 === lens2
+            f_plus, f_0, f_minus = $(prices_hip)([at(x₀ + ε, y₀ + ε), at(x₀, y₀), at(x₀ - ε, y₀ - ε)], pricing_method)
+            return GreekResult((f_plus - 2f_0 + f_minus) / (ε^2))
+        end
+        f_pp, f_pm, f_mp, f_mm = $(prices_hip)([at(x₀ + ε, y₀ + ε), at(x₀ + ε, y₀ - ε), at(x₀ - ε, y₀ + ε),
+                                                at(x₀ - ε, y₀ - ε)], pricing_method)
+        return GreekResult((f_pp - f_pm - f_mp + f_mm) / (4ε^2))
     end
     # LSM on the path source the reference's own LSM tests use (test/agreement/american_options.jl):
     # LognormalDynamics + BlackScholesExact on BlackScholesInputs.  More specific than the reference's method
@@ -669,6 +703,7 @@ function install!(; devices = nothing)
     @eval Hedgehog function solve(prob::BasketPricingProblem, method::CarrMadan)
         return $(carr_madan_basket_hip)(prob, method)
     end
+    INSTALLED[] = true
     return nothing
 end
 

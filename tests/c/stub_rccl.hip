@@ -214,6 +214,13 @@ int ncclCommAbort(ncclComm* c) {
   return kSuccess;
 }
 
+// a version no real RCCL reports: a line that names this library cannot be taken for one from the real thing
+int ncclGetVersion(int* v) {
+  if (!v) return kInvalidArgument;
+  *v = 9990000;
+  return kSuccess;
+}
+
 int ncclGroupStart() {
   ++g_depth;
   return kSuccess;

@@ -114,6 +114,16 @@ def main(out_path):
     out["groups"] = c1["complete"] - c0["complete"]
     out["groups_expected"] = 2 + (2 + 19 + 1) + (2 + 5 + 1)
     out["calls"] = c1["calls"] - c0["calls"]
+    # the count a caller may print next to "reduce: rccl" comes from a collective, and the line can name the library
+    out["selftest"] = list(mg.selftest())
+    out["selftest_host_context"] = list(host.selftest())
+    out["rccl_info"] = mg.rccl_info()
+    # several models on the same draws, sharded: one all-reduce of the 3 x 16 block
+    models = [_ffi.make_model(S0=100.1), _ffi.make_model(S0=99.9), _ffi.make_model(V0=0.05, strike=95.0)]
+    cm = _ffi.make_config(HES, EM, 10_001, 17, antithetic=1, seeds=seeds_for(10_001, 5))
+    c0m = counters()
+    out["multi_bit_equal"] = [bits(r) for r in mg.solve_multi(models, cm)] == [bits(r) for r in host.solve_multi(models, cm)]
+    out["multi_groups"] = counters()["complete"] - c0m["complete"]
     # serial enqueue gives the same bits
     mg.set_option(_ffi.HH_MGPU_OPT_ENQUEUE, _ffi.HH_MGPU_ENQUEUE_SERIAL)
     out["serial_enqueue_bit_equal"] = european(mg)[:2] == ref_eu[:2]
@@ -182,6 +192,29 @@ def main(out_path):
         out["lsm_strict_failure_code"] = e.code
     out["lsm_strict_failure_seconds"] = time.perf_counter() - t0
     mg.close()
+
+    # 4b. a shard that cannot be moved off the stream the failed collective sits on (here: a stream lent by the
+    #     caller): the call returns a status once the caller's buffers are free — it does not finish on that
+    #     stream — and the context refuses further work; destroying it must not wait for the orphan either
+    import torch
+    mg = _ffi.MultiGpu(DEV)
+    lent = torch.cuda.Stream()
+    mg.ctx(1).set_stream(lent.cuda_stream)
+    stub.stub_rccl_fail_at(2, 1)
+    t0 = time.perf_counter()
+    try:
+        european(mg)
+        out["stuck_code"] = 0
+    except _ffi.HedgehogMCError as e:
+        out["stuck_code"] = e.code
+    try:
+        european(mg)
+        out["stuck_second_code"] = 0
+    except _ffi.HedgehogMCError as e:
+        out["stuck_second_code"] = e.code
+        out["stuck_text"] = str(e)
+    mg.close()
+    out["stuck_seconds"] = time.perf_counter() - t0
 
     # 5. eight ranks, as on the node the driver benches (seven worker threads + the caller's)
     host8 = _ffi.MultiGpu([0] * 8, _ffi.HH_MGPU_HOST_SUM)

@@ -36,6 +36,14 @@ def test_launcher_starts_n_ranks_weak():
     assert out["global_paths"] == 2_000_000 and out["paths_covered"] == 2_000_000
 
 
+def test_a_substitute_collective_library_is_refused_unless_asked_for():
+    """$HEDGEHOG_MC_RCCL makes hh_mgpu bind another library in place of librccl (the tests' stand-in): bench.py
+    must not produce a line under it silently — exit code 2 before anything runs, whatever the mode."""
+    for flags in (("--gpus", "2", "--rehearse"), ("--gpus", "1", "--single-process"), ()):
+        p, out = run_bench(*flags, env={"HEDGEHOG_MC_RCCL": "/nonexistent/libfake_rccl.so"}, timeout=120)
+        assert p.returncode == 2 and out is None and "--allow-rccl-override" in p.stderr
+
+
 @pytest.mark.timeout(300)
 def test_launcher_strong_scaling_ranges_cover_the_ensemble():
     p, out = run_bench("--gpus", "3", "--rehearse", "--global-paths", "10000000")
@@ -106,6 +114,10 @@ def test_single_process_line_keeps_the_contract(hhlib):
         assert key in out
     assert out["single_process"] is True and out["n_gpus"] == 1 and out["steps"] == 5
     assert out["roofline"]["launches_timed"] == 5
+    # one device: AUTO keeps the host path (no collective to run): the line must not claim RCCL ranks
+    assert out["ranks_counted_by_the_exchange"] == 1 and out["rccl_library_from_env"] is False
+    assert (out["reduce"] == "rccl") == (out["rccl_ranks"] == 1)
+    assert len(out["per_rank_kernel_ms"]) == 1 and out["per_rank_kernel_ms"][0] > 0
     p, _ = run_bench("--gpus", "2", "--single-process", "--devices", "0,7", "--steps", "1", "--warmup", "0")
     assert p.returncode != 0  # fewer GPUs than asked: refused, never a smaller run
 
@@ -120,6 +132,7 @@ def test_one_rank_line_keeps_the_contract(hhlib):
                 "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
         assert key in out
     assert out["n_gpus"] == 1 and out["rccl_ranks"] == 1 and out["steps"] == 5
+    assert len(out["per_rank_kernel_ms"]) == 1 and out["collective"]["ranks_counted_by_all_reduce_of_ones"] == 1
     rf = out["roofline"]
     assert rf["bound"] == "hbm" and rf["frac"] == pytest.approx(rf["achieved"] / rf["peak"])
     assert rf["launches_timed"] == 5

@@ -155,3 +155,24 @@ def test_a_sum_that_equals_the_poison_pattern(hhlib):
     assert accumulate(ctx, m2, c2, True).tobytes() == accumulate(ctx, m2, c2, False).tobytes()
     c3 = o.make_config(HES, EM, n_paths, n_steps, seeds=seeds_for(n_paths), n_partials=1)
     assert accumulate(ctx, m, c3, True).tobytes() == accumulate(ctx, m, c3, False).tobytes()
+
+
+@pytest.mark.parametrize("n_paths", [2048 * 512 * 8 - 1, 2048 * 512 * 8 + 700, 2048 * 512 * 64 + 513])
+@pytest.mark.parametrize("anti", [0, 1])
+def test_exact_law_forms_one_eight_and_sixty_four_pairs_per_lane(hhlib, oracle, n_paths, anti):
+    """The exact-law kernel gives a lane 1, 8 or 64 pairs of trajectories by the ensemble's size
+    (exact_pairs_per_lane): each form against the oracle (montecarlo.jl:293-303, 412-414, 454-459), ragged
+    last workgroup included, and its in-kernel reduction against the separate kernel bit for bit."""
+    m = o.make_model(S0=100.0, sigma=0.2, r=0.05, T=1.0, strike=100.0, seeds={"S0": [1.0, 0.0], "sigma": [0.0, 1.0]},
+                     n_partials=2)
+    c = o.make_config(GBM, EXACT, n_paths, 1, antithetic=anti, seeds=np.array([77], dtype=np.uint64), n_partials=2,
+                      path_offset=3)  # odd offset: a lane's pair straddles two Philox blocks
+    a1 = accumulate(hhlib, m, c, True)
+    assert a1.tobytes() == accumulate(hhlib, m, c, False).tobytes()
+    r = _ffi.hh_result()
+    hhlib.lib.hh_mc_finalize(C.byref(m), C.byref(c), a1.ctypes.data, C.byref(r))
+    ro, _, _ = oracle.mc_solve(m, c, want_terminal=False)
+    assert r.price == pytest.approx(ro.price, rel=1e-11)
+    assert r.std_error == pytest.approx(ro.std_error, rel=1e-8)
+    for k in range(2):
+        assert r.dprice[k] == pytest.approx(ro.dprice[k], rel=1e-10)

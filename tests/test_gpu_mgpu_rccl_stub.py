@@ -4,7 +4,6 @@ librccl (tests/c/stub_rccl.hip; see tests/rccl_stub_worker.py for the scenarios)
 8-GPU node runs with the real RCCL (montecarlo.jl:478-493 stays one call)."""
 import json
 import os
-import shutil
 import subprocess
 import sys
 
@@ -13,16 +12,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-STUB_SRC = os.path.join(ROOT, "tests", "c", "stub_rccl.hip")
-STUB = os.path.join(ROOT, "tests", "c", "libstub_rccl.so")
-
-
-def build_stub():
-    if os.path.exists(STUB) and os.path.getmtime(STUB) >= os.path.getmtime(STUB_SRC):
-        return
-    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    subprocess.run([hipcc, "-shared", "-fPIC", "-O2", "-std=c++17", "--offload-arch=gfx950", STUB_SRC, "-o", STUB],
-                   check=True)
+from tests.c.build_stub import STUB, build_stub  # noqa: E402  (pytest-free: the product's build() uses it too)
 
 
 @pytest.fixture(scope="module")
@@ -43,6 +33,26 @@ def test_three_ranks_through_the_rccl_branch_equal_the_host_ordered_sum(run):
     assert run["lsm_bit_equal"] and run["lsm_heston_bit_equal"]  # price, std error, stopping times and values
     assert run["groups"] == run["groups_expected"]  # ONE all-reduce per solve; 2 + (steps - 1) + 1 per LSM solve
     assert run["calls"] == 3 * run["groups"]
+
+
+def test_rank_count_comes_from_a_collective_and_the_library_is_named(run):
+    """What bench.py prints next to "reduce: rccl": ranks counted by an all-reduce of ones through the solve's own
+    exchange, the file the entry points were bound from, its version, and that the environment chose it."""
+    assert run["selftest"] == [3, 1]            # three ranks, RCCL branch
+    assert run["selftest_host_context"] == [3, 0]
+    info = run["rccl_info"]
+    assert info["library"].endswith("libstub_rccl.so") and info["version"] == 9990000
+    assert info["from_env"] is True and info["usable"] is True
+
+
+def test_several_models_through_the_rccl_branch(run):
+    assert run["multi_bit_equal"] and run["multi_groups"] == 1
+
+
+def test_a_shard_that_cannot_leave_its_stream_makes_the_context_refuse(run):
+    assert run["stuck_code"] == -5 and run["stuck_second_code"] == -5
+    assert "create a new context" in run["stuck_text"] or "create a new one" in run["stuck_text"]
+    assert run["stuck_seconds"] < 2.5  # the stand-in's orphan would take three seconds
 
 
 def test_serial_and_threaded_enqueue_agree(run):
@@ -91,12 +101,23 @@ def test_bench_single_process_form_through_the_rccl_branch():
     build_stub()
     env = dict(os.environ, HEDGEHOG_MC_RCCL=STUB)
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--single-process",
-                        "--devices", "0,0,0", "--steps", "3", "--warmup", "1", "--paths", "30000", "--ramp-ms", "0"],
+                        "--devices", "0,0,0", "--steps", "3", "--warmup", "1", "--paths", "30000", "--ramp-ms", "0",
+                        "--allow-rccl-override"],
                        env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stderr[-3000:]
     line = json.loads(next(ln for ln in p.stdout.splitlines() if ln.startswith("{")))
     assert line["single_process"] is True and line["n_gpus"] == 3
-    assert line["reduce"] == "rccl" and line["rccl_ranks"] == 3
+    assert line["reduce"] == "rccl" and line["rccl_ranks"] == 3 and line["ranks_counted_by_the_exchange"] == 3
+    # … and WHO carried them: the line names the stand-in, so it cannot be taken for a real-RCCL record
+    assert line["rccl_library"].endswith("libstub_rccl.so") and line["rccl_library_from_env"] is True
+    assert line["rccl_version"] == 9990000
+    assert len(line["per_rank_kernel_ms"]) == 3 and all(t and t > 0 for t in line["per_rank_kernel_ms"])
+    assert len(line["enqueue_host_us"]["per_shard"]) == 3 and line["enqueue_host_us"]["phase"] > 0
     assert line["config"]["global_paths"] == 90000 and line["scaling"] == "weak"
+    # without the explicit flag a set $HEDGEHOG_MC_RCCL is refused before anything runs
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--single-process",
+                        "--devices", "0,0,0", "--steps", "1", "--warmup", "0", "--paths", "3000"],
+                       env=env, capture_output=True, text=True, timeout=120)
+    assert p.returncode == 2 and "allow-rccl-override" in p.stderr and not p.stdout.strip()
     assert abs(line["price"] - line["analytic_carr_madan"]) < 6 * line["std_error"] + 0.05  # Euler bias at dt = 1/252
     assert line["value"] > 0 and line["roofline"]["launches_timed"] == 3

@@ -258,3 +258,36 @@ def test_multi_at_the_headline_size_both_modes(hhlib):
         assert all(same_bits(a[0], b[0]) for a, b in zip(each, multi))
         delta = (multi[0][0].price - multi[1][0].price) / 0.2
         assert delta == pytest.approx(0.6557, abs=5e-3)  # Carr–Madan ∂/∂S0 of H252, Euler bias within
+
+
+# ---- sharded over the devices of a hh_mgpu (on a one-GPU box: several contexts on device 0) ----------------
+
+@pytest.mark.parametrize("G", [2, 3])
+@pytest.mark.parametrize("strat,noise", [(EM, GEN), (EM, REP), (EXACT, GEN)])
+def test_multi_over_shards(hhlib, oracle, G, strat, noise):
+    dyn = GBM if strat == EXACT else HES
+    n_paths, n_steps = 256 * 14 + 5, (1 if strat == EXACT else 9)
+    seeds = seeds_for(n_paths, 9)
+    models = bumped_models(dyn, 3, same_noise_law=True)
+    rep = oracle.wiener_fill(dyn, models[0].rho, models[0].T, n_steps, seeds) if noise == REP else None
+    c = o.make_config(dyn, strat, n_paths, n_steps, noise_mode=noise, seeds=seeds, replay=rep, antithetic=1)
+    one = solve_multi(hhlib, models, c, False)
+    mg = _ffi.MultiGpu([0] * G, _ffi.HH_MGPU_HOST_SUM)
+    try:
+        many = mg.solve_multi(models, c)
+    finally:
+        mg.close()
+    for k in range(3):
+        assert many[k].price == pytest.approx(one[k][0].price, rel=1e-13)
+        assert many[k].std_error == pytest.approx(one[k][0].std_error, rel=1e-10)
+        assert many[k].n_paths_done == n_paths
+
+
+def test_host_mirror_devices_keyword_reaches_bumped_greeks(hhlib):
+    import dataclasses
+    prob, m, eps = heston_problem(), heston_method(), 1e-3
+    m2 = dataclasses.replace(m, devices=(0, 0))
+    lens = hh.optic("market_inputs.spot")
+    g1 = hh.solve(hh.GreekProblem(prob, lens), hh.FiniteDifference(eps), m).greek
+    g2 = hh.solve(hh.GreekProblem(prob, lens), hh.FiniteDifference(eps), m2).greek
+    assert g2 == pytest.approx(g1, rel=1e-9)  # a difference of two prices that agree to 1e-13

@@ -143,14 +143,17 @@ def test_repeated_solves_reuse_the_device_seeds_and_sample_buffers():
     prob = heston_problem()
     cfg = hh.SimulationConfig(20_000, steps=20, seeds=np.arange(1, 20_001))
     method = hh.MonteCarlo(hh.HestonDynamics(), hh.EulerMaruyama(), cfg)
+    ctx = hh.get_context(0)
+    before = ctx.seeds_cache_stats()
     a = hh.solve(prob, method)
     ens_a = a.ensemble.copy()
     for _ in range(20):
         b = hh.solve(prob, method)  # samples never read: the buffer goes back to the pool with `b`
     assert b.price == a.price
     np.testing.assert_array_equal(b.ensemble, ens_a)
-    ctx = hh.get_context(0)
-    assert len(cfg._seeds_dev) == 1 and len(ctx.__dict__.get("_pool", [])) <= ctx._POOL_MAX
+    after = ctx.seeds_cache_stats()
+    assert after["uploads"] - before["uploads"] <= 1 and after["hits"] - before["hits"] >= 20
+    assert len(ctx.__dict__.get("_pool", [])) <= ctx._POOL_MAX
     assert hh.solve(prob, method, ensemble=False).ensemble is None
 
 

@@ -224,12 +224,12 @@ def test_rccl_stand_in_exports_what_the_library_binds():
     """tests/c/stub_rccl.hip must keep up with the RCCL entry points hh_mgpu.hip resolves with dlsym —
     otherwise the multi-rank tests would silently fall back to the host sum."""
     import subprocess
-    from tests.test_gpu_mgpu_rccl_stub import STUB, build_stub
+    from tests.c.build_stub import STUB, build_stub
     build_stub()
     src = open(os.path.join(ROOT, "hedgehog.jl_amd", "csrc", "hh_mgpu.hip")).read()
     bound = set(re.findall(r'dlsym\(api\.lib, "(nccl\w+)"\)', src))
     assert {"ncclCommInitAll", "ncclCommDestroy", "ncclCommAbort", "ncclAllReduce", "ncclGroupStart", "ncclGroupEnd",
-            "ncclGetErrorString"} == bound
+            "ncclGetErrorString", "ncclGetVersion"} == bound
     exported = subprocess.run(["nm", "-D", "--defined-only", STUB], capture_output=True, text=True, check=True).stdout
     for name in bound | {"stub_rccl_fail_at", "stub_rccl_counters"}:
         assert re.search(r"\bT " + name + r"\b", exported), name

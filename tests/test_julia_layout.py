@@ -176,7 +176,8 @@ def test_every_ccall_signature_matches_the_header_prototype():
                 "Csize_t": "u64", "Cdouble": "f64", "Float64": "f64", "Cvoid": "void"}[t]
 
     src = open(JULIA).read()
-    calls = re.findall(r"ccall\(\(:(hh_\w+),\s*LIB\[\]\),\s*([\w\{\}]+),\s*\((.*?)\),\s*\n?\s*[\w\.\(]", src, re.S)
+    # the argument tuple holds types only — braces, never parentheses
+    calls = re.findall(r"ccall\(\(:(hh_\w+),\s*LIB\[\]\),\s*([\w\{\}]+),\s*\(([^()]*)\),\s*\n?\s*[\w\.\(]", src, re.S)
     assert len(calls) >= 20
     for name, ret, args in calls:
         c_ret, c_args = protos[name]

@@ -38,6 +38,8 @@ rows = [
     ("heston_euler_replay_anti_1e6x252", model, cfg(1, 0, N, M, 1, 1), 100),
     ("heston_euler_generate_1e6x252", model, cfg(1, 0, N, M, 0), 60),
     ("lognormal_exact_1e6", m2, cfg(0, 1, N, 1, 0), 400),
+    ("lognormal_exact_1e7", m2, cfg(0, 1, 10 * N, 1, 0), 100),
+    ("lognormal_exact_1e8", m2, cfg(0, 1, 100 * N, 1, 0), 20),
     ("lognormal_euler_1e4x100 (config 1)", m2, cfg(0, 0, 10_000, 100, 0), 400),
     ("heston_euler_generate_1e4x100", model, cfg(1, 0, 10_000, 100, 0), 400),
 ]
