@@ -161,7 +161,7 @@ def test_cabi_header_and_library_agree():
     """Every function include/hedgehog_mc.h declares is bound in _ffi.SYMBOLS and exported by the
     built library (no compute call is made here)."""
     hdr = open(os.path.join(ROOT, "include", "hedgehog_mc.h")).read()
-    declared = set(re.findall(r"^\s*(?:int|void|size_t|const char\*|hh_ctx\*)\s+(hh_\w+)\s*\(", hdr, re.M))
+    declared = set(re.findall(r"^\s*(?:int|void|size_t|uint64_t|const char\*|hh_ctx\*)\s+(hh_\w+)\s*\(", hdr, re.M))
     bound = {s[0] for s in _ffi.SYMBOLS}
     assert declared == bound, declared ^ bound
     lib = hh.load_library()
