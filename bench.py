@@ -779,7 +779,7 @@ def main():
         # `solve_ms` of the rows below is the HIP-event time of EVERYTHING one hh_mc_accumulate enqueues (since
         # round 5 the timing hook brackets the call's last kernel too: a record reduction that is a kernel of its
         # own — Broadie–Kaya, baskets — is inside)
-        def multi_ms(models, cfg, reps=10, warm_ms=15.0):
+        def multi_ms(models, cfg, reps=20, warm_ms=40.0):
             K = len(models)
             arr = (_ffi.hh_model * K)(*models)
             acc_k = torch.zeros(K * _ffi.HH_ACC_LEN, dtype=torch.float64, device=dev)
@@ -806,7 +806,7 @@ def main():
                       "solves on the same seeds (greeks_problem.jl:296-303); here both models are stepped on each draw "
                       "in one pass — bit-identical prices (tests/test_gpu_multi.py)", "bump": eps}
         for key, cfg_n in (("generate", sh.config(_ffi.HH_NOISE_GENERATE)), ("replay", sh.config(_ffi.HH_NOISE_REPLAY))):
-            t_one, _ = kernel_ms(fd_models[0], cfg_n)
+            t_one, _ = kernel_ms(fd_models[0], cfg_n, reps=20, warm_ms=40.0)
             t_two, rr = multi_ms(fd_models, cfg_n)
             delta = (rr[0].price - rr[1].price) / (2 * eps * H252["S0"])
             ent = {"solve_ms": t_two, "two_separate_solves_ms": 2 * t_one, "ratio": t_two / (2 * t_one),

@@ -128,6 +128,18 @@ int ensure_poisoned(hh_ctx* ctx, size_t need) {
   return HH_OK;
 }
 
+// HH_OPT_FUSE_REDUCE = 2 (default), by what was measured (profiles/r05_c_fuse_ab.txt, same process, same box):
+// the simulation kernel reduces its own records when they are few (the whole grid is resident at once, the
+// reducer finds them all on its first look: -2 % on a 27 µs solve) and when the kernel runs long enough for
+// the reducer's wait to disappear behind the other workgroups' work (Euler, 10^6 x 252: -0.3 % in both noise
+// modes); a SHORT kernel with thousands of records (the exact law at 10^6-10^7 trajectories, 14-43 µs) is 1-4 %
+// faster with reduce_records_kernel behind it, whose 16 workgroups read the records in parallel.
+constexpr uint32_t kFuseAutoMaxRecords = 512, kFuseAutoMinSteps = 32;
+bool fuse_for(const hh_ctx* ctx, const hh_config* c) {
+  if (ctx->fuse_reduce != 2) return ctx->fuse_reduce == 1;
+  return hh::sim_records(*c) <= kFuseAutoMaxRecords || (c->strategy == HH_EULER_MARUYAMA && c->n_steps >= kFuseAutoMinSteps);
+}
+
 size_t replay_elems(uint64_t n_paths, uint32_t n_steps, int dynamics) {
   return (size_t)hh::tiles_for(n_paths) * n_steps * ncomp_of(dynamics) * hh::kTile;
 }
@@ -249,8 +261,8 @@ int hh_ctx_set_option(hh_ctx* ctx, int32_t option, int64_t value) {
       ctx->grid_form = (int)value;
       return HH_OK;
     case HH_OPT_FUSE_REDUCE:
-      if (value != 0 && value != 1)
-        return fail(ctx, HH_ERR_INVALID, "HH_OPT_FUSE_REDUCE: 1 (records reduced by the simulation kernel) or 0 (a second kernel)");
+      if (value < 0 || value > 2)
+        return fail(ctx, HH_ERR_INVALID, "HH_OPT_FUSE_REDUCE: 0 (a second kernel reduces the records), 1 (the simulation kernel does) or 2 (by size)");
       ctx->fuse_reduce = (int)value;
       return HH_OK;
     default:
@@ -413,7 +425,7 @@ static int run_simulation(hh_ctx* ctx, const hh_model* m, const hh_config* c, do
 
   hh::DevicePtrs p{};
   p.records = ctx->records;
-  const bool fuse = accum_dev && ctx->fuse_reduce && !bk;
+  const bool fuse = accum_dev && !bk && fuse_for(ctx, c);
   if (fuse) {  // records in the buffer that holds the poison pattern between launches (hh_sim.h)
     if ((rc = ensure_poisoned(ctx, (size_t)n_tiles * hh::kRecStride))) return rc;
     p.records = ctx->frecords;
@@ -525,7 +537,7 @@ int hh_mc_accumulate_multi(hh_ctx* ctx, const hh_model* models, uint32_t n_model
   HH_HIP(ctx, hipSetDevice(ctx->device));
   const uint32_t n_tiles = hh::tiles_for(c->n_paths);
   const size_t rec_elems = (size_t)n_tiles * hh::kRecStride;
-  const bool fuse = ctx->fuse_reduce != 0;
+  const bool fuse = fuse_for(ctx, c);
   if (fuse) rc = ensure_poisoned(ctx, (size_t)n_models * rec_elems);
   else rc = ensure(ctx, ctx->records, ctx->records_cap, (size_t)n_models * rec_elems);
   if (rc) return rc;

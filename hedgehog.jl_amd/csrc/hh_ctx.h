@@ -65,7 +65,7 @@ struct hh_ctx {
   long long lsm_spin_ticks = -1;          // hh_ctx_set_option(HH_OPT_LSM_SPIN_TICKS); < 0 = the default (1 s)
   double* frecords = nullptr;      // records of the launches that reduce them themselves: kPoison between launches (hh_sim.h)
   size_t frecords_cap = 0;         // in doubles
-  int fuse_reduce = 1;             // hh_ctx_set_option(HH_OPT_FUSE_REDUCE): record reduction inside the simulation kernel
+  int fuse_reduce = 2;             // hh_ctx_set_option(HH_OPT_FUSE_REDUCE): 0 a second kernel, 1 in the simulation kernel, 2 by size
   // seed vectors kept in device memory (hh_seeds_cache): content-addressed, least recently used one out
   struct SeedEntry {
     uint64_t* dev = nullptr;

@@ -468,34 +468,36 @@ __device__ __forceinline__ double sum_slot(const double* __restrict__ rec, uint3
                                            double* sm) {
   const int tid = threadIdx.x;
   double t = 0.0;
-  // records b = tid, tid + 256, … added in that order; eight loads are in flight before the first add
-  // (one dependent load per add made this kernel 8 µs on 4000 records; + 0.0 leaves a sum unchanged)
-  for (uint32_t b = tid; b < n; b += 256 * 8) {
-    double v[8];
+  // Records b = tid, tid + 256, … added in that order.  The kernel is pure latency — a strided load per add:
+  // SIXTEEN loads are in flight before the first add, so that the 3907 records of 10^6 trajectories are ONE
+  // round trip per thread (eight made it 6.5 µs; one dependent load per add 8 µs); + 0.0 leaves a sum unchanged.
+  for (uint32_t b = tid; b < n; b += 256 * 16) {
+    double v[16];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < 16; ++u) {
       const uint32_t i = b + 256u * u;
       v[u] = i < n ? rec[(size_t)i * kRecStride + slot] : 0.0;
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) t += v[u];
+    for (int u = 0; u < 16; ++u) t += v[u];
   }
-  __syncthreads();
+  __syncthreads();  // sm may still be read from the slot before
   sm[tid] = t;
   __syncthreads();
-#pragma unroll
-  for (int s = 128; s > 0; s >>= 1) {
-    if (tid < s) sm[tid] += sm[tid + s];
-    __syncthreads();
-  }
-  return sm[0];
+  // the binary tree over the 256 partial sums — steps 128 and 64 on LDS, the rest by shuffles in wave 0
+  // (tree256, hh_sim.h: the same adds in the same order as eight barrier-separated LDS steps)
+  double r = 0.0;
+  if (tid < 64) r = tree256(sm);
+  if (tid == 0) sm[256] = r;
+  __syncthreads();
+  return sm[256];
 }
 
 __global__ __launch_bounds__(256) void reduce_records_kernel(const double* __restrict__ rec,
                                                               uint32_t n, double n_paths,
                                                               double* __restrict__ accum,
                                                               const PartialMap map) {
-  __shared__ double sm[256];
+  __shared__ double sm[257];
   const int slot = blockIdx.x;
   rec += (size_t)blockIdx.y * n * kRecStride;  // group = one payoff of a basket
   accum += (size_t)blockIdx.y * kRecStride;

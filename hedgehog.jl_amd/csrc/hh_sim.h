@@ -456,11 +456,24 @@ __device__ __forceinline__ void finish_records(double* __restrict__ records, uin
   if (threadIdx.x == 0) gave_up = 0u;
   __syncthreads();
   const bool itm = map->n > 0;  // some direction has a passive part: the two in-the-money sums are live
+  // Every published word goes back to the poison as soon as the thread that read it has it in its partial sum
+  // (records i = tid mod NT are the ones of its virtual threads): the write-through stores then travel while
+  // the sums are finished, instead of holding the end of the kernel up.  A word that never came is poison already.
+  const double poison = __longlong_as_double((long long)kPoison);
+  const auto wsrc = __builtin_amdgcn_make_buffer_rsrc(records, 0, (int)(n_rec * (uint32_t)(kRecStride * 8)), 0x00020000);
+  const unsigned int ph = (unsigned int)(kPoison >> 32), pl = (unsigned int)kPoison;
   partial_pairs<NT>(records, n_rec, sm, &gave_up);
+  if (itm) partial_slots<NT, 2>(records, n_rec, [](int q) { return kRecItmS + q; }, sm + 512, &gave_up);
+  for (uint32_t i = threadIdx.x; i < n_rec; i += NT) {
+    __builtin_amdgcn_raw_buffer_store_b128(u32x4{pl, ph, pl, ph}, wsrc, (int)(i * (uint32_t)(kRecStride * 8)), 0, 16);  // Σp, Σp²: sc1
+    if (itm) {
+      store_through(records + (size_t)i * kRecStride + kRecItmS, poison);
+      store_through(records + (size_t)i * kRecStride + kRecItmS + 1, poison);
+    }
+  }
 #if HH_FINISH_STAMPS
   const unsigned long long st1 = wall_clock64();
 #endif
-  if (itm) partial_slots<NT, 2>(records, n_rec, [](int q) { return kRecItmS + q; }, sm + 512, &gave_up);
   __syncthreads();
   double s[4] = {0.0, 0.0, 0.0, 0.0}, d[P > 0 ? P : 1];
   if (threadIdx.x < 64) {
@@ -474,6 +487,10 @@ __device__ __forceinline__ void finish_records(double* __restrict__ records, uin
   if constexpr (P > 0) {  // the carried derivative sums
     __syncthreads();
     partial_slots<NT, P>(records, n_rec, [](int q) { return HH_ACC_DSUM + q; }, sm, &gave_up);
+    for (uint32_t i = threadIdx.x; i < n_rec; i += NT) {
+#pragma unroll
+      for (int j = 0; j < P; ++j) store_through(records + (size_t)i * kRecStride + HH_ACC_DSUM + j, poison);
+    }
     __syncthreads();
     if (threadIdx.x < 64) {
 #pragma unroll
@@ -502,23 +519,6 @@ __device__ __forceinline__ void finish_records(double* __restrict__ records, uin
     if (slot == 13) out = (double)wall_clock64();    // sums done
 #endif
     accum[slot] = gave_up ? __longlong_as_double(0x7FF8000000000000ll) : out;
-  }
-  // Every published word back to the poison, by the thread that read it (records i = tid mod NT are the ones
-  // of its virtual threads); a word that never came is poison already.  Σp, Σp²: one 16-byte store.
-  const double poison = __longlong_as_double((long long)kPoison);
-  const auto wsrc = __builtin_amdgcn_make_buffer_rsrc(records, 0, (int)(n_rec * (uint32_t)(kRecStride * 8)), 0x00020000);
-  const unsigned int ph = (unsigned int)(kPoison >> 32), pl = (unsigned int)kPoison;
-  for (uint32_t i = threadIdx.x; i < n_rec; i += NT) {
-    __builtin_amdgcn_raw_buffer_store_b128(u32x4{pl, ph, pl, ph}, wsrc, (int)(i * (uint32_t)(kRecStride * 8)), 0, 16);  // sc1
-    double* r = records + (size_t)i * kRecStride;
-    if constexpr (P > 0) {
-#pragma unroll
-      for (int j = 0; j < P; ++j) store_through(r + HH_ACC_DSUM + j, poison);
-    }
-    if (itm) {
-      store_through(r + kRecItmS, poison);
-      store_through(r + kRecItmS + 1, poison);
-    }
   }
 }
 

@@ -202,9 +202,13 @@ const char* hh_last_error(const hh_ctx* ctx); /* NUL-terminated, owned by ctx (o
  * the bound is only the last guard; 0 makes every workgroup give up at once, which is how the tests
  * force the give-up-and-redo path (hh_lsm_result.persistent_fallbacks counts it; same result).
  *
- * HH_OPT_FUSE_REDUCE: 1 (default) the simulation kernel of a single-payoff solve also adds its workgroups'
- * partial sums (the workgroup that finishes last does, in a fixed order) — one launch per solve; 0 a second
- * kernel adds them, as before round 5.  Same order of additions either way: bit-identical results. */
+ * HH_OPT_FUSE_REDUCE: who adds the workgroups' partial sums of a single-payoff solve (mean(payoffs),
+ * montecarlo.jl:490): 0 a second kernel (reduce_records_kernel), 1 the simulation kernel itself (the last
+ * tile's workgroup, once every record has arrived), 2 (default) by what was measured — the simulation kernel
+ * up to 512 records (a launch saved is 2 % of a small solve) and for Euler runs of 32 steps or more (the
+ * reducer's wait disappears behind the other workgroups: -0.3 % at 10^6 x 252), the second kernel for short
+ * kernels with thousands of records (the exact law at 10^6 - 10^7 trajectories: 1-4 % faster that way).  The
+ * same additions in the same order every way: bit-identical results. */
 enum hh_option { HH_OPT_LSM_FORM = 1, HH_OPT_BK_TERM_CACHE = 2, HH_OPT_GRID_FORM = 3, HH_OPT_LSM_SPIN_TICKS = 4,
                  HH_OPT_FUSE_REDUCE = 5 };
 enum hh_grid_form { HH_GRID_FORM_PER_DATE = 0, HH_GRID_FORM_BATCHED = 1 };

@@ -27,7 +27,7 @@ def accumulate(ctx, m, c, fused):
         ctx.synchronize()
         return acc.download(np.empty(_ffi.HH_ACC_LEN))
     finally:
-        ctx.set_option(_ffi.HH_OPT_FUSE_REDUCE, 1)
+        ctx.set_option(_ffi.HH_OPT_FUSE_REDUCE, 2)  # the default: by size
 
 
 def seeds_for(n, salt=0):
@@ -92,14 +92,17 @@ def test_records_are_ready_for_the_next_launch(hhlib, oracle):
     cfgs = [o.make_config(HES, EM, n, s, seeds=seeds_for(n, 8)) for n, s in shapes]
     want = [accumulate(ctx, m, c, False) for c in cfgs]
     bufs = [_ffi.DeviceBuffer(ctx, 8 * _ffi.HH_ACC_LEN) for _ in range(4 * len(cfgs))]
-    for rep in range(4):
-        for i, c in enumerate(cfgs):
-            ctx.check(ctx.lib.hh_mc_accumulate(ctx.handle, C.byref(m), C.byref(c), bufs[rep * len(cfgs) + i].ptr, None))
-    ctx.synchronize()
-    for rep in range(4):
-        for i in range(len(cfgs)):
-            got = bufs[rep * len(cfgs) + i].download(np.empty(_ffi.HH_ACC_LEN))
-            assert got.tobytes() == want[i].tobytes(), (rep, i)
+    for mode in (1, 2):  # always in the kernel; by size (the default: the launches then alternate between the two forms)
+        ctx.set_option(_ffi.HH_OPT_FUSE_REDUCE, mode)
+        for rep in range(4):
+            for i, c in enumerate(cfgs):
+                ctx.check(ctx.lib.hh_mc_accumulate(ctx.handle, C.byref(m), C.byref(c), bufs[rep * len(cfgs) + i].ptr, None))
+        ctx.synchronize()
+        ctx.set_option(_ffi.HH_OPT_FUSE_REDUCE, 2)
+        for rep in range(4):
+            for i in range(len(cfgs)):
+                got = bufs[rep * len(cfgs) + i].download(np.empty(_ffi.HH_ACC_LEN))
+                assert got.tobytes() == want[i].tobytes(), (mode, rep, i)
     ro, _, _ = oracle.mc_solve(m, cfgs[0], want_terminal=False)
     r = _ffi.hh_result()
     ctx.lib.hh_mc_finalize(C.byref(m), C.byref(cfgs[0]), want[0].ctypes.data, C.byref(r))
@@ -131,9 +134,11 @@ def test_live_slots_change_between_launches(hhlib):
     jobs = [(model_with(P, HES), o.make_config(HES, EM, n_paths, 5, seeds=seeds, n_partials=P)) for P in (0, 5, 1, 0, 3)]
     want = [accumulate(ctx, m, c, False) for m, c in jobs]
     bufs = [_ffi.DeviceBuffer(ctx, 8 * _ffi.HH_ACC_LEN) for _ in jobs]
+    ctx.set_option(_ffi.HH_OPT_FUSE_REDUCE, 1)
     for (m, c), b in zip(jobs, bufs):
         ctx.check(ctx.lib.hh_mc_accumulate(ctx.handle, C.byref(m), C.byref(c), b.ptr, None))
     ctx.synchronize()
+    ctx.set_option(_ffi.HH_OPT_FUSE_REDUCE, 2)
     for w, b in zip(want, bufs):
         assert b.download(np.empty(_ffi.HH_ACC_LEN)).tobytes() == w.tobytes()
 

@@ -137,17 +137,18 @@ def test_multi_path_major_replay_and_device_buffers(hhlib, oracle):
         assert tb[k].download(np.empty(n_paths)).tobytes() == want[k][1].tobytes()
 
 
-def test_multi_with_the_separate_reduction_kernel(hhlib):
+def test_multi_with_either_form_of_the_record_reduction(hhlib):
     n_paths = 256 * 40 + 9
     models = bumped_models(HES, 4, same_noise_law=False)
     c = o.make_config(HES, EM, n_paths, 12, seeds=seeds_for(n_paths, 8), antithetic=1)
     want = solve_multi(hhlib, models, c, False)
-    hhlib.set_option(_ffi.HH_OPT_FUSE_REDUCE, 0)
-    try:
-        got = solve_multi(hhlib, models, c, False)
-    finally:
-        hhlib.set_option(_ffi.HH_OPT_FUSE_REDUCE, 1)
-    assert all(same_bits(a[0], b[0]) for a, b in zip(want, got))
+    for mode in (0, 1):
+        hhlib.set_option(_ffi.HH_OPT_FUSE_REDUCE, mode)
+        try:
+            got = solve_multi(hhlib, models, c, False)
+        finally:
+            hhlib.set_option(_ffi.HH_OPT_FUSE_REDUCE, 2)
+        assert all(same_bits(a[0], b[0]) for a, b in zip(want, got)), mode
 
 
 def test_multi_broadie_kaya_is_one_chain_per_model(hhlib):

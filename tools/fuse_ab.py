@@ -79,5 +79,5 @@ for name, mdl, c, k in rows:
     r["wall_ratio_fused_over_separate"] = min(r["fused"]["wall_ms"]) / min(r["separate"]["wall_ms"])
     out[name] = r
     print(name, json.dumps(r), flush=True)
-ctx.set_option(_ffi.HH_OPT_FUSE_REDUCE, 1)
+ctx.set_option(_ffi.HH_OPT_FUSE_REDUCE, 2)
 ctx.synchronize()
