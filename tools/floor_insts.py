@@ -175,6 +175,15 @@ def main():
                                   "unit": "path-step", "phases": {**{"normals: " + k: v for k, v in NORMAL_PAIR.items()},
                                                                   **{k: v for k, v in GENERATE.items() if k != "two normals"}}},
         "lognormal_exact": {"lane_insts": exact, "floor_insts_per_unit": exact / 64.0, "unit": "path"},
+        "lognormal_exact_1e8": {"lane_insts": exact, "floor_insts_per_unit": exact / 64.0,
+                                "unit": "path (the same law; 64 pairs per lane amortise the workgroup's reduction)"},
+        # several models on the same draws (hh_multi.hip): the normals / the loads once, one Euler step per model
+        "heston_euler_generate_multi2": {"lane_insts": sum(GENERATE.values()) + GENERATE["Euler step"],
+                                         "floor_insts_per_unit": (sum(GENERATE.values()) + GENERATE["Euler step"]) / 64.0,
+                                         "unit": "path-step of the PASS (two models stepped on it; dW formed once: same rho, dt)"},
+        "heston_euler_replay_multi2": {"lane_insts": 2 * GENERATE["Euler step"],
+                                       "floor_insts_per_unit": 2 * GENERATE["Euler step"] / 64.0,
+                                       "unit": "path-step of the PASS (two Euler steps; the two loads are not VALU work)"},
         "broadie_kaya": {"lane_insts": bk_path, "floor_insts_per_unit": bk_path / 64.0, "unit": "path",
                          "per_cf_evaluation": {"fixed": cf_fixed, "per_bessel_series_term": CF_PER_BESSEL_TERM,
                                                "bessel_terms_mean": N, "lane_insts": cf_eval},
@@ -192,7 +201,8 @@ def main():
     print(f"Broadie-Kaya: J = {J:.2f} series terms, {N:.1f} Bessel terms per CF evaluation, CF evaluation = {cf_eval:.0f} (fixed {cf_fixed})")
     try:
         meas = json.load(open(os.path.join(ROOT, "profiles", "valu_insts.json")))
-        for k in ("heston_euler_generate", "lognormal_exact", "broadie_kaya", "lsm_chain"):
+        for k in ("heston_euler_generate", "heston_euler_generate_multi2", "heston_euler_replay_multi2", "lognormal_exact",
+                  "lognormal_exact_1e8", "broadie_kaya", "lsm_chain"):
             print(f"  frac_of_floor {k:24s} {out[k]['floor_insts_per_unit'] / meas[k]['valu_insts_per_unit']:.3f}")
     except Exception as e:  # noqa: BLE001
         print("no valu_insts.json:", e)
