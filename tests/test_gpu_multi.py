@@ -292,3 +292,26 @@ def test_host_mirror_devices_keyword_reaches_bumped_greeks(hhlib):
     g1 = hh.solve(hh.GreekProblem(prob, lens), hh.FiniteDifference(eps), m).greek
     g2 = hh.solve(hh.GreekProblem(prob, lens), hh.FiniteDifference(eps), m2).greek
     assert g2 == pytest.approx(g1, rel=1e-9)  # a difference of two prices that agree to 1e-13
+
+
+def test_random_model_sets_share_a_pass_bit_for_bit(hhlib):
+    """60 random sets of 2-6 models (every scalar drawn afresh, also ρ, T, call/put), random shapes and modes: the
+    shared pass against one solve per model, bitwise."""
+    rng = np.random.default_rng(20261004)
+    for case in range(60):
+        K = int(rng.integers(2, 7))
+        dyn = HES if rng.random() < 0.7 else GBM
+        strat = EM if dyn == HES or rng.random() < 0.5 else EXACT
+        n_paths = int(rng.integers(1, 3000))
+        n_steps = 1 if strat == EXACT else int(rng.integers(1, 40))
+        models = [o.make_model(S0=float(rng.uniform(50, 150)), V0=float(rng.uniform(0.005, 0.3)), kappa=float(rng.uniform(0.1, 5)),
+                               theta=float(rng.uniform(0.01, 0.3)), sigma=float(rng.uniform(0.05, 1.0)),
+                               rho=float(rng.uniform(-0.95, 0.95)), r=float(rng.uniform(-0.02, 0.1)), T=float(rng.uniform(0.05, 3.0)),
+                               strike=float(rng.uniform(50, 150)), cp=float(rng.choice([-1.0, 1.0]))) for _ in range(K)]
+        c = o.make_config(dyn, strat, n_paths, n_steps, antithetic=int(rng.integers(0, 2)), em_split=int(rng.integers(0, 2)),
+                          seeds=seeds_for(n_paths, case))
+        each = solve_each(hhlib, models, c, True)
+        multi = solve_multi(hhlib, models, c, True)
+        for k in range(K):
+            assert same_bits(each[k][0], multi[k][0]), (case, k)
+            assert each[k][1].tobytes() == multi[k][1].tobytes(), (case, k)

@@ -369,3 +369,45 @@ def test_full_path_entry_points_refuse_duals_instead_of_dropping_them():
         with pytest.raises(hh.MethodError, match="FiniteDifference"):
             _lsm_structs(hh.PricingProblem(put, mkt), mc)
     _lsm_structs(hh.PricingProblem(put, hh.BlackScholesInputs(ref, 0.05, 100.0, 0.2)), mc)
+
+
+def test_finite_difference_formulas_on_a_closed_form_method():
+    """greeks_problem.jl:279-303, 396-422 on a method that is NOT MonteCarlo: the host layer's FiniteDifference
+    solvers must then run the reference's plain sequence of solves (the shared pass is MonteCarlo's alone) —
+    checked against the Black–Scholes closed forms the reference's own tests use (test/unit/black_scholes.jl,
+    greeks_agreement.jl:32-120: AD = FD = analytic to 1e-5)."""
+    import math
+    ref, exp_ = hh.Date(2021, 1, 1), hh.Date(2022, 1, 1)
+    S, K, r, sig, T = 100.0, 100.0, 0.05, 0.2, 1.0
+    prob = hh.PricingProblem(hh.VanillaOption(K, exp_, hh.European(), hh.Call(), hh.Spot()),
+                             hh.BlackScholesInputs(ref, r, S, sig))
+    bs = hh.BlackScholesAnalytic()
+    d1 = (math.log(S / K) + (r + 0.5 * sig * sig) * T) / (sig * math.sqrt(T))
+    pdf = math.exp(-0.5 * d1 * d1) / math.sqrt(2 * math.pi)
+    delta, gamma, vega = 0.5 * (1 + math.erf(d1 / math.sqrt(2))), pdf / (S * sig * math.sqrt(T)), S * pdf * math.sqrt(T)
+    spot, vol = hh.SpotLens(), hh.VolLens(K, exp_)
+    for scheme, tol in ((hh.FDCentral(), 1e-6), (hh.FDForward(), 2e-3), (hh.FDBackward(), 2e-3)):
+        g = hh.solve(hh.GreekProblem(prob, spot), hh.FiniteDifference(1e-4, scheme), bs).greek
+        assert g == pytest.approx(delta, rel=tol)
+    assert hh.solve(hh.GreekProblem(prob, vol), hh.FiniteDifference(1e-4), bs).greek == pytest.approx(vega, rel=1e-6)
+    assert hh.solve(hh.SecondOrderGreekProblem(prob, spot, spot), hh.FiniteDifference(1e-2), bs).greek == \
+        pytest.approx(gamma, rel=1e-4)
+    vanna = -pdf * (d1 - sig * math.sqrt(T)) / sig  # ∂²C/∂S∂σ
+    assert hh.solve(hh.SecondOrderGreekProblem(prob, spot, vol), hh.FiniteDifference(1e-3), bs).greek == \
+        pytest.approx(vanna, rel=1e-3)
+    batch = hh.solve(hh.BatchGreekProblem(prob, (spot, vol)), hh.FiniteDifference(1e-4), bs)
+    assert batch[spot] == pytest.approx(delta, rel=1e-6) and batch[vol] == pytest.approx(vega, rel=1e-6)
+
+
+def test_problems_that_cannot_share_a_pass_are_left_to_the_plain_loop():
+    """solve_montecarlo_many says None (and touches no GPU) for what hh_mc_solve_multi does not take: a dual number in
+    a problem, one problem alone, more than HH_MAX_MODELS problems."""
+    from hedgehog_jl_amd.dual import Dual
+    ref, exp_ = hh.Date(2021, 1, 1), hh.Date(2022, 1, 1)
+    call = hh.VanillaOption(100.0, exp_, hh.European(), hh.Call(), hh.Spot())
+    mc = hh.MonteCarlo(hh.HestonDynamics(), hh.EulerMaruyama(), hh.SimulationConfig(50, steps=3, seeds=range(1, 51)))
+    plain = hh.PricingProblem(call, hh.HestonInputs(ref, 0.03, 100.0, 0.04, 2.0, 0.04, 0.3, -0.7))
+    dual = hh.PricingProblem(call, hh.HestonInputs(ref, 0.03, Dual(100.0, (1.0,)), 0.04, 2.0, 0.04, 0.3, -0.7))
+    assert hh.solve_montecarlo_many([plain], mc) is None
+    assert hh.solve_montecarlo_many([plain] * (_ffi.HH_MAX_MODELS + 1), mc) is None
+    assert hh.solve_montecarlo_many([plain, dual], mc) is None
