@@ -77,6 +77,7 @@ HH_OPT_BK_TERM_CACHE = 2
 HH_OPT_GRID_FORM = 3
 HH_OPT_LSM_SPIN_TICKS = 4
 HH_OPT_FUSE_REDUCE = 5
+HH_OPT_GRID_ORDER = 6
 HH_GRID_FORM_PER_DATE, HH_GRID_FORM_BATCHED = 0, 1
 HH_CM_GRAD_LEN = 8  # enum hh_cm_grad: S0, V0, kappa, theta, sigma, rho, r_drift, discount
 HH_LSM_FORM_PER_DATE, HH_LSM_FORM_PERSISTENT, HH_LSM_FORM_AUTO = 0, 1, 2

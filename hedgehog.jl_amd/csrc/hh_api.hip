@@ -191,6 +191,7 @@ void hh_ctx_destroy(hh_ctx* ctx) {
   if (ctx->basket_records) (void)hipFree(ctx->basket_records);
   if (ctx->basket_accum) (void)hipFree(ctx->basket_accum);
   if (ctx->bk_scratch) (void)hipFree(ctx->bk_scratch);
+  if (ctx->bk_sort) (void)hipFree(ctx->bk_sort);
   if (ctx->lsm_grid) (void)hipFree(ctx->lsm_grid);
   if (ctx->heston_var) (void)hipFree(ctx->heston_var);
   if (ctx->lsm_val) (void)hipFree(ctx->lsm_val);
@@ -259,6 +260,11 @@ int hh_ctx_set_option(hh_ctx* ctx, int32_t option, int64_t value) {
       if (value != HH_GRID_FORM_PER_DATE && value != HH_GRID_FORM_BATCHED)
         return fail(ctx, HH_ERR_INVALID, "HH_OPT_GRID_FORM: 0 (one chain per date) or 1 (dates batched)");
       ctx->grid_form = (int)value;
+      return HH_OK;
+    case HH_OPT_GRID_ORDER:
+      if (value != 0 && value != 1)
+        return fail(ctx, HH_ERR_INVALID, "HH_OPT_GRID_ORDER: 0 (a chain's pairs in their natural order) or 1 (sorted by their Bessel arguments)");
+      ctx->grid_order = (int)value;
       return HH_OK;
     case HH_OPT_FUSE_REDUCE:
       if (value < 0 || value > 2)
@@ -1030,6 +1036,10 @@ static int run_heston_grid(hh_ctx* ctx, const hh_model* m, const hh_config* c) {
   p.bk_scratch = ctx->bk_scratch;
   p.bk_table_key = &ctx->bk_table_key;
   p.bk_term_cache = ctx->bk_term_cache;
+  if (per_chain > 1 && ctx->grid_order) {  // the batched chains run their pairs in the order of their Bessel arguments
+    if ((rc = ensure(ctx, ctx->bk_sort, ctx->bk_sort_cap, hh::bk_grid_sort_bytes(n_chain)))) return rc;
+    p.bk_sort = ctx->bk_sort;
+  }
   if ((rc = stage_path_seeds(ctx, c, &p.seeds))) return rc;
   HH_HIP(ctx, hh::launch_fill_rows(ctx->lsm_grid, ctx->heston_var, n, m->S0, m->V0, ctx->stream));
   hh_model step_model = *m;

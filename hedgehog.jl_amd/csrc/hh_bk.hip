@@ -34,6 +34,8 @@
 #include <algorithm>
 #include <cmath>
 
+#include <hipcub/hipcub.hpp>
+
 #include "hh_bessel.h"
 #include "hh_kernels.h"
 #include "hh_math.h"
@@ -1118,6 +1120,50 @@ __global__ __launch_bounds__(256) void fill_rows_kernel(double* __restrict__ spo
   }
 }
 
+// ---- a grid chain's pairs in the order of their Bessel arguments -------------------------------------------------
+// A date of a grid is a SHORT transition: the Bessel argument ν_γ ∝ sqrt(V0·V_T)/dt is large and spread over
+// orders of magnitude, lanes of one wave sit in different regimes of the Bessel function (power series / Hankel
+// expansion) with series of different lengths, and the CF kernel runs at 0.53 active lanes per instruction
+// (profiles/r05_d_bk_refill_experiment.txt).  The same draws sorted by V_T run the chain 32 % faster
+// (profiles/r05_e_bk_sorted_short_T.txt).  So the pairs of a chain are ordered by a coarse key — exponent and
+// three mantissa bits of V0·V_T, a stable radix sort of (key, pair) — their draws and start variances gathered in
+// that order, the chain run on the gathered arrays, and ∫V scattered back.  Nothing a pair computes depends on
+// its neighbours, and the chain's counters are whole numbers: the grid is the same, bit for bit.
+__global__ __launch_bounds__(256) void grid_keys_kernel(const double* __restrict__ vt, const double* __restrict__ v0,
+                                                        uint32_t n, uint32_t* __restrict__ keys,
+                                                        uint32_t* __restrict__ idx) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n) return;
+  const double prod = v0[i] * vt[i];  // > 0 (both are floored at 2^-1000); positive doubles order like their bits
+  // exponent + three mantissa bits = eighth-octave bins, counted from 2^-28 and cut to ONE radix digit: products
+  // below 2^-28 share bin 0, above 2^4 bin 255 (variances from 1e-4 to 1 give 2^-27 … 2^0)
+  const int k = (int)((unsigned long long)__double_as_longlong(prod) >> 49) - ((1023 - 28) << 3);
+  keys[i] = (uint32_t)(k < 0 ? 0 : k > 255 ? 255 : k);
+  idx[i] = i;
+}
+constexpr int kGridKeyBits = 8;
+// below this many pairs the sort and the two copies cost more than the order saves (2.4·10^5 pairs: +8 %; 2.4·10^6: -16 %)
+constexpr uint64_t kGridOrderMinPairs = 1ull << 20;
+
+__global__ __launch_bounds__(256) void grid_gather_kernel(const double* __restrict__ draws, size_t stride,
+                                                          const double* __restrict__ v0, const uint32_t* __restrict__ perm,
+                                                          uint32_t n, double* __restrict__ draws_out,
+                                                          double* __restrict__ v0_out) {
+  const uint32_t s = blockIdx.x * 256u + threadIdx.x;
+  if (s >= n) return;
+  const uint32_t j = perm[s];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) draws_out[(size_t)k * stride + s] = draws[(size_t)k * stride + j];
+  v0_out[s] = v0[j];
+}
+
+__global__ __launch_bounds__(256) void grid_scatter_kernel(const double* __restrict__ iv_sorted,
+                                                           const uint32_t* __restrict__ perm, uint32_t n,
+                                                           double* __restrict__ iv) {
+  const uint32_t s = blockIdx.x * 256u + threadIdx.x;
+  if (s < n) iv[perm[s]] = iv_sorted[s];
+}
+
 }  // namespace
 
 constexpr size_t kSlotBitmapBytes = 8 * 128 + 128;  // one 128-byte line per XCD (kXcds = 8) + the side-store counter's
@@ -1313,6 +1359,19 @@ void bk_diag_ptrs(const void* scratch, uint64_t n_paths, int term_cache, const u
   *series_len = diag + lanes;
 }
 
+// device scratch of the ordered form of a grid chain over n_chain pairs: keys and pair indices (in / out), the
+// gathered draws [4], start variances and ∫V, the radix sort's own storage
+static size_t grid_sort_temp_bytes(uint64_t n_chain) {
+  size_t bytes = 0;
+  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr,
+                                           (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)n_chain, 0, kGridKeyBits);
+  return (bytes + 255) & ~(size_t)255;
+}
+size_t bk_grid_sort_bytes(uint64_t n_chain) {
+  const size_t lanes = (size_t)tiles_for(n_chain) * kTile;
+  return 4 * lanes * sizeof(uint32_t) + 6 * lanes * sizeof(double) + grid_sort_temp_bytes(n_chain) + 256;
+}
+
 int launch_bk_grid(const hh_model& m, const hh_config& c, const DevicePtrs& ptr, hipStream_t s,
                    double* spot_rows, double* var_rows, uint32_t k0, uint32_t n_dates, bool upload_tables) {
   BkArgs a{};
@@ -1326,7 +1385,34 @@ int launch_bk_grid(const hh_model& m, const hh_config& c, const DevicePtrs& ptr,
   if ((rc = bk_tables(a, L, ptr, s, upload_tables))) return rc;
   const dim3 rows(tiles_for(n_row)), b(kTile);
   hipLaunchKernelGGL(bk_draw_grid_kernel, rows, b, 0, s, a, n_row, k0, n_dates, var_rows);
-  bk_chain(a, L, s);
+  if (ptr.bk_sort && n_chain >= kGridOrderMinPairs && n_chain < (1ull << 31)) {  // the pairs in the order of their Bessel arguments (see grid_keys_kernel)
+    const size_t lanes = (size_t)L.n_tiles * kTile;
+    uint32_t* keys_in = reinterpret_cast<uint32_t*>(ptr.bk_sort);
+    uint32_t *keys_out = keys_in + lanes, *idx_in = keys_out + lanes, *perm = idx_in + lanes;
+    double* draws_sorted = reinterpret_cast<double*>(perm + lanes);
+    double *var_sorted = draws_sorted + 4 * lanes, *iv_sorted = var_sorted + lanes;
+    void* temp = iv_sorted + lanes;
+    size_t temp_bytes = grid_sort_temp_bytes(n_chain);
+    const uint32_t n = (uint32_t)n_chain;
+    const dim3 g256((n + 255u) / 256u), b256(256);
+    hipLaunchKernelGGL(grid_keys_kernel, g256, b256, 0, s, a.draws + 3 * a.draw_stride, static_cast<const double*>(var_rows), n,
+                       keys_in, idx_in);
+    if (hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, static_cast<const uint32_t*>(keys_in), keys_out,
+                                           static_cast<const uint32_t*>(idx_in), perm, (int)n, 0, kGridKeyBits, s) != hipSuccess)
+      return (int)hipErrorUnknown;
+    hipLaunchKernelGGL(grid_gather_kernel, g256, b256, 0, s, static_cast<const double*>(a.draws), a.draw_stride,
+                       static_cast<const double*>(var_rows), static_cast<const uint32_t*>(perm), n, draws_sorted, var_sorted);
+    BkArgs o = a;  // the chain on the gathered arrays: position s of the order stands for pair perm[s]
+    o.draws = draws_sorted;
+    o.draw_stride = lanes;
+    o.in_var = var_sorted;
+    o.iv_out = iv_sorted;
+    bk_chain(o, L, s);
+    hipLaunchKernelGGL(grid_scatter_kernel, g256, b256, 0, s, static_cast<const double*>(iv_sorted),
+                       static_cast<const uint32_t*>(perm), n, a.iv_store);
+  } else {
+    bk_chain(a, L, s);
+  }
   hipLaunchKernelGGL(bk_grid_spots_kernel, rows, b, 0, s, a, n_row, n_dates,
                      static_cast<const double*>(var_rows), spot_rows);
   return (int)hipGetLastError();

@@ -61,6 +61,9 @@ struct hh_ctx {
   uint64_t bk_last_n = 0;           // trajectories of the last Broadie–Kaya solve (hh_bk_decisions)
   int bk_last_cache = 0;            // … and the term cache it ran with
   int grid_form = HH_GRID_FORM_BATCHED;  // hh_ctx_set_option(HH_OPT_GRID_FORM)
+  int grid_order = 1;                    // hh_ctx_set_option(HH_OPT_GRID_ORDER): 1 = a chain's pairs sorted by their Bessel arguments
+  unsigned char* bk_sort = nullptr;      // scratch of the ordered form (hh::bk_grid_sort_bytes)
+  size_t bk_sort_cap = 0;
   uint64_t lsm_persistent_fallbacks = 0;  // persistent launches that gave up and were redone per date
   long long lsm_spin_ticks = -1;          // hh_ctx_set_option(HH_OPT_LSM_SPIN_TICKS); < 0 = the default (1 s)
   double* frecords = nullptr;      // records of the launches that reduce them themselves: kPoison between launches (hh_sim.h)

@@ -85,6 +85,8 @@ struct DevicePtrs {
   // bk_scratch keeps one BkTableKey next to it, zero-initialised
   struct BkTableKey* bk_table_key;
   int bk_term_cache;  // Broadie–Kaya: cached series terms per trajectory at most (0 = default)
+  void* bk_sort;      // exact grid: bk_grid_sort_bytes(pairs of a chain) of device memory — the chain then runs its
+                      // pairs in the order of their Bessel arguments (NULL: in their natural order; same grid)
   // Euler REPLAY: `replay` is the reference's own layout dW[path][step][comp] (rows of a multiple of
   // 16 bytes: replay_direct_path_major()) and is consumed as it stands by euler_pm_kernel
   bool replay_path_major;
@@ -173,6 +175,7 @@ int launch_bk_grid(const hh_model& m, const hh_config& c, const DevicePtrs& p, h
                    double* spot_rows, double* var_rows, uint32_t k0, uint32_t n_dates, bool upload_tables);
 // dates per chain for a grid of n_steps dates: all of them unless the pairs' term cache would pass its budget
 uint32_t bk_grid_dates_per_chain(uint64_t n_paths, uint32_t n_steps, int term_cache);
+size_t bk_grid_sort_bytes(uint64_t n_chain);
 constexpr int kBkTermCacheDefault = 256;
 size_t bk_scratch_bytes(uint64_t n_paths, int term_cache = 0);
 // where the last chain over n_paths trajectories left, per trajectory, its decision word (BkDecision bits:

@@ -202,6 +202,12 @@ const char* hh_last_error(const hh_ctx* ctx); /* NUL-terminated, owned by ctx (o
  * the bound is only the last guard; 0 makes every workgroup give up at once, which is how the tests
  * force the give-up-and-redo path (hh_lsm_result.persistent_fallbacks counts it; same result).
  *
+ * HH_OPT_GRID_ORDER: 1 (default) a batched chain of hh_heston_exact_grid (HH_GRID_FORM_BATCHED) runs its (date,
+ * trajectory) pairs sorted by a coarse key of V0·V_T — the size of their Bessel argument — so that the lanes of a
+ * wave share a regime of the Bessel function and series of similar length (short transitions spread both widely:
+ * 0.53 active lanes per instruction unsorted; the same draws sorted run the chain 32 % faster); 0: in their
+ * natural order.  The same grid either way, bit for bit.
+ *
  * HH_OPT_FUSE_REDUCE: who adds the workgroups' partial sums of a single-payoff solve (mean(payoffs),
  * montecarlo.jl:490): 0 a second kernel (reduce_records_kernel), 1 the simulation kernel itself (the last
  * tile's workgroup, once every record has arrived), 2 (default) by what was measured — the simulation kernel
@@ -210,7 +216,7 @@ const char* hh_last_error(const hh_ctx* ctx); /* NUL-terminated, owned by ctx (o
  * kernels with thousands of records (the exact law at 10^6 - 10^7 trajectories: 1-4 % faster that way).  The
  * same additions in the same order every way: bit-identical results. */
 enum hh_option { HH_OPT_LSM_FORM = 1, HH_OPT_BK_TERM_CACHE = 2, HH_OPT_GRID_FORM = 3, HH_OPT_LSM_SPIN_TICKS = 4,
-                 HH_OPT_FUSE_REDUCE = 5 };
+                 HH_OPT_FUSE_REDUCE = 5, HH_OPT_GRID_ORDER = 6 };
 enum hh_grid_form { HH_GRID_FORM_PER_DATE = 0, HH_GRID_FORM_BATCHED = 1 };
 enum hh_lsm_form { HH_LSM_FORM_PER_DATE = 0, HH_LSM_FORM_PERSISTENT = 1, HH_LSM_FORM_AUTO = 2 };
 int hh_ctx_set_option(hh_ctx* ctx, int32_t option, int64_t value);

@@ -15,7 +15,8 @@ from scipy import stats
 from hedgehog_jl_amd import _ffi
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
-H = dict(S0=100.0, V0=0.04, kappa=2.0, theta=0.04, sigma=0.3, rho=-0.7, r=0.03, T=1.0, strike=100.0, cp=1.0)
+T = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0  # 1/12: a date of the 12-date exact grid (short maturity: long series)
+H = dict(S0=100.0, V0=0.04, kappa=2.0, theta=0.04, sigma=0.3, rho=-0.7, r=0.03, T=T, strike=100.0, cp=1.0)
 s2 = H["sigma"] ** 2
 em = -math.expm1(-H["kappa"] * H["T"])
 d = 4 * H["kappa"] * H["theta"] / s2

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Exact Heston grid (hh_heston_exact_grid): dates batched into one kernel chain vs one chain per date
-(HH_OPT_GRID_FORM), kernel time by HIP events.  GPU box only."""
+(HH_OPT_GRID_FORM), and the batched chain with its pairs sorted by the size of their Bessel argument (HH_OPT_GRID_ORDER);
+kernel time by HIP events.  GPU box only."""
 import ctypes as C
 import os
 import sys
@@ -16,9 +17,11 @@ H252 = dict(S0=100.0, V0=0.04, kappa=2.0, theta=0.04, sigma=0.3, rho=-0.7, r=0.0
 for n, steps in ((20_000, 12), (200_000, 12), (200_000, 50), (1_000_000, 12), (50_000, 252)):
     seeds = torch.arange(1, n + 1, dtype=torch.int64, device="cuda:0")
     line = f"n={n:8d} x {steps:3d} dates:"
-    for form, name in ((_ffi.HH_GRID_FORM_PER_DATE, "chain per date"), (_ffi.HH_GRID_FORM_BATCHED, "dates batched")):
+    for form, order, name in ((_ffi.HH_GRID_FORM_PER_DATE, 0, "chain per date"), (_ffi.HH_GRID_FORM_BATCHED, 0, "dates batched"),
+                              (_ffi.HH_GRID_FORM_BATCHED, 1, "batched, pairs sorted by V0*VT")):
         ctx = hh.Context(0)
         ctx.check(ctx.lib.hh_ctx_set_option(ctx.handle, _ffi.HH_OPT_GRID_FORM, form))
+        ctx.check(ctx.lib.hh_ctx_set_option(ctx.handle, _ffi.HH_OPT_GRID_ORDER, order))
         m = _ffi.make_model(**H252, strike=100.0)
         c = _ffi.make_config(_ffi.HH_HESTON, _ffi.HH_BROADIE_KAYA, n, steps)
         c.seeds, c.seeds_on_device, c.seeds_len = seeds.data_ptr(), 1, n
