@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Merges the SQ_INSTS_VALU counts of a `rocprofv3 --pmc SQ_INSTS_VALU -- python3 tools/pmc_round5.py` pass into
-profiles/valu_insts.json (the rows bench.py's VALU rooflines read).  usage: valu_insts_r5.py <counter csv> <tag>"""
+profiles/valu_insts.json (the rows bench.py's VALU rooflines read).
+usage: valu_insts_r5.py <counter csv of tools/pmc_round5.py> <tag> [<counter csv of tools/bk_only.py grid>]"""
 import collections
 import csv
 import json
@@ -34,6 +35,14 @@ rows = {
     "lognormal_exact_1e8": (mean_of(lambda n: "exact_gbm_kernel<0, false, false, 64>" in n) / (100 * N), "path (64 pairs per lane: 10^8 paths)"),
     "broadie_kaya": (mean_of(lambda n: "::bk_" in n) / N, "path (draw + cf (series, inversion) + scan + ladder + fall-back kernels)"),
 }
+if len(sys.argv) > 3:  # the exact grid 2·10^5 x 12: EVERY kernel of the chain — draws, key / sort / gather / scatter, CF, scan, ladder, spots
+    g = collections.defaultdict(list)
+    for r in csv.DictReader(open(sys.argv[3])):
+        if r["Counter_Name"] == "SQ_INSTS_VALU" and "fill_rows" not in r["Kernel_Name"]:
+            g[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    total = sum(sum(v) / len(v) for v in g.values())
+    rows["heston_exact_grid"] = (total / (200_000 * 12),
+                                 "transition (variance rows + sort by V0·V_T + the chain over all (date, trajectory) pairs + spot rows)")
 dst = os.path.join(ROOT, "profiles", "valu_insts.json")
 out = json.load(open(dst))
 for key, (v, unit) in rows.items():
