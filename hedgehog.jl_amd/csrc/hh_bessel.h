@@ -34,11 +34,19 @@ struct cx {
   double re, im;
 };
 HH_MATH_FN cx operator+(cx a, cx b) { return {a.re + b.re, a.im + b.im}; }
-HH_MATH_FN cx operator*(cx a, cx b) { return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
+// (the library is built with -ffp-contract=off — the Euler kernels reproduce the reference's arithmetic bit for
+// bit — so the contraction is written out here: a complex product is 2 multiplies + 2 fma, not 4 + 2; some forty of the
+// instructions of one characteristic-function evaluation)
+HH_MATH_FN cx operator*(cx a, cx b) { return {fma(a.re, b.re, -(a.im * b.im)), fma(a.re, b.im, a.im * b.re)}; }
 HH_MATH_FN cx operator*(double s, cx a) { return {s * a.re, s * a.im}; }
 HH_MATH_FN cx cdiv(cx a, cx b) {
   const double inv = fm::rcp(fma(b.re, b.re, b.im * b.im));
   return {(a.re * b.re + a.im * b.im) * inv, (a.im * b.re - a.re * b.im) * inv};
+}
+// 1/b (cdiv({1, 0}, b) without the products by the constant 1 and 0 the compiler may not drop)
+HH_MATH_FN cx crcp(cx b) {
+  const double inv = fm::rcp(fma(b.re, b.re, b.im * b.im));
+  return {b.re * inv, -(b.im * inv)};
 }
 // |a| without hypot's range scaling (31 instructions): the moduli taken here (γ, ν_γ, ϕ, series
 // sums) are far from the overflow / underflow thresholds of a² + b²
@@ -234,7 +242,7 @@ HH_MATH_FN LogMul besseli_series(const BesselTable& t, cx z, double r, double ph
 // The sums are cut after k = 2M+1 where the next term is below 2^-55 — or, for r < 15.5 where the
 // expansion does not get that far, at its smallest term k ≈ 2r.
 HH_MATH_FN LogMul besseli_asym(const BesselTable& t, cx z, double r, double phi) {
-  const cx w = cdiv({1.0, 0.0}, z);
+  const cx w = crcp(z);
   const cx u = w * w;
   int M = (int)(r - 0.5);
   M = M < kHankelPairs - 1 ? M : kHankelPairs - 1;
@@ -277,19 +285,20 @@ HH_MATH_FN LogMul besseli_logmul(const BesselTable& t, const BesselTable& t0, in
   }
   const double r = cabs(z);
   LogMul res;
-  if (r < kSeriesR) {
+  // (one inlined copy of the series for its two regions — below R_s, and between R_s and R_t where it does not
+  // cancel and the Hankel sum has not converged yet)
+  const bool hankel = n_int == 0 || r >= t.hankel_from;
+  if (r < kSeriesR || (!hankel && r < t.series_rmax && (r - z.re <= 14.0 || z.im * z.im <= t.series_im2))) {
     res = besseli_series(t, z, r, phi);
-  } else if (n_int == 0 || r >= t.hankel_from) {
+  } else if (hankel) {
     res = besseli_asym(t, z, r, phi);
-  } else if (r < t.series_rmax && (r - z.re <= 14.0 || z.im * z.im <= t.series_im2)) {
-    res = besseli_series(t, z, r, phi);
   } else {
     // base order ν0, then I_ν = I_ν0 · Π_{k<n} I_{ν0+k+1}/I_{ν0+k}; the ratios come from the backward
     // recurrence r_k = 1 / (2(ν0+k+1)/z + r_{k+1}), the minimal solution for Re z >= 0.  |r_k| < 1: the
     // product is taken 32 ratios at a time and folded into the logarithm (a product of 32 cannot leave
     // the fp64 range; one complex log per ratio was 115 instructions each).
     res = besseli_asym(t0, z, r, phi);
-    const cx w = cdiv({2.0, 0.0}, z);
+    const cx w = 2.0 * crcp(z);
     const int n = n_int;
     int N = n + (int)r + 30;
     if (N > 4000) N = 4000;
@@ -297,7 +306,7 @@ HH_MATH_FN LogMul besseli_logmul(const BesselTable& t, const BesselTable& t0, in
     int in_prod = 0;
     for (int k = N - 1; k >= 0; --k) {
       const double o = t0.nu + (double)k + 1.0;
-      rk = cdiv({1.0, 0.0}, {o * w.re + rk.re, o * w.im + rk.im});
+      rk = crcp({fma(o, w.re, rk.re), fma(o, w.im, rk.im)});
       if (k < n) {
         prod = prod * rk;
         if (++in_prod == 32) {

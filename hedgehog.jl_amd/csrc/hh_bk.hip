@@ -46,7 +46,7 @@ namespace hh {
 namespace {
 
 constexpr double kPi = kBesselPi;
-constexpr double kTwoPi = kBesselTwoPi;
+constexpr double kTwoPi = kBesselTwoPi, kInvTwoPi = 0.15915494309189533577;
 
 #ifndef HH_BK_SLOTS
 #define HH_BK_SLOTS 1024
@@ -164,7 +164,7 @@ __device__ __forceinline__ cx evaluate_chf(const BkArgs& p, const BesselTable* b
   const cx ope = {1.0 + e.re, e.im};
   // ζ_γ = (1−e)/γ, η_γ = γ(1+e)/(1−e), ν_γ = 4√(V0 VT) γ e^{−γT/2} / (σ²(1−e))  (heston.jl:188-196):
   // all three divide by 1−e, and ζ_γ only enters as ζ_κ/ζ_γ = ζ_κ γ/(1−e) — one complex reciprocal
-  const cx g_over_ome = g * cdiv({1.0, 0.0}, ome);
+  const cx g_over_ome = g * crcp(ome);
   const cx eta_g = g_over_ome * ope;
   const cx nu_g = (it.sqrtV0VT * 4.0 * p.inv_sigma2) * (g_over_ome * eh);
   // continuous unwrapping of arg(ν_γ) (heston.jl:198-205)
@@ -173,8 +173,10 @@ __device__ __forceinline__ cx evaluate_chf(const BkArgs& p, const BesselTable* b
   if (isnan(theta_prev)) {
     thu = th;
   } else {
+    // (the quotient by a multiply: an IEEE division is 13 instructions here; the two can only round to different
+    // integers when the step is π to the last bit, where either branch continues the angle equally well)
     double dl = th - theta_prev;
-    dl -= kTwoPi * rint(dl / kTwoPi);
+    dl -= kTwoPi * rint(dl * kInvTwoPi);
     thu = theta_prev + dl;
   }
   theta_prev = thu;
