@@ -47,6 +47,7 @@ namespace {
 
 constexpr double kPi = kBesselPi;
 constexpr double kTwoPi = kBesselTwoPi, kInvTwoPi = 0.15915494309189533577;
+constexpr double kInvPi = 0.31830988618379067154, kTwoOverPi = 0.63661977236758134308;
 
 #ifndef HH_BK_SLOTS
 #define HH_BK_SLOTS 1024
@@ -67,9 +68,21 @@ constexpr int kHeavyGrid = HH_BK_HEAVY_GRID;   // workgroups of the fall-back ke
                                   // with the reference's controls, and the whole job when no series fits the term cache)
 static_assert(kHeavyGrid <= kSlots, "the fall-back kernel's workgroup b uses slot b");
 
-struct BkTables {
+// The weight of term j of the CDF series (sample_from_cf.jl:86: (2/π)·sin(h j x)·Re ϕ(h j)/j) is (2/π)/j — an
+// IEEE quotient, so the compile-time constants of the unrolled evaluation, this table (filled on the device by
+// bk_tables_kernel, read with the loop's uniform j: scalar loads) and a division in the kernel (beyond the
+// table) are the same numbers.
+constexpr int kCoefTerms = 1024;  // = the largest term cache (phi_cache_cap)
+struct BkBessel {
   BesselTable t[2];  // order ν, base order ν0
 };
+struct BkTables {
+  BesselTable t[2];
+  double coef[kCoefTerms + 1];  // [j] = (2/π)/j, j >= 1
+};
+__device__ __forceinline__ double cdf_weight(const double* coef, int j) {
+  return j <= kCoefTerms ? coef[uniform_index(j)] : kTwoOverPi / (double)j;
+}
 
 struct BkArgs {
   // model
@@ -205,11 +218,11 @@ struct PhiCache {
 };
 
 // cdf_from_cf (sample_from_cf.jl:75-96)
-__device__ double cdf_from_cf(const BkArgs& p, const BesselTable* bt, const CfIter& it, double x, double h, PhiCache& c,
-                              double& n_terms) {
+__device__ double cdf_from_cf(const BkArgs& p, const BesselTable* bt, const double* coef, const CfIter& it, double x, double h,
+                              PhiCache& c, double& n_terms) {
   if (x < 0.0) return 0.0;
-  double result = h * x / kPi;
-  const double pref = 2.0 / kPi, stop = kPi * p.cf_tol / 2.0;
+  double result = (h * x) * kInvPi;
+  const double stop = kPi * p.cf_tol / 2.0;
   double theta_tail = c.theta_cap;  // for terms beyond the cached ones
   // sin(h j x), j = 1, 2, …, by rotation (4 flops per term; error grows like j·eps) instead of one
   // sin() call per term
@@ -241,7 +254,7 @@ __device__ double cdf_from_cf(const BkArgs& p, const BesselTable* bt, const CfIt
         if (last) c.j_stop = j;
       }
     }
-    result += pref * sj * rcp_nr((double)j) * re;
+    result = fma(sj, cdf_weight(coef, j) * re, result);
     n_terms += 1.0;
     if (last) break;
     const double sn = fma(sj, c1, cj * s1);
@@ -623,38 +636,37 @@ __device__ __forceinline__ void series_phase(const BkArgs& p, const BesselTable*
 
 // The first kRegTerms series terms of a trajectory, held in registers for all the CDF evaluations of
 // its root search (H252: 10-13 terms, ~5 evaluations by the secant, ~13 by the ladder): the cache
-// column is read once instead of once per evaluation.
+// column is read once instead of once per evaluation — and each term already times its weight (2/π)/j
+// (cdf_weight), zero beyond the series' end: an evaluation is then one rotation step and ONE fma per term, no
+// test (adding sin·0 changes nothing).  Was 14 instructions per term: three products, the sum, the test and its
+// selects, the term counter and its selects.
 constexpr int kRegTerms = 16;
 __device__ __forceinline__ void load_terms(const double* col, size_t stride, int j_stop,
                                            double (&t)[kRegTerms]) {
 #pragma unroll
-  for (int j = 0; j < kRegTerms; ++j) t[j] = j < j_stop ? col[(size_t)j * stride] : 0.0;
+  for (int j = 0; j < kRegTerms; ++j) t[j] = j < j_stop ? (kTwoOverPi / (double)(j + 1)) * col[(size_t)j * stride] : 0.0;
 }
 
 // cdf_from_cf (sample_from_cf.jl:75-96) on the cached terms: same values, same summation order as
 // cdf_from_cf() above, one rotation step per term; terms beyond the registers come from the column
-__device__ __forceinline__ double cdf_cached(const double (&t)[kRegTerms], const double* col,
+__device__ __forceinline__ double cdf_cached(const double (&t)[kRegTerms], const double* col, const double* coef,
                                              size_t stride, int j_stop, double h, double x,
                                              double& n_terms) {
   if (x < 0.0) return 0.0;
-  double result = h * x / kPi;
-  const double pref = 2.0 / kPi;
+  double result = (h * x) * kInvPi;
   double s1, c1;
   sincos_cf(h * x, s1, c1);
   double sj = s1, cj = c1;
+  n_terms += (double)j_stop;
 #pragma unroll
   for (int j = 1; j <= kRegTerms; ++j) {
-    if (j <= j_stop) {
-      result += pref * sj * rcp_nr((double)j) * t[j - 1];
-      n_terms += 1.0;
-    }
+    result = fma(sj, t[j - 1], result);
     const double sn = fma(sj, c1, cj * s1);
     cj = fma(cj, c1, -(sj * s1));
     sj = sn;
   }
   for (int j = kRegTerms + 1; j <= j_stop; ++j) {
-    result += pref * sj * rcp_nr((double)j) * col[(size_t)(j - 1) * stride];
-    n_terms += 1.0;
+    result = fma(sj, cdf_weight(coef, j) * col[(size_t)(j - 1) * stride], result);
     if (j == j_stop) break;
     const double sn = fma(sj, c1, cj * s1);
     cj = fma(cj, c1, -(sj * s1));
@@ -670,7 +682,7 @@ __device__ __forceinline__ double cdf_cached(const double (&t)[kRegTerms], const
 // It is flagged in a per-wave ballot instead and finished, densely packed, by bk_ladder_kernel;
 // so is a trajectory whose series did not fit the cache (bk_fallback_kernel).  Flags are ballots in
 // trajectory order, so the result is bit-reproducible.  Called by every thread of the workgroup.
-__device__ __forceinline__ void invert_phase(const BkArgs& p, uint32_t tile, uint32_t tid, uint64_t path,
+__device__ __forceinline__ void invert_phase(const BkArgs& p, const double* coef, uint32_t tile, uint32_t tid, uint64_t path,
                                              bool live, const double* col, double h, double guess,
                                              double max_guess, int j_stop) {
   double acc[6] = {0, 0, 0, 0, 0, 0};  // Σp, Σp², newton_fail, bisect, maxguess, cf_terms
@@ -687,7 +699,7 @@ __device__ __forceinline__ void invert_phase(const BkArgs& p, uint32_t tile, uin
       double n_terms = 0.0, IV;
       uint32_t evals = 0;
       const bool ok = secant_inverse(
-          [&](double x) { return cdf_cached(t, col, p.cache_stride, j_stop, h, x, n_terms); }, u, guess,
+          [&](double x) { return cdf_cached(t, col, coef, p.cache_stride, j_stop, h, x, n_terms); }, u, guess,
           p.atol, p.newton_maxiter, IV, evals);
       p.diag[path] = evals;
       acc[5] = n_terms;
@@ -814,7 +826,7 @@ __global__ __launch_bounds__(kTile) void bk_cf_kernel(const BkArgs p, const BkTa
   double h = 0.0, guess = 0.0, max_guess = 0.0;
   int j_stop = 0;
   if (live) series_phase(p, bt, path, col, p.cache_stride, h, guess, max_guess, j_stop);
-  invert_phase(p, tile, tid, path, live, col, h, guess, max_guess, j_stop);
+  invert_phase(p, tabs->coef, tile, tid, path, live, col, h, guess, max_guess, j_stop);
   give_slot(p, slot);
 }
 
@@ -947,7 +959,7 @@ __global__ __launch_bounds__(kTile) void bk_ladder_kernel(const BkArgs p, const 
     double t[kRegTerms];
     load_terms(terms, tstride, j_stop, t);
     double n_terms = 0.0, IV;
-    auto cdf = [&](double x) { return cdf_cached(t, terms, tstride, j_stop, h, x, n_terms); };
+    auto cdf = [&](double x) { return cdf_cached(t, terms, tabs->coef, tstride, j_stop, h, x, n_terms); };
     double fa = cdf(0.0) - u;
     const double fb = cdf(max_guess) - u;
     uint32_t dec = p.diag[path];
@@ -1027,7 +1039,7 @@ __global__ __launch_bounds__(kTile) void bk_fallback_kernel(
     int stage = kSecantFirst;
     double x = xa;
     for (;;) {
-      const double f = cdf_from_cf(p, bt, s.cf, x, s.h, s.cache, n_terms) - s.u;
+      const double f = cdf_from_cf(p, bt, tabs->coef, s.cf, x, s.h, s.cache, n_terms) - s.u;
       if (stage == kSecantFirst) {
         fa = f;
         x = xb;
@@ -1104,12 +1116,14 @@ __global__ __launch_bounds__(kTile) void bk_fallback_kernel(
 
 // The host-made tables into device memory: ONE lane, constant indices (a lane-indexed read of the
 // by-value argument would again send the block through scratch), the compiler batches the scalar loads.
-__global__ __launch_bounds__(64) void bk_tables_kernel(const BkTables t, BkTables* __restrict__ dst) {
+__global__ __launch_bounds__(64) void bk_tables_kernel(const BkBessel t, BkTables* __restrict__ dst) {
+  for (int j = (int)threadIdx.x; j <= kCoefTerms; j += 64) dst->coef[j] = kTwoOverPi / (double)j;  // ([0] is not read)
   if (threadIdx.x != 0) return;
   const double* src = reinterpret_cast<const double*>(&t);
-  double* out = reinterpret_cast<double*>(dst);
+  double* out = reinterpret_cast<double*>(dst->t);
+  static_assert(sizeof(BkBessel) == sizeof(dst->t), "the Bessel tables of BkTables");
 #pragma unroll
-  for (size_t i = 0; i < sizeof(BkTables) / sizeof(double); ++i) out[i] = src[i];
+  for (size_t i = 0; i < sizeof(BkBessel) / sizeof(double); ++i) out[i] = src[i];
 }
 
 __global__ __launch_bounds__(256) void fill_rows_kernel(double* __restrict__ spot0,
@@ -1292,7 +1306,7 @@ int bk_tables(const BkArgs& a, const BkLayout& L, const DevicePtrs& ptr, hipStre
   if (ptr.bk_table_key)
     upload_tables = !(ptr.bk_table_key->where == L.tabs_dev && ptr.bk_table_key->nu == a.nu);
   if (upload_tables) {
-    BkTables tabs;
+    BkBessel tabs;
     if (!bessel_table(a.nu, tabs.t[0]) || !bessel_table(a.nu - a.n_int, tabs.t[1]))
       return (int)hipErrorInvalidValue;  // the series table of hh_bessel.h does not reach |z| = 13: not for ν > -1
     hipLaunchKernelGGL(bk_tables_kernel, dim3(1), dim3(64), 0, s, tabs, L.tabs_dev);
