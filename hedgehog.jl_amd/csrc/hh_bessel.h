@@ -205,35 +205,48 @@ HH_MATH_FN void horner2(cx& X, cx& Y, cx u, double cx_, double cy_) {
 //   I = (z/2)^ν / Γ(ν+1) · Σ_k T_k,  T_k = q^k / (k! (ν+1)_k) = T_{k-1} c_k q,  q = z²/4.
 // Even and odd terms apart, Q = q²:  Σ T_2m = 1 + d_1 Q (1 + d_2 Q (1 + …)),  d_m = c_{2m-1} c_{2m};
 //                                    Σ T_2m+1 = c_1 q (1 + e_1 Q (1 + e_2 Q (1 + …))),  e_m = c_{2m} c_{2m+1}
-HH_MATH_FN LogMul besseli_series(const BesselTable& t, cx z, double r, double phi) {
+// (r only sets the series' length — sqrt_rough is enough; the logarithm is taken of r2 = |z|² = r² itself:
+// ν log(r/2) = (ν/2) log(r²/4), one rounding of r² instead of the two of a square root)
+HH_MATH_FN LogMul besseli_series(const BesselTable& t, cx z, double r, double r2, double phi) {
   const cx q = 0.25 * (z * z);
   const cx Q = q * q;
   const int Mh = (series_terms(t, r) + 1) >> 1;  // steps of each half
   cx A = {1.0, 0.0}, B = {1.0, 0.0};
-  int m = uniform_index((wave_max6(Mh) + 1) & ~1);  // even: steps (m, m-1) down to (2, 1)
+  int m = uniform_index(wave_max6(Mh));
   const double* tab = t.series_de;
-  double d0 = tab[2 * m], e0 = tab[2 * m + 1], d1 = tab[2 * m - 2], e1 = tab[2 * m - 1];
-  while (true) {
-    const double dm = d0, em = e0, dn = d1, en = e1;
-    const int mn = uniform_index(m - 2);
-    if (mn >= 2) {  // the next two steps' coefficients, one iteration ahead of their use
-      d0 = tab[2 * mn]; e0 = tab[2 * mn + 1]; d1 = tab[2 * mn - 2]; e1 = tab[2 * mn - 1];
-    }
-    if (m <= Mh) {  // X = 1 + c Q X
+  if (m & 1) {  // (uniform) an odd count: its first step alone, then pairs — not a pair with one step nobody needs
+    const double dm = tab[2 * m], em = tab[2 * m + 1];
+    if (m <= Mh) {
       const cx qa = Q * A, qb = Q * B;
       A = {fma(dm, qa.re, 1.0), dm * qa.im};
       B = {fma(em, qb.re, 1.0), em * qb.im};
     }
-    if (m - 1 <= Mh) {
-      const cx qa = Q * A, qb = Q * B;
-      A = {fma(dn, qa.re, 1.0), dn * qa.im};
-      B = {fma(en, qb.re, 1.0), en * qb.im};
+    m -= 1;
+  }
+  if (m >= 2) {  // (uniform) even: steps (m, m-1) down to (2, 1)
+    double d0 = tab[2 * m], e0 = tab[2 * m + 1], d1 = tab[2 * m - 2], e1 = tab[2 * m - 1];
+    while (true) {
+      const double dm = d0, em = e0, dn = d1, en = e1;
+      const int mn = uniform_index(m - 2);
+      if (mn >= 2) {  // the next two steps' coefficients, one iteration ahead of their use
+        d0 = tab[2 * mn]; e0 = tab[2 * mn + 1]; d1 = tab[2 * mn - 2]; e1 = tab[2 * mn - 1];
+      }
+      if (m <= Mh) {  // X = 1 + c Q X
+        const cx qa = Q * A, qb = Q * B;
+        A = {fma(dm, qa.re, 1.0), dm * qa.im};
+        B = {fma(em, qb.re, 1.0), em * qb.im};
+      }
+      if (m - 1 <= Mh) {
+        const cx qa = Q * A, qb = Q * B;
+        A = {fma(dn, qa.re, 1.0), dn * qa.im};
+        B = {fma(en, qb.re, 1.0), en * qb.im};
+      }
+      if (mn < 2) break;
+      m = mn;
     }
-    if (mn < 2) break;
-    m = mn;
   }
   const cx S = A + t.series_c1 * (q * B);
-  return {{t.nu * fm::log(0.5 * r) - t.lgam, t.nu * phi}, S};
+  return {{(0.5 * t.nu) * fm::log(0.25 * r2) - t.lgam, t.nu * phi}, S};
 }
 
 // I_ν(z) by the Hankel expansion (DLMF 10.40.5), Re z >= 0, |z| = r >= t.hankel_from:
@@ -283,21 +296,24 @@ HH_MATH_FN LogMul besseli_logmul(const BesselTable& t, const BesselTable& t0, in
     phi -= pi_s;
     z = {-z.re, -z.im};
   }
-  const double r = cabs(z);
+  // |z|: to 2^-23 (one v_sqrt_f64) for the choice of the regime and the series' length; the Hankel expansion, which
+  // takes log r and the cut of its sums from it, gets the correctly rounded root
+  const double r2 = fma(z.re, z.re, z.im * z.im);
+  const double r = fm::sqrt_rough(r2);
   LogMul res;
   // (one inlined copy of the series for its two regions — below R_s, and between R_s and R_t where it does not
   // cancel and the Hankel sum has not converged yet)
   const bool hankel = n_int == 0 || r >= t.hankel_from;
   if (r < kSeriesR || (!hankel && r < t.series_rmax && (r - z.re <= 14.0 || z.im * z.im <= t.series_im2))) {
-    res = besseli_series(t, z, r, phi);
+    res = besseli_series(t, z, r, r2, phi);
   } else if (hankel) {
-    res = besseli_asym(t, z, r, phi);
+    res = besseli_asym(t, z, fm::sqrt_lean(r2), phi);
   } else {
     // base order ν0, then I_ν = I_ν0 · Π_{k<n} I_{ν0+k+1}/I_{ν0+k}; the ratios come from the backward
     // recurrence r_k = 1 / (2(ν0+k+1)/z + r_{k+1}), the minimal solution for Re z >= 0.  |r_k| < 1: the
     // product is taken 32 ratios at a time and folded into the logarithm (a product of 32 cannot leave
     // the fp64 range; one complex log per ratio was 115 instructions each).
-    res = besseli_asym(t0, z, r, phi);
+    res = besseli_asym(t0, z, fm::sqrt_lean(r2), phi);
     const cx w = 2.0 * crcp(z);
     const int n = n_int;
     int N = n + (int)r + 30;

@@ -154,12 +154,13 @@ __device__ __forceinline__ double rcp_nr(double x) { return fm::rcp(x); }
 __device__ __forceinline__ cx csqrt(cx z) {
   const double r = cabs(z);
   if (r == 0.0) return {0.0, 0.0};
+  double h;
   if (z.re >= 0.0) {
-    const double t = fm::sqrt_lean(0.5 * (r + z.re));
-    return {t, z.im * rcp_nr(2.0 * t)};
+    const double t = fm::sqrt_lean(0.5 * (r + z.re), &h);
+    return {t, fm::div_by_2sqrt(z.im, t, h)};
   }
-  const double t = fm::sqrt_lean(0.5 * (r - z.re));
-  return {fabs(z.im) * rcp_nr(2.0 * t), copysign(t, z.im)};
+  const double t = fm::sqrt_lean(0.5 * (r - z.re), &h);
+  return {fm::div_by_2sqrt(fabs(z.im), t, h), copysign(t, z.im)};
 }
 
 // per-trajectory CF state: HestonCFIterator (heston.jl:150-157)

@@ -46,15 +46,35 @@ HH_MATH_FN double rcp(double x) {
 // gives NaN (rsq = 0, 0·inf), where sqrt gives inf — the Broadie–Kaya stopping test leaves on NaN as it leaves on
 // inf; w = NaN gives NaN; w = -0.0 gives NaN (sqrt: -0.0; a sum of squares is never -0.0); w < 0 gives -inf or NaN
 // (the seed NaN is replaced by the cap), never a finite positive number.  Pinned on the device by tests/test_gpu_math_device.py.
-HH_MATH_FN double sqrt_lean(double w) {
+HH_MATH_FN double sqrt_lean(double w, double* half_rsqrt = nullptr) {
 #if defined(__HIP_DEVICE_COMPILE__)
   const double y = __builtin_fmin(__builtin_amdgcn_rsq(w), 0x1p1000);
   double g = w * y, h = 0.5 * y;
   const double r = fma(-h, g, 0.5);
   g = fma(g, r, g);
   h = fma(h, r, h);
+  if (half_rsqrt) *half_rsqrt = h;  // ≈ 1/(2 sqrt(w)) after the coupled step (relative error ~2^-45): see div_by_2sqrt
   g = fma(fma(-g, g, w), h, g);
   return fma(fma(-g, g, w), h, g);
+#else
+  if (half_rsqrt) *half_rsqrt = 0.5 / sqrt(w);
+  return sqrt(w);
+#endif
+}
+
+// a / (2t) for t = sqrt_lean(w, &h): the quotient from the square root's own h ≈ 1/(2t) and one residual
+// correction (4 instructions, <= 1 ulp: the correction term is ~2^-45 of the quotient and carries h's 2^-45) —
+// instead of a reciprocal of 2t (v_rcp_f64 + two Newton steps + two products: 8)
+HH_MATH_FN double div_by_2sqrt(double a, double t, double h) {
+  const double v = a * h;
+  return fma(fma(-(t + t), v, a), h, v);
+}
+
+// sqrt(w) to ~2^-23 relative, ONE instruction (v_sqrt_f64): for quantities that only choose a regime or a loop
+// length
+HH_MATH_FN double sqrt_rough(double w) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_sqrt(w);
 #else
   return sqrt(w);
 #endif
