@@ -506,9 +506,10 @@ int hh_mc_accumulate(hh_ctx* ctx, const hh_model* m, const hh_config* c, double*
   rc = run_simulation(ctx, m, c, terminal, false, nullptr, accum_dev, &reduced);
   if (rc) return rc;
   if (!reduced) {
-    const uint32_t n_rec = c->strategy == HH_BROADIE_KAYA ? hh::bk_record_count(c->n_paths) : hh::sim_records(*c);
-    HH_HIP(ctx, hh::launch_reduce_records(ctx->records, n_rec, (double)c->n_paths, accum_dev,
-                                          ctx->stream, 1, m, c));
+    const bool bk = c->strategy == HH_BROADIE_KAYA;
+    const uint32_t n_rec = bk ? hh::bk_record_count(c->n_paths) : hh::sim_records(*c);
+    HH_HIP(ctx, hh::launch_reduce_records(ctx->records, n_rec, (double)c->n_paths, accum_dev, ctx->stream, 1, m, c, false,
+                                          bk ? hh::bk_live_records(ctx->bk_scratch, c->n_paths) : nullptr));
   }
   if ((rc = end_timing(ctx))) return rc;
   if ((rc = release_host_operands(ctx))) return rc;
@@ -655,8 +656,8 @@ int hh_mc_accumulate_basket(hh_ctx* ctx, const hh_model* m, const hh_config* c,
   HH_HIP(ctx, hh::launch_reduce_records(ctx->basket_records, b.n_chunks, (double)c->n_paths,
                                         accum_dev, ctx->stream, n_payoffs, m, c, true));
   if (c->strategy == HH_BROADIE_KAYA) {  // the simulation's fall-back / series counters, for every payoff
-    HH_HIP(ctx, hh::launch_reduce_records(ctx->records, hh::bk_record_count(c->n_paths),
-                                          (double)c->n_paths, ctx->accum, ctx->stream, 1, m, c));
+    HH_HIP(ctx, hh::launch_reduce_records(ctx->records, hh::bk_record_count(c->n_paths), (double)c->n_paths, ctx->accum,
+                                          ctx->stream, 1, m, c, false, hh::bk_live_records(ctx->bk_scratch, c->n_paths)));
     HH_HIP(ctx, hh::launch_copy_bk_counters(ctx->accum, accum_dev, n_payoffs, ctx->stream));
   }
   if ((rc = end_timing(ctx))) return rc;
@@ -1057,7 +1058,7 @@ static int run_heston_grid(hh_ctx* ctx, const hh_model* m, const hh_config* c) {
       // the counters of the batch's pairs, kept in the slot of its first date
       HH_HIP(ctx, hh::launch_reduce_records(ctx->records, hh::bk_record_count(n * nd), (double)(n * nd),
                                             ctx->basket_accum + (size_t)k * HH_ACC_LEN, ctx->stream, 1,
-                                            &step_model, &step_cfg));
+                                            &step_model, &step_cfg, false, hh::bk_live_records(ctx->bk_scratch, n * nd)));
     }
     return HH_OK;
   }
@@ -1068,7 +1069,7 @@ static int run_heston_grid(hh_ctx* ctx, const hh_model* m, const hh_config* c) {
     HH_HIP(ctx, hh::launch_bk(step_model, step_cfg, p, ctx->stream, &tr, /*upload_tables=*/k == 0));
     HH_HIP(ctx, hh::launch_reduce_records(ctx->records, hh::bk_record_count(n), (double)n,
                                           ctx->basket_accum + (size_t)k * HH_ACC_LEN, ctx->stream,
-                                          1, &step_model, &step_cfg));
+                                          1, &step_model, &step_cfg, false, hh::bk_live_records(ctx->bk_scratch, n)));
   }
   return HH_OK;
 }

@@ -50,7 +50,7 @@ constexpr double kTwoPi = kBesselTwoPi, kInvTwoPi = 0.15915494309189533577;
 constexpr double kInvPi = 0.31830988618379067154, kTwoOverPi = 0.63661977236758134308;
 
 #ifndef HH_BK_SLOTS
-#define HH_BK_SLOTS 1024
+#define HH_BK_SLOTS 1536
 #endif
 #ifndef HH_BK_HEAVY_GRID
 #define HH_BK_HEAVY_GRID 64
@@ -58,8 +58,10 @@ constexpr double kInvPi = 0.31830988618379067154, kTwoOverPi = 0.636619772367581
 // Columns of cached series terms.  A lane's column belongs to a workgroup SLOT that a workgroup of the
 // CF kernel (or of the ladder kernel behind it) takes when it starts and gives back when it is done —
 // not to the trajectory: the cache is kSlots x 256 columns however many trajectories the chain has
-// (1024 slots = the 4 workgroups per CU that can be resident; 256 terms of 8 bytes: 0.54 GB for 10^4 and
-// for 10^8 trajectories alike).  A trajectory's terms are only needed again if its secant fails (2 % of
+// (1536 slots: the CF kernel takes 95 registers since its real-axis evaluations, so FIVE of its workgroups are
+// resident per CU, 1280 in all — with 1024 slots the fifth spun for a slot and the kernel ran 3 % slower than at a
+// forced four; with a slot for it, 5 % faster (profiles/r05_h_bk_ab.txt).  A bitmap word is 64 slots, hence 192
+// per XCD.  256 terms of 8 bytes: 0.81 GB for 10^4 and for 10^8 trajectories alike).  A trajectory's terms are only needed again if its secant fails (2 % of
 // them): the ladder kernel re-derives those.
 constexpr int kSlots = HH_BK_SLOTS;
 constexpr int kSideTerms = 64, kSideEntry = kSideTerms + 2;  // doubles per side-store entry: h, max_guess, terms
@@ -73,11 +75,20 @@ static_assert(kHeavyGrid <= kSlots, "the fall-back kernel's workgroup b uses slo
 // bk_tables_kernel, read with the loop's uniform j: scalar loads) and a division in the kernel (beyond the
 // table) are the same numbers.
 constexpr int kCoefTerms = 1024;  // = the largest term cache (phi_cache_cap)
+constexpr int kRegTerms = 16;     // series terms a lane holds in registers through its root search (load_terms)
 struct BkBessel {
   BesselTable t[2];  // order ν, base order ν0
 };
+// What the characteristic function at argument 0 needs of the MODEL (κ, σ², T) — the part of evaluate_chf that does
+// not depend on the trajectory, evaluated once (bk_tables_kernel) by the very code evaluate_chf runs: see chf_at_zero
+struct CfZero {
+  double x_re;    // Re(γ/(1−e)·e^{−γT/2}) at a = 0: ν_γ(0) = (4√(V0 VT)/σ²) · x_re
+  double c0, c1;  // Re of the exponent: c0 + (V0+VT)/σ² · c1 + log I_ν(ν_γ) − log I_ν(ν_κ)
+  double w_re;    // Re(ζ_κ γ/(1−e))
+};
 struct BkTables {
   BesselTable t[2];
+  CfZero zero;
   double coef[kCoefTerms + 1];  // [j] = (2/π)/j, j >= 1
 };
 __device__ __forceinline__ double cdf_weight(const double* coef, int j) {
@@ -129,7 +140,9 @@ struct BkArgs {
   double* phi_cache;               // [cache_cap][cache_stride] cached Re ϕ(h·j), one column per lane of a
   size_t cache_stride;             //   workgroup SLOT (kSlots·256 columns), not per trajectory
   int cache_cap;
-  uint32_t* slot_busy;             // slot bitmaps, one 128-byte line per XCD: 0 free / 1 taken (zeroed per launch)
+  uint32_t* slot_busy;             // slot bitmaps, one 128-byte line per XCD: 0 free / 1 taken.  Zeroed when the tables
+                                   // beside them are made; every workgroup gives its slot back, so a chain leaves
+                                   // them as it found them
   uint32_t static_slots;           // 1: the chain has at most kSlots tiles, slot = tile (no bitmap)
   uint32_t n_tiles;
   uint32_t* diag;                  // [3][draw_stride] per trajectory: decision word (BkDecision), series length,
@@ -140,7 +153,10 @@ struct BkArgs {
   // matter: a trajectory finds its own through diag[2]); a series longer than kSideTerms, or one that
   // comes when the store is full, is re-derived by the ladder kernel instead.
   double* side;                    // [side_cap][kSideEntry]
-  uint32_t* side_count;            // entries handed out (zeroed per launch, beside the slot bitmaps)
+  uint32_t* side_count;            // [0] entries handed out (zeroed with the bitmaps, then by each chain's
+                                   // bk_scan_kernel for the next one); [1] records of this chain the reduction reads
+                                   // (bk_live_records)
+  uint32_t* chunk_tile;            // [n_tiles + 1] tile that holds the first trajectory of each packed ladder chunk
   uint32_t side_cap;
   void* args_dev;                  // a copy of this struct in device memory (written by bk_scan_kernel)
                                    // for bk_fallback_kernel, whose code is too large to inline: passing
@@ -163,24 +179,46 @@ __device__ __forceinline__ cx csqrt(cx z) {
   return {fm::div_by_2sqrt(fabs(z.im), t, h), copysign(t, z.im)};
 }
 
+// csqrt() of a number that is not left of the imaginary axis (κ² − 2iσ²a): its first branch alone
+__device__ __forceinline__ cx csqrt_right(cx z) {
+  const double r = cabs(z);
+  if (r == 0.0) return {0.0, 0.0};
+  double h;
+  const double t = fm::sqrt_lean(0.5 * (r + z.re), &h);
+  return {t, fm::div_by_2sqrt(z.im, t, h)};
+}
+
 // per-trajectory CF state: HestonCFIterator (heston.jl:150-157)
 struct CfIter {
   double VT, sqrtV0VT, logI_k, sumV;  // sumV = (V0+VT)/σ²
 };
 
-// evaluate_chf (heston.jl:184-212).  theta_prev = NaN starts a new unwrapping sequence.
-__device__ __forceinline__ cx evaluate_chf(const BkArgs& p, const BesselTable* bt, const CfIter& it, double a,
-                                           double& theta_prev) {
-  const cx g = csqrt({p.kappa * p.kappa, -2.0 * p.sigma2 * a});
-  const cx eh = cexp({-0.5 * g.re * p.T, -0.5 * g.im * p.T});  // exp(-γT/2)
-  const cx e = eh * eh;                                          // exp(-γT)
+// The part of evaluate_chf that depends on the model and the argument a alone (heston.jl:186-196):
+//   γ = sqrt(κ² − 2iσ²a), e^{−γT/2}, γ/(1−e^{−γT}), η_γ, and x = γ e^{−γT/2}/(1−e^{−γT}) (ν_γ = 4√(V0 VT)/σ² · x)
+struct ChfPrefix {
+  cx g, g_over_ome, eta_g, x;
+};
+__device__ __forceinline__ ChfPrefix chf_prefix(double kappa, double sigma2, double T, double a) {
+  ChfPrefix f;
+  f.g = csqrt_right({kappa * kappa, -2.0 * sigma2 * a});
+  const cx eh = cexp({-0.5 * f.g.re * T, -0.5 * f.g.im * T});  // exp(-γT/2)
+  const cx e = eh * eh;                                        // exp(-γT)
   const cx ome = {1.0 - e.re, -e.im};
   const cx ope = {1.0 + e.re, e.im};
   // ζ_γ = (1−e)/γ, η_γ = γ(1+e)/(1−e), ν_γ = 4√(V0 VT) γ e^{−γT/2} / (σ²(1−e))  (heston.jl:188-196):
   // all three divide by 1−e, and ζ_γ only enters as ζ_κ/ζ_γ = ζ_κ γ/(1−e) — one complex reciprocal
-  const cx g_over_ome = g * crcp(ome);
-  const cx eta_g = g_over_ome * ope;
-  const cx nu_g = (it.sqrtV0VT * 4.0 * p.inv_sigma2) * (g_over_ome * eh);
+  f.g_over_ome = f.g * crcp(ome);
+  f.eta_g = f.g_over_ome * ope;
+  f.x = f.g_over_ome * eh;
+  return f;
+}
+
+// evaluate_chf (heston.jl:184-212).  theta_prev = NaN starts a new unwrapping sequence.
+__device__ __forceinline__ cx evaluate_chf(const BkArgs& p, const BesselTable* bt, const CfIter& it, double a,
+                                           double& theta_prev) {
+  const ChfPrefix f = chf_prefix(p.kappa, p.sigma2, p.T, a);
+  const cx g = f.g, g_over_ome = f.g_over_ome, eta_g = f.eta_g;
+  const cx nu_g = (it.sqrtV0VT * 4.0 * p.inv_sigma2) * f.x;
   // continuous unwrapping of arg(ν_γ) (heston.jl:198-205)
   const double th = fm::atan2(nu_g.im, nu_g.re);
   double thu;
@@ -200,6 +238,23 @@ __device__ __forceinline__ cx evaluate_chf(const BkArgs& p, const BesselTable* b
   const cx ex = {-0.5 * (g.re - p.kappa) * p.T + it.sumV * (p.eta_k - eta_g.re) + I.lg.re - it.logI_k,
                  -0.5 * g.im * p.T - it.sumV * eta_g.im + I.lg.im};
   return (cexp(ex) * I.mul) * (p.zeta_k * g_over_ome);
+}
+
+// Re ϕ(0) as evaluate_chf(…, a = 0, θ_prev = the angle at a small a) computes it — bit for bit — in real arithmetic.
+// At a = 0 every imaginary part above is a zero (γ = κ): the unwrapped angle comes out 0 whatever θ_prev was, the
+// Bessel function is taken on the real axis, both sines are of zero, and the prefix is the same for every
+// trajectory — bk_tables_kernel runs chf_prefix(κ, σ², T, 0) ONCE, with the code above, and leaves the four numbers
+// that survive in CfZero.  What remains per trajectory is a product, besseli_logmul_re, one exponential and two
+// products: ~150 instructions for ~510 (moments_from_cf evaluates ϕ(0) although it equals 1: cf_setup says why).
+__device__ __forceinline__ CfZero chf_zero(double kappa, double sigma2, double T, double eta_k, double zeta_k) {
+  const ChfPrefix f = chf_prefix(kappa, sigma2, T, 0.0);
+  return {f.x.re, -0.5 * (f.g.re - kappa) * T, eta_k - f.eta_g.re, zeta_k * f.g_over_ome.re};
+}
+__device__ __forceinline__ double chf_at_zero(const BkArgs& p, const BesselTable* bt, const CfZero& z, const CfIter& it) {
+  const double x0 = (it.sqrtV0VT * 4.0 * p.inv_sigma2) * z.x_re;
+  const LogMulRe I = besseli_logmul_re(bt[0], bt[1], p.n_int, x0);
+  const double ex = z.c0 + it.sumV * z.c1 + I.lg - it.logI_k;
+  return (fm::exp(ex) * I.mul) * z.w_re;
 }
 
 // The series terms ϕ(h·j) of cdf_from_cf do not depend on x: the reference re-evaluates them in
@@ -225,11 +280,13 @@ __device__ double cdf_from_cf(const BkArgs& p, const BesselTable* bt, const doub
   double result = (h * x) * kInvPi;
   const double stop = kPi * p.cf_tol / 2.0;
   double theta_tail = c.theta_cap;  // for terms beyond the cached ones
-  // sin(h j x), j = 1, 2, …, by rotation (4 flops per term; error grows like j·eps) instead of one
-  // sin() call per term
+  // sin(h j x), j = 1, 2, …, by recurrence instead of one sin() call per term: the first kRegTerms by
+  // sin((j+1)θ) = 2 cos θ sin(jθ) − sin((j−1)θ) (one fma; error ~ j² eps), the rest by rotation (four instructions;
+  // ~ j eps), re-anchored every 32 terms — cdf_cached() says why, and runs the same operations
   double s1, c1;
   sincos_cf(h * x, s1, c1);
-  double sj = s1, cj = c1;
+  double sj = s1, cj = c1, sp = 0.0;
+  const double tc = c1 + c1;
   for (int j = 1; j < 1000000; ++j) {
     const double aj = h * (double)j;
     double re;
@@ -258,10 +315,18 @@ __device__ double cdf_from_cf(const BkArgs& p, const BesselTable* bt, const doub
     result = fma(sj, cdf_weight(coef, j) * re, result);
     n_terms += 1.0;
     if (last) break;
-    const double sn = fma(sj, c1, cj * s1);
-    cj = fma(cj, c1, -(sj * s1));
-    sj = sn;
-    if ((j & 31) == 0) sincos_cf(h * x * (double)(j + 1), sj, cj);  // re-anchor long series
+    if (j < kRegTerms) {  // the first terms by the three-term recurrence, as cdf_cached() takes them
+      const double sn = fma(tc, sj, -sp);
+      sp = sj;
+      sj = sn;
+    } else if (j == kRegTerms) {
+      sincos_cf(h * x * (double)(j + 1), sj, cj);
+    } else {
+      const double sn = fma(sj, c1, cj * s1);
+      cj = fma(cj, c1, -(sj * s1));
+      sj = sn;
+      if ((j & 31) == 0) sincos_cf(h * x * (double)(j + 1), sj, cj);  // re-anchor long series
+    }
   }
   return result;
 }
@@ -423,8 +488,8 @@ __device__ __forceinline__ void cf_setup(const BkArgs& p, const BesselTable* bt,
   const double v0vt = V0 * VT;  // (a grid's start variance can itself be the 2^-1000 floor: no underflow to 0)
   cf.sqrtV0VT = v0vt >= 0x1p-960 ? sqrt(v0vt) : sqrt(V0) * sqrt(VT);
   cf.sumV = (V0 + VT) / p.sigma2;
-  const LogMul Ik = besseli_logmul(bt[0], bt[1], p.n_int, {p.nuk_factor * cf.sqrtV0VT, 0.0}, 0.0);
-  cf.logI_k = Ik.lg.re + fm::log(Ik.mul.re);  // real, positive argument: I_ν > 0
+  const LogMulRe Ik = besseli_logmul_re(bt[0], bt[1], p.n_int, p.nuk_factor * cf.sqrtV0VT);
+  cf.logI_k = Ik.lg + fm::log(Ik.mul);  // real, positive argument: I_ν > 0
   // moments_from_cf (sample_from_cf.jl:50-61): mean = Re(-i ϕ'(0)), variance = Re(-ϕ''(0)) - mean²
   // by central differences of step hm over ϕ(hm), ϕ(0), ϕ(-hm).  The law is real, so ϕ(-a) is the
   // conjugate of ϕ(a) — operation by operation, also in floating point — and is not evaluated.
@@ -434,9 +499,10 @@ __device__ __forceinline__ void cf_setup(const BkArgs& p, const BesselTable* bt,
   double th = __builtin_nan("");
   const double hm = p.moment_h;
   const cx pp = evaluate_chf(p, bt, cf, hm, th);
-  const cx p0 = evaluate_chf(p, bt, cf, 0.0, th);
+  // (bt is BkTables::t: the model's ϕ(0) constants lie behind the two Bessel tables)
+  const double p0_re = chf_at_zero(p, bt, reinterpret_cast<const BkTables*>(bt)->zero, cf);
   const double mean = pp.im / hm;                                          // (ϕ₊ - ϕ₋)/(2h)
-  const double var = -(2.0 * (pp.re - p0.re) / (hm * hm)) - mean * mean;  // (ϕ₊ - 2ϕ₀ + ϕ₋)/h²
+  const double var = -(2.0 * (pp.re - p0_re) / (hm * hm)) - mean * mean;  // (ϕ₊ - 2ϕ₀ + ϕ₋)/h²
   const double sd = sqrt(fmax(var, 1e-12));
   const double normal_sample = mean + sd * q_u;
   initial_guess = normal_sample > 0.0 ? normal_sample : mean * 0.01;
@@ -641,7 +707,6 @@ __device__ __forceinline__ void series_phase(const BkArgs& p, const BesselTable*
 // (cdf_weight), zero beyond the series' end: an evaluation is then one rotation step and ONE fma per term, no
 // test (adding sin·0 changes nothing).  Was 14 instructions per term: three products, the sum, the test and its
 // selects, the term counter and its selects.
-constexpr int kRegTerms = 16;
 __device__ __forceinline__ void load_terms(const double* col, size_t stride, int j_stop,
                                            double (&t)[kRegTerms]) {
 #pragma unroll
@@ -659,12 +724,25 @@ __device__ __forceinline__ double cdf_cached(const double (&t)[kRegTerms], const
   sincos_cf(h * x, s1, c1);
   double sj = s1, cj = c1;
   n_terms += (double)j_stop;
+  // sin((j+1)θ) = 2 cos θ · sin(jθ) − sin((j−1)θ): one fma per term where the rotation takes four instructions
+  // (a sixth of the inversion's work).  Its error grows like j² eps (a double root as θ -> 0) — 3e-14 over the sixteen
+  // register terms, nine orders below the inversion's tolerance — so the column terms beyond them keep the
+  // rotation, re-anchored.  Config 4: -6 %.
+  {
+    const double tc = c1 + c1;
+    double sp = 0.0;
 #pragma unroll
-  for (int j = 1; j <= kRegTerms; ++j) {
-    result = fma(sj, t[j - 1], result);
-    const double sn = fma(sj, c1, cj * s1);
-    cj = fma(cj, c1, -(sj * s1));
-    sj = sn;
+    for (int j = 1; j <= kRegTerms; ++j) {
+      result = fma(sj, t[j - 1], result);
+      const double sn = fma(tc, sj, -sp);
+      sp = sj;
+      sj = sn;
+      // (the two chains in step: left to itself the scheduler runs the sines ahead of the sum — sixteen of them
+      // live while the first evaluation's terms are still loading — and the kernel takes 107 registers instead of
+      // 95: four waves per SIMD instead of five)
+      asm volatile("" : "+v"(result), "+v"(sj));
+    }
+    if (j_stop > kRegTerms) sincos_cf(h * x * (double)(kRegTerms + 1), sj, cj);
   }
   for (int j = kRegTerms + 1; j <= j_stop; ++j) {
     result = fma(sj, cdf_weight(coef, j) * col[(size_t)(j - 1) * stride], result);
@@ -748,8 +826,8 @@ __device__ __forceinline__ void invert_phase(const BkArgs& p, const double* coef
 //  * Longer chains: the slots are REUSED, and a reused column must stay inside one XCD — the L2s of the
 //    eight XCDs are write-back and not coherent with each other, so a dirty line of a column's previous
 //    owner on another XCD could be written back over the new owner's terms (seen: 1 trajectory in 10^6
-//    moved when it was allowed).  Each XCD therefore owns kSlots / 8 slots (its 32 CUs hold 4 workgroups
-//    each = 128), as a bitmap of two 64-bit words in a 128-byte line of its own.  Wave 0 reads the XCD's
+//    moved when it was allowed).  Each XCD therefore owns kSlots / 8 slots (its 32 CUs hold 5 workgroups
+//    each = 160 of the 192), as a bitmap of three 64-bit words in a 128-byte line of its own.  Wave 0 reads the XCD's
 //    words, lane 0 claims a free bit with an atomic OR (which returns the word's current state when
 //    somebody else was faster), the slot goes to the other waves through LDS and is given back (atomic
 //    AND) at the end.  A slot's holder never waits for anything, so a workgroup that finds every slot
@@ -817,7 +895,15 @@ __device__ __forceinline__ void give_slot(const BkArgs& p, uint32_t slot) {
 // hoists loop-invariant table values into 215-247 registers — measured — and halves the occupancy)
 // (occupancy is not what bounds this kernel: forced to 5 waves per SIMD — 95 registers, 10 spilled — it runs as at
 // its natural 4, at 6 it spills 66 and takes 1.5 x the time: interleaved A/B of round 4)
-__global__ __launch_bounds__(kTile) void bk_cf_kernel(const BkArgs p, const BkTables* __restrict__ tabs) {
+#ifndef HH_BK_CF_WAVES
+#define HH_BK_CF_WAVES 0
+#endif
+#if HH_BK_CF_WAVES
+#define HH_BK_CF_OCC __attribute__((amdgpu_waves_per_eu(HH_BK_CF_WAVES, HH_BK_CF_WAVES)))
+#else
+#define HH_BK_CF_OCC
+#endif
+__global__ __launch_bounds__(kTile) HH_BK_CF_OCC void bk_cf_kernel(const BkArgs p, const BkTables* __restrict__ tabs) {
   const uint32_t tile = blockIdx.x, tid = threadIdx.x;
   const uint64_t path = (uint64_t)tile * kTile + tid;
   const bool live = path < p.n_paths;
@@ -884,25 +970,33 @@ __global__ __launch_bounds__(kScanThreads) void bk_scan_kernel(const BkArgs p, u
     const uint32_t c = cnt[t];
     prefix_a[t] = ra;
     prefix_b[t] = rb;
-    ra += c & 0xffffu;
+    // a tile holds at most kTile failed trajectories, so at most one packed chunk (kTile work items) starts in it
+    const uint32_t fa = c & 0xffffu, first = (ra + (uint32_t)kTile - 1u) / (uint32_t)kTile * (uint32_t)kTile;
+    if (first < ra + fa) p.chunk_tile[first / (uint32_t)kTile] = t;
+    ra += fa;
     rb += c >> 16;
   }
   if (tid == 0) {
     prefix_a[n_tiles] = ta;
     prefix_b[n_tiles] = tb;
+    const uint32_t chunks = (ta + (uint32_t)kTile - 1u) / (uint32_t)kTile;
+    p.chunk_tile[chunks] = n_tiles - 1u;  // where the last chunk's search ends
+    // records the reduction reads: the CF tiles, the fall-back kernel's, the ladder workgroups that have work
+    p.side_count[1] = n_tiles + (uint32_t)kHeavyGrid + chunks;
+    p.side_count[0] = 0u;  // the CF kernel is done with the side-store counter: ready for the next chain
   }
 }
 
 // trajectory of packed work item g: the last tile t with prefix[t] <= g, then the (g - prefix[t])-th
-// set bit of its 4 ballots
+// set bit of its 4 ballots.  [lo, hi): tiles to search, prefix[lo] <= g < prefix[hi]; `prefix` may be a copy of
+// that part in LDS (then `base` = the tile its element 0 stands for)
 __device__ __forceinline__ uint64_t packed_path(const unsigned long long* mask, const uint32_t* prefix,
-                                                uint32_t n_tiles, uint32_t g) {
-  uint32_t lo = 0, hi = n_tiles;  // invariant: prefix[lo] <= g < prefix[hi]
+                                                uint32_t lo, uint32_t hi, uint32_t g, uint32_t base = 0) {
   while (hi - lo > 1) {
     const uint32_t mid = (lo + hi) >> 1;
-    if (prefix[mid] <= g) lo = mid; else hi = mid;
+    if (prefix[mid - base] <= g) lo = mid; else hi = mid;
   }
-  uint32_t r = g - prefix[lo];
+  uint32_t r = g - prefix[lo - base];
   uint32_t bit = 0;
   for (int w = 0; w < kTile / 64; ++w) {
     unsigned long long mk = mask[(size_t)lo * (kTile / 64) + w];
@@ -923,15 +1017,23 @@ __device__ __forceinline__ uint64_t packed_path(const unsigned long long* mask, 
 // runs on those terms.  Only a series that found no room there is evaluated again — same operations,
 // same terms — into the column of the slot THIS workgroup takes.  One work item
 // per lane, no loop (see bk_cf_kernel): the grid covers the worst case (every trajectory failed) and the
-// workgroups beyond the packed list leave at once with an empty record.
+// workgroups beyond the packed list leave at once, without a record (bk_live_records).
 __global__ __launch_bounds__(kTile) void bk_ladder_kernel(const BkArgs p, const BkTables* __restrict__ tabs,
                                                           uint32_t n_tiles,
                                                           const uint32_t* __restrict__ prefix) {
   const uint32_t total = prefix[n_tiles];
-  double* rec = p.records + (size_t)(n_tiles + blockIdx.x) * kRecStride;
-  if (blockIdx.x * (uint32_t)kTile >= total) {  // uniform
-    if (threadIdx.x < (uint32_t)kRecStride) rec[threadIdx.x] = 0.0;
-    return;
+  if (blockIdx.x * (uint32_t)kTile >= total) return;  // (uniform) no work, no record: the reduction stops short of it
+  double* rec = p.records + (size_t)(n_tiles + (uint32_t)kHeavyGrid + blockIdx.x) * kRecStride;
+  // This chunk's trajectories lie in the tiles [t_lo, t_hi] (bk_scan_kernel left where each chunk starts): their
+  // prefix sums come into LDS in one round trip and the search runs there — the binary search over all tiles was
+  // twelve dependent round trips to the L2 in front of every lane's work, a third of this kernel's time.
+  constexpr uint32_t kSpan = 1024;
+  __shared__ uint32_t pre_sh[kSpan + 1];
+  const uint32_t t_lo = p.chunk_tile[blockIdx.x], t_hi = p.chunk_tile[blockIdx.x + 1u];
+  const bool staged = t_hi - t_lo < kSpan;  // (uniform) else: failures this sparse are searched in place
+  if (staged) {
+    for (uint32_t i = threadIdx.x; i <= t_hi - t_lo + 1u; i += kTile) pre_sh[i] = prefix[t_lo + i];
+    __syncthreads();
   }
   const BesselTable* bt = tabs->t;
   const uint32_t slot = take_slot(p, blockIdx.x);
@@ -940,7 +1042,8 @@ __global__ __launch_bounds__(kTile) void bk_ladder_kernel(const BkArgs p, const 
   double acc[6] = {0, 0, 0, 0, 0, 0};
   const uint32_t g = blockIdx.x * kTile + threadIdx.x;
   if (g < total) {
-    const uint64_t path = packed_path(p.fail_mask, prefix, n_tiles, g);
+    const uint64_t path = staged ? packed_path(p.fail_mask, pre_sh, t_lo, t_hi + 1u, g, t_lo)
+                                 : packed_path(p.fail_mask, prefix, t_lo, t_hi + 1u, g);
     double h, guess, max_guess;
     int j_stop;
     const double* terms = col;
@@ -1025,7 +1128,7 @@ __global__ __launch_bounds__(kTile) void bk_fallback_kernel(
   const BesselTable* bt = tabs->t;
   double acc[6] = {0, 0, 0, 0, 0, 0};
   for (uint32_t g = blockIdx.x * kTile + threadIdx.x; g < total; g += gridDim.x * kTile) {
-    const uint64_t path = packed_path(p.long_mask, prefix, n_tiles, g);
+    const uint64_t path = packed_path(p.long_mask, prefix, 0, n_tiles, g);
     PathSetup s;
     bk_setup(p, bt, path, s);
     double n_terms = 0.0;
@@ -1112,14 +1215,16 @@ __global__ __launch_bounds__(kTile) void bk_fallback_kernel(
     acc[0] += pay;
     acc[1] = fma(pay, pay, acc[1]);
   }
-  bk_store_record(acc, p.records + (size_t)(2 * n_tiles + blockIdx.x) * kRecStride);
+  bk_store_record(acc, p.records + (size_t)(n_tiles + blockIdx.x) * kRecStride);
 }
 
 // The host-made tables into device memory: ONE lane, constant indices (a lane-indexed read of the
 // by-value argument would again send the block through scratch), the compiler batches the scalar loads.
-__global__ __launch_bounds__(64) void bk_tables_kernel(const BkBessel t, BkTables* __restrict__ dst) {
+__global__ __launch_bounds__(64) void bk_tables_kernel(const BkBessel t, BkTables* __restrict__ dst, double kappa,
+                                                        double sigma2, double T, double eta_k, double zeta_k) {
   for (int j = (int)threadIdx.x; j <= kCoefTerms; j += 64) dst->coef[j] = kTwoOverPi / (double)j;  // ([0] is not read)
   if (threadIdx.x != 0) return;
+  dst->zero = chf_zero(kappa, sigma2, T, eta_k, zeta_k);
   const double* src = reinterpret_cast<const double*>(&t);
   double* out = reinterpret_cast<double*>(dst->t);
   static_assert(sizeof(BkBessel) == sizeof(dst->t), "the Bessel tables of BkTables");
@@ -1193,8 +1298,8 @@ static int phi_cache_cap(int term_cache) { return term_cache > 0 ? term_cache : 
 static size_t bk_masks_bytes(size_t n_tiles) {
   return 2 * n_tiles * (kTile / 64) * sizeof(unsigned long long);
 }
-static size_t bk_args_offset(size_t n_tiles) {  // … + prefix sums [2][n_tiles+1] + tile counts [n_tiles]
-  const size_t b = bk_masks_bytes(n_tiles) + (2 * (n_tiles + 1) + n_tiles) * sizeof(uint32_t) + 128 + kSlotBitmapBytes;
+static size_t bk_args_offset(size_t n_tiles) {  // … + prefix sums [2][n_tiles+1] + tile counts [n_tiles] + chunk starts [n_tiles+1]
+  const size_t b = bk_masks_bytes(n_tiles) + (3 * (n_tiles + 1) + n_tiles) * sizeof(uint32_t) + 128 + kSlotBitmapBytes;
   return (b + 255) & ~(size_t)255;
 }
 static size_t bk_tables_offset(size_t n_tiles) {
@@ -1221,7 +1326,19 @@ int launch_fill_rows(double* spot0, double* var0, uint64_t n, double S0, double 
 }
 
 uint32_t bk_record_count(uint64_t n_paths) {
-  return 2 * tiles_for(n_paths) + (uint32_t)kHeavyGrid;  // CF tiles | ladder workgroups (worst case) | fall-back
+  return 2 * tiles_for(n_paths) + (uint32_t)kHeavyGrid;  // CF tiles | fall-back | ladder workgroups (worst case)
+}
+// … of which a chain fills the first *bk_live_records(): the ladder workgroups that had work come last, the
+// reduction reads no further (10^6 trajectories: 4058 records instead of 7878 — one round trip per thread, 6 µs
+// instead of 11)
+// (the words behind the ballots: prefix sums [2][n_tiles + 1] | tile counts [n_tiles] | chunk starts [n_tiles + 1] |
+// then, on a 128-byte boundary, the slot bitmaps and the line of the two counters)
+static uint32_t* bk_slot_lines(unsigned char* base, size_t n_tiles) {
+  uint32_t* words = reinterpret_cast<uint32_t*>(base + bk_masks_bytes(n_tiles));
+  return reinterpret_cast<uint32_t*>((reinterpret_cast<uintptr_t>(words + 3 * (n_tiles + 1) + n_tiles) + 127) & ~(uintptr_t)127);
+}
+const uint32_t* bk_live_records(const void* scratch, uint64_t n_paths) {
+  return bk_slot_lines(static_cast<unsigned char*>(const_cast<void*>(scratch)), tiles_for(n_paths)) + 8 * 32 + 1;
 }
 
 size_t bk_scratch_bytes(uint64_t n_paths, int term_cache) {
@@ -1281,8 +1398,8 @@ int bk_prepare(const hh_model& m, const hh_config& c, const DevicePtrs& ptr, uin
   L.prefix = reinterpret_cast<uint32_t*>(a.long_mask + (size_t)n_tiles * (kTile / 64));
   L.prefix_long = L.prefix + n_tiles + 1;
   a.tile_counts = L.prefix_long + n_tiles + 1;
-  a.slot_busy = reinterpret_cast<uint32_t*>(
-      (reinterpret_cast<uintptr_t>(a.tile_counts + n_tiles) + 127) & ~(uintptr_t)127);  // 128-byte lines
+  a.chunk_tile = a.tile_counts + n_tiles;
+  a.slot_busy = bk_slot_lines(base, n_tiles);  // 128-byte lines
   a.args_dev = base + bk_args_offset(n_tiles);
   L.tabs_dev = reinterpret_cast<BkTables*>(base + bk_tables_offset(n_tiles));
   a.tabs_dev = L.tabs_dev;
@@ -1301,17 +1418,24 @@ int bk_prepare(const hh_model& m, const hh_config& c, const DevicePtrs& ptr, uin
   return 0;
 }
 
-// the Bessel tables depend on ν alone: repeated solves of one model (and the dates of a grid) find them in place
+// the Bessel tables depend on ν alone, the ϕ(0) constants beside them on κ, σ², T: repeated solves of one model
+// (and the dates of a grid) find them in place
 int bk_tables(const BkArgs& a, const BkLayout& L, const DevicePtrs& ptr, hipStream_t s, bool upload_tables) {
   // (where they lie depends on the chain's size: a grid's last, shorter batch of dates has its own place)
   if (ptr.bk_table_key)
-    upload_tables = !(ptr.bk_table_key->where == L.tabs_dev && ptr.bk_table_key->nu == a.nu);
+    upload_tables = !(ptr.bk_table_key->where == L.tabs_dev && ptr.bk_table_key->nu == a.nu &&
+                      ptr.bk_table_key->kappa == a.kappa && ptr.bk_table_key->sigma2 == a.sigma2 &&
+                      ptr.bk_table_key->T == a.T);
   if (upload_tables) {
+    // … and the slot bitmaps and the side-store counter beside them start from zero; after that every chain leaves
+    // them so (a workgroup gives its slot back, bk_scan_kernel resets the counter): no 5 µs fill per solve
+    (void)hipMemsetAsync(a.slot_busy, 0, kSlotBitmapBytes, s);
     BkBessel tabs;
     if (!bessel_table(a.nu, tabs.t[0]) || !bessel_table(a.nu - a.n_int, tabs.t[1]))
       return (int)hipErrorInvalidValue;  // the series table of hh_bessel.h does not reach |z| = 13: not for ν > -1
-    hipLaunchKernelGGL(bk_tables_kernel, dim3(1), dim3(64), 0, s, tabs, L.tabs_dev);
-    if (ptr.bk_table_key) *ptr.bk_table_key = BkTableKey{L.tabs_dev, a.nu};
+    hipLaunchKernelGGL(bk_tables_kernel, dim3(1), dim3(64), 0, s, tabs, L.tabs_dev, a.kappa, a.sigma2, a.T, a.eta_k,
+                       a.zeta_k);
+    if (ptr.bk_table_key) *ptr.bk_table_key = BkTableKey{L.tabs_dev, a.nu, a.kappa, a.sigma2, a.T};
   }
   return 0;
 }
@@ -1320,7 +1444,6 @@ int bk_tables(const BkArgs& a, const BkLayout& L, const DevicePtrs& ptr, hipStre
 void bk_chain(const BkArgs& a, const BkLayout& L, hipStream_t s) {
   const dim3 b(kTile), g(L.n_tiles);
   const BkTables* tabs = static_cast<const BkTables*>(L.tabs_dev);
-  (void)hipMemsetAsync(a.slot_busy, 0, kSlotBitmapBytes, s);  // slot bitmaps + the side-store counter
   hipLaunchKernelGGL(bk_cf_kernel, g, b, 0, s, a, tabs);
   hipLaunchKernelGGL(bk_scan_kernel, dim3(1), dim3(kScanThreads), 0, s, a, L.n_tiles, L.prefix, L.prefix_long);
   hipLaunchKernelGGL(bk_ladder_kernel, g, b, 0, s, a, tabs, L.n_tiles, L.prefix);

@@ -94,8 +94,9 @@ struct DevicePtrs {
 // can path-major increments of this shape be streamed without the repack pass?
 inline bool replay_direct_path_major(uint32_t n_steps, int ncomp) { return ((uint64_t)n_steps * ncomp) % 2 == 0; }
 struct BkTableKey {
-  const void* where;  // address of the tables inside the scratch buffer
-  double nu;          // Bessel order they were made for
+  const void* where;        // address of the tables inside the scratch buffer
+  double nu;                // Bessel order they were made for
+  double kappa, sigma2, T;  // … and the model constants of the ϕ(0) block beside them (hh_bk.hip, CfZero)
 };
 
 // several payoffs on ONE set of terminal samples (basket.jl:35-38, same-expiry payoffs)
@@ -182,15 +183,20 @@ size_t bk_scratch_bytes(uint64_t n_paths, int term_cache = 0);
 // secant evaluations | branch << 8 | bisection iterations << 16 | long-series bit 31) and its series length
 void bk_diag_ptrs(const void* scratch, uint64_t n_paths, int term_cache, const uint32_t** decisions,
                   const uint32_t** series_len);
-uint32_t bk_record_count(uint64_t n_paths);  // records the Broadie–Kaya chain writes (inversion tiles + packed kernels)
+uint32_t bk_record_count(uint64_t n_paths);  // records the Broadie–Kaya chain can write (inversion tiles + packed kernels)
+// device word that holds, once the chain over n_paths trajectories (or pairs) has run in `scratch`, how many of them
+// it DID write — the reduction reads that many (launch_reduce_records, n_records_dev)
+const uint32_t* bk_live_records(const void* scratch, uint64_t n_paths);
 // the four Broadie–Kaya counter slots of `src` (HH_ACC_LEN doubles) into each of n_groups accumulators
 int launch_copy_bk_counters(const double* src, double* accum, uint32_t n_groups, hipStream_t s);
 // row 0 of the exact Heston grid: spot0[i] = S0, var0[i] = V0
 int launch_fill_rows(double* spot0, double* var0, uint64_t n, double S0, double V0, hipStream_t s);
 // m, c given: finish the dual partials (active slots re-ordered, passive ones in closed form)
+// n_records_dev (device, optional): the launch reads min(*n_records_dev, n_records) records instead of n_records
 int launch_reduce_records(const double* records, uint32_t n_records, double n_paths, double* accum,
                           hipStream_t s, uint32_t n_groups = 1, const hh_model* m = nullptr,
-                          const hh_config* c = nullptr, bool basket = false);
+                          const hh_config* c = nullptr, bool basket = false,
+                          const uint32_t* n_records_dev = nullptr);
 int count_active_partials(const hh_model& m, const hh_config& c);
 int launch_basket_payoffs(const BasketArgs& b, uint32_t n_payoffs, uint32_t n_active_partials,
                           hipStream_t s);

@@ -496,9 +496,11 @@ __device__ __forceinline__ double sum_slot(const double* __restrict__ rec, uint3
 __global__ __launch_bounds__(256) void reduce_records_kernel(const double* __restrict__ rec,
                                                               uint32_t n, double n_paths,
                                                               double* __restrict__ accum,
-                                                              const PartialMap map) {
+                                                              const PartialMap map,
+                                                              const uint32_t* __restrict__ n_dev) {
   __shared__ double sm[257];
   const int slot = blockIdx.x;
+  if (n_dev) n = min(n, *n_dev);  // (uniform) the records a Broadie–Kaya chain filled: bk_live_records()
   rec += (size_t)blockIdx.y * n * kRecStride;  // group = one payoff of a basket
   accum += (size_t)blockIdx.y * kRecStride;
   double out;
@@ -775,7 +777,7 @@ int launch_simulation(const hh_model& m, const hh_config& c, const DevicePtrs& p
 
 int launch_reduce_records(const double* records, uint32_t n_records, double n_paths, double* accum,
                           hipStream_t s, uint32_t n_groups, const hh_model* m, const hh_config* c,
-                          bool basket) {
+                          bool basket, const uint32_t* n_records_dev) {
   PartialMap pm{};
   if (m && c && (basket || c->strategy != HH_BROADIE_KAYA)) {
     if (c->n_partials) pm = classify_partials(*m, *c);
@@ -784,7 +786,7 @@ int launch_reduce_records(const double* records, uint32_t n_records, double n_pa
       for (double& d : pm.dK) d = 0.0;
   }
   hipLaunchKernelGGL(reduce_records_kernel, dim3(kRecStride, n_groups), dim3(256), 0, s, records,
-                     n_records, n_paths, accum, pm);
+                     n_records, n_paths, accum, pm, n_records_dev);
   return (int)hipGetLastError();
 }
 

@@ -181,7 +181,7 @@ const char* hh_last_error(const hh_ctx* ctx); /* NUL-terminated, owned by ctx (o
  *
  * HH_OPT_BK_TERM_CACHE: how many CDF-series terms Re ϕ(h·j) the Broadie–Kaya kernels keep per column
  * (8 … 1024, default 256).  A column belongs to a resident workgroup slot of the kernel, not to a
- * trajectory, so the cache is 8 bytes x terms x 262 144 columns (0.54 GB at 256 terms) whatever the
+ * trajectory, so the cache is 8 bytes x terms x 393 216 columns (0.81 GB at 256 terms) whatever the
  * ensemble size; beside it a solve keeps 48 bytes per trajectory.  Series that fit are evaluated once
  * and inverted on the cached terms; a trajectory whose series is longer re-evaluates the terms beyond
  * the cache in every CDF call (as the reference does with all of them), in a separate, slower kernel.
