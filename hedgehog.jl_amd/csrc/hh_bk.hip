@@ -55,6 +55,15 @@ constexpr double kInvPi = 0.31830988618379067154, kTwoOverPi = 0.636619772367581
 #ifndef HH_BK_HEAVY_GRID
 #define HH_BK_HEAVY_GRID 64
 #endif
+// Two switches of a TEST build (tests/c/build_bk_check.py, tests/test_gpu_bk_forms.py), which must give the shipped
+// build's samples bit for bit: the trajectory's two real-axis evaluations through the complex code (1), and the ladder
+// kernel searching the prefix sums in place instead of in LDS (a span of 1 tile is never staged)
+#ifndef HH_BK_COMPLEX_SETUP
+#define HH_BK_COMPLEX_SETUP 0
+#endif
+#ifndef HH_BK_LADDER_SPAN
+#define HH_BK_LADDER_SPAN 1024
+#endif
 // Columns of cached series terms.  A lane's column belongs to a workgroup SLOT that a workgroup of the
 // CF kernel (or of the ladder kernel behind it) takes when it starts and gives back when it is done —
 // not to the trajectory: the cache is kSlots x 256 columns however many trajectories the chain has
@@ -128,6 +137,8 @@ struct BkArgs {
   // pairs of the batch, in_var = the variance rows of the batch (row-major, so pair i starts at in_var[i]),
   // in_spot = NULL, and the chain leaves the sampled ∫V of pair i in iv_out[i] instead of a spot
   double* iv_out;
+  const uint32_t* iv_perm;         // a chain that runs its pairs in another order (launch_bk_grid): position s of the
+                                   // chain stands for pair iv_perm[s], and ∫V goes to iv_out[iv_perm[s]]; else NULL
   double* records;                 // [2·n_tiles][kRecStride]: phase 1, then phase 2
   double* draws;                   // [4][draw_stride]: Z, u, normal quantile of u, V_T per trajectory
   size_t draw_stride;
@@ -488,8 +499,13 @@ __device__ __forceinline__ void cf_setup(const BkArgs& p, const BesselTable* bt,
   const double v0vt = V0 * VT;  // (a grid's start variance can itself be the 2^-1000 floor: no underflow to 0)
   cf.sqrtV0VT = v0vt >= 0x1p-960 ? sqrt(v0vt) : sqrt(V0) * sqrt(VT);
   cf.sumV = (V0 + VT) / p.sigma2;
+#if HH_BK_COMPLEX_SETUP  // a test build: both real evaluations through the complex code, as until round 5
+  const LogMul Ik = besseli_logmul(bt[0], bt[1], p.n_int, {p.nuk_factor * cf.sqrtV0VT, 0.0}, 0.0);
+  cf.logI_k = Ik.lg.re + fm::log(Ik.mul.re);
+#else
   const LogMulRe Ik = besseli_logmul_re(bt[0], bt[1], p.n_int, p.nuk_factor * cf.sqrtV0VT);
   cf.logI_k = Ik.lg + fm::log(Ik.mul);  // real, positive argument: I_ν > 0
+#endif
   // moments_from_cf (sample_from_cf.jl:50-61): mean = Re(-i ϕ'(0)), variance = Re(-ϕ''(0)) - mean²
   // by central differences of step hm over ϕ(hm), ϕ(0), ϕ(-hm).  The law is real, so ϕ(-a) is the
   // conjugate of ϕ(a) — operation by operation, also in floating point — and is not evaluated.
@@ -499,8 +515,12 @@ __device__ __forceinline__ void cf_setup(const BkArgs& p, const BesselTable* bt,
   double th = __builtin_nan("");
   const double hm = p.moment_h;
   const cx pp = evaluate_chf(p, bt, cf, hm, th);
+#if HH_BK_COMPLEX_SETUP
+  const double p0_re = evaluate_chf(p, bt, cf, 0.0, th).re;
+#else
   // (bt is BkTables::t: the model's ϕ(0) constants lie behind the two Bessel tables)
   const double p0_re = chf_at_zero(p, bt, reinterpret_cast<const BkTables*>(bt)->zero, cf);
+#endif
   const double mean = pp.im / hm;                                          // (ϕ₊ - ϕ₋)/(2h)
   const double var = -(2.0 * (pp.re - p0_re) / (hm * hm)) - mean * mean;  // (ϕ₊ - 2ϕ₀ + ϕ₋)/h²
   const double sd = sqrt(fmax(var, 1e-12));
@@ -544,7 +564,7 @@ __device__ __forceinline__ double bk_spot(const BkArgs& p, double logS0, double 
 __device__ __forceinline__ double bk_finish(const BkArgs& p, double logS0, double V0, double VT,
                                             double Z, double IV, uint64_t path) {
   if (p.iv_out) {  // a batch of dates: the spot rows are chained afterwards (bk_grid_spots_kernel)
-    p.iv_out[path] = IV;
+    p.iv_out[p.iv_perm ? p.iv_perm[path] : path] = IV;
     return 0.0;
   }
   const double S = bk_spot(p, logS0, V0, VT, Z, IV);
@@ -1027,7 +1047,7 @@ __global__ __launch_bounds__(kTile) void bk_ladder_kernel(const BkArgs p, const 
   // This chunk's trajectories lie in the tiles [t_lo, t_hi] (bk_scan_kernel left where each chunk starts): their
   // prefix sums come into LDS in one round trip and the search runs there — the binary search over all tiles was
   // twelve dependent round trips to the L2 in front of every lane's work, a third of this kernel's time.
-  constexpr uint32_t kSpan = 1024;
+  constexpr uint32_t kSpan = HH_BK_LADDER_SPAN;
   __shared__ uint32_t pre_sh[kSpan + 1];
   const uint32_t t_lo = p.chunk_tile[blockIdx.x], t_hi = p.chunk_tile[blockIdx.x + 1u];
   const bool staged = t_hi - t_lo < kSpan;  // (uniform) else: failures this sparse are searched in place
@@ -1267,23 +1287,27 @@ constexpr int kGridKeyBits = 8;
 // below this many pairs the sort and the two copies cost more than the order saves (2.4·10^5 pairs: +8 %; 2.4·10^6: -16 %)
 constexpr uint64_t kGridOrderMinPairs = 1ull << 20;
 
-__global__ __launch_bounds__(256) void grid_gather_kernel(const double* __restrict__ draws, size_t stride,
-                                                          const double* __restrict__ v0, const uint32_t* __restrict__ perm,
+// The draws and start variances into the chain's order.  NOT a gather by destination (out[s] = in[perm[s]]): the
+// sort is stable on 256 coarse keys, so neighbouring destinations come from sources a few hundred elements apart and
+// every 128-byte source line was fetched some six times over (0.19 ms for 2.4·10^6 pairs, a sixth of the whole
+// grid).  By SOURCE instead: the inverse permutation first (4 bytes per pair), then every source line is read once,
+// coalesced, and each element goes to its key's run — 256 runs that each fill front to back, so the L2 completes
+// their lines before it writes them.
+__global__ __launch_bounds__(256) void grid_inverse_kernel(const uint32_t* __restrict__ perm, uint32_t n,
+                                                           uint32_t* __restrict__ inv) {
+  const uint32_t s = blockIdx.x * 256u + threadIdx.x;
+  if (s < n) inv[perm[s]] = s;
+}
+__global__ __launch_bounds__(256) void grid_spread_kernel(const double* __restrict__ draws, size_t stride,
+                                                          const double* __restrict__ v0, const uint32_t* __restrict__ inv,
                                                           uint32_t n, double* __restrict__ draws_out,
                                                           double* __restrict__ v0_out) {
-  const uint32_t s = blockIdx.x * 256u + threadIdx.x;
-  if (s >= n) return;
-  const uint32_t j = perm[s];
+  const uint32_t j = blockIdx.x * 256u + threadIdx.x;
+  if (j >= n) return;
+  const uint32_t s = inv[j];
 #pragma unroll
   for (int k = 0; k < 4; ++k) draws_out[(size_t)k * stride + s] = draws[(size_t)k * stride + j];
   v0_out[s] = v0[j];
-}
-
-__global__ __launch_bounds__(256) void grid_scatter_kernel(const double* __restrict__ iv_sorted,
-                                                           const uint32_t* __restrict__ perm, uint32_t n,
-                                                           double* __restrict__ iv) {
-  const uint32_t s = blockIdx.x * 256u + threadIdx.x;
-  if (s < n) iv[perm[s]] = iv_sorted[s];
 }
 
 }  // namespace
@@ -1540,16 +1564,16 @@ int launch_bk_grid(const hh_model& m, const hh_config& c, const DevicePtrs& ptr,
     if (hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, static_cast<const uint32_t*>(keys_in), keys_out,
                                            static_cast<const uint32_t*>(idx_in), perm, (int)n, 0, kGridKeyBits, s) != hipSuccess)
       return (int)hipErrorUnknown;
-    hipLaunchKernelGGL(grid_gather_kernel, g256, b256, 0, s, static_cast<const double*>(a.draws), a.draw_stride,
-                       static_cast<const double*>(var_rows), static_cast<const uint32_t*>(perm), n, draws_sorted, var_sorted);
+    uint32_t* inv = keys_in;  // (the keys are dead once sorted)
+    hipLaunchKernelGGL(grid_inverse_kernel, g256, b256, 0, s, static_cast<const uint32_t*>(perm), n, inv);
+    hipLaunchKernelGGL(grid_spread_kernel, g256, b256, 0, s, static_cast<const double*>(a.draws), a.draw_stride,
+                       static_cast<const double*>(var_rows), static_cast<const uint32_t*>(inv), n, draws_sorted, var_sorted);
     BkArgs o = a;  // the chain on the gathered arrays: position s of the order stands for pair perm[s]
     o.draws = draws_sorted;
     o.draw_stride = lanes;
     o.in_var = var_sorted;
-    o.iv_out = iv_sorted;
+    o.iv_perm = perm;  // ∫V straight to its pair's place (was: a sorted array and a scatter pass of its own, 35 µs)
     bk_chain(o, L, s);
-    hipLaunchKernelGGL(grid_scatter_kernel, g256, b256, 0, s, static_cast<const double*>(iv_sorted),
-                       static_cast<const uint32_t*>(perm), n, a.iv_store);
   } else {
     bk_chain(a, L, s);
   }

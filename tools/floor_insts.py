@@ -93,7 +93,20 @@ CF_FIXED = {
     "exponent of phi (heston.jl:207-211)": 12, "exp of it (complex exp), x I.mul, x zeta_kappa gamma/(1 - e)": CEXP + 4 + 2 + 4,
 }
 CF_PER_BESSEL_TERM = 6   # two independent Horner chains (even / odd half), 12 instructions per two terms
-CDF_PER_CACHED_TERM = 7  # load Re phi_j, rotate (sin, cos)(h j x) (4), x 1/j (tabulated), fma into the sum
+# the two real-axis evaluations of a trajectory's set-up (round 5: besseli_logmul_re, chf_at_zero in hh_bk.hip): the
+# Bessel function of a positive real argument is 2 instructions per series term, and phi(0) needs of the model only
+# four numbers made once per chain (bk_tables_kernel)
+BESSEL_RE_FIXED = {"|x|, x^2, rough root, dispatch": 6, "q = x^2/4, Q = q^2": 2, "length n0 + n1 r, wave maximum": 12,
+                   "S = A + c1 q B": 3, "(nu/2) log(r^2/4) - lgamma": 33 + 2}
+BESSEL_RE_PER_TERM = 2
+CHF_ZERO = {"nu_gamma(0) = (4 sqrt(V0 VT)/sigma^2) x_re": 2, "exponent c0 + sumV c1 + log I - log I_kappa": 4,
+            "exp": sum(FM_EXP.values()), "x mul x w_re": 2}
+LOG_I_KAPPA = {"nu_kappa": 1, "log(mul), sum": 33 + 1}
+# one CDF evaluation of the root search on the cached terms (cdf_cached): sin, cos of h x once, then per term ONE fma of
+# the sum and ONE of the three-term recurrence sin((j+1)t) = 2 cos t sin(jt) - sin((j-1)t)  (round 4: a rotation, 7 per
+# term with the weight's product; the weight is now folded into the register terms once per trajectory)
+CDF_FIXED = sum(FM_SINCOS.values()) + 3
+CDF_PER_CACHED_TERM = 2
 DRAWS = {  # bk_draw_kernel: Z and u (one block + Box–Muller + uniforms), the NCchi^2 variance (d > 1: one gamma by
     # Marsaglia–Tsang: a normal, a uniform, one squeeze test; + shift normal), normal quantile of u
     "Philox blocks (3)": 3 * sum(PHILOX.values()), "Box–Muller x 2": 2 * (sum(NORMAL_PAIR.values()) - sum(PHILOX.values())),
@@ -165,7 +178,12 @@ def main():
     cf_fixed = sum(CF_FIXED.values())
     cf_eval = cf_fixed + CF_PER_BESSEL_TERM * N
     evals = 6.0  # CDF evaluations of the secant on cached terms (measured mean of hh_bk_decisions & 0xff at config 4: 5.6-6.2)
-    bk_path = (J + 2) * cf_eval + evals * J * CDF_PER_CACHED_TERM + sum(DRAWS.values()) + 60
+    bessel_re = sum(BESSEL_RE_FIXED.values()) + BESSEL_RE_PER_TERM * N
+    setup_re = sum(CHF_ZERO.values()) + bessel_re + sum(LOG_I_KAPPA.values()) + bessel_re
+    # J series terms + the moment evaluation at a = h_m (complex) | phi(0) and log I(nu_kappa) (real axis) | the root
+    # search | the draws | load / premultiply the register terms, finish (log S_T, exp, payoff)
+    bk_path = (J + 1) * cf_eval + setup_re + evals * (CDF_FIXED + J * CDF_PER_CACHED_TERM) + sum(DRAWS.values()) + 60
+    bk_path_r4 = (J + 2) * cf_eval + evals * J * 7 + sum(DRAWS.values()) + 60  # the algorithm as round 4 shipped it
     lsm = sum(LSM_INDUCTION.values()) + sum(GBM_GRID.values())
     exact = (sum(NORMAL_PAIR.values()) / 2 + 3 + sum(FM_EXP.values()) + 12) / 1.0  # one normal, mu + sd z, exp, payoff; per path
     out = {
@@ -187,8 +205,11 @@ def main():
         "broadie_kaya": {"lane_insts": bk_path, "floor_insts_per_unit": bk_path / 64.0, "unit": "path",
                          "per_cf_evaluation": {"fixed": cf_fixed, "per_bessel_series_term": CF_PER_BESSEL_TERM,
                                                "bessel_terms_mean": N, "lane_insts": cf_eval},
-                         "cf_evaluations_per_path": J + 2, "series_length_mean": J, "bessel_order": nu,
-                         "cdf_evaluations_on_cached_terms": evals, "per_cached_term": CDF_PER_CACHED_TERM,
+                         "cf_evaluations_per_path": J + 1, "real_axis_setup": setup_re,
+                         "series_length_mean": J, "bessel_order": nu,
+                         "cdf_evaluations_on_cached_terms": evals, "per_cdf_evaluation_fixed": CDF_FIXED,
+                         "per_cached_term": CDF_PER_CACHED_TERM,
+                         "round4_algorithm_lane_insts": bk_path_r4,
                          "draws": sum(DRAWS.values()),
                          "sample": "4000 V_T of config 4 (scipy ncx2), reference controls cf_tol 1e-3, n_sigma 5"},
         "lsm_chain": {"lane_insts": lsm, "floor_insts_per_unit": lsm / 64.0, "unit": "(trajectory, date)",
