@@ -14,9 +14,10 @@
 // cached terms; -DHH_BK_FUSED=0: bk_series_kernel and bk_invert_kernel apart) -> bk_scan_kernel ->
 // bk_ladder_kernel (bisection ladder for the flagged trajectories, packed) -> bk_fallback_kernel
 // (trajectories whose series outgrew the term cache; none with the reference's controls).
-// The draws live in their own launch because the NCχ² sampler's library calls (pow, lgamma, log,
-// normcdfinv) and the CF arithmetic are two different register-hungry programs: together they cost
-// 228 registers per lane (2 waves per SIMD); apart, the CF kernels fit 128 (4 waves).
+// The draws live in their own launch because the NCχ² sampler's library calls (pow, lgamma, log) and the CF
+// arithmetic are two different register-hungry programs: together they cost 228 registers per lane (2 waves
+// per SIMD); apart, the CF kernel fits 96 (5 waves).  (The normal quantile of u is hh_math.h's own since round 5 —
+// the library's normcdfinv was a third of the draw kernel.)
 //
 // Third-party pieces of the reference restated here from their published algorithms (DESIGN.md
 // "Broadie–Kaya"): complex log I_ν(z) for real ν > -1 (power series / Hankel asymptotics /
@@ -450,7 +451,7 @@ __device__ __forceinline__ void store_draws(const BkArgs& p, uint64_t i, double 
   double* d = p.draws + i;  // trajectory index == lane index of the CF kernels' tiles
   d[0] = Z;
   d[p.draw_stride] = u;
-  d[2 * p.draw_stride] = normcdfinv(u);  // quantile(Normal(), u) (sample_from_cf.jl:33)
+  d[2 * p.draw_stride] = fm::normal_quantile(u);  // quantile(Normal(), u) (sample_from_cf.jl:33)
   d[3 * p.draw_stride] = VT;
 }
 

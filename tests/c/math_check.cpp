@@ -53,6 +53,28 @@ int main() {
     const double ay = r * std::sin(ph) * std::exp2(-30.0 * U(rng) * (U(rng) < 0.3)), ax = r * std::cos(ph);
     e_at = std::fmax(e_at, ulp_err(hh::fm::atan2(ay, ax), atan2l((long double)ay, (long double)ax)));
   }
+  // the normal quantile against an 80-bit Newton refinement of Φ(x) = p, Φ by erfcl: body, both tails, far tails
+  double e_nq = 0;
+  for (int i = 0; i < 400000; ++i) {
+    double p = U(rng);
+    if (i % 4 == 1) p = std::exp2(-1000.0 * U(rng));            // far lower tail (third region below 1.4e-11)
+    if (i % 4 == 2) p = 1.0 - std::exp2(-52.0 * U(rng));         // upper tail up to 1 - 2^-52
+    if (!(p > 0.0 && p < 1.0)) continue;
+    const double got = hh::fm::normal_quantile(p);
+    long double x = got;
+    for (int it = 0; it < 4; ++it) {
+      const long double phi = expl(-0.5L * x * x) / sqrtl(2.0L * 3.14159265358979323846264338327950288L);
+      // Φ(x) - p; in the upper half from the complements, 1 - p being exact and erfcl free of cancellation there
+      const long double res = p < 0.5 ? 0.5L * erfcl(-x / sqrtl(2.0L)) - (long double)p
+                                      : (1.0L - (long double)p) - 0.5L * erfcl(x / sqrtl(2.0L));
+      x -= res / phi;
+    }
+    // near p = 1/2 the quantile passes through 0: absolute there
+    e_nq = std::fmax(e_nq, fabsl(x) > 1e-3L ? ulp_err(got, x) : (double)(fabsl((long double)got - x) / 2.2e-19L));
+  }
+  if (!(hh::fm::normal_quantile(0.0) < -1e300) || !(hh::fm::normal_quantile(1.0) > 1e300) ||
+      !std::isnan(hh::fm::normal_quantile(std::nan(""))) || hh::fm::normal_quantile(0.5) != 0.0)
+    e_nq = 1e9;
   // axes and diagonals
   const double pts[][2] = {{0, 1}, {0, -1}, {1, 0}, {-1, 0}, {1, 1}, {-1, 1}, {1, -1}, {-1, -1},
                            {0.4375, 1}, {0.6875, 1}, {1, 0.4375}, {1e-300, 1}, {1, 1e-300}};
@@ -62,7 +84,7 @@ int main() {
   if (!(hh::fm::exp(-2000.0) == 0.0) || !std::isinf(hh::fm::exp(2000.0)) || !(hh::fm::exp(0.0) == 1.0) ||
       !std::isnan(hh::fm::exp(std::nan(""))) || !(hh::fm::exp(-745.0) > 0.0))
     e_exp = 1e9;
-  std::printf("sin %d %.3f\ncos %d %.3f\nlog %d %.3f\natan2 %d %.3f\nexp %d %.3f\nwsin %d %.3f\nwcos %d %.3f\n", N, e_sin,
-              N, e_cos, N, e_log, N, e_at, N, e_exp, N, e_wsin, N, e_wcos);
+  std::printf("sin %d %.3f\ncos %d %.3f\nlog %d %.3f\natan2 %d %.3f\nexp %d %.3f\nwsin %d %.3f\nwcos %d %.3f\nnquant %d %.3f\n", N, e_sin,
+              N, e_cos, N, e_log, N, e_at, N, e_exp, N, e_wsin, N, e_wcos, 400000, e_nq);
   return 0;
 }
