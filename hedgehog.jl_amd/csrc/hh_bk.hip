@@ -474,11 +474,22 @@ __global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(4, 8))) v
   store_draws(p, path, Z, u, VT);
 }
 
+// The key a batched grid chain orders its (date, trajectory) pairs by (launch_bk_grid): the size of the Bessel
+// argument, V0·V_T, coarsely — exponent + three mantissa bits = eighth-octave bins, counted from 2^-28 and cut to ONE
+// radix digit: products below 2^-28 share bin 0, above 2^4 bin 255 (variances from 1e-4 to 1 give 2^-27 … 2^0).
+// Both factors are floored at 2^-1000, so the product is positive, and positive doubles order like their bits.
+__device__ __forceinline__ uint32_t grid_order_key(double v0, double vt) {
+  const int k = (int)((unsigned long long)__double_as_longlong(v0 * vt) >> 49) - ((1023 - 28) << 3);
+  return (uint32_t)(k < 0 ? 0 : k > 255 ? 255 : k);
+}
+
 // The variance chain of dates k0 … k0 + n_dates of a grid, one trajectory per thread: V of each date from the
 // one before (cheap: one non-central χ² draw), its draws left where the chain's pair (date, trajectory) =
 // b·n_row + trajectory finds them, the variance rows written on the way.
+// (keys, idx: non-NULL when the chain will run its pairs in order — each pair's key and its own index, for the sort)
 __global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(4, 8))) void bk_draw_grid_kernel(const BkArgs p, uint64_t n_row, uint32_t k0,
-                                                             uint32_t n_dates, double* __restrict__ var_rows) {
+                                                             uint32_t n_dates, double* __restrict__ var_rows,
+                                                             uint32_t* __restrict__ keys, uint32_t* __restrict__ idx) {
   const uint64_t path = (uint64_t)blockIdx.x * kTile + threadIdx.x;
   if (path >= n_row) return;
   const uint64_t key = p.seeds[path];
@@ -486,8 +497,13 @@ __global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(4, 8))) v
   for (uint32_t b = 0; b < n_dates; ++b) {
     double Z, u, VT;
     draw_transition(p, key, (uint64_t)(k0 + b), V, Z, u, VT);
-    store_draws(p, (uint64_t)b * n_row + path, Z, u, VT);
+    const uint64_t pair = (uint64_t)b * n_row + path;
+    store_draws(p, pair, Z, u, VT);
     var_rows[(uint64_t)(b + 1) * n_row + path] = VT;
+    if (keys) {  // uniform
+      keys[pair] = grid_order_key(V, VT);
+      idx[pair] = (uint32_t)pair;
+    }
     V = VT;
   }
 }
@@ -1272,18 +1288,6 @@ __global__ __launch_bounds__(256) void fill_rows_kernel(double* __restrict__ spo
 // three mantissa bits of V0·V_T, a stable radix sort of (key, pair) — their draws and start variances gathered in
 // that order, the chain run on the gathered arrays, and ∫V scattered back.  Nothing a pair computes depends on
 // its neighbours, and the chain's counters are whole numbers: the grid is the same, bit for bit.
-__global__ __launch_bounds__(256) void grid_keys_kernel(const double* __restrict__ vt, const double* __restrict__ v0,
-                                                        uint32_t n, uint32_t* __restrict__ keys,
-                                                        uint32_t* __restrict__ idx) {
-  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-  if (i >= n) return;
-  const double prod = v0[i] * vt[i];  // > 0 (both are floored at 2^-1000); positive doubles order like their bits
-  // exponent + three mantissa bits = eighth-octave bins, counted from 2^-28 and cut to ONE radix digit: products
-  // below 2^-28 share bin 0, above 2^4 bin 255 (variances from 1e-4 to 1 give 2^-27 … 2^0)
-  const int k = (int)((unsigned long long)__double_as_longlong(prod) >> 49) - ((1023 - 28) << 3);
-  keys[i] = (uint32_t)(k < 0 ? 0 : k > 255 ? 255 : k);
-  idx[i] = i;
-}
 constexpr int kGridKeyBits = 8;
 // below this many pairs the sort and the two copies cost more than the order saves (2.4·10^5 pairs: +8 %; 2.4·10^6: -16 %)
 constexpr uint64_t kGridOrderMinPairs = 1ull << 20;
@@ -1549,10 +1553,12 @@ int launch_bk_grid(const hh_model& m, const hh_config& c, const DevicePtrs& ptr,
   a.iv_out = a.iv_store;
   if ((rc = bk_tables(a, L, ptr, s, upload_tables))) return rc;
   const dim3 rows(tiles_for(n_row)), b(kTile);
-  hipLaunchKernelGGL(bk_draw_grid_kernel, rows, b, 0, s, a, n_row, k0, n_dates, var_rows);
-  if (ptr.bk_sort && n_chain >= kGridOrderMinPairs && n_chain < (1ull << 31)) {  // the pairs in the order of their Bessel arguments (see grid_keys_kernel)
-    const size_t lanes = (size_t)L.n_tiles * kTile;
-    uint32_t* keys_in = reinterpret_cast<uint32_t*>(ptr.bk_sort);
+  const bool ordered = ptr.bk_sort && n_chain >= kGridOrderMinPairs && n_chain < (1ull << 31);
+  const size_t lanes = (size_t)L.n_tiles * kTile;
+  uint32_t* keys_in = reinterpret_cast<uint32_t*>(ptr.bk_sort);
+  hipLaunchKernelGGL(bk_draw_grid_kernel, rows, b, 0, s, a, n_row, k0, n_dates, var_rows, ordered ? keys_in : nullptr,
+                     ordered ? keys_in + 2 * lanes : nullptr);
+  if (ordered) {  // the pairs in the order of their Bessel arguments (grid_order_key)
     uint32_t *keys_out = keys_in + lanes, *idx_in = keys_out + lanes, *perm = idx_in + lanes;
     double* draws_sorted = reinterpret_cast<double*>(perm + lanes);
     double *var_sorted = draws_sorted + 4 * lanes, *iv_sorted = var_sorted + lanes;
@@ -1560,8 +1566,6 @@ int launch_bk_grid(const hh_model& m, const hh_config& c, const DevicePtrs& ptr,
     size_t temp_bytes = grid_sort_temp_bytes(n_chain);
     const uint32_t n = (uint32_t)n_chain;
     const dim3 g256((n + 255u) / 256u), b256(256);
-    hipLaunchKernelGGL(grid_keys_kernel, g256, b256, 0, s, a.draws + 3 * a.draw_stride, static_cast<const double*>(var_rows), n,
-                       keys_in, idx_in);
     if (hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, static_cast<const uint32_t*>(keys_in), keys_out,
                                            static_cast<const uint32_t*>(idx_in), perm, (int)n, 0, kGridKeyBits, s) != hipSuccess)
       return (int)hipErrorUnknown;
