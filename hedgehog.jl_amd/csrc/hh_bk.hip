@@ -138,8 +138,10 @@ struct BkArgs {
   // pairs of the batch, in_var = the variance rows of the batch (row-major, so pair i starts at in_var[i]),
   // in_spot = NULL, and the chain leaves the sampled ∫V of pair i in iv_out[i] instead of a spot
   double* iv_out;
-  const uint32_t* iv_perm;         // a chain that runs its pairs in another order (launch_bk_grid): position s of the
-                                   // chain stands for pair iv_perm[s], and ∫V goes to iv_out[iv_perm[s]]; else NULL
+  const uint32_t* order;           // a chain that runs its pairs in another order (launch_bk_grid): position s of the
+                                   // chain stands for pair order[s] — its draws, its start variance and its ∫V are
+                                   // read and written THERE (pair_of); what the chain keeps for itself (decision words,
+                                   // side-store indices, cached terms) is indexed by s.  NULL: s itself
   double* records;                 // [2·n_tiles][kRecStride]: phase 1, then phase 2
   double* draws;                   // [4][draw_stride]: Z, u, normal quantile of u, V_T per trajectory
   size_t draw_stride;
@@ -175,6 +177,16 @@ struct BkArgs {
                                    // a by-value kernel argument by reference to its functions would put
                                    // a 2 KB copy per lane in scratch
 };
+
+// where the draws / start state / results of the chain's position `path` lie
+// (ORD: what the kernel was compiled for — the two hot kernels exist in both forms, so that the plain chain pays
+// nothing for the order: the test in the kernel cost it 1 %; -1: look at p.order)
+template <int ORD = -1>
+__device__ __forceinline__ uint64_t pair_of(const BkArgs& p, uint64_t path) {
+  if (ORD == 0) return path;
+  if (ORD == 1) return (uint64_t)p.order[path];
+  return p.order ? (uint64_t)p.order[path] : path;
+}
 
 // 1/x to <= 1 ulp: hardware reciprocal + two Newton steps (5 instructions; the IEEE division
 // sequence is 12).  The quantities divided here are moderate in size: no scaling needed.
@@ -564,8 +576,9 @@ __device__ __forceinline__ void bk_setup(const BkArgs& p, const BesselTable* bt,
   s.cache.j_stop = 0;
   s.cache.theta_run = __builtin_nan("");
   s.cache.theta_cap = __builtin_nan("");
-  const double V0 = p.in_var ? p.in_var[path] : p.V0;
-  const double* d = p.draws + path;
+  const uint64_t src = pair_of(p, path);
+  const double V0 = p.in_var ? p.in_var[src] : p.V0;
+  const double* d = p.draws + src;
   s.u = d[p.draw_stride];
   cf_setup(p, bt, V0, d[3 * p.draw_stride], d[2 * p.draw_stride], s.cf, s.initial_guess, s.max_guess, s.h);
 }
@@ -581,7 +594,7 @@ __device__ __forceinline__ double bk_spot(const BkArgs& p, double logS0, double 
 __device__ __forceinline__ double bk_finish(const BkArgs& p, double logS0, double V0, double VT,
                                             double Z, double IV, uint64_t path) {
   if (p.iv_out) {  // a batch of dates: the spot rows are chained afterwards (bk_grid_spots_kernel)
-    p.iv_out[p.iv_perm ? p.iv_perm[path] : path] = IV;
+    p.iv_out[path] = IV;
     return 0.0;
   }
   const double S = bk_spot(p, logS0, V0, VT, Z, IV);
@@ -595,10 +608,11 @@ __device__ __forceinline__ double bk_finish(const BkArgs& p, double logS0, doubl
 }
 // … and the finish of that trajectory from its sampled ∫V
 __device__ __forceinline__ double bk_finish_path(const BkArgs& p, uint64_t path, double IV) {
-  const double V0 = p.in_var ? p.in_var[path] : p.V0;
-  const double logS0 = p.in_spot ? fm::log(p.in_spot[path]) : p.logS0;  // heston.jl:84: S = exp(W[1]), then log(S0) :289
-  const double* d = p.draws + path;
-  return bk_finish(p, logS0, V0, d[3 * p.draw_stride], d[0], IV, path);
+  const uint64_t src = pair_of(p, path);
+  const double V0 = p.in_var ? p.in_var[src] : p.V0;
+  const double logS0 = p.in_spot ? fm::log(p.in_spot[src]) : p.logS0;  // heston.jl:84: S = exp(W[1]), then log(S0) :289
+  const double* d = p.draws + src;
+  return bk_finish(p, logS0, V0, d[3 * p.draw_stride], d[0], IV, src);
 }
 
 // … and the spot rows of the same dates once the chain has left ∫V of every pair in iv_out: log S chained date by
@@ -713,12 +727,14 @@ __device__ __forceinline__ bool secant_inverse(Cdf&& cdf, double u, double guess
 // is what fits 128 registers (4 waves per SIMD).  Returns h, the secant's first guess and the series
 // length (0: longer than the cache — the fall-back kernel runs this trajectory whole); leaves them
 // with max_guess in rec[] for the ladder kernel.
+template <int ORD>
 __device__ __forceinline__ void series_phase(const BkArgs& p, const BesselTable* bt, uint64_t path, double* col,
                                              size_t col_stride, double& h, double& initial_guess,
                                              double& max_guess, int& j_stop) {
   const bool grid = p.in_var != nullptr;
-  const double V0 = grid ? p.in_var[path] : p.V0;
-  const double* d = p.draws + path;
+  const uint64_t src = pair_of<ORD>(p, path);
+  const double V0 = grid ? p.in_var[src] : p.V0;
+  const double* d = p.draws + src;
   const double q_u = d[2 * p.draw_stride];
   const double VT = d[3 * p.draw_stride];
   CfIter cf;
@@ -798,13 +814,15 @@ __device__ __forceinline__ double cdf_cached(const double (&t)[kRegTerms], const
 // It is flagged in a per-wave ballot instead and finished, densely packed, by bk_ladder_kernel;
 // so is a trajectory whose series did not fit the cache (bk_fallback_kernel).  Flags are ballots in
 // trajectory order, so the result is bit-reproducible.  Called by every thread of the workgroup.
+template <int ORD>
 __device__ __forceinline__ void invert_phase(const BkArgs& p, const double* coef, uint32_t tile, uint32_t tid, uint64_t path,
                                              bool live, const double* col, double h, double guess,
                                              double max_guess, int j_stop) {
   double acc[6] = {0, 0, 0, 0, 0, 0};  // Σp, Σp², newton_fail, bisect, maxguess, cf_terms
   bool failed = false, too_long = false;
   if (live) {
-    const double u = p.draws[p.draw_stride + path];
+    const uint64_t src = pair_of<ORD>(p, path);
+    const double u = p.draws[p.draw_stride + src];
     p.diag[p.draw_stride + path] = (uint32_t)j_stop;
     if (j_stop == 0) {
       too_long = true;
@@ -821,10 +839,10 @@ __device__ __forceinline__ void invert_phase(const BkArgs& p, const double* coef
       acc[5] = n_terms;
       if (ok) {
         const bool grid = p.in_var != nullptr;
-        const double V0 = grid ? p.in_var[path] : p.V0;
-        const double logS0 = p.in_spot ? fm::log(p.in_spot[path]) : p.logS0;  // heston.jl:84, :289
-        const double pay = bk_finish(p, logS0, V0, p.draws[3 * p.draw_stride + path], p.draws[path],
-                                     IV, path);
+        const double V0 = grid ? p.in_var[src] : p.V0;
+        const double logS0 = p.in_spot ? fm::log(p.in_spot[src]) : p.logS0;  // heston.jl:84, :289
+        const double pay = bk_finish(p, logS0, V0, p.draws[3 * p.draw_stride + src], p.draws[src],
+                                     IV, src);
         acc[0] = pay;
         acc[1] = pay * pay;
       } else {
@@ -940,6 +958,7 @@ __device__ __forceinline__ void give_slot(const BkArgs& p, uint32_t slot) {
 #else
 #define HH_BK_CF_OCC
 #endif
+template <int ORD>
 __global__ __launch_bounds__(kTile) HH_BK_CF_OCC void bk_cf_kernel(const BkArgs p, const BkTables* __restrict__ tabs) {
   const uint32_t tile = blockIdx.x, tid = threadIdx.x;
   const uint64_t path = (uint64_t)tile * kTile + tid;
@@ -949,8 +968,8 @@ __global__ __launch_bounds__(kTile) HH_BK_CF_OCC void bk_cf_kernel(const BkArgs 
   double* col = p.phi_cache + (size_t)slot * kTile + tid;
   double h = 0.0, guess = 0.0, max_guess = 0.0;
   int j_stop = 0;
-  if (live) series_phase(p, bt, path, col, p.cache_stride, h, guess, max_guess, j_stop);
-  invert_phase(p, tabs->coef, tile, tid, path, live, col, h, guess, max_guess, j_stop);
+  if (live) series_phase<ORD>(p, bt, path, col, p.cache_stride, h, guess, max_guess, j_stop);
+  invert_phase<ORD>(p, tabs->coef, tile, tid, path, live, col, h, guess, max_guess, j_stop);
   give_slot(p, slot);
 }
 
@@ -1055,6 +1074,7 @@ __device__ __forceinline__ uint64_t packed_path(const unsigned long long* mask, 
 // same terms — into the column of the slot THIS workgroup takes.  One work item
 // per lane, no loop (see bk_cf_kernel): the grid covers the worst case (every trajectory failed) and the
 // workgroups beyond the packed list leave at once, without a record (bk_live_records).
+template <int ORD>
 __global__ __launch_bounds__(kTile) void bk_ladder_kernel(const BkArgs p, const BkTables* __restrict__ tabs,
                                                           uint32_t n_tiles,
                                                           const uint32_t* __restrict__ prefix) {
@@ -1094,9 +1114,10 @@ __global__ __launch_bounds__(kTile) void bk_ladder_kernel(const BkArgs p, const 
       terms = e + 2;
       tstride = 1;
     } else {  // too long for an entry, or the store was full: evaluate it again
-      series_phase(p, bt, path, col, stride, h, guess, max_guess, j_stop);
+      series_phase<ORD>(p, bt, path, col, stride, h, guess, max_guess, j_stop);
     }
-    const double u = p.draws[p.draw_stride + path];
+    const uint64_t src = pair_of<ORD>(p, path);
+    const double u = p.draws[p.draw_stride + src];
     double t[kRegTerms];
     load_terms(terms, tstride, j_stop, t);
     double n_terms = 0.0, IV;
@@ -1134,9 +1155,9 @@ __global__ __launch_bounds__(kTile) void bk_ladder_kernel(const BkArgs p, const 
     p.diag[path] = dec;
     acc[5] += n_terms;
     const bool grid = p.in_var != nullptr;
-    const double V0 = grid ? p.in_var[path] : p.V0;
-    const double logS0 = p.in_spot ? fm::log(p.in_spot[path]) : p.logS0;
-    const double pay = bk_finish(p, logS0, V0, p.draws[3 * p.draw_stride + path], p.draws[path], IV, path);
+    const double V0 = grid ? p.in_var[src] : p.V0;
+    const double logS0 = p.in_spot ? fm::log(p.in_spot[src]) : p.logS0;
+    const double pay = bk_finish(p, logS0, V0, p.draws[3 * p.draw_stride + src], p.draws[src], IV, src);
     acc[0] += pay;
     acc[1] = fma(pay, pay, acc[1]);
   }
@@ -1285,35 +1306,13 @@ __global__ __launch_bounds__(256) void fill_rows_kernel(double* __restrict__ spo
 // expansion) with series of different lengths, and the CF kernel runs at 0.53 active lanes per instruction
 // (profiles/r05_d_bk_refill_experiment.txt).  The same draws sorted by V_T run the chain 32 % faster
 // (profiles/r05_e_bk_sorted_short_T.txt).  So the pairs of a chain are ordered by a coarse key — exponent and
-// three mantissa bits of V0·V_T, a stable radix sort of (key, pair) — their draws and start variances gathered in
-// that order, the chain run on the gathered arrays, and ∫V scattered back.  Nothing a pair computes depends on
-// its neighbours, and the chain's counters are whole numbers: the grid is the same, bit for bit.
+// three mantissa bits of V0·V_T (grid_order_key, made by the variance kernel), a stable radix sort of (key, pair) —
+// and the chain runs its positions in that order, reading and writing each pair where it lies (BkArgs::order).
+// Nothing a pair computes depends on its neighbours, and the chain's counters are whole numbers: the grid is the
+// same, bit for bit.
 constexpr int kGridKeyBits = 8;
-// below this many pairs the sort and the two copies cost more than the order saves (2.4·10^5 pairs: +8 %; 2.4·10^6: -16 %)
+// below this many pairs the sort costs more than the order saves (2.4·10^5 pairs: +8 %; 2.4·10^6: -25 %)
 constexpr uint64_t kGridOrderMinPairs = 1ull << 20;
-
-// The draws and start variances into the chain's order.  NOT a gather by destination (out[s] = in[perm[s]]): the
-// sort is stable on 256 coarse keys, so neighbouring destinations come from sources a few hundred elements apart and
-// every 128-byte source line was fetched some six times over (0.19 ms for 2.4·10^6 pairs, a sixth of the whole
-// grid).  By SOURCE instead: the inverse permutation first (4 bytes per pair), then every source line is read once,
-// coalesced, and each element goes to its key's run — 256 runs that each fill front to back, so the L2 completes
-// their lines before it writes them.
-__global__ __launch_bounds__(256) void grid_inverse_kernel(const uint32_t* __restrict__ perm, uint32_t n,
-                                                           uint32_t* __restrict__ inv) {
-  const uint32_t s = blockIdx.x * 256u + threadIdx.x;
-  if (s < n) inv[perm[s]] = s;
-}
-__global__ __launch_bounds__(256) void grid_spread_kernel(const double* __restrict__ draws, size_t stride,
-                                                          const double* __restrict__ v0, const uint32_t* __restrict__ inv,
-                                                          uint32_t n, double* __restrict__ draws_out,
-                                                          double* __restrict__ v0_out) {
-  const uint32_t j = blockIdx.x * 256u + threadIdx.x;
-  if (j >= n) return;
-  const uint32_t s = inv[j];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) draws_out[(size_t)k * stride + s] = draws[(size_t)k * stride + j];
-  v0_out[s] = v0[j];
-}
 
 }  // namespace
 
@@ -1473,9 +1472,15 @@ int bk_tables(const BkArgs& a, const BkLayout& L, const DevicePtrs& ptr, hipStre
 void bk_chain(const BkArgs& a, const BkLayout& L, hipStream_t s) {
   const dim3 b(kTile), g(L.n_tiles);
   const BkTables* tabs = static_cast<const BkTables*>(L.tabs_dev);
-  hipLaunchKernelGGL(bk_cf_kernel, g, b, 0, s, a, tabs);
+  if (a.order)
+    hipLaunchKernelGGL(bk_cf_kernel<1>, g, b, 0, s, a, tabs);
+  else
+    hipLaunchKernelGGL(bk_cf_kernel<0>, g, b, 0, s, a, tabs);
   hipLaunchKernelGGL(bk_scan_kernel, dim3(1), dim3(kScanThreads), 0, s, a, L.n_tiles, L.prefix, L.prefix_long);
-  hipLaunchKernelGGL(bk_ladder_kernel, g, b, 0, s, a, tabs, L.n_tiles, L.prefix);
+  if (a.order)
+    hipLaunchKernelGGL(bk_ladder_kernel<1>, g, b, 0, s, a, tabs, L.n_tiles, L.prefix);
+  else
+    hipLaunchKernelGGL(bk_ladder_kernel<0>, g, b, 0, s, a, tabs, L.n_tiles, L.prefix);
   hipLaunchKernelGGL(bk_fallback_kernel, dim3(kHeavyGrid), b, 0, s,
                      static_cast<const BkArgs*>(a.args_dev), tabs, L.n_tiles, L.prefix_long);
 }
@@ -1528,8 +1533,8 @@ void bk_diag_ptrs(const void* scratch, uint64_t n_paths, int term_cache, const u
   *series_len = diag + lanes;
 }
 
-// device scratch of the ordered form of a grid chain over n_chain pairs: keys and pair indices (in / out), the
-// gathered draws [4], start variances and ∫V, the radix sort's own storage
+// device scratch of the ordered form of a grid chain over n_chain pairs: keys and pair indices (in / out), the radix
+// sort's own storage
 static size_t grid_sort_temp_bytes(uint64_t n_chain) {
   size_t bytes = 0;
   (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr,
@@ -1538,7 +1543,7 @@ static size_t grid_sort_temp_bytes(uint64_t n_chain) {
 }
 size_t bk_grid_sort_bytes(uint64_t n_chain) {
   const size_t lanes = (size_t)tiles_for(n_chain) * kTile;
-  return 4 * lanes * sizeof(uint32_t) + 6 * lanes * sizeof(double) + grid_sort_temp_bytes(n_chain) + 256;
+  return 4 * lanes * sizeof(uint32_t) + grid_sort_temp_bytes(n_chain) + 256;  // keys and pair indices, in and out
 }
 
 int launch_bk_grid(const hh_model& m, const hh_config& c, const DevicePtrs& ptr, hipStream_t s,
@@ -1560,24 +1565,17 @@ int launch_bk_grid(const hh_model& m, const hh_config& c, const DevicePtrs& ptr,
                      ordered ? keys_in + 2 * lanes : nullptr);
   if (ordered) {  // the pairs in the order of their Bessel arguments (grid_order_key)
     uint32_t *keys_out = keys_in + lanes, *idx_in = keys_out + lanes, *perm = idx_in + lanes;
-    double* draws_sorted = reinterpret_cast<double*>(perm + lanes);
-    double *var_sorted = draws_sorted + 4 * lanes, *iv_sorted = var_sorted + lanes;
-    void* temp = iv_sorted + lanes;
+    void* temp = perm + lanes;
     size_t temp_bytes = grid_sort_temp_bytes(n_chain);
-    const uint32_t n = (uint32_t)n_chain;
-    const dim3 g256((n + 255u) / 256u), b256(256);
     if (hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, static_cast<const uint32_t*>(keys_in), keys_out,
-                                           static_cast<const uint32_t*>(idx_in), perm, (int)n, 0, kGridKeyBits, s) != hipSuccess)
+                                           static_cast<const uint32_t*>(idx_in), perm, (int)n_chain, 0, kGridKeyBits, s) != hipSuccess)
       return (int)hipErrorUnknown;
-    uint32_t* inv = keys_in;  // (the keys are dead once sorted)
-    hipLaunchKernelGGL(grid_inverse_kernel, g256, b256, 0, s, static_cast<const uint32_t*>(perm), n, inv);
-    hipLaunchKernelGGL(grid_spread_kernel, g256, b256, 0, s, static_cast<const double*>(a.draws), a.draw_stride,
-                       static_cast<const double*>(var_rows), static_cast<const uint32_t*>(inv), n, draws_sorted, var_sorted);
-    BkArgs o = a;  // the chain on the gathered arrays: position s of the order stands for pair perm[s]
-    o.draws = draws_sorted;
-    o.draw_stride = lanes;
-    o.in_var = var_sorted;
-    o.iv_perm = perm;  // ∫V straight to its pair's place (was: a sorted array and a scatter pass of its own, 35 µs)
+    // The chain reads each pair's draws and start variance, and writes its ∫V, THROUGH the order (BkArgs::order): a
+    // pair's 48 bytes, fetched at random by a kernel that then computes for 0.3 µs per pair, hide behind the other
+    // waves' arithmetic.  Copying them into the order first (a gather by destination 0.19 ms; by source through the
+    // inverse permutation 0.10 ms) and scattering ∫V back (0.035) were passes the chain does not need.
+    BkArgs o = a;
+    o.order = perm;
     bk_chain(o, L, s);
   } else {
     bk_chain(a, L, s);

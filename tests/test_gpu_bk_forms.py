@@ -98,3 +98,25 @@ def test_ladder_one_chunk_spanning_every_tile(hhlib, check_lib):
     assert t1.tobytes() == t0.tobytes()
     assert r1.price == r0.price and r1.bk_newton_fail == r0.bk_newton_fail and r1.bk_bisect_fallback == r0.bk_bisect_fallback
     assert 0 < r1.bk_newton_fail <= 96  # sparse: fewer than one failure per four tiles, yet some
+
+
+def test_model_constants_beside_the_bessel_tables_follow_the_model(hhlib):
+    """The tables a chain finds in place are keyed by ν — and, since ϕ(0) takes four model constants from there (CfZero:
+    functions of κ, σ², T), by those too.  Three models with the SAME ν = 2κθ/σ² − 1 solved back to back in one context,
+    each against a context of its own."""
+    base = dict(PARAMS["h252"])
+    models = [base,
+              dict(base, kappa=4.0, theta=0.02),            # κθ unchanged: the same ν, another κ
+              dict(base, T=0.5),                            # the same ν, κ, σ: another T
+              dict(base, kappa=8.0, theta=0.04, sigma=0.6)]  # κθ/σ² unchanged: another σ² as well
+    nus = {round(2 * m["kappa"] * m["theta"] / m["sigma"] ** 2 - 1, 12) for m in models}
+    assert len(nus) == 1
+    n = 20_000
+    shared = [solve(hhlib.lib, hhlib.handle, m, n, 5)[1] for m in models + models[::-1]]
+    for m, got in zip(models + models[::-1], shared):
+        ctx = _ffi.Context(0)
+        try:
+            want = solve(ctx.lib, ctx.handle, m, n, 5)[1]
+        finally:
+            ctx.close()
+        assert got.tobytes() == want.tobytes()
