@@ -1093,19 +1093,27 @@ __global__ __launch_bounds__(kTile) void bk_ladder_kernel(const BkArgs p, const 
     __syncthreads();
   }
   const BesselTable* bt = tabs->t;
-  const uint32_t slot = take_slot(p, blockIdx.x);
-  double* col = p.phi_cache + (size_t)slot * kTile + threadIdx.x;
   const size_t stride = p.cache_stride;
   double acc[6] = {0, 0, 0, 0, 0, 0};
   const uint32_t g = blockIdx.x * kTile + threadIdx.x;
+  uint64_t path = 0;
+  uint32_t k = 0;
   if (g < total) {
-    const uint64_t path = staged ? packed_path(p.fail_mask, pre_sh, t_lo, t_hi + 1u, g, t_lo)
-                                 : packed_path(p.fail_mask, prefix, t_lo, t_hi + 1u, g);
+    path = staged ? packed_path(p.fail_mask, pre_sh, t_lo, t_hi + 1u, g, t_lo)
+                  : packed_path(p.fail_mask, prefix, t_lo, t_hi + 1u, g);
+    k = p.diag[2 * p.draw_stride + path];
+  }
+  // A column of the term cache only if some trajectory here has to evaluate its series again — with the reference's
+  // controls none has (every failed series is in the side store), and taking a slot is two atomics and two
+  // barriers in front of 4 µs of work
+  const bool need_slot = __syncthreads_or(g < total && k == kNoSide) != 0;  // (uniform)
+  const uint32_t slot = need_slot ? take_slot(p, blockIdx.x) : 0u;
+  double* col = p.phi_cache + (size_t)slot * kTile + threadIdx.x;
+  if (g < total) {
     double h, guess, max_guess;
     int j_stop;
     const double* terms = col;
     size_t tstride = stride;
-    const uint32_t k = p.diag[2 * p.draw_stride + path];
     if (k != kNoSide) {  // its series waits in the side store
       const double* e = p.side + (size_t)k * kSideEntry;
       h = e[0];
@@ -1162,7 +1170,7 @@ __global__ __launch_bounds__(kTile) void bk_ladder_kernel(const BkArgs p, const 
     acc[1] = fma(pay, pay, acc[1]);
   }
   bk_store_record(acc, rec);
-  give_slot(p, slot);
+  if (need_slot) give_slot(p, slot);
 }
 
 // Fall-back kernel: trajectories whose series did not fit the cache (cf_tol far below the reference's
