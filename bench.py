@@ -853,7 +853,7 @@ def main():
                 "paths_per_s": n_paths / (t4 * 1e-3), "solve_ms": t4, "kernel_ms": t4, "price": r4.price,
                 "std_error": r4.std_error, "cf_terms_per_path": r4.bk_cf_terms / n_paths,
                 "bisect_fallbacks": int(r4.bk_bisect_fallback),
-                "roofline": valu_roofline("bk_kernel + bk_scan_kernel + bk_fallback_kernel",
+                "roofline": valu_roofline("bk_draw_kernel + bk_cf_kernel + bk_scan_kernel + bk_ladder_kernel + bk_fallback_kernel + reduce_records_kernel",
                                           "broadie_kaya", float(n_paths), t4, vt)},
             "config3_antithetic_replay": {
                 "integrated_path_steps_per_s": 2.0 * n_paths * n_steps / (ta * 1e-3),
@@ -964,7 +964,7 @@ def main():
             "heston_exact_grid_2e5_paths_x_12_dates": {
                 "kernel_ms": t_grid, "transitions_per_s": n_g * st_g / (t_grid * 1e-3),
                 "cf_terms_per_transition": r_g.bk_cf_terms / (n_g * st_g),
-                "roofline": valu_roofline("bk_draw_grid + ONE bk chain over all (date, trajectory) pairs + bk_grid_spots",
+                "roofline": valu_roofline("bk_draw_grid_kernel + radix sort of the pairs + ONE bk chain over all (date, trajectory) pairs, read through the order + bk_grid_spots_kernel",
                                           "heston_exact_grid", float(n_g) * st_g, t_grid, vt)},
         }
 
