@@ -827,6 +827,12 @@ def main():
         c4 = _ffi.make_config(_ffi.HH_HESTON, _ffi.HH_BROADIE_KAYA, n_paths)
         c4.seeds, c4.seeds_on_device = sh.seeds.data_ptr(), 1
         t4, r4 = kernel_ms(model, c4, reps=5)
+        # the same law at ten times the size: what does not scale with the ensemble (the chain's small kernels, the CF
+        # kernel filling and draining: 74 us, profiles/r05_k_bk_sizes.txt) is 21 % of the 10^6 row and 2.5 % of this one
+        n4b = 10_000_000
+        c4b = _ffi.make_config(_ffi.HH_HESTON, _ffi.HH_BROADIE_KAYA, n4b)
+        c4b.seeds, c4b.seeds_on_device = sh.seeds.data_ptr(), 1
+        t4b, r4b = kernel_ms(model, c4b, reps=5)
         m2 = _ffi.make_model(S0=100.0, sigma=0.2, r=0.05, T=1.0, strike=100.0)
         c2 = _ffi.make_config(_ffi.HH_LOGNORMAL, _ffi.HH_EXACT_LAW, n_paths)
         c2.seeds, c2.seeds_on_device = sh.seeds.data_ptr(), 1
@@ -855,6 +861,11 @@ def main():
                 "bisect_fallbacks": int(r4.bk_bisect_fallback),
                 "roofline": valu_roofline("bk_draw_kernel + bk_cf_kernel + bk_scan_kernel + bk_ladder_kernel + bk_fallback_kernel + reduce_records_kernel",
                                           "broadie_kaya", float(n_paths), t4, vt)},
+            "config4_broadie_kaya_1e7": {
+                "paths": n4b, "paths_per_s": n4b / (t4b * 1e-3), "solve_ms": t4b, "price": r4b.price,
+                "std_error": r4b.std_error, "cf_terms_per_path": r4b.bk_cf_terms / n4b,
+                "note": "the 10^6 row is BASELINE's size; this one shows the chain where its fixed 74 us no longer count",
+                "roofline": valu_roofline("the same chain of kernels", "broadie_kaya", float(n4b), t4b, vt)},
             "config3_antithetic_replay": {
                 "integrated_path_steps_per_s": 2.0 * n_paths * n_steps / (ta * 1e-3),
                 "solve_ms": ta, "kernel_ms": ta, "price": ra.price, "std_error": ra.std_error,
