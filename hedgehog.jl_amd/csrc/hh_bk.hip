@@ -62,6 +62,9 @@ constexpr double kInvPi = 0.31830988618379067154, kTwoOverPi = 0.636619772367581
 #ifndef HH_BK_COMPLEX_SETUP
 #define HH_BK_COMPLEX_SETUP 0
 #endif
+#ifndef HH_BK_FUSE_DRAWS
+#define HH_BK_FUSE_DRAWS 1
+#endif
 #ifndef HH_BK_LADDER_SPAN
 #define HH_BK_LADDER_SPAN 1024
 #endif
@@ -958,11 +961,18 @@ __device__ __forceinline__ void give_slot(const BkArgs& p, uint32_t slot) {
 #else
 #define HH_BK_CF_OCC
 #endif
-template <int ORD>
+// (DRAW: the trajectory's three draws are made here instead of by bk_draw_kernel in front — the one-shot law in
+// GENERATE mode: a tile needs only its own draws, so the separate launch bought nothing but its own fill and drain)
+template <int ORD, bool DRAW = false>
 __global__ __launch_bounds__(kTile) HH_BK_CF_OCC void bk_cf_kernel(const BkArgs p, const BkTables* __restrict__ tabs) {
   const uint32_t tile = blockIdx.x, tid = threadIdx.x;
   const uint64_t path = (uint64_t)tile * kTile + tid;
   const bool live = path < p.n_paths;
+  if (DRAW && live) {
+    double Z, u, VT;
+    draw_transition(p, p.seeds[0], p.path_offset + path, p.V0, Z, u, VT);
+    store_draws(p, path, Z, u, VT);
+  }
   const BesselTable* bt = tabs->t;
   const uint32_t slot = take_slot(p, tile);
   double* col = p.phi_cache + (size_t)slot * kTile + tid;
@@ -1477,11 +1487,13 @@ int bk_tables(const BkArgs& a, const BkLayout& L, const DevicePtrs& ptr, hipStre
 }
 
 // CF work, prefix sums, ladder, fall-back — everything behind the draws
-void bk_chain(const BkArgs& a, const BkLayout& L, hipStream_t s) {
+void bk_chain(const BkArgs& a, const BkLayout& L, hipStream_t s, bool draw_in_chain = false) {
   const dim3 b(kTile), g(L.n_tiles);
   const BkTables* tabs = static_cast<const BkTables*>(L.tabs_dev);
   if (a.order)
     hipLaunchKernelGGL(bk_cf_kernel<1>, g, b, 0, s, a, tabs);
+  else if (draw_in_chain)
+    hipLaunchKernelGGL((bk_cf_kernel<0, true>), g, b, 0, s, a, tabs);
   else
     hipLaunchKernelGGL(bk_cf_kernel<0>, g, b, 0, s, a, tabs);
   hipLaunchKernelGGL(bk_scan_kernel, dim3(1), dim3(kScanThreads), 0, s, a, L.n_tiles, L.prefix, L.prefix_long);
@@ -1509,11 +1521,12 @@ int launch_bk(const hh_model& m, const hh_config& c, const DevicePtrs& ptr, hipS
   a.replay = c.noise_mode == HH_NOISE_REPLAY ? ptr.replay : nullptr;
   if ((rc = bk_tables(a, L, ptr, s, upload_tables))) return rc;
   const dim3 g(L.n_tiles), b(kTile);
+  const bool fuse_draws = HH_BK_FUSE_DRAWS && !a.replay && !a.in_var;  // the terminal law, drawn here
   if (a.replay)
     hipLaunchKernelGGL(bk_draw_kernel<true>, g, b, 0, s, a);
-  else
+  else if (!fuse_draws)
     hipLaunchKernelGGL(bk_draw_kernel<false>, g, b, 0, s, a);
-  bk_chain(a, L, s);
+  bk_chain(a, L, s, fuse_draws);
   return (int)hipGetLastError();
 }
 
