@@ -859,7 +859,7 @@ def main():
                 "paths_per_s": n_paths / (t4 * 1e-3), "solve_ms": t4, "kernel_ms": t4, "price": r4.price,
                 "std_error": r4.std_error, "cf_terms_per_path": r4.bk_cf_terms / n_paths,
                 "bisect_fallbacks": int(r4.bk_bisect_fallback),
-                "roofline": valu_roofline("bk_draw_kernel + bk_cf_kernel + bk_scan_kernel + bk_ladder_kernel + bk_fallback_kernel + reduce_records_kernel",
+                "roofline": valu_roofline("bk_cf_kernel (draws, series, inversion) + bk_scan_kernel + bk_ladder_kernel + bk_fallback_kernel + reduce_records_kernel",
                                           "broadie_kaya", float(n_paths), t4, vt)},
             "config4_broadie_kaya_1e7": {
                 "paths": n4b, "paths_per_s": n4b / (t4b * 1e-3), "solve_ms": t4b, "price": r4b.price,

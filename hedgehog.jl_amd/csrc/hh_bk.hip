@@ -8,16 +8,17 @@
 //   3. log S_T = μ + sqrt((1-ρ²)∫V)·Z                         heston.jl:278-300
 // then S_T = exp(.), payoff and the workgroup reduction as in hh_kernels.hip.
 //
-// Launch structure: bk_tables_kernel (the Bessel tables of ν into device memory) -> bk_draw_kernel (the
-// trajectory's three draws V_T, u, Z — or the caller's, in REPLAY mode — and the normal quantile of u)
-// -> bk_cf_kernel (characteristic function, moments, series terms, then the secant inversion on the
-// cached terms; -DHH_BK_FUSED=0: bk_series_kernel and bk_invert_kernel apart) -> bk_scan_kernel ->
+// Launch structure: bk_tables_kernel (the Bessel tables of ν and the model's ϕ(0) constants into device memory, when
+// they are not there already) -> bk_draw_kernel (the caller's three draws V_T, u, Z in REPLAY mode, and the normal
+// quantile of u; in GENERATE mode the one-shot law's draws are made by the CF kernel itself, a grid's by its variance
+// kernel) -> bk_cf_kernel (draws, characteristic function, moments, series terms, then the secant inversion on the
+// cached terms) -> bk_scan_kernel ->
 // bk_ladder_kernel (bisection ladder for the flagged trajectories, packed) -> bk_fallback_kernel
 // (trajectories whose series outgrew the term cache; none with the reference's controls).
-// The draws live in their own launch because the NCχ² sampler's library calls (pow, lgamma, log) and the CF
-// arithmetic are two different register-hungry programs: together they cost 228 registers per lane (2 waves
-// per SIMD); apart, the CF kernel fits 96 (5 waves).  (The normal quantile of u is hh_math.h's own since round 5 —
-// the library's normcdfinv was a third of the draw kernel.)
+// (Until round 5 the draws always had a launch of their own: with the library's pow / lgamma / log / normcdfinv and
+// machine LICM hoisting their literals, sampler and CF arithmetic together took 228 registers per lane.  Built
+// without that pass, and with hh_math.h's own normal quantile — the library's normcdfinv was a third of the draw
+// kernel — the sampler takes 92 and the CF arithmetic 95: one kernel of 95, five waves per SIMD.)
 //
 // Third-party pieces of the reference restated here from their published algorithms (DESIGN.md
 // "Broadie–Kaya"): complex log I_ν(z) for real ν > -1 (power series / Hankel asymptotics /
