@@ -779,7 +779,7 @@ def main():
         # `solve_ms` of the rows below is the HIP-event time of EVERYTHING one hh_mc_accumulate enqueues (since
         # round 5 the timing hook brackets the call's last kernel too: a record reduction that is a kernel of its
         # own — Broadie–Kaya, baskets — is inside)
-        def multi_ms(models, cfg, reps=20, warm_ms=40.0):
+        def multi_ms(models, cfg, reps=20, warm_ms=40.0, slots_per_call=1):
             K = len(models)
             arr = (_ffi.hh_model * K)(*models)
             acc_k = torch.zeros(K * _ffi.HH_ACC_LEN, dtype=torch.float64, device=dev)
@@ -792,7 +792,8 @@ def main():
             ctx.enable_timing(True)
             for _ in range(reps):
                 call()
-            t = float(np.median(ctx.read_timings()))
+            # (a Broadie–Kaya call closes one timing slot per model: the chain's, then each finish pass's)
+            t = float(np.median(np.asarray(ctx.read_timings()).reshape(reps, slots_per_call).sum(axis=1)))
             ctx.enable_timing(False)
             a = acc_k.cpu().numpy().copy()
             return t, [finalize(models[k], cfg, a[k * _ffi.HH_ACC_LEN:(k + 1) * _ffi.HH_ACC_LEN].copy()) for k in range(K)]
@@ -823,6 +824,19 @@ def main():
                                                 float(n_paths) * n_steps, t_two, vt)
             fd[key] = ent
         out["fd_central_delta_H252"] = fd
+        # … and of the same delta on the exact (Broadie–Kaya) law: a bumped spot is invisible to the variance process, so
+        # ONE chain serves both models (bk_refinish_kernel) — the reference has no other way to a Broadie–Kaya Greek
+        # than these bumps (no dual numbers through rand!, heston.jl:261-276)
+        cbk = _ffi.make_config(_ffi.HH_HESTON, _ffi.HH_BROADIE_KAYA, n_paths)
+        cbk.seeds, cbk.seeds_on_device = sh.seeds.data_ptr(), 1
+        t_bk1, _ = kernel_ms(fd_models[0], cbk, reps=5)
+        t_bk2, rbk = multi_ms(fd_models, cbk, reps=10, warm_ms=20.0, slots_per_call=2)
+        out["fd_central_delta_broadie_kaya"] = {
+            "what": "solve(GreekProblem(prob, spot), FiniteDifference(1e-3), MonteCarlo(HestonBroadieKaya)): two full solves "
+                    "in the reference; here one chain and a finish pass — each price bit-identical to its own solve "
+                    "(tests/test_gpu_multi.py)",
+            "solve_ms": t_bk2, "two_separate_solves_ms": 2 * t_bk1, "ratio": t_bk2 / (2 * t_bk1),
+            "delta": (rbk[0].price - rbk[1].price) / (2 * eps * H252["S0"]), "delta_fourier": H252_GREEKS_FOURIER[0]}
 
         c4 = _ffi.make_config(_ffi.HH_HESTON, _ffi.HH_BROADIE_KAYA, n_paths)
         c4.seeds, c4.seeds_on_device = sh.seeds.data_ptr(), 1

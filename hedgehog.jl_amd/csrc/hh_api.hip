@@ -535,10 +535,47 @@ int hh_mc_accumulate_multi(hh_ctx* ctx, const hh_model* models, uint32_t n_model
   if (c->n_partials)
     return fail(ctx, HH_ERR_UNSUPPORTED, "several models in one pass carry no dual partials (n_partials must be 0)");
   if (n_models == 1) return hh_mc_accumulate(ctx, models, c, accum_dev, terminals ? terminals[0] : nullptr);
-  if (c->strategy == HH_BROADIE_KAYA) {  // the CF inversion has no state to share: one chain per model
+  if (c->strategy == HH_BROADIE_KAYA) {
+    // One chain per set of models that the variance process cannot tell apart (hh::bk_same_chain: a bumped spot, rate,
+    // ρ, strike — the finite-difference delta / gamma / rho of greeks_problem.jl:279-329, 360-422): the first of a set
+    // runs the chain, the others are finished from the ∫V it left (bk_refinish_kernel, ~10 µs each), with the records —
+    // hence the sums — of a chain of their own.  A bumped κ, θ, σ, V0 or T is another chain.
+    const uint32_t count = hh::bk_record_count(c->n_paths);
+    if ((rc = ensure(ctx, ctx->records, ctx->records_cap, 2 * (size_t)count * hh::kRecStride))) return rc;  // BEFORE a chain runs
+    std::vector<int> leader(n_models, -1);
     for (uint32_t k = 0; k < n_models; ++k)
+      for (uint32_t j = 0; j < k; ++j)
+        if (leader[j] < 0 && hh::bk_same_chain(models[j], models[k])) {
+          leader[k] = (int)j;
+          break;
+        }
+    for (uint32_t k = 0; k < n_models; ++k) {
+      if (leader[k] >= 0) continue;
       if ((rc = hh_mc_accumulate(ctx, &models[k], c, accum_dev + (size_t)k * HH_ACC_LEN, terminals ? terminals[k] : nullptr)))
         return rc;
+      for (uint32_t f = k + 1; f < n_models; ++f) {
+        if (leader[f] != (int)k) continue;
+        double* terminal = terminals ? terminals[f] : nullptr;
+        hh::DevicePtrs p{};
+        p.records = ctx->records + (size_t)count * hh::kRecStride;
+        p.bk_scratch = ctx->bk_scratch;
+        p.bk_term_cache = ctx->bk_term_cache;
+        // (the draws, the ballots, the prefix sums and ∫V are where the chain left them: no seeds, no noise here)
+        if (terminal && c->terminal_on_device) {
+          p.terminal = terminal;
+        } else if (terminal) {
+          if ((rc = ensure(ctx, ctx->terminal, ctx->terminal_cap, (size_t)c->n_paths))) return rc;
+          p.terminal = ctx->terminal;
+        }
+        if (ctx->timing) HH_HIP(ctx, hipEventRecord(ctx->tev[ctx->t_count % hh_ctx::kTimingSlots][0], ctx->stream));
+        HH_HIP(ctx, hh::launch_bk_refinish(models[f], *c, p, ctx->records, ctx->stream));
+        HH_HIP(ctx, hh::launch_reduce_records(p.records, count, (double)c->n_paths, accum_dev + (size_t)f * HH_ACC_LEN,
+                                              ctx->stream, 1, &models[f], c, false,
+                                              hh::bk_live_records(ctx->bk_scratch, c->n_paths)));
+        if ((rc = end_timing(ctx))) return rc;
+        if ((rc = copy_back_terminal(ctx, c, terminal))) return rc;
+      }
+    }
     return HH_OK;
   }
   HH_HIP(ctx, hipSetDevice(ctx->device));

@@ -142,6 +142,10 @@ struct BkArgs {
   // pairs of the batch, in_var = the variance rows of the batch (row-major, so pair i starts at in_var[i]),
   // in_spot = NULL, and the chain leaves the sampled ∫V of pair i in iv_out[i] instead of a spot
   double* iv_out;
+  double* iv_keep;                 // the one-shot law also LEAVES each trajectory's sampled ∫V here (iv_store): a model that
+                                   // differs from this one in nothing the variance process sees (spot, rate, ρ, strike:
+                                   // a bumped Greek's partner) is finished from it without a chain of its own
+                                   // (launch_bk_refinish)
   const uint32_t* order;           // a chain that runs its pairs in another order (launch_bk_grid): position s of the
                                    // chain stands for pair order[s] — its draws, its start variance and its ∫V are
                                    // read and written THERE (pair_of); what the chain keeps for itself (decision words,
@@ -601,6 +605,7 @@ __device__ __forceinline__ double bk_finish(const BkArgs& p, double logS0, doubl
     p.iv_out[path] = IV;
     return 0.0;
   }
+  if (p.iv_keep) p.iv_keep[path] = IV;
   const double S = bk_spot(p, logS0, V0, VT, Z, IV);
   if (p.terminal) p.terminal[path] = S;
   if (p.out_spot) {
@@ -1295,6 +1300,59 @@ __global__ __launch_bounds__(kTile) void bk_fallback_kernel(
   bk_store_record(acc, p.records + (size_t)(n_tiles + blockIdx.x) * kRecStride);
 }
 
+// ---- a second model on a chain that has run ------------------------------------------------------------------------
+// solve(GreekProblem, FiniteDifference) on a Broadie–Kaya problem is two or three full solves on the same seeds
+// (greeks_problem.jl:279-329, 360-422) — and when the bump is of the spot, the rate, ρ or the strike, nothing the
+// variance process sees has moved: the same V_T, the same characteristic function, the same inversion, the same ∫V for
+// every trajectory.  The chain of the first model leaves ∫V per trajectory (BkArgs::iv_keep); this kernel finishes
+// another model from it: log S_T, payoff, and the SAME records — workgroup b of the three kernels of the chain
+// (CF tiles | fall-back | ladder chunks) sums the payoffs of the same trajectories in the same order through the same
+// tree (bk_store_record), so the sums are those of a chain of its own, bit for bit; the counters, which are the
+// chain's, are copied from the first model's records.
+__global__ __launch_bounds__(kTile) void bk_refinish_kernel(const BkArgs p, const double* __restrict__ rec0, uint32_t n_tiles,
+                                                            const uint32_t* __restrict__ prefix,
+                                                            const uint32_t* __restrict__ prefix_long) {
+  const uint32_t b = blockIdx.x, tid = threadIdx.x;
+  double acc[6] = {0, 0, 0, 0, 0, 0};
+  if (b < n_tiles) {  // a tile of the CF kernel: the trajectories whose secant stood
+    const uint64_t path = (uint64_t)b * kTile + tid;
+    const size_t w = (size_t)b * (kTile / 64) + (tid >> 6);
+    const bool left = ((p.fail_mask[w] | p.long_mask[w]) >> (tid & 63u)) & 1ull;  // finished by another kernel
+    if (path < p.n_paths && !left) {
+      const double pay = bk_finish_path(p, path, p.iv_keep[path]);
+      acc[0] = pay;
+      acc[1] = pay * pay;
+    }
+  } else if (b < n_tiles + (uint32_t)kHeavyGrid) {  // a workgroup of the fall-back kernel: packed, grid stride
+    const uint32_t total = prefix_long[n_tiles];
+    for (uint32_t g = (b - n_tiles) * kTile + tid; g < total; g += (uint32_t)kHeavyGrid * kTile) {
+      const uint64_t path = packed_path(p.long_mask, prefix_long, 0, n_tiles, g);
+      const double pay = bk_finish_path(p, path, p.iv_keep[path]);
+      acc[0] += pay;
+      acc[1] = fma(pay, pay, acc[1]);
+    }
+  } else {  // a chunk of the ladder kernel
+    const uint32_t c = b - n_tiles - (uint32_t)kHeavyGrid, total = prefix[n_tiles];
+    if (c * (uint32_t)kTile >= total) return;  // (uniform) as there: no work, no record
+    const uint32_t g = c * kTile + tid;
+    if (g < total) {
+      const uint64_t path = packed_path(p.fail_mask, prefix, p.chunk_tile[c], p.chunk_tile[c + 1u] + 1u, g);
+      const double pay = bk_finish_path(p, path, p.iv_keep[path]);
+      acc[0] += pay;
+      acc[1] = fma(pay, pay, acc[1]);
+    }
+  }
+  double* rec = p.records + (size_t)b * kRecStride;
+  bk_store_record(acc, rec);
+  if (tid == 0) {  // (the thread that wrote the record) the chain's counters
+    const double* r0 = rec0 + (size_t)b * kRecStride;
+    rec[HH_ACC_BK_NEWTON_FAIL] = r0[HH_ACC_BK_NEWTON_FAIL];
+    rec[HH_ACC_BK_BISECT] = r0[HH_ACC_BK_BISECT];
+    rec[HH_ACC_BK_MAXGUESS] = r0[HH_ACC_BK_MAXGUESS];
+    rec[HH_ACC_BK_CF_TERMS] = r0[HH_ACC_BK_CF_TERMS];
+  }
+}
+
 // The host-made tables into device memory: ONE lane, constant indices (a lane-indexed read of the
 // by-value argument would again send the block through scratch), the compiler batches the scalar loads.
 __global__ __launch_bounds__(64) void bk_tables_kernel(const BkBessel t, BkTables* __restrict__ dst, double kappa,
@@ -1456,7 +1514,7 @@ int bk_prepare(const hh_model& m, const hh_config& c, const DevicePtrs& ptr, uin
   a.cache_stride = bk_cache_columns(n_tiles);
   a.static_slots = n_tiles <= (uint32_t)kSlots ? 1u : 0u;
   a.draws = a.phi_cache + a.cache_stride * (size_t)a.cache_cap;
-  a.iv_store = a.draws + 4 * lanes;  // ∫V per pair of a grid chain
+  a.iv_store = a.draws + 4 * lanes;  // ∫V per pair of a grid chain / per trajectory of the one-shot law (iv_keep)
   a.diag = reinterpret_cast<uint32_t*>(a.iv_store + lanes);  // 3 x uint32 per lane in 2 doubles per lane
   a.side = a.iv_store + 3 * lanes;
   a.side_cap = (uint32_t)bk_side_cap(n_tiles);
@@ -1520,6 +1578,7 @@ int launch_bk(const hh_model& m, const hh_config& c, const DevicePtrs& ptr, hipS
   int rc = bk_prepare(m, c, ptr, c.n_paths, a, L);
   if (rc) return rc;
   a.replay = c.noise_mode == HH_NOISE_REPLAY ? ptr.replay : nullptr;
+  if (!tr) a.iv_keep = a.iv_store;  // the one-shot law: ∫V per trajectory stays, for launch_bk_refinish
   if ((rc = bk_tables(a, L, ptr, s, upload_tables))) return rc;
   const dim3 g(L.n_tiles), b(kTile);
   const bool fuse_draws = HH_BK_FUSE_DRAWS && !a.replay && !a.in_var;  // the terminal law, drawn here
@@ -1528,6 +1587,21 @@ int launch_bk(const hh_model& m, const hh_config& c, const DevicePtrs& ptr, hipS
   else if (!fuse_draws)
     hipLaunchKernelGGL(bk_draw_kernel<false>, g, b, 0, s, a);
   bk_chain(a, L, s, fuse_draws);
+  return (int)hipGetLastError();
+}
+
+bool bk_same_chain(const hh_model& a, const hh_model& b) {
+  return a.kappa == b.kappa && a.theta == b.theta && a.sigma == b.sigma && a.V0 == b.V0 && a.T == b.T;
+}
+
+int launch_bk_refinish(const hh_model& m, const hh_config& c, const DevicePtrs& ptr, const double* rec0, hipStream_t s) {
+  BkArgs a{};
+  BkLayout L{};
+  const int rc = bk_prepare(m, c, ptr, c.n_paths, a, L);  // the same places in the same scratch as the chain's own block
+  if (rc) return rc;
+  a.iv_keep = a.iv_store;
+  hipLaunchKernelGGL(bk_refinish_kernel, dim3(2 * L.n_tiles + (uint32_t)kHeavyGrid), dim3(kTile), 0, s, a, rec0, L.n_tiles,
+                     static_cast<const uint32_t*>(L.prefix), static_cast<const uint32_t*>(L.prefix_long));
   return (int)hipGetLastError();
 }
 

@@ -164,6 +164,12 @@ struct BkTransition {
 };
 // upload_tables = false: the Bessel tables of this (κ, θ, σ) are already in p.bk_scratch from an earlier
 // launch_bk on the SAME scratch buffer and trajectory count (the dates of one exact grid)
+// Two models whose one-shot Broadie–Kaya chains are the same chain: nothing the variance process and the inversion
+// see differs (κ, θ, σ, V0, T) — a bumped spot, rate, ρ or strike.  launch_bk_refinish finishes such a model from the
+// ∫V the chain of the other one left in the SAME scratch (same n_paths, same draws), with records that are those of a
+// chain of its own bit for bit; rec0 = the records of the model whose chain ran (the counters are copied from there).
+bool bk_same_chain(const hh_model& a, const hh_model& b);
+int launch_bk_refinish(const hh_model& m, const hh_config& c, const DevicePtrs& p, const double* rec0, hipStream_t s);
 int launch_bk(const hh_model& m, const hh_config& c, const DevicePtrs& p, hipStream_t s,
               const BkTransition* tr = nullptr, bool upload_tables = true);
 // Dates k0 … k0 + n_dates of an exact grid in ONE chain: the variance rows first (sequential in the date, cheap),

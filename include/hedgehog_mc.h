@@ -258,7 +258,11 @@ int hh_mc_finalize(const hh_model* model, const hh_config* cfg, const double* ac
  *              vector over path shards, then hh_mc_finalize(&models[k], cfg, accum + k·HH_ACC_LEN, &out[k]))
  *   terminals  NULL, or n_models pointers (each nullable): model k's samples at expiry, as `terminal` of hh_mc_solve
  * Up to 4 models share a pass (more run as ⌈n/4⌉ passes); Euler–Maruyama and the exact lognormal law share
- * their draws, Broadie–Kaya runs one chain per model (its sampler keeps no state a second model could reuse).
+ * their draws.  Broadie–Kaya shares a whole CHAIN between models that differ in nothing its variance process
+ * sees (κ, θ, σ, V0, T equal: a bumped spot, rate, ρ or strike — the finite-difference delta, gamma, rho): the
+ * first such model runs the chain, the others are finished from the ∫V it sampled (~10 µs each at 10^6
+ * trajectories; a central delta 0.355 ms for the reference's two solves of 0.336); a bumped κ, θ, σ, V0 or T is
+ * a chain of its own.
  * Path-major REPLAY increments are repacked to the tile-major layout first.
  */
 int hh_mc_solve_multi(hh_ctx* ctx, const hh_model* models, uint32_t n_models, const hh_config* cfg,

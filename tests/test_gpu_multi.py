@@ -151,14 +151,68 @@ def test_multi_with_either_form_of_the_record_reduction(hhlib):
         assert all(same_bits(a[0], b[0]) for a, b in zip(want, got)), mode
 
 
-def test_multi_broadie_kaya_is_one_chain_per_model(hhlib):
-    n_paths = 4000
-    models = bumped_models(HES, 3, same_noise_law=False)
+def bk_models():
+    """the bumps of finite-difference Greeks on a Broadie–Kaya problem: models 1-4 differ from model 0 in nothing the
+    variance process sees (they share its chain), 5 has a chain of its own (σ), 6 shares THAT one, 7 another (V0, κ)"""
+    base = {}
+    bumps = [dict(), dict(S0=100.1), dict(r=0.031, cp=-1.0), dict(rho=-0.65), dict(strike=101.0, S0=99.9),
+             dict(sigma=0.33), dict(sigma=0.33, S0=100.1, cp=-1.0), dict(V0=0.05, kappa=1.5)]
+    return [o.make_model(**{**base, **b}) for b in bumps]
+
+
+@pytest.mark.parametrize("controls, cache, what", [
+    (dict(), 0, "the reference's controls: a few dozen trajectories in the ladder"),
+    (dict(bk_newton_maxiter=2), 0, "most trajectories in the ladder: many chunks"),
+    (dict(bk_cf_tol=1e-6, bk_atol=1e-6, bk_newton_maxiter=20), 32, "series beyond a 32-term cache: the fall-back kernel's records too"),
+])
+def test_multi_broadie_kaya_shares_the_chain_where_the_variance_process_is_the_same(hhlib, controls, cache, what):
+    """hh_mc_solve_multi on HestonBroadieKaya: a bumped spot / rate / ρ / strike is finished from the ∫V the first
+    model's chain left (bk_refinish_kernel) — every model's price, sums, counters and samples as hh_mc_solve gives
+    them, bit for bit."""
+    n_paths = 256 * 37 + 45
+    models = bk_models()
     c = o.make_config(HES, BK, n_paths, 1, seeds=seeds_for(n_paths, 1))
+    for k, v in controls.items():
+        setattr(c, k, v)
+    if cache:
+        hhlib.set_option(_ffi.HH_OPT_BK_TERM_CACHE, cache)
+    try:
+        each = solve_each(hhlib, models, c, True)
+        multi = solve_multi(hhlib, models, c, True)
+        again = solve_each(hhlib, models[::-1], c, False)[::-1]  # and the context is as good as before
+    finally:
+        if cache:
+            hhlib.set_option(_ffi.HH_OPT_BK_TERM_CACHE, 256)
+    for k, ((r1, t1), (rk, tk), (r2, _)) in enumerate(zip(each, multi, again)):
+        assert same_bits(r1, rk) and same_bits(r1, r2), (what, k)
+        assert t1.tobytes() == tk.tobytes(), (what, k)
+        for f in ("bk_cf_terms", "bk_newton_fail", "bk_bisect_fallback", "bk_maxguess_fallback"):
+            assert getattr(rk, f) == getattr(r1, f), (what, k, f)
+    if controls.get("bk_newton_maxiter") == 2:
+        assert each[0][0].bk_newton_fail > 0.5 * n_paths
+    if cache:
+        dec, ln = np.zeros(n_paths, dtype=np.uint32), np.zeros(n_paths, dtype=np.uint32)
+        hhlib.check(hhlib.lib.hh_bk_decisions(hhlib.handle, n_paths, dec.ctypes.data, ln.ctypes.data))
+        assert (ln > cache).any()
+
+
+def test_multi_broadie_kaya_on_the_callers_draws_and_device_samples(hhlib):
+    import torch
+    n_paths = 5000
+    rng = np.random.default_rng(3)
+    draws = np.ascontiguousarray(np.stack([0.02 + 0.05 * rng.uniform(size=n_paths), rng.uniform(size=n_paths),
+                                           rng.standard_normal(n_paths)]))
+    models = bk_models()[:4]
+    c = o.make_config(HES, BK, n_paths, 1, noise_mode=REP, replay=draws.ravel())
     each = solve_each(hhlib, models, c, True)
-    multi = solve_multi(hhlib, models, c, True)
-    for (r1, t1), (rk, tk) in zip(each, multi):
-        assert same_bits(r1, rk) and t1.tobytes() == tk.tobytes() and rk.bk_cf_terms == r1.bk_cf_terms
+    K = len(models)
+    dev = [torch.zeros(n_paths, dtype=torch.float64, device="cuda:0") for _ in range(K)]
+    c.terminal_on_device = 1
+    res = (_ffi.hh_result * K)()
+    tp = (C.c_void_p * K)(*[t.data_ptr() for t in dev])
+    hhlib.check(hhlib.lib.hh_mc_solve_multi(hhlib.handle, (_ffi.hh_model * K)(*models), K, C.byref(c), res, tp))
+    for k in range(K):
+        assert same_bits(each[k][0], res[k]) and each[k][1].tobytes() == dev[k].cpu().numpy().tobytes(), k
 
 
 def test_multi_argument_errors(hhlib):
