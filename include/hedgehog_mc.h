@@ -572,9 +572,11 @@ int hh_wiener_fill(hh_ctx* ctx, int32_t dynamics, double rho, double T, uint32_t
 
 /*
  * Measurement hooks (the reference has no tracing; the build supplies its own).  When
- * enabled, every hh_mc_accumulate / hh_mc_solve brackets its SIMULATION kernel (not the staging
- * copies, not the record reduction) with HIP events on the ctx stream; hh_ctx_read_timings
- * synchronizes the stream and returns the elapsed ms of the launches recorded since the last read
+ * enabled, every hh_mc_accumulate / hh_mc_solve brackets EVERYTHING IT ENQUEUES — the simulation
+ * kernels and, where it is a kernel of its own, the record reduction; not the staging copies in front —
+ * with HIP events on the ctx stream (one slot per call; hh_mc_accumulate_multi on Broadie–Kaya: one per
+ * model — a chain's, then each finish pass's); hh_ctx_read_timings
+ * synchronizes the stream and returns the elapsed ms of the slots recorded since the last read
  * (at most 256 are kept).
  */
 int hh_ctx_enable_timing(hh_ctx* ctx, int32_t on);
