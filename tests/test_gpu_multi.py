@@ -269,6 +269,28 @@ def test_finite_difference_greek_is_the_references_two_solves(hhlib, scheme, pat
     assert np.float64(got).tobytes() == np.float64(want).tobytes()
 
 
+@pytest.mark.parametrize("path", ["market_inputs.spot", "market_inputs.rate.rate", "market_inputs.ρ", "payoff.strike",
+                                  "market_inputs.V0"])
+def test_finite_difference_greek_on_the_exact_heston_law(hhlib, path):
+    """The same through HestonBroadieKaya — the reference's only way to a Greek there (no dual numbers through rand!,
+    heston.jl:261-276): a bumped spot, rate, ρ or strike shares ONE chain with its partner (bk_refinish_kernel), a
+    bumped V0 runs two; either way the number of compute_fd_derivative on two plain solves, exactly."""
+    prob, lens, eps = heston_problem(), hh.optic(path), 1e-3
+    m = hh.MonteCarlo(hh.HestonDynamics(), hh.HestonBroadieKaya(), hh.SimulationConfig(20_000, steps=1, seeds=seeds_for(20_000, 23)))
+    x0 = lens(prob)
+    price = lambda x: hh.solve(hh.set(prob, lens, x), m, ensemble=False).price
+    want = (price(x0 * (1 + eps)) - price(x0 * (1 - eps))) / (2 * eps * x0)
+    got = hh.solve(hh.GreekProblem(prob, lens), hh.FiniteDifference(eps), m).greek
+    assert np.float64(got).tobytes() == np.float64(want).tobytes()
+    spot = hh.optic("market_inputs.spot")
+    if path == "market_inputs.spot":  # … and the gamma: three models, one chain
+        e2, s0 = 0.5, spot(prob)
+        f = lambda x: hh.solve(hh.set(prob, spot, x), m, ensemble=False).price
+        gamma = (f(s0 + e2) - 2 * f(s0) + f(s0 - e2)) / e2**2
+        got = hh.solve(hh.SecondOrderGreekProblem(prob, spot, spot), hh.FiniteDifference(e2), m).greek
+        assert np.float64(got).tobytes() == np.float64(gamma).tobytes()
+
+
 def test_second_order_greeks_are_the_references_stencils(hhlib):
     prob, m, eps = heston_problem(), heston_method(anti=True), 0.5
     spot, v0 = hh.optic("market_inputs.spot"), hh.optic("market_inputs.V0")
