@@ -66,6 +66,13 @@ HH_MATH_FN cx cexp(cx z) {
   sincos_cf(z.im, s, c);
   return {e * c, e * s};
 }
+// … for |Re z| < 1e9 (fm::exp_finite)
+HH_MATH_FN cx cexp_finite(cx z) {
+  const double e = fm::exp_finite(z.re);
+  double s, c;
+  sincos_cf(z.im, s, c);
+  return {e * c, e * s};
+}
 HH_MATH_FN cx clog(cx z) { return {fm::log(cabs(z)), fm::atan2(z.im, z.re)}; }
 
 constexpr int kHankelTerms = 32;   // a_0 … a_31

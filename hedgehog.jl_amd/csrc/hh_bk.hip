@@ -233,7 +233,7 @@ struct ChfPrefix {
 __device__ __forceinline__ ChfPrefix chf_prefix(double kappa, double sigma2, double T, double a) {
   ChfPrefix f;
   f.g = csqrt_right({kappa * kappa, -2.0 * sigma2 * a});
-  const cx eh = cexp({-0.5 * f.g.re * T, -0.5 * f.g.im * T});  // exp(-γT/2)
+  const cx eh = cexp_finite({-0.5 * f.g.re * T, -0.5 * f.g.im * T});  // exp(-γT/2): a finite exponent
   const cx e = eh * eh;                                        // exp(-γT)
   const cx ome = {1.0 - e.re, -e.im};
   const cx ope = {1.0 + e.re, e.im};
