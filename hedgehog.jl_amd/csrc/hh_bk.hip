@@ -1094,7 +1094,9 @@ template <int ORD>
 __global__ __launch_bounds__(kTile) void bk_ladder_kernel(const BkArgs p, const BkTables* __restrict__ tabs,
                                                           uint32_t n_tiles,
                                                           const uint32_t* __restrict__ prefix) {
-  const uint32_t total = prefix[n_tiles];
+  // (the three words this workgroup starts from, in ONE round trip: chunk_tile has n_tiles + 1 elements and is
+  // written up to the chunk count, so both reads are inside it for every workgroup, with or without work)
+  const uint32_t total = prefix[n_tiles], t_lo = p.chunk_tile[blockIdx.x], t_hi = p.chunk_tile[blockIdx.x + 1u];
   if (blockIdx.x * (uint32_t)kTile >= total) return;  // (uniform) no work, no record: the reduction stops short of it
   double* rec = p.records + (size_t)(n_tiles + (uint32_t)kHeavyGrid + blockIdx.x) * kRecStride;
   // This chunk's trajectories lie in the tiles [t_lo, t_hi] (bk_scan_kernel left where each chunk starts): their
@@ -1102,7 +1104,6 @@ __global__ __launch_bounds__(kTile) void bk_ladder_kernel(const BkArgs p, const 
   // twelve dependent round trips to the L2 in front of every lane's work, a third of this kernel's time.
   constexpr uint32_t kSpan = HH_BK_LADDER_SPAN;
   __shared__ uint32_t pre_sh[kSpan + 1];
-  const uint32_t t_lo = p.chunk_tile[blockIdx.x], t_hi = p.chunk_tile[blockIdx.x + 1u];
   const bool staged = t_hi - t_lo < kSpan;  // (uniform) else: failures this sparse are searched in place
   if (staged) {
     for (uint32_t i = threadIdx.x; i <= t_hi - t_lo + 1u; i += kTile) pre_sh[i] = prefix[t_lo + i];
@@ -1556,6 +1557,9 @@ void bk_chain(const BkArgs& a, const BkLayout& L, hipStream_t s, bool draw_in_ch
   else
     hipLaunchKernelGGL(bk_cf_kernel<0>, g, b, 0, s, a, tabs);
   hipLaunchKernelGGL(bk_scan_kernel, dim3(1), dim3(kScanThreads), 0, s, a, L.n_tiles, L.prefix, L.prefix_long);
+  // (the grid covers the worst case, one workgroup per possible chunk; the ~3800 that find no work cost nothing
+  // measurable: with 512 workgroups the kernel takes the same 19.7 µs — it is one wave's dependent chain of a dozen
+  // CDF evaluations)
   if (a.order)
     hipLaunchKernelGGL(bk_ladder_kernel<1>, g, b, 0, s, a, tabs, L.n_tiles, L.prefix);
   else
