@@ -66,6 +66,9 @@ constexpr double kInvPi = 0.31830988618379067154, kTwoOverPi = 0.636619772367581
 #ifndef HH_BK_FUSE_DRAWS
 #define HH_BK_FUSE_DRAWS 1
 #endif
+#ifndef HH_BK_LADDER_STAMPS
+#define HH_BK_LADDER_STAMPS 0  // a diagnostic build: where the ladder kernel's time goes (printf of s_memrealtime stamps)
+#endif
 #ifndef HH_BK_LADDER_SPAN
 #define HH_BK_LADDER_SPAN 1024
 #endif
@@ -1096,6 +1099,14 @@ __global__ __launch_bounds__(kTile) void bk_ladder_kernel(const BkArgs p, const 
                                                           const uint32_t* __restrict__ prefix) {
   // (the three words this workgroup starts from, in ONE round trip: chunk_tile has n_tiles + 1 elements and is
   // written up to the chunk count, so both reads are inside it for every workgroup, with or without work)
+#if HH_BK_LADDER_STAMPS
+  unsigned long long st[8] = {};
+  int st_n = 0;
+#define HH_LST() do { if (blockIdx.x == 0 && threadIdx.x == 0 && st_n < 8) st[st_n++] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define HH_LST() do {} while (0)
+#endif
+  HH_LST();
   const uint32_t total = prefix[n_tiles], t_lo = p.chunk_tile[blockIdx.x], t_hi = p.chunk_tile[blockIdx.x + 1u];
   if (blockIdx.x * (uint32_t)kTile >= total) return;  // (uniform) no work, no record: the reduction stops short of it
   double* rec = p.records + (size_t)(n_tiles + (uint32_t)kHeavyGrid + blockIdx.x) * kRecStride;
@@ -1123,6 +1134,7 @@ __global__ __launch_bounds__(kTile) void bk_ladder_kernel(const BkArgs p, const 
   // A column of the term cache only if some trajectory here has to evaluate its series again — with the reference's
   // controls none has (every failed series is in the side store), and taking a slot is two atomics and two
   // barriers in front of 4 µs of work
+  HH_LST();  // staged, path found, k loaded
   const bool need_slot = __syncthreads_or(g < total && k == kNoSide) != 0;  // (uniform)
   const uint32_t slot = need_slot ? take_slot(p, blockIdx.x) : 0u;
   double* col = p.phi_cache + (size_t)slot * kTile + threadIdx.x;
@@ -1147,8 +1159,10 @@ __global__ __launch_bounds__(kTile) void bk_ladder_kernel(const BkArgs p, const 
     load_terms(terms, tstride, j_stop, t);
     double n_terms = 0.0, IV;
     auto cdf = [&](double x) { return cdf_cached(t, terms, tabs->coef, tstride, j_stop, h, x, n_terms); };
+    HH_LST();  // series in registers
     double fa = cdf(0.0) - u;
     const double fb = cdf(max_guess) - u;
+    HH_LST();  // two end points
     uint32_t dec = p.diag[path];
     if (fa * fb > 0.0) {
       acc[4] += 1.0;
@@ -1177,17 +1191,25 @@ __global__ __launch_bounds__(kTile) void bk_ladder_kernel(const BkArgs p, const 
       IV = 0.5 * (lo_x + hi_x);
       dec |= kDecBisect | ((iters & 0xffu) << kDecItersShift);
     }
+    HH_LST();  // bisection done
     p.diag[path] = dec;
     acc[5] += n_terms;
     const bool grid = p.in_var != nullptr;
     const double V0 = grid ? p.in_var[src] : p.V0;
     const double logS0 = p.in_spot ? fm::log(p.in_spot[src]) : p.logS0;
     const double pay = bk_finish(p, logS0, V0, p.draws[3 * p.draw_stride + src], p.draws[src], IV, src);
+    HH_LST();  // finished
     acc[0] += pay;
     acc[1] = fma(pay, pay, acc[1]);
   }
   bk_store_record(acc, rec);
   if (need_slot) give_slot(p, slot);
+#if HH_BK_LADDER_STAMPS
+  HH_LST();
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    printf("ladder stamps (100 MHz ticks from entry): staged+path %llu, terms %llu, ends %llu, bisect %llu, finish %llu, record %llu\n",
+           st[1] - st[0], st[2] - st[0], st[3] - st[0], st[4] - st[0], st[5] - st[0], st[6] - st[0]);
+#endif
 }
 
 // Fall-back kernel: trajectories whose series did not fit the cache (cf_tol far below the reference's
