@@ -268,6 +268,37 @@ class Dist:
             self.pg = None
 
 
+def _pow10(n):
+    """1000000 -> '1e6', 125000 -> '125000'"""
+    k = len(str(n)) - 1
+    return "%de%d" % (n // 10 ** k, k) if n >= 1000 and n % 10 ** k == 0 else str(n)
+
+
+def metric_string(paths, n_steps, strong=False, n_global=0):
+    """the `metric` of a line names the workload that line RAN: built from the arguments, not a constant"""
+    what = "%s paths in all x %d steps" % (_pow10(n_global), n_steps) if strong else \
+        "%s paths x %d steps per GPU" % (_pow10(paths), n_steps)
+    return "MC path-steps/sec (Heston Euler-Maruyama, %s)" % what
+
+
+def predict_scaling(shard_ms, overhead_ms):
+    """What ONE GPU's figures say about N ranks sharing an ensemble of fixed size (strong scaling).
+    shard_ms: {N: ms of one step of the shard ceil(G/N), run alone}; overhead_ms: what a solve costs beside its
+    kernel and does not shrink with the shard — enqueue, the 16-double all-reduce, the synchronisation — as ONE rank
+    measures it.  -> {N: {...}}: `pipelined` = back-to-back independent solves, the exchange of one behind the kernel
+    of the next (how this bench's timed loop runs): a step is the longer of the two; `single_solve` = one solve from
+    call to result: kernel + overhead.  Efficiency = t(1) / (N t(N)).  No xGMI hop, no second rank, no straggler is in
+    these numbers: an upper bound on what a node can show."""
+    t1 = shard_ms[1]
+    out = {}
+    for n, t in sorted(shard_ms.items()):
+        pipe, single = max(t, overhead_ms), t + overhead_ms
+        out[n] = {"shard_ms_per_step": t,
+                  "efficiency_pipelined": max(t1, overhead_ms) / (n * pipe),
+                  "efficiency_single_solve": (t1 + overhead_ms) / (n * single)}
+    return out
+
+
 def shard_of(n_global, rank, world):
     """contiguous ranges of ceil(N/G) trajectories (hedgehog_jl_amd.shard_range)"""
     per = -(-n_global // world)
@@ -427,7 +458,7 @@ def single_process(args):
     n0 = int(cfgs[0].n_paths)
     rccl_used = mg.reduce_mode == _ffi.HH_MGPU_REDUCE_RCCL  # AFTER the run: a collective that failed fell back
     out = {
-        "metric": "MC path-steps/sec (Heston Euler-Maruyama, 1e6 paths x 252 steps per GPU)",
+        "metric": metric_string(args.paths, n_steps, strong, n_global),
         "value": tot * args.steps / dt, "value_cold": tot * args.steps / dt_c, "unit": "path-steps/s",
         "n_gpus": G, "single_process": True,
         "reduce": "rccl" if rccl_used else "host ordered sum",
@@ -657,7 +688,7 @@ def main():
             traffic = None
 
     out = {
-        "metric": "MC path-steps/sec (Heston Euler-Maruyama, 1e6 paths x 252 steps per GPU)",
+        "metric": metric_string(args.paths, n_steps, strong, n_global),
         "value": value,
         "value_cold": total_path_steps * args.steps / dt_cold,
         "value_default_mode": total_path_steps * args.steps / dt_gen,
@@ -757,6 +788,50 @@ def main():
         if world > 1:
             time.sleep(2.0)  # the other ranks are leaving their GPUs
         out["single_process"] = run_single_process_child(args, world)
+
+    # ---- what one GPU can say about the 1 -> 8 curve: each shard of ceil(G/N) alone ---------------
+    if world == 1 and not args.no_extra:
+        sp = out.get("single_process") or {}
+        try:  # a solve's cost beside its kernel, as the one-process form measured it with ONE rank
+            overhead_ms = max(0.0, float(sp["ms_per_step"]) - float(sp["per_rank_kernel_ms"][0]))
+        except Exception:  # noqa: BLE001
+            overhead_ms = None
+        sh = None
+        torch.cuda.empty_cache()
+        pred = {"label": "one GPU's figures, not a node's: every shard of ceil(G/N) trajectories was run ALONE on this "
+                         "GPU; the per-solve overhead is the one-process form's step time minus its kernel time with "
+                         "ONE rank (enqueue + all-reduce of 16 doubles + synchronisation).  No xGMI hop, no second "
+                         "rank, no straggler is in these numbers — an upper bound to read a SCALE record against",
+                "per_solve_overhead_ms_one_rank": overhead_ms,
+                "enqueue_host_us": sp.get("enqueue_host_us"), "reduce_of_that_run": sp.get("reduce"),
+                "strong": {}}
+        for G in (1_000_000, 10_000_000):
+            big = Shard(0, G)  # a prefix of its tiles is the shard of a smaller rank count
+            shard_ms = {}
+            for N in (1, 2, 4, 8):
+                n = -(-G // N)
+                cN = big.config(_ffi.HH_NOISE_REPLAY)
+                cN.n_paths = n
+                cN.seeds_len = n
+                cN.replay_len = lib.hh_replay_elems(n, n_steps, _ffi.HH_HESTON)
+                k = min(args.steps, 40)
+                dtN, _, _, _ = timed(model, cN, k, min(args.warmup, 5), args.ramp_ms)
+                shard_ms[N] = dtN / k * 1e3
+            rows = predict_scaling(shard_ms, overhead_ms or 0.0)
+            for N, row in rows.items():
+                row["paths_per_rank"] = -(-G // N)
+                row["predicted_value_pipelined"] = float(G) * n_steps / (max(row["shard_ms_per_step"], overhead_ms or 0.0) * 1e-3)
+            pred["strong"][str(G)] = {str(N): row for N, row in rows.items()}
+            big = None
+            torch.cuda.empty_cache()
+        # weak scaling (the driver's SCALE runs: --paths per GPU fixed): every rank repeats the N = 1 step; what is
+        # added is the exchange, hidden behind the next step's kernel as long as it is shorter than the kernel
+        t1 = dt_rep / args.steps * 1e3
+        pred["weak_%s_per_gpu" % _pow10(n_paths)] = {
+            str(N): {"ms_per_step": max(t1, overhead_ms or 0.0),
+                     "efficiency_pipelined": t1 / max(t1, overhead_ms or 0.0)} for N in (1, 2, 4, 8)}
+        out["predicted_scaling"] = pred
+        sh = Shard(g0, g1 - g0)  # the headline shard again, for the extras below
 
     accum = accums[0]
     if world == 1 and not args.no_extra:

@@ -20,7 +20,7 @@ HH_EULER_MARUYAMA, HH_EXACT_LAW, HH_BROADIE_KAYA = 0, 1, 2
 HH_NOISE_GENERATE, HH_NOISE_REPLAY = 0, 1
 HH_REPLAY_TILE_MAJOR, HH_REPLAY_PATH_MAJOR = 0, 1
 
-HH_OK, HH_ERR_INVALID, HH_ERR_UNSUPPORTED, HH_ERR_HIP, HH_ERR_NOMEM, HH_ERR_RCCL = 0, -1, -2, -3, -4, -5
+HH_OK, HH_ERR_INVALID, HH_ERR_UNSUPPORTED, HH_ERR_HIP, HH_ERR_NOMEM, HH_ERR_RCCL, HH_ERR_DEVICE_TIMEOUT = 0, -1, -2, -3, -4, -5, -6
 HH_MGPU_AUTO, HH_MGPU_HOST_SUM, HH_MGPU_RCCL = 0, 1, 2
 HH_MGPU_REDUCE_HOST, HH_MGPU_REDUCE_RCCL = 0, 1
 HH_MGPU_OPT_ENQUEUE = 1
@@ -78,6 +78,8 @@ HH_OPT_GRID_FORM = 3
 HH_OPT_LSM_SPIN_TICKS = 4
 HH_OPT_FUSE_REDUCE = 5
 HH_OPT_GRID_ORDER = 6
+HH_OPT_FINISH_SPIN_TICKS = 7
+HH_OPT_FINISH_TILE_FIRST = 8
 HH_GRID_FORM_PER_DATE, HH_GRID_FORM_BATCHED = 0, 1
 HH_CM_GRAD_LEN = 8  # enum hh_cm_grad: S0, V0, kappa, theta, sigma, rho, r_drift, discount
 HH_LSM_FORM_PER_DATE, HH_LSM_FORM_PERSISTENT, HH_LSM_FORM_AUTO = 0, 1, 2
@@ -102,6 +104,7 @@ SYMBOLS = [
     ("hh_ctx_reset_stream", C.c_int, [_vp]),
     ("hh_last_error", C.c_char_p, [_vp]),
     ("hh_ctx_set_option", C.c_int, [_vp, C.c_int32, C.c_int64]),
+    ("hh_ctx_check_last", C.c_int, [_vp]),
     ("hh_mc_solve", C.c_int, [_vp, C.POINTER(hh_model), C.POINTER(hh_config), C.POINTER(hh_result), _vp]),
     ("hh_mc_accumulate", C.c_int, [_vp, C.POINTER(hh_model), C.POINTER(hh_config), _vp, _vp]),
     ("hh_mc_solve_multi", C.c_int, [_vp, C.POINTER(hh_model), C.c_uint32, C.POINTER(hh_config), C.POINTER(hh_result), _vp]),
@@ -215,6 +218,11 @@ class Context:
 
     def synchronize(self):
         self.check(self.lib.hh_ctx_synchronize(self.handle))
+
+    def check_last(self):
+        """After asynchronous solves (accumulate): waits for the stream; raises HH_ERR_DEVICE_TIMEOUT when a record
+        reduction inside a simulation kernel gave up since the last check (the context has been reset by then)."""
+        self.check(self.lib.hh_ctx_check_last(self.handle))
 
     def seeds_on_device(self, seeds, fingerprint: int = 0) -> int:
         """Device address of this seed vector in the context's content-addressed cache (hh_seeds_cache): valid

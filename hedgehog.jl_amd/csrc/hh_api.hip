@@ -140,6 +140,40 @@ bool fuse_for(const hh_ctx* ctx, const hh_config* c) {
   return hh::sim_records(*c) <= kFuseAutoMaxRecords || (c->strategy == HH_EULER_MARUYAMA && c->n_steps >= kFuseAutoMinSteps);
 }
 
+// what a launch that reduces its own records needs of the context beside the poisoned buffer
+void fused_controls(const hh_ctx* ctx, hh::DevicePtrs& p) {
+  p.finish_state = ctx->finish_state;
+  p.finish_spin_ticks = ctx->finish_spin_ticks;
+  p.finish_tile_first = ctx->finish_tile_first;
+}
+
+// A reducer inside a simulation kernel gave up waiting for a record (hh_sim.h): the record buffer may hold that
+// record now, where the next launch would take it for its own.  With the stream idle: every word back to the
+// poison, the give-up word cleared.  Returns HH_OK when there was nothing to recover from.
+int recover_finish(hh_ctx* ctx) {
+  unsigned int state = 0;
+  HH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  HH_HIP(ctx, hipMemcpy(&state, ctx->finish_state, sizeof(state), hipMemcpyDeviceToHost));
+  if (state == 0u) return HH_OK;
+  if (ctx->frecords_cap)
+    HH_HIP(ctx, hipMemsetD32Async((hipDeviceptr_t)ctx->frecords, (int)(hh::kPoison & 0xffffffffull),
+                                  ctx->frecords_cap * 2, ctx->stream));
+  HH_HIP(ctx, hipMemsetAsync(ctx->finish_state, 0, 2 * sizeof(unsigned int), ctx->stream));
+  HH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  const long long ticks = ctx->finish_spin_ticks < 0 ? (long long)hh::kFinishSpinTicksDefault : ctx->finish_spin_ticks;
+  return fail(ctx, HH_ERR_DEVICE_TIMEOUT,
+              "the record reduction inside a simulation kernel gave up: a workgroup's record had not arrived after %lld "
+              "ticks of the 100 MHz clock (a queue preempted for that long, or a workgroup that died); the sums of that "
+              "solve, and of solves queued behind it, are lost — the context's record buffer has been reset and the "
+              "context can be used again", ticks);
+}
+
+// hh_mc_finalize refused an accumulator: because a reducer gave up (the named status), or for what it says
+int finalize_failed(hh_ctx* ctx, int rc) {
+  const int rf = recover_finish(ctx);
+  return rf ? rf : fail(ctx, rc, "finalize failed: the accumulator holds no trajectories");
+}
+
 size_t replay_elems(uint64_t n_paths, uint32_t n_steps, int dynamics) {
   return (size_t)hh::tiles_for(n_paths) * n_steps * ncomp_of(dynamics) * hh::kTile;
 }
@@ -165,6 +199,8 @@ int hh_ctx_create(hh_ctx** out, int device_id) {
       hipEventCreateWithFlags(&ctx->ev_switch, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->ev_stage, hipEventDisableTiming) != hipSuccess ||
       hipMalloc((void**)&ctx->accum, HH_ACC_LEN * sizeof(double)) != hipSuccess ||
+      hipMalloc((void**)&ctx->finish_state, 2 * sizeof(unsigned int)) != hipSuccess ||
+      hipMemset(ctx->finish_state, 0, 2 * sizeof(unsigned int)) != hipSuccess ||
       hipHostMalloc((void**)&ctx->accum_host, (HH_ACC_LEN + 8) * sizeof(double), hipHostMallocDefault) !=
           hipSuccess) {
     hh_ctx_destroy(ctx);
@@ -201,6 +237,7 @@ void hh_ctx_destroy(hh_ctx* ctx) {
     if (e.dev) (void)hipFree(e.dev);
   if (ctx->accum) (void)hipFree(ctx->accum);
   if (ctx->frecords) (void)hipFree(ctx->frecords);
+  if (ctx->finish_state) (void)hipFree(ctx->finish_state);
   if (ctx->accum_host) (void)hipHostFree(ctx->accum_host);
   for (auto& pr : ctx->tev)
     for (auto& e : pr)
@@ -265,6 +302,14 @@ int hh_ctx_set_option(hh_ctx* ctx, int32_t option, int64_t value) {
       if (value != 0 && value != 1)
         return fail(ctx, HH_ERR_INVALID, "HH_OPT_GRID_ORDER: 0 (a chain's pairs in their natural order) or 1 (sorted by their Bessel arguments)");
       ctx->grid_order = (int)value;
+      return HH_OK;
+    case HH_OPT_FINISH_SPIN_TICKS:
+      if (value < -1) return fail(ctx, HH_ERR_INVALID, "HH_OPT_FINISH_SPIN_TICKS: ticks of the 100 MHz clock, 0 = give up at once, -1 = default");
+      ctx->finish_spin_ticks = value;
+      return HH_OK;
+    case HH_OPT_FINISH_TILE_FIRST:
+      if (value != 0 && value != 1) return fail(ctx, HH_ERR_INVALID, "HH_OPT_FINISH_TILE_FIRST: 0 (the last tile's workgroup adds the records) or 1 (the first one's)");
+      ctx->finish_tile_first = (int)value;
       return HH_OK;
     case HH_OPT_FUSE_REDUCE:
       if (value < 0 || value > 2)
@@ -417,7 +462,8 @@ static int stage_noise(hh_ctx* ctx, const hh_config* c, hh::DevicePtrs& p, bool 
 }
 
 // accum_dev != NULL (and the ctx's HH_OPT_FUSE_REDUCE): the simulation kernel reduces its own records into
-// accum_dev — *reduced says whether it did (Broadie–Kaya's chain does not).  The timing slot opened here is
+// accum_dev — *reduced says whether it did.  The Broadie–Kaya chain always adds its own records (its tail kernel):
+// into accum_dev, or into ctx->accum when the caller has no use for the sums.  The timing slot opened here is
 // closed by end_timing() once the caller has enqueued its last kernel.
 static int run_simulation(hh_ctx* ctx, const hh_model* m, const hh_config* c, double* terminal,
                           bool need_terminal_dev, double** terminal_dev_out, double* accum_dev = nullptr,
@@ -436,11 +482,13 @@ static int run_simulation(hh_ctx* ctx, const hh_model* m, const hh_config* c, do
     if ((rc = ensure_poisoned(ctx, (size_t)n_tiles * hh::kRecStride))) return rc;
     p.records = ctx->frecords;
     p.accum = accum_dev;
+    fused_controls(ctx, p);
   }
-  if (reduced) *reduced = fuse;
+  if (reduced) *reduced = fuse || bk;
   if (bk) {
     rc = ensure_bk_scratch(ctx, hh::bk_scratch_bytes(c->n_paths, ctx->bk_term_cache));
     if (rc) return rc;
+    p.accum = accum_dev ? accum_dev : ctx->accum;
     p.bk_scratch = ctx->bk_scratch;
     p.bk_table_key = &ctx->bk_table_key;
     p.bk_term_cache = ctx->bk_term_cache;
@@ -505,12 +553,8 @@ int hh_mc_accumulate(hh_ctx* ctx, const hh_model* m, const hh_config* c, double*
   bool reduced = false;
   rc = run_simulation(ctx, m, c, terminal, false, nullptr, accum_dev, &reduced);
   if (rc) return rc;
-  if (!reduced) {
-    const bool bk = c->strategy == HH_BROADIE_KAYA;
-    const uint32_t n_rec = bk ? hh::bk_record_count(c->n_paths) : hh::sim_records(*c);
-    HH_HIP(ctx, hh::launch_reduce_records(ctx->records, n_rec, (double)c->n_paths, accum_dev, ctx->stream, 1, m, c, false,
-                                          bk ? hh::bk_live_records(ctx->bk_scratch, c->n_paths) : nullptr));
-  }
+  if (!reduced)
+    HH_HIP(ctx, hh::launch_reduce_records(ctx->records, hh::sim_records(*c), (double)c->n_paths, accum_dev, ctx->stream, 1, m, c));
   if ((rc = end_timing(ctx))) return rc;
   if ((rc = release_host_operands(ctx))) return rc;
   return copy_back_terminal(ctx, c, terminal);
@@ -535,6 +579,7 @@ int hh_mc_accumulate_multi(hh_ctx* ctx, const hh_model* models, uint32_t n_model
   if (c->n_partials)
     return fail(ctx, HH_ERR_UNSUPPORTED, "several models in one pass carry no dual partials (n_partials must be 0)");
   if (n_models == 1) return hh_mc_accumulate(ctx, models, c, accum_dev, terminals ? terminals[0] : nullptr);
+  HH_HIP(ctx, hipSetDevice(ctx->device));  // before anything is allocated: the caller's thread may be on another device
   if (c->strategy == HH_BROADIE_KAYA) {
     // One chain per set of models that the variance process cannot tell apart (hh::bk_same_chain: a bumped spot, rate,
     // ρ, strike — the finite-difference delta / gamma / rho of greeks_problem.jl:279-329, 360-422): the first of a set
@@ -560,7 +605,7 @@ int hh_mc_accumulate_multi(hh_ctx* ctx, const hh_model* models, uint32_t n_model
         p.records = ctx->records + (size_t)count * hh::kRecStride;
         p.bk_scratch = ctx->bk_scratch;
         p.bk_term_cache = ctx->bk_term_cache;
-        // (the draws, the ballots, the prefix sums and ∫V are where the chain left them: no seeds, no noise here)
+        // (the draws, the ballots and ∫V are where the chain left them: no seeds, no noise here)
         if (terminal && c->terminal_on_device) {
           p.terminal = terminal;
         } else if (terminal) {
@@ -578,7 +623,6 @@ int hh_mc_accumulate_multi(hh_ctx* ctx, const hh_model* models, uint32_t n_model
     }
     return HH_OK;
   }
-  HH_HIP(ctx, hipSetDevice(ctx->device));
   const uint32_t n_tiles = hh::tiles_for(c->n_paths);
   const size_t rec_elems = (size_t)n_tiles * hh::kRecStride;
   const bool fuse = fuse_for(ctx, c);
@@ -586,6 +630,7 @@ int hh_mc_accumulate_multi(hh_ctx* ctx, const hh_model* models, uint32_t n_model
   else rc = ensure(ctx, ctx->records, ctx->records_cap, (size_t)n_models * rec_elems);
   if (rc) return rc;
   hh::DevicePtrs base{};
+  if (fuse) fused_controls(ctx, base);
   if ((rc = stage_noise(ctx, c, base, /*tile_major_only=*/true))) return rc;
   // terminal samples: a model's own device buffer, or a slice of the ctx's staging buffer for a host buffer
   const size_t n_term = (size_t)c->n_paths * (c->antithetic ? 2 : 1);
@@ -644,7 +689,7 @@ int hh_mc_solve_multi(hh_ctx* ctx, const hh_model* models, uint32_t n_models, co
   const double total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   for (uint32_t k = 0; k < n_models; ++k) {
     std::memset(&out[k], 0, sizeof(hh_result));
-    if ((rc = hh_mc_finalize(&models[k], c, host + (size_t)k * HH_ACC_LEN, &out[k]))) return fail(ctx, rc, "finalize failed");
+    if ((rc = hh_mc_finalize(&models[k], c, host + (size_t)k * HH_ACC_LEN, &out[k]))) return finalize_failed(ctx, rc);
     out[k].kernel_ms = ms;
     out[k].total_ms = total;
   }
@@ -692,11 +737,8 @@ int hh_mc_accumulate_basket(hh_ctx* ctx, const hh_model* m, const hh_config* c,
   HH_HIP(ctx, hh::launch_basket_payoffs(b, n_payoffs, (uint32_t)n_active, ctx->stream));
   HH_HIP(ctx, hh::launch_reduce_records(ctx->basket_records, b.n_chunks, (double)c->n_paths,
                                         accum_dev, ctx->stream, n_payoffs, m, c, true));
-  if (c->strategy == HH_BROADIE_KAYA) {  // the simulation's fall-back / series counters, for every payoff
-    HH_HIP(ctx, hh::launch_reduce_records(ctx->records, hh::bk_record_count(c->n_paths), (double)c->n_paths, ctx->accum,
-                                          ctx->stream, 1, m, c, false, hh::bk_live_records(ctx->bk_scratch, c->n_paths)));
-    HH_HIP(ctx, hh::launch_copy_bk_counters(ctx->accum, accum_dev, n_payoffs, ctx->stream));
-  }
+  if (c->strategy == HH_BROADIE_KAYA)  // the simulation's fall-back / series counters (the chain left its sums in
+    HH_HIP(ctx, hh::launch_copy_bk_counters(ctx->accum, accum_dev, n_payoffs, ctx->stream));  // ctx->accum), for every payoff
   if ((rc = end_timing(ctx))) return rc;
   if ((rc = release_host_operands(ctx))) return rc;
   return copy_back_terminal(ctx, c, terminal);
@@ -727,7 +769,7 @@ int hh_mc_solve_basket(hh_ctx* ctx, const hh_model* m, const hh_config* c, const
   for (uint32_t k = 0; k < n_payoffs; ++k) {
     std::memset(&out[k], 0, sizeof(hh_result));
     rc = hh_mc_finalize(m, c, host.data() + (size_t)k * HH_ACC_LEN, &out[k]);
-    if (rc) return fail(ctx, rc, "finalize failed");
+    if (rc) return finalize_failed(ctx, rc);
     out[k].kernel_ms = ms;
     out[k].total_ms = total;
   }
@@ -778,13 +820,20 @@ int hh_mc_solve(hh_ctx* ctx, const hh_model* m, const hh_config* c, hh_result* o
                              hipMemcpyDeviceToHost, ctx->stream));
   HH_HIP(ctx, hipStreamSynchronize(ctx->stream));
   rc = hh_mc_finalize(m, c, ctx->accum_host, out);
-  if (rc) return fail(ctx, rc, "finalize failed");
+  if (rc) return finalize_failed(ctx, rc);
   float ms = 0.f;
   HH_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
   out->kernel_ms = ms;
   out->total_ms =
       std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   return HH_OK;
+}
+
+int hh_ctx_check_last(hh_ctx* ctx) {
+  if (!ctx) return HH_ERR_INVALID;
+  std::lock_guard<std::recursive_mutex> lock__(ctx->mu);
+  HH_HIP(ctx, hipSetDevice(ctx->device));
+  return recover_finish(ctx);
 }
 
 int hh_bk_decisions(hh_ctx* ctx, uint64_t n_paths, uint32_t* decisions, uint32_t* series_len) {
@@ -1090,12 +1139,9 @@ static int run_heston_grid(hh_ctx* ctx, const hh_model* m, const hh_config* c) {
                                ctx->stream));
     for (uint32_t k = 0; k < c->n_steps; k += per_chain) {
       const uint32_t nd = std::min(per_chain, c->n_steps - k);
+      p.accum = ctx->basket_accum + (size_t)k * HH_ACC_LEN;  // the counters of the batch's pairs, kept in the slot of its first date
       HH_HIP(ctx, hh::launch_bk_grid(step_model, step_cfg, p, ctx->stream, ctx->lsm_grid + (size_t)k * n,
                                      ctx->heston_var + (size_t)k * n, k, nd, /*upload_tables=*/k == 0));
-      // the counters of the batch's pairs, kept in the slot of its first date
-      HH_HIP(ctx, hh::launch_reduce_records(ctx->records, hh::bk_record_count(n * nd), (double)(n * nd),
-                                            ctx->basket_accum + (size_t)k * HH_ACC_LEN, ctx->stream, 1,
-                                            &step_model, &step_cfg, false, hh::bk_live_records(ctx->bk_scratch, n * nd)));
     }
     return HH_OK;
   }
@@ -1103,10 +1149,8 @@ static int run_heston_grid(hh_ctx* ctx, const hh_model* m, const hh_config* c) {
     const hh::BkTransition tr{ctx->lsm_grid + (size_t)k * n, ctx->heston_var + (size_t)k * n,
                               ctx->lsm_grid + (size_t)(k + 1) * n,
                               ctx->heston_var + (size_t)(k + 1) * n, k};
+    p.accum = ctx->basket_accum + (size_t)k * HH_ACC_LEN;
     HH_HIP(ctx, hh::launch_bk(step_model, step_cfg, p, ctx->stream, &tr, /*upload_tables=*/k == 0));
-    HH_HIP(ctx, hh::launch_reduce_records(ctx->records, hh::bk_record_count(n), (double)n,
-                                          ctx->basket_accum + (size_t)k * HH_ACC_LEN, ctx->stream,
-                                          1, &step_model, &step_cfg, false, hh::bk_live_records(ctx->bk_scratch, n)));
   }
   return HH_OK;
 }
@@ -1427,7 +1471,10 @@ int hh_seeds_cache(hh_ctx* ctx, const uint64_t* seeds, uint64_t n, uint64_t fing
       *dev_out = e.dev;
       return HH_OK;
     }
-    if (!e.dev ? victim->dev != nullptr : (victim->dev && e.stamp < victim->stamp)) victim = &e;
+    // the least recently used one goes — never the entry the call before this one returned (its stamp is the clock's):
+    // a second thread of this context may be between ITS lookup and the solve that reads the pointer
+    const bool newest = e.dev && e.stamp == ctx->seed_clock, victim_newest = victim->dev && victim->stamp == ctx->seed_clock;
+    if (!e.dev ? victim->dev != nullptr : (victim->dev && !newest && (victim_newest || e.stamp < victim->stamp))) victim = &e;
   }
   HH_HIP(ctx, hipSetDevice(ctx->device));
   if (victim->dev) {  // hipFree waits for the device: nothing in flight reads the copy any more

@@ -8,14 +8,21 @@
 //   3. log S_T = μ + sqrt((1-ρ²)∫V)·Z                         heston.jl:278-300
 // then S_T = exp(.), payoff and the workgroup reduction as in hh_kernels.hip.
 //
-// Launch structure: bk_tables_kernel (the Bessel tables of ν and the model's ϕ(0) constants into device memory, when
-// they are not there already) -> bk_draw_kernel (the caller's three draws V_T, u, Z in REPLAY mode, and the normal
-// quantile of u; in GENERATE mode the one-shot law's draws are made by the CF kernel itself, a grid's by its variance
-// kernel) -> bk_cf_kernel (draws, characteristic function, moments, series terms, then the secant inversion on the
-// cached terms) -> bk_scan_kernel ->
-// bk_ladder_kernel (bisection ladder for the flagged trajectories, packed) -> bk_fallback_kernel
-// (trajectories whose series outgrew the term cache; none with the reference's controls).
-// (Until round 5 the draws always had a launch of their own: with the library's pow / lgamma / log / normcdfinv and
+// Launch structure — TWO kernels per solve (three with the caller's own draws):
+//   bk_cf_kernel    one tile of 256 trajectories per workgroup: the three draws (GENERATE: made here; REPLAY: the
+//                   caller's, read here; a grid's: by its variance kernel in front), characteristic function,
+//                   moments, series terms, the secant inversion on the cached terms — and, for the trajectories
+//                   whose secant failed (2 %), the bisection ladder of inverse_cdf, run by the WAVE: the lanes of a
+//                   wave evaluate the next 3-6 levels of a failed trajectory's bisection tree at once (wave_ladder)
+//   bk_tail_kernel  (a) trajectories whose series outgrew the term cache run whole (none with the reference's
+//                   controls: the workgroups find a zero and go on), (b) the records of both kernels are added into
+//                   the accumulator.
+// bk_tables_kernel (the Bessel tables of ν and the model's ϕ(0) constants into device memory) runs in front when
+// they are not there already.
+// (Until round 5 the chain was CF kernel -> prefix scan -> packed ladder kernel -> fall-back kernel -> record
+// reduction: at 10^6 trajectories the four small kernels and their boundaries were 37 µs of 330 — the ladder alone
+// 19 µs, one wave's dependent chain of fifteen CDF evaluations.  profiles/r05_n_bk_sizes.txt, r05_o_bk_ladder_stamps.txt.)
+// (The draws had a launch of their own until round 5: with the library's pow / lgamma / log / normcdfinv and
 // machine LICM hoisting their literals, sampler and CF arithmetic together took 228 registers per lane.  Built
 // without that pass, and with hh_math.h's own normal quantile — the library's normcdfinv was a third of the draw
 // kernel — the sampler takes 92 and the CF arithmetic 95: one kernel of 95, five waves per SIMD.)
@@ -36,11 +43,10 @@
 #include <algorithm>
 #include <cmath>
 
-#include <hipcub/hipcub.hpp>
-
 #include "hh_bessel.h"
 #include "hh_kernels.h"
 #include "hh_math.h"
+#include "hh_reduce.h"
 #include "hh_rng.h"
 
 namespace hh {
@@ -58,19 +64,16 @@ constexpr double kInvPi = 0.31830988618379067154, kTwoOverPi = 0.636619772367581
 #define HH_BK_HEAVY_GRID 64
 #endif
 // Two switches of a TEST build (tests/c/build_bk_check.py, tests/test_gpu_bk_forms.py), which must give the shipped
-// build's samples bit for bit: the trajectory's two real-axis evaluations through the complex code (1), and the ladder
-// kernel searching the prefix sums in place instead of in LDS (a span of 1 tile is never staged)
+// build's samples bit for bit: the trajectory's two real-axis evaluations through the complex code (1), and the
+// bisection ladder run by the failed lane alone, statement for statement as sample_from_cf.jl:123-133 has it (1)
 #ifndef HH_BK_COMPLEX_SETUP
 #define HH_BK_COMPLEX_SETUP 0
 #endif
-#ifndef HH_BK_FUSE_DRAWS
-#define HH_BK_FUSE_DRAWS 1
+#ifndef HH_BK_SERIAL_LADDER
+#define HH_BK_SERIAL_LADDER 0
 #endif
-#ifndef HH_BK_LADDER_STAMPS
-#define HH_BK_LADDER_STAMPS 0  // a diagnostic build: where the ladder kernel's time goes (printf of s_memrealtime stamps)
-#endif
-#ifndef HH_BK_LADDER_SPAN
-#define HH_BK_LADDER_SPAN 1024
+#ifndef HH_BK_NO_LADDER
+#define HH_BK_NO_LADDER 0
 #endif
 // Columns of cached series terms.  A lane's column belongs to a workgroup SLOT that a workgroup of the
 // CF kernel (or of the ladder kernel behind it) takes when it starts and gives back when it is done —
@@ -81,11 +84,11 @@ constexpr double kInvPi = 0.31830988618379067154, kTwoOverPi = 0.636619772367581
 // per XCD.  256 terms of 8 bytes: 0.81 GB for 10^4 and for 10^8 trajectories alike).  A trajectory's terms are only needed again if its secant fails (2 % of
 // them): the ladder kernel re-derives those.
 constexpr int kSlots = HH_BK_SLOTS;
-constexpr int kSideTerms = 64, kSideEntry = kSideTerms + 2;  // doubles per side-store entry: h, max_guess, terms
-constexpr uint32_t kNoSide = 0xffffffffu;
-constexpr int kHeavyGrid = HH_BK_HEAVY_GRID;   // workgroups of the fall-back kernel (246 registers; it is empty
-                                  // with the reference's controls, and the whole job when no series fits the term cache)
-static_assert(kHeavyGrid <= kSlots, "the fall-back kernel's workgroup b uses slot b");
+constexpr int kHeavyGrid = HH_BK_HEAVY_GRID;   // workgroups of the tail kernel (169 registers: it holds the whole-trajectory
+                                  // code, idle with the reference's controls and the whole job when no series fits the
+                                  // term cache; its first kRecStride workgroups then add the records)
+static_assert(kHeavyGrid <= kSlots, "the tail kernel's workgroup b uses slot b");
+static_assert(kHeavyGrid >= kRecStride, "one workgroup of the tail kernel per accumulator slot");
 
 // The weight of term j of the CDF series (sample_from_cf.jl:86: (2/π)·sin(h j x)·Re ϕ(h j)/j) is (2/π)/j — an
 // IEEE quotient, so the compile-time constants of the unrolled evaluation, this table (filled on the device by
@@ -153,15 +156,13 @@ struct BkArgs {
                                    // chain stands for pair order[s] — its draws, its start variance and its ∫V are
                                    // read and written THERE (pair_of); what the chain keeps for itself (decision words,
                                    // side-store indices, cached terms) is indexed by s.  NULL: s itself
-  double* records;                 // [2·n_tiles][kRecStride]: phase 1, then phase 2
+  double* records;                 // [n_tiles + kHeavyGrid][kRecStride]: the CF kernel's tiles, then the tail kernel's workgroups
   double* draws;                   // [4][draw_stride]: Z, u, normal quantile of u, V_T per trajectory
   size_t draw_stride;
   const double* replay;            // REPLAY: the caller's [3][n_paths] V_T, u, Z (device), else NULL
   double* iv_store;                // [draw_stride]: where a grid chain keeps the sampled ∫V of its pairs (iv_out)
-  unsigned long long* fail_mask;   // [n_tiles][4] ballots: secant failed, the ladder is left (bk_ladder_kernel)
   unsigned long long* long_mask;   // [n_tiles][4] ballots: series longer than the cache, not inverted yet
-                                   //              (bk_fallback_kernel runs these whole)
-  uint32_t* tile_counts;           // [n_tiles] set bits of a tile's ballots: fail | long << 16
+                                   //              (bk_tail_kernel runs these whole)
   double* phi_cache;               // [cache_cap][cache_stride] cached Re ϕ(h·j), one column per lane of a
   size_t cache_stride;             //   workgroup SLOT (kSlots·256 columns), not per trajectory
   int cache_cap;
@@ -170,21 +171,15 @@ struct BkArgs {
                                    // them as it found them
   uint32_t static_slots;           // 1: the chain has at most kSlots tiles, slot = tile (no bitmap)
   uint32_t n_tiles;
-  uint32_t* diag;                  // [3][draw_stride] per trajectory: decision word (BkDecision), series length,
-                                   //   index of its side-store entry (kNoSide: none)
-  // Side store: the series of a trajectory whose secant FAILED (2 % of them) is copied here by the CF
-  // kernel — h, max_guess, then its terms — so that the ladder kernel finds it without evaluating the
-  // characteristic function again.  Entries are handed out by an atomic counter (their order does not
-  // matter: a trajectory finds its own through diag[2]); a series longer than kSideTerms, or one that
-  // comes when the store is full, is re-derived by the ladder kernel instead.
-  double* side;                    // [side_cap][kSideEntry]
-  uint32_t* side_count;            // [0] entries handed out (zeroed with the bitmaps, then by each chain's
-                                   // bk_scan_kernel for the next one); [1] records of this chain the reduction reads
-                                   // (bk_live_records)
-  uint32_t* chunk_tile;            // [n_tiles + 1] tile that holds the first trajectory of each packed ladder chunk
-  uint32_t side_cap;
-  void* args_dev;                  // a copy of this struct in device memory (written by bk_scan_kernel)
-                                   // for bk_fallback_kernel, whose code is too large to inline: passing
+  uint32_t* diag;                  // [2][draw_stride] per trajectory: decision word (BkDecision), series length
+  uint32_t* counters;              // the 128-byte line behind the slot bitmaps, zeroed with them:
+                                   //   [0] trajectories of this chain whose series outgrew the term cache (added to by
+                                   //       the CF kernel's tiles, read and zeroed again by the tail kernel)
+                                   //   [1] records of the last chain the reduction read (n_tiles, or n_tiles +
+                                   //       kHeavyGrid when [0] was not zero): what bk_refinish_kernel must reproduce
+                                   //   [2], [3] arrival counters of the tail kernel's two waits (zero between chains)
+  void* args_dev;                  // a copy of this struct in device memory (written by tile 0 of the CF kernel)
+                                   // for bk_tail_kernel, whose code is too large to inline: passing
                                    // a by-value kernel argument by reference to its functions would put
                                    // a 2 KB copy per lane in scratch
 };
@@ -441,9 +436,9 @@ __device__ int poisson(double mu, const PathDraws& dr, int& it) {
 
 // The three draws of a trajectory (reference order, heston.jl:246-259: V_T from the NCχ² law, then u
 // inside sample_from_cf, then Z inside sample_log_S_T) and the normal quantile of u, left in
-// draws[4][stride] for the CF kernels.  REPLAY: V_T, u, Z are the caller's (replay[3][n_paths]) —
+// draws[4][stride].  REPLAY: V_T, u, Z are the caller's (replay[3][n_paths]) —
 // the seam through which the reference's own draws reach sample_from_cf / inverse_cdf per trajectory.
-// the draws of one transition from start variance V0: stream `key`, indexed by G
+// The draws of one transition from start variance V0: stream `key`, indexed by G
 __device__ __forceinline__ void draw_transition(const BkArgs& p, uint64_t key, uint64_t G, double V0, double& Z,
                                                 double& u, double& VT) {
   const double lam = p.lam_num * V0 / p.lam_den;  // heston.jl:129
@@ -478,22 +473,14 @@ __device__ __forceinline__ void store_draws(const BkArgs& p, uint64_t i, double 
   d[3 * p.draw_stride] = VT;
 }
 
-template <bool REPLAY>
+// … for one transition of a grid run date by date (launch_bk with a BkTransition): the trajectory's own seed
+// (montecarlo.jl:331), indexed by the transition.  (The one-shot law's draws are made, or read from the caller's
+// buffer, by the CF kernel itself.)
 __global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(4, 8))) void bk_draw_kernel(const BkArgs p) {
   const uint64_t path = (uint64_t)blockIdx.x * kTile + threadIdx.x;
   if (path >= p.n_paths) return;
   double Z, u, VT;
-  if constexpr (REPLAY) {
-    VT = fmax(p.replay[path], 0x1p-1000);
-    u = p.replay[p.n_paths + path];
-    Z = p.replay[2 * p.n_paths + path];
-  } else {
-    // terminal law: ONE stream, seeds[1], indexed by trajectory (montecarlo.jl:456); grid: the
-    // trajectory's own seed (montecarlo.jl:331), indexed by the transition
-    const bool grid = p.in_var != nullptr;
-    draw_transition(p, grid ? p.seeds[path] : p.seeds[0], grid ? (uint64_t)p.step : p.path_offset + path,
-                    grid ? p.in_var[path] : p.V0, Z, u, VT);
-  }
+  draw_transition(p, p.seeds[path], (uint64_t)p.step, p.in_var[path], Z, u, VT);
   store_draws(p, path, Z, u, VT);
 }
 
@@ -509,10 +496,10 @@ __device__ __forceinline__ uint32_t grid_order_key(double v0, double vt) {
 // The variance chain of dates k0 … k0 + n_dates of a grid, one trajectory per thread: V of each date from the
 // one before (cheap: one non-central χ² draw), its draws left where the chain's pair (date, trajectory) =
 // b·n_row + trajectory finds them, the variance rows written on the way.
-// (keys, idx: non-NULL when the chain will run its pairs in order — each pair's key and its own index, for the sort)
+// (keys: non-NULL when the chain will run its pairs in order — each pair's key, for the counting sort)
 __global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(4, 8))) void bk_draw_grid_kernel(const BkArgs p, uint64_t n_row, uint32_t k0,
                                                              uint32_t n_dates, double* __restrict__ var_rows,
-                                                             uint32_t* __restrict__ keys, uint32_t* __restrict__ idx) {
+                                                             uint8_t* __restrict__ keys) {
   const uint64_t path = (uint64_t)blockIdx.x * kTile + threadIdx.x;
   if (path >= n_row) return;
   const uint64_t key = p.seeds[path];
@@ -523,10 +510,7 @@ __global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(4, 8))) v
     const uint64_t pair = (uint64_t)b * n_row + path;
     store_draws(p, pair, Z, u, VT);
     var_rows[(uint64_t)(b + 1) * n_row + path] = VT;
-    if (keys) {  // uniform
-      keys[pair] = grid_order_key(V, VT);
-      idx[pair] = (uint32_t)pair;
-    }
+    if (keys) keys[pair] = (uint8_t)grid_order_key(V, VT);  // uniform
     V = VT;
   }
 }
@@ -644,11 +628,11 @@ __global__ __launch_bounds__(kTile) void bk_grid_spots_kernel(const BkArgs p, ui
   }
 }
 
-// (tile_count, when given, receives the tile's number of failed | too-long trajectories: the sums of
-// the 0/1 flags in acc[2] and `n_long` — what bk_scan_kernel needs, without re-reading the ballots)
-__device__ __forceinline__ void bk_store_record(double (&acc)[6], double* rec, uint32_t* tile_count = nullptr,
+// (long_counter, when given, is added the tile's number of too-long trajectories — the sum of `n_long` — when there
+// are any: what tells bk_tail_kernel that it has work)
+__device__ __forceinline__ void bk_store_record(double (&acc)[6], double* rec, uint32_t* long_counter = nullptr,
                                                 double n_long = 0.0) {
-  if (tile_count) {  // uniform
+  if (long_counter) {  // uniform
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) n_long += __shfl_down(n_long, off, 64);
   }
@@ -672,10 +656,10 @@ __device__ __forceinline__ void bk_store_record(double (&acc)[6], double* rec, u
       t[i] = sm[0][i];
       for (int w = 1; w < kTile / 64; ++w) t[i] += sm[w][i];
     }
-    if (tile_count) {
+    if (long_counter) {
       double nl = sm[0][6];
       for (int w = 1; w < kTile / 64; ++w) nl += sm[w][6];
-      *tile_count = (uint32_t)t[2] | ((uint32_t)nl << 16);
+      if (nl > 0.0) atomicAdd(long_counter, (uint32_t)nl);
     }
     for (int i = 0; i < kRecStride; ++i) rec[i] = 0.0;
     rec[HH_ACC_SUM] = t[0];
@@ -731,18 +715,35 @@ __device__ __forceinline__ bool secant_inverse(Cdf&& cdf, double u, double guess
   return ok && !(x1 < 0.0);
 }
 
+// (what the phases of the CF kernel hand each other through LDS: see wave_ladder)
+constexpr int kLadderStash = 32;
+struct LadderShared {
+  double h[kTile], u[kTile], max_guess[kTile];  // in
+  double guess[kTile];                          // the secant's first guess (series_phase -> invert_phase)
+  double iv[kTile];                             // out: the sampled ∫V
+  int j_stop[kTile];                            // in
+  uint32_t res[kTile];                          // out: bisection iterations | max_guess branch << 31
+  double terms[kTile / 64][8][kRegTerms];       // [wave][group]: (2/π)/j · Re ϕ(h j), zero beyond the series' end
+  unsigned long long fail[kTile / 64];          // the waves' ballots of failed lanes
+  // a failed lane leaves the sixteen weighted terms it holds in registers here (entry = the order of arrival, kept in
+  // stash_of[thread]), so the ladder starts without a round trip to the term cache; the 33rd failure of a tile finds
+  // no entry and its group reads the column instead — same numbers
+  double stash[kLadderStash][kRegTerms];
+  unsigned char stash_of[kTile];
+  uint32_t stash_n;
+};
+__device__ __forceinline__ void lds_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); }
+
 // Series phase: the characteristic-function work of a trajectory — CF iterator, moments, and the
 // series terms Re ϕ(h·j), j = 1 … J (J set by the reference's stopping rule, sample_from_cf.jl:88),
 // evaluated ONCE in the reference's order with its continuous phase unwrapping and left in the
 // trajectory's column of the cache.  Nothing here depends on the CDF argument, so the root search
 // needs none of the complex Bessel machinery.  Everything a lane keeps here is the CF state — that
-// is what fits 128 registers (4 waves per SIMD).  Returns h, the secant's first guess and the series
-// length (0: longer than the cache — the fall-back kernel runs this trajectory whole); leaves them
-// with max_guess in rec[] for the ladder kernel.
+// is what fits 96 registers (5 waves per SIMD).  Returns h and the series length (0: longer than the cache —
+// the tail kernel runs this trajectory whole); leaves the secant's first guess and max_guess in LDS.
 template <int ORD>
 __device__ __forceinline__ void series_phase(const BkArgs& p, const BesselTable* bt, uint64_t path, double* col,
-                                             size_t col_stride, double& h, double& initial_guess,
-                                             double& max_guess, int& j_stop) {
+                                             size_t col_stride, LadderShared& sh, double& h, int& j_stop) {
   const bool grid = p.in_var != nullptr;
   const uint64_t src = pair_of<ORD>(p, path);
   const double V0 = grid ? p.in_var[src] : p.V0;
@@ -750,7 +751,12 @@ __device__ __forceinline__ void series_phase(const BkArgs& p, const BesselTable*
   const double q_u = d[2 * p.draw_stride];
   const double VT = d[3 * p.draw_stride];
   CfIter cf;
-  cf_setup(p, bt, V0, VT, q_u, cf, initial_guess, max_guess, h);
+  {  // (not in registers through the series: they are what this kernel is short of)
+    double initial_guess, max_guess;
+    cf_setup(p, bt, V0, VT, q_u, cf, initial_guess, max_guess, h);
+    sh.guess[threadIdx.x] = initial_guess;
+    sh.max_guess[threadIdx.x] = max_guess;
+  }
   const double stop = kPi * p.cf_tol / 2.0;
   double theta = __builtin_nan("");
   j_stop = 0;
@@ -780,7 +786,8 @@ __device__ __forceinline__ void load_terms(const double* col, size_t stride, int
 
 // cdf_from_cf (sample_from_cf.jl:75-96) on the cached terms: same values, same summation order as
 // cdf_from_cf() above, one rotation step per term; terms beyond the registers come from the column
-__device__ __forceinline__ double cdf_cached(const double (&t)[kRegTerms], const double* col, const double* coef,
+template <class Terms>
+__device__ __forceinline__ double cdf_cached(const Terms& t, const double* col, const double* coef,
                                              size_t stride, int j_stop, double h, double x,
                                              double& n_terms) {
   if (x < 0.0) return 0.0;
@@ -820,72 +827,258 @@ __device__ __forceinline__ double cdf_cached(const double (&t)[kRegTerms], const
   return result;
 }
 
-// Inversion phase: the secant iteration of inverse_cdf on the cached series, then log S_T and the
-// payoff.  A trajectory whose secant fails is NOT finished here: one such lane would keep its whole
-// wave in the ~15-evaluation bisection ladder (2 % of the paths fail, so 3 out of 4 waves would).
-// It is flagged in a per-wave ballot instead and finished, densely packed, by bk_ladder_kernel;
-// so is a trajectory whose series did not fit the cache (bk_fallback_kernel).  Flags are ballots in
-// trajectory order, so the result is bit-reproducible.  Called by every thread of the workgroup.
+// The bisection ladder of inverse_cdf (sample_from_cf.jl:123-133) for the trajectories of a tile whose secant failed
+// (2 % of them: 5.7 per tile), run by ONE WAVE of the workgroup for all of them at once.
+//
+// A failed trajectory's ladder is ~15 CDF evaluations in a dependent chain.  Left to its own lane it holds its wave
+// for all of them (three waves in four have such a lane); sent to a kernel of its own, densely packed, it was that
+// kernel's whole 19 µs behind a prefix scan.  But the abscissae of a bisection are known in advance as a TREE: the
+// midpoint of [lo, hi], then the midpoints of its two halves, … — each the same 0.5·(a + b) of the same two ancestors
+// the sequential loop would form.  So the 64 lanes of a wave are dealt to the failed trajectories of a batch in groups
+// of W = 64 / 32 / 16 / 8 (for 1 / 2 / 3-4 / 5-8 of them; a tile's failures go in batches of eight, batch b to wave
+// b mod 4), a group evaluates the W − 1 nodes of the next log2 W levels of its trajectory's tree in ONE turn, and then
+// WALKS them with the statements of the sequential loop — its sign test, its exact-zero test, its width test, its
+// iteration cap — on the values already there.  Every node's lane knows what the loop would do AT it (which half it
+// keeps: the sign of f(lo) never changes in a bisection; whether it stops there), two ballots hand that to the group,
+// and the walk is bit tests.  First turn: the two end points and log2 W − 1 levels.  A ladder of 13 midpoints is 3
+// turns for a lone trajectory, 5 in a group of eight — each one CDF evaluation long, for the whole batch.  Same
+// abscissae, same CDF values, same decisions: the same ∫V, decision word and counters as the sequential loop, bit for
+// bit (HH_BK_SERIAL_LADDER builds that loop; tests/test_gpu_bk_forms.py holds the two against each other).
+// (First built wave by wave — each wave its own failed lanes, 1.4 on average: the ladder then cost as many
+// instructions as the four kernels it replaced cost time, 0.348 ms before and after, profiles/r06_a_*.  Per tile
+// it is a third of that.)
+//
+// What a failed lane hands over and gets back lies in LDS (by thread), and so do a group's sixteen weighted terms
+// (a broadcast read per term instead of sixteen registers per lane: with them in registers, and a lane's own state
+// kept across the ladder, the CF kernel took 128 registers instead of 95 — four waves per SIMD instead of five).
+// thread of the r-th failed trajectory of the tile (r below their number)
+__device__ __forceinline__ uint32_t nth_failed(const LadderShared& sh, uint32_t r) {
+  uint32_t w = 0;
+#pragma unroll
+  for (uint32_t i = 0; i + 1 < (uint32_t)(kTile / 64); ++i) {
+    const uint32_t c = (uint32_t)__popcll(sh.fail[i]);
+    if (w == i && r >= c) {
+      r -= c;
+      w = i + 1;
+    }
+  }
+  unsigned long long m = sh.fail[w];
+  for (uint32_t i = 0; i < r; ++i) m &= m - 1ull;
+  return w * 64u + (uint32_t)__ffsll((long long)m) - 1u;
+}
+
+// Called by every lane of a wave, for batch `b0` of the tile's failed trajectories (the n_fail ballots are in sh.fail;
+// a barrier lies between their stores and this).  `col`: the caller's column of the term cache — a group reads its
+// trajectory's terms from THAT lane's column (same slot).
+__device__ __forceinline__ void wave_ladder(const BkArgs& p, const double* coef, const double* col, LadderShared& sh,
+                                            uint32_t first, uint32_t n) {
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const size_t stride = p.cache_stride;
+  const uint32_t lg = n == 1u ? 6u : n == 2u ? 5u : n <= 4u ? 4u : 3u;  // log2 of the lanes per group
+  const uint32_t W = 1u << lg;
+  const uint32_t grp = lane >> lg, node = lane & (W - 1u), base = lane & ~(W - 1u);
+  const bool gactive = grp < n;
+  const uint32_t owner = gactive ? nth_failed(sh, first + grp) : tid;  // (a thread of the workgroup)
+  const int JS = gactive ? sh.j_stop[owner] : 0;
+  const double* COL = col + ((int)owner - (int)tid);
+  double* T = sh.terms[wave][grp];
+  const uint32_t entry = gactive ? sh.stash_of[owner] : 0xffu;
+  for (uint32_t j = node; j < (uint32_t)kRegTerms; j += W)  // load_terms(), a term per lane
+    T[j] = entry < (uint32_t)kLadderStash ? sh.stash[entry][j] : (int)j < JS ? coef[j + 1u] * COL[(size_t)j * stride] : 0.0;
+  lds_fence();
+  // (what is read once per turn stays in LDS — h, u — and max_guess is the first `hi`: registers are what this
+  // kernel is short of)
+  double lo = 0.0, hi = sh.max_guess[owner];  // the state of the sequential loop: the same in every lane of a group
+  bool neg0 = false;         // f(lo) < 0: the loop's `fa < 0`, which no step of a bisection changes
+  uint32_t iters = 0;
+  bool done = !gactive, maxg = false, first_turn = true;
+  for (;;) {  // (uniform) one CDF evaluation per lane and turn
+    const uint32_t depth = first_turn ? lg - 1u : lg;  // levels of the tree this turn evaluates
+    // this lane's abscissa: an end point (first turn), or node `node` of the tree over [lo, hi] in heap order —
+    // root 1, children 2k (left half: hi = mid) and 2k + 1 (right half: lo = mid); [a, b] is what the loop holds
+    // when it comes to this node
+    double x = first_turn && node != 0u ? hi : 0.0, a = lo, b = hi;
+    bool ev = first_turn && (node == 0u || node == (W >> 1));
+    const bool in_tree = !ev && node >= 1u && node < (1u << depth);
+    if (in_tree) {
+      ev = true;
+      for (int i = 30 - __clz((int)node); i >= 0; --i) {
+        const double m = 0.5 * (a + b);
+        if ((node >> i) & 1u) a = m; else b = m;
+      }
+      x = 0.5 * (a + b);
+    }
+    double f = 0.0;
+    if (ev && !done) {
+      double unused = 0.0;
+      f = cdf_cached(T, COL, coef, stride, JS, sh.h[owner], x, unused) - sh.u[owner];
+    }
+    if (first_turn) {  // (uniform) the two end points: sample_from_cf.jl:123-126
+      const double f0 = __shfl(f, (int)base, 64), f1 = __shfl(f, (int)(base + (W >> 1)), 64);
+      if (!done) {
+        neg0 = f0 < 0.0;
+        if (f0 * f1 > 0.0) maxg = done = true;
+      }
+    }
+    // what the loop does AT this node (sample_from_cf.jl:127-133): keeps the right half when the sign is f(lo)'s,
+    // stops on an exact zero or when the interval it keeps is no wider than atol
+    const bool right = (f < 0.0) == neg0;
+    const double lo_k = f == 0.0 ? x : right ? x : a, hi_k = f == 0.0 ? x : right ? b : x;
+    const unsigned long long m_right = __ballot(in_tree && right);
+    const unsigned long long m_stop = __ballot(in_tree && (f == 0.0 || hi_k - lo_k <= p.atol));
+    uint32_t k = 1u, last = 0u;  // the walk
+    for (uint32_t lvl = 0; lvl < depth; ++lvl) {
+      if (!done) {
+        if ((int)iters >= p.bisect_maxiter) {
+          done = true;
+        } else {
+          ++iters;
+          last = k;
+          const uint32_t at = base + k;
+          if ((m_stop >> at) & 1ull) done = true;
+          k = 2u * k + (uint32_t)((m_right >> at) & 1ull);
+        }
+      }
+    }
+    const double lo_n = __shfl(lo_k, (int)(base + last), 64), hi_n = __shfl(hi_k, (int)(base + last), 64);
+    if (last != 0u) {
+      lo = lo_n;
+      hi = hi_n;
+    }
+    if (!done && (int)iters >= p.bisect_maxiter) done = true;
+    first_turn = false;
+    if (__ballot(!done) == 0ull) break;
+  }
+  if (gactive && node == 0u) {
+    sh.iv[owner] = maxg ? hi : 0.5 * (lo + hi);  // (no step was made when max_guess stands: hi still holds it)
+    sh.res[owner] = iters | (maxg ? 1u << 31 : 0u);
+  }
+}
+
+// The same ladder by the failed lane alone, as the reference writes it (a test build, HH_BK_SERIAL_LADDER)
+__device__ __forceinline__ void lane_ladder(const BkArgs& p, const double* coef, const double* col, LadderShared& sh) {
+  const uint32_t tid = threadIdx.x;
+  const int j_stop = sh.j_stop[tid];
+  const double h = sh.h[tid], u = sh.u[tid], max_guess = sh.max_guess[tid];
+  double t[kRegTerms];
+  load_terms(col, p.cache_stride, j_stop, t);
+  double unused = 0.0;
+  auto cdf = [&](double x) { return cdf_cached(t, col, coef, p.cache_stride, j_stop, h, x, unused); };
+  double fa = cdf(0.0) - u;
+  const double fb = cdf(max_guess) - u;
+  if (fa * fb > 0.0) {  // sample_from_cf.jl:124-126
+    sh.iv[tid] = max_guess;
+    sh.res[tid] = 1u << 31;
+    return;
+  }
+  double lo_x = 0.0, hi_x = max_guess;
+  uint32_t iters = 0;
+  for (int i = 0; i < p.bisect_maxiter; ++i) {
+    const double mid = 0.5 * (lo_x + hi_x);
+    const double fm = cdf(mid) - u;
+    ++iters;
+    if (fm == 0.0) {
+      lo_x = hi_x = mid;
+      break;
+    }
+    if ((fm < 0.0) == (fa < 0.0)) {
+      lo_x = mid;
+      fa = fm;
+    } else {
+      hi_x = mid;
+    }
+    if (hi_x - lo_x <= p.atol) break;
+  }
+  sh.iv[tid] = 0.5 * (lo_x + hi_x);
+  sh.res[tid] = iters;
+}
+
+// Inversion phase: the secant iteration of inverse_cdf on the cached series, for the trajectories it fails on the
+// bisection ladder (wave_ladder: one wave for the tile's failures), then log S_T and the payoff.  A trajectory whose series did not fit the cache is
+// flagged in a per-wave ballot and left to bk_tail_kernel.  A lane's payoff stays in its own place of the
+// workgroup's sum, so the record is bit-reproducible.  Called by every thread of the workgroup.
 template <int ORD>
 __device__ __forceinline__ void invert_phase(const BkArgs& p, const double* coef, uint32_t tile, uint32_t tid, uint64_t path,
-                                             bool live, const double* col, double h, double guess,
-                                             double max_guess, int j_stop) {
+                                             bool live, const double* col, LadderShared& sh, double h, int j_stop) {
   double acc[6] = {0, 0, 0, 0, 0, 0};  // Σp, Σp², newton_fail, bisect, maxguess, cf_terms
   bool failed = false, too_long = false;
-  if (live) {
+  uint32_t dec = 0;
+  // log S_T, the payoff and the trajectory's decision word, once its ∫V is known
+  auto finish = [&](double IV) {
     const uint64_t src = pair_of<ORD>(p, path);
-    const double u = p.draws[p.draw_stride + src];
+    p.diag[path] = dec;
+    const double V0 = p.in_var ? p.in_var[src] : p.V0;
+    const double logS0 = p.in_spot ? fm::log(p.in_spot[src]) : p.logS0;  // heston.jl:84, :289
+    const double pay = bk_finish(p, logS0, V0, p.draws[3 * p.draw_stride + src], p.draws[src], IV, src);
+    acc[0] = pay;
+    acc[1] = pay * pay;
+  };
+  if (live) {
     p.diag[p.draw_stride + path] = (uint32_t)j_stop;
     if (j_stop == 0) {
       too_long = true;
       p.diag[path] = kDecLongSeries;
     } else {
+      const double u = p.draws[p.draw_stride + pair_of<ORD>(p, path)];
       double t[kRegTerms];
       load_terms(col, p.cache_stride, j_stop, t);
       double n_terms = 0.0, IV;
-      uint32_t evals = 0;
-      const bool ok = secant_inverse(
-          [&](double x) { return cdf_cached(t, col, coef, p.cache_stride, j_stop, h, x, n_terms); }, u, guess,
-          p.atol, p.newton_maxiter, IV, evals);
-      p.diag[path] = evals;
+      failed = !secant_inverse(
+          [&](double x) { return cdf_cached(t, col, coef, p.cache_stride, j_stop, h, x, n_terms); }, u, sh.guess[tid],
+          p.atol, p.newton_maxiter, IV, dec);
       acc[5] = n_terms;
-      if (ok) {
-        const bool grid = p.in_var != nullptr;
-        const double V0 = grid ? p.in_var[src] : p.V0;
-        const double logS0 = p.in_spot ? fm::log(p.in_spot[src]) : p.logS0;  // heston.jl:84, :289
-        const double pay = bk_finish(p, logS0, V0, p.draws[3 * p.draw_stride + src], p.draws[src],
-                                     IV, src);
-        acc[0] = pay;
-        acc[1] = pay * pay;
+      if (failed) {  // to the ladder: what the wave needs of this trajectory (max_guess is there already)
+        sh.h[tid] = h;
+        sh.u[tid] = u;
+        sh.j_stop[tid] = j_stop;
+        const uint32_t entry = atomicAdd(&sh.stash_n, 1u);
+        sh.stash_of[tid] = (unsigned char)(entry < (uint32_t)kLadderStash ? entry : 0xffu);
+        if (entry < (uint32_t)kLadderStash) {
+#pragma unroll
+          for (int j = 0; j < kRegTerms; ++j) sh.stash[entry][j] = t[j];
+        }
       } else {
-        failed = true;
-        acc[2] = 1.0;
+        finish(IV);
       }
     }
   }
-  const unsigned long long m_fail = __ballot(failed), m_long = __ballot(too_long);
-  if (m_fail != 0ull) {  // the failed trajectories' series into the side store, for the ladder kernel
-    const uint32_t lane = tid & 63u;
-    uint32_t base = 0;
-    if (lane == 0) base = atomicAdd(p.side_count, (uint32_t)__popcll(m_fail));
-    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+  const unsigned long long m_fail = __ballot(failed);
+  if ((tid & 63u) == 0u) sh.fail[tid >> 6] = m_fail;
+  if (__syncthreads_or(failed)) {  // (uniform) nearly every tile
+    [[maybe_unused]] uint32_t n_fail = 0;
+#pragma unroll
+    for (int w = 0; w < kTile / 64; ++w) n_fail += (uint32_t)__popcll(sh.fail[w]);
+#if HH_BK_SERIAL_LADDER
+    if (failed) lane_ladder(p, coef, col, sh);
+#elif HH_BK_NO_LADDER  // a MEASUREMENT build (tools/bk_ab.py): what the kernel costs without the ladder — wrong samples
     if (failed) {
-      const uint32_t k = base + (uint32_t)__popcll(m_fail & ((1ull << lane) - 1ull));
-      const bool fits = k < p.side_cap && j_stop <= kSideTerms;
-      p.diag[2 * p.draw_stride + path] = fits ? k : kNoSide;
-      if (fits) {
-        double* e = p.side + (size_t)k * kSideEntry;
-        e[0] = h;
-        e[1] = max_guess;
-        for (int j = 0; j < j_stop; ++j) e[2 + j] = col[(size_t)j * p.cache_stride];
+      sh.iv[tid] = sh.max_guess[tid];
+      sh.res[tid] = 0u;
+    }
+#else
+    for (uint32_t b0 = (tid >> 6) * 8u; b0 < n_fail; b0 += (uint32_t)(kTile / 64) * 8u)  // (wave-uniform) batch b to wave b mod 4
+      wave_ladder(p, coef, col, sh, b0, n_fail - b0 < 8u ? n_fail - b0 : 8u);
+#endif
+    __syncthreads();
+    if (failed) {
+      const uint32_t res = sh.res[tid], iters = res & 0x7fffffffu;
+      acc[2] = 1.0;
+      // the CDF evaluations the sequential ladder makes: its two end points (one below zero returns before it
+      // counts: cdf_cached) and its midpoints, j_stop terms each
+      acc[5] += (double)sh.j_stop[tid] * (double)(1u + (sh.max_guess[tid] < 0.0 ? 0u : 1u) + iters);
+      if (res >> 31) {
+        acc[4] = 1.0;
+        dec |= kDecMaxGuess;
+      } else {
+        acc[3] = 1.0;
+        dec |= kDecBisect | ((iters & 0xffu) << kDecItersShift);
       }
+      finish(sh.iv[tid]);
     }
   }
-  if ((tid & 63) == 0) {
-    p.fail_mask[(size_t)tile * (kTile / 64) + (tid >> 6)] = m_fail;
-    p.long_mask[(size_t)tile * (kTile / 64) + (tid >> 6)] = m_long;
-  }
-  bk_store_record(acc, p.records + (size_t)tile * kRecStride, p.tile_counts + tile, too_long ? 1.0 : 0.0);
+  const unsigned long long m_long = __ballot(too_long);
+  if ((tid & 63) == 0) p.long_mask[(size_t)tile * (kTile / 64) + (tid >> 6)] = m_long;
+  bk_store_record(acc, p.records + (size_t)tile * kRecStride, p.counters, too_long ? 1.0 : 0.0);
 }
 
 // A workgroup's slot of the term cache.
@@ -937,7 +1130,7 @@ __device__ __forceinline__ uint32_t take_slot(const BkArgs& p, uint32_t own) {
     slot_sh = slot;
   }
   __syncthreads();
-  return slot_sh;
+  return (uint32_t)__builtin_amdgcn_readfirstlane((int)slot_sh);  // (uniform, and the compiler may know it)
 }
 __device__ __forceinline__ void give_slot(const BkArgs& p, uint32_t slot) {
   if (p.static_slots) return;
@@ -970,357 +1163,218 @@ __device__ __forceinline__ void give_slot(const BkArgs& p, uint32_t slot) {
 #else
 #define HH_BK_CF_OCC
 #endif
-// (DRAW: the trajectory's three draws are made here instead of by bk_draw_kernel in front — the one-shot law in
-// GENERATE mode: a tile needs only its own draws, so the separate launch bought nothing but its own fill and drain)
-template <int ORD, bool DRAW = false>
+// (DRAW: the trajectory's three draws are made (1: GENERATE) or read from the caller's buffer (2: REPLAY) here — the
+// one-shot law: a tile needs only its own draws, so a launch in front bought nothing but its own fill and drain.
+// 0: they are where a kernel in front left them — the variance kernel of a grid)
+template <int ORD, int DRAW = 0>
 __global__ __launch_bounds__(kTile) HH_BK_CF_OCC void bk_cf_kernel(const BkArgs p, const BkTables* __restrict__ tabs) {
   const uint32_t tile = blockIdx.x, tid = threadIdx.x;
   const uint64_t path = (uint64_t)tile * kTile + tid;
   const bool live = path < p.n_paths;
-  if (DRAW && live) {
+  if (tile == 0 && tid == 0) __builtin_memcpy(p.args_dev, &p, sizeof(BkArgs));  // for bk_tail_kernel
+  if (DRAW != 0 && live) {
     double Z, u, VT;
-    draw_transition(p, p.seeds[0], p.path_offset + path, p.V0, Z, u, VT);
+    if constexpr (DRAW == 2) {
+      VT = fmax(p.replay[path], 0x1p-1000);
+      u = p.replay[p.n_paths + path];
+      Z = p.replay[2 * p.n_paths + path];
+    } else {
+      draw_transition(p, p.seeds[0], p.path_offset + path, p.V0, Z, u, VT);
+    }
     store_draws(p, path, Z, u, VT);
   }
   const BesselTable* bt = tabs->t;
   const uint32_t slot = take_slot(p, tile);
   double* col = p.phi_cache + (size_t)slot * kTile + tid;
-  double h = 0.0, guess = 0.0, max_guess = 0.0;
+  __shared__ LadderShared sh;
+  if (tid == 0) sh.stash_n = 0u;  // (a barrier lies between this and the first failed lane: the series phase is
+  __syncthreads();                //  tens of microseconds long, but say so to the compiler and the hardware)
+  double h = 0.0;
   int j_stop = 0;
-  if (live) series_phase<ORD>(p, bt, path, col, p.cache_stride, h, guess, max_guess, j_stop);
-  invert_phase<ORD>(p, tabs->coef, tile, tid, path, live, col, h, guess, max_guess, j_stop);
+  if (live) series_phase<ORD>(p, bt, path, col, p.cache_stride, sh, h, j_stop);
+  invert_phase<ORD>(p, tabs->coef, tile, tid, path, live, col, sh, h, j_stop);
   give_slot(p, slot);
 }
 
-// exclusive prefix sums of the per-tile counts of both ballot arrays (the inversion phase leaves the counts,
-// 4 bytes per tile: a single workgroup reading the 64 bytes of ballots per tile instead is bound by
-// what one CU can pull, 16 µs at 10^6 trajectories).  ONE workgroup of 1024 threads: every thread adds
-// up a run of consecutive tiles, the run totals are scanned (shuffles inside a wave, then the 16 wave
-// totals), then the runs are expanded.  Its last thread also leaves the copy of the argument block
-// bk_fallback_kernel reads (BkArgs::args_dev).
-[[maybe_unused]] constexpr int kScanThreads = 1024;
-__global__ __launch_bounds__(kScanThreads) void bk_scan_kernel(const BkArgs p, uint32_t n_tiles,
-                                                               uint32_t* __restrict__ prefix_a,
-                                                               uint32_t* __restrict__ prefix_b) {
-  __shared__ uint32_t wsum[2][kScanThreads / 64];
-  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-  if (tid == kScanThreads - 1) __builtin_memcpy(p.args_dev, &p, sizeof(BkArgs));
-  const uint32_t* __restrict__ cnt = p.tile_counts;
-  const uint32_t per = (n_tiles + kScanThreads - 1) / kScanThreads;
-  const uint32_t t0 = min(tid * per, n_tiles), t1 = min(t0 + per, n_tiles);
-  uint32_t ca = 0, cb = 0;
-#pragma unroll 4
-  for (uint32_t t = t0; t < t1; ++t) {
-    const uint32_t c = cnt[t];
-    ca += c & 0xffffu;
-    cb += c >> 16;
-  }
-  uint32_t ia = ca, ib = cb;  // inclusive scan of the run totals inside the wave
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const uint32_t va = __shfl_up(ia, off, 64), vb = __shfl_up(ib, off, 64);
-    if (lane >= (uint32_t)off) {
-      ia += va;
-      ib += vb;
-    }
-  }
-  if (lane == 63) {
-    wsum[0][wave] = ia;
-    wsum[1][wave] = ib;
-  }
-  __syncthreads();
-  uint32_t ba = 0, bb = 0, ta = 0, tb = 0;  // totals of the waves before this one; of all waves
-#pragma unroll
-  for (uint32_t w = 0; w < kScanThreads / 64; ++w) {
-    const uint32_t xa = wsum[0][w], xb = wsum[1][w];
-    if (w < wave) {
-      ba += xa;
-      bb += xb;
-    }
-    ta += xa;
-    tb += xb;
-  }
-  uint32_t ra = ba + ia - ca, rb = bb + ib - cb;  // exclusive: start of this thread's run
-  for (uint32_t t = t0; t < t1; ++t) {
-    const uint32_t c = cnt[t];
-    prefix_a[t] = ra;
-    prefix_b[t] = rb;
-    // a tile holds at most kTile failed trajectories, so at most one packed chunk (kTile work items) starts in it
-    const uint32_t fa = c & 0xffffu, first = (ra + (uint32_t)kTile - 1u) / (uint32_t)kTile * (uint32_t)kTile;
-    if (first < ra + fa) p.chunk_tile[first / (uint32_t)kTile] = t;
-    ra += fa;
-    rb += c >> 16;
-  }
-  if (tid == 0) {
-    prefix_a[n_tiles] = ta;
-    prefix_b[n_tiles] = tb;
-    const uint32_t chunks = (ta + (uint32_t)kTile - 1u) / (uint32_t)kTile;
-    p.chunk_tile[chunks] = n_tiles - 1u;  // where the last chunk's search ends
-    // records the reduction reads: the CF tiles, the fall-back kernel's, the ladder workgroups that have work
-    p.side_count[1] = n_tiles + (uint32_t)kHeavyGrid + chunks;
-    p.side_count[0] = 0u;  // the CF kernel is done with the side-store counter: ready for the next chain
-  }
-}
-
-// trajectory of packed work item g: the last tile t with prefix[t] <= g, then the (g - prefix[t])-th
-// set bit of its 4 ballots.  [lo, hi): tiles to search, prefix[lo] <= g < prefix[hi]; `prefix` may be a copy of
-// that part in LDS (then `base` = the tile its element 0 stands for)
-__device__ __forceinline__ uint64_t packed_path(const unsigned long long* mask, const uint32_t* prefix,
-                                                uint32_t lo, uint32_t hi, uint32_t g, uint32_t base = 0) {
-  while (hi - lo > 1) {
-    const uint32_t mid = (lo + hi) >> 1;
-    if (prefix[mid - base] <= g) lo = mid; else hi = mid;
-  }
-  uint32_t r = g - prefix[lo - base];
-  uint32_t bit = 0;
-  for (int w = 0; w < kTile / 64; ++w) {
-    unsigned long long mk = mask[(size_t)lo * (kTile / 64) + w];
-    const uint32_t c = (uint32_t)__popcll(mk);
-    if (r < c) {
-      for (uint32_t i = 0; i < r; ++i) mk &= mk - 1;  // drop the r lowest set bits
-      bit = (uint32_t)w * 64u + (uint32_t)(__ffsll((long long)mk) - 1);
-      break;
-    }
-    r -= c;
-  }
-  return (uint64_t)lo * kTile + bit;
-}
-
-// Ladder kernel: the fall-back of inverse_cdf (sample_from_cf.jl:123-133) for the trajectories whose
-// secant failed, densely packed (one per lane, in trajectory order).  The CF kernel's column of such a
-// trajectory has long been reused; its series waits in the side store (BkArgs::side), and the ladder
-// runs on those terms.  Only a series that found no room there is evaluated again — same operations,
-// same terms — into the column of the slot THIS workgroup takes.  One work item
-// per lane, no loop (see bk_cf_kernel): the grid covers the worst case (every trajectory failed) and the
-// workgroups beyond the packed list leave at once, without a record (bk_live_records).
-template <int ORD>
-__global__ __launch_bounds__(kTile) void bk_ladder_kernel(const BkArgs p, const BkTables* __restrict__ tabs,
-                                                          uint32_t n_tiles,
-                                                          const uint32_t* __restrict__ prefix) {
-  // (the three words this workgroup starts from, in ONE round trip: chunk_tile has n_tiles + 1 elements and is
-  // written up to the chunk count, so both reads are inside it for every workgroup, with or without work)
-#if HH_BK_LADDER_STAMPS
-  unsigned long long st[8] = {};
-  int st_n = 0;
-#define HH_LST() do { if (blockIdx.x == 0 && threadIdx.x == 0 && st_n < 8) st[st_n++] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#else
-#define HH_LST() do {} while (0)
-#endif
-  HH_LST();
-  const uint32_t total = prefix[n_tiles], t_lo = p.chunk_tile[blockIdx.x], t_hi = p.chunk_tile[blockIdx.x + 1u];
-  if (blockIdx.x * (uint32_t)kTile >= total) return;  // (uniform) no work, no record: the reduction stops short of it
-  double* rec = p.records + (size_t)(n_tiles + (uint32_t)kHeavyGrid + blockIdx.x) * kRecStride;
-  // This chunk's trajectories lie in the tiles [t_lo, t_hi] (bk_scan_kernel left where each chunk starts): their
-  // prefix sums come into LDS in one round trip and the search runs there — the binary search over all tiles was
-  // twelve dependent round trips to the L2 in front of every lane's work, a third of this kernel's time.
-  constexpr uint32_t kSpan = HH_BK_LADDER_SPAN;
-  __shared__ uint32_t pre_sh[kSpan + 1];
-  const bool staged = t_hi - t_lo < kSpan;  // (uniform) else: failures this sparse are searched in place
-  if (staged) {
-    for (uint32_t i = threadIdx.x; i <= t_hi - t_lo + 1u; i += kTile) pre_sh[i] = prefix[t_lo + i];
-    __syncthreads();
-  }
-  const BesselTable* bt = tabs->t;
-  const size_t stride = p.cache_stride;
-  double acc[6] = {0, 0, 0, 0, 0, 0};
-  const uint32_t g = blockIdx.x * kTile + threadIdx.x;
-  uint64_t path = 0;
-  uint32_t k = 0;
-  if (g < total) {
-    path = staged ? packed_path(p.fail_mask, pre_sh, t_lo, t_hi + 1u, g, t_lo)
-                  : packed_path(p.fail_mask, prefix, t_lo, t_hi + 1u, g);
-    k = p.diag[2 * p.draw_stride + path];
-  }
-  // A column of the term cache only if some trajectory here has to evaluate its series again — with the reference's
-  // controls none has (every failed series is in the side store), and taking a slot is two atomics and two
-  // barriers in front of 4 µs of work
-  HH_LST();  // staged, path found, k loaded
-  const bool need_slot = __syncthreads_or(g < total && k == kNoSide) != 0;  // (uniform)
-  const uint32_t slot = need_slot ? take_slot(p, blockIdx.x) : 0u;
-  double* col = p.phi_cache + (size_t)slot * kTile + threadIdx.x;
-  if (g < total) {
-    double h, guess, max_guess;
-    int j_stop;
-    const double* terms = col;
-    size_t tstride = stride;
-    if (k != kNoSide) {  // its series waits in the side store
-      const double* e = p.side + (size_t)k * kSideEntry;
-      h = e[0];
-      max_guess = e[1];
-      j_stop = (int)p.diag[p.draw_stride + path];
-      terms = e + 2;
-      tstride = 1;
-    } else {  // too long for an entry, or the store was full: evaluate it again
-      series_phase<ORD>(p, bt, path, col, stride, h, guess, max_guess, j_stop);
-    }
-    const uint64_t src = pair_of<ORD>(p, path);
-    const double u = p.draws[p.draw_stride + src];
-    double t[kRegTerms];
-    load_terms(terms, tstride, j_stop, t);
-    double n_terms = 0.0, IV;
-    auto cdf = [&](double x) { return cdf_cached(t, terms, tabs->coef, tstride, j_stop, h, x, n_terms); };
-    HH_LST();  // series in registers
-    double fa = cdf(0.0) - u;
-    const double fb = cdf(max_guess) - u;
-    HH_LST();  // two end points
-    uint32_t dec = p.diag[path];
-    if (fa * fb > 0.0) {
-      acc[4] += 1.0;
-      IV = max_guess;  // sample_from_cf.jl:124-126
-      dec |= kDecMaxGuess;
-    } else {
-      acc[3] += 1.0;
-      double lo_x = 0.0, hi_x = max_guess;
-      uint32_t iters = 0;
-      for (int i = 0; i < p.bisect_maxiter; ++i) {
-        const double mid = 0.5 * (lo_x + hi_x);
-        const double fm = cdf(mid) - u;
-        ++iters;
-        if (fm == 0.0) {
-          lo_x = hi_x = mid;
-          break;
-        }
-        if ((fm < 0.0) == (fa < 0.0)) {
-          lo_x = mid;
-          fa = fm;
-        } else {
-          hi_x = mid;
-        }
-        if (hi_x - lo_x <= p.atol) break;
-      }
-      IV = 0.5 * (lo_x + hi_x);
-      dec |= kDecBisect | ((iters & 0xffu) << kDecItersShift);
-    }
-    HH_LST();  // bisection done
-    p.diag[path] = dec;
-    acc[5] += n_terms;
-    const bool grid = p.in_var != nullptr;
-    const double V0 = grid ? p.in_var[src] : p.V0;
-    const double logS0 = p.in_spot ? fm::log(p.in_spot[src]) : p.logS0;
-    const double pay = bk_finish(p, logS0, V0, p.draws[3 * p.draw_stride + src], p.draws[src], IV, src);
-    HH_LST();  // finished
-    acc[0] += pay;
-    acc[1] = fma(pay, pay, acc[1]);
-  }
-  bk_store_record(acc, rec);
-  if (need_slot) give_slot(p, slot);
-#if HH_BK_LADDER_STAMPS
-  HH_LST();
-  if (blockIdx.x == 0 && threadIdx.x == 0)
-    printf("ladder stamps (100 MHz ticks from entry): staged+path %llu, terms %llu, ends %llu, bisect %llu, finish %llu, record %llu\n",
-           st[1] - st[0], st[2] - st[0], st[3] - st[0], st[4] - st[0], st[5] - st[0], st[6] - st[0]);
-#endif
-}
-
-// Fall-back kernel: trajectories whose series did not fit the cache (cf_tol far below the reference's
-// default) run whole here — secant, then the ladder if it fails — evaluating the terms beyond the
-// cache on every use, as the reference does with all of them.  Densely packed, grid stride; with
-// the default controls there are none and the launch returns at once.
+// Tail kernel, kHeavyGrid workgroups behind the CF kernel.
+//
+// (a) Trajectories whose series did not fit the cache (cf_tol far below the reference's default) run whole here —
+// secant, then the ladder if it fails — evaluating the terms beyond the cache on every use, as the reference does
+// with all of them.  The CF kernel counted them (BkArgs::counters[0]); with the reference's controls the count is
+// zero and this part is one scalar load.  Otherwise workgroup b takes the tiles b, b + kHeavyGrid, … that have such
+// trajectories (found 256 tiles at a time), a lane its own trajectory of the tile: a fixed assignment, so the
+// workgroup's record is reproducible (and bk_refinish_kernel can rebuild it).
 // Every CDF evaluation of the root search — the two starting points of the secant, its iterates, the two
 // ends of the ladder, the bisection's midpoints — goes through ONE call of cdf_from_cf below, the search
 // itself being a small state machine around it (the same statements, in the same order, as
-// secant_inverse and the ladder of bk_ladder_kernel).  With the CDF inlined at four places the kernel took
+// secant_inverse and lane_ladder).  With the CDF inlined at four places the kernel took
 // 248 registers and kept the trajectory's state in scratch (the calls that did not inline took it by
-// reference); with one place it is 154 registers and nothing in scratch.  (Capped at 128 the allocator
+// reference); with one place it is ~160 registers and nothing in scratch.  (Capped at 128 the allocator
 // spills 8-30 registers whatever part of the search state is parked in LDS: the pressure is inside the one
-// CF evaluation, which this kernel runs with its full series every time.  Three waves per SIMD, then, for
-// a kernel that is empty with the reference's controls.)
-__global__ __launch_bounds__(kTile) void bk_fallback_kernel(
-    const BkArgs* __restrict__ args, const BkTables* __restrict__ tabs, uint32_t n_tiles,
-    const uint32_t* __restrict__ prefix) {
-  const uint32_t total = prefix[n_tiles];
-  const BkArgs& p = *args;
-  const BesselTable* bt = tabs->t;
-  double acc[6] = {0, 0, 0, 0, 0, 0};
-  for (uint32_t g = blockIdx.x * kTile + threadIdx.x; g < total; g += gridDim.x * kTile) {
-    const uint64_t path = packed_path(p.long_mask, prefix, 0, n_tiles, g);
-    PathSetup s;
-    bk_setup(p, bt, path, s);
-    double n_terms = 0.0;
-    enum Stage { kSecantFirst, kSecant, kLadderLo, kLadderHi, kBisect };
-    // secant_inverse: Order2 restated as the secant iteration from (x0 + dx, x0), dx = h + |x0| h², h = eps^(1/3).
-    // The secant's (x0, f0), (x1, f1) and the ladder's (lo, f(lo)), hi share their registers: xa, fa, xb, fb
-    const double hs = 6.0554544523933395e-06;
-    double xb = s.initial_guess;                   // secant: x1            ladder: hi
-    double xa = xb + hs + fabs(xb) * hs * hs;      // secant: x0            ladder: lo
-    double fa = 0.0;                               // secant: f0            ladder: f(lo)
-    uint32_t dec = kDecLongSeries, evals = 1, iters = 0;
-    int stage = kSecantFirst;
-    double x = xa;
-    for (;;) {
-      const double f = cdf_from_cf(p, bt, tabs->coef, s.cf, x, s.h, s.cache, n_terms) - s.u;
-      if (stage == kSecantFirst) {
-        fa = f;
-        x = xb;
-        stage = kSecant;
-        continue;
-      }
-      if (stage == kSecant) {
-        const double fb = f, f0 = fa;
-        ++evals;
-        const bool ok = fabs(fb) <= p.atol;
-        if (!ok && !((int)evals >= p.newton_maxiter || fb == f0)) {
-          const double x2 = xb - fb * (xb - xa) / (fb - f0);
-          if (isfinite(x2)) {
-            xa = xb;
-            fa = fb;
-            x = xb = x2;
-            continue;
-          }
+// CF evaluation, which this kernel runs with its full series every time.)
+//
+// (b) The records of the chain — the CF kernel's tiles, and this kernel's workgroups when (a) had work — are added
+// into `accum` by the first kRecStride workgroups, one accumulator slot each, in reduce_records_kernel's order
+// (sum_slot).  When (a) had work they wait for every workgroup's record first: kHeavyGrid workgroups are resident
+// together on any device this library runs on, each arrives once, none waits before it has arrived.
+__device__ __forceinline__ void tail_whole_trajectory(const BkArgs& p, const BesselTable* bt, const double* coef,
+                                                      uint64_t path, double (&acc)[6]) {
+  PathSetup s;
+  bk_setup(p, bt, path, s);
+  double n_terms = 0.0;
+  enum Stage { kSecantFirst, kSecant, kLadderLo, kLadderHi, kBisect };
+  // secant_inverse: Order2 restated as the secant iteration from (x0 + dx, x0), dx = h + |x0| h², h = eps^(1/3).
+  // The secant's (x0, f0), (x1, f1) and the ladder's (lo, f(lo)), hi share their registers: xa, fa, xb, fb
+  const double hs = 6.0554544523933395e-06;
+  double xb = s.initial_guess;                   // secant: x1            ladder: hi
+  double xa = xb + hs + fabs(xb) * hs * hs;      // secant: x0            ladder: lo
+  double fa = 0.0;                               // secant: f0            ladder: f(lo)
+  uint32_t dec = kDecLongSeries, evals = 1, iters = 0;
+  int stage = kSecantFirst;
+  double x = xa;
+  for (;;) {
+    const double f = cdf_from_cf(p, bt, coef, s.cf, x, s.h, s.cache, n_terms) - s.u;
+    if (stage == kSecantFirst) {
+      fa = f;
+      x = xb;
+      stage = kSecant;
+      continue;
+    }
+    if (stage == kSecant) {
+      const double fb = f, f0 = fa;
+      ++evals;
+      const bool ok = fabs(fb) <= p.atol;
+      if (!ok && !((int)evals >= p.newton_maxiter || fb == f0)) {
+        const double x2 = xb - fb * (xb - xa) / (fb - f0);
+        if (isfinite(x2)) {
+          xa = xb;
+          fa = fb;
+          x = xb = x2;
+          continue;
         }
-        dec |= evals;
-        x = xb;                            // the secant's answer, should it stand
-        if (ok && !(xb < 0.0)) break;
-        acc[2] += 1.0;  // the fall-back ladder (sample_from_cf.jl:123-133)
-        x = xa = 0.0;
-        xb = s.max_guess;
-        stage = kLadderLo;
-        continue;
       }
-      if (stage == kLadderLo) {
-        fa = f;
-        x = xb;
-        stage = kLadderHi;
-        continue;
-      }
-      if (stage == kLadderHi) {
-        if (fa * f > 0.0) {
-          acc[4] += 1.0;
-          dec |= kDecMaxGuess;  // x = max_guess (sample_from_cf.jl:124-126)
-          break;
-        }
-        acc[3] += 1.0;
-        dec |= kDecBisect;
-        x = 0.5 * (xa + xb);
-        if (p.bisect_maxiter <= 0) break;
-        stage = kBisect;
-        continue;
-      }
-      // kBisect: f is the CDF residual at the midpoint x
-      ++iters;
-      if (f == 0.0) {
-        xa = xb = x;
-      } else if ((f < 0.0) == (fa < 0.0)) {
-        xa = x;
-        fa = f;
-      } else {
-        xb = x;
-      }
-      x = 0.5 * (xa + xb);
-      if (f == 0.0 || xb - xa <= p.atol || (int)iters >= p.bisect_maxiter) {
-        dec |= (iters & 0xffu) << kDecItersShift;
+      dec |= evals;
+      x = xb;                            // the secant's answer, should it stand
+      if (ok && !(xb < 0.0)) break;
+      acc[2] += 1.0;  // the fall-back ladder (sample_from_cf.jl:123-133)
+      x = xa = 0.0;
+      xb = s.max_guess;
+      stage = kLadderLo;
+      continue;
+    }
+    if (stage == kLadderLo) {
+      fa = f;
+      x = xb;
+      stage = kLadderHi;
+      continue;
+    }
+    if (stage == kLadderHi) {
+      if (fa * f > 0.0) {
+        acc[4] += 1.0;
+        dec |= kDecMaxGuess;  // x = max_guess (sample_from_cf.jl:124-126)
         break;
       }
+      acc[3] += 1.0;
+      dec |= kDecBisect;
+      x = 0.5 * (xa + xb);
+      if (p.bisect_maxiter <= 0) break;
+      stage = kBisect;
+      continue;
     }
-    const double IV = x;
-    p.diag[path] = dec;
-    p.diag[p.draw_stride + path] = (uint32_t)s.cache.j_stop;
-    acc[5] += n_terms;
-    const double pay = bk_finish_path(p, path, IV);
-    acc[0] += pay;
-    acc[1] = fma(pay, pay, acc[1]);
+    // kBisect: f is the CDF residual at the midpoint x
+    ++iters;
+    if (f == 0.0) {
+      xa = xb = x;
+    } else if ((f < 0.0) == (fa < 0.0)) {
+      xa = x;
+      fa = f;
+    } else {
+      xb = x;
+    }
+    x = 0.5 * (xa + xb);
+    if (f == 0.0 || xb - xa <= p.atol || (int)iters >= p.bisect_maxiter) {
+      dec |= (iters & 0xffu) << kDecItersShift;
+      break;
+    }
   }
-  bk_store_record(acc, p.records + (size_t)(n_tiles + blockIdx.x) * kRecStride);
+  const double IV = x;
+  p.diag[path] = dec;
+  p.diag[p.draw_stride + path] = (uint32_t)s.cache.j_stop;
+  acc[5] += n_terms;
+  const double pay = bk_finish_path(p, path, IV);
+  acc[0] += pay;
+  acc[1] = fma(pay, pay, acc[1]);
+}
+
+// The tiles of tail workgroup b that hold a trajectory for it, in increasing order: fn(tile) for each.  256 tiles
+// are looked at per turn (a lane reads the four ballots of ONE tile), the hits handed on through LDS.
+template <class Fn>
+__device__ __forceinline__ void for_long_tiles(const unsigned long long* __restrict__ long_mask, uint32_t n_tiles,
+                                               uint32_t b, Fn&& fn) {
+  __shared__ unsigned char hit[kTile];
+  for (uint32_t t0 = b; t0 < n_tiles; t0 += (uint32_t)kHeavyGrid * kTile) {  // (uniform)
+    const uint32_t t = t0 + threadIdx.x * (uint32_t)kHeavyGrid;
+    unsigned long long any = 0ull;
+    if (t < n_tiles) {
+#pragma unroll
+      for (int w = 0; w < kTile / 64; ++w) any |= long_mask[(size_t)t * (kTile / 64) + w];
+    }
+    __syncthreads();  // the turn before is done with `hit`
+    hit[threadIdx.x] = any != 0ull;
+    __syncthreads();
+    for (uint32_t i = 0; i < (uint32_t)kTile; ++i)
+      if (hit[i]) fn(t0 + i * (uint32_t)kHeavyGrid);  // (uniform)
+  }
+}
+
+__global__ __launch_bounds__(kTile) void bk_tail_kernel(const BkArgs* __restrict__ args, const BkTables* __restrict__ tabs,
+                                                        uint32_t n_tiles, double n_paths, double* __restrict__ accum) {
+  const BkArgs& p = *args;
+  const uint32_t b = blockIdx.x, tid = threadIdx.x;
+  uint32_t* cnt = p.counters;
+  const uint32_t n_long = __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (uniform)
+  if (n_long != 0u) {
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    for_long_tiles(p.long_mask, n_tiles, b, [&](uint32_t tile) {
+      const uint64_t path = (uint64_t)tile * kTile + tid;
+      if ((p.long_mask[(size_t)tile * (kTile / 64) + (tid >> 6)] >> (tid & 63u)) & 1ull)
+        tail_whole_trajectory(p, tabs->t, tabs->coef, path, acc);
+    });
+    bk_store_record(acc, p.records + (size_t)(n_tiles + b) * kRecStride);
+    // every workgroup has read counters[0] and left its record before a reducer goes on: all arrive, the reducers
+    // wait.  (Plain stores, an agent-scope release behind the workgroup's barrier, an agent-scope acquire behind
+    // the wait: MI355X_MICROARCH.md, inter-workgroup visibility.  The path of a tolerance nobody prices with.)
+    __syncthreads();
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_fetch_add(cnt + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (b >= (uint32_t)kRecStride) return;
+    if (tid == 0) {
+      while (__hip_atomic_load(cnt + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (uint32_t)kHeavyGrid)
+        __builtin_amdgcn_s_sleep(8);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // the last reducer through leaves the line as the next chain expects it
+      if (__hip_atomic_fetch_add(cnt + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (uint32_t)kRecStride - 1u) {
+        __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(cnt + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(cnt + 3, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    __syncthreads();
+  } else if (b >= (uint32_t)kRecStride) {
+    return;
+  }
+  // (b) slot b of the accumulator
+  __shared__ double sm[257];
+  const uint32_t n_rec = n_long != 0u ? n_tiles + (uint32_t)kHeavyGrid : n_tiles;
+  const double out = sum_slot(p.records, n_rec, (int)b, sm);
+  if (tid == 0) {
+    accum[b] = b == (uint32_t)HH_ACC_NPATHS ? n_paths : out;
+    if (b == 0u) cnt[1] = n_rec;
+  }
 }
 
 // ---- a second model on a chain that has run ------------------------------------------------------------------------
@@ -1328,42 +1382,31 @@ __global__ __launch_bounds__(kTile) void bk_fallback_kernel(
 // (greeks_problem.jl:279-329, 360-422) — and when the bump is of the spot, the rate, ρ or the strike, nothing the
 // variance process sees has moved: the same V_T, the same characteristic function, the same inversion, the same ∫V for
 // every trajectory.  The chain of the first model leaves ∫V per trajectory (BkArgs::iv_keep); this kernel finishes
-// another model from it: log S_T, payoff, and the SAME records — workgroup b of the three kernels of the chain
-// (CF tiles | fall-back | ladder chunks) sums the payoffs of the same trajectories in the same order through the same
+// another model from it: log S_T, payoff, and the SAME records — workgroup b of the two kernels of the chain
+// (CF tiles | tail workgroups) sums the payoffs of the same trajectories in the same order through the same
 // tree (bk_store_record), so the sums are those of a chain of its own, bit for bit; the counters, which are the
 // chain's, are copied from the first model's records.
-__global__ __launch_bounds__(kTile) void bk_refinish_kernel(const BkArgs p, const double* __restrict__ rec0, uint32_t n_tiles,
-                                                            const uint32_t* __restrict__ prefix,
-                                                            const uint32_t* __restrict__ prefix_long) {
+__global__ __launch_bounds__(kTile) void bk_refinish_kernel(const BkArgs p, const double* __restrict__ rec0, uint32_t n_tiles) {
   const uint32_t b = blockIdx.x, tid = threadIdx.x;
+  if (b >= p.counters[1]) return;  // (uniform) the chain's tail kernel had no trajectories: no records of it
   double acc[6] = {0, 0, 0, 0, 0, 0};
-  if (b < n_tiles) {  // a tile of the CF kernel: the trajectories whose secant stood
+  if (b < n_tiles) {  // a tile of the CF kernel: every trajectory but the too-long ones
     const uint64_t path = (uint64_t)b * kTile + tid;
-    const size_t w = (size_t)b * (kTile / 64) + (tid >> 6);
-    const bool left = ((p.fail_mask[w] | p.long_mask[w]) >> (tid & 63u)) & 1ull;  // finished by another kernel
+    const bool left = (p.long_mask[(size_t)b * (kTile / 64) + (tid >> 6)] >> (tid & 63u)) & 1ull;  // finished by the tail kernel
     if (path < p.n_paths && !left) {
       const double pay = bk_finish_path(p, path, p.iv_keep[path]);
       acc[0] = pay;
       acc[1] = pay * pay;
     }
-  } else if (b < n_tiles + (uint32_t)kHeavyGrid) {  // a workgroup of the fall-back kernel: packed, grid stride
-    const uint32_t total = prefix_long[n_tiles];
-    for (uint32_t g = (b - n_tiles) * kTile + tid; g < total; g += (uint32_t)kHeavyGrid * kTile) {
-      const uint64_t path = packed_path(p.long_mask, prefix_long, 0, n_tiles, g);
-      const double pay = bk_finish_path(p, path, p.iv_keep[path]);
-      acc[0] += pay;
-      acc[1] = fma(pay, pay, acc[1]);
-    }
-  } else {  // a chunk of the ladder kernel
-    const uint32_t c = b - n_tiles - (uint32_t)kHeavyGrid, total = prefix[n_tiles];
-    if (c * (uint32_t)kTile >= total) return;  // (uniform) as there: no work, no record
-    const uint32_t g = c * kTile + tid;
-    if (g < total) {
-      const uint64_t path = packed_path(p.fail_mask, prefix, p.chunk_tile[c], p.chunk_tile[c + 1u] + 1u, g);
-      const double pay = bk_finish_path(p, path, p.iv_keep[path]);
-      acc[0] += pay;
-      acc[1] = fma(pay, pay, acc[1]);
-    }
+  } else {  // a workgroup of the tail kernel: its tiles, in its order
+    for_long_tiles(p.long_mask, n_tiles, b - n_tiles, [&](uint32_t tile) {
+      const uint64_t path = (uint64_t)tile * kTile + tid;
+      if ((p.long_mask[(size_t)tile * (kTile / 64) + (tid >> 6)] >> (tid & 63u)) & 1ull) {
+        const double pay = bk_finish_path(p, path, p.iv_keep[path]);
+        acc[0] += pay;
+        acc[1] = fma(pay, pay, acc[1]);
+      }
+    });
   }
   double* rec = p.records + (size_t)b * kRecStride;
   bk_store_record(acc, rec);
@@ -1410,37 +1453,139 @@ __global__ __launch_bounds__(256) void fill_rows_kernel(double* __restrict__ spo
 // and the chain runs its positions in that order, reading and writing each pair where it lies (BkArgs::order).
 // Nothing a pair computes depends on its neighbours, and the chain's counters are whole numbers: the grid is the
 // same, bit for bit.
-constexpr int kGridKeyBits = 8;
-// below this many pairs the sort costs more than the order saves (2.4·10^5 pairs: +8 %; 2.4·10^6: -25 %)
+// The sort is a counting sort of ONE 8-bit digit, three small kernels in this file (until round 5: a general radix
+// sort from a library, three kernels of its own and 42 µs for 2.4·10^6 pairs): a run of kSortRun consecutive pairs per
+// WAVE — (1) its 256-bin histogram (LDS atomics), (2) per digit, the exclusive prefix sums of the runs' counts, (3) the
+// scatter: a run's pairs in 16 rounds of 64, a lane's place = its digit's base + the run's offset + the pairs of the
+// same digit in front of it in the run (the lanes with its digit found by eight ballots, the running count per digit
+// in LDS).  Stable: equal keys stay in pair order — the order a stable radix sort of (key, pair) gives.
+constexpr int kSortRun = 1024;                           // consecutive pairs per wave
+constexpr int kSortWaves = kTile / 64;
+static_assert(kSortRun % 64 == 0, "whole rounds of a wave");
+
+__global__ __launch_bounds__(kTile) void grid_sort_count_kernel(const uint8_t* __restrict__ keys, uint32_t n, uint32_t n_runs,
+                                                                uint32_t* __restrict__ counts) {
+  __shared__ uint32_t hist[kSortWaves][256];
+  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u, run = blockIdx.x * kSortWaves + wave;
+  for (uint32_t d = lane; d < 256u; d += 64u) hist[wave][d] = 0u;
+  __syncthreads();
+  if (run < n_runs) {
+    const uint32_t base = run * (uint32_t)kSortRun;
+#pragma unroll 4
+    for (uint32_t r = 0; r < (uint32_t)kSortRun / 64u; ++r) {
+      const uint32_t i = base + r * 64u + lane;
+      if (i < n) atomicAdd(&hist[wave][keys[i]], 1u);
+    }
+  }
+  __syncthreads();
+  if (run < n_runs)
+    for (uint32_t d = lane; d < 256u; d += 64u) counts[(size_t)d * n_runs + run] = hist[wave][d];
+}
+
+// workgroup d: counts[d][0 … n_runs) -> their exclusive prefix sums in place, the digit's total in totals[d]
+__global__ __launch_bounds__(kTile) void grid_sort_scan_kernel(uint32_t* __restrict__ counts, uint32_t n_runs,
+                                                               uint32_t* __restrict__ totals) {
+  __shared__ uint32_t wsum[kTile / 64];
+  uint32_t* c = counts + (size_t)blockIdx.x * n_runs;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const uint32_t per = (n_runs + kTile - 1) / kTile;  // a thread's stretch of consecutive runs
+  const uint32_t r0 = min(tid * per, n_runs), r1 = min(r0 + per, n_runs);
+  uint32_t mine = 0;
+  for (uint32_t r = r0; r < r1; ++r) mine += c[r];
+  uint32_t inc = mine;  // inclusive scan of the stretch totals inside the wave
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t v = __shfl_up(inc, off, 64);
+    if (lane >= (uint32_t)off) inc += v;
+  }
+  if (lane == 63u) wsum[wave] = inc;
+  __syncthreads();
+  uint32_t before = 0, total = 0;
+#pragma unroll
+  for (uint32_t w = 0; w < kTile / 64; ++w) {
+    if (w < wave) before += wsum[w];
+    total += wsum[w];
+  }
+  uint32_t run_at = before + inc - mine;
+  for (uint32_t r = r0; r < r1; ++r) {
+    const uint32_t v = c[r];
+    c[r] = run_at;
+    run_at += v;
+  }
+  if (tid == 0) totals[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(kTile) void grid_sort_scatter_kernel(const uint8_t* __restrict__ keys, uint32_t n, uint32_t n_runs,
+                                                                  const uint32_t* __restrict__ offs,
+                                                                  const uint32_t* __restrict__ totals,
+                                                                  uint32_t* __restrict__ order) {
+  __shared__ uint32_t at[kSortWaves][256];  // where the next pair of digit d of this wave's run goes
+  __shared__ uint32_t wsum[kTile / 64];
+  const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u, run = blockIdx.x * kSortWaves + wave;
+  // the digits' bases: exclusive prefix sums of the 256 totals (thread d: digit d)
+  const uint32_t tot = totals[tid];
+  uint32_t inc = tot;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t v = __shfl_up(inc, off, 64);
+    if (lane >= (uint32_t)off) inc += v;
+  }
+  if (lane == 63u) wsum[wave] = inc;
+  __syncthreads();
+  uint32_t base_d = inc - tot;
+#pragma unroll
+  for (uint32_t w = 0; w < kTile / 64; ++w)
+    if (w < wave) base_d += wsum[w];
+#pragma unroll
+  for (uint32_t w = 0; w < (uint32_t)kSortWaves; ++w) {
+    const uint32_t rw = blockIdx.x * kSortWaves + w;
+    at[w][tid] = rw < n_runs ? base_d + offs[(size_t)tid * n_runs + rw] : 0u;
+  }
+  __syncthreads();
+  if (run >= n_runs) return;  // (wave-uniform; no barrier below)
+  const uint32_t first = run * (uint32_t)kSortRun;
+  for (uint32_t r = 0; r < (uint32_t)kSortRun / 64u; ++r) {
+    const uint32_t i = first + r * 64u + lane;
+    const bool valid = i < n;
+    const uint32_t key = valid ? (uint32_t)keys[i] : 0u;
+    unsigned long long peers = __ballot(valid);  // the lanes of this round with this lane's digit
+#pragma unroll
+    for (int bit = 0; bit < 8; ++bit) {
+      const bool set = (key >> bit) & 1u;
+      const unsigned long long bl = __ballot(set);
+      peers &= set ? bl : ~bl;
+    }
+    const uint32_t rank = (uint32_t)__popcll(peers & ((1ull << lane) - 1ull));
+    uint32_t place = 0;
+    if (valid && rank == 0u) {  // the first of its digit: takes the places of all of them
+      place = __hip_atomic_load(&at[wave][key], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_store(&at[wave][key], place + (uint32_t)__popcll(peers), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    place = (uint32_t)__shfl((int)place, valid ? __ffsll((long long)peers) - 1 : (int)lane, 64);
+    if (valid) order[place + rank] = i;
+  }
+}
+
+// below this many pairs the sort costs more than the order saves (round 5, with the library's sort: 2.4·10^5 pairs
+// +8 %, 2.4·10^6 -25 %)
 constexpr uint64_t kGridOrderMinPairs = 1ull << 20;
 
 }  // namespace
 
-constexpr size_t kSlotBitmapBytes = 8 * 128 + 128;  // one 128-byte line per XCD (kXcds = 8) + the side-store counter's
+constexpr size_t kSlotBitmapBytes = 8 * 128 + 128;  // one 128-byte line per XCD (kXcds = 8) + the line of BkArgs::counters
 
 // series terms cached per column: term_cache (HH_OPT_BK_TERM_CACHE; 0 = kBkTermCacheDefault).  The columns
 // belong to workgroup slots, so the cache does not grow with the ensemble.
 static int phi_cache_cap(int term_cache) { return term_cache > 0 ? term_cache : kBkTermCacheDefault; }
 
-// ballots (fail, long) | prefix sums (fail, long) | tile counts | slot flags | device copy of the argument block | Bessel tables
-static size_t bk_masks_bytes(size_t n_tiles) {
-  return 2 * n_tiles * (kTile / 64) * sizeof(unsigned long long);
-}
-static size_t bk_args_offset(size_t n_tiles) {  // … + prefix sums [2][n_tiles+1] + tile counts [n_tiles] + chunk starts [n_tiles+1]
-  const size_t b = bk_masks_bytes(n_tiles) + (3 * (n_tiles + 1) + n_tiles) * sizeof(uint32_t) + 128 + kSlotBitmapBytes;
-  return (b + 255) & ~(size_t)255;
-}
-static size_t bk_tables_offset(size_t n_tiles) {
-  return bk_args_offset(n_tiles) + ((sizeof(BkArgs) + 255) & ~(size_t)255);
-}
-static size_t bk_flags_bytes(size_t n_tiles) {
-  return bk_tables_offset(n_tiles) + ((sizeof(BkTables) + 255) & ~(size_t)255);
-}
-// side-store entries: one trajectory in sixteen (2 % fail with the reference's controls), at least 4096
-static size_t bk_side_cap(size_t n_tiles) {
-  const size_t c = n_tiles * kTile / 16;
-  return c < 4096 ? 4096 : c;
-}
+// The head of the scratch buffer:
+//   ballots of the too-long trajectories [n_tiles][4] | (128-byte boundary) slot bitmaps, 8 lines | counters, 1 line |
+//   (256-byte boundary) device copy of the argument block | (256) Bessel tables and ϕ(0) constants
+static size_t bk_masks_bytes(size_t n_tiles) { return n_tiles * (kTile / 64) * sizeof(unsigned long long); }
+static size_t bk_lines_offset(size_t n_tiles) { return (bk_masks_bytes(n_tiles) + 127) & ~(size_t)127; }
+static size_t bk_args_offset(size_t n_tiles) { return (bk_lines_offset(n_tiles) + kSlotBitmapBytes + 255) & ~(size_t)255; }
+static size_t bk_tables_offset(size_t n_tiles) { return bk_args_offset(n_tiles) + ((sizeof(BkArgs) + 255) & ~(size_t)255); }
+static size_t bk_flags_bytes(size_t n_tiles) { return bk_tables_offset(n_tiles) + ((sizeof(BkTables) + 255) & ~(size_t)255); }
 // columns of cached terms: one per lane of a workgroup slot (fewer slots than tiles are never needed)
 static size_t bk_cache_columns(size_t n_tiles) {
   const size_t slots = n_tiles < (size_t)kHeavyGrid ? (size_t)kHeavyGrid : n_tiles < (size_t)kSlots ? n_tiles : (size_t)kSlots;
@@ -1454,35 +1599,27 @@ int launch_fill_rows(double* spot0, double* var0, uint64_t n, double S0, double 
 }
 
 uint32_t bk_record_count(uint64_t n_paths) {
-  return 2 * tiles_for(n_paths) + (uint32_t)kHeavyGrid;  // CF tiles | fall-back | ladder workgroups (worst case)
+  return tiles_for(n_paths) + (uint32_t)kHeavyGrid;  // CF tiles | the tail kernel's workgroups
 }
-// … of which a chain fills the first *bk_live_records(): the ladder workgroups that had work come last, the
-// reduction reads no further (10^6 trajectories: 4058 records instead of 7878 — one round trip per thread, 6 µs
-// instead of 11)
-// (the words behind the ballots: prefix sums [2][n_tiles + 1] | tile counts [n_tiles] | chunk starts [n_tiles + 1] |
-// then, on a 128-byte boundary, the slot bitmaps and the line of the two counters)
-static uint32_t* bk_slot_lines(unsigned char* base, size_t n_tiles) {
-  uint32_t* words = reinterpret_cast<uint32_t*>(base + bk_masks_bytes(n_tiles));
-  return reinterpret_cast<uint32_t*>((reinterpret_cast<uintptr_t>(words + 3 * (n_tiles + 1) + n_tiles) + 127) & ~(uintptr_t)127);
-}
+// … of which a chain fills the first *bk_live_records(): the tail kernel's workgroups leave records only when
+// they had trajectories to run (BkArgs::counters[1], written by the tail kernel)
 const uint32_t* bk_live_records(const void* scratch, uint64_t n_paths) {
-  return bk_slot_lines(static_cast<unsigned char*>(const_cast<void*>(scratch)), tiles_for(n_paths)) + 8 * 32 + 1;
+  const unsigned char* base = static_cast<const unsigned char*>(scratch);
+  return reinterpret_cast<const uint32_t*>(base + bk_lines_offset(tiles_for(n_paths)) + 8 * 128) + 1;
 }
 
 size_t bk_scratch_bytes(uint64_t n_paths, int term_cache) {
   const size_t n_tiles = tiles_for(n_paths);
-  // flags + prefix | cached series terms [cap][columns] (per workgroup SLOT: independent of n_paths) |
-  // per trajectory: draws [4] | ∫V [1] | decision word, series length, side index (3 x uint32 in 2 doubles) |
-  // side store: kSideEntry doubles for one trajectory in sixteen
+  // head | cached series terms [cap][columns] (per workgroup SLOT: independent of n_paths) |
+  // per trajectory: draws [4] | ∫V [1] | decision word, series length (2 x uint32)
   return bk_flags_bytes(n_tiles) + bk_cache_columns(n_tiles) * (size_t)phi_cache_cap(term_cache) * sizeof(double) +
-         n_tiles * kTile * sizeof(double) * 7 + bk_side_cap(n_tiles) * (size_t)kSideEntry * sizeof(double);
+         n_tiles * kTile * sizeof(double) * 6;
 }
 
 namespace {
 
 struct BkLayout {
   uint32_t n_tiles;
-  uint32_t *prefix, *prefix_long;
   BkTables* tabs_dev;
 };
 
@@ -1517,17 +1654,12 @@ int bk_prepare(const hh_model& m, const hh_config& c, const DevicePtrs& ptr, uin
   a.terminal = ptr.terminal;
   a.records = ptr.records;
   const uint32_t n_tiles = tiles_for(n_chain);
-  // scratch: ballots (fail, long) + prefix | cached series terms [cap][lanes] | draws [4][lanes] | rec [4][lanes] | ∫V [lanes]
   const size_t lanes = (size_t)n_tiles * kTile;
   unsigned char* base = reinterpret_cast<unsigned char*>(ptr.bk_scratch);
-  a.fail_mask = reinterpret_cast<unsigned long long*>(base);
-  a.long_mask = a.fail_mask + (size_t)n_tiles * (kTile / 64);
+  a.long_mask = reinterpret_cast<unsigned long long*>(base);
   L.n_tiles = n_tiles;
-  L.prefix = reinterpret_cast<uint32_t*>(a.long_mask + (size_t)n_tiles * (kTile / 64));
-  L.prefix_long = L.prefix + n_tiles + 1;
-  a.tile_counts = L.prefix_long + n_tiles + 1;
-  a.chunk_tile = a.tile_counts + n_tiles;
-  a.slot_busy = bk_slot_lines(base, n_tiles);  // 128-byte lines
+  a.slot_busy = reinterpret_cast<uint32_t*>(base + bk_lines_offset(n_tiles));  // 128-byte lines
+  a.counters = a.slot_busy + 8 * 32;                                            // the line behind the eight slot bitmaps
   a.args_dev = base + bk_args_offset(n_tiles);
   L.tabs_dev = reinterpret_cast<BkTables*>(base + bk_tables_offset(n_tiles));
   a.tabs_dev = L.tabs_dev;
@@ -1538,10 +1670,7 @@ int bk_prepare(const hh_model& m, const hh_config& c, const DevicePtrs& ptr, uin
   a.static_slots = n_tiles <= (uint32_t)kSlots ? 1u : 0u;
   a.draws = a.phi_cache + a.cache_stride * (size_t)a.cache_cap;
   a.iv_store = a.draws + 4 * lanes;  // ∫V per pair of a grid chain / per trajectory of the one-shot law (iv_keep)
-  a.diag = reinterpret_cast<uint32_t*>(a.iv_store + lanes);  // 3 x uint32 per lane in 2 doubles per lane
-  a.side = a.iv_store + 3 * lanes;
-  a.side_cap = (uint32_t)bk_side_cap(n_tiles);
-  a.side_count = a.slot_busy + 8 * 32;  // the 128-byte line behind the eight slot bitmaps
+  a.diag = reinterpret_cast<uint32_t*>(a.iv_store + lanes);  // 2 x uint32 per lane
   a.draw_stride = lanes;
   return 0;
 }
@@ -1555,8 +1684,8 @@ int bk_tables(const BkArgs& a, const BkLayout& L, const DevicePtrs& ptr, hipStre
                       ptr.bk_table_key->kappa == a.kappa && ptr.bk_table_key->sigma2 == a.sigma2 &&
                       ptr.bk_table_key->T == a.T);
   if (upload_tables) {
-    // … and the slot bitmaps and the side-store counter beside them start from zero; after that every chain leaves
-    // them so (a workgroup gives its slot back, bk_scan_kernel resets the counter): no 5 µs fill per solve
+    // … and the slot bitmaps and the counters beside them start from zero; after that every chain leaves them so
+    // (a workgroup gives its slot back, bk_tail_kernel resets what it counted with): no 5 µs fill per solve
     (void)hipMemsetAsync(a.slot_busy, 0, kSlotBitmapBytes, s);
     BkBessel tabs;
     if (!bessel_table(a.nu, tabs.t[0]) || !bessel_table(a.nu - a.n_int, tabs.t[1]))
@@ -1568,32 +1697,28 @@ int bk_tables(const BkArgs& a, const BkLayout& L, const DevicePtrs& ptr, hipStre
   return 0;
 }
 
-// CF work, prefix sums, ladder, fall-back — everything behind the draws
-void bk_chain(const BkArgs& a, const BkLayout& L, hipStream_t s, bool draw_in_chain = false) {
+// the chain behind the draws: the CF kernel (draw: 0 the draws are in place, 1 made there, 2 the caller's, read
+// there), then the tail kernel, which leaves the sums of the chain's records in `accum` (slot HH_ACC_NPATHS: n_acc)
+void bk_chain(const BkArgs& a, const BkLayout& L, hipStream_t s, double* accum, double n_acc, int draw = 0) {
   const dim3 b(kTile), g(L.n_tiles);
   const BkTables* tabs = static_cast<const BkTables*>(L.tabs_dev);
   if (a.order)
     hipLaunchKernelGGL(bk_cf_kernel<1>, g, b, 0, s, a, tabs);
-  else if (draw_in_chain)
-    hipLaunchKernelGGL((bk_cf_kernel<0, true>), g, b, 0, s, a, tabs);
+  else if (draw == 1)
+    hipLaunchKernelGGL((bk_cf_kernel<0, 1>), g, b, 0, s, a, tabs);
+  else if (draw == 2)
+    hipLaunchKernelGGL((bk_cf_kernel<0, 2>), g, b, 0, s, a, tabs);
   else
     hipLaunchKernelGGL(bk_cf_kernel<0>, g, b, 0, s, a, tabs);
-  hipLaunchKernelGGL(bk_scan_kernel, dim3(1), dim3(kScanThreads), 0, s, a, L.n_tiles, L.prefix, L.prefix_long);
-  // (the grid covers the worst case, one workgroup per possible chunk; the ~3800 that find no work cost nothing
-  // measurable: with 512 workgroups the kernel takes the same 19.7 µs — it is one wave's dependent chain of a dozen
-  // CDF evaluations)
-  if (a.order)
-    hipLaunchKernelGGL(bk_ladder_kernel<1>, g, b, 0, s, a, tabs, L.n_tiles, L.prefix);
-  else
-    hipLaunchKernelGGL(bk_ladder_kernel<0>, g, b, 0, s, a, tabs, L.n_tiles, L.prefix);
-  hipLaunchKernelGGL(bk_fallback_kernel, dim3(kHeavyGrid), b, 0, s,
-                     static_cast<const BkArgs*>(a.args_dev), tabs, L.n_tiles, L.prefix_long);
+  hipLaunchKernelGGL(bk_tail_kernel, dim3(kHeavyGrid), b, 0, s, static_cast<const BkArgs*>(a.args_dev), tabs, L.n_tiles,
+                     n_acc, accum);
 }
 
 }  // namespace
 
 int launch_bk(const hh_model& m, const hh_config& c, const DevicePtrs& ptr, hipStream_t s,
               const BkTransition* tr, bool upload_tables) {
+  if (!ptr.accum) return (int)hipErrorInvalidValue;  // the chain adds its own records
   BkArgs a{};
   BkLayout L{};
   if (tr) {
@@ -1606,13 +1731,13 @@ int launch_bk(const hh_model& m, const hh_config& c, const DevicePtrs& ptr, hipS
   a.replay = c.noise_mode == HH_NOISE_REPLAY ? ptr.replay : nullptr;
   if (!tr) a.iv_keep = a.iv_store;  // the one-shot law: ∫V per trajectory stays, for launch_bk_refinish
   if ((rc = bk_tables(a, L, ptr, s, upload_tables))) return rc;
-  const dim3 g(L.n_tiles), b(kTile);
-  const bool fuse_draws = HH_BK_FUSE_DRAWS && !a.replay && !a.in_var;  // the terminal law, drawn here
-  if (a.replay)
-    hipLaunchKernelGGL(bk_draw_kernel<true>, g, b, 0, s, a);
-  else if (!fuse_draws)
-    hipLaunchKernelGGL(bk_draw_kernel<false>, g, b, 0, s, a);
-  bk_chain(a, L, s, fuse_draws);
+  int draw = a.replay ? 2 : 1;  // the terminal law: drawn, or read, by the CF kernel
+  if (a.in_var) {               // a transition of a grid: its own kernel
+    if (a.replay) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(bk_draw_kernel, dim3(L.n_tiles), dim3(kTile), 0, s, a);
+    draw = 0;
+  }
+  bk_chain(a, L, s, ptr.accum, (double)c.n_paths, draw);
   return (int)hipGetLastError();
 }
 
@@ -1626,8 +1751,7 @@ int launch_bk_refinish(const hh_model& m, const hh_config& c, const DevicePtrs& 
   const int rc = bk_prepare(m, c, ptr, c.n_paths, a, L);  // the same places in the same scratch as the chain's own block
   if (rc) return rc;
   a.iv_keep = a.iv_store;
-  hipLaunchKernelGGL(bk_refinish_kernel, dim3(2 * L.n_tiles + (uint32_t)kHeavyGrid), dim3(kTile), 0, s, a, rec0, L.n_tiles,
-                     static_cast<const uint32_t*>(L.prefix), static_cast<const uint32_t*>(L.prefix_long));
+  hipLaunchKernelGGL(bk_refinish_kernel, dim3(L.n_tiles + (uint32_t)kHeavyGrid), dim3(kTile), 0, s, a, rec0, L.n_tiles);
   return (int)hipGetLastError();
 }
 
@@ -1655,21 +1779,17 @@ void bk_diag_ptrs(const void* scratch, uint64_t n_paths, int term_cache, const u
   *series_len = diag + lanes;
 }
 
-// device scratch of the ordered form of a grid chain over n_chain pairs: keys and pair indices (in / out), the radix
-// sort's own storage
-static size_t grid_sort_temp_bytes(uint64_t n_chain) {
-  size_t bytes = 0;
-  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr,
-                                           (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)n_chain, 0, kGridKeyBits);
-  return (bytes + 255) & ~(size_t)255;
-}
+// device scratch of the ordered form of a grid chain over n_chain pairs:
+//   the order [lanes] x uint32 | counts [256][n_runs] x uint32 | totals [256] x uint32 | keys [lanes] x uint8
+static uint32_t grid_sort_runs(uint64_t n_chain) { return (uint32_t)((n_chain + kSortRun - 1) / kSortRun); }
 size_t bk_grid_sort_bytes(uint64_t n_chain) {
   const size_t lanes = (size_t)tiles_for(n_chain) * kTile;
-  return 4 * lanes * sizeof(uint32_t) + grid_sort_temp_bytes(n_chain) + 256;  // keys and pair indices, in and out
+  return lanes * sizeof(uint32_t) + ((size_t)256 * grid_sort_runs(n_chain) + 256) * sizeof(uint32_t) + lanes + 256;
 }
 
 int launch_bk_grid(const hh_model& m, const hh_config& c, const DevicePtrs& ptr, hipStream_t s,
                    double* spot_rows, double* var_rows, uint32_t k0, uint32_t n_dates, bool upload_tables) {
+  if (!ptr.accum) return (int)hipErrorInvalidValue;
   BkArgs a{};
   BkLayout L{};
   const uint64_t n_row = c.n_paths, n_chain = n_row * n_dates;
@@ -1682,25 +1802,28 @@ int launch_bk_grid(const hh_model& m, const hh_config& c, const DevicePtrs& ptr,
   const dim3 rows(tiles_for(n_row)), b(kTile);
   const bool ordered = ptr.bk_sort && n_chain >= kGridOrderMinPairs && n_chain < (1ull << 31);
   const size_t lanes = (size_t)L.n_tiles * kTile;
-  uint32_t* keys_in = reinterpret_cast<uint32_t*>(ptr.bk_sort);
-  hipLaunchKernelGGL(bk_draw_grid_kernel, rows, b, 0, s, a, n_row, k0, n_dates, var_rows, ordered ? keys_in : nullptr,
-                     ordered ? keys_in + 2 * lanes : nullptr);
+  const uint32_t n_runs = grid_sort_runs(n_chain);
+  uint32_t* perm = reinterpret_cast<uint32_t*>(ptr.bk_sort);
+  uint32_t* counts = perm + lanes;
+  uint32_t* totals = counts + (size_t)256 * n_runs;
+  uint8_t* keys = reinterpret_cast<uint8_t*>(totals + 256);
+  hipLaunchKernelGGL(bk_draw_grid_kernel, rows, b, 0, s, a, n_row, k0, n_dates, var_rows, ordered ? keys : nullptr);
   if (ordered) {  // the pairs in the order of their Bessel arguments (grid_order_key)
-    uint32_t *keys_out = keys_in + lanes, *idx_in = keys_out + lanes, *perm = idx_in + lanes;
-    void* temp = perm + lanes;
-    size_t temp_bytes = grid_sort_temp_bytes(n_chain);
-    if (hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, static_cast<const uint32_t*>(keys_in), keys_out,
-                                           static_cast<const uint32_t*>(idx_in), perm, (int)n_chain, 0, kGridKeyBits, s) != hipSuccess)
-      return (int)hipErrorUnknown;
+    const dim3 sort_grid((n_runs + kSortWaves - 1) / kSortWaves);
+    hipLaunchKernelGGL(grid_sort_count_kernel, sort_grid, b, 0, s, static_cast<const uint8_t*>(keys), (uint32_t)n_chain,
+                       n_runs, counts);
+    hipLaunchKernelGGL(grid_sort_scan_kernel, dim3(256), b, 0, s, counts, n_runs, totals);
+    hipLaunchKernelGGL(grid_sort_scatter_kernel, sort_grid, b, 0, s, static_cast<const uint8_t*>(keys), (uint32_t)n_chain,
+                       n_runs, static_cast<const uint32_t*>(counts), static_cast<const uint32_t*>(totals), perm);
     // The chain reads each pair's draws and start variance, and writes its ∫V, THROUGH the order (BkArgs::order): a
     // pair's 48 bytes, fetched at random by a kernel that then computes for 0.3 µs per pair, hide behind the other
     // waves' arithmetic.  Copying them into the order first (a gather by destination 0.19 ms; by source through the
     // inverse permutation 0.10 ms) and scattering ∫V back (0.035) were passes the chain does not need.
     BkArgs o = a;
     o.order = perm;
-    bk_chain(o, L, s);
+    bk_chain(o, L, s, ptr.accum, (double)n_chain);
   } else {
-    bk_chain(a, L, s);
+    bk_chain(a, L, s, ptr.accum, (double)n_chain);
   }
   hipLaunchKernelGGL(bk_grid_spots_kernel, rows, b, 0, s, a, n_row, n_dates,
                      static_cast<const double*>(var_rows), spot_rows);

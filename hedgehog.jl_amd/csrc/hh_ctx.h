@@ -69,6 +69,9 @@ struct hh_ctx {
   double* frecords = nullptr;      // records of the launches that reduce them themselves: kPoison between launches (hh_sim.h)
   size_t frecords_cap = 0;         // in doubles
   int fuse_reduce = 2;             // hh_ctx_set_option(HH_OPT_FUSE_REDUCE): 0 a second kernel, 1 in the simulation kernel, 2 by size
+  unsigned int* finish_state = nullptr;  // device word: a reducer inside a simulation kernel gave up (hh_sim.h); cleared by recover_finish
+  long long finish_spin_ticks = -1;      // hh_ctx_set_option(HH_OPT_FINISH_SPIN_TICKS); < 0 = the default (5 s)
+  int finish_tile_first = 0;             // hh_ctx_set_option(HH_OPT_FINISH_TILE_FIRST)
   // seed vectors kept in device memory (hh_seeds_cache): content-addressed, least recently used one out
   struct SeedEntry {
     uint64_t* dev = nullptr;

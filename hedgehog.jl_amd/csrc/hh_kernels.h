@@ -15,6 +15,7 @@ constexpr int kRecStride = HH_ACC_LEN;
 // what every word of the self-reducing launches' record buffer holds between launches (hh_sim.h, finish_records):
 // a quiet NaN no arithmetic produces; both 32-bit halves alike, so that hipMemsetD32 can write it
 constexpr unsigned long long kPoison = 0x7FF8C0DE7FF8C0DEull;
+constexpr unsigned long long kFinishSpinTicksDefault = 500000000ull;  // 5 s of the 100 MHz clock
 constexpr int kRecItmS = 11;  // Σ 1[itm]·cp·S   (kRecItmS + 1: Σ 1[itm]·cp)
 
 // value + P partials (forward-mode dual number; ForwardDiff.Dual{Tag,Float64,P} on the reference
@@ -69,6 +70,12 @@ struct SimArgs {
   // leaves the reduced HH_ACC_LEN-double accumulator vector in `accum`.  nullptr: records only.
   double* accum;          // device; then `records` is a buffer that holds kPoison between launches
   double acc_n_paths;     // what goes into slot HH_ACC_NPATHS
+  // … its reducer: the workgroup of tile `reducer_tile` (the last one; the first under HH_OPT_FINISH_TILE_FIRST),
+  // which waits at most `finish_spin_ticks` of the 100 MHz clock for a record and, when it gives up, says so in
+  // finish_state[0] — a word of the context that stays set until the host has put the record buffer right again
+  unsigned int* finish_state;
+  unsigned long long finish_spin_ticks;
+  uint32_t reducer_tile;
   PartialMap map;         // how the requested directions come out of the carried ones (map.n = n_partials)
 };
 
@@ -80,6 +87,9 @@ struct DevicePtrs {
   double* records;
   double* accum;          // non-NULL: the simulation kernel also reduces its records into this vector, and
                           // `records` is a poisoned buffer (hh_sim.h, finish_records)
+  unsigned int* finish_state;       // … with the context's give-up word (SimArgs::finish_state), its wait bound in
+  long long finish_spin_ticks = -1; //   ticks (< 0: kFinishSpinTicksDefault) and which tile's workgroup reduces
+  int finish_tile_first = 0;        //   (0: the last)
   void* bk_scratch;  // Broadie–Kaya: bk_scratch_bytes() of device memory
   // Broadie–Kaya: which Bessel tables bk_scratch holds (NULL = unknown, always uploaded): the owner of
   // bk_scratch keeps one BkTableKey next to it, zero-initialised
@@ -125,12 +135,13 @@ inline uint32_t tiles_for(uint64_t n_paths) { return (uint32_t)((n_paths + kTile
 // chip always has >= 2048 workgroups to run and the reducer at most a few thousand records to add.  The form is
 // a function of the shard's n_paths alone, so a result is reproducible for a given (n_paths, sharding) as
 // everywhere else.
+#ifndef HH_EXACT_PAIRS_SMALL
+#define HH_EXACT_PAIRS_SMALL 4
+#endif
 constexpr int kExactPairs = 8, kExactPairsHuge = 64;
-inline int exact_pairs_per_lane(uint64_t n_paths) {
-  return n_paths >= (uint64_t)2048 * 512 * kExactPairsHuge ? kExactPairsHuge
-         : n_paths >= (uint64_t)2048 * 512 * kExactPairs   ? kExactPairs
-                                                           : 1;
-}
+constexpr int kExactPairsSmall = HH_EXACT_PAIRS_SMALL;  // below 2048·512·8 trajectories (hh_kernels.hip says why)
+// (defined in hh_kernels.hip: $HEDGEHOG_MC_EXACT_PAIRS overrides it for a measurement — tools/exact_pairs_ab.py)
+int exact_pairs_per_lane(uint64_t n_paths);
 inline uint32_t exact_records(uint64_t n_paths) {
   const uint64_t per = 512ull * (uint64_t)exact_pairs_per_lane(n_paths);
   return (uint32_t)((n_paths + per - 1) / per);
@@ -189,7 +200,7 @@ size_t bk_scratch_bytes(uint64_t n_paths, int term_cache = 0);
 // secant evaluations | branch << 8 | bisection iterations << 16 | long-series bit 31) and its series length
 void bk_diag_ptrs(const void* scratch, uint64_t n_paths, int term_cache, const uint32_t** decisions,
                   const uint32_t** series_len);
-uint32_t bk_record_count(uint64_t n_paths);  // records the Broadie–Kaya chain can write (inversion tiles + packed kernels)
+uint32_t bk_record_count(uint64_t n_paths);  // records the Broadie–Kaya chain can write (the CF kernel's tiles + the tail kernel's workgroups)
 // device word that holds, once the chain over n_paths trajectories (or pairs) has run in `scratch`, how many of them
 // it DID write — the reduction reads that many (launch_reduce_records, n_records_dev)
 const uint32_t* bk_live_records(const void* scratch, uint64_t n_paths);

@@ -12,6 +12,7 @@
 // register pipeline; GENERATE draws them in registers from Philox keyed by the trajectory seed.
 // Every workgroup leaves one record of partial sums; a second tiny kernel adds the records in a
 // fixed order, so results are bit-reproducible for a given (n_paths, sharding).
+#include <cstdlib>
 #include <type_traits>
 
 #include "hh_sim.h"
@@ -245,7 +246,7 @@ __attribute__((amdgpu_waves_per_eu(REPLAY ? HH_REPLAY_MINW : 1,
 #pragma unroll
   for (int j = 0; j < PPT; ++j) finish_path<P, ANTI>(st[j], sa[ANTI ? j : 0], a, path0 + j, acc);
   block_reduce_publish<4 + P, kTile / PPT / 64, 2>(acc, a.records + (size_t)tile * kRecStride, a.accum != nullptr, a.map.n > 0);
-  if (a.accum && reduces_records(tile, a.n_tiles)) finish_records<kTile / PPT, P>(a.records, a.n_tiles, a.acc_n_paths, a.accum, &a.map);
+  if (a.accum && reduces_records(tile, a)) finish_records<kTile / PPT, P>(a);
 }
 
 #ifdef HH_REPLAY_VARIANTS
@@ -414,7 +415,7 @@ __attribute__((amdgpu_waves_per_eu(1, HH_PM_MAXW))) void euler_pm_kernel(const S
   for (int i = 0; i < 4 + P; ++i) acc[i] = 0.0;
   finish_path<P, ANTI>(st, sa, a, path, acc);
   block_reduce_publish<4 + P, kTile / 64, 2>(acc, a.records + (size_t)tile * kRecStride, a.accum != nullptr, a.map.n > 0);
-  if (a.accum && reduces_records(tile, a.n_tiles)) finish_records<kTile, P>(a.records, a.n_tiles, a.acc_n_paths, a.accum, &a.map);
+  if (a.accum && reduces_records(tile, a)) finish_records<kTile, P>(a);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -457,41 +458,12 @@ __global__ __launch_bounds__(kTile) void exact_gbm_kernel(const SimArgs<P> a) {
     }
   }
   block_reduce_publish<4 + P, kTile / 64, 2>(acc, a.records + (size_t)chunk * kRecStride, a.accum != nullptr, a.map.n > 0);
-  if (a.accum && reduces_records(chunk, a.n_tiles)) finish_records<kTile, P>(a.records, a.n_tiles, a.acc_n_paths, a.accum, &a.map);
+  if (a.accum && reduces_records(chunk, a)) finish_records<kTile, P>(a);
 }
 
 // ------------------------------------------------------------------------------------------
 // record reduction: one workgroup per accumulator slot, fixed summation order
 // ------------------------------------------------------------------------------------------
-
-__device__ __forceinline__ double sum_slot(const double* __restrict__ rec, uint32_t n, int slot,
-                                           double* sm) {
-  const int tid = threadIdx.x;
-  double t = 0.0;
-  // Records b = tid, tid + 256, … added in that order.  The kernel is pure latency — a strided load per add:
-  // SIXTEEN loads are in flight before the first add, so that the 3907 records of 10^6 trajectories are ONE
-  // round trip per thread (eight made it 6.5 µs; one dependent load per add 8 µs); + 0.0 leaves a sum unchanged.
-  for (uint32_t b = tid; b < n; b += 256 * 16) {
-    double v[16];
-#pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const uint32_t i = b + 256u * u;
-      v[u] = i < n ? rec[(size_t)i * kRecStride + slot] : 0.0;
-    }
-#pragma unroll
-    for (int u = 0; u < 16; ++u) t += v[u];
-  }
-  __syncthreads();  // sm may still be read from the slot before
-  sm[tid] = t;
-  __syncthreads();
-  // the binary tree over the 256 partial sums — steps 128 and 64 on LDS, the rest by shuffles in wave 0
-  // (tree256, hh_sim.h: the same adds in the same order as eight barrier-separated LDS steps)
-  double r = 0.0;
-  if (tid < 64) r = tree256(sm);
-  if (tid == 0) sm[256] = r;
-  __syncthreads();
-  return sm[256];
-}
 
 __global__ __launch_bounds__(256) void reduce_records_kernel(const double* __restrict__ rec,
                                                               uint32_t n, double n_paths,
@@ -500,8 +472,8 @@ __global__ __launch_bounds__(256) void reduce_records_kernel(const double* __res
                                                               const uint32_t* __restrict__ n_dev) {
   __shared__ double sm[257];
   const int slot = blockIdx.x;
+  rec += (size_t)blockIdx.y * n * kRecStride;  // group = one payoff of a basket (the ALLOCATED count is the groups' stride)
   if (n_dev) n = min(n, *n_dev);  // (uniform) the records a Broadie–Kaya chain filled: bk_live_records()
-  rec += (size_t)blockIdx.y * n * kRecStride;  // group = one payoff of a basket
   accum += (size_t)blockIdx.y * kRecStride;
   double out;
   const int k = slot - HH_ACC_DSUM;
@@ -633,6 +605,21 @@ static PartialMap classify_partials(const hh_model& m, const hh_config& c) {
   return pm;
 }
 
+// Pairs of trajectories per lane of the exact-law kernels: 1 / 2 / 4 in a small ensemble (kExactPairsSmall),
+// kExactPairs / kExactPairsHuge in a large / huge one.  A function of n_paths alone — every launcher and every
+// record count in the library asks here.
+int exact_pairs_per_lane(uint64_t n_paths) {
+  static const int forced = [] {
+    const char* e = getenv("HEDGEHOG_MC_EXACT_PAIRS");  // a measurement: 1, 2, 4, 8 or 64 for every size
+    const int v = e ? atoi(e) : 0;
+    return (v == 1 || v == 2 || v == 4 || v == kExactPairs || v == kExactPairsHuge) ? v : 0;
+  }();
+  if (forced) return forced;
+  return n_paths >= (uint64_t)2048 * 512 * kExactPairsHuge ? kExactPairsHuge
+         : n_paths >= (uint64_t)2048 * 512 * kExactPairs   ? kExactPairs
+                                                           : kExactPairsSmall;
+}
+
 int count_active_partials(const hh_model& m, const hh_config& c) {
   return classify_partials(m, c).n_active;
 }
@@ -683,6 +670,9 @@ static SimArgs<P> make_args(const hh_model& m, const hh_config& c, const DeviceP
   a.records = p.records;
   a.accum = p.accum;
   a.acc_n_paths = (double)c.n_paths;
+  a.finish_state = p.finish_state;
+  a.finish_spin_ticks = p.finish_spin_ticks < 0 ? kFinishSpinTicksDefault : (unsigned long long)p.finish_spin_ticks;
+  a.reducer_tile = p.finish_tile_first ? 0u : a.n_tiles - 1u;
   a.map = pm;
   return a;
 }
@@ -750,6 +740,8 @@ static int launch_sim_p(const hh_model& m, const hh_config& c, const DevicePtrs&
       const int pairs = exact_pairs_per_lane(c.n_paths);
       return pairs == kExactPairsHuge ? exact_gbm_kernel<P, R, A, kExactPairsHuge>
              : pairs == kExactPairs   ? exact_gbm_kernel<P, R, A, kExactPairs>
+             : pairs == 4             ? exact_gbm_kernel<P, R, A, 4>
+             : pairs == 2             ? exact_gbm_kernel<P, R, A, 2>
                                       : exact_gbm_kernel<P, R, A, 1>;
     };
     using T = std::true_type;

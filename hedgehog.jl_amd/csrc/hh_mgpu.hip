@@ -169,6 +169,16 @@ int mfail(hh_mgpu* mg, int code, const char* fmt, ...) {
   return code;
 }
 
+// hh_mc_finalize refused the summed accumulator: because a shard's in-kernel record reduction gave up (every shard's
+// context is asked — hh_ctx_check_last resets the ones it finds so — and the named status goes to the caller), or for
+// what it says
+int mfinalize_failed(hh_mgpu* mg, int rc) {
+  for (int g = 0; g < mg->n; ++g)
+    if (hh_ctx_check_last(mg->ctx[g]) == HH_ERR_DEVICE_TIMEOUT)
+      rc = mfail(mg, HH_ERR_DEVICE_TIMEOUT, "device %d: %s", g, hh_last_error(mg->ctx[g]));
+  return rc == HH_ERR_DEVICE_TIMEOUT ? rc : mfail(mg, rc, "finalize failed: the accumulator holds no trajectories");
+}
+
 #define HH_MHIP(mg, expr)                                                                     \
   do {                                                                                        \
     hipError_t e__ = (hipError_t)(expr);                                                      \
@@ -644,8 +654,15 @@ int hh_mgpu_selftest(hh_mgpu* mg, int32_t* ranks_out, int32_t* reduce_mode_out) 
     }
     total = mg->host[0];
     for (size_t i = 0; i < (size_t)mg->n * HH_ACC_LEN; ++i)
-      if (mg->host[i] != total)
-        return mfail(mg, HH_ERR_RCCL, "self-test: the ranks disagree on the all-reduced count (%g vs %g)", mg->host[i], total);
+      if (mg->host[i] != total) {
+        // a collective that returns different sums to different ranks must not carry a solve: as after a failed one,
+        // the communicators are aborted and later solves add on the host (or fail, where RCCL was required)
+        mfail(mg, HH_ERR_RCCL, "self-test: the ranks disagree on the all-reduced count (%g vs %g) — communicators aborted",
+              mg->host[i], total);
+        (void)rccl_give_up(mg);
+        wait_fences(mg);
+        return HH_ERR_RCCL;
+      }
   } else {
     for (int g = 0; g < mg->n; ++g) {
       HH_MHIP_DRAIN(mg, hipSetDevice(mg->devices[g]));
@@ -713,7 +730,7 @@ int hh_mgpu_solve_shards(hh_mgpu* mg, const hh_model* m, const hh_config* cfgs, 
   int rc = run_shards(mg, m, cfgs, nullptr, terminals, &kernel_ms);
   if (rc) return rc;
   rc = hh_mc_finalize(m, &cfgs[first], mg->host, out);  // reads n_partials and the discount seeds only
-  if (rc) return mfail(mg, rc, "finalize failed");
+  if (rc) return mfinalize_failed(mg, rc);
   out->kernel_ms = kernel_ms;
   out->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   return HH_OK;
@@ -827,7 +844,7 @@ int hh_mgpu_solve(hh_mgpu* mg, const hh_model* m, const hh_config* cfg, hh_resul
     }
   }
   rc = hh_mc_finalize(m, cfg, mg->host, out);
-  if (rc) return mfail(mg, rc, "finalize failed");
+  if (rc) return mfinalize_failed(mg, rc);
   out->kernel_ms = kernel_ms;
   out->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   return HH_OK;
@@ -853,7 +870,7 @@ int hh_mgpu_solve_multi(hh_mgpu* mg, const hh_model* models, uint32_t n_models, 
   for (uint32_t k = 0; k < n_models; ++k) {
     std::memset(&out[k], 0, sizeof(hh_result));
     rc = hh_mc_finalize(&models[k], cfg, mg->host + (size_t)k * HH_ACC_LEN, &out[k]);
-    if (rc) return mfail(mg, rc, "finalize failed");
+    if (rc) return mfinalize_failed(mg, rc);
     out[k].kernel_ms = kernel_ms;
     out[k].total_ms = total;
   }
@@ -880,7 +897,7 @@ int hh_mgpu_solve_basket(hh_mgpu* mg, const hh_model* m, const hh_config* cfg, c
   for (uint32_t k = 0; k < n_payoffs; ++k) {
     std::memset(&out[k], 0, sizeof(hh_result));
     rc = hh_mc_finalize(m, cfg, mg->host + (size_t)k * HH_ACC_LEN, &out[k]);
-    if (rc) return mfail(mg, rc, "finalize failed");
+    if (rc) return mfinalize_failed(mg, rc);
     out[k].kernel_ms = kernel_ms;
     out[k].total_ms = total;
   }
@@ -1018,7 +1035,7 @@ static int lsm_attempt(hh_mgpu* mg, const hh_model* m, const hh_config* cfg, int
     HH_MHIP(mg, hipEventElapsedTime(&ms, mg->ctx[g]->ev0, mg->ctx[g]->ev1));
     if (ms > worst) worst = ms;
   }
-  if ((rc = hh_lsm_finalize(mg->host, out))) return mfail(mg, rc, "finalize failed");
+  if ((rc = hh_lsm_finalize(mg->host, out))) return mfinalize_failed(mg, rc);
   out->rows_regressed = rg[0];
   out->rows_skipped = sk[0];
   out->form = HH_LSM_FORM_PER_DATE;

@@ -159,11 +159,11 @@ __attribute__((amdgpu_waves_per_eu(1, REPLAY ? HH_MULTI_MAXW : 8))) void euler_m
     if (k) __syncthreads();  // the reduction's LDS staging is reused
     block_reduce_publish<4, kTile / 64, 2>(acc, a.m[k].records + (size_t)tile * kRecStride, a.m[k].accum != nullptr, false);
   }
-  if (a0.accum && reduces_records(tile, a0.n_tiles)) {
+  if (a0.accum && reduces_records(tile, a0)) {
 #pragma unroll
     for (int k = 0; k < K; ++k) {
       if (k) __syncthreads();
-      finish_records<kTile, 0>(a.m[k].records, a0.n_tiles, a.m[k].acc_n_paths, a.m[k].accum, &a.m[k].map);
+      finish_records<kTile, 0>(a.m[k]);
     }
   }
 }
@@ -202,11 +202,11 @@ __global__ __launch_bounds__(kTile) void exact_multi_kernel(const MultiArgs<K> a
     if (k) __syncthreads();  // the reduction's LDS staging is reused
     block_reduce_publish<4, kTile / 64, 2>(acc[k], a.m[k].records + (size_t)chunk * kRecStride, a.m[k].accum != nullptr, false);
   }
-  if (a0.accum && reduces_records(chunk, a0.n_tiles)) {
+  if (a0.accum && reduces_records(chunk, a0)) {
 #pragma unroll
     for (int k = 0; k < K; ++k) {
       if (k) __syncthreads();
-      finish_records<kTile, 0>(a.m[k].records, a0.n_tiles, a.m[k].acc_n_paths, a.m[k].accum, &a.m[k].map);
+      finish_records<kTile, 0>(a.m[k]);
     }
   }
 }
@@ -252,6 +252,8 @@ static int launch_multi(const hh_model* models, const hh_config& c, const Device
       const int pairs = exact_pairs_per_lane(c.n_paths);
       return pairs == kExactPairsHuge ? exact_multi_kernel<R, A, K, kExactPairsHuge>
              : pairs == kExactPairs   ? exact_multi_kernel<R, A, K, kExactPairs>
+             : pairs == 4             ? exact_multi_kernel<R, A, K, 4>
+             : pairs == 2             ? exact_multi_kernel<R, A, K, 2>
                                       : exact_multi_kernel<R, A, K, 1>;
     };
     using T = std::true_type;

@@ -6,6 +6,7 @@
 #include <type_traits>
 
 #include "hh_kernels.h"
+#include "hh_reduce.h"
 #include "hh_rng.h"
 
 namespace hh {
@@ -269,24 +270,28 @@ __device__ __forceinline__ void exact_pair_normals(const SimArgs<P>& a, uint64_t
 // between words or workgroups is assumed.  When it has its sums it poisons every record again for the next
 // launch.  The last tile's workgroup is the last one dispatched, so as a rule every record is there when it
 // looks; if not it waits — it holds one workgroup slot, every other workgroup needs only a slot of its own, so
-// the grid drains whatever the dispatch order — and after kFinishSpinTicks of the 100 MHz clock (a record
-// that never comes: a workgroup died) it gives up and leaves NaN in the accumulator, which hh_mc_finalize
-// refuses.
+// the grid drains whatever the dispatch order — and after SimArgs::finish_spin_ticks of the 100 MHz clock (5 s:
+// a record that never comes — a workgroup died, or the queue was preempted for that long) it gives up: NaN in
+// the accumulator, which hh_mc_finalize refuses, and a 1 in the context's give-up word (SimArgs::finish_state).
+// That word is what keeps a give-up from poisoning LATER solves: the record of the straggler, should it still
+// come, lands on a buffer the reducer has already poisoned again and would pass for a record of the next launch.
+// So every reducer looks at the word first and, while it is set, waits for nothing and leaves NaN itself —
+// launches queued behind a give-up fail too, visibly — until the host, which learns of it from the NaN (or from
+// hh_ctx_check_last), has filled the buffer with the poison again and cleared the word (recover_finish, hh_api.hip).
 //
 // Measured alternatives (profiles/r05_a_fuse_ab.txt): a ticket per workgroup drawn with a returning atomic
 // ("last one in reduces") holds every workgroup for its store drain and the atomic's round trip — +9 % on the
 // REPLAY kernel at two workgroups per CU, and 3907 adds to one address are 45 µs on an 8 µs exact-law kernel;
 // a resident grid of workgroups looping over tiles (one ticket each) loses 3.5-4 % to the fixed assignment.
 
-constexpr unsigned long long kFinishSpinTicks = 500000000ull;   // 5 s
 #ifndef HH_FINISH_STAMPS
 #define HH_FINISH_STAMPS 0
 #endif
-#ifndef HH_FINISH_TILE_FIRST
-#define HH_FINISH_TILE_FIRST 0  // 1 (a test build): the FIRST tile's workgroup reduces, so it has to wait for nearly every record
-#endif
-__device__ __forceinline__ bool reduces_records(uint32_t tile, uint32_t n_tiles) {
-  return HH_FINISH_TILE_FIRST ? tile == 0u : tile == n_tiles - 1u;
+// which workgroup reduces: SimArgs::reducer_tile — the last tile's; the FIRST one's under HH_OPT_FINISH_TILE_FIRST
+// (a diagnostic: it then has to wait for nearly every record)
+template <class Args>
+__device__ __forceinline__ bool reduces_records(uint32_t tile, const Args& a) {
+  return tile == a.reducer_tile;
 }
 
 __device__ __forceinline__ void store_through(double* p, double v) {
@@ -347,10 +352,11 @@ constexpr int kFinishBatch = 16;
 using u32x4 = __attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int;
 
 // true while the caller should read again; after the spin bound: *gave_up is set and the wait is over
-__device__ __forceinline__ bool keep_waiting(unsigned long long& t0, bool& give, unsigned int* gave_up) {
+__device__ __forceinline__ bool keep_waiting(unsigned long long& t0, bool& give, unsigned int* gave_up,
+                                             unsigned long long spin_ticks) {
   const unsigned long long now = wall_clock64();
   if (t0 == 0) t0 = now;
-  if (now - t0 > kFinishSpinTicks) {  // a record that never comes: NaN sums, and say so
+  if (now - t0 >= spin_ticks) {  // a record that never comes: NaN sums, and say so
     *gave_up = 1u;
     give = true;
     return false;
@@ -362,10 +368,10 @@ __device__ __forceinline__ bool keep_waiting(unsigned long long& t0, bool& give,
 // slots 0 and 1 of every record -> sm[vt], sm[256 + vt]
 template <int NT>
 __device__ __forceinline__ void partial_pairs(const double* rec, uint32_t n, double* __restrict__ sm,
-                                              unsigned int* gave_up) {
+                                              unsigned int* gave_up, unsigned long long spin_ticks, bool dirty) {
   static_assert(256 % NT == 0, "the 256 virtual threads are dealt evenly");
   const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(rec), 0, (int)(n * (uint32_t)(kRecStride * 8)), 0x00020000);
-  bool give = *gave_up != 0u;  // set in an earlier pass: do not wait again
+  bool give = *gave_up != 0u || dirty;  // set in an earlier pass, or by an earlier launch: do not wait
   for (int vt = threadIdx.x; vt < 256; vt += NT) {
     double t0 = 0.0, t1 = 0.0;
     for (uint32_t b = vt; b < n; b += 256 * kFinishBatch) {
@@ -382,7 +388,7 @@ __device__ __forceinline__ void partial_pairs(const double* rec, uint32_t n, dou
           const unsigned long long hi = ((unsigned long long)v[u][3] << 32) | v[u][2];
           there = there && lo != kPoison && hi != kPoison;
         }
-        if (there || give || !keep_waiting(since, give, gave_up)) break;
+        if (there || give || !keep_waiting(since, give, gave_up, spin_ticks)) break;
       }
 #pragma unroll
       for (int u = 0; u < kFinishBatch; ++u) {
@@ -398,9 +404,10 @@ __device__ __forceinline__ void partial_pairs(const double* rec, uint32_t n, dou
 // NS other slots of every record -> sm[q·256 + vt]
 template <int NT, int NS, class SlotOf>
 __device__ __forceinline__ void partial_slots(const double* __restrict__ rec, uint32_t n, SlotOf slot_of,
-                                              double* __restrict__ sm, unsigned int* gave_up) {
+                                              double* __restrict__ sm, unsigned int* gave_up, unsigned long long spin_ticks,
+                                              bool dirty) {
   constexpr int kB = NS <= 2 ? kFinishBatch : 8;
-  bool give = *gave_up != 0u;
+  bool give = *gave_up != 0u || dirty;
   for (int vt = threadIdx.x; vt < 256; vt += NT) {
     double t[NS];
 #pragma unroll
@@ -419,7 +426,7 @@ __device__ __forceinline__ void partial_slots(const double* __restrict__ rec, ui
             there = there && !is_poison(v[q][u]);
           }
         }
-        if (there || give || !keep_waiting(since, give, gave_up)) break;
+        if (there || give || !keep_waiting(since, give, gave_up, spin_ticks)) break;
       }
 #pragma unroll
       for (int q = 0; q < NS; ++q)
@@ -431,28 +438,25 @@ __device__ __forceinline__ void partial_slots(const double* __restrict__ rec, ui
   }
 }
 
-// The binary tree of sum_slot() over 256 partial sums, by ONE wave without a barrier: the steps 128 and 64
-// on four LDS words per lane, the rest by shuffles — the same adds in the same order.  Result in every lane.
-__device__ __forceinline__ double tree256(const double* __restrict__ p) {
-  const int l = threadIdx.x & 63;
-  double a = p[l] + p[l + 128];
-  const double b = p[l + 64] + p[l + 192];
-  a += b;
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off, 64);
-  return __shfl(a, 0, 64);
-}
-
 // Called by every thread of the reducing workgroup (reduces_records) after block_reduce_publish(…, true).
 // NT = threads of the workgroup.
-template <int NT, int P>
-__device__ __forceinline__ void finish_records(double* __restrict__ records, uint32_t n_rec, double n_paths,
-                                               double* __restrict__ accum, const PartialMap* map) {
+template <int NT, int P, class Args>
+__device__ __forceinline__ void finish_records(const Args& a) {
+  double* __restrict__ records = a.records;
+  double* __restrict__ accum = a.accum;
+  const uint32_t n_rec = a.n_tiles;
+  const double n_paths = a.acc_n_paths;
+  const PartialMap* map = &a.map;
+  const unsigned long long spin_ticks = a.finish_spin_ticks;
   __shared__ double sm[4 * 256];
   __shared__ unsigned int gave_up;
 #if HH_FINISH_STAMPS  // a diagnostic build (tools/finish_stamps.py): where the tail's time goes, in accum[11..15]
   const unsigned long long st0 = wall_clock64();
 #endif
+  // (a give-up of an earlier launch the host has not dealt with yet: this buffer cannot be trusted, wait for nothing.
+  // Every thread asks for the word itself, in FRONT of its record loads and needing it only behind them: loads come
+  // back in order, so the question costs the tail no round trip of its own)
+  const bool dirty = __hip_atomic_load(a.finish_state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
   if (threadIdx.x == 0) gave_up = 0u;
   __syncthreads();
   const bool itm = map->n > 0;  // some direction has a passive part: the two in-the-money sums are live
@@ -462,8 +466,8 @@ __device__ __forceinline__ void finish_records(double* __restrict__ records, uin
   const double poison = __longlong_as_double((long long)kPoison);
   const auto wsrc = __builtin_amdgcn_make_buffer_rsrc(records, 0, (int)(n_rec * (uint32_t)(kRecStride * 8)), 0x00020000);
   const unsigned int ph = (unsigned int)(kPoison >> 32), pl = (unsigned int)kPoison;
-  partial_pairs<NT>(records, n_rec, sm, &gave_up);
-  if (itm) partial_slots<NT, 2>(records, n_rec, [](int q) { return kRecItmS + q; }, sm + 512, &gave_up);
+  partial_pairs<NT>(records, n_rec, sm, &gave_up, spin_ticks, dirty);
+  if (itm) partial_slots<NT, 2>(records, n_rec, [](int q) { return kRecItmS + q; }, sm + 512, &gave_up, spin_ticks, dirty);
   for (uint32_t i = threadIdx.x; i < n_rec; i += NT) {
     __builtin_amdgcn_raw_buffer_store_b128(u32x4{pl, ph, pl, ph}, wsrc, (int)(i * (uint32_t)(kRecStride * 8)), 0, 16);  // Σp, Σp²: sc1
     if (itm) {
@@ -486,7 +490,7 @@ __device__ __forceinline__ void finish_records(double* __restrict__ records, uin
   }
   if constexpr (P > 0) {  // the carried derivative sums
     __syncthreads();
-    partial_slots<NT, P>(records, n_rec, [](int q) { return HH_ACC_DSUM + q; }, sm, &gave_up);
+    partial_slots<NT, P>(records, n_rec, [](int q) { return HH_ACC_DSUM + q; }, sm, &gave_up, spin_ticks, dirty);
     for (uint32_t i = threadIdx.x; i < n_rec; i += NT) {
 #pragma unroll
       for (int j = 0; j < P; ++j) store_through(records + (size_t)i * kRecStride + HH_ACC_DSUM + j, poison);
@@ -518,7 +522,8 @@ __device__ __forceinline__ void finish_records(double* __restrict__ records, uin
     if (slot == 12) out = (double)st1;               // thread `slot` has all its records
     if (slot == 13) out = (double)wall_clock64();    // sums done
 #endif
-    accum[slot] = gave_up ? __longlong_as_double(0x7FF8000000000000ll) : out;
+    accum[slot] = (gave_up || dirty) ? __longlong_as_double(0x7FF8000000000000ll) : out;
+    if (slot == 0 && gave_up) __hip_atomic_store(a.finish_state, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 

@@ -67,7 +67,10 @@ enum hh_status {
   HH_ERR_UNSUPPORTED = -2, /* combination the reference itself cannot run (e.g. BK + antithetic)  */
   HH_ERR_HIP = -3,         /* HIP runtime error, or no HIP device                                 */
   HH_ERR_NOMEM = -4,
-  HH_ERR_RCCL = -5         /* RCCL missing or failed where the caller REQUIRED it (HH_MGPU_RCCL)  */
+  HH_ERR_RCCL = -5,        /* RCCL missing or failed where the caller REQUIRED it (HH_MGPU_RCCL)  */
+  HH_ERR_DEVICE_TIMEOUT = -6 /* the record reduction inside a simulation kernel gave up waiting for a
+                                workgroup's record (HH_OPT_FINISH_SPIN_TICKS): that solve's sums are lost,
+                                the context has been reset and is usable again (hh_ctx_check_last)    */
 };
 
 /* montecarlo.jl:8-22 */
@@ -214,12 +217,32 @@ const char* hh_last_error(const hh_ctx* ctx); /* NUL-terminated, owned by ctx (o
  * up to 512 records (a launch saved is 2 % of a small solve) and for Euler runs of 32 steps or more (the
  * reducer's wait disappears behind the other workgroups: -0.3 % at 10^6 x 252), the second kernel for short
  * kernels with thousands of records (the exact law at 10^6 - 10^7 trajectories: 1-4 % faster that way).  The
- * same additions in the same order every way: bit-identical results. */
+ * same additions in the same order every way: bit-identical results.
+ *
+ * HH_OPT_FINISH_SPIN_TICKS: how long the workgroup that adds the records INSIDE a simulation kernel
+ * (HH_OPT_FUSE_REDUCE) waits for a record that has not arrived, in ticks of the 100 MHz constant clock (default
+ * -1 = 5·10^8 = five seconds).  Every workgroup needs only a slot of its own to finish, so the bound is the last
+ * guard against a workgroup that died or a queue preempted for that long.  When it is passed the solve's sums are
+ * NaN, and — because the missing record may still land in the buffer the next launch reads — every solve queued
+ * behind it on this context gives NaN too, until the host has reset the buffer: hh_mc_solve and its kin do that
+ * themselves and return HH_ERR_DEVICE_TIMEOUT; callers of the asynchronous entry points ask with
+ * hh_ctx_check_last.  0 makes the reducer give up on the first record it does not find, which — with
+ * HH_OPT_FINISH_TILE_FIRST = 1: the FIRST tile's workgroup adds the records instead of the last one's, so nearly
+ * none is there when it looks — is how the tests force that path. */
 enum hh_option { HH_OPT_LSM_FORM = 1, HH_OPT_BK_TERM_CACHE = 2, HH_OPT_GRID_FORM = 3, HH_OPT_LSM_SPIN_TICKS = 4,
-                 HH_OPT_FUSE_REDUCE = 5, HH_OPT_GRID_ORDER = 6 };
+                 HH_OPT_FUSE_REDUCE = 5, HH_OPT_GRID_ORDER = 6, HH_OPT_FINISH_SPIN_TICKS = 7,
+                 HH_OPT_FINISH_TILE_FIRST = 8 };
 enum hh_grid_form { HH_GRID_FORM_PER_DATE = 0, HH_GRID_FORM_BATCHED = 1 };
 enum hh_lsm_form { HH_LSM_FORM_PER_DATE = 0, HH_LSM_FORM_PERSISTENT = 1, HH_LSM_FORM_AUTO = 2 };
 int hh_ctx_set_option(hh_ctx* ctx, int32_t option, int64_t value);
+/*
+ * For callers of the ASYNCHRONOUS entry points (hh_mc_accumulate and its kin, whose sums stay on the device): waits
+ * for the context's stream, then HH_OK — or HH_ERR_DEVICE_TIMEOUT when a record reduction inside a simulation kernel
+ * gave up since the last check (HH_OPT_FINISH_SPIN_TICKS): the accumulators written since then hold NaN, the
+ * context's record buffer has been reset, the context is usable again.  Call it where the sums are read back (a NaN
+ * in slot HH_ACC_NPATHS says why), or once per batch of solves.
+ */
+int hh_ctx_check_last(hh_ctx* ctx);
 
 /*
  * Replaces the body of solve(prob, ::MonteCarlo) (montecarlo.jl:478-493): simulate, payoff,
@@ -594,7 +617,10 @@ int hh_ctx_read_timings(hh_ctx* ctx, double* ms, int32_t cap, int32_t* n_out);
  * context, the least recently used one goes first, all go with the context.  *dev_out stays valid until a
  * later hh_seeds_cache call of this context MISSES (an eviction frees it): ask right before every solve,
  * pass the pointer as cfg->seeds with seeds_on_device = 1, do not keep it.  The upload is synchronous — the
- * host vector is free to change when the call returns.
+ * host vector is free to change when the call returns.  The entry the call BEFORE a miss returned is never the one
+ * evicted, so two host threads that share a context and each look up, then solve, cannot free each other's vector
+ * between the two steps; more than two such threads serialise lookup + solve themselves (a context is one stream:
+ * they gain nothing from running side by side).
  */
 #define HH_SEED_CACHE_ENTRIES 8
 uint64_t hh_seeds_fingerprint(const uint64_t* seeds, uint64_t n);  /* pure host arithmetic; never 0 */

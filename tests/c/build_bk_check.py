@@ -1,15 +1,17 @@
-"""Builds tests/c/libhh_bk_check.so: the product library with two Broadie–Kaya code paths switched back to the forms
-they replaced — the trajectory's real-axis evaluations through the complex code (HH_BK_COMPLEX_SETUP), the ladder
-kernel searching the prefix sums in place (HH_BK_LADDER_SPAN = 1).  tests/test_gpu_bk_forms.py holds the shipped build
-to this one bit for bit.  No pytest here: __graft_entry__.build() calls this too (non-fatally), so that the file
-travels to the GPU box with the snapshot."""
+"""Builds tests/c/libhh_bk_check.so: the product library with two Broadie–Kaya code paths in their plain forms — the
+trajectory's real-axis evaluations through the complex code (HH_BK_COMPLEX_SETUP), and the bisection ladder of a
+trajectory whose secant failed run by its own lane, statement for statement as sample_from_cf.jl:123-133 writes it
+(HH_BK_SERIAL_LADDER; the shipped build walks the bisection tree with the whole wave).  tests/test_gpu_bk_forms.py
+holds the shipped build to this one bit for bit; its session fixture calls this (a minute of hipcc where the file
+is missing or older than the sources — `python tests/c/build_bk_check.py` makes it ahead of a GPU run, and the file
+travels with the snapshot)."""
 import importlib.util
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 OUT = os.path.join(HERE, "libhh_bk_check.so")
-FLAGS = ("-DHH_BK_COMPLEX_SETUP=1", "-DHH_BK_LADDER_SPAN=1")
+FLAGS = ("-DHH_BK_COMPLEX_SETUP=1", "-DHH_BK_SERIAL_LADDER=1")
 
 
 def build_bk_check():

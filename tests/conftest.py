@@ -8,6 +8,23 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# HH_SANITIZE=1 (make test-cpu-asan): the host-compiled checks are built with AddressSanitizer + UBSan.  Their
+# executables run WITHOUT the preloaded libasan of the python that started them (they link their own).
+SANITIZE = os.environ.get("HH_SANITIZE") == "1"
+
+
+def host_cxxflags():
+    if SANITIZE:
+        return ["-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer"]
+    return ["-O2"]
+
+
+def host_env():
+    env = dict(os.environ)
+    env.pop("LD_PRELOAD", None)
+    return env
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

@@ -12,7 +12,10 @@ from hedgehog_jl_amd import _ffi
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
-ORACLE_LIB = os.path.join(ORACLE_DIR, "libhh_oracle.so")
+# HH_SANITIZE=1 (make test-cpu-asan): the AddressSanitizer + UBSan build of the same file, loaded into a python that
+# runs with libasan preloaded
+SANITIZE = os.environ.get("HH_SANITIZE") == "1"
+ORACLE_LIB = os.path.join(ORACLE_DIR, "_asan", "libhh_oracle.so") if SANITIZE else os.path.join(ORACLE_DIR, "libhh_oracle.so")
 
 _vp = C.c_void_p
 
@@ -83,7 +86,7 @@ class Oracle:
 
 
 def build():
-    subprocess.run(["make", "-C", ORACLE_DIR, "-s"], check=True)
+    subprocess.run(["make", "-C", ORACLE_DIR, "-s"] + (["asan"] if SANITIZE else []), check=True)
 
 
 def load() -> Oracle:

@@ -36,6 +36,30 @@ def test_launcher_starts_n_ranks_weak():
     assert out["global_paths"] == 2_000_000 and out["paths_covered"] == 2_000_000
 
 
+def test_the_metric_string_names_the_workload_that_ran():
+    import bench
+    assert bench.metric_string(1_000_000, 252) == "MC path-steps/sec (Heston Euler-Maruyama, 1e6 paths x 252 steps per GPU)"
+    assert "125000 paths x 252 steps per GPU" in bench.metric_string(125_000, 252)
+    assert "1e7 paths in all x 100 steps" in bench.metric_string(0, 100, True, 10_000_000)
+
+
+def test_predicted_scaling_arithmetic():
+    """predicted_scaling of the N = 1 line: from each shard's time ALONE and one rank's per-solve overhead."""
+    import bench
+    rows = bench.predict_scaling({1: 8.0, 2: 4.0, 4: 2.0, 8: 1.0}, 0.0)  # perfectly divisible work, free exchange
+    assert all(abs(r["efficiency_pipelined"] - 1.0) < 1e-15 and abs(r["efficiency_single_solve"] - 1.0) < 1e-15
+               for r in rows.values())
+    rows = bench.predict_scaling({1: 8.0, 2: 4.0, 4: 2.0, 8: 1.0}, 0.5)
+    # one solve, call to result: (8 + .5) / (8 (1 + .5)); back-to-back solves hide the exchange while it is the shorter
+    assert rows[8]["efficiency_single_solve"] == pytest.approx(8.5 / 12.0)
+    assert rows[8]["efficiency_pipelined"] == pytest.approx(1.0) and rows[1]["efficiency_single_solve"] == 1.0
+    rows = bench.predict_scaling({1: 8.0, 8: 1.0}, 2.0)  # the exchange longer than the shard: it sets the step
+    assert rows[8]["efficiency_pipelined"] == pytest.approx(8.0 / (8 * 2.0))
+    rows = bench.predict_scaling({1: 0.58, 2: 0.31, 4: 0.18, 8: 0.11}, 0.02)  # a shard that does not fill the chip
+    assert rows[2]["efficiency_pipelined"] == pytest.approx(0.58 / 0.62)
+    assert rows[8]["efficiency_pipelined"] < rows[4]["efficiency_pipelined"] < rows[2]["efficiency_pipelined"] < 1.0
+
+
 def test_a_substitute_collective_library_is_refused_unless_asked_for():
     """$HEDGEHOG_MC_RCCL makes hh_mgpu bind another library in place of librccl (the tests' stand-in): bench.py
     must not produce a line under it silently — exit code 2 before anything runs, whatever the mode."""

@@ -13,12 +13,14 @@ import numpy as np
 import pytest
 
 mp = pytest.importorskip("mpmath")
+from tests.conftest import host_cxxflags, host_env
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _build(tmp_path):
     exe = tmp_path / "bessel_check"
-    subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off",
+    subprocess.run(["g++", *host_cxxflags(), "-std=c++17", "-ffp-contract=off",
                     "-I", os.path.join(ROOT, "hedgehog.jl_amd", "csrc"),
                     os.path.join(ROOT, "tests", "c", "bessel_check.cpp"), "-o", str(exe)], check=True)
     return str(exe)
@@ -47,7 +49,7 @@ def test_besseli_against_mpmath(tmp_path):
     exe = _build(tmp_path)
     cases = _cases()
     text = "".join(f"{nu!r} {re!r} {im!r}\n" for nu, re, im in cases)
-    out = subprocess.run([exe], input=text, check=True, capture_output=True, text=True).stdout.split("\n")
+    out = subprocess.run([exe], input=text, check=True, capture_output=True, text=True, env=host_env()).stdout.split("\n")
     assert "table-bound-violated" not in out
     mp.mp.dps = 40
     worst = 0.0

@@ -1,14 +1,17 @@
-"""Two Broadie–Kaya code paths of round 5 against the forms they replaced, bit for bit (a second build of the library,
-tests/c/build_bk_check.py):
+"""Two Broadie–Kaya code paths of the shipped library against their plain forms, bit for bit (a second build of the
+library, tests/c/build_bk_check.py):
 
 * log I_ν(ν_κ) and the characteristic function at 0 (moments_from_cf, sample_from_cf.jl:50-61; heston.jl:184-212) are
-  evaluated on the real axis — besseli_logmul_re, chf_at_zero — where they went through the complex code: the real
-  code is the complex code's real parts operation by operation, so NO sample may move;
-* the ladder kernel finds its trajectories by a search in LDS over the tiles of its chunk, where it searched the
-  prefix sums of all tiles in place: the same trajectories, the same records.
+  evaluated on the real axis — besseli_logmul_re, chf_at_zero — where the plain form goes through the complex code:
+  the real code is the complex code's real parts operation by operation, so NO sample may move;
+* the bisection ladder of a trajectory whose secant failed (sample_from_cf.jl:123-133) is run by its WAVE — the lanes
+  evaluate the next levels of the bisection tree at once, then walk them with the loop's own tests (wave_ladder) —
+  where the plain form is that loop in the failed lane: the same abscissae, the same decisions, the same ∫V, the same
+  decision words and counters.
 
-Every regime of tests/test_gpu_bk.py, plus controls that send most trajectories to the ladder (many chunks) and almost
-none (one chunk spanning every tile)."""
+Every regime of tests/test_gpu_bk.py, plus controls that send nearly every trajectory to the ladder (batches of eight
+per wave), a lone one per wave, iteration caps that end a ladder in the middle of a tree, tolerances that end it at
+its first level or after fifty."""
 import ctypes as C
 import os
 
@@ -51,7 +54,7 @@ def solve(lib, h, prm, n, seed, **controls):
 
 
 @pytest.mark.parametrize("name", sorted(PARAMS))
-def test_real_axis_setup_and_staged_ladder_move_no_sample(hhlib, check_lib, name):
+def test_real_axis_setup_and_wave_ladder_move_no_sample(hhlib, check_lib, name):
     lib, h = check_lib
     n = 30_000
     r1, t1 = solve(hhlib.lib, hhlib.handle, PARAMS[name], n, 777)
@@ -71,21 +74,45 @@ def solve_replay(lib, h, prm, draws):
     return res, term
 
 
-def test_ladder_chunks_dense(hhlib, check_lib):
-    """every secant gives up after its two starting points: nearly all trajectories in the ladder, a chunk per tile"""
-    lib, h = check_lib
-    n = 100_000
-    r1, t1 = solve(hhlib.lib, hhlib.handle, PARAMS["h252"], n, 31, bk_newton_maxiter=2)
-    r0, t0 = solve(lib, h, PARAMS["h252"], n, 31, bk_newton_maxiter=2)
+def same(r1, t1, r0, t0):
     assert t1.tobytes() == t0.tobytes()
-    assert r1.price == r0.price and r1.bk_newton_fail == r0.bk_newton_fail and r1.bk_bisect_fallback == r0.bk_bisect_fallback
-    assert r1.bk_newton_fail > 0.5 * n
+    for f in ("price", "std_error", "bk_newton_fail", "bk_bisect_fallback", "bk_maxguess_fallback", "bk_cf_terms"):
+        assert getattr(r1, f) == getattr(r0, f), f
 
 
-def test_ladder_one_chunk_spanning_every_tile(hhlib, check_lib):
+def decisions(lib, h, n):
+    dec, ln = np.zeros(n, np.uint32), np.zeros(n, np.uint32)
+    assert lib.hh_bk_decisions(h, n, dec.ctypes.data, ln.ctypes.data) == 0
+    return dec, ln
+
+
+@pytest.mark.parametrize("controls", [
+    dict(bk_newton_maxiter=2),                                   # every secant gives up at once: 64 failed lanes per wave
+    dict(bk_newton_maxiter=2, bk_bisect_maxiter=1),              # … and the ladder's cap ends it inside the first tree
+    dict(bk_newton_maxiter=2, bk_bisect_maxiter=3),
+    dict(bk_newton_maxiter=2, bk_bisect_maxiter=7),
+    dict(bk_newton_maxiter=3, bk_atol=1e-13),                    # ~45 midpoints: many turns of the wave
+    dict(bk_newton_maxiter=2, bk_atol=0.5),                      # the width test ends it at the first midpoints
+    dict(bk_newton_maxiter=4),                                   # a mixed wave: some lanes in the ladder, some not
+], ids=lambda c: "-".join(f"{k[3:]}={v}" for k, v in c.items()))
+def test_wave_ladder_against_the_lane_by_lane_loop(hhlib, check_lib, controls):
+    lib, h = check_lib
+    n = 50_000
+    for name in ("h252", "q2"):
+        r1, t1 = solve(hhlib.lib, hhlib.handle, PARAMS[name], n, 31, **controls)
+        d1 = decisions(hhlib.lib, hhlib.handle, n)
+        r0, t0 = solve(lib, h, PARAMS[name], n, 31, **controls)
+        d0 = decisions(lib, h, n)
+        same(r1, t1, r0, t0)
+        assert (d1[0] == d0[0]).all() and (d1[1] == d0[1]).all()
+        if controls.get("bk_newton_maxiter") == 2 and "bk_atol" not in controls:
+            assert r1.bk_newton_fail > 0.5 * n
+
+
+def test_wave_ladder_lone_failures(hhlib, check_lib):
     """The caller's draws (REPLAY): the same V_T and the median u for every trajectory — the secant converges — but for
-    a few dozen, far in the tails, spread over 1172 tiles: ONE ladder chunk whose trajectories lie more tiles apart
-    than the kernel stages in LDS, so the shipped build searches in place there too (and must find the same ones)."""
+    a few dozen far in the tails, spread over 1172 tiles: a wave has at most one or two of them, so all 64 (or 32)
+    lanes walk one trajectory's tree."""
     lib, h = check_lib
     n = 300_000
     rng = np.random.default_rng(3)
@@ -95,9 +122,30 @@ def test_ladder_one_chunk_spanning_every_tile(hhlib, check_lib):
     draws = np.ascontiguousarray(draws)
     r1, t1 = solve_replay(hhlib.lib, hhlib.handle, PARAMS["h252"], draws)
     r0, t0 = solve_replay(lib, h, PARAMS["h252"], draws)
-    assert t1.tobytes() == t0.tobytes()
-    assert r1.price == r0.price and r1.bk_newton_fail == r0.bk_newton_fail and r1.bk_bisect_fallback == r0.bk_bisect_fallback
+    same(r1, t1, r0, t0)
     assert 0 < r1.bk_newton_fail <= 96  # sparse: fewer than one failure per four tiles, yet some
+
+
+@pytest.mark.parametrize("k", [1, 2, 3, 4, 5, 8, 9, 17, 64])
+def test_wave_ladder_group_sizes(hhlib, check_lib, k):
+    """k lanes of ONE tile with uniforms far in a tail (the caller's draws; which tail fails the secant is the
+    model's business, so both are tried): the group widths 64 / 32 / 16 / 8 and the batches behind the first eight,
+    in one wave and spread over the four"""
+    lib, h = check_lib
+    n = 1024
+    fails = 0
+    for variant in range(4):
+        rng = np.random.default_rng(100 * k + variant)
+        draws = np.stack([np.full(n, 0.045), np.full(n, 0.5), rng.standard_normal(n)])
+        where = 256 + (64 * 2 + rng.choice(64, k, replace=False) if variant < 2 else rng.choice(256, k, replace=False))
+        draws[1, where] = (1e-9 if variant % 2 == 0 else 1.0 - 1e-9)
+        draws = np.ascontiguousarray(draws)
+        r1, t1 = solve_replay(hhlib.lib, hhlib.handle, PARAMS["h252"], draws)
+        r0, t0 = solve_replay(lib, h, PARAMS["h252"], draws)
+        same(r1, t1, r0, t0)
+        assert r1.bk_newton_fail <= k
+        fails += r1.bk_newton_fail
+    assert fails >= k  # one of the two tails sends its lanes to the ladder
 
 
 def test_model_constants_beside_the_bessel_tables_follow_the_model(hhlib):

@@ -181,3 +181,79 @@ def test_exact_law_forms_one_eight_and_sixty_four_pairs_per_lane(hhlib, oracle, 
     assert r.std_error == pytest.approx(ro.std_error, rel=1e-8)
     for k in range(2):
         assert r.dprice[k] == pytest.approx(ro.dprice[k], rel=1e-10)
+
+
+# ---- the reducer's give-up path: forced, named, and left behind (hh_sim.h; hh_api.hip recover_finish) ---------------
+
+def _forced(ctx, on):
+    ctx.set_option(_ffi.HH_OPT_FUSE_REDUCE, 1 if on else 2)
+    ctx.set_option(_ffi.HH_OPT_FINISH_TILE_FIRST, 1 if on else 0)  # the first tile's workgroup reduces: nothing is there yet
+    ctx.set_option(_ffi.HH_OPT_FINISH_SPIN_TICKS, 0 if on else -1)  # … and it does not wait
+
+
+def test_a_give_up_is_named_and_the_next_solve_is_a_fresh_contexts(oracle):
+    """A reducer that gives up (forced: the FIRST tile reduces and waits zero ticks, on a grid many times the chip) leaves
+    NaN sums and a record buffer the stragglers go on writing into.  hh_mc_solve must say what happened
+    (HH_ERR_DEVICE_TIMEOUT, not "finalize failed"), and the NEXT solve on the same context — same shape, so the same
+    record words — must be the solve of a fresh context, bit for bit."""
+    n_paths, n_steps = 256 * 3000, 16
+    m = o.make_model()
+    c = o.make_config(HES, EM, n_paths, n_steps, seeds=seeds_for(n_paths, 12))
+    fresh = _ffi.Context(0)
+    ctx = _ffi.Context(0)
+    try:
+        want = _ffi.hh_result()
+        fresh.check(fresh.lib.hh_mc_solve(fresh.handle, C.byref(m), C.byref(c), C.byref(want), None))
+        _forced(ctx, True)
+        res = _ffi.hh_result()
+        rc = ctx.lib.hh_mc_solve(ctx.handle, C.byref(m), C.byref(c), C.byref(res), None)
+        assert rc == _ffi.HH_ERR_DEVICE_TIMEOUT
+        msg = ctx.lib.hh_last_error(ctx.handle).decode()
+        assert "gave up" in msg and "record" in msg
+        _forced(ctx, False)
+        for fuse in (1, 2, 0):
+            ctx.set_option(_ffi.HH_OPT_FUSE_REDUCE, fuse)
+            got = _ffi.hh_result()
+            ctx.check(ctx.lib.hh_mc_solve(ctx.handle, C.byref(m), C.byref(c), C.byref(got), None))
+            assert (got.price, got.sumsq_payoff, got.n_paths_done) == (want.price, want.sumsq_payoff, want.n_paths_done)
+        ro, _, _ = oracle.mc_solve(m, c, want_terminal=False)
+        assert want.price == pytest.approx(ro.price, rel=1e-11)
+    finally:
+        ctx.close()
+        fresh.close()
+
+
+def test_solves_queued_behind_a_give_up_fail_closed_until_the_host_checks():
+    """The asynchronous entry point: a give-up, then two more launches queued behind it WITHOUT the host looking.  They
+    must not pass a straggler's record off as their own: every accumulator written after the give-up holds NaN, until
+    hh_ctx_check_last has said why (once) and reset the buffer; after that the context computes as a fresh one."""
+    n_paths, n_steps = 256 * 3000, 16
+    m = o.make_model()
+    c = o.make_config(HES, EM, n_paths, n_steps, seeds=seeds_for(n_paths, 13))
+    ctx = _ffi.Context(0)
+    try:
+        want = accumulate(ctx, m, c, False)
+        accs = [_ffi.DeviceBuffer(ctx, 8 * _ffi.HH_ACC_LEN) for _ in range(3)]
+        _forced(ctx, True)
+        ctx.check(ctx.lib.hh_mc_accumulate(ctx.handle, C.byref(m), C.byref(c), accs[0].ptr, None))
+        ctx.set_option(_ffi.HH_OPT_FINISH_TILE_FIRST, 0)   # the launches behind it: the shipped form, default bound
+        ctx.set_option(_ffi.HH_OPT_FINISH_SPIN_TICKS, -1)
+        for a in accs[1:]:
+            ctx.check(ctx.lib.hh_mc_accumulate(ctx.handle, C.byref(m), C.byref(c), a.ptr, None))
+        assert ctx.lib.hh_ctx_check_last(ctx.handle) == _ffi.HH_ERR_DEVICE_TIMEOUT
+        for a in accs:
+            got = a.download(np.empty(_ffi.HH_ACC_LEN))
+            assert np.isnan(got[_ffi.HH_ACC_NPATHS]) and np.isnan(got[_ffi.HH_ACC_SUM])
+        assert ctx.lib.hh_ctx_check_last(ctx.handle) == _ffi.HH_OK  # said once; the context is in order again
+        ctx.set_option(_ffi.HH_OPT_FUSE_REDUCE, 2)
+        assert accumulate(ctx, m, c, True).tobytes() == want.tobytes()
+        ctx.check_last()
+    finally:
+        ctx.close()
+
+
+def test_check_last_is_quiet_after_ordinary_solves(hhlib):
+    m = o.make_model()
+    c = o.make_config(HES, EM, 256 * 50 + 3, 4, seeds=seeds_for(256 * 50 + 3, 14))
+    accumulate(hhlib, m, c, True)
+    hhlib.check_last()

@@ -9,16 +9,18 @@ import subprocess
 
 import pytest
 
+from tests.conftest import host_cxxflags, host_env
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.skipif(shutil.which("g++") is None, reason="needs g++")
 def test_hh_math_against_long_double_libm(tmp_path):
     exe = tmp_path / "math_check"
-    subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off",
+    subprocess.run(["g++", *host_cxxflags(), "-std=c++17", "-ffp-contract=off",
                     "-I", os.path.join(ROOT, "hedgehog.jl_amd", "csrc"),
                     os.path.join(ROOT, "tests", "c", "math_check.cpp"), "-o", str(exe)], check=True)
-    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True, env=host_env()).stdout
     err = {ln.split()[0]: float(ln.split()[2]) for ln in out.strip().splitlines()}
     assert set(err) == {"sin", "cos", "log", "atan2", "exp", "wsin", "wcos", "nquant"}
     # exp <= 1.5 ulp; the wide sincos (|x| <= 2^45, three-term reduction) as good as the narrow one

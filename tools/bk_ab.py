@@ -31,6 +31,8 @@ ctxs = {}
 for tag, path in libs.items():
     lib = C.CDLL(path)
     for name, res, args in _ffi.SYMBOLS:
+        if not hasattr(lib, name):  # an older build kept for comparison
+            continue
         f = getattr(lib, name)
         f.restype, f.argtypes = res, args
     h = C.c_void_p()
