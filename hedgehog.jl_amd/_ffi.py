@@ -49,6 +49,7 @@ class hh_config(C.Structure):
         ("bk_n_sigma", C.c_double), ("bk_cf_tol", C.c_double), ("bk_atol", C.c_double),
         ("bk_moment_h", C.c_double),
         ("bk_newton_maxiter", C.c_int32), ("bk_bisect_maxiter", C.c_int32),
+        ("bk_root_form", C.c_int32), ("bk_bracket_form", C.c_int32), ("bk_caps", C.c_int32), ("reserved0", C.c_int32),
         ("seeds_len", C.c_uint64), ("replay_len", C.c_uint64),
     ]
 
@@ -72,6 +73,9 @@ class hh_lsm_result(C.Structure):
                 ("form", C.c_int32), ("persistent_fallbacks", C.c_int32)]
 
 
+HH_BK_ROOT_SECANT, HH_BK_ROOT_ORDER2 = 0, 1
+HH_BK_BRACKET_MIDPOINT, HH_BK_BRACKET_ROOTS = 0, 1
+HH_BK_CAPS_AS_WRITTEN, HH_BK_CAPS_ROOTS_DEFAULT = 0, 1
 HH_OPT_LSM_FORM = 1
 HH_OPT_BK_TERM_CACHE = 2
 HH_OPT_GRID_FORM = 3

@@ -82,6 +82,10 @@ int validate(hh_ctx* ctx, const hh_model* m, const hh_config* c) {
     if (m->sigma == 0.0 || m->kappa == 0.0 || !(m->V0 > 0.0))
       return fail(ctx, HH_ERR_INVALID, "HestonBroadieKaya needs sigma != 0, kappa != 0, V0 > 0");
     // d = 4κθ/σ² degrees of freedom of the noncentral chi-squared law (heston.jl:128), λ >= 0 (:129)
+    if ((c->bk_root_form != HH_BK_ROOT_SECANT && c->bk_root_form != HH_BK_ROOT_ORDER2) ||
+        (c->bk_bracket_form != HH_BK_BRACKET_MIDPOINT && c->bk_bracket_form != HH_BK_BRACKET_ROOTS) ||
+        (c->bk_caps != HH_BK_CAPS_AS_WRITTEN && c->bk_caps != HH_BK_CAPS_ROOTS_DEFAULT))
+      return fail(ctx, HH_ERR_INVALID, "bk_root_form, bk_bracket_form, bk_caps: 0 or 1 each (hedgehog_mc.h)");
     if (!bk_law_ok(m, m->T))
       return fail(ctx, HH_ERR_INVALID, "HestonBroadieKaya needs 1e-8 <= d = 4 kappa theta / sigma^2 <= 1e6 "
                                        "(Bessel order d/2 - 1 strictly above -1, tables up to order 5e5) and "

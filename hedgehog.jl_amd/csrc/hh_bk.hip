@@ -94,6 +94,7 @@ static_assert(kHeavyGrid >= kRecStride, "one workgroup of the tail kernel per ac
 // IEEE quotient, so the compile-time constants of the unrolled evaluation, this table (filled on the device by
 // bk_tables_kernel, read with the loop's uniform j: scalar loads) and a division in the kernel (beyond the
 // table) are the same numbers.
+constexpr int kRootsMaxIters = 40;  // Roots.jl's own `maxiters` of a secant-type method (hh_config.bk_caps = 1)
 constexpr int kCoefTerms = 1024;  // = the largest term cache (phi_cache_cap)
 constexpr int kRegTerms = 16;     // series terms a lane holds in registers through its root search (load_terms)
 struct BkBessel {
@@ -133,6 +134,8 @@ struct BkArgs {
   // controls (sample_from_cf.jl:27,50,75,105-113)
   double n_sigma, cf_tol, atol, moment_h;
   int newton_maxiter, bisect_maxiter;
+  int root_form, bracket_form, caps;  // hh_config.bk_root_form / bk_bracket_form / bk_caps: other than 0, 0, 0 the
+                                      // whole chain runs in the tail kernel (tail_whole_trajectory)
   // problem
   uint64_t n_paths, path_offset;
   const uint64_t* seeds;
@@ -1191,7 +1194,8 @@ __global__ __launch_bounds__(kTile) HH_BK_CF_OCC void bk_cf_kernel(const BkArgs 
   __syncthreads();                //  tens of microseconds long, but say so to the compiler and the hardware)
   double h = 0.0;
   int j_stop = 0;
-  if (live) series_phase<ORD>(p, bt, path, col, p.cache_stride, sh, h, j_stop);
+  // (another reading of the reference's root searches was asked for: every trajectory runs whole in the tail kernel)
+  if (live && (p.root_form | p.bracket_form | p.caps) == 0) series_phase<ORD>(p, bt, path, col, p.cache_stride, sh, h, j_stop);
   invert_phase<ORD>(p, tabs->coef, tile, tid, path, live, col, sh, h, j_stop);
   give_slot(p, slot);
 }
@@ -1217,20 +1221,37 @@ __global__ __launch_bounds__(kTile) HH_BK_CF_OCC void bk_cf_kernel(const BkArgs 
 // into `accum` by the first kRecStride workgroups, one accumulator slot each, in reduce_records_kernel's order
 // (sum_slot).  When (a) had work they wait for every workgroup's record first: kHeavyGrid workgroups are resident
 // together on any device this library runs on, each arrives once, none waits before it has arrived.
+// (Also the home of the OTHER READINGS of the reference's two `find_zero` calls — hh_config.bk_root_form,
+// bk_bracket_form, bk_caps; include/hedgehog_mc.h has the table: Roots' Order2 as a Steffensen step guarded by a secant
+// step, its bisection over the bit patterns of the ends, the `maxeval` keyword ignored.  A chain run with any of them
+// sends EVERY trajectory here — they are a parity seam, to be decided by one Julia run, not a pricing path — so the
+// CF kernel carries none of it.)
+__device__ __forceinline__ double roots_middle(double a, double b) {  // Roots.jl `_middle` for 0 <= a < b, finite
+  const unsigned long long ia = (unsigned long long)__double_as_longlong(a), ib = (unsigned long long)__double_as_longlong(b);
+  return __longlong_as_double((long long)((ia + ib) >> 1));
+}
+__device__ __forceinline__ int sign_of(double x) { return (x > 0.0) - (x < 0.0); }
+
 __device__ __forceinline__ void tail_whole_trajectory(const BkArgs& p, const BesselTable* bt, const double* coef,
                                                       uint64_t path, double (&acc)[6]) {
   PathSetup s;
   bk_setup(p, bt, path, s);
   double n_terms = 0.0;
-  enum Stage { kSecantFirst, kSecant, kLadderLo, kLadderHi, kBisect };
+  enum Stage { kSecantFirst, kSecant, kSteffProbe, kLadderLo, kLadderHi, kBisect };
+  const bool order2 = p.root_form == HH_BK_ROOT_ORDER2, roots_bisect = p.bracket_form == HH_BK_BRACKET_ROOTS;
+  const bool own_caps = p.caps == HH_BK_CAPS_ROOTS_DEFAULT;
+  // evaluations (secant) / steps (Order2) of the first search, iterations of the bisection
+  const int cap_first = own_caps ? (order2 ? kRootsMaxIters : 2 + kRootsMaxIters) : p.newton_maxiter;
+  const int cap_bisect = own_caps ? 4096 : p.bisect_maxiter;
   // secant_inverse: Order2 restated as the secant iteration from (x0 + dx, x0), dx = h + |x0| h², h = eps^(1/3).
-  // The secant's (x0, f0), (x1, f1) and the ladder's (lo, f(lo)), hi share their registers: xa, fa, xb, fb
-  const double hs = 6.0554544523933395e-06;
+  // The secant's (x0, f0), (x1, f1) and the ladder's (lo, f(lo)), (hi, f(hi)) share their registers: xa, fa, xb, fb
+  const double hs = 6.0554544523933395e-06, eps = 0x1p-52;
   double xb = s.initial_guess;                   // secant: x1            ladder: hi
   double xa = xb + hs + fabs(xb) * hs * hs;      // secant: x0            ladder: lo
-  double fa = 0.0;                               // secant: f0            ladder: f(lo)
-  uint32_t dec = kDecLongSeries, evals = 1, iters = 0;
-  int stage = kSecantFirst;
+  double fa = 0.0, fb = 0.0;                     // secant: f0, f1        ladder: f(lo), f(hi)
+  uint32_t dec = (p.root_form | p.bracket_form | p.caps) ? 0u : kDecLongSeries, evals = 1, iters = 0;
+  int stage = kSecantFirst, steps = 0, sgn = 0;
+  bool out_set = false;  // the bisection met an exact zero: x is the answer
   double x = xa;
   for (;;) {
     const double f = cdf_from_cf(p, bt, coef, s.cf, x, s.h, s.cache, n_terms) - s.u;
@@ -1240,22 +1261,63 @@ __device__ __forceinline__ void tail_whole_trajectory(const BkArgs& p, const Bes
       stage = kSecant;
       continue;
     }
-    if (stage == kSecant) {
-      const double fb = f, f0 = fa;
+    if (stage == kSecant || stage == kSteffProbe) {
       ++evals;
-      const bool ok = fabs(fb) <= p.atol;
-      if (!ok && !((int)evals >= p.newton_maxiter || fb == f0)) {
-        const double x2 = xb - fb * (xb - xa) / (fb - f0);
-        if (isfinite(x2)) {
+      bool ok = false, go_on = false;
+      if (stage == kSteffProbe) {  // f = f(x1 - sgn f1): the Steffensen step itself
+        const double d = f != fb ? -(double)sgn * fb * fb / (f - fb) : __builtin_inf();
+        if (isfinite(d)) {
           xa = xb;
           fa = fb;
-          x = xb = x2;
+          x = xb = xb - d;
+          ++steps;
+          stage = kSecant;
           continue;
         }
+        x = xb;  // the search ends where it stood
+      } else if (!order2) {
+        fb = f;
+        ok = fabs(fb) <= p.atol;
+        if (!ok && !((int)evals >= cap_first || fb == fa)) {
+          const double x2 = xb - fb * (xb - xa) / (fb - fa);
+          if (isfinite(x2)) {
+            xa = xb;
+            fa = fb;
+            x = xb = x2;
+            go_on = true;
+          }
+        }
+      } else {  // Roots.Order2: assess_convergence, then a guarded step
+        fb = f;
+        const double tol = fmax(p.atol, fabs(xb) * 4.0 * eps);
+        if (isfinite(xb) && isfinite(fb)) {
+          if (fabs(fb) <= tol) {
+            ok = true;
+          } else if (fabs(xb - xa) <= fmax(eps, fmax(fabs(xb), fabs(xa)) * eps)) {
+            ok = fabs(fb) <= cbrt(tol);
+          } else if (steps < cap_first) {
+            if (1000.0 * fabs(fb) > fmax(1.0, fabs(xb))) {  // f is large: a secant step
+              const double d = fb != fa ? fb * (xb - xa) / (fb - fa) : __builtin_inf();
+              if (isfinite(d)) {
+                xa = xb;
+                fa = fb;
+                x = xb = xb - d;
+                ++steps;
+                go_on = true;
+              }
+            } else {  // a Steffensen step: first the probe at x1 - sgn·f1
+              sgn = xb != xa ? sign_of((fb - fa) / (xb - xa)) : 0;
+              x = xb - (double)sgn * fb;
+              stage = kSteffProbe;
+              go_on = true;
+            }
+          }
+        }
       }
-      dec |= evals;
-      x = xb;                            // the secant's answer, should it stand
-      if (ok && !(xb < 0.0)) break;
+      if (go_on) continue;
+      dec |= evals < 0xffu ? evals : 0xffu;
+      x = xb;                            // the first search's answer, should it stand
+      if (ok && !(xb < 0.0 || fabs(fb) > p.atol)) break;
       acc[2] += 1.0;  // the fall-back ladder (sample_from_cf.jl:123-133)
       x = xa = 0.0;
       xb = s.max_guess;
@@ -1269,34 +1331,53 @@ __device__ __forceinline__ void tail_whole_trajectory(const BkArgs& p, const Bes
       continue;
     }
     if (stage == kLadderHi) {
-      if (fa * f > 0.0) {
+      fb = f;
+      if (fa * fb > 0.0) {
         acc[4] += 1.0;
         dec |= kDecMaxGuess;  // x = max_guess (sample_from_cf.jl:124-126)
         break;
       }
       acc[3] += 1.0;
       dec |= kDecBisect;
-      x = 0.5 * (xa + xb);
-      if (p.bisect_maxiter <= 0) break;
+      x = roots_bisect ? roots_middle(xa, xb) : 0.5 * (xa + xb);
+      if (cap_bisect <= 0 || (roots_bisect && !(xa < x && x < xb))) break;
       stage = kBisect;
       continue;
     }
     // kBisect: f is the CDF residual at the midpoint x
     ++iters;
-    if (f == 0.0) {
-      xa = xb = x;
-    } else if ((f < 0.0) == (fa < 0.0)) {
-      xa = x;
-      fa = f;
+    bool stop;
+    if (roots_bisect) {  // Roots.Bisection: to the last bit, the end with the smaller residual
+      if (f == 0.0) {
+        out_set = true;
+      } else if (sign_of(fa) * sign_of(f) < 0) {
+        xb = x;
+        fb = f;
+      } else {
+        xa = x;
+        fa = f;
+      }
+      const double mid = roots_middle(xa, xb);
+      stop = out_set || (int)iters >= cap_bisect || !(xa < mid && mid < xb);
+      if (!out_set) x = stop ? mid : mid;
     } else {
-      xb = x;
+      if (f == 0.0) {
+        xa = xb = x;
+      } else if ((f < 0.0) == (fa < 0.0)) {
+        xa = x;
+        fa = f;
+      } else {
+        xb = x;
+      }
+      x = 0.5 * (xa + xb);
+      stop = f == 0.0 || xb - xa <= p.atol || (int)iters >= cap_bisect;
     }
-    x = 0.5 * (xa + xb);
-    if (f == 0.0 || xb - xa <= p.atol || (int)iters >= p.bisect_maxiter) {
+    if (stop) {
       dec |= (iters & 0xffu) << kDecItersShift;
       break;
     }
   }
+  if (roots_bisect && (dec & kDecBisect) && !out_set) x = fabs(fa) < fabs(fb) ? xa : xb;
   const double IV = x;
   p.diag[path] = dec;
   p.diag[p.draw_stride + path] = (uint32_t)s.cache.j_stop;
@@ -1648,6 +1729,9 @@ int bk_prepare(const hh_model& m, const hh_config& c, const DevicePtrs& ptr, uin
   a.moment_h = c.bk_moment_h > 0.0 ? c.bk_moment_h : 1e-2;
   a.newton_maxiter = c.bk_newton_maxiter > 0 ? c.bk_newton_maxiter : 10;
   a.bisect_maxiter = c.bk_bisect_maxiter > 0 ? c.bk_bisect_maxiter : 100;
+  a.root_form = c.bk_root_form;
+  a.bracket_form = c.bk_bracket_form;
+  a.caps = c.bk_caps;
   a.n_paths = n_chain;
   a.path_offset = c.path_offset;
   a.seeds = ptr.seeds;

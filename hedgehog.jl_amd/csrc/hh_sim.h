@@ -371,7 +371,8 @@ __device__ __forceinline__ void partial_pairs(const double* rec, uint32_t n, dou
                                               unsigned int* gave_up, unsigned long long spin_ticks, bool dirty) {
   static_assert(256 % NT == 0, "the 256 virtual threads are dealt evenly");
   const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(rec), 0, (int)(n * (uint32_t)(kRecStride * 8)), 0x00020000);
-  bool give = *gave_up != 0u || dirty;  // set in an earlier pass, or by an earlier launch: do not wait
+  bool give = *gave_up != 0u;  // set in an earlier pass: do not wait again (`dirty`: by an earlier launch — asked for
+                               // last, behind the record loads it was issued in front of)
   for (int vt = threadIdx.x; vt < 256; vt += NT) {
     double t0 = 0.0, t1 = 0.0;
     for (uint32_t b = vt; b < n; b += 256 * kFinishBatch) {
@@ -388,7 +389,7 @@ __device__ __forceinline__ void partial_pairs(const double* rec, uint32_t n, dou
           const unsigned long long hi = ((unsigned long long)v[u][3] << 32) | v[u][2];
           there = there && lo != kPoison && hi != kPoison;
         }
-        if (there || give || !keep_waiting(since, give, gave_up, spin_ticks)) break;
+        if (there || give || dirty || !keep_waiting(since, give, gave_up, spin_ticks)) break;
       }
 #pragma unroll
       for (int u = 0; u < kFinishBatch; ++u) {
@@ -407,7 +408,7 @@ __device__ __forceinline__ void partial_slots(const double* __restrict__ rec, ui
                                               double* __restrict__ sm, unsigned int* gave_up, unsigned long long spin_ticks,
                                               bool dirty) {
   constexpr int kB = NS <= 2 ? kFinishBatch : 8;
-  bool give = *gave_up != 0u || dirty;
+  bool give = *gave_up != 0u;
   for (int vt = threadIdx.x; vt < 256; vt += NT) {
     double t[NS];
 #pragma unroll
@@ -426,7 +427,7 @@ __device__ __forceinline__ void partial_slots(const double* __restrict__ rec, ui
             there = there && !is_poison(v[q][u]);
           }
         }
-        if (there || give || !keep_waiting(since, give, gave_up, spin_ticks)) break;
+        if (there || give || dirty || !keep_waiting(since, give, gave_up, spin_ticks)) break;
       }
 #pragma unroll
       for (int q = 0; q < NS; ++q)

@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define HH_ABI_VERSION 5
+#define HH_ABI_VERSION 6
 #define HH_MAX_PARTIALS 8   /* max. number of dual-number partials carried through one solve    */
 #define HH_TILE_PATHS 256   /* paths per tile of the tile-major REPLAY layout (see below)        */
 #define HH_ACC_LEN 16       /* doubles in the accumulator vector exchanged between GPUs          */
@@ -79,6 +79,14 @@ enum hh_dynamics { HH_LOGNORMAL = 0, HH_HESTON = 1 };
 enum hh_strategy { HH_EULER_MARUYAMA = 0, HH_EXACT_LAW = 1, HH_BROADIE_KAYA = 2 };
 enum hh_noise_mode { HH_NOISE_GENERATE = 0, HH_NOISE_REPLAY = 1 };
 enum hh_replay_layout { HH_REPLAY_TILE_MAJOR = 0, HH_REPLAY_PATH_MAJOR = 1 };
+
+/* readings of find_zero(func, x0, Order2(); atol, maxeval) / find_zero(func, (0, max_guess); xtol, maxeval) */
+enum hh_bk_root_form { HH_BK_ROOT_SECANT = 0,    /* the secant iteration from (x0 + dx, x0)                        */
+                       HH_BK_ROOT_ORDER2 = 1 };  /* Roots' Order2: a Steffensen step, a secant step while f is large */
+enum hh_bk_bracket_form { HH_BK_BRACKET_MIDPOINT = 0, /* arithmetic bisection to width <= atol                      */
+                          HH_BK_BRACKET_ROOTS = 1 };  /* Roots' Bisection: midpoints of the BIT PATTERNS, to the last bit */
+enum hh_bk_caps { HH_BK_CAPS_AS_WRITTEN = 0,     /* `maxeval` caps evaluations / iterations as the author meant    */
+                  HH_BK_CAPS_ROOTS_DEFAULT = 1 };/* `maxeval` is no keyword of Roots 2 and is ignored: 40 steps / none */
 
 typedef struct hh_ctx hh_ctx; /* opaque: device, stream, scratch */
 
@@ -133,6 +141,16 @@ typedef struct hh_config {
   double bk_moment_h;        /* h = 1e-2                                                          */
   int32_t bk_newton_maxiter; /* 10                                                                */
   int32_t bk_bisect_maxiter; /* 100                                                               */
+  /* How the two `find_zero` calls of inverse_cdf (sample_from_cf.jl:118,128) are READ — Roots.jl is not part of the
+     reference's tree, and three things about those calls cannot be told from its text (the enums above name them,
+     DESIGN.md says why; julia/parity_replay.jl's `bk_root_probe` + tools/check_reference_replay.py decide them on a
+     Julia host).
+     All 0 = what this library prices with.  Any other value sends the whole ensemble through the whole-trajectory
+     kernel (a parity seam, ~10x slower), with the same draws.                                              */
+  int32_t bk_root_form;      /* enum hh_bk_root_form                                              */
+  int32_t bk_bracket_form;   /* enum hh_bk_bracket_form                                           */
+  int32_t bk_caps;           /* enum hh_bk_caps                                                   */
+  int32_t reserved0;         /* 0                                                                 */
   /* Optional operand-shape checks (0 = not checked): the number of ELEMENTS behind `seeds` and
      `replay`.  When given, a buffer shorter than what the kernels will index is rejected with
      HH_ERR_INVALID on the host instead of faulting on the device.                               */

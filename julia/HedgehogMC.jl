@@ -10,7 +10,7 @@
 #     sol = Hedgehog.solve(prob, MonteCarlo(HestonDynamics(), EulerMaruyama(), cfg))
 #     G   = Hedgehog.solve(BatchGreekProblem(prob, lenses), ForwardAD(), mc)    # ONE fused pass
 #
-# What is bound (include/hedgehog_mc.h, HH_ABI_VERSION 5): hh_mc_solve (solve_hip, with the REPLAY
+# What is bound (include/hedgehog_mc.h, HH_ABI_VERSION 6): hh_mc_solve (solve_hip, with the REPLAY
 # keywords), hh_mc_solve_multi / hh_mgpu_solve_multi (prices_hip: the solves of a bumped Greek on shared draws),
 # hh_seeds_cache (the library's own seed cache), hh_mgpu_create / hh_mgpu_solve (solve_hip(...; devices = 0:7): several GPUs behind the one
 # call), hh_mc_accumulate + hh_mc_finalize (solve_sharded_hip: one process per GPU), hh_mc_solve_basket, hh_carr_madan,
@@ -31,7 +31,7 @@ const LIB = Ref{String}(get(ENV, "HEDGEHOG_MC_LIB",
 
 const HH_MAX_PARTIALS = 8
 const HH_ACC_LEN = 16
-const HH_ABI_VERSION = 5
+const HH_ABI_VERSION = 6
 const HH_NOISE_GENERATE, HH_NOISE_REPLAY = Int32(0), Int32(1)
 const HH_REPLAY_TILE_MAJOR, HH_REPLAY_PATH_MAJOR = Int32(0), Int32(1)
 
@@ -52,6 +52,7 @@ struct HHConfig
     seeds::Ptr{UInt64}; replay::Ptr{Cdouble}
     bk_n_sigma::Cdouble; bk_cf_tol::Cdouble; bk_atol::Cdouble; bk_moment_h::Cdouble
     bk_newton_maxiter::Int32; bk_bisect_maxiter::Int32
+    bk_root_form::Int32; bk_bracket_form::Int32; bk_caps::Int32; reserved0::Int32   # readings of find_zero: all 0 = shipped
     seeds_len::UInt64; replay_len::UInt64
 end
 
@@ -201,7 +202,7 @@ function _structs(r; em_split::Bool = true, compat_sqrt_alpha::Bool = false,
                       UInt64(path_offset),
                       (seeds_dev != C_NULL ? Ptr{UInt64}(seeds_dev) : pointer(r.seeds)) + 8 * seed_offset,
                       replay === nothing ? Ptr{Cdouble}(C_NULL) : pointer(replay),
-                      0.0, 0.0, 0.0, 0.0, Int32(0), Int32(0),
+                      0.0, 0.0, 0.0, 0.0, Int32(0), Int32(0), Int32(0), Int32(0), Int32(0), Int32(0),
                       UInt64(length(r.seeds) - seed_offset),
                       UInt64(replay === nothing ? 0 : length(replay)))
     return model, config
@@ -562,7 +563,7 @@ function solve_lsm_hip(prob::PricingProblem{VanillaOption{TS,TE,Hedgehog.America
         config = HHConfig(Int32(0), Int32(1), Int32(anti), Int32(1), Int32(0), Int32(0), Int32(0), Int32(0),
                           Int32(0), Int32(0), UInt32(nsteps), UInt32(0), UInt64(n),
                           UInt64(0), pointer(seeds), Ptr{Cdouble}(C_NULL), 0.0, 0.0, 0.0, 0.0, Int32(0), Int32(0),
-                          UInt64(length(seeds)), UInt64(0))
+                          Int32(0), Int32(0), Int32(0), Int32(0), UInt64(length(seeds)), UInt64(0))
         if devices !== nothing
             mg = multi_gpu(devices)
             rc = ccall((:hh_mgpu_lsm_solve, LIB[]), Cint,
@@ -608,7 +609,7 @@ function heston_exact_paths_hip(prob::PricingProblem{P,I}, method::MonteCarlo) w
                         Float64(m.ρ), Float64(zero_rate(m.rate, 0.0)), 1.0, Float64(T),
                         Float64(payoff.strike), 1.0, ntuple(_ -> Ptr{Cdouble}(C_NULL), 8)...)
         config = HHConfig(1, 2, false, 1, 0, 0, 0, 0, 0, 0, UInt32(nsteps), UInt32(0), UInt64(n),
-                          UInt64(0), pointer(seeds), Ptr{Cdouble}(C_NULL), 0.0, 0.0, 0.0, 0.0, 0, 0,
+                          UInt64(0), pointer(seeds), Ptr{Cdouble}(C_NULL), 0.0, 0.0, 0.0, 0.0, 0, 0, 0, 0, 0, 0,
                           UInt64(length(seeds)), UInt64(0))
         rc = ccall((:hh_heston_exact_grid, LIB[]), Cint,
                    (Ptr{Cvoid}, Ref{HHModel}, Ref{HHConfig}, Ptr{Cdouble}, Ptr{Cdouble}, Int32, Ptr{Cvoid}),

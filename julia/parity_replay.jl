@@ -6,7 +6,7 @@
 # Julia + Hedgehog.jl (+ its dependencies; nothing else):
 #
 #     julia --project julia/parity_replay.jl out_dir                  # writes out_dir/manifest.json + *.bin
-#     julia --project julia/parity_replay.jl out_dir probe            # the first case only (em_split, seconds)
+#     julia --project julia/parity_replay.jl out_dir probe            # the two deciding cases only (em_split, bk_root_probe: seconds)
 #     python tools/check_reference_replay.py out_dir/manifest.json    # on the MI355X box
 #
 # Mechanism: every case simulates with the reference's OWN functions and records what its RNGs
@@ -16,6 +16,8 @@
 #   exact_lognormal  the standard normals behind rand(rng, Normal(μ̃, σ̃), n) (montecarlo.jl:413,456)
 #   bk               V_T, u, Z of rand(rng, ::LogHestonDistribution) (heston.jl:246-259), re-drawn on a
 #                    copy of the generator in the reference's order
+#   bk_root_probe    every abscissa the reference's inverse_cdf (sample_from_cf.jl:105-135) asks of its CDF, for 64
+#                    (V_T, u) pairs: the iterates of Roots.jl's two find_zero calls, which decide the reading
 #   lsm              the spot grid extract_spot_grid hands the regression (least_squares_montecarlo.jl:47-85)
 # and stores the reference's results next to them: terminal samples, price, AD Greeks, stopping info.
 # File formats: little-endian Float64 / Int32, shapes in the manifest; tests/golden/replay_selftest/
@@ -83,6 +85,57 @@ end
 # u or at K = u + dt·f(u) (`em_split`, SURVEY §8a-4).  8 steps of dt = 1/8 make the two forms differ by percents
 # per trajectory; tools/check_reference_replay.py prints `VERDICT em_split = 0|1 matches the reference`.
 export_euler("em_split_probe", hprob, heston, HestonDynamics(), 64, 8)
+
+# SECOND, also in `probe` mode (seconds): ---- Broadie–Kaya: what inverse_cdf ASKS of its CDF (the iterates of Roots.jl's two find_zero calls) --------
+# The one place where the restatement is KNOWN to be a reading: `find_zero(func, x0, Order2(); atol, maxeval)` and
+# `find_zero(func, (0, max_guess); xtol, maxeval)` (sample_from_cf.jl:118,128) — Roots.jl is a dependency, and whether
+# Order2 is a secant or a Steffensen iteration there, whether its bisection halves the interval or the bit patterns,
+# and whether `maxeval` / `xtol` are keywords it knows at all, cannot be read from the reference.  For 64 (V_T, u)
+# pairs — 48 as the generator gives them, 16 with the uniform pushed far into a tail so that the fall-back ladder
+# runs — the reference's OWN inverse_cdf is called with a CDF closure that records every abscissa it is asked for.
+# tools/check_reference_replay.py runs the CPU restatement in every reading and prints
+# `VERDICT bk_root_form = …, bk_bracket_form = …, bk_caps = …`.  Everything up to the closure is the reference's own
+# code (HestonCFIterator, moments_from_cf, cdf_from_cf); the five lines between them are sample_from_cf.jl:31-37.
+let N = 64
+    law = marginal_law(hprob, HestonDynamics(), hprob.payoff.expiry)
+    rng = Xoshiro(20240611)
+    VT = Vector{Float64}(undef, N); U = similar(VT); G0 = similar(VT); GM = similar(VT); HH = similar(VT); SOL = similar(VT)
+    counts = Vector{Int32}(undef, N); xs_all = Float64[]; threw = Vector{Int32}(undef, N)
+    for i in 1:N
+        VT[i] = Hedgehog.sample_V_T(rng, law)
+        u = Distributions.rand(rng, Uniform(0, 1))
+        i > 48 && (u = isodd(i) ? 1e-9 * (i - 47) : 1 - 1e-9 * (i - 47))
+        U[i] = u
+        ϕ = Hedgehog.HestonCFIterator(VT[i], law)
+        mean, variance = Hedgehog.moments_from_cf(ϕ)
+        σ² = max(variance, 1e-12)
+        normal_sample = mean + sqrt(σ²) * quantile(Normal(), u)
+        G0[i] = normal_sample > 0 ? normal_sample : mean * 0.01
+        GM[i] = mean + 11 * sqrt(σ²)
+        HH[i] = π / (mean + 5 * √σ²)
+        xs = Float64[]
+        cdf = x -> (push!(xs, Float64(x)); Hedgehog.cdf_from_cf(ϕ, x, HH[i]))
+        threw[i] = 0
+        SOL[i] = try
+            Hedgehog.inverse_cdf(cdf, u, G0[i], GM[i])
+        catch                                     # an exception that escapes inverse_cdf's own catch block
+            threw[i] = 1
+            NaN
+        end
+        counts[i] = length(xs)
+        append!(xs_all, xs)
+    end
+    T = yearfrac(hprob.market_inputs.rate.reference_date, hprob.payoff.expiry)
+    add_case!("bk_root_probe"; kind = "bk_root_probe", n = N, model = model_json(heston, T),
+              VT = wbin("bk_root_probe.VT.bin", VT), u = wbin("bk_root_probe.u.bin", U),
+              initial_guess = wbin("bk_root_probe.guess.bin", G0), max_guess = wbin("bk_root_probe.max_guess.bin", GM),
+              h = wbin("bk_root_probe.h.bin", HH), sol = wbin("bk_root_probe.sol.bin", SOL),
+              counts = wbin("bk_root_probe.counts.bin", counts), threw = wbin("bk_root_probe.threw.bin", threw),
+              xs = wbin("bk_root_probe.xs.bin", xs_all),
+              layout = "VT, u, initial_guess, max_guess, h, sol: Float64[n]; counts, threw: Int32[n]; xs: Float64[sum(counts)] — " *
+                       "trajectory i's requests are the counts[i] numbers behind those of the trajectories before it")
+end
+
 if !(length(ARGS) >= 2 && ARGS[2] == "probe")
 export_euler("heston_euler", hprob, heston, HestonDynamics(), 20_000, 252)
 export_euler("heston_euler_antithetic", hprob, heston, HestonDynamics(), 5_000, 100; antithetic = true)

@@ -21,9 +21,11 @@ and what is RESTATED from published algorithms (third-party in the reference):
   * besseli(ν, z), complex z: scipy.special.ive — the same AMOS library SpecialFunctions.jl wraps
   * NoncentralChisq(d, λ) draw: d > 1: (Z+√λ)² + χ²(d−1); else Poisson(λ/2) mixture of central χ²;
     gamma by Marsaglia–Tsang (2000), Poisson by inversion (mean < 10) or Hörmann's PTRS (1993)
-  * find_zero(f, x0, Order2(); atol, maxeval): secant iteration from (x0 + dx, x0),
+  * find_zero(f, x0, Order2(); atol, maxeval): by default a secant iteration from (x0 + dx, x0),
     dx = h + |x0| h², h = eps^(1/3) (Roots.jl's default secant start), |f| ≤ atol, ≤ maxeval evals
-  * find_zero(f, (0, b); xtol, maxeval): plain bisection
+  * find_zero(f, (0, b); xtol, maxeval): by default plain bisection
+    — both ALSO as Roots.jl states them (Steffensen guarded by secant; bisection over bit patterns) and with the
+    `maxeval` keyword ignored: the fork table above inverse_cdf, decided by the iterate probe of a Julia run
   * draws: Philox4x32-10 keyed by seeds[1], counter = (trajectory index, draw block) — the
     reference's ONE sequential stream (montecarlo.jl:456) is replaced by per-trajectory counters so
     that trajectories are independent of each other and of the sharding.
@@ -302,30 +304,128 @@ SECANT_H = np.finfo(np.float64).eps ** (1.0 / 3.0)
 
 DEC_BISECT, DEC_MAXGUESS, DEC_ITERS_SHIFT = 1 << 8, 2 << 8, 16  # decision word: hh_bk_decisions (hedgehog_mc.h)
 
+# ---- the forks of `find_zero` ------------------------------------------------------------------------------------
+# inverse_cdf (sample_from_cf.jl:105-135) calls Roots.jl twice — `find_zero(func, x0, Order2(); atol, maxeval)` and
+# `find_zero(func, (0, max_guess); xtol, maxeval)` — and Roots (2.2.6 in the reference's Project.toml) is not under
+# /root/reference.  Three things about those calls cannot be decided from the reference's text, so each exists here
+# in both readings (and in the kernels: hh_config.bk_root_form / bk_bracket_form / bk_caps); the defaults are what
+# this repository has shipped since round 1, and ONE run of julia/parity_replay.jl (its `bk_root_probe` case: every x
+# the reference's own inverse_cdf asks of its CDF) decides between them — tools/check_reference_replay.py prints the
+# verdict.
+#   root_form     0  SECANT: the plain secant iteration from (x0 + dx, x0)
+#                 1  ORDER2: Roots' `Order2()` as its documentation and source (as remembered; the probe decides)
+#                    state it — a Steffensen step (two evaluations: at x1 - sgn·f1, then at the new iterate), replaced
+#                    by a secant step while f is large (1000·|f(x1)| > max(1, |x1|)); convergence when |f| <= max(atol,
+#                    4 eps |x|), or when the iterates stall (|x1 - x0| <= max(eps, eps·max|x|)) with |f| below the cube
+#                    root of that tolerance
+#   bracket_form  0  MIDPOINT: arithmetic bisection, stopped at width <= atol (what `xtol = atol` asks for)
+#                 1  ROOTS: Roots' `Bisection()` for Float64 — the midpoint taken over the BIT PATTERNS of the two ends
+#                    (`_middle`), run until the ends are adjacent floats (~62 steps from (0, b)), which is what happens
+#                    if `xtol` is not a keyword Roots 2 knows (its tolerances are xatol / xrtol) and is ignored
+#   caps          0  AS_WRITTEN: `maxeval` caps the evaluations (secant) / iterations (bisection) as the reference's
+#                    author meant
+#                 1  ROOTS_DEFAULT: `maxeval` is not a keyword Roots 2 knows (`maxiters`, alias `maxevals`) and is
+#                    ignored: Order2 stops after Roots' own 40 steps, the bisection only at the last bit
+ROOT_SECANT, ROOT_ORDER2 = 0, 1
+BRACKET_MIDPOINT, BRACKET_ROOTS = 0, 1
+CAPS_AS_WRITTEN, CAPS_ROOTS_DEFAULT = 0, 1
+ROOTS_MAXITERS = 40
+_EPS = float(np.finfo(np.float64).eps)
 
-def inverse_cdf(cdf, u, initial_guess, max_guess, atol=1e-4, maxiter_newton=10,
-                maxiter_bisection=100, stats=None, trace=None):
-    """sample_from_cf.jl:105-135.  trace (a list): receives the trajectory's decision word —
-    secant evaluations | branch << 8 | bisection iterations << 16 — what the search DID."""
-    func = lambda y: cdf(y) - u
-    # --- find_zero(func, initial_guess, Order2(); atol, maxeval) restated as a secant iteration
-    ok, sol, fsol = False, float("nan"), float("nan")
-    x1 = initial_guess
+
+def _sign(x):
+    return int(x > 0) - int(x < 0)
+
+
+def roots_middle(a, b):
+    """Roots.jl `_middle(x::Float64, y::Float64)`: halfway between the two numbers' bit patterns (same sign, finite);
+    0.0 when the signs differ."""
+    if not (math.isfinite(a) and math.isfinite(b)):
+        return a + b
+    if _sign(a) != _sign(b) and a != 0.0 and b != 0.0:
+        return 0.0
+    negate = a < 0 or b < 0
+    ia = int(np.float64(abs(a)).view(np.uint64))
+    ib = int(np.float64(abs(b)).view(np.uint64))
+    m = float(np.uint64((ia + ib) >> 1).view(np.float64))
+    return -m if negate else m
+
+
+def _secant_search(func, guess, atol, max_evals):
+    """-> (converged, x, f(x), evaluations)"""
+    x1 = guess
     x0 = x1 + SECANT_H + abs(x1) * SECANT_H * SECANT_H
     f0, f1 = func(x0), func(x1)
     evals = 2
     while True:
         if abs(f1) <= atol:
-            ok, sol, fsol = True, x1, f1
-            break
-        if evals >= maxiter_newton or f1 == f0:
-            break
+            return True, x1, f1, evals
+        if evals >= max_evals or f1 == f0:
+            return False, x1, f1, evals
         x2 = x1 - f1 * (x1 - x0) / (f1 - f0)
         if not math.isfinite(x2):
-            break
+            return False, x1, f1, evals
         x0, f0 = x1, f1
         x1, f1 = x2, func(x2)
         evals += 1
+
+
+def _order2_search(func, guess, atol, max_steps):
+    """Roots.Order2 (see the fork table above) -> (converged, x, f(x), evaluations)"""
+    x1 = guess
+    x0 = x1 + SECANT_H + abs(x1) * SECANT_H * SECANT_H   # Roots' default second point of a secant-type method
+    f0, f1 = func(x0), func(x1)
+    evals, steps = 2, 0
+    while True:
+        if not (math.isfinite(x1) and math.isfinite(f1)):
+            return False, x1, f1, evals
+        tol = max(atol, abs(x1) * 4.0 * _EPS)
+        if abs(f1) <= tol:                                                   # :f_converged
+            return True, x1, f1, evals
+        if abs(x1 - x0) <= max(_EPS, max(abs(x1), abs(x0)) * _EPS):         # :x_converged — accepted if f is small-ish
+            return abs(f1) <= float(np.cbrt(tol)), x1, f1, evals
+        if steps >= max_steps:
+            return False, x1, f1, evals
+        if 1000.0 * abs(f1) > max(1.0, abs(x1)):                             # guarded: a secant step
+            d = f1 * (x1 - x0) / (f1 - f0) if f1 != f0 else float("inf")
+            if not math.isfinite(d):
+                return False, x1, f1, evals
+            x2 = x1 - d
+            f2 = func(x2)
+            evals += 1
+        else:                                                                # a Steffensen step
+            sgn = _sign((f1 - f0) / (x1 - x0)) if x1 != x0 else 0
+            fs = func(x1 - sgn * f1)
+            evals += 1
+            d = -sgn * f1 * f1 / (fs - f1) if fs != f1 else float("inf")
+            if not math.isfinite(d):
+                return False, x1, f1, evals
+            x2 = x1 - d
+            f2 = func(x2)
+            evals += 1
+        x0, f0, x1, f1 = x1, f1, x2, f2
+        steps += 1
+
+
+def inverse_cdf(cdf, u, initial_guess, max_guess, atol=1e-4, maxiter_newton=10,
+                maxiter_bisection=100, stats=None, trace=None, root_form=ROOT_SECANT,
+                bracket_form=BRACKET_MIDPOINT, caps=CAPS_AS_WRITTEN, xs=None):
+    """sample_from_cf.jl:105-135.  trace (a list): receives the trajectory's decision word —
+    evaluations of the first search | branch << 8 | bisection iterations << 16 — what the search DID.
+    xs (a list): receives every abscissa the CDF is asked for, in order (the exchange format of the iterate probe:
+    julia/parity_replay.jl `bk_root_probe`)."""
+    def func(y):
+        if xs is not None:
+            xs.append(float(y))
+        return cdf(y) - u
+    if root_form == ROOT_ORDER2:
+        ok, sol, fsol, evals = _order2_search(func, initial_guess, atol,
+                                              maxiter_newton if caps == CAPS_AS_WRITTEN else ROOTS_MAXITERS)
+    else:
+        ok, sol, fsol, evals = _secant_search(func, initial_guess, atol,
+                                              maxiter_newton if caps == CAPS_AS_WRITTEN else 2 + ROOTS_MAXITERS)
+    evals = min(evals, 0xff)
+    # (the reference evaluates func(sol) once more for its `abs(func(sol)) > atol` test: the same number again)
     if ok and not (sol < 0 or abs(fsol) > atol):
         if trace is not None:
             trace.append(evals)
@@ -344,19 +444,37 @@ def inverse_cdf(cdf, u, initial_guess, max_guess, atol=1e-4, maxiter_newton=10,
         stats["bisect"] += 1
     a, b = 0.0, max_guess
     iters, out = 0, None
-    for _ in range(maxiter_bisection):
-        mid = 0.5 * (a + b)
-        fm = func(mid)
-        iters += 1
-        if fm == 0.0:
-            out = mid
-            break
-        if (fm < 0) == (fa < 0):
-            a, fa = mid, fm
-        else:
-            b = mid
-        if b - a <= atol:
-            break
+    if bracket_form == BRACKET_ROOTS:
+        cap = maxiter_bisection if caps == CAPS_AS_WRITTEN else 4096
+        while iters < cap:
+            mid = roots_middle(a, b)
+            if not (a < mid < b):          # the ends are adjacent floats: nothing between them
+                break
+            fm = func(mid)
+            iters += 1
+            if fm == 0.0:
+                out = mid
+                break
+            if _sign(fa) * _sign(fm) < 0:
+                b, fb = mid, fm
+            else:
+                a, fa = mid, fm
+        if out is None:
+            out = a if abs(fa) < abs(fb) else b  # the end with the smaller residual
+    else:
+        for _ in range(maxiter_bisection if caps == CAPS_AS_WRITTEN else 4096):
+            mid = 0.5 * (a + b)
+            fm = func(mid)
+            iters += 1
+            if fm == 0.0:
+                out = mid
+                break
+            if (fm < 0) == (fa < 0):
+                a, fa = mid, fm
+            else:
+                b = mid
+            if b - a <= atol:
+                break
     if trace is not None:
         trace.append(evals | DEC_BISECT | ((iters & 0xff) << DEC_ITERS_SHIFT))
     return 0.5 * (a + b) if out is None else out
@@ -364,7 +482,8 @@ def inverse_cdf(cdf, u, initial_guess, max_guess, atol=1e-4, maxiter_newton=10,
 
 def sample_from_cf(u, it: HestonCFIterator, n=5, cf_tol=1e-3, atol=1e-4, moment_h=1e-2,
                    maxiter_newton=10, maxiter_bisection=100, stats=None, counter=None,
-                   sequential=False, trace=None):
+                   sequential=False, trace=None, root_form=ROOT_SECANT, bracket_form=BRACKET_MIDPOINT,
+                   caps=CAPS_AS_WRITTEN, xs=None, setup=None):
     """sample_from_cf.jl:27-41 (the uniform u is supplied by the caller)."""
     mean, variance = moments_from_cf(it, moment_h)
     s2 = max(variance, 1e-12)
@@ -376,8 +495,10 @@ def sample_from_cf(u, it: HestonCFIterator, n=5, cf_tol=1e-3, atol=1e-4, moment_
         cdf = lambda x: _cdf_seq(it, x, h, cf_tol, counter)
     else:
         cdf = lambda x: cdf_from_cf(it, x, h, cf_tol, counter=counter)
+    if setup is not None:  # what the search starts from (the iterate probe exports it)
+        setup.update(initial_guess=initial_guess, max_guess=max_guess, h=h)
     return inverse_cdf(cdf, u, initial_guess, max_guess, atol, maxiter_newton, maxiter_bisection,
-                       stats, trace)
+                       stats, trace, root_form, bracket_form, caps, xs)
 
 
 def sample_log_S_T(V_T, integral_V, Z, d):

@@ -167,13 +167,13 @@ def test_cabi_header_and_library_agree():
     lib = hh.load_library()
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.hh_abi_version() == 5
+    assert lib.hh_abi_version() == 6
     assert lib.hh_replay_elems(257, 3, 1) == 2 * 3 * 2 * 256
     assert lib.hh_replay_elems(256, 5, 0) == 5 * 256
     # struct layouts seen by ctypes == what the compiler laid out (sizes are part of the ABI)
     assert C.sizeof(_ffi.hh_model) == 11 * 8 + 8 * 8
     assert C.sizeof(_ffi.hh_result) == 4 * 8 + 8 * 8 + 5 * 8 + 2 * 8
-    assert C.sizeof(_ffi.hh_config) == 10 * 4 + 2 * 4 + 2 * 8 + 2 * 8 + 4 * 8 + 2 * 4 + 2 * 8
+    assert C.sizeof(_ffi.hh_config) == 10 * 4 + 2 * 4 + 2 * 8 + 2 * 8 + 4 * 8 + 2 * 4 + 4 * 4 + 2 * 8
 
 
 def test_marginal_law_is_the_reference_formula_quirk_included():

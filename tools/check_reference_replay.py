@@ -11,8 +11,11 @@ case misses its bar.  Bars: terminal samples 1e-10 relative per trajectory (fp64
 different order of fused operations), price 1e-10, AD Greeks 1e-8, Broadie–Kaya samples 1e-7 on 98 %
 of the trajectories (the |F(x) - u| <= 1e-4 stopping rule may flip on rounding), LSM stopping times
 identical on 99.8 %.  For the Euler cases both step forms are tried: the one that matches is
-StochasticDiffEq's EM() — this settles `em_split`.  Run on the reference's export this
-is the check that turns "parity unpinned" into "pinned"."""
+StochasticDiffEq's EM() — this settles `em_split`.  The `bk_root_probe` case (every abscissa the
+reference's inverse_cdf asked of its CDF) is held against the CPU restatement in every reading of Roots.jl's two
+find_zero calls and ends in `VERDICT bk_root_form = …, bk_bracket_form = …, bk_caps = …` — the values to put into
+hh_config (and to make the defaults, if they are not).  Run on the reference's export this is the check that turns
+"parity unpinned" into "pinned"."""
 import ctypes as C
 import json
 import os
@@ -21,8 +24,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np  # noqa: E402
 
-import hedgehog_jl_amd as hh  # noqa: E402
-from hedgehog_jl_amd import _ffi  # noqa: E402
+from hedgehog_jl_amd import _ffi  # noqa: E402  (struct builders only; the GPU context is made in main())
 
 
 def _f8(base, name):
@@ -131,7 +133,116 @@ def check_lsm(ctx, base, cs):
     return ok, {"same_stopping_time": f"{same.mean():.5f}", "max_rel_val": f"{e_v:.3e}", "price": f"{e_p:.3e}"}
 
 
-CHECKS = {"euler": check_euler, "exact_lognormal": check_exact, "bk": check_bk, "lsm": check_lsm}
+# ---- the iterate probe: which reading of Roots.jl's two find_zero calls the reference runs ---------------------------
+# (CPU only: the exported abscissae against the CPU restatement run in every reading; the kernels follow the
+# restatement per trajectory in each — tests/test_gpu_bk_root_forms.py)
+ROOT_VERDICT = {}
+
+
+def _first_seen(xs):
+    """a request sequence without re-evaluations: the reference asks for func(sol), func(0), func(max_guess) a second
+    time (its own acceptance test; find_zero's bracket set-up) — an abscissa counts where it is FIRST asked for"""
+    seen, out = set(), []
+    for x in xs:
+        if x not in seen:
+            seen.add(x)
+            out.append(x)
+    return out
+
+
+def _split_search_ladder(xs, max_guess):
+    """(abscissae of the first search, abscissae of the bisection behind the ladder's two end points) — the ladder
+    starts where 0.0 is asked for (no iterate of a search from a positive guess is exactly 0.0)"""
+    xs = _first_seen(xs)
+    if 0.0 not in xs:
+        return xs, None
+    k = xs.index(0.0)
+    return xs[:k], [x for x in xs[k + 1:] if x != max_guess]
+
+
+def _same_sequence(a, b, rtol=1e-7):
+    return len(a) == len(b) and all(abs(x - y) <= rtol * max(abs(x), abs(y), 1e-3) for x, y in zip(a, b))
+
+
+def root_probe_readings(base, cs):
+    """-> {"search": {(root_form, caps): trajectories reproduced}, "ladder": {(bracket_form, caps): …}, "n_search": …,
+    "n_ladder": …} for a `bk_root_probe` case"""
+    from oracle import bk_oracle as B
+    n = cs["n"]
+    VT, U = _f8(base, cs["VT"]), _f8(base, cs["u"])
+    GM = _f8(base, cs["max_guess"])
+    counts = np.fromfile(os.path.join(base, cs["counts"]), dtype="<i4")
+    xs_all = _f8(base, cs["xs"])
+    assert VT.size == n and U.size == n and counts.size == n and xs_all.size == int(counts.sum())
+    off = np.concatenate([[0], np.cumsum(counts)])
+    mj = cs["model"]
+    dist = B.LogHestonDistribution(mj["S0"], mj["V0"], mj["kappa"], mj["theta"], mj["sigma"], mj["rho"], mj["r"], mj["T"])
+    search = {(rf, cp): 0 for rf in (0, 1) for cp in (0, 1)}
+    ladder = {(bf, cp): 0 for bf in (0, 1) for cp in (0, 1)}
+    n_ladder = 0
+    for i in range(n):
+        ref_s, ref_l = _split_search_ladder([float(x) for x in xs_all[off[i]:off[i + 1]]], float(GM[i]))
+        n_ladder += ref_l is not None
+        it = B.HestonCFIterator(float(VT[i]), dist)
+        got = {}
+        for rf in (0, 1):
+            for bf in (0, 1):
+                for cp in (0, 1):
+                    xs = []
+                    B.sample_from_cf(float(U[i]), it, root_form=rf, bracket_form=bf, caps=cp, xs=xs)
+                    got[(rf, bf, cp)] = _split_search_ladder(xs, float(GM[i]))
+        for (rf, cp) in search:
+            search[(rf, cp)] += _same_sequence(got[(rf, 0, cp)][0], ref_s)
+        if ref_l is not None:
+            for (bf, cp) in ladder:  # (the ladder is reached after the first search: read it under every first reading)
+                ladder[(bf, cp)] += any(g[1] is not None and _same_sequence(g[1], ref_l)
+                                        for g in (got[(rf, bf, cp)] for rf in (0, 1)))
+    return {"search": search, "ladder": ladder, "n_search": n, "n_ladder": n_ladder}
+
+
+def _name_reading(scores, total, names, share=0.9):
+    """the reading(s) that reproduce at least `share` of the trajectories; a fork whose two readings reproduce the same
+    ones was not exercised by the sample"""
+    best = max(scores.values())
+    if total == 0 or best < share * total:
+        return None, best
+    return sorted(k for k, v in scores.items() if v == best), best
+
+
+def check_root_probe(ctx, base, cs):
+    r = root_probe_readings(base, cs)
+    hit_s, best_s = _name_reading(r["search"], r["n_search"], None)
+    hit_l, best_l = _name_reading(r["ladder"], r["n_ladder"], None)
+    ROOT_VERDICT[cs["name"]] = (r, hit_s, hit_l)
+    ok = hit_s is not None and (r["n_ladder"] == 0 or hit_l is not None)
+    return ok, {"search": ",".join(f"root{rf}/caps{cp}:{v}" for (rf, cp), v in sorted(r["search"].items())) + f"/{r['n_search']}",
+                "ladder": ",".join(f"bracket{bf}/caps{cp}:{v}" for (bf, cp), v in sorted(r["ladder"].items())) + f"/{r['n_ladder']}"}
+
+
+def root_verdict_line(name):
+    r, hit_s, hit_l = ROOT_VERDICT[name]
+    ROOT = {0: "0 (secant)", 1: "1 (Roots' Order2: Steffensen guarded by secant)"}
+    BRK = {0: "0 (arithmetic midpoint to atol)", 1: "1 (Roots' Bisection over bit patterns, to the last bit)"}
+    CAP = {0: "0 (maxeval honoured)", 1: "1 (maxeval ignored)"}
+
+    def say(hit, table, what):
+        if hit is None:
+            return f"{what} undecided (no reading reproduces 90 % of the trajectories)", "?"
+        forms = sorted({k[0] for k in hit})
+        caps = sorted({k[1] for k in hit})
+        f = table[forms[0]] if len(forms) == 1 else "either (the sample does not tell them apart)"
+        c = CAP[caps[0]] if len(caps) == 1 else "either (no trajectory of the sample reaches a cap)"
+        return f"{what} = {f}", c
+    a, ca = say(hit_s, ROOT, "bk_root_form")
+    b, cb = (f"bk_bracket_form: no trajectory of the sample reached the ladder", "?") if r["n_ladder"] == 0 else \
+        say(hit_l, BRK, "bk_bracket_form")
+    caps = ca if ca == cb or cb == "?" else (cb if ca.startswith("either") else ca if cb.startswith("either")
+                                            else f"first search {ca}, bisection {cb}")
+    return f"VERDICT {a}, {b}, bk_caps = {caps} ({name}: {r['n_search']} trajectories, {r['n_ladder']} through the ladder)"
+
+
+CHECKS = {"euler": check_euler, "exact_lognormal": check_exact, "bk": check_bk, "lsm": check_lsm,
+          "bk_root_probe": check_root_probe}
 
 
 def main(path):
@@ -141,7 +252,11 @@ def main(path):
         man = {"cases": [dict(man, name="heston_euler", kind="euler", dynamics="heston",
                               model={k: man[k] for k in ("S0", "strike", "r", "V0", "kappa", "theta",
                                                          "sigma", "rho", "T", "cp")})]}
-    ctx = hh.get_context(0)
+    need_gpu = any(cs["kind"] != "bk_root_probe" for cs in man["cases"])
+    ctx = None
+    if need_gpu:  # (a manifest that holds only iterate probes is checked on the CPU)
+        import hedgehog_jl_amd as hh
+        ctx = hh.get_context(0)
     bad = 0
     for cs in man["cases"]:
         ok, info = CHECKS[cs["kind"]](ctx, base, cs)
@@ -157,6 +272,8 @@ def main(path):
         else:
             print(f"VERDICT em_split undecided on {name} ({errs})")
         break
+    for name in ROOT_VERDICT:
+        print(root_verdict_line(name))
     return bad
 
 
