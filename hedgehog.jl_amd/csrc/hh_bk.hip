@@ -75,6 +75,12 @@ constexpr double kInvPi = 0.31830988618379067154, kTwoOverPi = 0.636619772367581
 #ifndef HH_BK_NO_LADDER
 #define HH_BK_NO_LADDER 0
 #endif
+#ifndef HH_BK_LADDER_PER_WAVE
+#define HH_BK_LADDER_PER_WAVE 0
+#endif
+#ifndef HH_BK_LADDER_BATCH
+#define HH_BK_LADDER_BATCH 8
+#endif
 // Columns of cached series terms.  A lane's column belongs to a workgroup SLOT that a workgroup of the
 // CF kernel (or of the ladder kernel behind it) takes when it starts and gives back when it is done —
 // not to the trajectory: the cache is kSlots x 256 columns however many trajectories the chain has
@@ -856,6 +862,14 @@ __device__ __forceinline__ double cdf_cached(const Terms& t, const double* col, 
 // kept across the ladder, the CF kernel took 128 registers instead of 95 — four waves per SIMD instead of five).
 // thread of the r-th failed trajectory of the tile (r below their number)
 __device__ __forceinline__ uint32_t nth_failed(const LadderShared& sh, uint32_t r) {
+#if HH_BK_LADDER_PER_WAVE  // an A/B build: every wave walks the ladders of its OWN failed lanes, no barrier in front
+  {
+    const uint32_t wv = threadIdx.x >> 6;
+    unsigned long long mw = sh.fail[wv];
+    for (uint32_t i = 0; i < r; ++i) mw &= mw - 1ull;
+    return wv * 64u + (uint32_t)__ffsll((long long)mw) - 1u;
+  }
+#endif
   uint32_t w = 0;
 #pragma unroll
   for (uint32_t i = 0; i + 1 < (uint32_t)(kTile / 64); ++i) {
@@ -1047,7 +1061,30 @@ __device__ __forceinline__ void invert_phase(const BkArgs& p, const double* coef
   }
   const unsigned long long m_fail = __ballot(failed);
   if ((tid & 63u) == 0u) sh.fail[tid >> 6] = m_fail;
+#if HH_BK_LADDER_PER_WAVE
+  if (m_fail != 0ull) {  // (wave-uniform)
+    lds_fence();
+    const uint32_t n_w = (uint32_t)__popcll(m_fail);
+    for (uint32_t b0 = 0; b0 < n_w; b0 += 8u) wave_ladder(p, coef, col, sh, b0, n_w - b0 < 8u ? n_w - b0 : 8u);
+    lds_fence();
+    if (failed) {
+      const uint32_t res = sh.res[tid], iters = res & 0x7fffffffu;
+      acc[2] = 1.0;
+      acc[5] += (double)sh.j_stop[tid] * (double)(1u + (sh.max_guess[tid] < 0.0 ? 0u : 1u) + iters);
+      if (res >> 31) {
+        acc[4] = 1.0;
+        dec |= kDecMaxGuess;
+      } else {
+        acc[3] = 1.0;
+        dec |= kDecBisect | ((iters & 0xffu) << kDecItersShift);
+      }
+      finish(sh.iv[tid]);
+    }
+  }
+  if (false) {
+#else
   if (__syncthreads_or(failed)) {  // (uniform) nearly every tile
+#endif
     [[maybe_unused]] uint32_t n_fail = 0;
 #pragma unroll
     for (int w = 0; w < kTile / 64; ++w) n_fail += (uint32_t)__popcll(sh.fail[w]);
@@ -1059,8 +1096,9 @@ __device__ __forceinline__ void invert_phase(const BkArgs& p, const double* coef
       sh.res[tid] = 0u;
     }
 #else
-    for (uint32_t b0 = (tid >> 6) * 8u; b0 < n_fail; b0 += (uint32_t)(kTile / 64) * 8u)  // (wave-uniform) batch b to wave b mod 4
-      wave_ladder(p, coef, col, sh, b0, n_fail - b0 < 8u ? n_fail - b0 : 8u);
+    constexpr uint32_t kBatch = HH_BK_LADDER_BATCH;  // failed trajectories a wave walks at once (8: groups of 8 lanes)
+    for (uint32_t b0 = (tid >> 6) * kBatch; b0 < n_fail; b0 += (uint32_t)(kTile / 64) * kBatch)  // (wave-uniform) batch b to wave b mod 4
+      wave_ladder(p, coef, col, sh, b0, n_fail - b0 < kBatch ? n_fail - b0 : kBatch);
 #endif
     __syncthreads();
     if (failed) {

@@ -293,6 +293,21 @@ template <class Args>
 __device__ __forceinline__ bool reduces_records(uint32_t tile, const Args& a) {
   return tile == a.reducer_tile;
 }
+// The context's give-up word (finish_records says what it is for) by a SCALAR load: issued when the reducer starts,
+// waited for where the sums are written.  The word lies on a line nobody else touches — a trip to HBM — and vector
+// loads return in order: asked for in front of the record loads it held them all up (+1.7 µs per solve), asked for
+// at the kernel's start it cost the REPLAY kernel 1.2 % (profiles/r06_e_headline_ab_vs_round5.txt, r06_g_*).  The
+// scalar unit has its own queue and counter.  The scalar cache is invalidated when a kernel starts, and a give-up this
+// launch must know of happened in a launch before it on the stream: the value cannot be stale.
+__device__ __forceinline__ unsigned int scalar_load_begin(const unsigned int* p) {
+  unsigned int v;
+  asm volatile("s_load_dword %0, %1, 0x0" : "=s"(v) : "s"(p) : "memory");
+  return v;  // NOT valid before scalar_load_end()
+}
+__device__ __forceinline__ unsigned int scalar_load_end(unsigned int v) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(v) : : "memory");
+  return v;
+}
 
 __device__ __forceinline__ void store_through(double* p, double v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // global_store_dwordx2 … sc1
@@ -353,11 +368,18 @@ using u32x4 = __attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigne
 
 // true while the caller should read again; after the spin bound: *gave_up is set and the wait is over
 __device__ __forceinline__ bool keep_waiting(unsigned long long& t0, bool& give, unsigned int* gave_up,
-                                             unsigned long long spin_ticks) {
+                                             unsigned long long spin_ticks, const unsigned int* state) {
   const unsigned long long now = wall_clock64();
   if (t0 == 0) t0 = now;
   if (now - t0 >= spin_ticks) {  // a record that never comes: NaN sums, and say so
     *gave_up = 1u;
+    give = true;
+    return false;
+  }
+  // a wait that has lasted 20 µs (the last record of a healthy launch is 7 µs away at most): is this a buffer to wait
+  // on at all?  (Not asked at the first miss: the word is a trip to HBM, and the next look at the records would queue
+  // behind it — +1.5 µs on every REPLAY solve, profiles/r06_h_headline_ab_vs_round5.txt)
+  if (now - t0 > 2000ull && __hip_atomic_load(state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
     give = true;
     return false;
   }
@@ -368,11 +390,10 @@ __device__ __forceinline__ bool keep_waiting(unsigned long long& t0, bool& give,
 // slots 0 and 1 of every record -> sm[vt], sm[256 + vt]
 template <int NT>
 __device__ __forceinline__ void partial_pairs(const double* rec, uint32_t n, double* __restrict__ sm,
-                                              unsigned int* gave_up, unsigned long long spin_ticks, bool dirty) {
+                                              unsigned int* gave_up, unsigned long long spin_ticks, const unsigned int* state) {
   static_assert(256 % NT == 0, "the 256 virtual threads are dealt evenly");
   const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(rec), 0, (int)(n * (uint32_t)(kRecStride * 8)), 0x00020000);
-  bool give = *gave_up != 0u;  // set in an earlier pass: do not wait again (`dirty`: by an earlier launch — asked for
-                               // last, behind the record loads it was issued in front of)
+  bool give = *gave_up != 0u;  // set in an earlier pass: do not wait again
   for (int vt = threadIdx.x; vt < 256; vt += NT) {
     double t0 = 0.0, t1 = 0.0;
     for (uint32_t b = vt; b < n; b += 256 * kFinishBatch) {
@@ -389,7 +410,7 @@ __device__ __forceinline__ void partial_pairs(const double* rec, uint32_t n, dou
           const unsigned long long hi = ((unsigned long long)v[u][3] << 32) | v[u][2];
           there = there && lo != kPoison && hi != kPoison;
         }
-        if (there || give || dirty || !keep_waiting(since, give, gave_up, spin_ticks)) break;
+        if (there || give || !keep_waiting(since, give, gave_up, spin_ticks, state)) break;
       }
 #pragma unroll
       for (int u = 0; u < kFinishBatch; ++u) {
@@ -406,7 +427,7 @@ __device__ __forceinline__ void partial_pairs(const double* rec, uint32_t n, dou
 template <int NT, int NS, class SlotOf>
 __device__ __forceinline__ void partial_slots(const double* __restrict__ rec, uint32_t n, SlotOf slot_of,
                                               double* __restrict__ sm, unsigned int* gave_up, unsigned long long spin_ticks,
-                                              bool dirty) {
+                                              const unsigned int* state) {
   constexpr int kB = NS <= 2 ? kFinishBatch : 8;
   bool give = *gave_up != 0u;
   for (int vt = threadIdx.x; vt < 256; vt += NT) {
@@ -427,7 +448,7 @@ __device__ __forceinline__ void partial_slots(const double* __restrict__ rec, ui
             there = there && !is_poison(v[q][u]);
           }
         }
-        if (there || give || dirty || !keep_waiting(since, give, gave_up, spin_ticks)) break;
+        if (there || give || !keep_waiting(since, give, gave_up, spin_ticks, state)) break;
       }
 #pragma unroll
       for (int q = 0; q < NS; ++q)
@@ -454,10 +475,9 @@ __device__ __forceinline__ void finish_records(const Args& a) {
 #if HH_FINISH_STAMPS  // a diagnostic build (tools/finish_stamps.py): where the tail's time goes, in accum[11..15]
   const unsigned long long st0 = wall_clock64();
 #endif
-  // (a give-up of an earlier launch the host has not dealt with yet: this buffer cannot be trusted, wait for nothing.
-  // Every thread asks for the word itself, in FRONT of its record loads and needing it only behind them: loads come
-  // back in order, so the question costs the tail no round trip of its own)
-  const bool dirty = __hip_atomic_load(a.finish_state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+  // (a give-up of an earlier launch the host has not dealt with yet: this buffer cannot be trusted — the sums are NaN
+  // whatever it holds, and a wait for a record that looks missing ends at once: keep_waiting asks too)
+  const unsigned int state_in_flight = scalar_load_begin(a.finish_state);
   if (threadIdx.x == 0) gave_up = 0u;
   __syncthreads();
   const bool itm = map->n > 0;  // some direction has a passive part: the two in-the-money sums are live
@@ -467,8 +487,8 @@ __device__ __forceinline__ void finish_records(const Args& a) {
   const double poison = __longlong_as_double((long long)kPoison);
   const auto wsrc = __builtin_amdgcn_make_buffer_rsrc(records, 0, (int)(n_rec * (uint32_t)(kRecStride * 8)), 0x00020000);
   const unsigned int ph = (unsigned int)(kPoison >> 32), pl = (unsigned int)kPoison;
-  partial_pairs<NT>(records, n_rec, sm, &gave_up, spin_ticks, dirty);
-  if (itm) partial_slots<NT, 2>(records, n_rec, [](int q) { return kRecItmS + q; }, sm + 512, &gave_up, spin_ticks, dirty);
+  partial_pairs<NT>(records, n_rec, sm, &gave_up, spin_ticks, a.finish_state);
+  if (itm) partial_slots<NT, 2>(records, n_rec, [](int q) { return kRecItmS + q; }, sm + 512, &gave_up, spin_ticks, a.finish_state);
   for (uint32_t i = threadIdx.x; i < n_rec; i += NT) {
     __builtin_amdgcn_raw_buffer_store_b128(u32x4{pl, ph, pl, ph}, wsrc, (int)(i * (uint32_t)(kRecStride * 8)), 0, 16);  // Σp, Σp²: sc1
     if (itm) {
@@ -491,7 +511,7 @@ __device__ __forceinline__ void finish_records(const Args& a) {
   }
   if constexpr (P > 0) {  // the carried derivative sums
     __syncthreads();
-    partial_slots<NT, P>(records, n_rec, [](int q) { return HH_ACC_DSUM + q; }, sm, &gave_up, spin_ticks, dirty);
+    partial_slots<NT, P>(records, n_rec, [](int q) { return HH_ACC_DSUM + q; }, sm, &gave_up, spin_ticks, a.finish_state);
     for (uint32_t i = threadIdx.x; i < n_rec; i += NT) {
 #pragma unroll
       for (int j = 0; j < P; ++j) store_through(records + (size_t)i * kRecStride + HH_ACC_DSUM + j, poison);
@@ -523,6 +543,7 @@ __device__ __forceinline__ void finish_records(const Args& a) {
     if (slot == 12) out = (double)st1;               // thread `slot` has all its records
     if (slot == 13) out = (double)wall_clock64();    // sums done
 #endif
+    const bool dirty = scalar_load_end(state_in_flight) != 0u;
     accum[slot] = (gave_up || dirty) ? __longlong_as_double(0x7FF8000000000000ll) : out;
     if (slot == 0 && gave_up) __hip_atomic_store(a.finish_state, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }

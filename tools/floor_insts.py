@@ -182,7 +182,11 @@ def main():
     setup_re = sum(CHF_ZERO.values()) + bessel_re + sum(LOG_I_KAPPA.values()) + bessel_re
     # J series terms + the moment evaluation at a = h_m (complex) | phi(0) and log I(nu_kappa) (real axis) | the root
     # search | the draws | load / premultiply the register terms, finish (log S_T, exp, payoff)
-    bk_path = (J + 1) * cf_eval + setup_re + evals * (CDF_FIXED + J * CDF_PER_CACHED_TERM) + sum(DRAWS.values()) + 60
+    # … and the bisection ladder of the 2.2 % of trajectories whose secant fails (BENCH: 22 197 of 10^6): its two end
+    # points and ~13 midpoints, as the SEQUENTIAL loop evaluates them (what the wave-walk of the tree spends beyond
+    # that — the nodes of the branches not taken — is the implementation's, not the algorithm's)
+    ladder = 0.0222 * 15.0 * (CDF_FIXED + J * CDF_PER_CACHED_TERM)
+    bk_path = (J + 1) * cf_eval + setup_re + evals * (CDF_FIXED + J * CDF_PER_CACHED_TERM) + ladder + sum(DRAWS.values()) + 60
     bk_path_r4 = (J + 2) * cf_eval + evals * J * 7 + sum(DRAWS.values()) + 60  # the algorithm as round 4 shipped it
     lsm = sum(LSM_INDUCTION.values()) + sum(GBM_GRID.values())
     exact = (sum(NORMAL_PAIR.values()) / 2 + 3 + sum(FM_EXP.values()) + 12) / 1.0  # one normal, mu + sd z, exp, payoff; per path
@@ -207,7 +211,7 @@ def main():
                                                "bessel_terms_mean": N, "lane_insts": cf_eval},
                          "cf_evaluations_per_path": J + 1, "real_axis_setup": setup_re,
                          "series_length_mean": J, "bessel_order": nu,
-                         "cdf_evaluations_on_cached_terms": evals, "per_cdf_evaluation_fixed": CDF_FIXED,
+                         "cdf_evaluations_on_cached_terms": evals, "ladder_lane_insts_mean": ladder, "per_cdf_evaluation_fixed": CDF_FIXED,
                          "per_cached_term": CDF_PER_CACHED_TERM,
                          "round4_algorithm_lane_insts": bk_path_r4,
                          "draws": sum(DRAWS.values()),

@@ -31,14 +31,14 @@ rows = {
                                      "path-step of the PASS (two models stepped on it)"),
     "heston_euler_replay_multi2": (mean_of(lambda n: "euler_multi_kernel<hh::HestonModel<0, true>, true, false, 2" in n) / (N * M),
                                    "path-step of the PASS (two models stepped on it)"),
-    "lognormal_exact": (mean_of(lambda n: "exact_gbm_kernel<0, false, false, 1>" in n) / N, "path (one pair per lane: 10^6 paths)"),
+    "lognormal_exact": (mean_of(lambda n: "exact_gbm_kernel<0, false, false, 4>" in n) / N, "path (four pairs per lane: 10^6 paths)"),
     "lognormal_exact_1e8": (mean_of(lambda n: "exact_gbm_kernel<0, false, false, 64>" in n) / (100 * N), "path (64 pairs per lane: 10^8 paths)"),
-    "broadie_kaya": (mean_of(lambda n: "::bk_" in n) / N, "path (draw + cf (series, inversion) + scan + ladder + fall-back kernels)"),
+    "broadie_kaya": (mean_of(lambda n: "::bk_" in n) / N, "path (bk_cf_kernel: draws, series, inversion, ladder + bk_tail_kernel)"),
 }
-if len(sys.argv) > 3:  # the exact grid 2·10^5 x 12: EVERY kernel of the chain — draws, key / sort / gather / scatter, CF, scan, ladder, spots
+if len(sys.argv) > 3:  # the exact grid 2·10^5 x 12: EVERY kernel of the chain — draws + keys, the three counting-sort kernels, CF, tail, spots
     g = collections.defaultdict(list)
     for r in csv.DictReader(open(sys.argv[3])):
-        if r["Counter_Name"] == "SQ_INSTS_VALU" and "fill_rows" not in r["Kernel_Name"]:
+        if r["Counter_Name"] == "SQ_INSTS_VALU" and "fill_rows" not in r["Kernel_Name"] and "bk_tables" not in r["Kernel_Name"]:
             g[r["Kernel_Name"]].append(float(r["Counter_Value"]))
     total = sum(sum(v) / len(v) for v in g.values())
     rows["heston_exact_grid"] = (total / (200_000 * 12),
