@@ -948,7 +948,7 @@ def main():
                 "paths_per_s": n_paths / (t4 * 1e-3), "solve_ms": t4, "kernel_ms": t4, "price": r4.price,
                 "std_error": r4.std_error, "cf_terms_per_path": r4.bk_cf_terms / n_paths,
                 "bisect_fallbacks": int(r4.bk_bisect_fallback),
-                "roofline": valu_roofline("bk_cf_kernel (draws, series, inversion) + bk_scan_kernel + bk_ladder_kernel + bk_fallback_kernel + reduce_records_kernel",
+                "roofline": valu_roofline("bk_cf_kernel (draws, series, inversion, the ladder walked by one wave per tile) + bk_tail_kernel (long series: none; the record sums)",
                                           "broadie_kaya", float(n_paths), t4, vt)},
             "config4_broadie_kaya_1e7": {
                 "paths": n4b, "paths_per_s": n4b / (t4b * 1e-3), "solve_ms": t4b, "price": r4b.price,
@@ -1064,7 +1064,7 @@ def main():
             "heston_exact_grid_2e5_paths_x_12_dates": {
                 "kernel_ms": t_grid, "transitions_per_s": n_g * st_g / (t_grid * 1e-3),
                 "cf_terms_per_transition": r_g.bk_cf_terms / (n_g * st_g),
-                "roofline": valu_roofline("bk_draw_grid_kernel + radix sort of the pairs + ONE bk chain over all (date, trajectory) pairs, read through the order + bk_grid_spots_kernel",
+                "roofline": valu_roofline("bk_draw_grid_kernel + counting sort of the pairs by one 8-bit key (three kernels) + ONE bk chain over all (date, trajectory) pairs, read through the order + bk_grid_spots_kernel",
                                           "heston_exact_grid", float(n_g) * st_g, t_grid, vt)},
         }
 

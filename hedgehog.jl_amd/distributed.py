@@ -105,7 +105,12 @@ def solve_sharded(prob, method: MonteCarlo, group=None, accumulate=None,
     lib = _ffi.load_library()
     rc = lib.hh_mc_finalize(C.byref(model), C.byref(c), acc_host.ctypes.data, C.byref(res))
     if rc != 0:
-        raise _ffi.HedgehogMCError(rc, "hh_mc_finalize failed")
+        # NaN sums: a record reduction inside SOME rank's kernel gave up (the all-reduce spread its NaN).  The rank
+        # it happened on gets the named status from its own context; every rank raises.
+        if accumulate is None:
+            _ffi.get_context(rank_device(method.device, group, device)).check_last()
+        raise _ffi.HedgehogMCError(rc, "hh_mc_finalize failed: the summed accumulator holds no trajectories "
+                                       "(another rank's solve lost its sums?)")
     del keep, seeds
     return MonteCarloSolution(prob, method, _price_from(res, discount, P), None,
                               std_error=res.std_error, result=res)

@@ -354,6 +354,9 @@ function solve_sharded_hip(prob::PricingProblem{VanillaOption{TS,TE,European,C,S
             rc = ccall((:hh_memcpy_d2h, LIB[]), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Csize_t),
                        ctx.handle, pointer(acc), dev_acc[], 8 * HH_ACC_LEN)
             rc == 0 || error("hh_memcpy_d2h failed ($rc): $(last_error(ctx))")
+            # the sums were left on the device by an asynchronous call: did a record reduction inside the kernel give up?
+            rc = ccall((:hh_ctx_check_last, LIB[]), Cint, (Ptr{Cvoid},), ctx.handle)
+            rc == 0 || error("hh_mc_accumulate lost its sums ($rc): $(last_error(ctx))")
             ccall((:hh_device_free, LIB[]), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), ctx.handle, dev_acc[])
         end
         allreduce!(acc)                                        # SUM over the ranks, in place
