@@ -81,6 +81,7 @@ constexpr double kInvPi = 0.31830988618379067154, kTwoOverPi = 0.636619772367581
 #ifndef HH_BK_LADDER_BATCH
 #define HH_BK_LADDER_BATCH 8
 #endif
+
 // Columns of cached series terms.  A lane's column belongs to a workgroup SLOT that a workgroup of the
 // CF kernel (or of the ladder kernel behind it) takes when it starts and gives back when it is done —
 // not to the trajectory: the cache is kSlots x 256 columns however many trajectories the chain has
@@ -853,9 +854,11 @@ __device__ __forceinline__ double cdf_cached(const Terms& t, const double* col, 
 // turns for a lone trajectory, 5 in a group of eight — each one CDF evaluation long, for the whole batch.  Same
 // abscissae, same CDF values, same decisions: the same ∫V, decision word and counters as the sequential loop, bit for
 // bit (HH_BK_SERIAL_LADDER builds that loop; tests/test_gpu_bk_forms.py holds the two against each other).
-// (First built wave by wave — each wave its own failed lanes, 1.4 on average: the ladder then cost as many
-// instructions as the four kernels it replaced cost time, 0.348 ms before and after, profiles/r06_a_*.  Per tile
-// it is a third of that.)
+// (What it costs: ~20 µs of the 0.32 ms at 10^6 trajectories, however it is organised — one wave per tile in batches
+// of 8, 4 or 2 (HH_BK_LADDER_BATCH), every wave its own lanes with no barrier in front (HH_BK_LADDER_PER_WAVE), the
+// walking wave at raised priority: all within 1 % of each other, profiles/r06_g_bk_ab_ladder_forms.txt, r06_k_*.
+// Half of it is the instructions — a turn is one CDF evaluation, ~250 of a tile's 39 000 wave-instructions — the rest
+// the three waves that wait.  The four small kernels this replaced cost 37 µs + their boundaries.)
 //
 // What a failed lane hands over and gets back lies in LDS (by thread), and so do a group's sixteen weighted terms
 // (a broadcast read per term instead of sixteen registers per lane: with them in registers, and a lane's own state
