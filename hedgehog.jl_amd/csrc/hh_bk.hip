@@ -72,15 +72,6 @@ constexpr double kInvPi = 0.31830988618379067154, kTwoOverPi = 0.636619772367581
 #ifndef HH_BK_SERIAL_LADDER
 #define HH_BK_SERIAL_LADDER 0
 #endif
-#ifndef HH_BK_NO_LADDER
-#define HH_BK_NO_LADDER 0
-#endif
-#ifndef HH_BK_LADDER_PER_WAVE
-#define HH_BK_LADDER_PER_WAVE 0
-#endif
-#ifndef HH_BK_LADDER_BATCH
-#define HH_BK_LADDER_BATCH 8
-#endif
 
 // Columns of cached series terms.  A lane's column belongs to a workgroup SLOT that a workgroup of the
 // CF kernel (or of the ladder kernel behind it) takes when it starts and gives back when it is done —
@@ -855,7 +846,7 @@ __device__ __forceinline__ double cdf_cached(const Terms& t, const double* col, 
 // abscissae, same CDF values, same decisions: the same ∫V, decision word and counters as the sequential loop, bit for
 // bit (HH_BK_SERIAL_LADDER builds that loop; tests/test_gpu_bk_forms.py holds the two against each other).
 // (What it costs: ~20 µs of the 0.32 ms at 10^6 trajectories, however it is organised — one wave per tile in batches
-// of 8, 4 or 2 (HH_BK_LADDER_BATCH), every wave its own lanes with no barrier in front (HH_BK_LADDER_PER_WAVE), the
+// of 8, 4 or 2, every wave its own lanes with no barrier in front (tools/variants/bk_ladder_variants.inc), the
 // walking wave at raised priority: all within 1 % of each other, profiles/r06_g_bk_ab_ladder_forms.txt, r06_k_*.
 // Half of it is the instructions — a turn is one CDF evaluation, ~250 of a tile's 39 000 wave-instructions — the rest
 // the three waves that wait.  The four small kernels this replaced cost 37 µs + their boundaries.)
@@ -865,7 +856,7 @@ __device__ __forceinline__ double cdf_cached(const Terms& t, const double* col, 
 // kept across the ladder, the CF kernel took 128 registers instead of 95 — four waves per SIMD instead of five).
 // thread of the r-th failed trajectory of the tile (r below their number)
 __device__ __forceinline__ uint32_t nth_failed(const LadderShared& sh, uint32_t r) {
-#if HH_BK_LADDER_PER_WAVE  // an A/B build: every wave walks the ladders of its OWN failed lanes, no barrier in front
+#if defined(HH_BK_LADDER_VARIANTS) && HH_BK_LADDER_PER_WAVE  // every wave its OWN failed lanes (bk_ladder_variants.inc)
   {
     const uint32_t wv = threadIdx.x >> 6;
     unsigned long long mw = sh.fail[wv];
@@ -1064,62 +1055,39 @@ __device__ __forceinline__ void invert_phase(const BkArgs& p, const double* coef
   }
   const unsigned long long m_fail = __ballot(failed);
   if ((tid & 63u) == 0u) sh.fail[tid >> 6] = m_fail;
-#if HH_BK_LADDER_PER_WAVE
-  if (m_fail != 0ull) {  // (wave-uniform)
-    lds_fence();
-    const uint32_t n_w = (uint32_t)__popcll(m_fail);
-    for (uint32_t b0 = 0; b0 < n_w; b0 += 8u) wave_ladder(p, coef, col, sh, b0, n_w - b0 < 8u ? n_w - b0 : 8u);
-    lds_fence();
-    if (failed) {
-      const uint32_t res = sh.res[tid], iters = res & 0x7fffffffu;
-      acc[2] = 1.0;
-      acc[5] += (double)sh.j_stop[tid] * (double)(1u + (sh.max_guess[tid] < 0.0 ? 0u : 1u) + iters);
-      if (res >> 31) {
-        acc[4] = 1.0;
-        dec |= kDecMaxGuess;
-      } else {
-        acc[3] = 1.0;
-        dec |= kDecBisect | ((iters & 0xffu) << kDecItersShift);
-      }
-      finish(sh.iv[tid]);
+  // what a failed lane takes back from the ladder: its ∫V, its counters, the rest of its decision word
+  auto after_ladder = [&]() {
+    const uint32_t res = sh.res[tid], iters = res & 0x7fffffffu;
+    acc[2] = 1.0;
+    // the CDF evaluations the sequential ladder makes: its two end points (one below zero returns before it
+    // counts: cdf_cached) and its midpoints, j_stop terms each
+    acc[5] += (double)sh.j_stop[tid] * (double)(1u + (sh.max_guess[tid] < 0.0 ? 0u : 1u) + iters);
+    if (res >> 31) {
+      acc[4] = 1.0;
+      dec |= kDecMaxGuess;
+    } else {
+      acc[3] = 1.0;
+      dec |= kDecBisect | ((iters & 0xffu) << kDecItersShift);
     }
-  }
-  if (false) {
+    finish(sh.iv[tid]);
+  };
+#ifdef HH_BK_LADDER_VARIANTS  // A/B builds (tools/variants/bk_ladder_variants.inc): other organisations of the same walk
+#include "bk_ladder_variants.inc"
 #else
   if (__syncthreads_or(failed)) {  // (uniform) nearly every tile
-#endif
-    [[maybe_unused]] uint32_t n_fail = 0;
-#pragma unroll
-    for (int w = 0; w < kTile / 64; ++w) n_fail += (uint32_t)__popcll(sh.fail[w]);
 #if HH_BK_SERIAL_LADDER
     if (failed) lane_ladder(p, coef, col, sh);
-#elif HH_BK_NO_LADDER  // a MEASUREMENT build (tools/bk_ab.py): what the kernel costs without the ladder — wrong samples
-    if (failed) {
-      sh.iv[tid] = sh.max_guess[tid];
-      sh.res[tid] = 0u;
-    }
 #else
-    constexpr uint32_t kBatch = HH_BK_LADDER_BATCH;  // failed trajectories a wave walks at once (8: groups of 8 lanes)
-    for (uint32_t b0 = (tid >> 6) * kBatch; b0 < n_fail; b0 += (uint32_t)(kTile / 64) * kBatch)  // (wave-uniform) batch b to wave b mod 4
-      wave_ladder(p, coef, col, sh, b0, n_fail - b0 < kBatch ? n_fail - b0 : kBatch);
+    uint32_t n_fail = 0;
+#pragma unroll
+    for (int w = 0; w < kTile / 64; ++w) n_fail += (uint32_t)__popcll(sh.fail[w]);
+    for (uint32_t b0 = (tid >> 6) * 8u; b0 < n_fail; b0 += (uint32_t)(kTile / 64) * 8u)  // (wave-uniform) batch b to wave b mod 4
+      wave_ladder(p, coef, col, sh, b0, n_fail - b0 < 8u ? n_fail - b0 : 8u);
 #endif
     __syncthreads();
-    if (failed) {
-      const uint32_t res = sh.res[tid], iters = res & 0x7fffffffu;
-      acc[2] = 1.0;
-      // the CDF evaluations the sequential ladder makes: its two end points (one below zero returns before it
-      // counts: cdf_cached) and its midpoints, j_stop terms each
-      acc[5] += (double)sh.j_stop[tid] * (double)(1u + (sh.max_guess[tid] < 0.0 ? 0u : 1u) + iters);
-      if (res >> 31) {
-        acc[4] = 1.0;
-        dec |= kDecMaxGuess;
-      } else {
-        acc[3] = 1.0;
-        dec |= kDecBisect | ((iters & 0xffu) << kDecItersShift);
-      }
-      finish(sh.iv[tid]);
-    }
+    if (failed) after_ladder();
   }
+#endif
   const unsigned long long m_long = __ballot(too_long);
   if ((tid & 63) == 0) p.long_mask[(size_t)tile * (kTile / 64) + (tid >> 6)] = m_long;
   bk_store_record(acc, p.records + (size_t)tile * kRecStride, p.counters, too_long ? 1.0 : 0.0);
