@@ -327,3 +327,49 @@ if given is not None:
         assert np.mean(rel > 1e-3) <= 0.05, (nu, np.sort(rel)[-8:])
         # the payoff is 1-Lipschitz in S_T: the prices cannot differ by more than the mean sample difference
         assert abs(res.price - ref["price"]) <= D * np.mean(np.abs(term - ref["terminal"])) * (1 + 1e-9) + 1e-9
+
+
+def test_bk_tail_kernel_beyond_its_first_turn_of_tiles():
+    """More than 64 x 256 tiles (4.2·10^6 trajectories), a term cache that a share of the series outgrows: a tail
+    workgroup then looks at its tiles in more than one turn of 256 (for_long_tiles), every tail workgroup has work, the
+    reducers wait for all of them — and a second model that shares the chain (a bumped spot: bk_refinish_kernel) rebuilds
+    those records in the same order.  Against the same ensemble with the default cache, where no series is too long:
+    the same decisions and samples up to where the series terms were rounded; and the shared chain against each model's
+    own solve, bit for bit."""
+    prm = PARAMS["h252"]
+    n = 256 * 16384 + 777
+    ctx = _ffi.Context(0)
+    try:
+        m = o.make_model(**prm)
+        c = o.make_config(_ffi.HH_HESTON, _ffi.HH_BROADIE_KAYA, n, seeds=[99])
+        c.bk_cf_tol = 2e-5  # series of ~20-30 terms
+        out = {}
+        for cache in (256, 24):
+            ctx.set_option(_ffi.HH_OPT_BK_TERM_CACHE, cache)
+            res = _ffi.hh_result()
+            term = np.zeros(n)
+            ctx.check(ctx.lib.hh_mc_solve(ctx.handle, C.byref(m), C.byref(c), C.byref(res), term.ctypes.data))
+            dec, ln = gpu_decisions(ctx, n)
+            out[cache] = (res, term, dec, ln)
+        (r1, t1, d1, l1), (r2, t2, d2, l2) = out[256], out[24]
+        long_ = (d2 >> 31).astype(bool)
+        assert (d1 >> 31).sum() == 0 and (long_ == (l2 > 24)).all()
+        assert 0.02 < long_.mean() < 0.98, long_.mean()  # some series fit, some do not: both kernels have work everywhere
+        tiles_with_long = np.unique(np.nonzero(long_)[0] // 256)
+        assert tiles_with_long.max() >= 64 * 256  # … beyond a tail workgroup's first turn
+        np.testing.assert_array_equal(l1, l2)
+        same = (d1 & 0x7fffffff) == (d2 & 0x7fffffff)
+        assert same.mean() > 0.999
+        np.testing.assert_allclose(t2[same], t1[same], rtol=1e-9)
+        assert r2.price == pytest.approx(r1.price, rel=1e-6)
+        # the shared chain with the small cache: records of the tail workgroups rebuilt by bk_refinish_kernel
+        models = [m, o.make_model(**dict(prm, S0=prm["S0"] * 1.001))]
+        res2 = (_ffi.hh_result * 2)()
+        ctx.check(ctx.lib.hh_mc_solve_multi(ctx.handle, (_ffi.hh_model * 2)(*models), 2, C.byref(c), res2, None))
+        for k in range(2):
+            own = _ffi.hh_result()
+            ctx.check(ctx.lib.hh_mc_solve(ctx.handle, C.byref(models[k]), C.byref(c), C.byref(own), None))
+            assert (res2[k].price, res2[k].sumsq_payoff, res2[k].bk_cf_terms) == (own.price, own.sumsq_payoff, own.bk_cf_terms)
+        assert res2[0].price == r2.price
+    finally:
+        ctx.close()
