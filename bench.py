@@ -937,9 +937,11 @@ def main():
             "config2_lognormal_exact": {
                 "paths_per_s": n_paths / (t2 * 1e-3), "solve_ms": t2, "kernel_ms": t2, "price": r2.price,
                 "analytic": 10.450583572185565,
-                "note": "BASELINE's size (10^6): ONE launch of ~15 us — launch-bound, its fraction says little; "
-                        "the 10^8 row beside it is the kernel",
-                "roofline": valu_roofline("exact_gbm_kernel<1 pair per lane>", "lognormal_exact", float(n_paths), t2, vt)},
+                "note": "BASELINE's size (10^6): ONE launch (489 workgroups, four pairs of trajectories per lane, the last "
+                        "workgroup adds the records), ~11 us by the HIP events around a single call, 8.6 us per solve back to "
+                        "back (profiles/r06_c_exact_pairs_ab.txt) — launch-bound, its fraction says little; the 10^8 row "
+                        "beside it is the kernel",
+                "roofline": valu_roofline("exact_gbm_kernel<4 pairs per lane>", "lognormal_exact", float(n_paths), t2, vt)},
             "config2_lognormal_exact_1e8": {
                 "paths": n2b, "paths_per_s": n2b / (t2b * 1e-3), "solve_ms": t2b, "price": r2b.price,
                 "std_error": r2b.std_error, "analytic": 10.450583572185565,
@@ -953,7 +955,7 @@ def main():
             "config4_broadie_kaya_1e7": {
                 "paths": n4b, "paths_per_s": n4b / (t4b * 1e-3), "solve_ms": t4b, "price": r4b.price,
                 "std_error": r4b.std_error, "cf_terms_per_path": r4b.bk_cf_terms / n4b,
-                "note": "the 10^6 row is BASELINE's size; this one shows the chain where its fixed 74 us no longer count",
+                "note": "the 10^6 row is BASELINE's size; this one shows the chain where its fixed ~45 us (fill, drain, the tail kernel) no longer count",
                 "roofline": valu_roofline("the same chain of kernels", "broadie_kaya", float(n4b), t4b, vt)},
             "config3_antithetic_replay": {
                 "integrated_path_steps_per_s": 2.0 * n_paths * n_steps / (ta * 1e-3),

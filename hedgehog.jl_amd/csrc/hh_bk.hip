@@ -1418,12 +1418,20 @@ __device__ __forceinline__ void for_long_tiles(const unsigned long long* __restr
 }
 
 __global__ __launch_bounds__(kTile) void bk_tail_kernel(const BkArgs* __restrict__ args, const BkTables* __restrict__ tabs,
-                                                        uint32_t n_tiles, double n_paths, double* __restrict__ accum) {
-  const BkArgs& p = *args;
+                                                        uint32_t n_tiles, double n_paths, double* __restrict__ accum,
+                                                        uint32_t* __restrict__ cnt, const double* __restrict__ records) {
   const uint32_t b = blockIdx.x, tid = threadIdx.x;
-  uint32_t* cnt = p.counters;
-  const uint32_t n_long = __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (uniform)
+  __shared__ double sm[257];
+  // The common case first, in ONE round trip: the count of too-long trajectories and — workgroup b < 16: slot b of —
+  // the CF tiles' records are asked for together (`cnt`, `records` are kernel arguments: no load of the argument
+  // block in front); the count is looked at when the sums are there.
+  const uint32_t n_long_v = __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  double out = 0.0;
+  if (b < (uint32_t)kRecStride) out = sum_slot(records, n_tiles, (int)b, sm);
+  const uint32_t n_long = (uint32_t)__builtin_amdgcn_readfirstlane((int)n_long_v);  // (uniform)
+  uint32_t n_rec = n_tiles;
   if (n_long != 0u) {
+    const BkArgs& p = *args;
     double acc[6] = {0, 0, 0, 0, 0, 0};
     for_long_tiles(p.long_mask, n_tiles, b, [&](uint32_t tile) {
       const uint64_t path = (uint64_t)tile * kTile + tid;
@@ -1431,7 +1439,7 @@ __global__ __launch_bounds__(kTile) void bk_tail_kernel(const BkArgs* __restrict
         tail_whole_trajectory(p, tabs->t, tabs->coef, path, acc);
     });
     bk_store_record(acc, p.records + (size_t)(n_tiles + b) * kRecStride);
-    // every workgroup has read counters[0] and left its record before a reducer goes on: all arrive, the reducers
+    // every workgroup has read the count and left its record before a reducer goes on: all arrive, the reducers
     // wait.  (Plain stores, an agent-scope release behind the workgroup's barrier, an agent-scope acquire behind
     // the wait: MI355X_MICROARCH.md, inter-workgroup visibility.  The path of a tolerance nobody prices with.)
     __syncthreads();
@@ -1454,13 +1462,11 @@ __global__ __launch_bounds__(kTile) void bk_tail_kernel(const BkArgs* __restrict
       }
     }
     __syncthreads();
+    n_rec = n_tiles + (uint32_t)kHeavyGrid;
+    out = sum_slot(records, n_rec, (int)b, sm);  // again, with the tail workgroups' records behind the tiles'
   } else if (b >= (uint32_t)kRecStride) {
     return;
   }
-  // (b) slot b of the accumulator
-  __shared__ double sm[257];
-  const uint32_t n_rec = n_long != 0u ? n_tiles + (uint32_t)kHeavyGrid : n_tiles;
-  const double out = sum_slot(p.records, n_rec, (int)b, sm);
   if (tid == 0) {
     accum[b] = b == (uint32_t)HH_ACC_NPATHS ? n_paths : out;
     if (b == 0u) cnt[1] = n_rec;
@@ -1804,7 +1810,7 @@ void bk_chain(const BkArgs& a, const BkLayout& L, hipStream_t s, double* accum, 
   else
     hipLaunchKernelGGL(bk_cf_kernel<0>, g, b, 0, s, a, tabs);
   hipLaunchKernelGGL(bk_tail_kernel, dim3(kHeavyGrid), b, 0, s, static_cast<const BkArgs*>(a.args_dev), tabs, L.n_tiles,
-                     n_acc, accum);
+                     n_acc, accum, a.counters, static_cast<const double*>(a.records));
 }
 
 }  // namespace
