@@ -73,6 +73,7 @@ constexpr double kInvPi = 0.31830988618379067154, kTwoOverPi = 0.636619772367581
 #define HH_BK_SERIAL_LADDER 0
 #endif
 
+
 // Columns of cached series terms.  A lane's column belongs to a workgroup SLOT that a workgroup of the
 // CF kernel (or of the ladder kernel behind it) takes when it starts and gives back when it is done —
 // not to the trajectory: the cache is kSlots x 256 columns however many trajectories the chain has
@@ -1165,8 +1166,9 @@ __device__ __forceinline__ void give_slot(const BkArgs& p, uint32_t slot) {
 // flight sit in VGPRs and the kernel needs 192)
 // (one tile per workgroup, NOT a grid-stride loop over the tiles: with a loop around this body the compiler
 // hoists loop-invariant table values into 215-247 registers — measured — and halves the occupancy)
-// (occupancy is not what bounds this kernel: forced to 5 waves per SIMD — 95 registers, 10 spilled — it runs as at
-// its natural 4, at 6 it spills 66 and takes 1.5 x the time: interleaved A/B of round 4)
+// (occupancy: at its 95 registers five workgroups are resident per CU; capped at 4 / 3 / 2 by an LDS pad the chain
+// takes +2 % / +12 % / +41 % at 10^6 trajectories and +4.5 % / +17 % / +53 % at 10^7 — profiles/r06_o_bk_occupancy.txt;
+// at 6 waves per SIMD it would have to spill 66 registers: 1.5 x the time, round 4)
 #ifndef HH_BK_CF_WAVES
 #define HH_BK_CF_WAVES 0
 #endif
