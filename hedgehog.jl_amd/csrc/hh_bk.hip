@@ -1569,11 +1569,16 @@ __global__ __launch_bounds__(kTile) void grid_sort_count_kernel(const uint8_t* _
   __syncthreads();
   if (run < n_runs) {
     const uint32_t base = run * (uint32_t)kSortRun;
-#pragma unroll 4
-    for (uint32_t r = 0; r < (uint32_t)kSortRun / 64u; ++r) {
-      const uint32_t i = base + r * 64u + lane;
-      if (i < n) atomicAdd(&hist[wave][keys[i]], 1u);
+    constexpr int kRounds = kSortRun / 64;
+    uint32_t key[kRounds];  // all of a lane's keys first: sixteen loads in flight, not sixteen round trips in a row
+#pragma unroll
+    for (int r = 0; r < kRounds; ++r) {
+      const uint32_t i = base + (uint32_t)r * 64u + lane;
+      key[r] = i < n ? (uint32_t)keys[i] : 256u;
     }
+#pragma unroll
+    for (int r = 0; r < kRounds; ++r)
+      if (key[r] < 256u) atomicAdd(&hist[wave][key[r]], 1u);
   }
   __syncthreads();
   if (run < n_runs)
@@ -1642,10 +1647,18 @@ __global__ __launch_bounds__(kTile) void grid_sort_scatter_kernel(const uint8_t*
   __syncthreads();
   if (run >= n_runs) return;  // (wave-uniform; no barrier below)
   const uint32_t first = run * (uint32_t)kSortRun;
-  for (uint32_t r = 0; r < (uint32_t)kSortRun / 64u; ++r) {
-    const uint32_t i = first + r * 64u + lane;
-    const bool valid = i < n;
-    const uint32_t key = valid ? (uint32_t)keys[i] : 0u;
+  constexpr int kRounds = kSortRun / 64;
+  uint32_t keyr[kRounds];  // (as in the counting kernel: the loads first)
+#pragma unroll
+  for (int r = 0; r < kRounds; ++r) {
+    const uint32_t i = first + (uint32_t)r * 64u + lane;
+    keyr[r] = i < n ? (uint32_t)keys[i] : 256u;
+  }
+#pragma unroll
+  for (int r = 0; r < kRounds; ++r) {
+    const uint32_t i = first + (uint32_t)r * 64u + lane;
+    const bool valid = keyr[r] < 256u;
+    const uint32_t key = keyr[r] & 255u;
     unsigned long long peers = __ballot(valid);  // the lanes of this round with this lane's digit
 #pragma unroll
     for (int bit = 0; bit < 8; ++bit) {
