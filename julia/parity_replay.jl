@@ -107,12 +107,12 @@ let N = 64
         i > 48 && (u = isodd(i) ? 1e-9 * (i - 47) : 1 - 1e-9 * (i - 47))
         U[i] = u
         ϕ = Hedgehog.HestonCFIterator(VT[i], law)
-        mean, variance = Hedgehog.moments_from_cf(ϕ)
+        m1, variance = Hedgehog.moments_from_cf(ϕ)         # (`m1`: `mean` is Statistics.mean further down this file)
         σ² = max(variance, 1e-12)
-        normal_sample = mean + sqrt(σ²) * quantile(Normal(), u)
-        G0[i] = normal_sample > 0 ? normal_sample : mean * 0.01
-        GM[i] = mean + 11 * sqrt(σ²)
-        HH[i] = π / (mean + 5 * √σ²)
+        normal_sample = m1 + sqrt(σ²) * quantile(Normal(), u)
+        G0[i] = normal_sample > 0 ? normal_sample : m1 * 0.01
+        GM[i] = m1 + 11 * sqrt(σ²)
+        HH[i] = π / (m1 + 5 * √σ²)
         xs = Float64[]
         cdf = x -> (push!(xs, Float64(x)); Hedgehog.cdf_from_cf(ϕ, x, HH[i]))
         threw[i] = 0
