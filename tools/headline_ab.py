@@ -2,7 +2,8 @@
 """The headline launch (10^6 x 252 Heston Euler, REPLAY and GENERATE) timed through hh_mc_accumulate for the
 libraries named on the command line, interleaved in one process-per-library sequence on ONE box — what a change
 of the kernels cost or gained, free of box-to-box clock differences.  usage: headline_ab.py <lib.so> [<lib.so> …]
-(each library runs in a child process; this file with --child does the timing)."""
+(each library runs in a child process; this file with --child does the timing).  HH_AB_TIMING=1: with the library's
+timing hook on, as bench.py's timed loop runs it (hh_ctx_enable_timing) — then also the hook's mean kernel time."""
 import json
 import os
 import subprocess
@@ -44,15 +45,26 @@ def child():
             for _ in range(8):
                 assert lib.hh_mc_accumulate(h, C.byref(m), C.byref(c), acc, None) == 0
             lib.hh_ctx_synchronize(h)
-        walls = []
+        walls, kern = [], []
+        hook = os.environ.get("HH_AB_TIMING") == "1"
+        reps = min(reps, 200) if hook else reps  # the hook keeps 256 slots
         for _ in range(3):
             lib.hh_ctx_synchronize(h)
+            if hook:
+                lib.hh_ctx_enable_timing(h, 1)
             t0 = time.perf_counter()
             for _ in range(reps):
                 lib.hh_mc_accumulate(h, C.byref(m), C.byref(c), acc, None)
             lib.hh_ctx_synchronize(h)
             walls.append((time.perf_counter() - t0) / reps * 1e3)
+            if hook:
+                buf, k = (C.c_double * 256)(), C.c_int32()
+                lib.hh_ctx_read_timings(h, buf, 256, C.byref(k))
+                kern.append(sum(buf[i] for i in range(k.value)) / max(k.value, 1))
+                lib.hh_ctx_enable_timing(h, 0)
         out[name + "_wall_ms_per_solve"] = [round(w, 5) for w in walls]
+        if hook:
+            out[name + "_hook_kernel_ms"] = [round(x, 5) for x in kern]
     print(json.dumps(out), flush=True)
 
 
