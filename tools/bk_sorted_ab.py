@@ -49,4 +49,10 @@ key = np.floor(np.log2(VT) * 8).astype(np.int64)
 run(np.lexsort((u, key)), "sorted by (log2 V_T in 1/8 bins, u)")
 run(np.argsort(key, kind="stable"), "stable sort by log-scale bin")
 run(np.argsort(u), "sorted by u")
+# what a sort INSIDE each tile of 256 trajectories (no pass over the ensemble) would buy: by V_T, and by a 16-bin key of it
+tiles = idx // 256
+run(np.lexsort((VT, tiles)), "each tile of 256 sorted by V_T")
+edges = np.quantile(VT, np.linspace(0, 1, 17)[1:-1])
+run(np.lexsort((idx, np.searchsorted(edges, VT), tiles)), "each tile by a 16-quantile bin of V_T")
+run(np.lexsort((idx, np.clip(key - key.min(), 0, None) // 2, tiles)), "each tile by log2 V_T in 1/4 bins")
 run(idx, "random order again")
