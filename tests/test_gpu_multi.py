@@ -391,3 +391,49 @@ def test_random_model_sets_share_a_pass_bit_for_bit(hhlib):
         for k in range(K):
             assert same_bits(each[k][0], multi[k][0]), (case, k)
             assert each[k][1].tobytes() == multi[k][1].tobytes(), (case, k)
+
+
+def _n_gpus():
+    import torch
+    return torch.cuda.device_count()
+
+
+@pytest.mark.skipif("_n_gpus() < 2", reason="needs two GPUs: a context on a device that is not the calling thread's current one")
+def test_accumulate_multi_broadie_kaya_from_a_thread_on_another_device(hhlib):
+    """hh_mc_accumulate_multi grows the context's record buffer before it launches anything: it must do so on the
+    CONTEXT's device whatever the calling thread's current device is (the Broadie–Kaya branch returns before the
+    common hipSetDevice).  A context on device 1 driven from a thread that sits on device 0 gives device 0's bits."""
+    import threading
+
+    import torch
+    n_paths = 256 * 37 + 45  # above one tile row, ragged: the doubled record buffer is (re)allocated by this call
+    models = bk_models()[:3]
+    K = len(models)
+    c = o.make_config(HES, BK, n_paths, 1, seeds=seeds_for(n_paths, 1))
+    want = solve_multi(hhlib, models, c, False)
+    other = _ffi.Context(1)
+    acc = torch.zeros(K * _ffi.HH_ACC_LEN, dtype=torch.float64, device="cuda:1")
+    got, err = [], []
+
+    def run():
+        try:
+            torch.cuda.set_device(0)  # this thread's current device is NOT the context's
+            other.check(other.lib.hh_mc_accumulate_multi(other.handle, (_ffi.hh_model * K)(*models), K, C.byref(c),
+                                                          acc.data_ptr(), None))
+            other.check(other.lib.hh_ctx_synchronize(other.handle))
+            host = acc.cpu().numpy()
+            for k in range(K):
+                r = _ffi.hh_result()
+                a = np.ascontiguousarray(host[k * _ffi.HH_ACC_LEN:(k + 1) * _ffi.HH_ACC_LEN])
+                other.check(other.lib.hh_mc_finalize(C.byref(models[k]), C.byref(c), a.ctypes.data, C.byref(r)))
+                got.append(r)
+        except Exception as e:  # noqa: BLE001 — handed to the asserting thread
+            err.append(e)
+
+    t = threading.Thread(target=run)
+    t.start()
+    t.join()
+    other.close()
+    assert not err, err
+    for k in range(K):
+        assert same_bits(want[k][0], got[k]), k
