@@ -688,57 +688,37 @@ enum BkDecision : uint32_t {
   kDecLongSeries = 1u << 31     // series longer than the term cache: ran whole in bk_fallback_kernel
 };
 
-// The iteration as a state that can be PUT DOWN between two steps and taken up again — by another lane — with the same
-// statements in the same order (invert_phase hands a tile's slow trajectories to one wave): 0 converged, 1 failed,
-// 2 put down after `pause_at` evaluations (before the next step is formed).
-struct SecantState {
-  double x0, f0, x1, f1;
-  int evals;
-};
-enum : int { kSecantOk = 0, kSecantFailed = 1, kSecantPaused = 2 };
-template <class Cdf>
-__device__ __forceinline__ void secant_start(Cdf&& cdf, double u, double guess, SecantState& s) {
-  const double hs = 6.0554544523933395e-06;
-  s.x1 = guess;
-  s.x0 = s.x1 + hs + fabs(s.x1) * hs * hs;
-  s.f0 = cdf(s.x0) - u;
-  s.f1 = cdf(s.x1) - u;
-  s.evals = 2;
-}
-template <class Cdf>
-__device__ __forceinline__ int secant_run(Cdf&& cdf, double u, double atol, int maxiter, int pause_at, SecantState& s) {
-  while (true) {
-    if (fabs(s.f1) <= atol) return kSecantOk;
-    if (s.evals >= maxiter || s.f1 == s.f0) return kSecantFailed;
-    if (s.evals >= pause_at) return kSecantPaused;
-    const double x2 = s.x1 - s.f1 * (s.x1 - s.x0) / (s.f1 - s.f0);
-    if (!isfinite(x2)) return kSecantFailed;
-    s.x0 = s.x1;
-    s.f0 = s.f1;
-    s.x1 = x2;
-    s.f1 = cdf(x2) - u;
-    ++s.evals;
-  }
-}
-// (the whole search in one lane: root, evaluations, and whether it stands — sample_from_cf.jl:116-122)
 template <class Cdf>
 __device__ __forceinline__ bool secant_inverse(Cdf&& cdf, double u, double guess, double atol,
                                                int maxiter, double& root, uint32_t& evals_out) {
-  SecantState s;
-  secant_start(cdf, u, guess, s);
-  const int st = secant_run(cdf, u, atol, maxiter, 0x7fffffff, s);
-  root = s.x1;
-  evals_out = (uint32_t)s.evals;
-  return st == kSecantOk && !(s.x1 < 0.0);
+  const double hs = 6.0554544523933395e-06;
+  double x1 = guess;
+  double x0 = x1 + hs + fabs(x1) * hs * hs;
+  double f0 = cdf(x0) - u;
+  double f1 = cdf(x1) - u;
+  int evals = 2;
+  bool ok = false;
+  while (true) {
+    if (fabs(f1) <= atol) {
+      ok = true;
+      break;
+    }
+    if (evals >= maxiter || f1 == f0) break;
+    const double x2 = x1 - f1 * (x1 - x0) / (f1 - f0);
+    if (!isfinite(x2)) break;
+    x0 = x1;
+    f0 = f1;
+    x1 = x2;
+    f1 = cdf(x2) - u;
+    ++evals;
+  }
+  root = x1;
+  evals_out = (uint32_t)evals;
+  return ok && !(x1 < 0.0);
 }
 
 // (what the phases of the CF kernel hand each other through LDS: see wave_ladder)
-constexpr int kLadderStash = 64;
-// evaluations after which a secant that has not ended is PUT DOWN and handed to wave 0 (invert_phase)
-#ifndef HH_BK_SECANT_HANDOVER
-#define HH_BK_SECANT_HANDOVER 5
-#endif
-constexpr int kSecantHandOver = HH_BK_SECANT_HANDOVER;  // (0: every lane keeps its secant to the end)
+constexpr int kLadderStash = 32;
 struct LadderShared {
   double h[kTile], u[kTile], max_guess[kTile];  // in
   double guess[kTile];                          // the secant's first guess (series_phase -> invert_phase)
@@ -748,15 +728,11 @@ struct LadderShared {
   double terms[kTile / 64][8][kRegTerms];       // [wave][group]: (2/π)/j · Re ϕ(h j), zero beyond the series' end
   unsigned long long fail[kTile / 64];          // the waves' ballots of failed lanes
   // a failed lane leaves the sixteen weighted terms it holds in registers here (entry = the order of arrival, kept in
-  // stash_of[thread]), so the ladder starts without a round trip to the term cache; the 65th of a tile finds
+  // stash_of[thread]), so the ladder starts without a round trip to the term cache; the 33rd failure of a tile finds
   // no entry and its group reads the column instead — same numbers
   double stash[kLadderStash][kRegTerms];
   unsigned char stash_of[kTile];
   uint32_t stash_n;
-  // a secant put down after kSecantHandOver evaluations, by stash entry (its terms are the entry's): the two points it
-  // holds, and whose it is (| 0x8000; without the bit: a failed trajectory's entry, terms only)
-  double px0[kLadderStash], pf0[kLadderStash], px1[kLadderStash], pf1[kLadderStash];
-  unsigned short powner[kLadderStash];
 };
 __device__ __forceinline__ void lds_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); }
 
@@ -1037,10 +1013,12 @@ template <int ORD>
 __device__ __forceinline__ void invert_phase(const BkArgs& p, const double* coef, uint32_t tile, uint32_t tid, uint64_t path,
                                              bool live, const double* col, LadderShared& sh, double h, int j_stop) {
   double acc[6] = {0, 0, 0, 0, 0, 0};  // Σp, Σp², newton_fail, bisect, maxguess, cf_terms
-  bool failed = false, too_long = false, handed = false;
+  bool failed = false, too_long = false;
   uint32_t dec = 0;
   double root = 0.0;  // the trajectory's ∫V: the secant's, or the ladder's behind it
-  // log S_T, the payoff and the trajectory's decision word, once its ∫V is known (ONE call below)
+  // log S_T, the payoff and the trajectory's decision word, once its ∫V is known.  (ONE call, behind the ladder: with a
+  // call for the trajectories the secant finished and another for the ladder's, three waves in four ran the payoff
+  // code twice — 0.6 % of the chain, profiles/r06_v_bk_secant_hand_over.txt)
   auto finish = [&](double IV) {
     const uint64_t src = pair_of<ORD>(p, path);
     p.diag[path] = dec;
@@ -1060,84 +1038,23 @@ __device__ __forceinline__ void invert_phase(const BkArgs& p, const double* coef
       double t[kRegTerms];
       load_terms(col, p.cache_stride, j_stop, t);
       double n_terms = 0.0;
-      auto cdf = [&](double x) { return cdf_cached(t, col, coef, p.cache_stride, j_stop, h, x, n_terms); };
-      SecantState ss;
-      secant_start(cdf, u, sh.guess[tid], ss);
-      // The secant of a trajectory ends after 4.3 evaluations on average, but a wave runs until its LAST lane has: 8.8
-      // (0.49 active lanes, profiles/r06_t_bk_evals_hist.txt).  So a lane whose secant has not ended after
-      // kSecantHandOver evaluations puts it down (~21 of a tile's 256 do) and wave 0 takes them all up, a lane each.
-#if HH_BK_SERIAL_LADDER || HH_BK_SECANT_HANDOVER == 0
-      int pause_at = 0x7fffffff;
-#else
-      int pause_at = kSecantHandOver;
-#endif
-      while (true) {
-        const int st = secant_run(cdf, u, p.atol, p.newton_maxiter, pause_at, ss);
-        if (st == kSecantOk && !(ss.x1 < 0.0)) break;  // it stands (sample_from_cf.jl:119-122)
-        // to another lane — failed: the ladder's wave; put down: wave 0.  What that lane needs of this trajectory
-        // (max_guess is there already); the weighted terms into a stash entry while there is one
+      failed = !secant_inverse(
+          [&](double x) { return cdf_cached(t, col, coef, p.cache_stride, j_stop, h, x, n_terms); }, u, sh.guess[tid],
+          p.atol, p.newton_maxiter, root, dec);
+      acc[5] = n_terms;
+      if (failed) {  // to the ladder: what the wave needs of this trajectory (max_guess is there already)
         sh.h[tid] = h;
         sh.u[tid] = u;
         sh.j_stop[tid] = j_stop;
         const uint32_t entry = atomicAdd(&sh.stash_n, 1u);
-        const bool room = entry < (uint32_t)kLadderStash;
-        sh.stash_of[tid] = (unsigned char)(room ? entry : 0xffu);
-        if (room) {
+        sh.stash_of[tid] = (unsigned char)(entry < (uint32_t)kLadderStash ? entry : 0xffu);
+        if (entry < (uint32_t)kLadderStash) {
 #pragma unroll
           for (int j = 0; j < kRegTerms; ++j) sh.stash[entry][j] = t[j];
         }
-        if (st != kSecantPaused) {
-          if (room) sh.powner[entry] = (unsigned short)tid;
-          failed = true;
-          break;
-        }
-        if (room) {
-          sh.px0[entry] = ss.x0;
-          sh.pf0[entry] = ss.f0;
-          sh.px1[entry] = ss.x1;
-          sh.pf1[entry] = ss.f1;
-          sh.powner[entry] = (unsigned short)(tid | 0x8000u);
-          handed = true;
-          break;
-        }
-        pause_at = 0x7fffffff;  // no entry left: it goes on where it is
-      }
-      root = ss.x1;
-      dec = (uint32_t)ss.evals;
-      acc[5] = n_terms;
-    }
-  }
-#if !HH_BK_SERIAL_LADDER && HH_BK_SECANT_HANDOVER != 0
-  if (__syncthreads_or(handed)) {  // (uniform) nearly every tile
-    if (tid < 64u) {
-      const uint32_t n_e = sh.stash_n < (uint32_t)kLadderStash ? sh.stash_n : (uint32_t)kLadderStash;
-      if (tid < n_e && (sh.powner[tid] & 0x8000u)) {
-        const uint32_t owner = sh.powner[tid] & 0x7fffu;
-        double t2[kRegTerms];
-#pragma unroll
-        for (int j = 0; j < kRegTerms; ++j) t2[j] = sh.stash[tid][j];
-        SecantState s2{sh.px0[tid], sh.pf0[tid], sh.px1[tid], sh.pf1[tid], kSecantHandOver};
-        const double* col2 = col + ((int)owner - (int)tid);  // the owner's column of the same slot
-        const int js2 = sh.j_stop[owner];
-        const double h2 = sh.h[owner], u2 = sh.u[owner];
-        double nt = 0.0;
-        const int st2 = secant_run([&](double x) { return cdf_cached(t2, col2, coef, p.cache_stride, js2, h2, x, nt); },
-                                   u2, p.atol, p.newton_maxiter, 0x7fffffff, s2);
-        sh.iv[owner] = s2.x1;
-        sh.res[owner] = (uint32_t)s2.evals | (st2 == kSecantOk ? 1u << 30 : 0u);
-        sh.guess[owner] = nt;  // (the first guess has been used)
       }
     }
-    __syncthreads();
-    if (handed) {  // as if the lane had gone on itself
-      const uint32_t r = sh.res[tid];
-      root = sh.iv[tid];
-      dec = r & 0xffu;
-      acc[5] += sh.guess[tid];
-      failed = !((r >> 30) & 1u) || root < 0.0;
-    }
   }
-#endif
   const unsigned long long m_fail = __ballot(failed);
   if ((tid & 63u) == 0u) sh.fail[tid >> 6] = m_fail;
   // what a failed lane takes back from the ladder: its ∫V, its counters, the rest of its decision word
