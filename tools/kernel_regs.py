@@ -25,7 +25,7 @@ def kernels_of(obj):
             return []
         notes = subprocess.run([f"{LLVM}/llvm-readelf", "--notes", co], capture_output=True, text=True).stdout
     out = []
-    for blk in re.split(r"\n\s*- ", notes):
+    for blk in re.split(r"\n\s*- (?=\.agpr_count:)", notes):  # a kernel's map starts with its first key
         name = re.search(r"\.name:\s+(\S+)", blk)
         if not name or ".vgpr_count" not in blk:
             continue
