@@ -41,6 +41,7 @@
 // the hot CF kernel — whose Horner constants are SGPR literals already — drops from 122 to 105 registers and
 // runs 2-5 % faster (interleaved A/B, tools/bk_ab.py: config 4 0.499 -> 0.474 ms, exact grid 1.736 -> 1.706).
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 
 #include "hh_bessel.h"
@@ -180,6 +181,8 @@ struct BkArgs {
                                    //   [1] records of the last chain the reduction read (n_tiles, or n_tiles +
                                    //       kHeavyGrid when [0] was not zero): what bk_refinish_kernel must reproduce
                                    //   [2], [3] arrival counters of the tail kernel's two waits (zero between chains)
+  uint32_t drain_tile;             // first tile of the chain's last round (n_tiles - the workgroups the device holds at
+                                   // once; 0xffffffff for a chain of one round): from here on tiles start at raised priority
   void* args_dev;                  // a copy of this struct in device memory (written by tile 0 of the CF kernel)
                                    // for bk_tail_kernel, whose code is too large to inline: passing
                                    // a by-value kernel argument by reference to its functions would put
@@ -1188,6 +1191,16 @@ __global__ __launch_bounds__(kTile) HH_BK_CF_OCC void bk_cf_kernel(const BkArgs 
   const uint64_t path = (uint64_t)tile * kTile + tid;
   const bool live = path < p.n_paths;
   if (tile == 0 && tid == 0) __builtin_memcpy(p.args_dev, &p, sizeof(BkArgs));  // for bk_tail_kernel
+#if defined(HH_BK_TILE_STAMPS) && HH_BK_TILE_STAMPS  // diagnostic build (tools/bk_tile_timeline.py): when a tile ran, and where
+  const unsigned long long stamp0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz
+#endif
+  // The tiles of the LAST ROUND — the last occupants of the chip's workgroup slots — issue ahead of the older waves
+  // beside them.  The hardware issues oldest-first, so at the end of a chain the final five waves of a SIMD finish one
+  // after the other, the last of them alone at a quarter of the issue rate: a drain of 100 µs behind the last start
+  // (tools/bk_tile_timeline.py).  Raised, they take 75 instead of 96 µs each while the round before them gives way:
+  // -1 … -3.5 % of the chain at every size from 1.1 to 6 rounds, -0.3 % at 30 (profiles/r06_ab_bk_last_round_priority.txt;
+  // two rounds raised: +6 %, half a round: a third of the gain, priorities graded by start order: no better).
+  if (tile >= p.drain_tile) __builtin_amdgcn_s_setprio(3);
   if (DRAW != 0 && live) {
     double Z, u, VT;
     if constexpr (DRAW == 2) {
@@ -1211,6 +1224,17 @@ __global__ __launch_bounds__(kTile) HH_BK_CF_OCC void bk_cf_kernel(const BkArgs 
   if (live && (p.root_form | p.bracket_form | p.caps) == 0) series_phase<ORD>(p, bt, path, col, p.cache_stride, sh, h, j_stop);
   invert_phase<ORD>(p, tabs->coef, tile, tid, path, live, col, sh, h, j_stop);
   give_slot(p, slot);
+#if defined(HH_BK_TILE_STAMPS) && HH_BK_TILE_STAMPS
+  // (in place of the series lengths of the tile's last three trajectories: start, end in 10 ns ticks, XCD | CU id)
+  __syncthreads();
+  if (tid == 0 && (uint64_t)(tile + 1) * kTile <= p.n_paths) {
+    uint32_t* out = p.diag + p.draw_stride + (size_t)tile * kTile + (kTile - 3);
+    out[0] = (uint32_t)stamp0;
+    out[1] = (uint32_t)__builtin_amdgcn_s_memrealtime();
+    out[2] = ((uint32_t)__builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20) << 16) |  // XCC_ID
+             ((uint32_t)__builtin_amdgcn_s_getreg(((16 - 1) << 11) | (0 << 6) | 4) & 0xffffu);  // HW_ID: wave, simd, cu, sh, se
+  }
+#endif
 }
 
 // Tail kernel, kHeavyGrid workgroups behind the CF kernel.
@@ -1815,7 +1839,27 @@ int bk_tables(const BkArgs& a, const BkLayout& L, const DevicePtrs& ptr, hipStre
 
 // the chain behind the draws: the CF kernel (draw: 0 the draws are in place, 1 made there, 2 the caller's, read
 // there), then the tail kernel, which leaves the sums of the chain's records in `accum` (slot HH_ACC_NPATHS: n_acc)
-void bk_chain(const BkArgs& a, const BkLayout& L, hipStream_t s, double* accum, double n_acc, int draw = 0) {
+// workgroups of the CF kernel the current device holds at once (its four instantiations have the same registers and LDS)
+uint32_t cf_resident_workgroups() {
+  static std::atomic<uint32_t> cache[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0u;
+  uint32_t v = cache[dev].load(std::memory_order_relaxed);
+  if (v == 0u) {
+    int cus = 0, per_cu = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, bk_cf_kernel<0, 1>, kTile, 0) != hipSuccess || cus <= 0 || per_cu <= 0)
+      return 0u;
+    v = (uint32_t)cus * (uint32_t)per_cu;
+    cache[dev].store(v, std::memory_order_relaxed);
+  }
+  return v;
+}
+
+void bk_chain(const BkArgs& a0, const BkLayout& L, hipStream_t s, double* accum, double n_acc, int draw = 0) {
+  BkArgs a = a0;
+  const uint32_t resident = cf_resident_workgroups();
+  a.drain_tile = resident != 0u && L.n_tiles > resident ? L.n_tiles - resident : 0xffffffffu;
   const dim3 b(kTile), g(L.n_tiles);
   const BkTables* tabs = static_cast<const BkTables*>(L.tabs_dev);
   if (a.order)

@@ -17,6 +17,8 @@ GRID = len(sys.argv) > 1 and sys.argv[1] == "grid"  # the exact Heston grid 2e5 
 n = 200_000 if GRID else int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 libs = {"shipped": _ffi.LIB_PATH}
 for f in sorted(glob.glob(os.path.join(ROOT, "hedgehog.jl_amd", "lib", "variants", "libhh_bk_*.so"))):
+    if "stamps" in os.path.basename(f):  # diagnostic builds with in-kernel stamps (tools/bk_tile_timeline.py)
+        continue
     libs[os.path.basename(f)[9:-3]] = f
 seed0 = torch.tensor([99], dtype=torch.int64, device="cuda")
 acc = torch.zeros(16, dtype=torch.float64, device="cuda")
