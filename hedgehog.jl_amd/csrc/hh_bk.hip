@@ -1199,7 +1199,8 @@ __global__ __launch_bounds__(kTile) HH_BK_CF_OCC void bk_cf_kernel(const BkArgs 
   // after the other, the last of them alone at a quarter of the issue rate: a drain of 100 µs behind the last start
   // (tools/bk_tile_timeline.py).  Raised, they take 75 instead of 96 µs each while the round before them gives way:
   // -1 … -3.5 % of the chain at every size from 1.1 to 6 rounds, -0.3 % at 30 (profiles/r06_ab_bk_last_round_priority.txt;
-  // two rounds raised: +6 %, half a round: a third of the gain, priorities graded by start order: no better).
+  // two rounds raised: +6 %, half a round: a third of the gain, priorities graded by start order or falling with a
+  // tile's progress: no better; EVERY tile's priority falling with its progress: +9 % — oldest-first is right until the end).
   if (tile >= p.drain_tile) __builtin_amdgcn_s_setprio(3);
   if (DRAW != 0 && live) {
     double Z, u, VT;
