@@ -1584,6 +1584,7 @@ __global__ __launch_bounds__(256) void fill_rows_kernel(double* __restrict__ spo
 // scatter: a run's pairs in 16 rounds of 64, a lane's place = its digit's base + the run's offset + the pairs of the
 // same digit in front of it in the run (the lanes with its digit found by eight ballots, the running count per digit
 // in LDS).  Stable: equal keys stay in pair order — the order a stable radix sort of (key, pair) gives.
+// (measured, 2.4·10^6 pairs: runs of 2048 the same 31 µs, 512: 47, 256: 86 — the [digit][run] table of counts is what costs)
 constexpr int kSortRun = 1024;                           // consecutive pairs per wave
 constexpr int kSortWaves = kTile / 64;
 static_assert(kSortRun % 64 == 0, "whole rounds of a wave");
