@@ -916,8 +916,8 @@ def main():
         c4 = _ffi.make_config(_ffi.HH_HESTON, _ffi.HH_BROADIE_KAYA, n_paths)
         c4.seeds, c4.seeds_on_device = sh.seeds.data_ptr(), 1
         t4, r4 = kernel_ms(model, c4, reps=5)
-        # the same law at ten times the size: what does not scale with the ensemble (the chain's small kernels, the CF
-        # kernel filling and draining: 74 us, profiles/r05_k_bk_sizes.txt) is 21 % of the 10^6 row and 2.5 % of this one
+        # the same law at ten times the size: what does not scale with the ensemble (the tail kernel, the CF kernel's
+        # drain: ~40 us, profiles/r06_ae_bk_sizes.txt) is 13 % of the 10^6 row and 1.5 % of this one
         n4b = 10_000_000
         c4b = _ffi.make_config(_ffi.HH_HESTON, _ffi.HH_BROADIE_KAYA, n4b)
         c4b.seeds, c4b.seeds_on_device = sh.seeds.data_ptr(), 1
@@ -955,7 +955,7 @@ def main():
             "config4_broadie_kaya_1e7": {
                 "paths": n4b, "paths_per_s": n4b / (t4b * 1e-3), "solve_ms": t4b, "price": r4b.price,
                 "std_error": r4b.std_error, "cf_terms_per_path": r4b.bk_cf_terms / n4b,
-                "note": "the 10^6 row is BASELINE's size; this one shows the chain where its fixed ~45 us (fill, drain, the tail kernel) no longer count",
+                "note": "the 10^6 row is BASELINE's size; this one shows the chain where its fixed ~40 us (the drain of a grid whose waves issue oldest-first, the tail kernel: profiles/r06_ab_bk_last_round_priority.txt) no longer count",
                 "roofline": valu_roofline("the same chain of kernels", "broadie_kaya", float(n4b), t4b, vt)},
             "config3_antithetic_replay": {
                 "integrated_path_steps_per_s": 2.0 * n_paths * n_steps / (ta * 1e-3),
