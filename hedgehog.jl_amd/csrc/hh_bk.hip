@@ -13,7 +13,9 @@
 //                   caller's, read here; a grid's: by its variance kernel in front), characteristic function,
 //                   moments, series terms, the secant inversion on the cached terms — and, for the trajectories
 //                   whose secant failed (2 %), the bisection ladder of inverse_cdf, run by the WAVE: the lanes of a
-//                   wave evaluate the next 3-6 levels of a failed trajectory's bisection tree at once (wave_ladder)
+//                   wave evaluate the next 3-6 levels of a failed trajectory's bisection tree at once (wave_ladder).
+//                   The tiles of the chain's last round start at raised priority (the drain of a grid whose waves
+//                   issue oldest-first; bk_cf_kernel)
 //   bk_tail_kernel  (a) trajectories whose series outgrew the term cache run whole (none with the reference's
 //                   controls: the workgroups find a zero and go on), (b) the records of both kernels are added into
 //                   the accumulator.
