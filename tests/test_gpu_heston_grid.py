@@ -314,12 +314,14 @@ if given is not None:
         return _PER_DATE[0]
 
 
-@pytest.mark.parametrize("name,prm,steps,n", [("h252", H252, 12, 100_001), ("q2", Q2, 5, 230_000), ("h252_small", H252, 3, 700)])
+@pytest.mark.parametrize("name,prm,steps,n", [("h252", H252, 12, 100_001), ("q2", Q2, 5, 230_000), ("h252_small", H252, 3, 700),
+                                             ("h252_last_workgroup_of_the_sort_half_empty", H252, 3, 350_000)])
 def test_sorted_and_natural_order_of_a_chain_give_the_same_grid(name, prm, steps, n):
     """HH_OPT_GRID_ORDER: a batched chain runs its (date, trajectory) pairs sorted by a coarse key of V0·V_T (lanes
     of a wave then share a regime of the Bessel function) or in their natural order — nothing a pair computes
     depends on its neighbours and the counters are whole numbers: the same rows, the same counters, bit for bit.
-    (The order is applied from 2^20 pairs on: the first two cases; the third stays in its natural order either way.)"""
+    (The order is applied from 2^20 pairs on: the first two cases and the last — 1026 runs of the counting sort, two of
+    the four waves of its last workgroup without one; the third stays in its natural order either way.)"""
     seeds = np.random.default_rng(steps + 100).integers(1, 2**63, n).astype(np.uint64)
     out = []
     for order in (0, 1):
